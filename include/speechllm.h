@@ -1,0 +1,238 @@
+/*
+ * speechllm.h — C ABI of libspeechllm.so: the MI355X (gfx950) hot path of the speech-prompted LLM
+ * pipeline (HuBERT encoder -> pooled projector -> Llama prefill + KV-cached greedy decode).
+ *
+ * The reference (wonjune-kang/llm-speech-summarization) has no native code and no FFI: its hot path
+ * is Python calling HuggingFace `transformers` modules.  Each entry point below therefore cites the
+ * reference / HF call it replaces (ref: = /root/reference, hf: = site-packages/transformers).  The
+ * Python host mirror of the reference classes (the .py files of llm-speech-summarization_amd/) binds these with
+ * ctypes; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no C++ / torch types cross this boundary.
+ *   - Every device buffer (weights, activations, KV cache, workspace) is allocated and owned by the
+ *     caller.  The library never allocates or frees device memory and never synchronises, except
+ *     sl_greedy_generate (documented there).  All launches are asynchronous on `stream`.
+ *   - Return value: 0 on success, a negative sl_status otherwise; sl_last_error() gives the text.
+ *   - dtype: SL_F32 (exact-fp32 MFMA, the parity mode) or SL_BF16 (bf16 storage, fp32 accumulate).
+ *   - Layouts: activations row-major (tokens, channels); Linear weights in nn.Linear layout
+ *     (out_features, in_features); conv weights re-laid out by the host as documented per call.
+ */
+#ifndef SPEECHLLM_H
+#define SPEECHLLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sl_stream; /* hipStream_t */
+
+enum sl_dtype { SL_F32 = 0, SL_BF16 = 1 };
+enum sl_status {
+  SL_OK = 0,
+  SL_ERR_ARG = -1,      /* bad shape / alignment / enum */
+  SL_ERR_LAUNCH = -2,   /* HIP launch or runtime error */
+  SL_ERR_UNSUPPORTED = -3
+};
+enum sl_act { SL_ACT_NONE = 0, SL_ACT_GELU = 1, SL_ACT_SILU_MUL = 2 };
+
+const char* sl_last_error(void);       /* thread-local, never NULL */
+int sl_version(void);                  /* ABI version, bumps on any signature change */
+int sl_device_arch(char* buf, int n);  /* gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-" */
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM  C[b] = act(A[b] . W[b]^T + bias[b]) + residual[b]        (TN: both operands K-contiguous)
+ * Replaces every nn.Linear / F.linear on the path (hf:models/hubert/modeling_hubert.py:229,
+ * 293-300,340,360-365; hf:models/llama/modeling_llama.py:174-176,254-256,280; lm_head
+ * ref:model/audio_llama.py:67) and, through lda < K (overlapping rows), the strided Conv1d layers
+ * 1..6 of the HuBERT feature extractor (hf:...hubert.py:141) and the grouped positional conv
+ * (hf:...hubert.py:47-53) as implicit GEMMs without an im2col buffer.
+ *   A: (M, K) row stride lda;  W: (N, K) row stride ldw;  C: (M, Nout) row stride ldc
+ *   act == SL_ACT_SILU_MUL: W rows come in blocks of 16 gate rows followed by 16 up rows;
+ *     Nout = N/2, C[m][16p+c] = silu(gate) * up  (hf:...llama.py:175).  Otherwise Nout = N.
+ *   bias (N) and residual (M, Nout; row stride ldr) may be NULL.  Order: +bias, act, +residual.
+ *   out_f32 != 0 writes C as float regardless of dtype (logits).
+ *   Requirements: K % 8 == 0 (bf16) / K % 4 == 0 (f32); A, W 16-byte aligned rows.
+ *   M <= 64 dispatches to the weight-streaming (HBM-bound) skinny kernel used by decode.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* A; int64_t lda; int64_t strideA;
+  const void* W; int64_t ldw; int64_t strideW;
+  void* C; int64_t ldc; int64_t strideC;
+  const void* bias; int64_t strideBias;
+  const void* residual; int64_t ldr; int64_t strideR;
+  int32_t M, N, K, batch;
+  int32_t dtype, act, out_f32, reserved;
+} sl_gemm_args;
+int sl_gemm(const sl_gemm_args* a, sl_stream stream);
+
+/* LayerNorm over the last dim, optional fused GELU (conv layers: hf:...hubert.py:144-150;
+ * encoder LNs hf:...hubert.py:515,517,612; feature projection :226).  In-place allowed. */
+int sl_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int32_t cols,
+                 float eps, int32_t gelu, int32_t dtype, sl_stream stream);
+
+/* LlamaRMSNorm (hf:models/llama/modeling_llama.py:62-67): y = w * (x * rsqrt(mean(x^2)+eps)). */
+int sl_rmsnorm(const void* x, void* y, const void* w, int64_t rows, int32_t cols, float eps, int32_t dtype,
+               sl_stream stream);
+
+/* HuBERT conv layer 0: Conv1d(1 -> C, k, stride) + LayerNorm(C) + GELU fused, channel-last output
+ * (hf:...hubert.py:141-150 for layer_id 0).  wave: (n_samples) float32 (always fp32 on input:
+ * ref:inference.py:166);  w: (C, k) float32;  out: (L, C) dtype, L = (n_samples-k)/stride+1.
+ * C must be 64*{1,2,4,8}. */
+int sl_hubert_conv0(const float* wave, int64_t n_samples, const float* w, const float* bias,
+                    const float* gamma, const float* beta, void* out, int32_t C, int32_t k, int32_t stride,
+                    float eps, int32_t dtype, sl_stream stream);
+
+/* Positional-conv input staging: x (T, H) -> xg (groups, T + k, H/groups), zero halo of k/2 rows
+ * on both sides, so each group's conv window is one contiguous GEMM row (hf:...hubert.py:47-53). */
+int sl_posconv_stage(const void* x, void* xg, int64_t T, int32_t H, int32_t groups, int32_t k,
+                     int32_t dtype, sl_stream stream);
+
+/* AvgPool1d(kernel, stride) over time on channel-last rows (ref:model/audio_encoder.py:59-63):
+ * y[p] = mean(x[p*stride .. p*stride+kernel)).  Also serves ctc_pool via explicit ranges
+ * (ref:model/audio_encoder.py:78-82): ranges = int32 (P,2) device array or NULL. */
+int sl_avgpool_rows(const void* x, void* y, int64_t T, int32_t H, int32_t kernel, int32_t stride,
+                    const int32_t* ranges, int64_t P, int32_t dtype, sl_stream stream);
+
+/* Embedding row gather (hf:...llama.py:380-381; ref:utils.py:63-64). ids int32 on device. */
+int sl_embed_gather(const void* table, const int32_t* ids, void* out, int64_t n, int32_t cols,
+                    int32_t dtype, sl_stream stream);
+
+/* Flash-style attention forward, variable-length packed sequences.
+ *   head_dim 64, non-causal: HuBERT (hf:...hubert.py:234-259);  head_dim 128, causal GQA: Llama
+ *   prefill (hf:...llama.py:191-213).  softmax in fp32, scores scaled by `scale`.
+ *   q/out: token t of sequence s is row cu_q[s] + t;   k/v: row cu_k[s] + t.
+ *   element address = base + row*row_stride + head*head_stride (strides in elements).
+ *   Causal: key j visible to query i iff j <= i + (klen - qlen). */
+typedef struct {
+  const void* q; int64_t q_row_stride, q_head_stride;
+  const void* k; int64_t k_row_stride, k_head_stride;
+  const void* v; int64_t v_row_stride, v_head_stride;
+  void* out; int64_t o_row_stride, o_head_stride;
+  const int32_t* cu_q;   /* (nseq+1) device */
+  const int32_t* cu_k;   /* (nseq)   device: first k/v row of each sequence */
+  const int32_t* klen;   /* (nseq)   device: number of keys of each sequence */
+  int32_t nseq, max_qlen, n_heads, n_kv_heads, head_dim, causal, dtype, reserved;
+  float scale;
+} sl_attn_args;
+int sl_attn_fwd(const sl_attn_args* a, sl_stream stream);
+
+/* RoPE (rotate_half form, hf:...llama.py:130-160) on the q and k slices of a fused QKV activation,
+ * then KV-cache append (hf:cache_utils.py:127-145 restated as write-at-position).
+ *   qkv: (n_tok, (n_heads + 2 n_kv) * D);  q is rotated in place;
+ *   k,v -> cache (n_seq_slots, n_kv, max_ctx, D) at [tok_seq[t]][:, tok_pos[t]].
+ *   cos/sin: (rope_len, D/2) float32 tables computed on the host exactly as HF does. */
+int sl_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const int32_t* tok_seq, const int32_t* tok_pos,
+                      const float* cos, const float* sin, int64_t n_tok, int32_t n_heads, int32_t n_kv,
+                      int32_t D, int32_t max_ctx, int32_t dtype, sl_stream stream);
+
+/* One-token GQA attention against the KV cache (decode; hf:...llama.py:191-213 with q_len 1).
+ *   q: row b of (B, n_heads*D) with row stride q_stride;  ctx_len[b] keys are attended (the
+ *   current token must already be appended).  out: (B, n_heads*D).  K/V rows are read from
+ *   cache (slots, n_kv, max_ctx, D). */
+int sl_attn_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out,
+                   const int32_t* ctx_len, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D,
+                   int32_t max_ctx, float scale, int32_t dtype, sl_stream stream);
+
+/* Greedy token selection (hf:generation/utils.py:2894,2925-2936): argmax over fp32 logits (lowest index
+ * on ties), pad finished rows, EOS check, append to out_ids[b][gen_count[b]], advance gen_count and
+ * ctx_len.  logits (B, V) float; eos_ids is a HOST array of at most 8 ids (passed by value to the
+ * kernel).  Device state, all int32 (B): unfinished (1 until the row emits EOS), ctx_len, gen_count,
+ * finish_len (gen_count at the row's EOS), next_ids (fed to the next embedding gather);
+ * out_ids (B, max_new) int32. */
+int sl_greedy_select(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids_host, int32_t n_eos,
+                     int32_t pad_id, int32_t use_eos, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
+                     int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-model entry points (C++ host runtime inside the library: layer loops, workspace carving,
+ * hipGraph capture of the decode step).  Weight tables are plain structs of device pointers.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+} sl_hubert_layer;
+
+typedef struct {
+  int32_t dtype, n_conv, hidden, n_layers, n_heads, ffn, pos_k, pos_groups;
+  int32_t conv_dim[8], conv_kernel[8], conv_stride[8];
+  float ln_eps;   /* encoder / feature-projection LayerNorm eps; conv LayerNorms use 1e-5 */
+  int32_t pool_kernel, pool_stride, llm_dim, reserved;
+  const float *conv0_w, *conv0_b, *conv0_g, *conv0_beta;       /* fp32: (C,k), (C), (C), (C) */
+  const void *conv_w[8], *conv_b[8], *conv_g[8], *conv_beta[8]; /* i>=1: (C_out, k*C_in) tap-major */
+  const void *fp_ln_g, *fp_ln_b, *fp_w, *fp_b;                  /* feature projection */
+  const void *pos_w, *pos_b;          /* (groups, H/groups, k*H/groups) weight-norm folded; (H) */
+  const sl_hubert_layer* layers;      /* host array, n_layers entries */
+  const void *final_ln_g, *final_ln_b;
+  const void *proj_w, *proj_b;        /* embed_projection (llm_dim, hidden) */
+} sl_hubert_model;
+
+/* AudioEncoder.forward with the `pool` downsample for a batch of utterances
+ * (ref:model/audio_encoder.py:56-63,87).  Every utterance is encoded at its own length (no padding,
+ * so results equal the reference's batch-size-1 behaviour): the conv feature extractor
+ * and positional conv run per utterance, the 24 transformer layers run on all frames packed together
+ * with variable-length attention.
+ *   waves: device fp32, utterances concatenated; sample_offsets_host: (n_utt+1) host int64.
+ *   out: rows of out_ld elements; utterance u's P_u rows go to row out_row_offsets_host[u] (so the
+ *   encoder writes straight into the LLM prompt buffer, ref:utils.py:66-72), or packed if NULL.
+ *   last_hidden: optional (sum T_u, hidden) packed encoder output before pooling. */
+size_t sl_hubert_workspace_bytes(const sl_hubert_model* m, const int64_t* sample_offsets_host, int32_t n_utt);
+int sl_hubert_num_frames(const sl_hubert_model* m, int64_t n_samples);
+int sl_hubert_forward(const sl_hubert_model* m, const float* waves, const int64_t* sample_offsets_host, int32_t n_utt,
+                      void* out, int64_t out_ld, const int64_t* out_row_offsets_host, void* last_hidden,
+                      void* workspace, size_t workspace_bytes, sl_stream stream);
+
+typedef struct {
+  const void *norm1, *wqkv, *wo, *norm2, *wgu, *wdown;   /* wgu: 16-row gate/up interleave */
+} sl_llama_layer;
+
+typedef struct {
+  int32_t dtype, hidden, n_layers, n_heads, n_kv_heads, head_dim, ffn, vocab;
+  float rms_eps; int32_t rope_len;
+  const void *embed, *lm_head, *final_norm;
+  const float *rope_cos, *rope_sin;      /* (rope_len, head_dim/2) */
+  const sl_llama_layer* layers;          /* host array */
+} sl_llama_model;
+
+typedef struct {
+  void* k_cache; void* v_cache;  /* (n_layers, slots, n_kv, max_ctx, D) each */
+  int32_t slots, max_ctx;
+} sl_kv_cache;
+
+/* LlamaModel.forward over packed prompt embeddings + last-token logits
+ * (hf:...llama.py:367-417 + ref:model/audio_llama.py:67 with logits for the last position only).
+ *   x: (n_tok, hidden) packed prompts (modified in place: residual stream);  cu_seqlens (nseq+1)
+ *   host array.  Writes K/V for positions [0, len) of slot s, logits (nseq, vocab) fp32, and
+ *   ctx_len[s] = len (device int32).  hidden_taps, if non-NULL, receives the (n_layers+1) hidden
+ *   states (each (n_tok, hidden), last one post-norm) like output_hidden_states=True. */
+size_t sl_llama_workspace_bytes(const sl_llama_model* m, int64_t n_tok, int32_t nseq);
+int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host,
+                     int32_t nseq, float* logits, int32_t* ctx_len_dev, void* hidden_taps, void* workspace,
+                     size_t workspace_bytes, sl_stream stream);
+
+/* One KV-cached decode step for B sequences: embeds next_ids, runs all layers with M = B, writes
+ * logits (B, vocab) fp32 (B <= 64).  The new token's K/V are appended at position ctx_len[b] and
+ * ctx_len[b]+1 keys are attended; ctx_len itself is advanced by sl_greedy_select.  Reads/writes only
+ * device state, so the call is hipGraph-capturable.  Workspace: sl_llama_workspace_bytes(m, B, B) + B*hidden. */
+int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids_dev,
+                         const int32_t* ctx_len_dev, int32_t B, float* logits, void* workspace,
+                         size_t workspace_bytes, sl_stream stream);
+
+/* GenerationMixin._sample in greedy mode from prompt embeddings (ref:inference.py:60-66):
+ * prefill + up to max_new_tokens decode steps replayed from one captured hipGraph.  out_ids_host
+ * (nseq, max_new_tokens) int32 receives new tokens only; *n_steps_host the number of columns
+ * produced (all rows finished => early stop, checked every `check_every` steps).  This call
+ * synchronises `stream` (it returns host data). */
+size_t sl_generate_workspace_bytes(const sl_llama_model* m, int64_t n_tok, int32_t nseq, int32_t max_new_tokens);
+int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host,
+                       int32_t nseq, int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos,
+                       int32_t pad_id, int32_t use_eos, int32_t check_every, int32_t* out_ids_host,
+                       int32_t* n_steps_host, float* timings_ms_host /* [prefill, decode] or NULL */,
+                       void* workspace, size_t workspace_bytes, sl_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEECHLLM_H */

@@ -1,0 +1,163 @@
+"""ctypes binding of libspeechllm.so (include/speechllm.h).
+
+The product path has NO CPU fallback: if the shared library is missing or an entry point fails, an
+exception is raised.  PyTorch is used only to own device memory and streams; raw pointers cross the
+C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspeechllm.so")
+
+SL_F32, SL_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SILU_MUL = 0, 1, 2
+
+c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class SpeechLLMError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_vp), ("lda", c_i64), ("strideA", c_i64),
+                ("W", c_vp), ("ldw", c_i64), ("strideW", c_i64),
+                ("C", c_vp), ("ldc", c_i64), ("strideC", c_i64),
+                ("bias", c_vp), ("strideBias", c_i64),
+                ("residual", c_vp), ("ldr", c_i64), ("strideR", c_i64),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("batch", c_i32),
+                ("dtype", c_i32), ("act", c_i32), ("out_f32", c_i32), ("reserved", c_i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", c_vp), ("q_row_stride", c_i64), ("q_head_stride", c_i64),
+                ("k", c_vp), ("k_row_stride", c_i64), ("k_head_stride", c_i64),
+                ("v", c_vp), ("v_row_stride", c_i64), ("v_head_stride", c_i64),
+                ("out", c_vp), ("o_row_stride", c_i64), ("o_head_stride", c_i64),
+                ("cu_q", c_vp), ("cu_k", c_vp), ("klen", c_vp),
+                ("nseq", c_i32), ("max_qlen", c_i32), ("n_heads", c_i32), ("n_kv_heads", c_i32),
+                ("head_dim", c_i32), ("causal", c_i32), ("dtype", c_i32), ("reserved", c_i32),
+                ("scale", c_f32)]
+
+
+class HubertLayer(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b",
+                                    "w1", "b1", "w2", "b2")]
+
+
+class HubertModel(C.Structure):
+    _fields_ = [("dtype", c_i32), ("n_conv", c_i32), ("hidden", c_i32), ("n_layers", c_i32),
+                ("n_heads", c_i32), ("ffn", c_i32), ("pos_k", c_i32), ("pos_groups", c_i32),
+                ("conv_dim", c_i32 * 8), ("conv_kernel", c_i32 * 8), ("conv_stride", c_i32 * 8),
+                ("ln_eps", c_f32),
+                ("pool_kernel", c_i32), ("pool_stride", c_i32), ("llm_dim", c_i32), ("reserved", c_i32),
+                ("conv0_w", c_vp), ("conv0_b", c_vp), ("conv0_g", c_vp), ("conv0_beta", c_vp),
+                ("conv_w", c_vp * 8), ("conv_b", c_vp * 8), ("conv_g", c_vp * 8), ("conv_beta", c_vp * 8),
+                ("fp_ln_g", c_vp), ("fp_ln_b", c_vp), ("fp_w", c_vp), ("fp_b", c_vp),
+                ("pos_w", c_vp), ("pos_b", c_vp),
+                ("layers", C.POINTER(HubertLayer)),
+                ("final_ln_g", c_vp), ("final_ln_b", c_vp),
+                ("proj_w", c_vp), ("proj_b", c_vp)]
+
+
+class LlamaLayer(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("norm1", "wqkv", "wo", "norm2", "wgu", "wdown")]
+
+
+class LlamaModel(C.Structure):
+    _fields_ = [("dtype", c_i32), ("hidden", c_i32), ("n_layers", c_i32), ("n_heads", c_i32),
+                ("n_kv_heads", c_i32), ("head_dim", c_i32), ("ffn", c_i32), ("vocab", c_i32),
+                ("rms_eps", c_f32), ("rope_len", c_i32),
+                ("embed", c_vp), ("lm_head", c_vp), ("final_norm", c_vp),
+                ("rope_cos", c_vp), ("rope_sin", c_vp),
+                ("layers", C.POINTER(LlamaLayer))]
+
+
+class KVCache(C.Structure):
+    _fields_ = [("k_cache", c_vp), ("v_cache", c_vp), ("slots", c_i32), ("max_ctx", c_i32)]
+
+
+_PROTOS = {
+    "sl_last_error": (C.c_char_p, []),
+    "sl_version": (c_i32, []),
+    "sl_device_arch": (c_i32, [C.c_char_p, c_i32]),
+    "sl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "sl_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32, c_vp]),
+    "sl_rmsnorm": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),
+    "sl_hubert_conv0": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "sl_posconv_stage": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sl_avgpool_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp]),
+    "sl_embed_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "sl_attn_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
+    "sl_rope_kv_append": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sl_attn_decode": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "sl_greedy_select": (c_i32, [c_vp, c_i32, c_i32, C.POINTER(c_i32), c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                 c_i32, c_vp]),
+    "sl_hubert_workspace_bytes": (c_sz, [C.POINTER(HubertModel), C.POINTER(c_i64), c_i32]),
+    "sl_hubert_num_frames": (c_i32, [C.POINTER(HubertModel), c_i64]),
+    "sl_hubert_forward": (c_i32, [C.POINTER(HubertModel), c_vp, C.POINTER(c_i64), c_i32, c_vp, c_i64, C.POINTER(c_i64), c_vp,
+                                  c_vp, c_sz, c_vp]),
+    "sl_llama_workspace_bytes": (c_sz, [C.POINTER(LlamaModel), c_i64, c_i32]),
+    "sl_llama_prefill": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, C.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp,
+                                 c_vp, c_sz, c_vp]),
+    "sl_llama_decode_step": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "sl_generate_workspace_bytes": (c_sz, [C.POINTER(LlamaModel), c_i64, c_i32, c_i32]),
+    "sl_greedy_generate": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, C.POINTER(c_i32), c_i32, c_i32,
+                                   C.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i32), C.POINTER(c_i32),
+                                   C.POINTER(c_f32), c_vp, c_sz, c_vp]),
+}
+
+EXPORTS = tuple(_PROTOS)
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SpeechLLMError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C llm-speech-summarization_amd/csrc`). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)  # AttributeError if an export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().sl_last_error().decode("utf-8", "replace")
+        raise SpeechLLMError(f"{what or 'libspeechllm'} failed ({rc}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return SL_F32
+    if dt == torch.bfloat16:
+        return SL_BF16
+    raise SpeechLLMError(f"unsupported dtype {dt}: the HIP path computes in float32 or bfloat16")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t: torch.Tensor, name: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise SpeechLLMError(f"{name} must live on the GPU: the hot path is HIP-only")
+    if not t.is_contiguous():
+        raise SpeechLLMError(f"{name} must be contiguous")

@@ -1,0 +1,185 @@
+"""AudioEncoder: host-side mirror of ref:model/audio_encoder.py:16-88 driving the HIP encoder.
+
+Same constructor arguments, attributes (`downsample_method`, `downsample_factor`, `encoder_base`) and
+`forward(input, ctc_pool_ranges=None) -> (B, P, llm_dim)` contract, same exceptions for bad configs.
+The arithmetic (HuBERT feature extractor, transformer, pooling, projection) runs in libspeechllm via
+`sl_hubert_forward`; this class only owns buffers and weight tables.  There is no PyTorch fallback.
+
+Differences from the reference, all deliberate:
+  * the encoder architecture comes from a local `config.json` or the built-in table of hub ids (no network);
+  * `forward` also accepts a list of 1-D waveforms of different lengths (each encoded at its own length);
+  * `stack` with T % factor == 0 keeps all frames instead of returning an empty sequence (Q5);
+  * Whisper is not built in this round -> explicit SpeechLLMError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .weights import KNOWN_HUBERT, HubertArch, HubertDeviceWeights, normalize_encoder_state_dict
+
+
+def resolve_hubert_arch(type_str: str) -> HubertArch:
+    cfg_path = os.path.join(type_str, "config.json")
+    if os.path.isdir(type_str) and os.path.exists(cfg_path):
+        with open(cfg_path) as f:
+            return HubertArch.from_hf_config(json.load(f))
+    if type_str in KNOWN_HUBERT:
+        return KNOWN_HUBERT[type_str]
+    raise L.SpeechLLMError(f"unknown audio encoder '{type_str}': give a local directory with config.json or one of {list(KNOWN_HUBERT)}")
+
+
+class AudioEncoder:
+    def __init__(self, config, device, dtype: torch.dtype = torch.bfloat16, arch: Optional[HubertArch] = None):
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = dtype
+        base = self.config.model.audio_encoder.base
+        if base == "hubert":
+            self.encoder_base = "hubert"
+        elif base == "whisper":
+            raise L.SpeechLLMError("the Whisper encoder path (ref:model/audio_encoder.py:10-13) is not built yet (SURVEY.md §8 a12)")
+        else:
+            raise Exception("Unexpected encoder type in config.")
+        self.arch = arch or resolve_hubert_arch(self.config.model.audio_encoder.type)
+        self.downsample_method = self.config.model.audio_encoder.downsample_method
+        self.downsample_factor = self.config.model.audio_encoder.downsample_factor
+        if self.downsample_method not in ("pool", "stack", "ctc_pool"):
+            raise Exception("Invalid downsampling method for audio encoder.")
+        self.pool_kernel = self.pool_stride = 0
+        if self.downsample_method == "pool":
+            self.pool_kernel = self.config.model.audio_encoder.pooling.kernel_size
+            self.pool_stride = self.config.model.audio_encoder.pooling.stride
+        self.llm_dim = self.config.model.llm_embedding_channels
+        self.weights: Optional[HubertDeviceWeights] = None
+        self._state: Optional[Dict[str, torch.Tensor]] = None
+        self._ws: Optional[torch.Tensor] = None
+        self.training = False
+        self.last_encode_ms = None
+
+    # -- nn.Module-like surface the reference's callers use ------------------------------------
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = normalize_encoder_state_dict(state_dict)
+        self._state = {k: v.detach().float().cpu() for k, v in sd.items()}
+        if self.device.type == "cuda":
+            self._upload()
+        return self
+
+    def state_dict(self):
+        if self._state is None:
+            raise L.SpeechLLMError("AudioEncoder has no weights yet: call load_state_dict first")
+        return dict(self._state)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise L.SpeechLLMError("training mode (dropout/layerdrop/spec-augment + backward) is not built in this round")
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self._state is not None and self.device.type == "cuda":
+            self._upload()
+        return self
+
+    def _upload(self):
+        self.weights = HubertDeviceWeights(self.arch, self._state, self.llm_dim, self.device, self.dtype,
+                                           pool_kernel=max(self.pool_kernel, 1), pool_stride=max(self.pool_stride, 1),
+                                           downsample=self.downsample_method)
+
+    # -- forward -------------------------------------------------------------------------------
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode_packed(self, waves: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None,
+                      out_row_offsets: Optional[Sequence[int]] = None, want_last_hidden: bool = False):
+        """Encode utterances of arbitrary lengths.  Returns (out, P_list, last_hidden|None, T_list).
+
+        `out` (rows, llm_dim) + `out_row_offsets` let the encoder write each utterance's embeddings
+        directly at its place inside a prompt buffer (ref:utils.py:66-72 concatenation becomes a no-op).
+        """
+        if self.weights is None:
+            raise L.SpeechLLMError("AudioEncoder weights are not on the GPU: call load_state_dict(...).to('cuda')")
+        lib = L.lib()
+        m = self.weights.struct
+        lens = [int(w.numel()) for w in waves]
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        flat = torch.cat([w.reshape(-1).to(device=self.device, dtype=torch.float32) for w in waves]).contiguous()
+        n_utt = len(waves)
+        offs_c = (C.c_int64 * (n_utt + 1))(*offs)
+        T = [self.arch.num_frames(n) for n in lens]
+        pool = self.downsample_method == "pool"
+        P = [((t - self.pool_kernel) // self.pool_stride + 1) if pool else 0 for t in T]
+        nbytes = lib.sl_hubert_workspace_bytes(C.byref(m), offs_c, n_utt)
+        if nbytes == 0:
+            raise L.SpeechLLMError("sl_hubert_workspace_bytes: " + lib.sl_last_error().decode())
+        ws = self._workspace(nbytes)
+        last_hidden = None
+        if want_last_hidden or not pool:
+            last_hidden = torch.empty((sum(T), self.arch.hidden_size), device=self.device, dtype=self.dtype)
+        rows_c = None
+        if pool:
+            if out is None:
+                out = torch.empty((sum(P), self.llm_dim), device=self.device, dtype=self.dtype)
+            if out_row_offsets is not None:
+                rows_c = (C.c_int64 * n_utt)(*[int(r) for r in out_row_offsets])
+        L.check(lib.sl_hubert_forward(C.byref(m), flat.data_ptr(), offs_c, n_utt, L.ptr(out), (out.stride(0) if out is not None else 0),
+                                      rows_c, L.ptr(last_hidden), ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_hubert_forward")
+        return out, P, last_hidden, T
+
+    def _downsample_host(self, hidden: torch.Tensor, ctc_pool_ranges) -> torch.Tensor:
+        """stack / ctc_pool on one utterance's (T, H) frames, composed from HIP ops (ref:model/audio_encoder.py:65-87)."""
+        w, b = self.weights.proj_w, self.weights.proj_b
+        if self.downsample_method == "stack":
+            f = self.downsample_factor
+            keep = (hidden.shape[0] // f) * f  # Q5 fix: crop only the remainder
+            stacked = hidden[:keep].reshape(keep // f, f * hidden.shape[1]).contiguous()
+            return ops.gemm(stacked, w, bias=b)
+        assert ctc_pool_ranges is not None, "Need to specify CTC pool ranges if using ctc_pool downsample method."
+        ranges = torch.tensor([list(r) for r in ctc_pool_ranges[0]], dtype=torch.int32, device=self.device)
+        pooled = ops.avgpool_rows(hidden, ranges=ranges)
+        return ops.gemm(pooled, w, bias=b)
+
+    def forward(self, input: Union[torch.Tensor, List[torch.Tensor]], ctc_pool_ranges=None) -> torch.Tensor:
+        if torch.is_tensor(input):
+            if input.dim() == 1:
+                input = input[None]
+            waves = [input[i] for i in range(input.shape[0])]
+        else:
+            waves = list(input)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        if self.downsample_method == "pool":
+            out, P, _, _ = self.encode_packed(waves)
+            end.record()
+            self._events = (start, end)
+            if len(set(P)) != 1:
+                raise L.SpeechLLMError("forward() returns a dense (B,P,C) tensor: use encode_packed for ragged batches")
+            return out.view(len(waves), P[0], self.llm_dim)
+        outs = []
+        _, _, hidden, T = self.encode_packed(waves, want_last_hidden=True)
+        t0 = 0
+        for t in T:
+            outs.append(self._downsample_host(hidden[t0:t0 + t], ctc_pool_ranges))
+            t0 += t
+        end.record()
+        self._events = (start, end)
+        if len(outs) != 1:
+            # the reference's stack / ctc_pool paths assume batch size 1 (ref:model/audio_encoder.py:68,77)
+            raise L.SpeechLLMError("stack / ctc_pool downsampling assumes batch size 1, as the reference does")
+        return outs[0][None]
+
+    __call__ = forward

@@ -1,0 +1,168 @@
+// common.h — shared device/host helpers for libspeechllm (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/speechllm.h"
+
+// ----------------------------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------------------------
+void sl_set_error(const char* fmt, ...);
+
+#define SL_CHECK_ARG(cond, ...)      \
+  do {                               \
+    if (!(cond)) {                   \
+      sl_set_error(__VA_ARGS__);     \
+      return SL_ERR_ARG;             \
+    }                                \
+  } while (0)
+
+#define SL_CHECK_LAUNCH(what)                                                        \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      sl_set_error("%s: %s", what, hipGetErrorString(e__));                          \
+      return SL_ERR_LAUNCH;                                                          \
+    }                                                                                \
+  } while (0)
+
+#define SL_HIP(call)                                                                 \
+  do {                                                                               \
+    hipError_t e__ = (call);                                                         \
+    if (e__ != hipSuccess) {                                                         \
+      sl_set_error("%s failed: %s", #call, hipGetErrorString(e__));                  \
+      return SL_ERR_LAUNCH;                                                          \
+    }                                                                                \
+  } while (0)
+
+#define SL_TRY(call)            \
+  do {                          \
+    int r__ = (call);           \
+    if (r__ != 0) return r__;   \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// element types.  bf16 is carried as its 16 raw bits; conversion f32->bf16 is a plain cast so hipcc
+// emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-preserving: MI355X_MICROARCH "Correctness").
+// ----------------------------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t bits;
+};
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// 16-byte streaming load with the non-temporal hint (weights read once per token: guide nt-weights)
+__device__ __forceinline__ uint4 ld_nt16(const void* p) {
+  u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_bits_to_f32(v.bits); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return bf16_t{f32_to_bf16_bits(v)}; }
+
+// 16-byte vector of T: 4 floats or 8 bf16.  VEC = elements per 16 bytes.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void unpack(const uint4& u, float* f) {
+    f[0] = __builtin_bit_cast(float, u.x); f[1] = __builtin_bit_cast(float, u.y);
+    f[2] = __builtin_bit_cast(float, u.z); f[3] = __builtin_bit_cast(float, u.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__builtin_bit_cast(uint32_t, f[0]), __builtin_bit_cast(uint32_t, f[1]),
+                      __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3]));
+  }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void unpack(const uint4& u, float* f) {
+    f[0] = bf16_bits_to_f32(u.x & 0xffffu); f[1] = bf16_bits_to_f32(u.x >> 16);
+    f[2] = bf16_bits_to_f32(u.y & 0xffffu); f[3] = bf16_bits_to_f32(u.y >> 16);
+    f[4] = bf16_bits_to_f32(u.z & 0xffffu); f[5] = bf16_bits_to_f32(u.z >> 16);
+    f[6] = bf16_bits_to_f32(u.w & 0xffffu); f[7] = bf16_bits_to_f32(u.w >> 16);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]),
+                      pack2_bf16(f[6], f[7]));
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// MFMA 16x16 tile step, dtype-generic.  One "k-step" consumes 64 bytes of K per operand row:
+//   bf16: 32 k  -> one v_mfma_f32_16x16x32_bf16
+//   f32 : 16 k  -> four v_mfma_f32_16x16x4_f32 (exact fp32 fma chain)
+// Lane l = (r = l & 15, q = l >> 4) supplies, for BOTH operands, the 16 bytes at k-offset q*VEC of
+// row r of its operand tile (A: output row, B: output column).  For f32 the four MFMAs take element
+// s of each lane's float4, i.e. k = 4q + s: a k-permutation shared by A and B, so the sum is exact.
+// Accumulator (C/D) layout: lane (c = l & 15, q = l >> 4) holds D[row 4q + i][col c], i = 0..3.
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct MMA;
+template <> struct MMA<bf16_t> {
+  static constexpr int KSTEP = 32;
+  static __device__ __forceinline__ void step(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                  acc, 0, 0, 0);
+  }
+};
+template <> struct MMA<float> {
+  static constexpr int KSTEP = 16;
+  static __device__ __forceinline__ void step(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// math
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// dtype dispatch on the host
+#define SL_DISPATCH_DTYPE(dtype, T, ...)                      \
+  do {                                                        \
+    if ((dtype) == SL_F32) {                                  \
+      using T = float;                                        \
+      __VA_ARGS__;                                            \
+    } else if ((dtype) == SL_BF16) {                          \
+      using T = bf16_t;                                       \
+      __VA_ARGS__;                                            \
+    } else {                                                  \
+      sl_set_error("unknown dtype %d", (int)(dtype));         \
+      return SL_ERR_ARG;                                      \
+    }                                                         \
+  } while (0)
+
+static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; }

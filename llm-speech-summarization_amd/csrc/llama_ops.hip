@@ -1,0 +1,303 @@
+// llama_ops.hip — the small Llama-side kernels: embedding gather, RoPE + KV-cache append, one-token GQA
+// attention against the cache, greedy token selection.  All HBM/latency-bound; 16-byte accesses, fp32 math.
+#include "common.h"
+
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const T* __restrict__ table, const int32_t* __restrict__ ids,
+                                                           T* __restrict__ out, int64_t n, int cols) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int cpr = cols / VEC;
+  const int64_t total = n * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cpr;
+    const int ch = (int)(i % cpr);
+    *(uint4*)(out + row * cols + ch * VEC) = *(const uint4*)(table + (int64_t)ids[row] * cols + ch * VEC);
+  }
+}
+
+extern "C" int sl_embed_gather(const void* table, const int32_t* ids, void* out, int64_t n, int32_t cols, int32_t dtype,
+                               sl_stream stream) {
+  SL_CHECK_ARG(table && ids && out && n >= 0 && cols > 0, "sl_embed_gather: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(cols % vec == 0, "sl_embed_gather: cols=%d must be a multiple of %d", cols, vec);
+  if (n == 0) return 0;
+  const int64_t total = n * (cols / vec);
+  const unsigned grid = (unsigned)(ceil_div64(total, 256) < 4096 ? ceil_div64(total, 256) : 4096);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((embed_gather_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)table, ids, (T*)out, n, cols);
+  });
+  SL_CHECK_LAUNCH("embed_gather");
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// RoPE + KV append.  One thread owns chunk j of the first half of a head and the matching chunk of the
+// second half (rotate_half pairs d with d + D/2).
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                             const int32_t* __restrict__ tok_seq, const int32_t* __restrict__ tok_pos,
+                                                             const float* __restrict__ cosT, const float* __restrict__ sinT, int64_t n_tok,
+                                                             int nh, int nkv, int D, int max_ctx) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int half = D / 2, cph = half / VEC;  // chunks per half head
+  const int heads = nh + 2 * nkv;
+  const int64_t total = n_tok * heads * cph;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % cph);
+    const int h = (int)((i / cph) % heads);
+    const int64_t t = i / ((int64_t)cph * heads);
+    T* src = qkv + t * (int64_t)heads * D + (int64_t)h * D + j * VEC;
+    const int pos = tok_pos[t];
+    uint4 u1 = *(const uint4*)src, u2 = *(const uint4*)(src + half);
+    if (h < nh + nkv) {
+      float a[VEC], b[VEC], c[VEC], s[VEC], o1[VEC], o2[VEC];
+      Vec16<T>::unpack(u1, a);
+      Vec16<T>::unpack(u2, b);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        c[e] = cosT[(int64_t)pos * half + j * VEC + e];
+        s[e] = sinT[(int64_t)pos * half + j * VEC + e];
+        o1[e] = a[e] * c[e] - b[e] * s[e];  // x*cos + rotate_half(x)*sin, first half: -x2*sin
+        o2[e] = b[e] * c[e] + a[e] * s[e];  // second half: +x1*sin
+      }
+      u1 = Vec16<T>::pack(o1);
+      u2 = Vec16<T>::pack(o2);
+    }
+    if (h < nh) {
+      *(uint4*)src = u1;
+      *(uint4*)(src + half) = u2;
+    } else {
+      const bool isk = h < nh + nkv;
+      const int kvh = isk ? h - nh : h - nh - nkv;
+      T* dst = (isk ? kc : vc) + (((int64_t)tok_seq[t] * nkv + kvh) * max_ctx + pos) * D + j * VEC;
+      *(uint4*)dst = u1;
+      *(uint4*)(dst + half) = u2;
+    }
+  }
+}
+
+extern "C" int sl_rope_kv_append(void* qkv, void* k_cache, void* v_cache, const int32_t* tok_seq, const int32_t* tok_pos,
+                                 const float* cos, const float* sin, int64_t n_tok, int32_t n_heads, int32_t n_kv, int32_t D,
+                                 int32_t max_ctx, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(qkv && k_cache && v_cache && tok_seq && tok_pos && cos && sin, "sl_rope_kv_append: null pointer");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(D % (2 * vec) == 0, "sl_rope_kv_append: head_dim=%d must be a multiple of %d", D, 2 * vec);
+  if (n_tok == 0) return 0;
+  const int64_t total = n_tok * (n_heads + 2 * n_kv) * (D / 2 / vec);
+  const unsigned grid = (unsigned)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((rope_kv_append_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (T*)qkv, (T*)k_cache, (T*)v_cache,
+                       tok_seq, tok_pos, cos, sin, n_tok, n_heads, n_kv, D, max_ctx);
+  });
+  SL_CHECK_LAUNCH("rope_kv_append");
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// One-token attention against the cache (decode).  Block = (kv head, sequence); the REP query heads
+// that share the kv head are processed together so K and V are streamed once.
+//   phase 1: scores  — a 16-lane group per key, each lane D/16 dims, xor-shuffle reduce
+//   phase 2: softmax — one wave per query head over the LDS score row
+//   phase 3: P.V     — 16 key groups x 16 dim chunks, LDS reduce over key groups
+// ----------------------------------------------------------------------------------------------
+template <typename T, int D, int REP>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ q, int64_t q_stride, const T* __restrict__ kc,
+                                                          const T* __restrict__ vc, T* __restrict__ out, const int32_t* __restrict__ ctx_len,
+                                                          int ctx_add, int nh, int nkv, int max_ctx, float scale) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int EPL = D / 16;       // elements per lane of a 16-lane group (8 for D=128)
+  constexpr int CPLN = EPL / VEC;   // 16-byte chunks per lane: 1 (bf16) or 2 (f32)
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int kvh = blockIdx.x, b = blockIdx.y;
+  const int n_keys = ctx_len[b] + ctx_add;
+  float* sc = dsm;                          // [REP][max_ctx]
+  float* red = dsm + REP * max_ctx;         // [16][REP][D]
+  float* inv_sum = red + 16 * REP * D;      // [REP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, gl = lane & 15;
+
+  const T* kbase = kc + ((int64_t)b * nkv + kvh) * max_ctx * D;
+  const T* vbase = vc + ((int64_t)b * nkv + kvh) * max_ctx * D;
+
+  // phase 1
+  float qr[REP][EPL];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) {
+    const T* qp = q + (int64_t)b * q_stride + (int64_t)(kvh * REP + h) * D + gl * EPL;
+#pragma unroll
+    for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(*(const uint4*)(qp + c * VEC), &qr[h][c * VEC]);
+  }
+  for (int key0 = 0; key0 < n_keys; key0 += 16) {
+    const int key = key0 + wave * 4 + grp;
+    const int kk = key < n_keys ? key : n_keys - 1;
+    float kf[EPL];
+#pragma unroll
+    for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(*(const uint4*)(kbase + (int64_t)kk * D + gl * EPL + c * VEC), &kf[c * VEC]);
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d = fmaf(qr[h][e], kf[e], d);
+      d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+      if (gl == 0 && key < n_keys) sc[h * max_ctx + key] = d * scale;
+    }
+  }
+  __syncthreads();
+  // phase 2
+  for (int h = wave; h < REP; h += 4) {
+    float m = -INFINITY;
+    for (int k = lane; k < n_keys; k += 64) m = fmaxf(m, sc[h * max_ctx + k]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int k = lane; k < n_keys; k += 64) {
+      const float p = __expf(sc[h * max_ctx + k] - m);
+      sc[h * max_ctx + k] = p;
+      s += p;
+    }
+    s = wave_sum(s);
+    if (lane == 0) inv_sum[h] = 1.0f / s;
+  }
+  __syncthreads();
+  // phase 3
+  {
+    const int kg = tid >> 4, dc = tid & 15;
+    float acc[REP][EPL];
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[h][e] = 0.f;
+    for (int key = kg; key < n_keys; key += 16) {
+      float vf[EPL];
+#pragma unroll
+      for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(*(const uint4*)(vbase + (int64_t)key * D + dc * EPL + c * VEC), &vf[c * VEC]);
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        // bf16 mode: probabilities are rounded to the storage dtype before P.V as HF eager does
+        const float p = to_f32(from_f32<T>(sc[h * max_ctx + key] * inv_sum[h]));
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[h][e] = fmaf(p, vf[e], acc[h][e]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) red[(kg * REP + h) * D + dc * EPL + e] = acc[h][e];
+  }
+  __syncthreads();
+  for (int o = tid; o < REP * D; o += 256) {
+    const int h = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) s += red[(kg * REP + h) * D + d];
+    out[(int64_t)b * nh * D + (int64_t)(kvh * REP + h) * D + d] = from_f32<T>(s);
+  }
+}
+
+template <typename T, int REP>
+static int launch_attn_decode(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, const int32_t* ctx_len,
+                              int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
+  constexpr int D = 128;
+  const size_t lds = ((size_t)REP * max_ctx + 16 * REP * D + REP) * sizeof(float);
+  SL_CHECK_ARG(lds <= 160 * 1024, "sl_attn_decode: max_ctx=%d needs %zu B of LDS (> 160 KiB)", max_ctx, lds);
+  auto kern = attn_decode_kernel<T, D, REP>;
+  if (lds > 64 * 1024) SL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(nkv, B), dim3(256), lds, st, (const T*)q, q_stride, (const T*)kc, (const T*)vc, (T*)out, ctx_len, ctx_add,
+                     nh, nkv, max_ctx, scale);
+  SL_CHECK_LAUNCH("attn_decode");
+  return 0;
+}
+
+int sl_attn_decode_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, const int32_t* ctx_len,
+                        int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx, float scale, int32_t dtype,
+                        hipStream_t st) {
+  SL_CHECK_ARG(q && k_cache && v_cache && out && ctx_len && B > 0, "sl_attn_decode: bad arguments");
+  SL_CHECK_ARG(D == 128, "sl_attn_decode: head_dim %d not built (Llama family uses 128)", D);
+  SL_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "sl_attn_decode: n_heads %% n_kv != 0");
+  const int rep = n_heads / n_kv;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    switch (rep) {
+      case 1: return launch_attn_decode<T, 1>(q, q_stride, k_cache, v_cache, out, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      case 2: return launch_attn_decode<T, 2>(q, q_stride, k_cache, v_cache, out, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      case 3: return launch_attn_decode<T, 3>(q, q_stride, k_cache, v_cache, out, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      case 4: return launch_attn_decode<T, 4>(q, q_stride, k_cache, v_cache, out, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      default: sl_set_error("sl_attn_decode: n_heads/n_kv=%d not built (1..4)", rep); return SL_ERR_UNSUPPORTED;
+    }
+  });
+}
+
+extern "C" int sl_attn_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out,
+                              const int32_t* ctx_len, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx, float scale,
+                              int32_t dtype, sl_stream stream) {
+  return sl_attn_decode_impl(q, q_stride, k_cache, v_cache, out, ctx_len, 0, B, n_heads, n_kv, D, max_ctx, scale, dtype, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------------
+// greedy selection: one block per sequence row
+// ----------------------------------------------------------------------------------------------
+struct EosList { int ids[8]; int n; };
+
+__global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __restrict__ logits, int V, EosList eos, int pad_id, int use_eos,
+                                                             int advance_ctx, int32_t* __restrict__ unfinished, int32_t* __restrict__ ctx_len,
+                                                             int32_t* __restrict__ gen_count, int32_t* __restrict__ finish_len,
+                                                             int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new) {
+  __shared__ float smax[16];
+  __shared__ int sidx[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (int64_t)b * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < V; i += 1024) {
+    const float v = row[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }   // NaN never wins, like a strict '>' scan
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { smax[wave] = best; sidx[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (smax[w] > best || (smax[w] == best && sidx[w] < bi)) { best = smax[w]; bi = sidx[w]; }
+    if (bi == 0x7fffffff) bi = 0;
+    int tok = bi;
+    int unf = unfinished[b];
+    if (use_eos) tok = unf ? tok : pad_id;   // hf:generation/utils.py:2928-2929
+    const int n = gen_count[b];
+    if (n < max_new) out_ids[(int64_t)b * max_new + n] = tok;
+    gen_count[b] = n + 1;
+    next_ids[b] = tok;
+    if (use_eos && unf) {
+      bool is_eos = false;
+      for (int e = 0; e < eos.n; ++e) is_eos |= (tok == eos.ids[e]);
+      if (is_eos) { unfinished[b] = 0; finish_len[b] = n + 1; }
+    }
+    if (advance_ctx) ctx_len[b] += 1;
+  }
+}
+
+int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
+                          int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
+                          int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st) {
+  SL_CHECK_ARG(logits && unfinished && ctx_len && gen_count && finish_len && next_ids && out_ids && B > 0 && V > 0,
+               "sl_greedy_select: bad arguments");
+  SL_CHECK_ARG(n_eos >= 0 && n_eos <= 8, "sl_greedy_select: at most 8 eos ids");
+  EosList e;
+  e.n = n_eos;
+  for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
+  hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, st, logits, V, e, pad_id, use_eos, advance_ctx, unfinished, ctx_len,
+                     gen_count, finish_len, next_ids, out_ids, max_new);
+  SL_CHECK_LAUNCH("greedy_select");
+  return 0;
+}
+
+extern "C" int sl_greedy_select(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
+                                int32_t use_eos, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len,
+                                int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream) {
+  return sl_greedy_select_impl(logits, B, V, eos_ids, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
+                               out_ids, max_new, (hipStream_t)stream);
+}

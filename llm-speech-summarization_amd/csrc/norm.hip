@@ -1,0 +1,95 @@
+// norm.hip — LayerNorm (+optional GELU) and Llama RMSNorm.  HBM-bound row kernels: one wave per row,
+// 16-byte loads, the whole row lives in registers between the statistics and the write (one read, one
+// write of HBM per element).  Statistics in fp32 as the reference's fp32 / autocast-to-fp32 path does.
+#include "common.h"
+
+constexpr int NORM_MAXF = 64;  // floats per lane -> rows of up to 4096 elements
+
+template <typename T, bool RMS>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ g,
+                                                        const T* __restrict__ b, int64_t rows, int cols, float eps, int gelu) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int MAXCH = NORM_MAXF / VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = cols / VEC;  // 16-byte chunks per row
+  const T* xr = x + row * cols;
+  T* yr = y + row * cols;
+
+  float v[MAXCH][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const uint4 u = *(const uint4*)(xr + ch * VEC);
+      Vec16<T>::unpack(u, v[i]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += RMS ? v[i][e] * v[i][e] : v[i][e];
+    }
+  }
+  s = wave_sum(s);
+  float mean = 0.f, rstd;
+  if constexpr (RMS) {
+    rstd = rsqrtf(s / (float)cols + eps);
+  } else {
+    mean = s / (float)cols;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
+      }
+    }
+    s2 = wave_sum(s2);
+    rstd = rsqrtf(s2 / (float)cols + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      float gg[VEC], bb[VEC], o[VEC];
+      Vec16<T>::unpack(*(const uint4*)(g + ch * VEC), gg);
+      if constexpr (!RMS) Vec16<T>::unpack(*(const uint4*)(b + ch * VEC), bb);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if constexpr (RMS) {
+          // hf:models/llama/modeling_llama.py:66-67: normalised value is cast to the input dtype first
+          const float t = to_f32(from_f32<T>(v[i][e] * rstd));
+          o[e] = gg[e] * t;
+        } else {
+          float t = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+          o[e] = gelu ? gelu_erf(t) : t;
+        }
+      }
+      *(uint4*)(yr + ch * VEC) = Vec16<T>::pack(o);
+    }
+  }
+}
+
+template <typename T, bool RMS>
+static int launch_norm(const void* x, void* y, const void* g, const void* b, int64_t rows, int cols, float eps, int gelu,
+                       hipStream_t st) {
+  constexpr int VEC = Vec16<T>::VEC;
+  SL_CHECK_ARG(cols % VEC == 0 && cols <= 64 * NORM_MAXF, "norm: cols=%d must be a multiple of %d and <= %d", cols, VEC, 64 * NORM_MAXF);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL((norm_rows_kernel<T, RMS>), dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, (const T*)x, (T*)y,
+                     (const T*)g, (const T*)b, rows, cols, eps, gelu);
+  SL_CHECK_LAUNCH("norm_rows");
+  return 0;
+}
+
+extern "C" int sl_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int32_t cols, float eps,
+                            int32_t gelu, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(x && y && gamma && beta && rows >= 0 && cols > 0, "sl_layernorm: bad arguments");
+  SL_DISPATCH_DTYPE(dtype, T, return (launch_norm<T, false>(x, y, gamma, beta, rows, cols, eps, gelu, (hipStream_t)stream)));
+}
+
+extern "C" int sl_rmsnorm(const void* x, void* y, const void* w, int64_t rows, int32_t cols, float eps, int32_t dtype,
+                          sl_stream stream) {
+  SL_CHECK_ARG(x && y && w && rows >= 0 && cols > 0, "sl_rmsnorm: bad arguments");
+  SL_DISPATCH_DTYPE(dtype, T, return (launch_norm<T, true>(x, y, w, nullptr, rows, cols, eps, 0, (hipStream_t)stream)));
+}

@@ -1,0 +1,491 @@
+// runtime.hip — C++ host runtime above the kernels: HuBERT encoder forward over a batch of utterances,
+// Llama prefill / decode step / greedy generation (decode step captured once into a hipGraph and
+// replayed, all per-step state lives on the device).  Workspace is carved from one caller-owned buffer.
+#include <vector>
+
+#include "common.h"
+
+int sl_attn_decode_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, const int32_t* ctx_len,
+                        int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx, float scale, int32_t dtype,
+                        hipStream_t st);
+int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
+                          int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
+                          int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st);
+
+namespace {
+
+struct Carver {
+  unsigned char* base;
+  size_t off = 0, cap;
+  Carver(void* b, size_t c) : base((unsigned char*)b), cap(c) {}
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+  bool ok() const { return off <= cap; }
+};
+
+int gemm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* res,
+         int64_t ldr, int M, int N, int K, int act, int out_f32, hipStream_t st) {
+  sl_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.residual = res; a.ldr = ldr;
+  a.M = M; a.N = N; a.K = K; a.batch = 1; a.dtype = dtype; a.act = act; a.out_f32 = out_f32;
+  return sl_gemm(&a, (sl_stream)st);
+}
+
+inline unsigned char* bptr(void* p) { return (unsigned char*)p; }
+
+}  // namespace
+
+// ================================================================================================
+// HuBERT
+// ================================================================================================
+extern "C" int sl_hubert_num_frames(const sl_hubert_model* m, int64_t n_samples) {
+  int64_t L = n_samples;
+  for (int i = 0; i < m->n_conv; ++i) {
+    if (L < m->conv_kernel[i]) return 0;
+    L = (L - m->conv_kernel[i]) / m->conv_stride[i] + 1;
+  }
+  return (int)L;
+}
+
+struct HubertPlan {
+  int64_t max_conv_elems = 0;  // largest conv activation (elements) over layers and utterances
+  int64_t total_T = 0, max_T = 0, total_P = 0;
+  std::vector<int64_t> T, P, tok0;
+};
+
+static int hubert_plan(const sl_hubert_model* m, const int64_t* offs, int n_utt, HubertPlan& pl) {
+  pl.T.resize(n_utt); pl.P.resize(n_utt); pl.tok0.resize(n_utt + 1);
+  for (int u = 0; u < n_utt; ++u) {
+    int64_t L = offs[u + 1] - offs[u];
+    for (int i = 0; i < m->n_conv; ++i) {
+      SL_CHECK_ARG(L >= m->conv_kernel[i], "sl_hubert_forward: utterance %d too short (%lld samples)", u, (long long)(offs[u + 1] - offs[u]));
+      L = (L - m->conv_kernel[i]) / m->conv_stride[i] + 1;
+      if (L * m->conv_dim[i] > pl.max_conv_elems) pl.max_conv_elems = L * m->conv_dim[i];
+    }
+    pl.T[u] = L;
+    SL_CHECK_ARG(L >= m->pool_kernel, "sl_hubert_forward: utterance %d gives %lld frames < pool kernel %d", u, (long long)L, m->pool_kernel);
+    pl.P[u] = (L - m->pool_kernel) / m->pool_stride + 1;
+    pl.tok0[u] = pl.total_T;
+    pl.total_T += L;
+    pl.total_P += pl.P[u];
+    if (L > pl.max_T) pl.max_T = L;
+  }
+  pl.tok0[n_utt] = pl.total_T;
+  return 0;
+}
+
+struct HubertWs {
+  void *convA, *convB, *feat, *x, *ln, *qkv, *att, *mid, *xg, *pooled;
+  int32_t *cu, *cuk, *klen;
+};
+
+static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n_utt, void* base, size_t cap, HubertWs& w) {
+  const size_t sz = sl_dtype_size(m->dtype);
+  const int H = m->hidden;
+  Carver c(base, cap);
+  w.convA = c.take(pl.max_conv_elems * sz);
+  w.convB = c.take(pl.max_conv_elems * sz);
+  w.feat = c.take(pl.total_T * m->conv_dim[m->n_conv - 1] * sz);
+  w.x = c.take(pl.total_T * H * sz);
+  w.ln = c.take(pl.total_T * H * sz);
+  w.qkv = c.take(pl.total_T * 3 * H * sz);
+  w.att = c.take(pl.total_T * H * sz);
+  w.mid = c.take(pl.total_T * (int64_t)m->ffn * sz);
+  w.xg = c.take((pl.max_T + m->pos_k) * H * sz);
+  w.pooled = c.take(pl.total_P * H * sz);
+  w.cu = (int32_t*)c.take((n_utt + 1) * sizeof(int32_t));
+  w.cuk = (int32_t*)c.take(n_utt * sizeof(int32_t));
+  w.klen = (int32_t*)c.take(n_utt * sizeof(int32_t));
+  return c.off + 256;
+}
+
+extern "C" size_t sl_hubert_workspace_bytes(const sl_hubert_model* m, const int64_t* sample_offsets_host, int32_t n_utt) {
+  HubertPlan pl;
+  if (hubert_plan(m, sample_offsets_host, n_utt, pl) != 0) return 0;
+  HubertWs w;
+  return hubert_carve(m, pl, n_utt, nullptr, 0, w);
+}
+
+extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, const int64_t* sample_offsets_host, int32_t n_utt,
+                                 void* out, int64_t out_ld, const int64_t* out_row_offsets_host, void* last_hidden, void* workspace,
+                                 size_t workspace_bytes, sl_stream stream) {
+  SL_CHECK_ARG(m && waves && sample_offsets_host && workspace && n_utt > 0, "sl_hubert_forward: bad arguments");
+  SL_CHECK_ARG((m->proj_w && out) || (!m->proj_w && last_hidden), "sl_hubert_forward: need `out` (pool) or `last_hidden` (host-side downsample)");
+  SL_CHECK_ARG(m->n_conv >= 2 && m->n_conv <= 8 && m->hidden % m->n_heads == 0 && m->hidden / m->n_heads == 64,
+               "sl_hubert_forward: need 2..8 conv layers and head_dim 64 (hidden=%d heads=%d)", m->hidden, m->n_heads);
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = m->dtype;
+  const size_t sz = sl_dtype_size(dt);
+  const int H = m->hidden;
+  HubertPlan pl;
+  SL_TRY(hubert_plan(m, sample_offsets_host, n_utt, pl));
+  HubertWs w;
+  const size_t need = hubert_carve(m, pl, n_utt, workspace, workspace_bytes, w);
+  SL_CHECK_ARG(need <= workspace_bytes, "sl_hubert_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+  const int Cl = m->conv_dim[m->n_conv - 1];
+
+  // ---- per utterance: conv feature extractor -> feat rows [tok0, tok0+T)
+  for (int u = 0; u < n_utt; ++u) {
+    const int64_t n = sample_offsets_host[u + 1] - sample_offsets_host[u];
+    int64_t L = (n - m->conv_kernel[0]) / m->conv_stride[0] + 1;
+    void* cur = w.convA;
+    void* nxt = w.convB;
+    SL_TRY(sl_hubert_conv0(waves + sample_offsets_host[u], n, m->conv0_w, m->conv0_b, m->conv0_g, m->conv0_beta, cur, m->conv_dim[0],
+                           m->conv_kernel[0], m->conv_stride[0], 1e-5f, dt, stream));
+    for (int i = 1; i < m->n_conv; ++i) {
+      const int Cin = m->conv_dim[i - 1], Cout = m->conv_dim[i], k = m->conv_kernel[i], s = m->conv_stride[i];
+      const int64_t Lo = (L - k) / s + 1;
+      void* dst = (i == m->n_conv - 1) ? (void*)(bptr(w.feat) + pl.tok0[u] * Cl * sz) : nxt;
+      // implicit GEMM: output row t reads the k*Cin contiguous elements starting at input row t*s
+      SL_TRY(gemm(dt, cur, (int64_t)s * Cin, m->conv_w[i], (int64_t)k * Cin, dst, Cout, m->conv_b[i], nullptr, 0, (int)Lo, Cout, k * Cin,
+                  SL_ACT_NONE, 0, st));
+      SL_TRY(sl_layernorm(dst, dst, m->conv_g[i], m->conv_beta[i], Lo, Cout, 1e-5f, 1, dt, stream));
+      cur = dst;
+      nxt = (cur == w.convA) ? w.convB : w.convA;
+      L = Lo;
+    }
+  }
+  // ---- feature projection on the packed tokens
+  const int NT = (int)pl.total_T;
+  SL_TRY(sl_layernorm(w.feat, w.feat, m->fp_ln_g, m->fp_ln_b, NT, Cl, m->ln_eps, 0, dt, stream));
+  SL_TRY(gemm(dt, w.feat, Cl, m->fp_w, Cl, w.x, H, m->fp_b, nullptr, 0, NT, H, Cl, SL_ACT_NONE, 0, st));
+  // ---- positional conv embedding, per utterance: x += gelu(grouped_conv(x))  (written to w.ln, then swapped)
+  {
+    const int G = m->pos_groups, Hg = H / G, k = m->pos_k;
+    for (int u = 0; u < n_utt; ++u) {
+      const int64_t T = pl.T[u];
+      unsigned char* xu = bptr(w.x) + pl.tok0[u] * H * sz;
+      unsigned char* yu = bptr(w.ln) + pl.tok0[u] * H * sz;
+      SL_TRY(sl_posconv_stage(xu, w.xg, T, H, G, k, dt, stream));
+      sl_gemm_args a;
+      memset(&a, 0, sizeof(a));
+      a.A = w.xg; a.lda = Hg; a.strideA = (T + k) * Hg;
+      a.W = m->pos_w; a.ldw = (int64_t)k * Hg; a.strideW = (int64_t)Hg * k * Hg;
+      a.C = yu; a.ldc = H; a.strideC = Hg;
+      a.bias = m->pos_b; a.strideBias = Hg;
+      a.residual = xu; a.ldr = H; a.strideR = Hg;
+      a.M = (int)T; a.N = Hg; a.K = k * Hg; a.batch = G; a.dtype = dt; a.act = SL_ACT_GELU;
+      SL_TRY(sl_gemm(&a, stream));
+    }
+    void* t = w.x; w.x = w.ln; w.ln = t;
+  }
+  // ---- transformer layers on packed tokens, varlen attention
+  {
+    std::vector<int32_t> cu(n_utt + 1), kl(n_utt);
+    for (int u = 0; u <= n_utt; ++u) cu[u] = (int32_t)pl.tok0[u];
+    for (int u = 0; u < n_utt; ++u) kl[u] = (int32_t)pl.T[u];
+    SL_HIP(hipMemcpyAsync(w.cu, cu.data(), (n_utt + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipMemcpyAsync(w.cuk, cu.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipMemcpyAsync(w.klen, kl.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipStreamSynchronize(st));  // host vectors go out of scope; pageable copies are staged but be explicit
+  }
+  for (int l = 0; l < m->n_layers; ++l) {
+    const sl_hubert_layer& L = m->layers[l];
+    SL_TRY(sl_layernorm(w.x, w.ln, L.ln1_g, L.ln1_b, NT, H, m->ln_eps, 0, dt, stream));
+    SL_TRY(gemm(dt, w.ln, H, L.wqkv, H, w.qkv, 3 * H, L.bqkv, nullptr, 0, NT, 3 * H, H, SL_ACT_NONE, 0, st));
+    sl_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.q = w.qkv; a.q_row_stride = 3 * H; a.q_head_stride = 64;
+    a.k = bptr(w.qkv) + (size_t)H * sz; a.k_row_stride = 3 * H; a.k_head_stride = 64;
+    a.v = bptr(w.qkv) + (size_t)2 * H * sz; a.v_row_stride = 3 * H; a.v_head_stride = 64;
+    a.out = w.att; a.o_row_stride = H; a.o_head_stride = 64;
+    a.cu_q = w.cu; a.cu_k = w.cuk; a.klen = w.klen;
+    a.nseq = n_utt; a.max_qlen = (int)pl.max_T; a.n_heads = m->n_heads; a.n_kv_heads = m->n_heads; a.head_dim = 64; a.causal = 0;
+    a.dtype = dt; a.scale = 0.125f;
+    SL_TRY(sl_attn_fwd(&a, stream));
+    SL_TRY(gemm(dt, w.att, H, L.wo, H, w.x, H, L.bo, w.x, H, NT, H, H, SL_ACT_NONE, 0, st));
+    SL_TRY(sl_layernorm(w.x, w.ln, L.ln2_g, L.ln2_b, NT, H, m->ln_eps, 0, dt, stream));
+    SL_TRY(gemm(dt, w.ln, H, L.w1, H, w.mid, m->ffn, L.b1, nullptr, 0, NT, m->ffn, H, SL_ACT_GELU, 0, st));
+    SL_TRY(gemm(dt, w.mid, m->ffn, L.w2, m->ffn, w.x, H, L.b2, w.x, H, NT, H, m->ffn, SL_ACT_NONE, 0, st));
+  }
+  void* lh = last_hidden ? last_hidden : w.ln;
+  SL_TRY(sl_layernorm(w.x, lh, m->final_ln_g, m->final_ln_b, NT, H, m->ln_eps, 0, dt, stream));
+  // ---- AvgPool over time + projection into the caller's (prompt) buffer
+  int64_t prow = 0;
+  if (!m->proj_w) return 0;  // stack / ctc_pool: the host finishes from last_hidden
+  for (int u = 0; u < n_utt; ++u) {
+    unsigned char* src = bptr(lh) + pl.tok0[u] * H * sz;
+    unsigned char* pooled = bptr(w.pooled) + prow * H * sz;
+    SL_TRY(sl_avgpool_rows(src, pooled, pl.T[u], H, m->pool_kernel, m->pool_stride, nullptr, pl.P[u], dt, stream));
+    const int64_t orow = out_row_offsets_host ? out_row_offsets_host[u] : prow;
+    SL_TRY(gemm(dt, pooled, H, m->proj_w, H, bptr(out) + orow * out_ld * sz, out_ld, m->proj_b, nullptr, 0, (int)pl.P[u], m->llm_dim, H,
+                SL_ACT_NONE, 0, st));
+    prow += pl.P[u];
+  }
+  return 0;
+}
+
+// ================================================================================================
+// Llama
+// ================================================================================================
+struct LlamaWs {
+  void *h, *qkv, *att, *mid, *last;
+  int32_t *tok_seq, *tok_pos, *cu, *cuk, *klen;
+};
+
+static size_t llama_carve(const sl_llama_model* m, int64_t n_tok, int nseq, void* base, size_t cap, LlamaWs& w) {
+  const size_t sz = sl_dtype_size(m->dtype);
+  const int qkv_w = (m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
+  Carver c(base, cap);
+  w.h = c.take(n_tok * m->hidden * sz);
+  w.qkv = c.take(n_tok * qkv_w * sz);
+  w.att = c.take(n_tok * (int64_t)m->n_heads * m->head_dim * sz);
+  w.mid = c.take(n_tok * (int64_t)m->ffn * sz);
+  w.last = c.take((size_t)nseq * m->hidden * sz);
+  w.tok_seq = (int32_t*)c.take(n_tok * sizeof(int32_t));
+  w.tok_pos = (int32_t*)c.take(n_tok * sizeof(int32_t));
+  w.cu = (int32_t*)c.take((nseq + 1) * sizeof(int32_t));
+  w.cuk = (int32_t*)c.take(nseq * sizeof(int32_t));
+  w.klen = (int32_t*)c.take(nseq * sizeof(int32_t));
+  return c.off + 256;
+}
+
+extern "C" size_t sl_llama_workspace_bytes(const sl_llama_model* m, int64_t n_tok, int32_t nseq) {
+  LlamaWs w;
+  return llama_carve(m, n_tok, nseq, nullptr, 0, w);
+}
+
+static int llama_check(const sl_llama_model* m, const sl_kv_cache* kv) {
+  SL_CHECK_ARG(m && kv && m->layers && m->embed && m->lm_head && m->final_norm && m->rope_cos && m->rope_sin, "llama: null model field");
+  SL_CHECK_ARG(m->head_dim == 128, "llama: head_dim %d not built (128)", m->head_dim);
+  SL_CHECK_ARG(kv->k_cache && kv->v_cache && kv->slots > 0 && kv->max_ctx > 0, "llama: bad kv cache");
+  SL_CHECK_ARG(kv->max_ctx <= m->rope_len, "llama: max_ctx %d exceeds the rope table (%d)", kv->max_ctx, m->rope_len);
+  return 0;
+}
+
+static inline size_t kv_layer_bytes(const sl_llama_model* m, const sl_kv_cache* kv) {
+  return (size_t)kv->slots * m->n_kv_heads * kv->max_ctx * m->head_dim * sl_dtype_size(m->dtype);
+}
+
+// one decoder layer over `n` token rows; attention chosen by `decode`
+static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, void* x, int64_t n, LlamaWs& w, bool decode, int nseq,
+                       int max_qlen, const int32_t* ctx_len_dev, hipStream_t st) {
+  const sl_llama_layer& L = m->layers[l];
+  const int dt = m->dtype, H = m->hidden, D = m->head_dim, nh = m->n_heads, nkv = m->n_kv_heads;
+  const int qkv_w = (nh + 2 * nkv) * D;
+  const size_t sz = sl_dtype_size(dt);
+  void* kc = bptr(kv->k_cache) + (size_t)l * kv_layer_bytes(m, kv);
+  void* vc = bptr(kv->v_cache) + (size_t)l * kv_layer_bytes(m, kv);
+  const float scale = 1.0f / sqrtf((float)D);
+  SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st));
+  SL_TRY(gemm(dt, w.h, H, L.wqkv, H, w.qkv, qkv_w, nullptr, nullptr, 0, (int)n, qkv_w, H, SL_ACT_NONE, 0, st));
+  SL_TRY(sl_rope_kv_append(w.qkv, kc, vc, w.tok_seq, decode ? ctx_len_dev : w.tok_pos, m->rope_cos, m->rope_sin, n, nh, nkv, D, kv->max_ctx,
+                           dt, (sl_stream)st));
+  if (decode) {
+    SL_TRY(sl_attn_decode_impl(w.qkv, qkv_w, kc, vc, w.att, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
+  } else {
+    sl_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.q = w.qkv; a.q_row_stride = qkv_w; a.q_head_stride = D;
+    a.k = kc; a.k_row_stride = D; a.k_head_stride = (int64_t)kv->max_ctx * D;
+    a.v = vc; a.v_row_stride = D; a.v_head_stride = (int64_t)kv->max_ctx * D;
+    a.out = w.att; a.o_row_stride = (int64_t)nh * D; a.o_head_stride = D;
+    a.cu_q = w.cu; a.cu_k = w.cuk; a.klen = w.klen;
+    a.nseq = nseq; a.max_qlen = max_qlen; a.n_heads = nh; a.n_kv_heads = nkv; a.head_dim = D; a.causal = 1; a.dtype = dt; a.scale = scale;
+    SL_TRY(sl_attn_fwd(&a, (sl_stream)st));
+  }
+  SL_TRY(gemm(dt, w.att, (int64_t)nh * D, L.wo, (int64_t)nh * D, x, H, nullptr, x, H, (int)n, H, nh * D, SL_ACT_NONE, 0, st));
+  SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st));
+  SL_TRY(gemm(dt, w.h, H, L.wgu, H, w.mid, m->ffn, nullptr, nullptr, 0, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, st));
+  SL_TRY(gemm(dt, w.mid, m->ffn, L.wdown, m->ffn, x, H, nullptr, x, H, (int)n, H, m->ffn, SL_ACT_NONE, 0, st));
+  (void)sz;
+  return 0;
+}
+
+extern "C" int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                                float* logits, int32_t* ctx_len_dev, void* hidden_taps, void* workspace, size_t workspace_bytes,
+                                sl_stream stream) {
+  SL_TRY(llama_check(m, kv));
+  SL_CHECK_ARG(x && cu_seqlens_host && logits && ctx_len_dev && workspace && nseq > 0 && nseq <= kv->slots, "sl_llama_prefill: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_tok = cu_seqlens_host[nseq];
+  const int dt = m->dtype, H = m->hidden;
+  const size_t sz = sl_dtype_size(dt);
+  LlamaWs w;
+  const size_t need = llama_carve(m, n_tok, nseq, workspace, workspace_bytes, w);
+  SL_CHECK_ARG(need <= workspace_bytes, "sl_llama_prefill: workspace %zu B < required %zu B", workspace_bytes, need);
+  std::vector<int32_t> tseq(n_tok), tpos(n_tok), cuk(nseq), kl(nseq);
+  int max_q = 0;
+  for (int s = 0; s < nseq; ++s) {
+    const int len = cu_seqlens_host[s + 1] - cu_seqlens_host[s];
+    SL_CHECK_ARG(len > 0 && len <= kv->max_ctx, "sl_llama_prefill: sequence %d length %d outside (0, max_ctx=%d]", s, len, kv->max_ctx);
+    for (int t = 0; t < len; ++t) { tseq[cu_seqlens_host[s] + t] = s; tpos[cu_seqlens_host[s] + t] = t; }
+    cuk[s] = s * m->n_kv_heads * kv->max_ctx;  // first cache row of the sequence (rows of D elements, head-major inside)
+    kl[s] = len;
+    if (len > max_q) max_q = len;
+  }
+  SL_HIP(hipMemcpyAsync(w.tok_seq, tseq.data(), n_tok * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.tok_pos, tpos.data(), n_tok * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.cu, cu_seqlens_host, (nseq + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.cuk, cuk.data(), nseq * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.klen, kl.data(), nseq * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(ctx_len_dev, kl.data(), nseq * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipStreamSynchronize(st));
+  for (int l = 0; l < m->n_layers; ++l) {
+    if (hidden_taps) SL_HIP(hipMemcpyAsync(bptr(hidden_taps) + (size_t)l * n_tok * H * sz, x, n_tok * H * sz, hipMemcpyDeviceToDevice, st));
+    SL_TRY(llama_layer(m, kv, l, x, n_tok, w, false, nseq, max_q, nullptr, st));
+  }
+  if (hidden_taps) {
+    SL_TRY(sl_rmsnorm(x, bptr(hidden_taps) + (size_t)m->n_layers * n_tok * H * sz, m->final_norm, n_tok, H, m->rms_eps, dt, stream));
+  }
+  // last-token rows -> final norm -> lm_head (fp32 logits)
+  for (int s = 0; s < nseq; ++s)
+    SL_HIP(hipMemcpyAsync(bptr(w.last) + (size_t)s * H * sz, bptr(x) + (size_t)(cu_seqlens_host[s + 1] - 1) * H * sz, H * sz,
+                          hipMemcpyDeviceToDevice, st));
+  SL_TRY(sl_rmsnorm(w.last, w.last, m->final_norm, nseq, H, m->rms_eps, dt, stream));
+  SL_TRY(gemm(dt, w.last, H, m->lm_head, H, logits, m->vocab, nullptr, nullptr, 0, nseq, m->vocab, H, SL_ACT_NONE, 1, st));
+  return 0;
+}
+
+// decode-step state carved from the tail of the workspace by sl_greedy_generate, or supplied by the caller
+static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids, const int32_t* ctx_len, int B, float* logits,
+                       void* x, LlamaWs& w, hipStream_t st) {
+  const int dt = m->dtype, H = m->hidden;
+  SL_TRY(sl_embed_gather(m->embed, next_ids, x, B, H, dt, (sl_stream)st));
+  for (int l = 0; l < m->n_layers; ++l) SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st));
+  SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st));
+  SL_TRY(gemm(dt, w.last, H, m->lm_head, H, logits, m->vocab, nullptr, nullptr, 0, B, m->vocab, H, SL_ACT_NONE, 1, st));
+  return 0;
+}
+
+__global__ void iota_kernel(int32_t* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+extern "C" int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids_dev, const int32_t* ctx_len_dev,
+                                    int32_t B, float* logits, void* workspace, size_t workspace_bytes, sl_stream stream) {
+  SL_TRY(llama_check(m, kv));
+  SL_CHECK_ARG(next_ids_dev && ctx_len_dev && logits && workspace && B > 0 && B <= kv->slots && B <= 64, "sl_llama_decode_step: bad arguments (B<=64)");
+  hipStream_t st = (hipStream_t)stream;
+  LlamaWs w;
+  Carver c(workspace, workspace_bytes);
+  void* x = c.take((size_t)B * m->hidden * sl_dtype_size(m->dtype));
+  c.take(0);
+  const size_t off = c.off;
+  SL_CHECK_ARG(off <= workspace_bytes, "sl_llama_decode_step: workspace too small");
+  const size_t need = off + llama_carve(m, B, B, bptr(workspace) + off, workspace_bytes - off, w);
+  SL_CHECK_ARG(need <= workspace_bytes, "sl_llama_decode_step: workspace %zu B < required %zu B", workspace_bytes, need);
+  hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
+  SL_CHECK_LAUNCH("iota");
+  return decode_step(m, kv, next_ids_dev, ctx_len_dev, B, logits, x, w, st);
+}
+
+extern "C" size_t sl_generate_workspace_bytes(const sl_llama_model* m, int64_t n_tok, int32_t nseq, int32_t max_new_tokens) {
+  LlamaWs w;
+  size_t a = llama_carve(m, n_tok > nseq ? n_tok : nseq, nseq, nullptr, 0, w);
+  a += (size_t)nseq * m->hidden * sl_dtype_size(m->dtype) + 256;    // decode x
+  a += (size_t)nseq * m->vocab * sizeof(float) + 256;               // logits
+  a += ((size_t)nseq * (5 + max_new_tokens)) * sizeof(int32_t) + 8 * 256;
+  return a;
+}
+
+extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                                  int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
+                                  int32_t check_every, int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host,
+                                  void* workspace, size_t workspace_bytes, sl_stream stream) {
+  SL_TRY(llama_check(m, kv));
+  SL_CHECK_ARG(x && cu_seqlens_host && out_ids_host && n_steps_host && workspace && nseq > 0 && nseq <= 64 && max_new_tokens > 0,
+               "sl_greedy_generate: bad arguments (nseq<=64)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_tok = cu_seqlens_host[nseq];
+  const int B = nseq;
+  for (int s = 0; s < nseq; ++s)
+    SL_CHECK_ARG(cu_seqlens_host[s + 1] - cu_seqlens_host[s] + max_new_tokens <= kv->max_ctx,
+                 "sl_greedy_generate: prompt %d (%d tokens) + %d new tokens exceeds max_ctx %d", s,
+                 cu_seqlens_host[s + 1] - cu_seqlens_host[s], max_new_tokens, kv->max_ctx);
+  SL_CHECK_ARG(sl_generate_workspace_bytes(m, n_tok, nseq, max_new_tokens) <= workspace_bytes, "sl_greedy_generate: workspace %zu B < required %zu B",
+               workspace_bytes, sl_generate_workspace_bytes(m, n_tok, nseq, max_new_tokens));
+  // carve: generation state first, then the prefill/decode scratch
+  Carver c(workspace, workspace_bytes);
+  float* logits = (float*)c.take((size_t)B * m->vocab * sizeof(float));
+  void* xdec = c.take((size_t)B * m->hidden * sl_dtype_size(m->dtype));
+  int32_t* unfinished = (int32_t*)c.take(B * sizeof(int32_t));
+  int32_t* ctx_len = (int32_t*)c.take(B * sizeof(int32_t));
+  int32_t* gen_count = (int32_t*)c.take(B * sizeof(int32_t));
+  int32_t* finish_len = (int32_t*)c.take(B * sizeof(int32_t));
+  int32_t* next_ids = (int32_t*)c.take(B * sizeof(int32_t));
+  int32_t* out_ids = (int32_t*)c.take((size_t)B * max_new_tokens * sizeof(int32_t));
+  c.take(0);
+  void* scratch = bptr(workspace) + c.off;
+  const size_t scratch_bytes = workspace_bytes - c.off;
+
+  std::vector<int32_t> ones(B, 1), zeros(B, 0);
+  SL_HIP(hipMemcpyAsync(unfinished, ones.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(gen_count, zeros.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(finish_len, zeros.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemsetAsync(out_ids, 0, (size_t)B * max_new_tokens * sizeof(int32_t), st));
+
+  hipEvent_t ev[3];
+  for (auto& e : ev) SL_HIP(hipEventCreate(&e));
+  SL_HIP(hipEventRecord(ev[0], st));
+  SL_TRY(sl_llama_prefill(m, kv, x, cu_seqlens_host, nseq, logits, ctx_len, nullptr, scratch, scratch_bytes, stream));
+  SL_TRY(sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 0, unfinished, ctx_len, gen_count, finish_len, next_ids,
+                               out_ids, max_new_tokens, st));
+  SL_HIP(hipEventRecord(ev[1], st));
+
+  // decode: one captured step, replayed.  Scratch layout for M = B rows.
+  LlamaWs w;
+  llama_carve(m, B, B, scratch, scratch_bytes, w);
+  hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
+  SL_CHECK_LAUNCH("iota");
+  int steps_done = 1;
+  std::vector<int32_t> unf_host(B, 1);
+  bool all_done = false;
+  if (max_new_tokens > 1) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    SL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, st);
+    if (rc == 0)
+      rc = sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
+                                 out_ids, max_new_tokens, st);
+    hipError_t ce = hipStreamEndCapture(st, &graph);
+    if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) { sl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce)); return SL_ERR_LAUNCH; }
+    SL_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    if (check_every <= 0) check_every = 16;
+    while (steps_done < max_new_tokens) {
+      SL_HIP(hipGraphLaunch(exec, st));
+      ++steps_done;
+      if (use_eos && (steps_done % check_every == 0) && steps_done < max_new_tokens) {
+        SL_HIP(hipMemcpyAsync(unf_host.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        SL_HIP(hipStreamSynchronize(st));
+        all_done = true;
+        for (int b = 0; b < B; ++b) all_done = all_done && (unf_host[b] == 0);
+        if (all_done) break;
+      }
+    }
+    SL_HIP(hipEventRecord(ev[2], st));
+    SL_HIP(hipStreamSynchronize(st));
+    hipGraphExecDestroy(exec);
+    hipGraphDestroy(graph);
+  } else {
+    SL_HIP(hipEventRecord(ev[2], st));
+    SL_HIP(hipStreamSynchronize(st));
+  }
+  // results
+  std::vector<int32_t> fin(B);
+  SL_HIP(hipMemcpy(unf_host.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  SL_HIP(hipMemcpy(fin.data(), finish_len, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  SL_HIP(hipMemcpy(out_ids_host, out_ids, (size_t)B * max_new_tokens * sizeof(int32_t), hipMemcpyDeviceToHost));
+  int n_cols = steps_done;
+  if (use_eos) {
+    all_done = true;
+    int mx = 0;
+    for (int b = 0; b < B; ++b) { all_done = all_done && unf_host[b] == 0; if (fin[b] > mx) mx = fin[b]; }
+    if (all_done) n_cols = mx;  // HF stops at the step where the last row emitted its EOS
+  }
+  *n_steps_host = n_cols;
+  if (timings_ms_host) {
+    SL_HIP(hipEventElapsedTime(&timings_ms_host[0], ev[0], ev[1]));
+    SL_HIP(hipEventElapsedTime(&timings_ms_host[1], ev[1], ev[2]));
+  }
+  for (auto& e : ev) hipEventDestroy(e);
+  return 0;
+}

@@ -1,0 +1,88 @@
+"""LLMSpeechTextInference: drop-in mirror of ref:inference.py:18-137 on the HIP path.
+
+Same constructor signature, attributes (`config, device, audio_encoder, llm_type, llm_tokenizer,
+prompt_prefix, prompt_suffix, llm`) and methods (`generate_llm_response`, `generate_text_response`,
+`generate_audio_response`) with the reference's order of operations:
+    audio -> AudioEncoder -> [text[1:] | audio] -> [prefix | . | suffix[1:]] -> greedy generate -> decode.
+Optional keyword arguments (`tokenizer`, `llm`, `dtype`) let callers inject a tokenizer object or
+already-built models where hub downloads are impossible; when omitted the reference's loading path
+(local checkpoint directory named by `config.model.llm_type`) is followed.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+from .audio_encoder import AudioEncoder
+from .audio_llama import AudioLlamaForCausalLM
+from .utils import (LLAMA_PROMPT_PREFIX, LLAMA_PROMPT_SUFFIX, MINICHAT_PROMPT_PREFIX, MINICHAT_PROMPT_SUFFIX,
+                    merge_prompt_tokens)
+
+
+class LLMSpeechTextInference():
+    def __init__(self, config, audio_encoder_checkpoint, device, *, tokenizer=None, llm: Optional[AudioLlamaForCausalLM] = None,
+                 audio_encoder: Optional[AudioEncoder] = None, dtype: torch.dtype = torch.bfloat16):
+        self.config = config
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.SpeechLLMError("LLMSpeechTextInference runs on the MI355X HIP path only (device must be cuda:N)")
+
+        # Audio encoder (ref:inference.py:24-28): flat state-dict checkpoint, strict load.
+        if audio_encoder is None:
+            checkpoint = audio_encoder_checkpoint
+            if isinstance(checkpoint, str):
+                checkpoint = torch.load(checkpoint, map_location="cpu")
+            audio_encoder = AudioEncoder(self.config, self.device, dtype=dtype)
+            audio_encoder.load_state_dict(checkpoint)
+        self.audio_encoder = audio_encoder.eval().to(self.device)
+
+        # Tokenizer (ref:inference.py:31-37).
+        self.llm_type = self.config.model.llm_type
+        if tokenizer is None:
+            from transformers import AutoTokenizer  # host-side text processing only
+            tokenizer = AutoTokenizer.from_pretrained(self.llm_type, use_fast=False, padding_side="left")
+            tokenizer.pad_token = tokenizer.eos_token
+        self.llm_tokenizer = tokenizer
+
+        if "llama" in self.llm_type.lower():  # ref:inference.py:39-44 (substring test)
+            self.prompt_prefix, self.prompt_suffix = LLAMA_PROMPT_PREFIX, LLAMA_PROMPT_SUFFIX
+        else:
+            self.prompt_prefix, self.prompt_suffix = MINICHAT_PROMPT_PREFIX, MINICHAT_PROMPT_SUFFIX
+
+        # Frozen LLM (ref:inference.py:46-52).
+        if llm is None:
+            llm = AudioLlamaForCausalLM.from_pretrained(self.llm_type, use_cache=True, torch_dtype=dtype)
+        self.llm = llm.eval().to(self.device)
+
+    def generate_llm_response(self, inputs_embeds, max_new_tokens=256) -> List[str]:
+        generate_ids = self.llm.generate(input_ids=None, inputs_embeds=inputs_embeds, max_new_tokens=max_new_tokens)
+        self.last_generate_ids = generate_ids
+        return self.llm_tokenizer.batch_decode(generate_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+
+    def generate_text_response(self, input_text, max_new_tokens=256) -> str:
+        # note the spaces around the user text (ref:inference.py:78)
+        full_text_prompt = f"{self.prompt_prefix} {input_text}{self.prompt_suffix} "
+        prompt_input_ids = self.llm_tokenizer(full_text_prompt, return_tensors='pt').input_ids.to(self.device)
+        prompt_embeds = self.llm.model.embed_tokens(prompt_input_ids)
+        return self.generate_llm_response(inputs_embeds=prompt_embeds, max_new_tokens=max_new_tokens)[0]
+
+    def generate_audio_response(self, audio, additional_text_prompt="", max_new_tokens=256) -> str:
+        audio_tensor = torch.as_tensor(audio, dtype=torch.float32).unsqueeze(0).to(self.device)
+        if self.audio_encoder.downsample_method == "ctc_pool":
+            # the reference calls an undefined self.get_ctc_pool_ranges here
+            raise AttributeError("'LLMSpeechTextInference' object has no attribute 'get_ctc_pool_ranges'")
+        audio_embeds = self.audio_encoder(audio_tensor, ctc_pool_ranges=None)
+
+        if len(additional_text_prompt) > 0:  # text prompt goes before the audio, BOS dropped (ref:inference.py:113-122)
+            additional_text_input_ids = self.llm_tokenizer(additional_text_prompt, return_tensors='pt').input_ids[:, 1:].to(self.device)
+            text_embeds = self.llm.model.embed_tokens(additional_text_input_ids)
+            combined_embeds = torch.cat([text_embeds, audio_embeds], dim=1)
+        else:
+            combined_embeds = audio_embeds
+
+        prompt_emb_sequence = merge_prompt_tokens(inputs_embeds=combined_embeds, tokenizer=self.llm_tokenizer,
+                                                  embed_tokens=self.llm.model.embed_tokens, llm_type=self.llm_type,
+                                                  device=self.device)
+        return self.generate_llm_response(prompt_emb_sequence, max_new_tokens)[0]

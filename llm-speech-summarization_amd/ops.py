@@ -1,0 +1,154 @@
+"""Thin tensor-level wrappers over the per-op C-ABI entry points (used by the kernel parity tests and by
+host code that composes ops outside the whole-model entry points).  Every function launches HIP kernels
+on the current torch stream; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         act: int = L.ACT_NONE, out_f32: bool = False, *, M: Optional[int] = None, K: Optional[int] = None,
+         lda: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = act(A W^T + bias) + residual.  `M/K/lda` override the view for implicit-GEMM convolutions."""
+    L.require_gpu(A, "A"); L.require_gpu(W, "W")
+    N = W.shape[0]
+    K = W.shape[1] if K is None else K
+    M = A.shape[0] if M is None else M
+    lda = A.stride(0) if lda is None else lda
+    n_out = N // 2 if act == L.ACT_SILU_MUL else N
+    if out is None:
+        out = torch.empty((M, n_out), device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
+    a = L.GemmArgs()
+    a.A, a.lda, a.strideA = L.ptr(A), lda, 0
+    a.W, a.ldw, a.strideW = L.ptr(W), W.stride(0), 0
+    a.C, a.ldc, a.strideC = L.ptr(out), out.stride(0), 0
+    a.bias, a.strideBias = L.ptr(bias), 0
+    a.residual, a.ldr, a.strideR = L.ptr(residual), (residual.stride(0) if residual is not None else 0), 0
+    a.M, a.N, a.K, a.batch = M, N, K, 1
+    a.dtype, a.act, a.out_f32 = L.dtype_code(A.dtype), act, int(out_f32)
+    L.check(L.lib().sl_gemm(C.byref(a), L.stream_ptr()), "sl_gemm")
+    return out
+
+
+def gemm_batched(args: "L.GemmArgs") -> None:
+    L.check(L.lib().sl_gemm(C.byref(args), L.stream_ptr()), "sl_gemm")
+
+
+def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float, gelu: bool = False) -> torch.Tensor:
+    L.require_gpu(x, "x")
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    L.check(L.lib().sl_layernorm(L.ptr(x), L.ptr(y), L.ptr(g), L.ptr(b), rows, x.shape[-1], eps, int(gelu),
+                                 L.dtype_code(x.dtype), L.stream_ptr()), "sl_layernorm")
+    return y
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    L.require_gpu(x, "x")
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    L.check(L.lib().sl_rmsnorm(L.ptr(x), L.ptr(y), L.ptr(w), rows, x.shape[-1], eps, L.dtype_code(x.dtype), L.stream_ptr()),
+            "sl_rmsnorm")
+    return y
+
+
+def hubert_conv0(wave: torch.Tensor, w: torch.Tensor, bias, gamma, beta, dtype: torch.dtype, k: int = 10, stride: int = 5,
+                 eps: float = 1e-5) -> torch.Tensor:
+    L.require_gpu(wave, "wave")
+    n = wave.numel()
+    Cout = w.shape[0]
+    Lout = (n - k) // stride + 1
+    out = torch.empty((Lout, Cout), device=wave.device, dtype=dtype)
+    L.check(L.lib().sl_hubert_conv0(L.ptr(wave), n, L.ptr(w), L.ptr(bias), L.ptr(gamma), L.ptr(beta), L.ptr(out), Cout, k, stride,
+                                    eps, L.dtype_code(dtype), L.stream_ptr()), "sl_hubert_conv0")
+    return out
+
+
+def posconv_stage(x: torch.Tensor, groups: int, k: int) -> torch.Tensor:
+    T, H = x.shape
+    xg = torch.empty((groups, T + k, H // groups), device=x.device, dtype=x.dtype)
+    L.check(L.lib().sl_posconv_stage(L.ptr(x), L.ptr(xg), T, H, groups, k, L.dtype_code(x.dtype), L.stream_ptr()), "sl_posconv_stage")
+    return xg
+
+
+def avgpool_rows(x: torch.Tensor, kernel: int = 8, stride: int = 4, ranges: Optional[torch.Tensor] = None) -> torch.Tensor:
+    T, H = x.shape
+    P = ranges.shape[0] if ranges is not None else (T - kernel) // stride + 1
+    y = torch.empty((P, H), device=x.device, dtype=x.dtype)
+    L.check(L.lib().sl_avgpool_rows(L.ptr(x), L.ptr(y), T, H, kernel, stride, L.ptr(ranges), P, L.dtype_code(x.dtype), L.stream_ptr()),
+            "sl_avgpool_rows")
+    return y
+
+
+def embed_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    ids32 = ids.to(device=table.device, dtype=torch.int32).contiguous().view(-1)
+    out = torch.empty((ids32.numel(), table.shape[1]), device=table.device, dtype=table.dtype)
+    L.check(L.lib().sl_embed_gather(L.ptr(table), L.ptr(ids32), L.ptr(out), ids32.numel(), table.shape[1], L.dtype_code(table.dtype),
+                                    L.stream_ptr()), "sl_embed_gather")
+    return out
+
+
+def attn_fwd(q, k, v, out, cu_q, cu_k, klen, *, q_strides, k_strides, v_strides, o_strides, nseq, max_qlen, n_heads, n_kv_heads,
+             head_dim, causal, scale) -> torch.Tensor:
+    a = L.AttnArgs()
+    a.q, a.q_row_stride, a.q_head_stride = L.ptr(q), q_strides[0], q_strides[1]
+    a.k, a.k_row_stride, a.k_head_stride = L.ptr(k), k_strides[0], k_strides[1]
+    a.v, a.v_row_stride, a.v_head_stride = L.ptr(v), v_strides[0], v_strides[1]
+    a.out, a.o_row_stride, a.o_head_stride = L.ptr(out), o_strides[0], o_strides[1]
+    a.cu_q, a.cu_k, a.klen = L.ptr(cu_q), L.ptr(cu_k), L.ptr(klen)
+    a.nseq, a.max_qlen, a.n_heads, a.n_kv_heads = nseq, max_qlen, n_heads, n_kv_heads
+    a.head_dim, a.causal, a.dtype, a.scale = head_dim, int(causal), L.dtype_code(out.dtype), scale
+    L.check(L.lib().sl_attn_fwd(C.byref(a), L.stream_ptr()), "sl_attn_fwd")
+    return out
+
+
+def attn_packed_qkv(qkv: torch.Tensor, seqlens: Sequence[int], n_heads: int, n_kv_heads: int, head_dim: int, causal: bool,
+                    scale: float) -> torch.Tensor:
+    """Attention over a packed fused (tokens, (nh+2nkv)*D) activation (the HuBERT layout)."""
+    dev = qkv.device
+    cu = torch.tensor([0] + list(torch.tensor(seqlens).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+    klen = torch.tensor(list(seqlens), dtype=torch.int32, device=dev)
+    ntok = qkv.shape[0]
+    rs = qkv.stride(0)
+    out = torch.empty((ntok, n_heads * head_dim), device=dev, dtype=qkv.dtype)
+    qv = qkv
+    kv = qkv[:, n_heads * head_dim:]
+    vv = qkv[:, (n_heads + n_kv_heads) * head_dim:]
+    a = L.AttnArgs()
+    a.q, a.q_row_stride, a.q_head_stride = qv.data_ptr(), rs, head_dim
+    a.k, a.k_row_stride, a.k_head_stride = kv.data_ptr(), rs, head_dim
+    a.v, a.v_row_stride, a.v_head_stride = vv.data_ptr(), rs, head_dim
+    a.out, a.o_row_stride, a.o_head_stride = out.data_ptr(), n_heads * head_dim, head_dim
+    a.cu_q, a.cu_k, a.klen = cu.data_ptr(), cu.data_ptr(), klen.data_ptr()
+    a.nseq, a.max_qlen, a.n_heads, a.n_kv_heads = len(seqlens), max(seqlens), n_heads, n_kv_heads
+    a.head_dim, a.causal, a.dtype, a.scale = head_dim, int(causal), L.dtype_code(qkv.dtype), scale
+    L.check(L.lib().sl_attn_fwd(C.byref(a), L.stream_ptr()), "sl_attn_fwd")
+    return out
+
+
+def rope_kv_append(qkv, k_cache, v_cache, tok_seq, tok_pos, cos, sin, n_heads, n_kv, D, max_ctx) -> None:
+    L.check(L.lib().sl_rope_kv_append(L.ptr(qkv), L.ptr(k_cache), L.ptr(v_cache), L.ptr(tok_seq), L.ptr(tok_pos), L.ptr(cos), L.ptr(sin),
+                                      qkv.shape[0], n_heads, n_kv, D, max_ctx, L.dtype_code(qkv.dtype), L.stream_ptr()),
+            "sl_rope_kv_append")
+
+
+def attn_decode(q, q_stride, k_cache, v_cache, ctx_len, n_heads, n_kv, D, max_ctx, scale) -> torch.Tensor:
+    B = ctx_len.shape[0]
+    out = torch.empty((B, n_heads * D), device=q.device, dtype=q.dtype)
+    L.check(L.lib().sl_attn_decode(L.ptr(q), q_stride, L.ptr(k_cache), L.ptr(v_cache), L.ptr(out), L.ptr(ctx_len), B, n_heads, n_kv, D,
+                                   max_ctx, scale, L.dtype_code(q.dtype), L.stream_ptr()), "sl_attn_decode")
+    return out
+
+
+def greedy_select(logits, eos_ids, pad_id, use_eos, unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids) -> None:
+    B, V = logits.shape
+    eos = (C.c_int32 * max(1, len(eos_ids)))(*eos_ids)
+    L.check(L.lib().sl_greedy_select(L.ptr(logits), B, V, eos, len(eos_ids), pad_id, int(use_eos), L.ptr(unfinished), L.ptr(ctx_len),
+                                     L.ptr(gen_count), L.ptr(finish_len), L.ptr(next_ids), L.ptr(out_ids), out_ids.shape[1],
+                                     L.stream_ptr()), "sl_greedy_select")

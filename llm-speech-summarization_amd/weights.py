@@ -1,0 +1,275 @@
+"""State-dict -> device weight tables for libspeechllm.
+
+Accepts the checkpoints the reference consumes:
+  * AudioEncoder: flat state-dict (ref:inference.py:24-26) or `{"audio_encoder": ...}` (ref:trainer.py:516-528),
+    weight-norm keys in either spelling (`weight_g/weight_v` | `parametrizations.weight.original0/1`);
+  * LLM: HF LlamaForCausalLM state-dict (ref:inference.py:47-52).
+and lays the tensors out for the HIP kernels (layout notes in include/speechllm.h):
+  conv i>=1  (C_out, C_in, k) -> (C_out, k*C_in) tap-major      (implicit GEMM over channel-last rows)
+  pos-conv   weight-norm folded, (H, H/g, k) -> (g, H/g, k*H/g)
+  q/k/v      fused into one (3H | (nh+2nkv)D, H) matrix
+  gate/up    fused in 16-row interleaved blocks so silu(gate)*up is a GEMM epilogue
+  RoPE       cos/sin tables computed on the host exactly as hf:models/llama/modeling_llama.py:110-127
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+# ------------------------------------------------------------------------------------------------
+# architecture descriptions (what HF's config.json carries for the two model families)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class HubertArch:
+    conv_dim: Tuple[int, ...] = (512,) * 7
+    conv_kernel: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    hidden_size: int = 1024
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    intermediate_size: int = 4096
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+
+    def num_frames(self, n: int) -> int:
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            n = (n - k) // s + 1
+        return n
+
+    @staticmethod
+    def from_hf_config(d: dict) -> "HubertArch":
+        if d.get("feat_extract_norm", "layer") != "layer" or not d.get("do_stable_layer_norm", True):
+            raise L.SpeechLLMError("only the layer-norm / stable-layer-norm HuBERT variant (hubert-large) is built")
+        return HubertArch(tuple(d["conv_dim"]), tuple(d["conv_kernel"]), tuple(d["conv_stride"]), d["hidden_size"],
+                          d["num_hidden_layers"], d["num_attention_heads"], d["intermediate_size"],
+                          d["num_conv_pos_embeddings"], d["num_conv_pos_embedding_groups"], d.get("layer_norm_eps", 1e-5))
+
+
+@dataclass
+class LlamaArch:
+    hidden_size: int = 3072
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 24
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    intermediate_size: int = 8192
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: Optional[dict] = None
+    tie_word_embeddings: bool = True
+    eos_token_ids: Tuple[int, ...] = (128001, 128008, 128009)
+    pad_token_id: Optional[int] = None
+    bos_token_id: Optional[int] = 128000
+
+    @staticmethod
+    def from_hf_config(d: dict) -> "LlamaArch":
+        rs = d.get("rope_scaling") or d.get("rope_parameters")
+        theta = d.get("rope_theta", (rs or {}).get("rope_theta", 10000.0))
+        scaling = None
+        if rs and rs.get("rope_type", rs.get("type", "default")) == "llama3":
+            scaling = {k: rs[k] for k in ("factor", "low_freq_factor", "high_freq_factor", "original_max_position_embeddings")}
+        elif rs and rs.get("rope_type", rs.get("type", "default")) not in ("default", None):
+            raise L.SpeechLLMError(f"rope type {rs.get('rope_type')} not built (default, llama3)")
+        eos = d.get("eos_token_id", 2)
+        eos = tuple(eos) if isinstance(eos, (list, tuple)) else (eos,)
+        nh = d["num_attention_heads"]
+        return LlamaArch(d["hidden_size"], d["num_hidden_layers"], nh, d.get("num_key_value_heads", nh),
+                         d.get("head_dim") or d["hidden_size"] // nh, d["intermediate_size"], d["vocab_size"],
+                         d.get("rms_norm_eps", 1e-6), theta, scaling, d.get("tie_word_embeddings", False), eos,
+                         d.get("pad_token_id"), d.get("bos_token_id"))
+
+
+KNOWN_HUBERT = {"facebook/hubert-large-ls960-ft": HubertArch(), "facebook/hubert-large-ll60k": HubertArch()}
+KNOWN_LLAMA = {
+    "meta-llama/Llama-3.2-3B-Instruct": LlamaArch(
+        rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)),
+    "GeneZC/MiniChat-2-3B": LlamaArch(hidden_size=3072, num_hidden_layers=24, num_attention_heads=24, num_key_value_heads=24,
+                                      head_dim=128, intermediate_size=8192, vocab_size=49216, rms_norm_eps=1e-5,
+                                      rope_theta=10000.0, rope_scaling=None, tie_word_embeddings=False, eos_token_ids=(2,),
+                                      pad_token_id=None, bos_token_id=1),
+}
+
+
+# ------------------------------------------------------------------------------------------------
+# RoPE tables (host, fp32) — hf:modeling_rope_utils.py:636-660, hf:models/llama/modeling_llama.py:110-127
+# ------------------------------------------------------------------------------------------------
+def rope_inv_freq(a: LlamaArch) -> torch.Tensor:
+    dim = a.head_dim
+    inv_freq = 1.0 / (a.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).to(torch.float) / dim))
+    if a.rope_scaling is None:
+        return inv_freq
+    factor, low, high = a.rope_scaling["factor"], a.rope_scaling["low_freq_factor"], a.rope_scaling["high_freq_factor"]
+    old_len = a.rope_scaling["original_max_position_embeddings"]
+    low_wl, high_wl = old_len / low, old_len / high
+    wavelen = 2 * math.pi / inv_freq
+    inv_l = torch.where(wavelen > low_wl, inv_freq / factor, inv_freq)
+    smooth = (old_len / wavelen - low) / (high - low)
+    smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+    medium = ~(wavelen < high_wl) * ~(wavelen > low_wl)
+    return torch.where(medium, smoothed, inv_l)
+
+
+def rope_tables(a: LlamaArch, length: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    freqs = torch.arange(length, dtype=torch.float32)[:, None] * rope_inv_freq(a)[None, :]
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# HuBERT / AudioEncoder
+# ------------------------------------------------------------------------------------------------
+def normalize_encoder_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    if "audio_encoder" in sd and isinstance(sd["audio_encoder"], dict):
+        sd = sd["audio_encoder"]
+    return sd
+
+
+def fold_pos_conv_weight(sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    if prefix + "parametrizations.weight.original0" in sd:
+        g, v = sd[prefix + "parametrizations.weight.original0"], sd[prefix + "parametrizations.weight.original1"]
+    elif prefix + "weight_g" in sd:
+        g, v = sd[prefix + "weight_g"], sd[prefix + "weight_v"]
+    else:
+        return sd[prefix + "weight"].float()
+    g, v = g.float(), v.float()
+    return v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+
+
+class HubertDeviceWeights:
+    """Owns the device tensors and the sl_hubert_model struct that points at them."""
+
+    def __init__(self, arch: HubertArch, sd: Dict[str, torch.Tensor], llm_dim: int, device, dtype: torch.dtype,
+                 pool_kernel: int = 8, pool_stride: int = 4, downsample: str = "pool"):
+        sd = normalize_encoder_state_dict(sd)
+        self.arch, self.dtype, self.device, self.llm_dim = arch, dtype, device, llm_dim
+        self._keep: List[torch.Tensor] = []
+        H, G, kpos = arch.hidden_size, arch.num_conv_pos_embedding_groups, arch.num_conv_pos_embeddings
+        if H // arch.num_attention_heads != 64:
+            raise L.SpeechLLMError("HuBERT head_dim must be 64 for the built attention kernel")
+
+        def dev(t: torch.Tensor, dt=None) -> torch.Tensor:
+            t = t.detach().to(device=device, dtype=dt or dtype).contiguous()
+            self._keep.append(t)
+            return t
+
+        m = L.HubertModel()
+        m.dtype = L.dtype_code(dtype)
+        m.n_conv, m.hidden, m.n_layers = len(arch.conv_dim), H, arch.num_hidden_layers
+        m.n_heads, m.ffn, m.pos_k, m.pos_groups = arch.num_attention_heads, arch.intermediate_size, kpos, G
+        for i in range(m.n_conv):
+            m.conv_dim[i], m.conv_kernel[i], m.conv_stride[i] = arch.conv_dim[i], arch.conv_kernel[i], arch.conv_stride[i]
+        m.ln_eps, m.pool_kernel, m.pool_stride, m.llm_dim = arch.layer_norm_eps, pool_kernel, pool_stride, llm_dim
+        p = "encoder.feature_extractor.conv_layers."
+        m.conv0_w = dev(sd[p + "0.conv.weight"].reshape(arch.conv_dim[0], -1), torch.float32).data_ptr()
+        m.conv0_b = dev(sd[p + "0.conv.bias"], torch.float32).data_ptr()
+        m.conv0_g = dev(sd[p + "0.layer_norm.weight"], torch.float32).data_ptr()
+        m.conv0_beta = dev(sd[p + "0.layer_norm.bias"], torch.float32).data_ptr()
+        for i in range(1, m.n_conv):
+            w = sd[p + f"{i}.conv.weight"]  # (Cout, Cin, k) -> (Cout, k, Cin) -> (Cout, k*Cin)
+            m.conv_w[i] = dev(w.permute(0, 2, 1).reshape(w.shape[0], -1)).data_ptr()
+            m.conv_b[i] = dev(sd[p + f"{i}.conv.bias"]).data_ptr()
+            m.conv_g[i] = dev(sd[p + f"{i}.layer_norm.weight"]).data_ptr()
+            m.conv_beta[i] = dev(sd[p + f"{i}.layer_norm.bias"]).data_ptr()
+        p = "encoder.feature_projection."
+        m.fp_ln_g, m.fp_ln_b = dev(sd[p + "layer_norm.weight"]).data_ptr(), dev(sd[p + "layer_norm.bias"]).data_ptr()
+        m.fp_w, m.fp_b = dev(sd[p + "projection.weight"]).data_ptr(), dev(sd[p + "projection.bias"]).data_ptr()
+        p = "encoder.encoder.pos_conv_embed.conv."
+        wpos = fold_pos_conv_weight(sd, p)  # (H, H/G, k): out, cin, tap
+        Hg = H // G
+        m.pos_w = dev(wpos.permute(0, 2, 1).reshape(G, Hg, kpos * Hg)).data_ptr()
+        m.pos_b = dev(sd[p + "bias"]).data_ptr()
+        self._layers = (L.HubertLayer * arch.num_hidden_layers)()
+        for li in range(arch.num_hidden_layers):
+            p = f"encoder.encoder.layers.{li}."
+            a = p + "attention."
+            lay = self._layers[li]
+            lay.ln1_g, lay.ln1_b = dev(sd[p + "layer_norm.weight"]).data_ptr(), dev(sd[p + "layer_norm.bias"]).data_ptr()
+            lay.wqkv = dev(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0)).data_ptr()
+            lay.bqkv = dev(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0)).data_ptr()
+            lay.wo, lay.bo = dev(sd[a + "out_proj.weight"]).data_ptr(), dev(sd[a + "out_proj.bias"]).data_ptr()
+            lay.ln2_g = dev(sd[p + "final_layer_norm.weight"]).data_ptr()
+            lay.ln2_b = dev(sd[p + "final_layer_norm.bias"]).data_ptr()
+            f = p + "feed_forward."
+            lay.w1, lay.b1 = dev(sd[f + "intermediate_dense.weight"]).data_ptr(), dev(sd[f + "intermediate_dense.bias"]).data_ptr()
+            lay.w2, lay.b2 = dev(sd[f + "output_dense.weight"]).data_ptr(), dev(sd[f + "output_dense.bias"]).data_ptr()
+        m.layers = C.cast(self._layers, C.POINTER(L.HubertLayer))
+        m.final_ln_g = dev(sd["encoder.encoder.layer_norm.weight"]).data_ptr()
+        m.final_ln_b = dev(sd["encoder.encoder.layer_norm.bias"]).data_ptr()
+        self.proj_w = dev(sd["embed_projection.weight"])
+        self.proj_b = dev(sd["embed_projection.bias"])
+        if downsample == "pool":
+            m.proj_w, m.proj_b = self.proj_w.data_ptr(), self.proj_b.data_ptr()
+        else:  # stack / ctc_pool: the host composes the downsample from ops on last_hidden
+            m.proj_w, m.proj_b = None, None
+        self.struct = m
+
+    def n_params(self) -> int:
+        return sum(t.numel() for t in self._keep)
+
+
+# ------------------------------------------------------------------------------------------------
+# Llama
+# ------------------------------------------------------------------------------------------------
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """(F,H),(F,H) -> (2F,H) in blocks of 16 gate rows then 16 up rows (SL_ACT_SILU_MUL layout)."""
+    F_, H = gate.shape
+    if F_ % 16:
+        raise L.SpeechLLMError("intermediate_size must be a multiple of 16")
+    return torch.stack([gate.reshape(F_ // 16, 16, H), up.reshape(F_ // 16, 16, H)], dim=1).reshape(2 * F_, H)
+
+
+class LlamaDeviceWeights:
+    def __init__(self, arch: LlamaArch, sd: Dict[str, torch.Tensor], device, dtype: torch.dtype, rope_len: int = 8192):
+        self.arch, self.dtype, self.device = arch, dtype, device
+        self._keep: List[torch.Tensor] = []
+        if arch.head_dim != 128:
+            raise L.SpeechLLMError("Llama head_dim must be 128 for the built attention kernels")
+
+        def dev(t: torch.Tensor, dt=None) -> torch.Tensor:
+            t = t.detach().to(device=device, dtype=dt or dtype).contiguous()
+            self._keep.append(t)
+            return t
+
+        m = L.LlamaModel()
+        m.dtype = L.dtype_code(dtype)
+        m.hidden, m.n_layers, m.n_heads, m.n_kv_heads = arch.hidden_size, arch.num_hidden_layers, arch.num_attention_heads, arch.num_key_value_heads
+        m.head_dim, m.ffn, m.vocab, m.rms_eps, m.rope_len = arch.head_dim, arch.intermediate_size, arch.vocab_size, arch.rms_norm_eps, rope_len
+        self.embed = dev(sd["model.embed_tokens.weight"])
+        m.embed = self.embed.data_ptr()
+        self.lm_head = dev(sd["lm_head.weight"]) if "lm_head.weight" in sd and not arch.tie_word_embeddings else self.embed
+        m.lm_head = self.lm_head.data_ptr()
+        m.final_norm = dev(sd["model.norm.weight"]).data_ptr()
+        cos, sin = rope_tables(arch, rope_len)
+        m.rope_cos, m.rope_sin = dev(cos, torch.float32).data_ptr(), dev(sin, torch.float32).data_ptr()
+        self._layers = (L.LlamaLayer * arch.num_hidden_layers)()
+        for li in range(arch.num_hidden_layers):
+            p = f"model.layers.{li}."
+            lay = self._layers[li]
+            lay.norm1 = dev(sd[p + "input_layernorm.weight"]).data_ptr()
+            lay.wqkv = dev(torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"],
+                                      sd[p + "self_attn.v_proj.weight"]], 0)).data_ptr()
+            lay.wo = dev(sd[p + "self_attn.o_proj.weight"]).data_ptr()
+            lay.norm2 = dev(sd[p + "post_attention_layernorm.weight"]).data_ptr()
+            lay.wgu = dev(interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"])).data_ptr()
+            lay.wdown = dev(sd[p + "mlp.down_proj.weight"]).data_ptr()
+        m.layers = C.cast(self._layers, C.POINTER(L.LlamaLayer))
+        self.struct = m
+
+    def n_params(self) -> int:
+        return sum(t.numel() for t in self._keep if t.dtype == self.dtype)
+
+    def weight_bytes_per_token(self) -> int:
+        """Bytes of weights one decode step streams: every layer matrix + final norm + lm_head."""
+        a = self.arch
+        per_layer = (a.num_attention_heads + 2 * a.num_key_value_heads) * a.head_dim * a.hidden_size \
+            + a.num_attention_heads * a.head_dim * a.hidden_size + 3 * a.intermediate_size * a.hidden_size + 2 * a.hidden_size
+        total = per_layer * a.num_hidden_layers + a.hidden_size + a.vocab_size * a.hidden_size
+        return total * (2 if self.dtype == torch.bfloat16 else 4)

@@ -141,8 +141,10 @@ def gen_encoder(enc_mod):
     for n in (16000, 32000):
         wave = ri.synthetic_waveform(n, seed=1234 + n)[None]
         out = m(wave)
+        keep = taps if n == 16000 else {k: taps[k] for k in ("conv6", "feature_projection", "layer0", "layer1",
+                                                             "last_hidden_state")}
         save(f"enc_tiny_pool_{n}", n_samples=n, wave_seed=1234 + n, weight_seed=11, audio_embeds=out,
-             **{k: v for k, v in taps.items()})
+             **{k: v for k, v in keep.items()})
     # stack (T%4 != 0 -> parity; T%4 == 0 -> reference returns empty, quirk Q5) and ctc_pool
     m, _ = build_ref_encoder(enc_mod, TINY_HUBERT, 256, seed=12, method="stack")
     for n in (16000, 16720):  # T = 49 (49%4=1) and T = 52 (52%4=0)

@@ -10,7 +10,7 @@ from oracle.llama_oracle import LlamaCfg
 LLAMA_ID = "meta-llama/Llama-3.2-3B-Instruct"
 MINICHAT_ID = "GeneZC/MiniChat-2-3B"
 
-TINY_HUBERT = HubertCfg(conv_dim=(32,) * 7, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+TINY_HUBERT = HubertCfg(conv_dim=(64,) * 7, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
                         intermediate_size=256, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
 WIDE_HUBERT = HubertCfg(num_hidden_layers=2)  # full HuBERT-large width, 2 layers
 TINY_LLAMA = LlamaCfg(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,

@@ -1,0 +1,277 @@
+"""GPU: each HIP kernel, called through the C ABI, against a plain PyTorch fp32 reference of the same op.
+
+Tolerances (relative L2): fp32 mode 2e-5 (exact-fp32 MFMA, only summation order differs); bf16 mode
+1.5e-2 with both sides fed the same bf16-rounded inputs (differences = bf16 rounding of the output and
+of P in attention).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+L = pkg("_lib")
+ops = pkg("ops")
+weights = pkg("weights")
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * std
+
+
+def q(x, dt):
+    """value seen by the kernel: rounded to the storage dtype, back in fp32 for the reference."""
+    return x.to(dt).float()
+
+
+def test_library_loads_and_reports_gfx950():
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    L.check(L.lib().sl_device_arch(buf, 64))
+    assert buf.value.decode().startswith("gfx950"), buf.value
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(499, 1024, 1024), (130, 96, 192), (128, 128, 64), (257, 3072, 1024), (1000, 512, 1536)])
+def test_gemm_tiled_bias_gelu_residual(dt, M, N, K):
+    A, W, b, R = rnd(M, K, seed=1), rnd(N, K, seed=2, std=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = F.gelu(q(A, dt) @ q(W, dt).T + q(b, dt)) + q(R, dt)
+    out = ops.gemm(A.to(dev(), dt), W.to(dev(), dt), bias=b.to(dev(), dt), residual=R.to(dev(), dt), act=L.ACT_GELU)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+    ref2 = q(A, dt) @ q(W, dt).T
+    out2 = ops.gemm(A.to(dev(), dt), W.to(dev(), dt), out_f32=True)
+    assert out2.dtype == torch.float32
+    assert rel_err(out2.cpu(), ref2) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [1, 3, 16, 17, 32, 50, 64])
+@pytest.mark.parametrize("N,K", [(3072, 3072), (160, 8192), (1000, 256), (48, 40)])
+def test_gemm_skinny(dt, M, N, K):
+    if dt == torch.float32 and K % 4 or dt == torch.bfloat16 and K % 8:
+        pytest.skip("K alignment")
+    A, W, R = rnd(M, K, seed=5), rnd(N, K, seed=6, std=K ** -0.5), rnd(M, N, seed=7)
+    ref = q(A, dt) @ q(W, dt).T + q(R, dt)
+    out = ops.gemm(A.to(dev(), dt), W.to(dev(), dt), residual=R.to(dev(), dt))
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+    out32 = ops.gemm(A.to(dev(), dt), W.to(dev(), dt), out_f32=True)
+    assert rel_err(out32.cpu(), q(A, dt) @ q(W, dt).T) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [5, 137, 300])
+def test_gemm_silu_mul_interleaved(dt, M):
+    H, Fd = 256, 512
+    x, g, u = rnd(M, H, seed=8), rnd(Fd, H, seed=9, std=H ** -0.5), rnd(Fd, H, seed=10, std=H ** -0.5)
+    wgu = weights.interleave_gate_up(g, u)
+    ref = F.silu(q(x, dt) @ q(g, dt).T) * (q(x, dt) @ q(u, dt).T)
+    out = ops.gemm(x.to(dev(), dt), wgu.to(dev(), dt), act=L.ACT_SILU_MUL)
+    assert out.shape == (M, Fd)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_implicit_conv_overlapping_rows(dt):
+    """Conv1d(C->C2, k=3, s=2) on channel-last rows as a GEMM with lda = s*C < K = k*C."""
+    Lin, Cc, C2, k, s = 401, 64, 96, 3, 2
+    x, w, b = rnd(Lin, Cc, seed=11), rnd(C2, Cc, k, seed=12, std=(Cc * k) ** -0.5), rnd(C2, seed=13)
+    ref = F.conv1d(q(x, dt).T[None], q(w, dt), q(b, dt), stride=s)[0].T
+    Lo = (Lin - k) // s + 1
+    wt = w.permute(0, 2, 1).reshape(C2, k * Cc).contiguous()
+    out = ops.gemm(x.to(dev(), dt), wt.to(dev(), dt), bias=b.to(dev(), dt), M=Lo, K=k * Cc, lda=s * Cc)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cols", [512, 1024, 3072, 128])
+def test_layernorm_and_rmsnorm(dt, cols):
+    x, g, b = rnd(77, cols, seed=14), 1 + rnd(cols, seed=15, std=0.1), rnd(cols, seed=16, std=0.1)
+    xd, gd, bd = x.to(dev(), dt), g.to(dev(), dt), b.to(dev(), dt)
+    ref = F.layer_norm(q(x, dt), (cols,), q(g, dt), q(b, dt), 1e-5)
+    assert rel_err(ops.layernorm(xd, gd, bd, 1e-5).float().cpu(), ref) < TOL[dt]
+    assert rel_err(ops.layernorm(xd, gd, bd, 1e-5, gelu=True).float().cpu(), F.gelu(ref)) < TOL[dt]
+    xf = q(x, dt)
+    ref = q(g, dt) * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert rel_err(ops.rmsnorm(xd, gd, 1e-5).float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Cc,n", [(512, 16000), (64, 4000), (512, 407)])
+def test_hubert_conv0_fused(dt, Cc, n):
+    wave = rnd(n, seed=17, std=0.1)
+    w, b, g, be = rnd(Cc, 1, 10, seed=18, std=0.4), rnd(Cc, seed=19, std=0.1), 1 + rnd(Cc, seed=20, std=0.1), rnd(Cc, seed=21, std=0.1)
+    y = F.conv1d(wave[None, None], w, b, stride=5)[0].T
+    ref = F.gelu(F.layer_norm(y, (Cc,), g, be, 1e-5))
+    out = ops.hubert_conv0(wave.to(dev()), w.reshape(Cc, 10).to(dev()), b.to(dev()), g.to(dev()), be.to(dev()), dt)
+    assert out.shape == ref.shape
+    assert rel_err(out.float().cpu(), ref) < (1e-5 if dt == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_posconv_stage_and_grouped_conv(dt):
+    import ctypes as C
+    T, H, G, k = 131, 256, 4, 16
+    Hg = H // G
+    x, w, b = rnd(T, H, seed=22), rnd(H, Hg, k, seed=23, std=(Hg * k) ** -0.5), rnd(H, seed=24, std=0.1)
+    pos = F.conv1d(q(x, dt).T[None], q(w, dt), q(b, dt), padding=k // 2, groups=G)[0][:, :-1].T
+    ref = q(x, dt) + F.gelu(pos)
+    xd = x.to(dev(), dt)
+    xg = ops.posconv_stage(xd, G, k)
+    assert xg.shape == (G, T + k, Hg)
+    assert torch.equal(xg[:, k // 2:k // 2 + T].permute(1, 0, 2).reshape(T, H), xd) and float(xg[:, :k // 2].abs().max()) == 0
+    wd = w.permute(0, 2, 1).reshape(G, Hg, k * Hg).contiguous().to(dev(), dt)
+    bd = b.to(dev(), dt)
+    out = torch.empty_like(xd)
+    a = L.GemmArgs()
+    a.A, a.lda, a.strideA = xg.data_ptr(), Hg, (T + k) * Hg
+    a.W, a.ldw, a.strideW = wd.data_ptr(), k * Hg, Hg * k * Hg
+    a.C, a.ldc, a.strideC = out.data_ptr(), H, Hg
+    a.bias, a.strideBias = bd.data_ptr(), Hg
+    a.residual, a.ldr, a.strideR = xd.data_ptr(), H, Hg
+    a.M, a.N, a.K, a.batch, a.dtype, a.act = T, Hg, k * Hg, G, L.dtype_code(dt), L.ACT_GELU
+    ops.gemm_batched(a)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_avgpool_rows_and_ranges(dt):
+    x = rnd(49, 128, seed=25)
+    xd = x.to(dev(), dt)
+    ref = F.avg_pool1d(q(x, dt).T[None], 8, 4)[0].T
+    assert rel_err(ops.avgpool_rows(xd, 8, 4).float().cpu(), ref) < TOL[dt]
+    ranges = [(0, 3), (3, 4), (4, 11), (11, 30), (30, 49)]
+    ref = torch.stack([q(x, dt)[s:e].mean(0) for s, e in ranges])
+    r = torch.tensor(ranges, dtype=torch.int32, device=dev())
+    assert rel_err(ops.avgpool_rows(xd, ranges=r).float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_embed_gather(dt):
+    table = rnd(1000, 256, seed=26).to(dev(), dt)
+    ids = torch.tensor([[0, 999, 5, 5, 123]])
+    assert torch.equal(ops.embed_gather(table, ids), table[ids.view(-1).to(dev())])
+
+
+def ref_attention(qh, kh, vh, causal, scale, dt):
+    """qh (nh,Sq,D) kh/vh (nkv,Sk,D) fp32 -> (Sq, nh*D); softmax fp32; P rounded to dt like the kernel."""
+    nh, Sq, D = qh.shape
+    nkv, Sk, _ = kh.shape
+    rep = nh // nkv
+    kr, vr = kh.repeat_interleave(rep, 0), vh.repeat_interleave(rep, 0)
+    s = qh @ kr.transpose(1, 2) * scale
+    if causal:
+        i = torch.arange(Sq)[:, None] + (Sk - Sq)
+        s = s.masked_fill(torch.arange(Sk)[None, :] > i, float("-inf"))
+    p = F.softmax(s, dim=-1)
+    return (p @ vr).transpose(0, 1).reshape(Sq, nh * D)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("seqlens", [[499], [64], [1, 63, 65, 200], [130, 17]])
+def test_attention_noncausal_d64_varlen(dt, seqlens):
+    nh, D = 4, 64
+    ntok = sum(seqlens)
+    qkv = rnd(ntok, 3 * nh * D, seed=27)
+    out = ops.attn_packed_qkv(qkv.to(dev(), dt), seqlens, nh, nh, D, False, D ** -0.5).float().cpu()
+    t0 = 0
+    for n in seqlens:
+        blk = q(qkv[t0:t0 + n], dt).view(n, 3, nh, D)
+        ref = ref_attention(blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1), False, D ** -0.5, dt)
+        assert rel_err(out[t0:t0 + n], ref) < TOL[dt], n
+        t0 += n
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("seqlens", [[137], [5, 64, 129], [300]])
+@pytest.mark.parametrize("nh,nkv", [(6, 2), (2, 2)])
+def test_attention_causal_gqa_d128(dt, seqlens, nh, nkv):
+    D = 128
+    ntok = sum(seqlens)
+    qkv = rnd(ntok, (nh + 2 * nkv) * D, seed=28)
+    out = ops.attn_packed_qkv(qkv.to(dev(), dt), seqlens, nh, nkv, D, True, D ** -0.5).float().cpu()
+    t0 = 0
+    for n in seqlens:
+        blk = q(qkv[t0:t0 + n], dt)
+        qh = blk[:, :nh * D].view(n, nh, D).transpose(0, 1)
+        kh = blk[:, nh * D:(nh + nkv) * D].view(n, nkv, D).transpose(0, 1)
+        vh = blk[:, (nh + nkv) * D:].view(n, nkv, D).transpose(0, 1)
+        assert rel_err(out[t0:t0 + n], ref_attention(qh, kh, vh, True, D ** -0.5, dt)) < TOL[dt], n
+        t0 += n
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_rope_kv_append_and_decode_attention(dt):
+    arch = weights.LlamaArch(hidden_size=256, num_attention_heads=6, num_key_value_heads=2, head_dim=128,
+                             rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                               original_max_position_embeddings=8192))
+    nh, nkv, D, max_ctx, B = 6, 2, 128, 96, 3
+    cos, sin = weights.rope_tables(arch, max_ctx)
+    lens = [70, 1, 33]  # tokens already in the cache per sequence (prefill), then one decode token each
+    ntok = sum(lens)
+    qkv = rnd(ntok, (nh + 2 * nkv) * D, seed=29)
+    tok_seq = torch.tensor(sum([[s] * n for s, n in enumerate(lens)], []), dtype=torch.int32)
+    tok_pos = torch.tensor(sum([list(range(n)) for n in lens], []), dtype=torch.int32)
+    kc = torch.zeros(B, nkv, max_ctx, D, device=dev(), dtype=dt)
+    vc = torch.zeros_like(kc)
+    qd = qkv.to(dev(), dt)
+    ops.rope_kv_append(qd, kc, vc, tok_seq.to(dev()), tok_pos.to(dev()), cos.to(dev()), sin.to(dev()), nh, nkv, D, max_ctx)
+
+    def rope(x, pos):  # x (n, heads, D) fp32
+        c = torch.cat([cos[pos], cos[pos]], -1)[:, None]
+        s = torch.cat([sin[pos], sin[pos]], -1)[:, None]
+        x1, x2 = x[..., :D // 2], x[..., D // 2:]
+        return x * c + torch.cat([-x2, x1], -1) * s
+
+    qf = q(qkv, dt)
+    q_ref = rope(qf[:, :nh * D].view(ntok, nh, D), tok_pos.long())
+    k_ref = rope(qf[:, nh * D:(nh + nkv) * D].view(ntok, nkv, D), tok_pos.long())
+    v_ref = qf[:, (nh + nkv) * D:].view(ntok, nkv, D)
+    tol = 1e-6 if dt == torch.float32 else 6e-3
+    assert rel_err(qd[:, :nh * D].float().cpu().view(ntok, nh, D), q_ref) < tol
+    t0 = 0
+    for s, n in enumerate(lens):
+        assert rel_err(kc[s, :, :n].float().cpu(), k_ref[t0:t0 + n].transpose(0, 1)) < tol
+        assert torch.equal(vc[s, :, :n].float().cpu(), v_ref[t0:t0 + n].transpose(0, 1))
+        t0 += n
+    # decode attention: query = last prefill token of each sequence, attends its whole context
+    last = torch.tensor([sum(lens[:i + 1]) - 1 for i in range(B)])
+    qlast = qd[last.to(dev())].contiguous()
+    ctx = torch.tensor(lens, dtype=torch.int32, device=dev())
+    out = ops.attn_decode(qlast, qlast.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    for s, n in enumerate(lens):
+        qh = qlast[s, :nh * D].float().cpu().view(nh, 1, D)
+        ref = ref_attention(qh, kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
+        assert rel_err(out[s], ref[0]) < TOL[dt]
+
+
+def test_greedy_select_semantics():
+    B, V, max_new = 4, 5000, 6
+    logits = rnd(B, V, seed=30)
+    logits[0, 777] = 50.0
+    logits[1, 10] = 60.0; logits[1, 4000] = 60.0   # tie -> lowest index
+    logits[2, 7] = 70.0                             # eos id
+    logits[3, 1234] = 80.0                          # row already finished -> pad
+    ld = logits.to(dev())
+    unfinished = torch.tensor([1, 1, 1, 0], dtype=torch.int32, device=dev())
+    ctx = torch.tensor([5, 6, 7, 8], dtype=torch.int32, device=dev())
+    gen = torch.tensor([0, 1, 2, 3], dtype=torch.int32, device=dev())
+    fin = torch.zeros(B, dtype=torch.int32, device=dev())
+    nxt = torch.zeros(B, dtype=torch.int32, device=dev())
+    out = torch.full((B, max_new), -1, dtype=torch.int32, device=dev())
+    ops.greedy_select(ld, [7, 9], 99, True, unfinished, ctx, gen, fin, nxt, out)
+    assert nxt.tolist() == [777, 10, 7, 99]
+    assert unfinished.tolist() == [1, 1, 0, 0]
+    assert ctx.tolist() == [6, 7, 8, 9] and gen.tolist() == [1, 2, 3, 4] and fin.tolist() == [0, 0, 3, 0]
+    assert out[0, 0] == 777 and out[1, 1] == 10 and out[2, 2] == 7 and out[3, 3] == 99

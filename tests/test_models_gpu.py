@@ -1,0 +1,216 @@
+"""GPU: whole-model parity of the HIP path (through the C ABI and the host mirrors of the reference
+classes) against the golden fixtures generated from the reference and against the CPU oracle.
+
+fp32 mode: hidden states <= 1e-4 relative L2 vs the reference fixtures, greedy ids IDENTICAL.
+bf16 mode: weights rounded to bf16 on both sides; hidden states <= 3e-2 relative L2 (stated tolerance).
+"""
+import pytest
+import torch
+
+from conftest import golden, pkg, rel_err, t
+from oracle import hubert_oracle as ho
+from oracle import kd_oracle as ko
+from oracle import llama_oracle as lo
+from oracle.golden_cfgs import TINY_HUBERT, TINY_LLAMA, TINY_MHA, WIDE_HUBERT, WIDE_LLAMA
+
+pytestmark = pytest.mark.gpu
+
+ri = pkg("random_init")
+cfgm = pkg("config")
+enc_mod = pkg("audio_encoder")
+llama_mod = pkg("audio_llama")
+weights = pkg("weights")
+inf_mod = pkg("inference")
+utils = pkg("utils")
+
+DEV = "cuda:0"
+F32_TOL, BF16_TOL = 1e-4, 3e-2
+
+
+def hubert_arch(c):
+    return weights.HubertArch(c.conv_dim, c.conv_kernel, c.conv_stride, c.hidden_size, c.num_hidden_layers,
+                              c.num_attention_heads, c.intermediate_size, c.num_conv_pos_embeddings,
+                              c.num_conv_pos_embedding_groups, c.layer_norm_eps)
+
+
+def llama_arch(c):
+    return weights.LlamaArch(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, c.head_dim,
+                             c.intermediate_size, c.vocab_size, c.rms_norm_eps, c.rope_theta, c.rope_scaling,
+                             c.tie_word_embeddings, tuple(c.eos_token_ids), c.pad_token_id)
+
+
+def make_encoder(c, llm_dim, seed, dtype, method="pool", **sdkw):
+    conf = cfgm.from_dict(dict(model=dict(audio_encoder=dict(base="hubert", type="synthetic", downsample_method=method,
+                                                             downsample_factor=4, pooling=dict(kernel_size=8, stride=4)),
+                                          llm_embedding_channels=llm_dim, llm_type=utils.LLAMA_ID)))
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=dtype, arch=hubert_arch(c))
+    sd = ri.hubert_encoder_state_dict(c, llm_dim, seed=seed, downsample=method, **sdkw)
+    enc.load_state_dict(sd)
+    return enc.eval().to(DEV), sd
+
+
+def make_llama(c, seed, dtype, max_ctx=256):
+    sd = ri.llama_state_dict(c, seed=seed)
+    llm = llama_mod.AudioLlamaForCausalLM(llama_arch(c), dict(sd), torch_dtype=dtype, device=DEV, max_ctx=max_ctx)
+    return llm, sd
+
+
+@pytest.mark.parametrize("n", [16000, 32000])
+def test_encoder_tiny_fp32_vs_reference_fixture(n):
+    g = golden(f"enc_tiny_pool_{n}")
+    enc, _ = make_encoder(TINY_HUBERT, 256, int(g["weight_seed"]), torch.float32)
+    wave = ri.synthetic_waveform(n, seed=int(g["wave_seed"]))
+    out, P, last_hidden, T = enc.encode_packed([wave], want_last_hidden=True)
+    assert T[0] == TINY_HUBERT.num_frames(n) and P[0] == g["audio_embeds"].shape[1]
+    assert rel_err(last_hidden.cpu(), t(g["last_hidden_state"])[0]) < F32_TOL
+    assert rel_err(out.cpu(), t(g["audio_embeds"])[0]) < F32_TOL
+    assert rel_err(enc(wave[None].to(DEV)).cpu(), t(g["audio_embeds"])) < F32_TOL
+
+
+def test_encoder_weight_norm_legacy_keys_and_nested_checkpoint():
+    g = golden("enc_tiny_pool_16000")
+    enc, sd = make_encoder(TINY_HUBERT, 256, int(g["weight_seed"]), torch.float32, weight_norm_keys="legacy")
+    enc.load_state_dict({"audio_encoder": sd, "epoch": 3})  # trainer-style checkpoint (ref:trainer.py:516-528)
+    wave = ri.synthetic_waveform(16000, seed=int(g["wave_seed"]))
+    assert rel_err(enc(wave[None].to(DEV)).cpu(), t(g["audio_embeds"])) < F32_TOL
+
+
+def test_encoder_stack_ctcpool_and_batch():
+    g = golden("enc_tiny_stack_16000")
+    enc, _ = make_encoder(TINY_HUBERT, 256, 12, torch.float32, method="stack")
+    wave = ri.synthetic_waveform(16000, seed=int(g["wave_seed"]))
+    assert rel_err(enc(wave[None].to(DEV)).cpu(), t(g["audio_embeds"])) < F32_TOL
+    # T % 4 == 0: documented divergence from the reference's empty output -> T/4 rows
+    g0 = golden("enc_tiny_stack_16720")
+    wave = ri.synthetic_waveform(16720, seed=int(g0["wave_seed"]))
+    assert enc(wave[None].to(DEV)).shape[1] == int(g0["T"]) // 4
+    g = golden("enc_tiny_ctcpool_16000")
+    enc, _ = make_encoder(TINY_HUBERT, 256, 13, torch.float32, method="ctc_pool")
+    wave = ri.synthetic_waveform(16000, seed=int(g["wave_seed"]))
+    out = enc(wave[None].to(DEV), [[tuple(r) for r in g["ranges"].tolist()]])
+    assert rel_err(out.cpu(), t(g["audio_embeds"])) < F32_TOL
+    g = golden("enc_tiny_pool_batch2")
+    enc, _ = make_encoder(TINY_HUBERT, 256, 11, torch.float32)
+    wave = torch.stack([ri.synthetic_waveform(24000, seed=int(s)) for s in g["wave_seeds"]])
+    assert rel_err(enc(wave.to(DEV)).cpu(), t(g["audio_embeds"])) < F32_TOL
+
+
+def test_encoder_ragged_batch_equals_single_utterances():
+    enc, sd = make_encoder(TINY_HUBERT, 256, 11, torch.float32)
+    waves = [ri.synthetic_waveform(n, seed=n) for n in (9000, 16000, 12345)]
+    out, P, _, _ = enc.encode_packed(waves)
+    r0 = 0
+    for w, p in zip(waves, P):
+        ref = ho.audio_encoder_forward(sd, TINY_HUBERT, w[None])[0]
+        assert ref.shape[0] == p and rel_err(out[r0:r0 + p].cpu(), ref) < F32_TOL
+        r0 += p
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_encoder_wide_hubert_large_width(dtype, tol):
+    g = golden("enc_wide_pool_32000")
+    enc, sd = make_encoder(WIDE_HUBERT, 3072, int(g["weight_seed"]), dtype)
+    wave = ri.synthetic_waveform(32000, seed=int(g["wave_seed"]))
+    out, P, last_hidden, T = enc.encode_packed([wave], want_last_hidden=True)
+    if dtype == torch.float32:
+        ref_h, ref_o = t(g["last_hidden_state"])[0], t(g["audio_embeds"])[0]
+    else:  # same bf16-rounded weights on the oracle side (conv0 stays fp32 in the kernel)
+        keep32 = "conv_layers.0."
+        sdq = {k: (v if keep32 in k else v.to(torch.bfloat16).float()) for k, v in sd.items()}
+        taps = {}
+        ref_o = ho.audio_encoder_forward(sdq, WIDE_HUBERT, wave[None], taps=taps)[0]
+        ref_h = taps["last_hidden_state"][0]
+    assert rel_err(last_hidden.float().cpu(), ref_h) < tol
+    assert rel_err(out.float().cpu(), ref_o) < tol
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_gqa", TINY_LLAMA), ("tiny_mha", TINY_MHA)])
+def test_llama_tiny_fp32_forward_and_generate(name, cfg):
+    g = golden(f"llama_{name}")
+    llm, _ = make_llama(cfg, int(g["weight_seed"]), torch.float32)
+    gen = torch.Generator().manual_seed(int(g["embeds_seed"]))
+    x = (torch.randn(1, int(g["S"]), cfg.hidden_size, generator=gen) * 0.05).to(DEV)
+    out = llm(inputs_embeds=x, output_hidden_states=True)
+    assert rel_err(out.logits.cpu(), t(g["logits"])) < F32_TOL
+    assert rel_err(torch.stack(out.hidden_states).cpu(), t(g["hidden_states"])) < F32_TOL
+    llm.generation_config.eos_token_id = None
+    assert torch.equal(llm.generate(inputs_embeds=x, max_new_tokens=32).cpu(), t(g["ids_noeos"]))
+    llm.generation_config.eos_token_id = list(cfg.eos_token_ids)
+    assert torch.equal(llm.generate(inputs_embeds=x, max_new_tokens=32).cpu(), t(g["ids_eos"]))
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_gqa", TINY_LLAMA), ("tiny_mha", TINY_MHA)])
+def test_llama_left_padded_batch_forward(name, cfg):
+    g = golden(f"llama_{name}_padbatch")
+    llm, _ = make_llama(cfg, int(g["weight_seed"]), torch.float32)
+    out = llm(inputs_embeds=t(g["x"]).to(DEV), attention_mask=t(g["mask"]).to(DEV), output_hidden_states=True)
+    m = t(g["mask"]).bool()
+    assert rel_err(out.logits.cpu()[m], t(g["logits"])[m]) < F32_TOL
+    assert rel_err(out.hidden_states[-1].cpu()[m], t(g["last_hidden"])[m]) < F32_TOL
+
+
+def test_llama_batched_generate_equals_single():
+    cfg = TINY_LLAMA
+    llm, sd = make_llama(cfg, 31, torch.float32)
+    gen = torch.Generator().manual_seed(5)
+    prompts = [torch.randn(n, cfg.hidden_size, generator=gen) * 0.05 for n in (9, 21, 14)]
+    llm.generation_config.eos_token_id = list(cfg.eos_token_ids)
+    ids = llm.generate(inputs_embeds=[p.to(DEV) for p in prompts], max_new_tokens=24).cpu()
+    refs = [lo.greedy_generate(sd, cfg, p[None], 24, use_eos=True)[0] for p in prompts]
+    width = max(r.shape[0] for r in refs)
+    assert ids.shape[1] == width
+    for b, r in enumerate(refs):
+        assert torch.equal(ids[b, :r.shape[0]], r)
+        assert bool((ids[b, r.shape[0]:] == cfg.pad_token_id).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llama_wide_llama32_width(dtype):
+    g = golden("llama_wide")
+    cfg = WIDE_LLAMA
+    llm, sd = make_llama(cfg, int(g["weight_seed"]), dtype)
+    gen = torch.Generator().manual_seed(int(g["embeds_seed"]))
+    x = (torch.randn(1, int(g["S"]), cfg.hidden_size, generator=gen) * 0.02)
+    out = llm(inputs_embeds=x.to(DEV), output_hidden_states=True)
+    hs = torch.stack(out.hidden_states).float().cpu()
+    if dtype == torch.float32:
+        assert rel_err(hs, t(g["hidden_states"])) < F32_TOL
+        assert rel_err(out.logits[:, -1].cpu(), t(g["last_logits"])) < F32_TOL
+        llm.generation_config.eos_token_id = None
+        ids = llm.generate(inputs_embeds=x.to(DEV), max_new_tokens=12).cpu()
+        assert float(t(g["margins"]).min()) > 1e-4      # fixture steps are margin-qualified
+        assert torch.equal(ids, t(g["ids_noeos"]))      # bit-exact greedy ids at fp32
+    else:
+        sdq = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+        ref = lo.llama_forward(sdq, cfg, x.to(torch.bfloat16).float(), output_hidden_states=True)
+        assert rel_err(hs, torch.stack(ref["hidden_states"])) < BF16_TOL
+        assert rel_err(out.logits[:, -1].cpu(), ref["logits"][:, -1]) < BF16_TOL
+
+
+class StubTokenizer:
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, text, return_tensors="pt"):
+        from types import SimpleNamespace
+        return SimpleNamespace(input_ids=self.table[text].clone())
+
+    def batch_decode(self, ids, **kw):
+        return [" ".join(str(int(i)) for i in row) for row in ids]
+
+
+def test_generate_audio_response_pipeline_fp32_ids_match_reference():
+    g = golden("pipeline_tiny")
+    cfg = TINY_LLAMA
+    enc, _ = make_encoder(TINY_HUBERT, cfg.hidden_size, int(g["enc_seed"]), torch.float32)
+    llm, _ = make_llama(cfg, int(g["llm_seed"]), torch.float32)
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: t(g["prefix_ids"]), utils.LLAMA_PROMPT_SUFFIX: t(g["suffix_ids"]),
+                         "EXTRA": t(g["text_prompt_ids"])})
+    conf = enc.config
+    inf = inf_mod.LLMSpeechTextInference(conf, None, DEV, tokenizer=tok, llm=llm, audio_encoder=enc, dtype=torch.float32)
+    wave = ri.synthetic_waveform(int(g["n_samples"]), seed=int(g["wave_seed"])).numpy()
+    text = inf.generate_audio_response(wave, max_new_tokens=40)
+    assert torch.equal(inf.last_generate_ids.cpu(), t(g["ids_audio"]))
+    assert text == " ".join(str(int(i)) for i in g["ids_audio"][0])
+    inf.generate_audio_response(wave, additional_text_prompt="EXTRA", max_new_tokens=40)
+    assert torch.equal(inf.last_generate_ids.cpu(), t(g["ids_text_audio"]))
