@@ -440,12 +440,16 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
   if (max_new_tokens > 1) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    SL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, st);
+    // Capture on a private stream (the caller's may be the legacy null stream, which cannot capture);
+    // capturing records the launches without running them, the graph is then replayed on `st`.
+    static thread_local hipStream_t cap = nullptr;
+    if (!cap) SL_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    SL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, cap);
     if (rc == 0)
       rc = sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
-                                 out_ids, max_new_tokens, st);
-    hipError_t ce = hipStreamEndCapture(st, &graph);
+                                 out_ids, max_new_tokens, cap);
+    hipError_t ce = hipStreamEndCapture(cap, &graph);
     if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
     if (ce != hipSuccess) { sl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce)); return SL_ERR_LAUNCH; }
     SL_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
