@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on MI355X: HuBERT-large -> Llama-3.2-3B bf16 inference
+(BASELINE.json configs[1]), one step = one batch of synthetic 16 kHz utterances through
+encode -> [prefix | audio | suffix[1:]] -> prefill -> KV-cached greedy decode (generate_audio_response,
+ref:inference.py:95-137), random-init weights of the true shapes, inputs resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
+
+Prints ONE JSON line (rank 0).  value = generated tokens/s of the whole job (all ranks, all pipeline
+stages inside the timed region); audio_sec_per_s = encoder-stage throughput from HIP events in the same
+steps.  roofline = the dominant decode kernel (gate/up weight-streaming GEMM) against the HBM peak.
+cpu_baseline = the CPU oracle (oracle/*.py, a port of the reference's HF path) on a bounded sample.
+Multi-GPU: inference shards by utterance, replicas only, no data-path collective (weak scaling).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+PKG = "llm-speech-summarization_amd"
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+
+
+def mod(name):
+    return importlib.import_module(PKG + "." + name)
+
+
+def gpu_llama_state_dict(arch, seed, device):
+    """Same key layout as random_init.llama_state_dict, drawn on the GPU (3.2 B params in seconds)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    H, hd, nh, nkv, F_ = arch.hidden_size, arch.head_dim, arch.num_attention_heads, arch.num_key_value_heads, arch.intermediate_size
+
+    def rn(*s, std=0.02):
+        return (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * std).to(torch.bfloat16)
+
+    sd = {"model.embed_tokens.weight": rn(arch.vocab_size, H)}
+    for li in range(arch.num_hidden_layers):
+        p = f"model.layers.{li}."
+        sd[p + "self_attn.q_proj.weight"] = rn(nh * hd, H)
+        sd[p + "self_attn.k_proj.weight"] = rn(nkv * hd, H)
+        sd[p + "self_attn.v_proj.weight"] = rn(nkv * hd, H)
+        sd[p + "self_attn.o_proj.weight"] = rn(H, nh * hd)
+        sd[p + "mlp.gate_proj.weight"] = rn(F_, H)
+        sd[p + "mlp.up_proj.weight"] = rn(F_, H)
+        sd[p + "mlp.down_proj.weight"] = rn(H, F_)
+        sd[p + "input_layernorm.weight"] = (1.0 + rn(H, std=0.1).float()).to(torch.bfloat16)
+        sd[p + "post_attention_layernorm.weight"] = (1.0 + rn(H, std=0.1).float()).to(torch.bfloat16)
+    sd["model.norm.weight"] = (1.0 + rn(H, std=0.1).float()).to(torch.bfloat16)
+    return sd
+
+
+def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tokens, full_new_tokens):
+    """The CPU oracle on ONE 10 s utterance: encode + prefill + `new_tokens` decode steps, fp32, all host
+    cores; projected to the metric's unit for `full_new_tokens` tokens per utterance."""
+    from oracle import hubert_oracle as ho, llama_oracle as lo
+    # torch's CPU GEMMs stop scaling (and collapse when oversubscribed across sockets) well before the
+    # 256 hardware threads of the GPU node: use up to 32 threads and report that number
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    hc = ho.HubertCfg(harch.conv_dim, harch.conv_kernel, harch.conv_stride, harch.hidden_size, harch.num_hidden_layers,
+                      harch.num_attention_heads, harch.intermediate_size, harch.num_conv_pos_embeddings,
+                      harch.num_conv_pos_embedding_groups, harch.layer_norm_eps)
+    lc = lo.LlamaCfg(larch.hidden_size, larch.num_hidden_layers, larch.num_attention_heads, larch.num_key_value_heads,
+                     larch.head_dim, larch.intermediate_size, larch.vocab_size, larch.rms_norm_eps, larch.rope_theta,
+                     larch.rope_scaling, larch.tie_word_embeddings, tuple(larch.eos_token_ids), larch.pad_token_id)
+    llm_sd = {k: v.float().cpu() for k, v in llm_sd_gpu.items()}  # same tensors as the GPU run (bf16 values in fp32)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        audio = ho.audio_encoder_forward(enc_sd, hc, wave[None].cpu())
+        t1 = time.perf_counter()
+        emb = llm_sd["model.embed_tokens.weight"]
+        prompt = torch.cat([emb[prefix], audio, emb[suffix][:, 1:]], dim=1)
+        out = lo.llama_forward(llm_sd, lc, prompt, last_logits_only=True)
+        t2 = time.perf_counter()
+        past = out["past"]
+        for _ in range(new_tokens):
+            nxt = out["logits"][:, -1].argmax(-1)
+            out = lo.llama_forward(llm_sd, lc, emb[nxt][:, None, :], past=past, last_logits_only=True)
+            past = out["past"]
+        t3 = time.perf_counter()
+    enc_s, pre_s, tok_s = t1 - t0, t2 - t1, (t3 - t2) / new_tokens
+    e2e = full_new_tokens / (enc_s + pre_s + full_new_tokens * tok_s)
+    return {"value": round(e2e, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "audio_sec_per_s": round(wave.numel() / 16000.0 / enc_s, 2), "decode_tokens_per_s": round(1.0 / tok_s, 3),
+            "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s: encoder {enc_s:.2f} s, prefill S={prompt.shape[1]} {pre_s:.2f} s, "
+                       f"{new_tokens} decode steps {tok_s * 1e3:.0f} ms/token, fp32 oracle; value projected to "
+                       f"{full_new_tokens} tokens per utterance at batch 1")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per step per GPU")
+    ap.add_argument("--audio-sec", type=float, default=10.0)
+    ap.add_argument("--max-new-tokens", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-decode-steps", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL: only the timing barrier / max-reduce, never on the data path
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    L, ri, cfgm, weights = mod("_lib"), mod("random_init"), mod("config"), mod("weights")
+    enc_mod, llama_mod, utils = mod("audio_encoder"), mod("audio_llama"), mod("utils")
+    L.lib()
+
+    # ---- models: HuBERT-large + Llama-3.2-3B shapes, random init, bf16 ------------------------------
+    harch = weights.KNOWN_HUBERT["facebook/hubert-large-ls960-ft"]
+    larch = weights.KNOWN_LLAMA[utils.LLAMA_ID]
+    conf = cfgm.load_config(os.path.join(REPO, "config", "llama3_hubert.yaml"))
+    enc_sd = ri.hubert_encoder_state_dict(harch, larch.hidden_size, seed=0)
+    enc = enc_mod.AudioEncoder(conf, dev, dtype=torch.bfloat16, arch=harch)
+    enc.load_state_dict(enc_sd).eval().to(dev)
+    llm_sd = gpu_llama_state_dict(larch, 0, dev)
+    B, new = args.batch, args.max_new_tokens
+    n_samples = int(args.audio_sec * 16000)
+    prefix = ri.synthetic_ids(9, larch.vocab_size, seed=7, bos=larch.bos_token_id or 0)
+    suffix = ri.synthetic_ids(5, larch.vocab_size, seed=8, bos=larch.bos_token_id or 0)
+    T = harch.num_frames(n_samples)
+    P = (T - 8) // 4 + 1
+    S = prefix.shape[1] + P + suffix.shape[1] - 1
+    max_ctx = ((S + new + 63) // 64) * 64
+    keep_sd = dict(llm_sd) if (rank == 0 and not args.no_cpu_baseline) else None
+    llm = llama_mod.AudioLlamaForCausalLM(larch, llm_sd, torch_dtype=torch.bfloat16, device=dev, max_ctx=max_ctx, max_batch=B)
+    del llm_sd
+    wts = llm._dev()
+
+    # ---- synthetic inputs, resident in HBM -------------------------------------------------------------
+    waves = [ri.synthetic_waveform(n_samples, seed=1234 + rank * 1000 + i).to(dev) for i in range(B)]
+    emb = llm.model.embed_tokens
+    pre_e, suf_e = emb(prefix.to(dev))[0], emb(suffix.to(dev))[0, 1:]
+    n_pre = pre_e.shape[0]
+    x = torch.empty((B * S, larch.hidden_size), device=dev, dtype=torch.bfloat16)
+    audio_rows = [b * S + n_pre for b in range(B)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    enc_ms, prefill_ms, decode_ms = [], [], []
+
+    def step(record):
+        # prompt assembly: prefix/suffix rows are copied, the encoder writes the audio rows in place
+        xv = x.view(B, S, -1)
+        xv[:, :n_pre] = pre_e
+        xv[:, n_pre + P:] = suf_e
+        ev[0].record()
+        enc.encode_packed(waves, out=x, out_row_offsets=audio_rows)
+        ev[1].record()
+        ids, n_cols = llm.generate_packed(x, [S] * B, new, use_eos=False)
+        if record:
+            enc_ms.append(ev[0].elapsed_time(ev[1]))
+            prefill_ms.append(llm.last_timings_ms[0])
+            decode_ms.append(llm.last_timings_ms[1])
+        return ids, n_cols
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, n_cols = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert n_cols == new and ids.shape == (B, new)
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline probe: the dominant decode kernel, launched as decode launches it, HIP events on its stream
+    gemm_probe = None
+    if rank == 0:
+        ops = mod("ops")
+        H, F_ = larch.hidden_size, larch.intermediate_size
+        xin = torch.randn(B, H, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        out = torch.empty(B, F_, device=dev, dtype=torch.bfloat16)
+        wgu = [t for t in wts._keep if t.dim() == 2 and t.shape == (2 * F_, H)]
+        assert len(wgu) == larch.num_hidden_layers
+        for w in wgu:
+            ops.gemm(xin, w, act=L.ACT_SILU_MUL, out=out)
+        n_probe = 8 * len(wgu)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n_probe):
+            ops.gemm(xin, wgu[i % len(wgu)], act=L.ACT_SILU_MUL, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        dur_ms = e0.elapsed_time(e1) / n_probe
+        alg_bytes = 2 * F_ * H * 2 + B * H * 2 + B * F_ * 2  # weights once + activations in/out
+        gemm_probe = (alg_bytes, dur_ms)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    tokens = B * new * args.steps * world
+    mean = lambda v: sum(v) / max(1, len(v))
+    alg_bytes, dur_ms = gemm_probe
+    achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_gateup.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    dec_step_ms = mean(decode_ms) / max(1, new - 1)
+    step_bytes = wts.weight_bytes_per_token() + B * (S + new / 2) * 2 * larch.num_key_value_heads * larch.head_dim * 2 * larch.num_hidden_layers
+    result = {
+        "metric": "generated tokens/s (audio-sec/s encoded alongside), HuBERT-large -> Llama-3.2-3B generate_audio_response",
+        "value": round(tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: HuBERT-large + Llama-3.2-3B bf16 inference, batch of synthetic 16 kHz utterances",
+                   "utterances_per_gpu": B, "audio_sec": args.audio_sec, "prompt_tokens": S, "max_new_tokens": new,
+                   "parallelism": f"replicas x{world} (sharded by utterance, no collective)"},
+        "audio_sec_per_s": round(B * args.audio_sec * world / (mean(enc_ms) * 1e-3), 1),
+        "stage_ms": {"encode": round(mean(enc_ms), 3), "prefill": round(mean(prefill_ms), 3), "decode": round(mean(decode_ms), 3),
+                     "decode_per_step": round(dec_step_ms, 4)},
+        "decode_step_hbm": {"algorithmic_GB": round(step_bytes / 1e9, 3), "achieved_GBps": round(step_bytes / (dec_step_ms * 1e-3) / 1e9, 1),
+                            "frac_of_peak": round(step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "roofline": {"kernel": "gemm_skinny_kernel<bf16, SILU_MUL> (gate/up projection, decode)", "bound": "hbm",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(dur_ms * 1e3, 2)},
+    }
+    if not args.no_cpu_baseline:
+        del llm, wts
+        result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
