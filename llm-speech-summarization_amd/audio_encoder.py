@@ -154,6 +154,9 @@ class AudioEncoder:
         return ops.gemm(pooled, w, bias=b)
 
     def forward(self, input: Union[torch.Tensor, List[torch.Tensor]], ctc_pool_ranges=None) -> torch.Tensor:
+        if self.weights is None:
+            raise L.SpeechLLMError("AudioEncoder weights are not on the GPU: call load_state_dict(...).to('cuda') — "
+                                   "the encoder runs on the HIP path only")
         if torch.is_tensor(input):
             if input.dim() == 1:
                 input = input[None]

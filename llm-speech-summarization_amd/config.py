@@ -2,7 +2,13 @@
 the reference loads it with OmegaConf, ref:inference.py:158) and exposes it with attribute access."""
 from __future__ import annotations
 
+import re
+
 import yaml
+
+# PyYAML (YAML 1.1) reads `5e-5` as a string; OmegaConf, which the reference uses, reads it as a float
+# (ref:config/llama3_hubert.yaml:30 `lr: 5e-5`).  Resolve such scalars the OmegaConf way.
+_FLOAT_RE = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)[eE][+-]?\d+$")
 
 
 class AttrDict(dict):
@@ -23,6 +29,8 @@ def _wrap(o):
         return AttrDict({k: _wrap(v) for k, v in o.items()})
     if isinstance(o, list):
         return [_wrap(v) for v in o]
+    if isinstance(o, str) and _FLOAT_RE.match(o):
+        return float(o)
     return o
 
 

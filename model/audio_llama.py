@@ -1,0 +1,7 @@
+"""Reference import path `from model.audio_llama import AudioLlamaForCausalLM` (ref:model/audio_llama.py) -> HIP-backed mirror."""
+import importlib as _il
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+AudioLlamaForCausalLM = _il.import_module("llm-speech-summarization_amd.audio_llama").AudioLlamaForCausalLM

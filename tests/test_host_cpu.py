@@ -1,0 +1,165 @@
+"""CPU (no GPU): host logic, the C-ABI library's exports, loud failure without the HIP path, and the
+world_size-2 sharding/report plumbing over gloo."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO, pkg
+from oracle import hubert_oracle as ho
+from oracle import llama_oracle as lo
+from oracle.golden_cfgs import TINY_HUBERT, TINY_LLAMA
+
+L = pkg("_lib")
+utils = pkg("utils")
+weights = pkg("weights")
+cfgm = pkg("config")
+ri = pkg("random_init")
+distm = pkg("dist")
+
+
+def test_library_exports_every_symbol_declared_in_header():
+    hdr = open(os.path.join(REPO, "include", "speechllm.h")).read()
+    declared = set(re.findall(r"\b(sl_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/speechllm.h but not exported"
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    assert L.lib().sl_version() == 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    a = L.GemmArgs()
+    a.M, a.N, a.K, a.batch, a.dtype = 4, 4, 6, 1, L.SL_BF16   # K not a multiple of 8
+    rc = L.lib().sl_gemm(ctypes.byref(a), None)
+    assert rc == -1 and b"multiple of 8" in L.lib().sl_last_error()
+    with pytest.raises(L.SpeechLLMError):
+        L.check(rc, "sl_gemm")
+
+
+def test_product_path_has_no_cpu_fallback():
+    conf = cfgm.load_config(os.path.join(REPO, "config", "llama3_hubert.yaml"))
+    enc = pkg("audio_encoder").AudioEncoder(conf, "cpu", dtype=torch.float32, arch=weights.HubertArch(
+        TINY_HUBERT.conv_dim, TINY_HUBERT.conv_kernel, TINY_HUBERT.conv_stride, TINY_HUBERT.hidden_size, 2, 2, 256, 16, 4))
+    enc.load_state_dict(ri.hubert_encoder_state_dict(TINY_HUBERT, 3072, seed=0))
+    with pytest.raises(L.SpeechLLMError):
+        enc(torch.zeros(1, 16000))
+    with pytest.raises(L.SpeechLLMError):
+        pkg("inference").LLMSpeechTextInference(conf, None, "cpu")
+    with pytest.raises(L.SpeechLLMError):
+        pkg("ops").rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-5)
+
+
+@pytest.mark.parametrize("name", ["llama3_hubert", "minichat_hubert", "llama3_whisper", "minichat_whisper"])
+def test_configs_follow_reference_schema(name):
+    c = cfgm.load_config(os.path.join(REPO, "config", name + ".yaml"))
+    assert c.seed_everything == 1234 and c.audio.sampling_rate == 16000
+    assert c.model.audio_encoder.downsample_method == "pool" and c.model.audio_encoder.pooling.kernel_size == 8
+    assert c.model.audio_encoder.pooling.stride == 4 and c.model.llm_embedding_channels == 3072
+    assert c.train.grad_accum_interval == 16 and c.train.fd_loss_connector_layers == [0, 5, 11, 17, 23]
+    assert c.train.optimizer.lr == 5e-5 and c.log.validation_interval == 30000
+    utils.prompt_template(c.model.llm_type)
+    if c.model.audio_encoder.base == "whisper":
+        with pytest.raises(L.SpeechLLMError):
+            pkg("audio_encoder").AudioEncoder(c, "cpu")
+
+
+def test_prompt_templates_and_errors():
+    assert utils.prompt_template("meta-llama/Llama-3.2-3B-Instruct") == (utils.LLAMA_PROMPT_PREFIX, utils.LLAMA_PROMPT_SUFFIX)
+    assert utils.prompt_template("/models/MiniChat-2-3B")[0] == "[|User|]"
+    with pytest.raises(Exception, match="Unknown LLM type."):
+        utils.prompt_template("gpt2")
+    assert utils.LLAMA_PROMPT_PREFIX.endswith("user<|end_header_id|>\n\n") and utils.MINICHAT_PROMPT_SUFFIX == "</s>[|Assistant|]"
+    bad = cfgm.from_dict(dict(model=dict(audio_encoder=dict(base="wav2vec", type="x", downsample_method="pool", downsample_factor=4),
+                                         llm_embedding_channels=8)))
+    with pytest.raises(Exception, match="Unexpected encoder type in config."):
+        pkg("audio_encoder").AudioEncoder(bad, "cpu")
+
+
+def test_num_audio_embeds_matches_oracle():
+    for n in (16000, 32000, 80000, 160000, 163200, 480000, 12345):
+        assert utils.compute_num_audio_embeds(n) == ho.compute_num_audio_embeds(n)
+
+
+def test_sequence_assembly_host_logic():
+    table = torch.randn(50, 8)
+    emb = lambda ids: table[ids]
+    from types import SimpleNamespace
+    pre, suf = torch.tensor([[0, 3, 4]]), torch.tensor([[0, 9, 8, 7]])
+    tok = lambda text, return_tensors="pt": SimpleNamespace(input_ids=pre if text == utils.LLAMA_PROMPT_PREFIX else suf)
+    x = torch.randn(1, 5, 8)
+    seq = utils.merge_prompt_tokens(x, tok, emb, utils.LLAMA_ID, "cpu")
+    assert seq.shape == (1, 3 + 5 + 3, 8) and torch.equal(seq[0, 3:8], x[0]) and torch.equal(seq[0, 8:], table[suf[0, 1:]])
+    resp = [torch.tensor([11, 12, 13]), torch.tensor([21, 22])]
+    a, am, t_, tm = utils.batch_full_embed_sequence([x[0], x[0, :2]], [torch.tensor([1, 2]), torch.tensor([5])], resp, tok, emb,
+                                                    utils.LLAMA_ID, "cpu", process_text=True)
+    assert a.shape == (2, 3 + 5 + 3 + 2, 8) and am.tolist()[1][:4] == [0, 0, 0, 0] and am.sum().item() == 13 + 9
+    assert t_.shape[1] == 3 + 2 + 3 + 2 and tm[1].sum().item() == 3 + 1 + 3 + 1
+    assert torch.equal(utils.construct_attention_mask([2, 4]), torch.tensor([[0, 0, 1, 1], [1, 1, 1, 1]]))
+
+
+def test_weight_layouts():
+    g, u = torch.arange(32 * 4.0).view(32, 4), -torch.arange(32 * 4.0).view(32, 4)
+    w = weights.interleave_gate_up(g, u)
+    assert torch.equal(w[:16], g[:16]) and torch.equal(w[16:32], u[:16]) and torch.equal(w[32:48], g[16:])
+    sd = ri.hubert_encoder_state_dict(TINY_HUBERT, 64, seed=1)
+    p = "encoder.encoder.pos_conv_embed.conv."
+    assert torch.allclose(weights.fold_pos_conv_weight(sd, p), ho.pos_conv_weight(sd, "encoder.encoder.pos_conv_embed."))
+    arch = weights.LlamaArch(hidden_size=256, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+                             rope_scaling=TINY_LLAMA.rope_scaling)
+    cos, sin = weights.rope_tables(arch, 300)
+    c_ref, s_ref = lo.rope_cos_sin(TINY_LLAMA, torch.arange(300))
+    assert torch.equal(cos, c_ref[:, :64]) and torch.equal(sin, s_ref[:, :64])   # bit-identical tables to the oracle's
+    a2 = weights.LlamaArch.from_hf_config(dict(hidden_size=3072, num_hidden_layers=28, num_attention_heads=24, num_key_value_heads=8,
+                                               head_dim=128, intermediate_size=8192, vocab_size=128256, rms_norm_eps=1e-5,
+                                               rope_theta=500000.0, tie_word_embeddings=True, eos_token_id=[128001, 128008, 128009],
+                                               rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0,
+                                                                 high_freq_factor=4.0, original_max_position_embeddings=8192)))
+    assert a2 == weights.KNOWN_LLAMA[utils.LLAMA_ID].__class__(**{**a2.__dict__}) and a2.rope_scaling["factor"] == 32.0
+
+
+def test_random_init_is_deterministic_and_shaped():
+    a, b = ri.llama_state_dict(TINY_LLAMA, seed=3), ri.llama_state_dict(TINY_LLAMA, seed=3)
+    assert all(torch.equal(a[k], b[k]) for k in a) and "lm_head.weight" not in a
+    sd = ri.hubert_encoder_state_dict(ho.HUBERT_LARGE.__class__(num_hidden_layers=1), 3072, seed=0)
+    assert sd["embed_projection.weight"].shape == (3072, 1024)
+    assert sd["encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original1"].shape == (1024, 64, 128)
+    w = ri.synthetic_waveform(1000)
+    assert w.abs().max() <= 1.0 and abs(float(w.std()) - 0.1) < 0.02
+
+
+def test_shard_indices_partition_and_balance():
+    lens = [2, 4, 6, 8, 10, 12, 15, 20, 25, 32] * 3
+    for world in (1, 2, 4, 8):
+        shards = [distm.shard_indices(lens, r, world) for r in range(world)]
+        assert sorted(sum(shards, [])) == list(range(len(lens)))
+        secs = [sum(lens[i] for i in s) for s in shards]
+        assert max(secs) - min(secs) <= 32
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = list(range(1, 22))
+    mine = distm.shard_indices(lens, rank, world)
+    tokens, audio = distm.sum_over_ranks([len(mine) * 7.0, float(sum(lens[i] for i in mine))], "cpu")
+    slowest = distm.max_over_ranks(1.0 + rank, "cpu")
+    q.put((rank, tokens, audio, slowest))
+    dist.destroy_process_group()
+
+
+def test_two_rank_report_plumbing_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    for _, tokens, audio, slowest in res:
+        assert tokens == 21 * 7.0 and audio == sum(range(1, 22)) and slowest == 2.0
