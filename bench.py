@@ -198,15 +198,19 @@ def main():
         H, F_ = larch.hidden_size, larch.intermediate_size
         xin = torch.randn(B, H, device=dev, dtype=torch.float32).to(torch.bfloat16)
         out = torch.empty(B, F_, device=dev, dtype=torch.bfloat16)
-        wgu = [t for t in wts._keep if t.dim() == 2 and t.shape == (2 * F_, H)]
+        wgu = wts.dec_wgu  # the fragment-packed, RMSNorm-folded gate/up matrices the decode graph streams
         assert len(wgu) == larch.num_hidden_layers
+
+        def probe(w):
+            ops.gemm_decode(xin, w, 2 * F_, act=L.ACT_SILU_MUL, fuse_rms=bool(wts.struct.dec_fused_norm), eps=larch.rms_norm_eps, out=out)
+
         for w in wgu:
-            ops.gemm(xin, w, act=L.ACT_SILU_MUL, out=out)
+            probe(w)
         n_probe = 8 * len(wgu)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(n_probe):
-            ops.gemm(xin, wgu[i % len(wgu)], act=L.ACT_SILU_MUL, out=out)
+            probe(wgu[i % len(wgu)])
         e1.record()
         torch.cuda.synchronize()
         dur_ms = e0.elapsed_time(e1) / n_probe

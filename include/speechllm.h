@@ -37,7 +37,8 @@ enum sl_status {
   SL_ERR_LAUNCH = -2,   /* HIP launch or runtime error */
   SL_ERR_UNSUPPORTED = -3
 };
-enum sl_act { SL_ACT_NONE = 0, SL_ACT_GELU = 1, SL_ACT_SILU_MUL = 2 };
+enum sl_act { SL_ACT_NONE = 0, SL_ACT_GELU = 1, SL_ACT_SILU_MUL = 2, SL_ACT_ROPE_KV = 3 };
+enum sl_w_layout { SL_W_ROWMAJOR = 0, SL_W_PACKED = 1 };
 
 const char* sl_last_error(void);       /* thread-local, never NULL */
 int sl_version(void);                  /* ABI version, bumps on any signature change */
@@ -65,9 +66,34 @@ typedef struct {
   const void* bias; int64_t strideBias;
   const void* residual; int64_t ldr; int64_t strideR;
   int32_t M, N, K, batch;
-  int32_t dtype, act, out_f32, reserved;
+  int32_t dtype, act, out_f32, w_layout;
 } sl_gemm_args;
 int sl_gemm(const sl_gemm_args* a, sl_stream stream);
+
+/* Fragment-major weight packing for the decode (M <= 64) weight-streaming kernel:
+ *   dst[f][s][lane][e] = src[16 f + (lane & 15)][KSTEP s + VEC (lane >> 4) + e],  VEC = 8 (bf16) / 4 (f32),
+ *   KSTEP = 4 VEC, f < ceil(N/16) (rows past N are zero), so one wave-level weight load is 1 KiB contiguous
+ *   (+25..45 % HBM throughput over 16 x 64-byte row segments, tools/tune_skinny.hip).  K %% KSTEP == 0.
+ *   dst holds ceil(N/16)*16*K elements.  Pass it to sl_gemm with w_layout = SL_W_PACKED. */
+int sl_pack_weight(const void* src, int64_t ld_src, void* dst, int32_t N, int32_t K, int32_t dtype, sl_stream stream);
+
+/* Decode-only fusions on top of sl_gemm (M <= 64, packed weights):
+ *   fuse_rms  — the consuming Linear absorbs the preceding LlamaRMSNorm (hf:...llama.py:62-67): the
+ *               gain is pre-multiplied into W on the host and out[m] *= rsqrt(mean(x[m]^2) + rms_eps),
+ *               with the mean taken from the activation fragments the kernel streams anyway;
+ *   act == SL_ACT_ROPE_KV — N = (n_heads + 2 n_kv) * 128 fused q|k|v rows whose q/k heads are stored
+ *               in 16-row blocks alternating the two rotate_half halves ([0:16],[64:80],[16:32],...):
+ *               the epilogue applies RoPE (hf:...llama.py:130-160), writes q to C (row stride ldc,
+ *               natural head layout) and k, v straight into the cache at [tok_seq][head][tok_pos]
+ *               (replaces sl_rope_kv_append + the qkv round trip). */
+typedef struct {
+  int32_t fuse_rms; float rms_eps;
+  const float* rope_cos; const float* rope_sin;
+  const int32_t* tok_pos; const int32_t* tok_seq;
+  void* k_cache; void* v_cache;
+  int32_t n_heads, n_kv_heads, max_ctx, reserved;
+} sl_gemm_fused;
+int sl_gemm_fused_decode(const sl_gemm_args* a, const sl_gemm_fused* fx, sl_stream stream);
 
 /* LayerNorm over the last dim, optional fused GELU (conv layers: hf:...hubert.py:144-150;
  * encoder LNs hf:...hubert.py:515,517,612; feature projection :226).  In-place allowed. */
@@ -137,6 +163,14 @@ int sl_attn_decode(const void* q, int64_t q_stride, const void* k_cache, const v
                    const int32_t* ctx_len, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D,
                    int32_t max_ctx, float scale, int32_t dtype, sl_stream stream);
 
+/* Flash-decoding form of sl_attn_decode: the context is split into 64-key blocks (grid = n_kv x B x
+ * ceil(max_ctx/64)) whose fp32 partial (O, max, sum) records are merged by a second kernel, so batch 1
+ * fills the chip too.  workspace: sl_attn_decode_workspace_bytes(B, n_heads, n_kv, max_ctx). */
+size_t sl_attn_decode_workspace_bytes(int32_t B, int32_t n_heads, int32_t n_kv, int32_t max_ctx);
+int sl_attn_decode_split(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out,
+                         void* workspace, const int32_t* ctx_len, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D,
+                         int32_t max_ctx, float scale, int32_t dtype, sl_stream stream);
+
 /* Greedy token selection (hf:generation/utils.py:2894,2925-2936): argmax over fp32 logits (lowest index
  * on ties), pad finished rows, EOS check, append to out_ids[b][gen_count[b]], advance gen_count and
  * ctx_len.  logits (B, V) float; eos_ids is a HOST array of at most 8 ids (passed by value to the
@@ -185,7 +219,11 @@ int sl_hubert_forward(const sl_hubert_model* m, const float* waves, const int64_
                       void* workspace, size_t workspace_bytes, sl_stream stream);
 
 typedef struct {
-  const void *norm1, *wqkv, *wo, *norm2, *wgu, *wdown;   /* wgu: 16-row gate/up interleave */
+  const void *norm1, *wqkv, *wo, *norm2, *wgu, *wdown;   /* row-major (prefill); wgu: 16-row gate/up interleave */
+  /* decode copies, fragment-packed (sl_pack_weight); NULL -> decode falls back to the row-major set.
+   * wqkv_dec rows: q/k heads in rotate_half pair order (see sl_gemm_fused); if dec_fused_norm the
+   * RMSNorm gains are pre-multiplied into wqkv_dec / wgu_dec (and final_norm into lm_head_dec). */
+  const void *wqkv_dec, *wo_dec, *wgu_dec, *wdown_dec;
 } sl_llama_layer;
 
 typedef struct {
@@ -194,6 +232,8 @@ typedef struct {
   const void *embed, *lm_head, *final_norm;
   const float *rope_cos, *rope_sin;      /* (rope_len, head_dim/2) */
   const sl_llama_layer* layers;          /* host array */
+  const void* lm_head_dec;               /* packed (gain-folded if dec_fused_norm) or NULL */
+  int32_t dec_fused_norm, reserved;
 } sl_llama_model;
 
 typedef struct {

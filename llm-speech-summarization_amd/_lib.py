@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspeechllm.so")
 
 SL_F32, SL_BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_SILU_MUL = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU_MUL, ACT_ROPE_KV = 0, 1, 2, 3
+W_ROWMAJOR, W_PACKED = 0, 1
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -31,7 +32,12 @@ class GemmArgs(C.Structure):
                 ("bias", c_vp), ("strideBias", c_i64),
                 ("residual", c_vp), ("ldr", c_i64), ("strideR", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("batch", c_i32),
-                ("dtype", c_i32), ("act", c_i32), ("out_f32", c_i32), ("reserved", c_i32)]
+                ("dtype", c_i32), ("act", c_i32), ("out_f32", c_i32), ("w_layout", c_i32)]
+
+
+class GemmFused(C.Structure):
+    _fields_ = [("fuse_rms", c_i32), ("rms_eps", c_f32), ("rope_cos", c_vp), ("rope_sin", c_vp), ("tok_pos", c_vp), ("tok_seq", c_vp),
+                ("k_cache", c_vp), ("v_cache", c_vp), ("n_heads", c_i32), ("n_kv_heads", c_i32), ("max_ctx", c_i32), ("reserved", c_i32)]
 
 
 class AttnArgs(C.Structure):
@@ -66,7 +72,7 @@ class HubertModel(C.Structure):
 
 
 class LlamaLayer(C.Structure):
-    _fields_ = [(n, c_vp) for n in ("norm1", "wqkv", "wo", "norm2", "wgu", "wdown")]
+    _fields_ = [(n, c_vp) for n in ("norm1", "wqkv", "wo", "norm2", "wgu", "wdown", "wqkv_dec", "wo_dec", "wgu_dec", "wdown_dec")]
 
 
 class LlamaModel(C.Structure):
@@ -75,7 +81,8 @@ class LlamaModel(C.Structure):
                 ("rms_eps", c_f32), ("rope_len", c_i32),
                 ("embed", c_vp), ("lm_head", c_vp), ("final_norm", c_vp),
                 ("rope_cos", c_vp), ("rope_sin", c_vp),
-                ("layers", C.POINTER(LlamaLayer))]
+                ("layers", C.POINTER(LlamaLayer)),
+                ("lm_head_dec", c_vp), ("dec_fused_norm", c_i32), ("reserved", c_i32)]
 
 
 class KVCache(C.Structure):
@@ -87,6 +94,10 @@ _PROTOS = {
     "sl_version": (c_i32, []),
     "sl_device_arch": (c_i32, [C.c_char_p, c_i32]),
     "sl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "sl_pack_weight": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "sl_gemm_fused_decode": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmFused), c_vp]),
+    "sl_attn_decode_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "sl_attn_decode_split": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sl_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32, c_vp]),
     "sl_rmsnorm": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),
     "sl_hubert_conv0": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),

@@ -44,7 +44,7 @@ class _EmbedTokens:
 
 class AudioLlamaForCausalLM:
     def __init__(self, arch: LlamaArch, state_dict: Dict[str, torch.Tensor], torch_dtype: torch.dtype = torch.bfloat16,
-                 device=None, max_ctx: int = 2048, max_batch: int = 16):
+                 device=None, max_ctx: int = 2048, max_batch: int = 16, pack_decode: bool = True):
         if torch_dtype == torch.float16:
             # the reference runs fp16 autocast (ref:inference.py:50); gfx950 MFMA path here is bf16 / exact fp32
             torch_dtype = torch.bfloat16
@@ -57,7 +57,7 @@ class AudioLlamaForCausalLM:
                                                  do_sample=False)
         self._sd = state_dict
         self.device = torch.device("cpu")
-        self.max_ctx, self.max_batch = max_ctx, max_batch
+        self.max_ctx, self.max_batch, self.pack_decode = max_ctx, max_batch, pack_decode
         self._w: Optional[LlamaDeviceWeights] = None
         self._kv = None
         self._ws: Optional[torch.Tensor] = None
@@ -96,6 +96,8 @@ class AudioLlamaForCausalLM:
         self.device = torch.device(device)
         if self.device.type == "cuda" and self._w is None:
             self._w = LlamaDeviceWeights(self.arch, self._sd, self.device, self.dtype, rope_len=max(self.max_ctx, 64))
+            if self.pack_decode:
+                self._w.build_decode_weights()
             self._sd = None  # device copy is the only copy from here on (6.4 GB bf16 for Llama-3.2-3B)
         return self
 

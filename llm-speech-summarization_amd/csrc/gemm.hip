@@ -174,30 +174,61 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// skinny kernel (M <= 16*MT)
+// skinny kernel (M <= 16*MT): HBM-bound weight streaming for decode.
+//   block = RF 16-row weight fragments x NW waves; wave w takes 64-byte k-steps w, w+NW, ... with U steps
+//   of loads in flight; W fragments go global -> VGPR -> MFMA (A operand), the M activation rows are the
+//   B operand (re-read from L2); partial sums meet once in LDS.
+//   PACKED: W is stored fragment-major [ceil(N/16)][K/KSTEP][64 lanes][16 B] (sl_pack_weight layout), so
+//   every wave-level weight load is one contiguous 1 KiB (measured +25..45 % over row-major 16 x 64 B).
+//   Epilogues: NONE/GELU (+bias, +residual), SILU_MUL (fragment pairs = gate, up), ROPE_KV (fragment
+//   pairs = the two rotate_half halves of a head; q is written rotated, k/v go straight into the cache).
+//   fuse_rms: the RMSNorm gain is pre-folded into W and the per-row rsqrt(mean(x^2)+eps) is computed
+//   from the x fragments the block loads anyway, then applied to the accumulators.
 // ----------------------------------------------------------------------------------------------
-template <typename T, int MT, int ACT, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p) {
+struct SkinnyX {
+  const float* cos; const float* sin;      // (rope_len, 64) tables
+  const int32_t* pos; const int32_t* seq;  // per activation row: position / cache slot
+  void* kc; void* vc;                      // this layer's caches (slots, n_kv, max_ctx, 128)
+  int nh, nkv, max_ctx, fuse_rms;
+  float eps;
+};
+
+template <typename T, int MT, int ACT, int RF, int NW, int U, bool PACKED>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX sx) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int KSTEP = MMA<T>::KSTEP;
-  constexpr int RF = (ACT == SL_ACT_SILU_MUL) ? 2 : 1;  // 16-row weight fragments per block
   constexpr int RB = 16 * RF;
-  constexpr int U = 4;  // k-steps in flight per wave
+  constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+  static_assert(!PAIRS || RF % 2 == 0, "pair epilogues need an even number of fragments");
   __shared__ float red[NW][RB][MT * 16 + 1];
+  __shared__ float red_ss[NW][4][MT * 16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int z = blockIdx.y;
   const int n0 = blockIdx.x * RB;
+  const int nks_full = p.K / KSTEP;  // full 64-byte steps
 
   const T* A = (const T*)p.A + (int64_t)z * p.sA;
   const T* W = (const T*)p.W + (int64_t)z * p.sW;
 
   const T* wp[RF];
+  int64_t wstep;  // elements between consecutive k-steps of one fragment row
+  if constexpr (PACKED) {
+    const int nfrag = (p.N + 15) >> 4;
+    wstep = 64 * VEC;
 #pragma unroll
-  for (int f = 0; f < RF; ++f) {
-    int wr = n0 + f * 16 + r; wr = wr < p.N ? wr : p.N - 1;
-    wp[f] = W + (int64_t)wr * p.ldw + q * VEC;
+    for (int f = 0; f < RF; ++f) {
+      int fi = (n0 >> 4) + f; fi = fi < nfrag ? fi : nfrag - 1;
+      wp[f] = W + (int64_t)fi * nks_full * (64 * VEC) + lane * VEC;
+    }
+  } else {
+    wstep = KSTEP;
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      int wr = n0 + f * 16 + r; wr = wr < p.N ? wr : p.N - 1;
+      wp[f] = W + (int64_t)wr * p.ldw + q * VEC;
+    }
   }
   const T* xp[MT];
 #pragma unroll
@@ -207,56 +238,79 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p) {
   }
 
   f32x4 acc[RF][MT];
+  float ss[MT];
 #pragma unroll
-  for (int f = 0; f < RF; ++f)
+  for (int t = 0; t < MT; ++t) {
+    ss[t] = 0.f;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < RF; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool fuse = sx.fuse_rms != 0;
 
-  const int nks_full = p.K / KSTEP;  // full 64-byte steps
+  auto sumsq = [&](const uint4& u, float& s) {
+    float e[VEC];
+    Vec16<T>::unpack(u, e);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s = fmaf(e[j], e[j], s);
+  };
+
   int ks = wave;
-  // main: U interleaved steps per iteration, all loads issued before the first MFMA
   for (; ks + (U - 1) * NW < nks_full; ks += U * NW) {
     uint4 fw[U][RF], fx[U][MT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t k = (int64_t)(ks + u * NW) * KSTEP;
+      const int64_t kk = ks + u * NW;
 #pragma unroll
-      for (int f = 0; f < RF; ++f) fw[u][f] = ld_nt16(wp[f] + k);
+      for (int f = 0; f < RF; ++f) fw[u][f] = ld_nt16(wp[f] + kk * wstep);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) fx[u][t] = *(const uint4*)(xp[t] + k);
+      for (int t = 0; t < MT; ++t) fx[u][t] = *(const uint4*)(xp[t] + kk * KSTEP);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int f = 0; f < RF; ++f)
 #pragma unroll
         for (int t = 0; t < MT; ++t) MMA<T>::step(acc[f][t], fw[u][f], fx[u][t]);
+      if (fuse) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) sumsq(fx[u][t], ss[t]);
+      }
+    }
   }
   for (; ks < nks_full; ks += NW) {
-    const int64_t k = (int64_t)ks * KSTEP;
     uint4 fw[RF], fx[MT];
 #pragma unroll
-    for (int f = 0; f < RF; ++f) fw[f] = ld_nt16(wp[f] + k);
+    for (int f = 0; f < RF; ++f) fw[f] = ld_nt16(wp[f] + (int64_t)ks * wstep);
 #pragma unroll
-    for (int t = 0; t < MT; ++t) fx[t] = *(const uint4*)(xp[t] + k);
+    for (int t = 0; t < MT; ++t) fx[t] = *(const uint4*)(xp[t] + (int64_t)ks * KSTEP);
 #pragma unroll
     for (int f = 0; f < RF; ++f)
 #pragma unroll
       for (int t = 0; t < MT; ++t) MMA<T>::step(acc[f][t], fw[f], fx[t]);
+    if (fuse) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) sumsq(fx[t], ss[t]);
+    }
   }
-  // K tail (K % KSTEP != 0): one predicated step, taken by the wave whose turn it is
-  if (nks_full * KSTEP < p.K && (nks_full % NW) == wave) {
-    const int64_t k = (int64_t)nks_full * KSTEP;
-    const bool ok = (k + q * VEC) < p.K;
-    uint4 fw[RF], fx[MT];
+  if constexpr (!PACKED) {
+    // K tail (K % KSTEP != 0): one predicated step, taken by the wave whose turn it is
+    if (nks_full * KSTEP < p.K && (nks_full % NW) == wave) {
+      const int64_t k = (int64_t)nks_full * KSTEP;
+      const bool ok = (k + q * VEC) < p.K;
+      uint4 fw[RF], fx[MT];
 #pragma unroll
-    for (int f = 0; f < RF; ++f) fw[f] = ok ? *(const uint4*)(wp[f] + k) : make_uint4(0, 0, 0, 0);
+      for (int f = 0; f < RF; ++f) fw[f] = ok ? *(const uint4*)(wp[f] + k) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < MT; ++t) fx[t] = ok ? *(const uint4*)(xp[t] + k) : make_uint4(0, 0, 0, 0);
+      for (int t = 0; t < MT; ++t) fx[t] = ok ? *(const uint4*)(xp[t] + k) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int f = 0; f < RF; ++f)
+      for (int f = 0; f < RF; ++f)
 #pragma unroll
-      for (int t = 0; t < MT; ++t) MMA<T>::step(acc[f][t], fw[f], fx[t]);
+        for (int t = 0; t < MT; ++t) MMA<T>::step(acc[f][t], fw[f], fx[t]);
+      if (fuse) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) sumsq(fx[t], ss[t]);
+      }
+    }
   }
 
   // D[weight row 4q+i][x row r]  ->  red[wave][f*16 + 4q+i][t*16 + r]
@@ -266,27 +320,69 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p) {
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) red[wave][f * 16 + q * 4 + i][t * 16 + r] = acc[f][t][i];
+  if (fuse) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) red_ss[wave][q][t * 16 + r] = ss[t];
+  }
   __syncthreads();
 
   void* Cb = p.out_f32 ? (void*)((float*)p.C + (int64_t)z * p.sC) : (void*)((T*)p.C + (int64_t)z * p.sC);
   const T* bias = p.bias ? (const T*)p.bias + (int64_t)z * p.sBias : nullptr;
   const void* Rb = p.res ? (const void*)((const T*)p.res + (int64_t)z * p.sR) : nullptr;
-  for (int o = tid; o < 16 * p.M; o += NW * 64) {
-    const int m = o >> 4, n = o & 15;
-    if constexpr (ACT == SL_ACT_SILU_MUL) {
-      const int ocol = blockIdx.x * 16 + n;
-      if (ocol >= (p.N >> 1)) continue;
-      float g = 0.f, u = 0.f;
+  auto row_scale = [&](int m) -> float {
+    if (!fuse) return 1.0f;
+    float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) { g += red[w][n][m]; u += red[w][16 + n][m]; }
-      if (bias) { g += to_f32(bias[n0 + n]); u += to_f32(bias[n0 + 16 + n]); }
-      store_out<T>(p, Cb, Rb, m, ocol, silu(g) * u);
-    } else {
+    for (int w = 0; w < NW; ++w) s += red_ss[w][0][m] + red_ss[w][1][m] + red_ss[w][2][m] + red_ss[w][3][m];
+    return rsqrtf(s / (float)p.K + sx.eps);
+  };
+  auto rsum = [&](int n, int m) -> float {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][n][m];
+    return v;
+  };
+
+  if constexpr (PAIRS) {
+    constexpr int NP = RF / 2;
+    for (int o = tid; o < NP * 16 * p.M; o += NW * 64) {
+      const int n = o & 15, pr = (o >> 4) % NP, m = o / (16 * NP);
+      const float rs = row_scale(m);
+      float a = rsum((2 * pr) * 16 + n, m) * rs, b = rsum((2 * pr + 1) * 16 + n, m) * rs;
+      if constexpr (ACT == SL_ACT_SILU_MUL) {
+        const int ocol = ((n0 >> 4) / 2 + pr) * 16 + n;
+        if (ocol >= (p.N >> 1)) continue;
+        if (bias) { a += to_f32(bias[n0 + (2 * pr) * 16 + n]); b += to_f32(bias[n0 + (2 * pr + 1) * 16 + n]); }
+        store_out<T>(p, Cb, Rb, m, ocol, silu(a) * b);
+      } else {  // ROPE_KV: global fragment gf; a head is 8 fragments (D = 128)
+        const int gf = (n0 >> 4) + 2 * pr;
+        if (gf * 16 >= p.N) continue;
+        const int hh = gf >> 3, j = (gf & 7) >> 1;
+        const int pos = sx.pos[m];
+        if (hh < sx.nh + sx.nkv) {
+          const int d = j * 16 + n;  // a = x[d], b = x[d + 64]
+          const float c = sx.cos[(int64_t)pos * 64 + d], s = sx.sin[(int64_t)pos * 64 + d];
+          const float o1 = a * c - b * s, o2 = b * c + a * s;
+          if (hh < sx.nh) {
+            T* dst = (T*)Cb + (int64_t)m * p.ldc + hh * 128 + d;
+            dst[0] = from_f32<T>(o1); dst[64] = from_f32<T>(o2);
+          } else {
+            T* dst = (T*)sx.kc + (((int64_t)sx.seq[m] * sx.nkv + (hh - sx.nh)) * sx.max_ctx + pos) * 128 + d;
+            dst[0] = from_f32<T>(o1); dst[64] = from_f32<T>(o2);
+          }
+        } else {  // v rows are in natural order: fragments 2j, 2j+1
+          const int d = (gf & 7) * 16 + n;
+          T* dst = (T*)sx.vc + (((int64_t)sx.seq[m] * sx.nkv + (hh - sx.nh - sx.nkv)) * sx.max_ctx + pos) * 128 + d;
+          dst[0] = from_f32<T>(a); dst[16] = from_f32<T>(b);
+        }
+      }
+    }
+  } else {
+    for (int o = tid; o < RB * p.M; o += NW * 64) {
+      const int n = o % RB, m = o / RB;
       const int col = n0 + n;
       if (col >= p.N) continue;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) v += red[w][n][m];
+      float v = rsum(n, m) * row_scale(m);
       if (bias) v += to_f32(bias[col]);
       if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
       store_out<T>(p, Cb, Rb, m, col, v);
@@ -307,48 +403,82 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int MT, int ACT>
-static int launch_skinny_mt(GemmP& p, int batch, hipStream_t st) {
-  const int RB = (ACT == SL_ACT_SILU_MUL) ? 32 : 16;
-  const int nblk = (p.N + RB - 1) / RB;
-  dim3 grid(nblk, batch);
-  // few row blocks (N = hidden): spread K over 8 waves so the chip still has enough loads in flight
-  if (nblk * batch < 1024 && p.K >= 2048)
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, ACT, 8>), grid, dim3(512), 0, st, p);
-  else
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, ACT, 4>), grid, dim3(256), 0, st, p);
+template <typename T, int MT, int ACT, int RF, int NW, int U, bool PACKED>
+static int launch_skinny_cfg(GemmP& p, const SkinnyX& sx, int batch, hipStream_t st) {
+  dim3 grid((p.N + 16 * RF - 1) / (16 * RF), batch);
+  hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, ACT, RF, NW, U, PACKED>), grid, dim3(NW * 64), 0, st, p, sx);
   SL_CHECK_LAUNCH("gemm_skinny");
   return 0;
 }
 
+// Structure per shape, from the sweep in tools/tune_skinny.hip (MI355X, bf16, M = 16):
+//   many fragments (gate/up, lm_head): 4 fragments x 4 waves  — x fragment reused 4x from registers
+//   mid (qkv, N = 5120):                2 fragments x 8 waves
+//   few (N = hidden: o, down):          1-2 fragments x 16 waves — K spread wide so 192 blocks still fill HBM
+template <typename T, int MT, int ACT, bool PACKED>
+static int launch_skinny_mt(GemmP& p, const SkinnyX& sx, int batch, hipStream_t st) {
+  constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+  const int nfrag = (p.N + 15) / 16;
+  if (nfrag * batch >= 1024 && MT <= 2) return launch_skinny_cfg<T, MT, ACT, 4, 4, 4, PACKED>(p, sx, batch, st);
+  if (nfrag * batch >= 256 || PAIRS) return launch_skinny_cfg<T, MT, ACT, 2, 8, (MT <= 2 ? 4 : 2), PACKED>(p, sx, batch, st);
+  if constexpr (!PAIRS) return launch_skinny_cfg<T, MT, ACT, 1, 16, 2, PACKED>(p, sx, batch, st);
+  return 0;
+}
+
 template <typename T, int ACT>
-static int launch_skinny(GemmP& p, int batch, hipStream_t st) {
-  if (p.M <= 16) return launch_skinny_mt<T, 1, ACT>(p, batch, st);
-  if (p.M <= 32) return launch_skinny_mt<T, 2, ACT>(p, batch, st);
-  return launch_skinny_mt<T, 4, ACT>(p, batch, st);
+static int launch_skinny(GemmP& p, const SkinnyX& sx, int batch, bool packed, hipStream_t st) {
+  if (packed) {
+    if constexpr (ACT == SL_ACT_GELU) {
+      sl_set_error("sl_gemm: packed weights are not built with the GELU epilogue");
+      return SL_ERR_UNSUPPORTED;
+    } else {
+      if (p.M <= 16) return launch_skinny_mt<T, 1, ACT, true>(p, sx, batch, st);
+      if (p.M <= 32) return launch_skinny_mt<T, 2, ACT, true>(p, sx, batch, st);
+      return launch_skinny_mt<T, 4, ACT, true>(p, sx, batch, st);
+    }
+  }
+  if constexpr (ACT == SL_ACT_ROPE_KV) {
+    sl_set_error("sl_gemm: the ROPE_KV epilogue needs packed weights");
+    return SL_ERR_UNSUPPORTED;
+  } else {
+    if (p.M <= 16) return launch_skinny_mt<T, 1, ACT, false>(p, sx, batch, st);
+    if (p.M <= 32) return launch_skinny_mt<T, 2, ACT, false>(p, sx, batch, st);
+    return launch_skinny_mt<T, 4, ACT, false>(p, sx, batch, st);
+  }
 }
 
 template <typename T>
-static int gemm_typed(const sl_gemm_args* a, GemmP& p, hipStream_t st) {
+static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStream_t st) {
   const bool skinny = a->M <= 64;
+  const bool packed = a->w_layout == SL_W_PACKED;
+  if (!skinny && (packed || a->act == SL_ACT_ROPE_KV || sx.fuse_rms)) {
+    sl_set_error("sl_gemm: packed weights / ROPE_KV / fused RMSNorm are decode (M <= 64) features, M=%d", a->M);
+    return SL_ERR_UNSUPPORTED;
+  }
   switch (a->act) {
-    case SL_ACT_NONE: return skinny ? launch_skinny<T, SL_ACT_NONE>(p, a->batch, st) : launch_tiled<T, SL_ACT_NONE>(p, a->batch, st);
-    case SL_ACT_GELU: return skinny ? launch_skinny<T, SL_ACT_GELU>(p, a->batch, st) : launch_tiled<T, SL_ACT_GELU>(p, a->batch, st);
-    case SL_ACT_SILU_MUL: return skinny ? launch_skinny<T, SL_ACT_SILU_MUL>(p, a->batch, st) : launch_tiled<T, SL_ACT_SILU_MUL>(p, a->batch, st);
+    case SL_ACT_NONE: return skinny ? launch_skinny<T, SL_ACT_NONE>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_NONE>(p, a->batch, st);
+    case SL_ACT_GELU: return skinny ? launch_skinny<T, SL_ACT_GELU>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_GELU>(p, a->batch, st);
+    case SL_ACT_SILU_MUL: return skinny ? launch_skinny<T, SL_ACT_SILU_MUL>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_SILU_MUL>(p, a->batch, st);
+    case SL_ACT_ROPE_KV: return launch_skinny<T, SL_ACT_ROPE_KV>(p, sx, a->batch, packed, st);
   }
   sl_set_error("sl_gemm: unknown act %d", a->act);
   return SL_ERR_ARG;
 }
 
-extern "C" int sl_gemm(const sl_gemm_args* a, sl_stream stream) {
+int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, hipStream_t st) {
   SL_CHECK_ARG(a != nullptr, "sl_gemm: null args");
   SL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0, "sl_gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   SL_CHECK_ARG(a->dtype == SL_F32 || a->dtype == SL_BF16, "sl_gemm: bad dtype %d", a->dtype);
   const int vec = a->dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(a->K % vec == 0, "sl_gemm: K=%d must be a multiple of %d", a->K, vec);
-  SL_CHECK_ARG(a->lda % vec == 0 && a->ldw % vec == 0 && a->strideA % vec == 0 && a->strideW % vec == 0,
-               "sl_gemm: lda/ldw/strides must keep rows 16-byte aligned");
+  SL_CHECK_ARG(a->lda % vec == 0 && a->strideA % vec == 0, "sl_gemm: lda/strideA must keep rows 16-byte aligned");
   SL_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "sl_gemm: A and W must be 16-byte aligned");
+  if (a->w_layout == SL_W_PACKED) {
+    SL_CHECK_ARG(a->K % (4 * vec) == 0, "sl_gemm: packed weights need K %% %d == 0", 4 * vec);
+  } else {
+    SL_CHECK_ARG(a->w_layout == SL_W_ROWMAJOR, "sl_gemm: unknown w_layout %d", a->w_layout);
+    SL_CHECK_ARG(a->ldw % vec == 0 && a->strideW % vec == 0, "sl_gemm: ldw/strideW must keep rows 16-byte aligned");
+  }
   if (a->act == SL_ACT_SILU_MUL) SL_CHECK_ARG(a->N % 32 == 0, "sl_gemm: SILU_MUL needs N %% 32 == 0 (16-row gate/up blocks)");
   GemmP p;
   p.A = a->A; p.lda = a->lda; p.sA = a->strideA;
@@ -358,7 +488,25 @@ extern "C" int sl_gemm(const sl_gemm_args* a, sl_stream stream) {
   p.res = a->residual; p.ldr = a->ldr; p.sR = a->strideR;
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
-  hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == SL_F32) return gemm_typed<float>(a, p, st);
-  return gemm_typed<bf16_t>(a, p, st);
+  SkinnyX sx;
+  memset(&sx, 0, sizeof(sx));
+  if (fx) {
+    sx.fuse_rms = fx->fuse_rms; sx.eps = fx->rms_eps;
+    sx.cos = fx->rope_cos; sx.sin = fx->rope_sin; sx.pos = fx->tok_pos; sx.seq = fx->tok_seq;
+    sx.kc = fx->k_cache; sx.vc = fx->v_cache; sx.nh = fx->n_heads; sx.nkv = fx->n_kv_heads; sx.max_ctx = fx->max_ctx;
+  }
+  if (a->act == SL_ACT_ROPE_KV) {
+    SL_CHECK_ARG(fx && fx->rope_cos && fx->rope_sin && fx->tok_pos && fx->tok_seq && fx->k_cache && fx->v_cache,
+                 "sl_gemm: ROPE_KV epilogue needs the sl_gemm_fused tables");
+    SL_CHECK_ARG(a->N == (fx->n_heads + 2 * fx->n_kv_heads) * 128 && a->batch == 1, "sl_gemm: ROPE_KV expects N = (n_heads + 2 n_kv) * 128");
+  }
+  if (a->dtype == SL_F32) return gemm_typed<float>(a, p, sx, st);
+  return gemm_typed<bf16_t>(a, p, sx, st);
+}
+
+extern "C" int sl_gemm(const sl_gemm_args* a, sl_stream stream) { return sl_gemm_impl(a, nullptr, (hipStream_t)stream); }
+
+extern "C" int sl_gemm_fused_decode(const sl_gemm_args* a, const sl_gemm_fused* fx, sl_stream stream) {
+  SL_CHECK_ARG(fx != nullptr, "sl_gemm_fused_decode: null fused args");
+  return sl_gemm_impl(a, fx, (hipStream_t)stream);
 }

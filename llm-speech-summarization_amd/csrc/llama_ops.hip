@@ -301,3 +301,223 @@ extern "C" int sl_greedy_select(const float* logits, int32_t B, int32_t V, const
   return sl_greedy_select_impl(logits, B, V, eos_ids, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
                                out_ids, max_new, (hipStream_t)stream);
 }
+
+// ----------------------------------------------------------------------------------------------
+// fragment-major weight packing (see sl_pack_weight in speechllm.h)
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const T* __restrict__ src, int64_t ld, T* __restrict__ dst, int N, int K) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int KSTEP = 4 * VEC;
+  const int nks = K / KSTEP;
+  const int64_t total = (int64_t)((N + 15) / 16) * nks * 64;  // one 16-byte chunk per (fragment, k-step, lane)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const int64_t fs = i >> 6;
+    const int s = (int)(fs % nks);
+    const int64_t f = fs / nks;
+    const int64_t row = f * 16 + (lane & 15);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < N) v = *(const uint4*)(src + row * ld + (int64_t)s * KSTEP + (lane >> 4) * VEC);
+    *(uint4*)(dst + i * VEC) = v;
+  }
+}
+
+extern "C" int sl_pack_weight(const void* src, int64_t ld_src, void* dst, int32_t N, int32_t K, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(src && dst && N > 0 && K > 0, "sl_pack_weight: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(K % (4 * vec) == 0 && ld_src % vec == 0, "sl_pack_weight: K=%d must be a multiple of %d", K, 4 * vec);
+  const int64_t total = (int64_t)((N + 15) / 16) * (K / (4 * vec)) * 64;
+  const unsigned grid = (unsigned)(ceil_div64(total, 256) < 16384 ? ceil_div64(total, 256) : 16384);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, ld_src, (T*)dst, N, K);
+  });
+  SL_CHECK_LAUNCH("pack_weight");
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Flash-decoding: one-token attention split over the context so that small batches still fill the chip.
+//   grid (kv head, sequence, split); each block owns 64 keys: scores -> local softmax -> partial P.V,
+//   and leaves (O[REP][128], m[REP], l[REP]) in fp32; a second tiny kernel merges the splits.
+// ----------------------------------------------------------------------------------------------
+constexpr int DSPLIT = 64;  // keys per block
+
+template <typename T, int REP>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restrict__ q, int64_t q_stride, const T* __restrict__ kc,
+                                                                const T* __restrict__ vc, float* __restrict__ part,
+                                                                const int32_t* __restrict__ ctx_len, int ctx_add, int nkv, int max_ctx,
+                                                                float scale) {
+  constexpr int D = 128;
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int EPL = D / 16, CPLN = EPL / VEC;
+  constexpr int PSTRIDE = REP * D + 2 * REP;  // floats per partial record
+  __shared__ float sc[REP][DSPLIT];
+  __shared__ float red[16][REP][D];
+  const int kvh = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, gl = lane & 15;
+  const int n_keys = ctx_len[b] + ctx_add;
+  const int k0 = sp * DSPLIT;
+  float* rec = part + (((int64_t)b * nkv + kvh) * nsplit + sp) * PSTRIDE;
+  if (k0 >= n_keys) {  // empty split: neutral record
+    if (tid < REP) { rec[REP * D + tid] = -INFINITY; rec[REP * D + REP + tid] = 0.f; }
+    return;
+  }
+  const int nk = (n_keys - k0) < DSPLIT ? (n_keys - k0) : DSPLIT;
+  const T* kbase = kc + (((int64_t)b * nkv + kvh) * max_ctx + k0) * D;
+  const T* vbase = vc + (((int64_t)b * nkv + kvh) * max_ctx + k0) * D;
+
+  // phase 1: scores, 4 passes of 16 keys, all loads issued first
+  float qr[REP][EPL];
+#pragma unroll
+  for (int h = 0; h < REP; ++h) {
+    const T* qp = q + (int64_t)b * q_stride + (int64_t)(kvh * REP + h) * D + gl * EPL;
+#pragma unroll
+    for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(*(const uint4*)(qp + c * VEC), &qr[h][c * VEC]);
+  }
+  uint4 kraw[4][CPLN];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    int key = ps * 16 + wave * 4 + grp;
+    key = key < nk ? key : nk - 1;
+#pragma unroll
+    for (int c = 0; c < CPLN; ++c) kraw[ps][c] = *(const uint4*)(kbase + (int64_t)key * D + gl * EPL + c * VEC);
+  }
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int key = ps * 16 + wave * 4 + grp;
+    float kf[EPL];
+#pragma unroll
+    for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(kraw[ps][c], &kf[c * VEC]);
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d = fmaf(qr[h][e], kf[e], d);
+      d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+      if (gl == 0) sc[h][key] = key < nk ? d * scale : -INFINITY;
+    }
+  }
+  __syncthreads();
+  // phase 2: local softmax, one wave per head, one key per lane
+  for (int h = wave; h < REP; h += 4) {
+    const float s = sc[h][lane];
+    const float m = wave_max(s);
+    const float p = __expf(s - m);  // masked keys: exp(-inf) = 0
+    const float l = wave_sum(p);
+    sc[h][lane] = p;
+    if (lane == 0) { rec[REP * D + h] = m; rec[REP * D + REP + h] = l; }
+  }
+  __syncthreads();
+  // phase 3: partial P.V
+  {
+    const int kg = tid >> 4, dc = tid & 15;
+    uint4 vraw[4][CPLN];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      int key = kg + 16 * ps;
+      key = key < nk ? key : nk - 1;
+#pragma unroll
+      for (int c = 0; c < CPLN; ++c) vraw[ps][c] = *(const uint4*)(vbase + (int64_t)key * D + dc * EPL + c * VEC);
+    }
+    float acc[REP][EPL];
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[h][e] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int key = kg + 16 * ps;
+      float vf[EPL];
+#pragma unroll
+      for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(vraw[ps][c], &vf[c * VEC]);
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        const float p = sc[h][key];  // 0 for keys past nk
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[h][e] = fmaf(p, vf[e], acc[h][e]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) red[kg][h][dc * EPL + e] = acc[h][e];
+  }
+  __syncthreads();
+  for (int o = tid; o < REP * D; o += 256) {
+    const int h = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) s += red[kg][h][d];
+    rec[h * D + d] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ out, int nh, int nkv,
+                                                                  int nsplit) {
+  constexpr int D = 128;
+  const int b = blockIdx.y, head = blockIdx.x, d = threadIdx.x;
+  const int rep = nh / nkv, kvh = head / rep, h = head % rep;
+  const int pstride = rep * D + 2 * rep;
+  const float* base = part + ((int64_t)b * nkv + kvh) * nsplit * pstride;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, base[(int64_t)s * pstride + rep * D + h]);
+  float L = 0.f, o = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* rec = base + (int64_t)s * pstride;
+    const float m = rec[rep * D + h];
+    if (m == -INFINITY) continue;
+    const float w = __expf(m - M);
+    L += w * rec[rep * D + rep + h];
+    o += w * rec[h * D + d];
+  }
+  out[((int64_t)b * nh + head) * D + d] = from_f32<T>(L > 0.f ? o / L : 0.f);
+}
+
+size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx) {
+  const int rep = n_heads / n_kv, nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;
+  return (size_t)B * n_kv * nsplit * (rep * 128 + 2 * rep) * sizeof(float);
+}
+
+template <typename T, int REP>
+static int launch_attn_decode_split(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, float* part,
+                                    const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
+  const int nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;
+  hipLaunchKernelGGL((attn_decode_split_kernel<T, REP>), dim3(nkv, B, nsplit), dim3(256), 0, st, (const T*)q, q_stride, (const T*)kc,
+                     (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale);
+  SL_CHECK_LAUNCH("attn_decode_split");
+  hipLaunchKernelGGL((attn_decode_combine_kernel<T>), dim3(nh, B), dim3(128), 0, st, part, (T*)out, nh, nkv, nsplit);
+  SL_CHECK_LAUNCH("attn_decode_combine");
+  return 0;
+}
+
+int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
+                              const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
+                              float scale, int32_t dtype, hipStream_t st) {
+  SL_CHECK_ARG(q && k_cache && v_cache && out && workspace && ctx_len && B > 0, "sl_attn_decode_split: bad arguments");
+  SL_CHECK_ARG(D == 128, "sl_attn_decode_split: head_dim %d not built (128)", D);
+  SL_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "sl_attn_decode_split: n_heads %% n_kv != 0");
+  float* part = (float*)workspace;
+  const int rep = n_heads / n_kv;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    switch (rep) {
+      case 1: return launch_attn_decode_split<T, 1>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      case 2: return launch_attn_decode_split<T, 2>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      case 3: return launch_attn_decode_split<T, 3>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      case 4: return launch_attn_decode_split<T, 4>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      default: sl_set_error("sl_attn_decode_split: n_heads/n_kv=%d not built (1..4)", rep); return SL_ERR_UNSUPPORTED;
+    }
+  });
+}
+
+extern "C" size_t sl_attn_decode_workspace_bytes(int32_t B, int32_t n_heads, int32_t n_kv, int32_t max_ctx) {
+  return sl_attn_decode_split_ws(B, n_heads, n_kv, max_ctx);
+}
+
+extern "C" int sl_attn_decode_split(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
+                                    const int32_t* ctx_len, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx, float scale,
+                                    int32_t dtype, sl_stream stream) {
+  return sl_attn_decode_split_impl(q, q_stride, k_cache, v_cache, out, workspace, ctx_len, 0, B, n_heads, n_kv, D, max_ctx, scale, dtype,
+                                   (hipStream_t)stream);
+}

@@ -12,6 +12,12 @@ int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32
                           int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
                           int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st);
 
+int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
+                              const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
+                              float scale, int32_t dtype, hipStream_t st);
+size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx);
+int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, hipStream_t st);
+
 namespace {
 
 struct Carver {
@@ -224,7 +230,7 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
 // Llama
 // ================================================================================================
 struct LlamaWs {
-  void *h, *qkv, *att, *mid, *last;
+  void *h, *qkv, *att, *mid, *last, *part;
   int32_t *tok_seq, *tok_pos, *cu, *cuk, *klen;
 };
 
@@ -237,6 +243,7 @@ static size_t llama_carve(const sl_llama_model* m, int64_t n_tok, int nseq, void
   w.att = c.take(n_tok * (int64_t)m->n_heads * m->head_dim * sz);
   w.mid = c.take(n_tok * (int64_t)m->ffn * sz);
   w.last = c.take((size_t)nseq * m->hidden * sz);
+  w.part = c.take(nseq <= 64 ? sl_attn_decode_split_ws(nseq, m->n_heads, m->n_kv_heads, m->rope_len) : 0);  // rope_len >= max_ctx
   w.tok_seq = (int32_t*)c.take(n_tok * sizeof(int32_t));
   w.tok_pos = (int32_t*)c.take(n_tok * sizeof(int32_t));
   w.cu = (int32_t*)c.take((nseq + 1) * sizeof(int32_t));
@@ -263,21 +270,52 @@ static inline size_t kv_layer_bytes(const sl_llama_model* m, const sl_kv_cache* 
 }
 
 // one decoder layer over `n` token rows; attention chosen by `decode`
+// decode GEMM on the fragment-packed weights, optionally absorbing the preceding RMSNorm / RoPE+KV-append
+static int dec_gemm(const sl_llama_model* m, const void* A, int64_t lda, const void* Wp, void* C, int64_t ldc, const void* res, int M, int N,
+                    int K, int act, int out_f32, const sl_gemm_fused* fx, hipStream_t st) {
+  sl_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.W = Wp; a.ldw = K; a.C = C; a.ldc = ldc; a.residual = res; a.ldr = ldc;
+  a.M = M; a.N = N; a.K = K; a.batch = 1; a.dtype = m->dtype; a.act = act; a.out_f32 = out_f32; a.w_layout = SL_W_PACKED;
+  return sl_gemm_impl(&a, fx, st);
+}
+
+// one decoder layer over `n` token rows; attention chosen by `decode`
 static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, void* x, int64_t n, LlamaWs& w, bool decode, int nseq,
                        int max_qlen, const int32_t* ctx_len_dev, hipStream_t st) {
   const sl_llama_layer& L = m->layers[l];
   const int dt = m->dtype, H = m->hidden, D = m->head_dim, nh = m->n_heads, nkv = m->n_kv_heads;
   const int qkv_w = (nh + 2 * nkv) * D;
-  const size_t sz = sl_dtype_size(dt);
   void* kc = bptr(kv->k_cache) + (size_t)l * kv_layer_bytes(m, kv);
   void* vc = bptr(kv->v_cache) + (size_t)l * kv_layer_bytes(m, kv);
   const float scale = 1.0f / sqrtf((float)D);
+  if (decode && L.wqkv_dec && L.wo_dec && L.wgu_dec && L.wdown_dec) {
+    // 5-6 launches per layer: [norm+]qkv+rope+append | attention (split + merge) | o+res | [norm+]gate/up+silu.mul | down+res
+    sl_gemm_fused fx;
+    memset(&fx, 0, sizeof(fx));
+    fx.fuse_rms = m->dec_fused_norm; fx.rms_eps = m->rms_eps;
+    fx.rope_cos = m->rope_cos; fx.rope_sin = m->rope_sin; fx.tok_pos = ctx_len_dev; fx.tok_seq = w.tok_seq;
+    fx.k_cache = kc; fx.v_cache = vc; fx.n_heads = nh; fx.n_kv_heads = nkv; fx.max_ctx = kv->max_ctx;
+    const void* a_in = x;
+    if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
+    SL_TRY(dec_gemm(m, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st));
+    SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
+    SL_TRY(dec_gemm(m, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st));
+    sl_gemm_fused fn;
+    memset(&fn, 0, sizeof(fn));
+    fn.fuse_rms = m->dec_fused_norm; fn.rms_eps = m->rms_eps;
+    a_in = x;
+    if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
+    SL_TRY(dec_gemm(m, a_in, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st));
+    SL_TRY(dec_gemm(m, w.mid, m->ffn, L.wdown_dec, x, H, x, (int)n, H, m->ffn, SL_ACT_NONE, 0, nullptr, st));
+    return 0;
+  }
   SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st));
   SL_TRY(gemm(dt, w.h, H, L.wqkv, H, w.qkv, qkv_w, nullptr, nullptr, 0, (int)n, qkv_w, H, SL_ACT_NONE, 0, st));
   SL_TRY(sl_rope_kv_append(w.qkv, kc, vc, w.tok_seq, decode ? ctx_len_dev : w.tok_pos, m->rope_cos, m->rope_sin, n, nh, nkv, D, kv->max_ctx,
                            dt, (sl_stream)st));
   if (decode) {
-    SL_TRY(sl_attn_decode_impl(w.qkv, qkv_w, kc, vc, w.att, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
+    SL_TRY(sl_attn_decode_split_impl(w.qkv, qkv_w, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
   } else {
     sl_attn_args a;
     memset(&a, 0, sizeof(a));
@@ -293,7 +331,6 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
   SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st));
   SL_TRY(gemm(dt, w.h, H, L.wgu, H, w.mid, m->ffn, nullptr, nullptr, 0, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, st));
   SL_TRY(gemm(dt, w.mid, m->ffn, L.wdown, m->ffn, x, H, nullptr, x, H, (int)n, H, m->ffn, SL_ACT_NONE, 0, st));
-  (void)sz;
   return 0;
 }
 
@@ -348,6 +385,14 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
   const int dt = m->dtype, H = m->hidden;
   SL_TRY(sl_embed_gather(m->embed, next_ids, x, B, H, dt, (sl_stream)st));
   for (int l = 0; l < m->n_layers; ++l) SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st));
+  if (m->lm_head_dec) {
+    sl_gemm_fused fx;
+    memset(&fx, 0, sizeof(fx));
+    fx.fuse_rms = m->dec_fused_norm; fx.rms_eps = m->rms_eps;
+    const void* a_in = x;
+    if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.last; }
+    return dec_gemm(m, a_in, H, m->lm_head_dec, logits, m->vocab, nullptr, B, m->vocab, H, SL_ACT_NONE, 1, &fx, st);
+  }
   SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st));
   SL_TRY(gemm(dt, w.last, H, m->lm_head, H, logits, m->vocab, nullptr, nullptr, 0, B, m->vocab, H, SL_ACT_NONE, 1, st));
   return 0;

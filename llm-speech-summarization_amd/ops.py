@@ -152,3 +152,50 @@ def greedy_select(logits, eos_ids, pad_id, use_eos, unfinished, ctx_len, gen_cou
     L.check(L.lib().sl_greedy_select(L.ptr(logits), B, V, eos, len(eos_ids), pad_id, int(use_eos), L.ptr(unfinished), L.ptr(ctx_len),
                                      L.ptr(gen_count), L.ptr(finish_len), L.ptr(next_ids), L.ptr(out_ids), out_ids.shape[1],
                                      L.stream_ptr()), "sl_greedy_select")
+
+
+def pack_weight(W: torch.Tensor) -> torch.Tensor:
+    """(N,K) row-major -> fragment-packed buffer for the decode kernel (sl_pack_weight)."""
+    L.require_gpu(W, "W")
+    n, k = W.shape
+    out = torch.empty(((n + 15) // 16 * 16, k), device=W.device, dtype=W.dtype)
+    L.check(L.lib().sl_pack_weight(L.ptr(W), W.stride(0), L.ptr(out), n, k, L.dtype_code(W.dtype), L.stream_ptr()), "sl_pack_weight")
+    return out
+
+
+def gemm_decode(A: torch.Tensor, Wp: torch.Tensor, N: int, *, residual=None, act: int = L.ACT_NONE, out_f32: bool = False,
+                fuse_rms: bool = False, eps: float = 1e-5, rope=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode GEMM on packed weights.  rope = dict(cos, sin, pos, seq, k_cache, v_cache, n_heads, n_kv, max_ctx) for ACT_ROPE_KV."""
+    M, K = A.shape
+    if act == L.ACT_SILU_MUL:
+        n_out = N // 2
+    elif act == L.ACT_ROPE_KV:
+        n_out = rope["n_heads"] * 128
+    else:
+        n_out = N
+    if out is None:
+        out = torch.empty((M, n_out), device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
+    a = L.GemmArgs()
+    a.A, a.lda = L.ptr(A), A.stride(0)
+    a.W, a.ldw = L.ptr(Wp), K
+    a.C, a.ldc = L.ptr(out), out.stride(0)
+    a.residual, a.ldr = L.ptr(residual), (residual.stride(0) if residual is not None else 0)
+    a.M, a.N, a.K, a.batch = M, N, K, 1
+    a.dtype, a.act, a.out_f32, a.w_layout = L.dtype_code(A.dtype), act, int(out_f32), L.W_PACKED
+    f = L.GemmFused()
+    f.fuse_rms, f.rms_eps = int(fuse_rms), eps
+    if rope is not None:
+        f.rope_cos, f.rope_sin, f.tok_pos, f.tok_seq = L.ptr(rope["cos"]), L.ptr(rope["sin"]), L.ptr(rope["pos"]), L.ptr(rope["seq"])
+        f.k_cache, f.v_cache = L.ptr(rope["k_cache"]), L.ptr(rope["v_cache"])
+        f.n_heads, f.n_kv_heads, f.max_ctx = rope["n_heads"], rope["n_kv"], rope["max_ctx"]
+    L.check(L.lib().sl_gemm_fused_decode(C.byref(a), C.byref(f), L.stream_ptr()), "sl_gemm_fused_decode")
+    return out
+
+
+def attn_decode_split(q, q_stride, k_cache, v_cache, ctx_len, n_heads, n_kv, D, max_ctx, scale) -> torch.Tensor:
+    B = ctx_len.shape[0]
+    out = torch.empty((B, n_heads * D), device=q.device, dtype=q.dtype)
+    ws = torch.empty(int(L.lib().sl_attn_decode_workspace_bytes(B, n_heads, n_kv, max_ctx)), dtype=torch.uint8, device=q.device)
+    L.check(L.lib().sl_attn_decode_split(L.ptr(q), q_stride, L.ptr(k_cache), L.ptr(v_cache), L.ptr(out), L.ptr(ws), L.ptr(ctx_len), B,
+                                         n_heads, n_kv, D, max_ctx, scale, L.dtype_code(q.dtype), L.stream_ptr()), "sl_attn_decode_split")
+    return out

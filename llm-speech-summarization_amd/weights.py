@@ -262,6 +262,54 @@ class LlamaDeviceWeights:
             lay.wdown = dev(sd[p + "mlp.down_proj.weight"]).data_ptr()
         m.layers = C.cast(self._layers, C.POINTER(L.LlamaLayer))
         self.struct = m
+        self.decode_packed = False
+
+    def build_decode_weights(self, fuse_norm: Optional[bool] = None) -> None:
+        """Second, decode-only copy of every matrix in the fragment-packed layout the weight-streaming kernel
+        reads at full HBM rate (sl_pack_weight), q/k rows in rotate_half pair order for the fused RoPE epilogue
+        and — in bf16 mode — the RMSNorm gains folded in (sl_gemm_fused).  Costs one extra copy of the
+        weights in HBM (6.4 GB bf16 for Llama-3.2-3B of 288 GB); the prefill path keeps the row-major set."""
+        if self.decode_packed:
+            return
+        a, dt, dev_ = self.arch, self.dtype, self.device
+        if fuse_norm is None:
+            fuse_norm = dt == torch.bfloat16  # fp32 = parity mode: keep the reference's op order exactly
+        lib, code = L.lib(), L.dtype_code(dt)
+        kstep = 32 if dt == torch.bfloat16 else 16
+        H, D, nh, nkv, F_ = a.hidden_size, a.head_dim, a.num_attention_heads, a.num_key_value_heads, a.intermediate_size
+        if H % kstep or (nh * D) % kstep or F_ % kstep:
+            return  # shapes the packed kernel does not take: decode stays on the row-major path
+
+        def pack(t: torch.Tensor) -> torch.Tensor:
+            t = t.contiguous()
+            n, k = t.shape
+            out = torch.empty(((n + 15) // 16 * 16, k), device=dev_, dtype=dt)
+            L.check(lib.sl_pack_weight(t.data_ptr(), t.stride(0), out.data_ptr(), n, k, code, L.stream_ptr()), "sl_pack_weight")
+            self._keep.append(out)
+            return out
+
+        def fold(w: torch.Tensor, gain: torch.Tensor) -> torch.Tensor:
+            return (w.float() * gain.float()[None, :]).to(dt) if fuse_norm else w
+
+        blk = torch.arange(16, device=dev_)
+        head_perm = torch.cat([torch.cat([blk + 16 * j, blk + 64 + 16 * j]) for j in range(4)])  # [0:16],[64:80],[16:32],...
+        perm = torch.cat([head_perm + 128 * h for h in range(nh + nkv)] + [torch.arange((nh + nkv) * 128, (nh + 2 * nkv) * 128, device=dev_)])
+        by_ptr = {t.data_ptr(): t for t in self._keep}
+        self.dec_wgu: List[torch.Tensor] = []
+        for li in range(a.num_hidden_layers):
+            lay = self._layers[li]
+            wqkv, wo, wgu, wdown = by_ptr[lay.wqkv], by_ptr[lay.wo], by_ptr[lay.wgu], by_ptr[lay.wdown]
+            n1, n2 = by_ptr[lay.norm1], by_ptr[lay.norm2]
+            lay.wqkv_dec = pack(fold(wqkv, n1)[perm]).data_ptr()
+            lay.wo_dec = pack(wo).data_ptr()
+            wgu_p = pack(fold(wgu, n2))
+            self.dec_wgu.append(wgu_p)
+            lay.wgu_dec = wgu_p.data_ptr()
+            lay.wdown_dec = pack(wdown).data_ptr()
+        self.struct.lm_head_dec = pack(fold(self.lm_head, by_ptr[self.struct.final_norm])).data_ptr()
+        self.struct.dec_fused_norm = int(bool(fuse_norm))
+        torch.cuda.synchronize(dev_)
+        self.decode_packed = True
 
     def n_params(self) -> int:
         return sum(t.numel() for t in self._keep if t.dtype == self.dtype)

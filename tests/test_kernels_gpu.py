@@ -275,3 +275,81 @@ def test_greedy_select_semantics():
     assert unfinished.tolist() == [1, 1, 0, 0]
     assert ctx.tolist() == [6, 7, 8, 9] and gen.tolist() == [1, 2, 3, 4] and fin.tolist() == [0, 0, 3, 0]
     assert out[0, 0] == 777 and out[1, 1] == 10 and out[2, 2] == 7 and out[3, 3] == 99
+
+
+# ---- decode-path kernels: packed weights, fused RMSNorm, fused RoPE + KV append, flash-decoding ----------
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [1, 16, 17, 40])
+@pytest.mark.parametrize("N,K", [(3072, 3072), (5120, 1024), (1000, 256), (33000, 512)])
+def test_gemm_packed_matches_rowmajor_reference(dt, M, N, K):
+    A, W, R = rnd(M, K, seed=31), rnd(N, K, seed=32, std=K ** -0.5), rnd(M, N, seed=33)
+    Wd = W.to(dev(), dt)
+    Wp = ops.pack_weight(Wd)
+    assert Wp.shape[0] == (N + 15) // 16 * 16
+    ref = q(A, dt) @ q(W, dt).T + q(R, dt)
+    out = ops.gemm_decode(A.to(dev(), dt), Wp, N, residual=R.to(dev(), dt))
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+    assert rel_err(ops.gemm_decode(A.to(dev(), dt), Wp, N, out_f32=True).cpu(), q(A, dt) @ q(W, dt).T) < 2e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [1, 16, 33])
+def test_gemm_packed_fused_rmsnorm_and_silu(dt, M):
+    H, Fd = 512, 1024
+    x, gain = rnd(M, H, seed=34), 1 + rnd(H, seed=35, std=0.1)
+    g, u = rnd(Fd, H, seed=36, std=H ** -0.5), rnd(Fd, H, seed=37, std=H ** -0.5)
+    xf = q(x, dt)
+    normed = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
+    wg, wu = q(g * gain[None], dt), q(u * gain[None], dt)      # gain folded into the weight, then rounded
+    ref = F.silu(normed @ wg.T) * (normed @ wu.T)
+    wgu = weights.interleave_gate_up(g * gain[None], u * gain[None]).to(dev(), dt)
+    out = ops.gemm_decode(x.to(dev(), dt), ops.pack_weight(wgu), 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5)
+    assert out.shape == (M, Fd)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [1, 5, 16])
+def test_gemm_packed_rope_kv_epilogue_equals_separate_kernels(dt, M):
+    arch = weights.LlamaArch(hidden_size=256, num_attention_heads=6, num_key_value_heads=2, head_dim=128,
+                             rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                               original_max_position_embeddings=8192))
+    nh, nkv, D, H, max_ctx = 6, 2, 128, 256, 64
+    cos, sin = [t_.to(dev()) for t_ in weights.rope_tables(arch, max_ctx)]
+    x = rnd(M, H, seed=38).to(dev(), dt)
+    W = rnd((nh + 2 * nkv) * D, H, seed=39, std=H ** -0.5).to(dev(), dt)
+    pos = torch.tensor([(7 * i + 3) % max_ctx for i in range(M)], dtype=torch.int32, device=dev())
+    seq = torch.arange(M, dtype=torch.int32, device=dev())
+    # reference path: plain GEMM -> sl_rope_kv_append
+    qkv = ops.gemm(x, W, out_f32=False)
+    kc1 = torch.zeros(M, nkv, max_ctx, D, device=dev(), dtype=dt); vc1 = torch.zeros_like(kc1)
+    ops.rope_kv_append(qkv, kc1, vc1, seq, pos, cos, sin, nh, nkv, D, max_ctx)
+    # fused path: rows of q/k heads in rotate_half pair order
+    blk = torch.arange(16)
+    hp = torch.cat([torch.cat([blk + 16 * j, blk + 64 + 16 * j]) for j in range(4)])
+    perm = torch.cat([hp + 128 * h for h in range(nh + nkv)] + [torch.arange((nh + nkv) * 128, (nh + 2 * nkv) * 128)])
+    Wp = ops.pack_weight(W[perm.to(dev())].contiguous())
+    kc2 = torch.zeros_like(kc1); vc2 = torch.zeros_like(kc1)
+    qout = ops.gemm_decode(x, Wp, (nh + 2 * nkv) * D, act=L.ACT_ROPE_KV,
+                           rope=dict(cos=cos, sin=sin, pos=pos, seq=seq, k_cache=kc2, v_cache=vc2, n_heads=nh, n_kv=nkv, max_ctx=max_ctx))
+    tol = 1e-6 if dt == torch.float32 else 8e-3   # bf16: the fused path rounds once instead of twice
+    assert rel_err(qout.float().cpu(), qkv[:, :nh * D].float().cpu()) < tol
+    assert rel_err(kc2.float().cpu(), kc1.float().cpu()) < tol
+    assert rel_err(vc2.float().cpu(), vc1.float().cpu()) < tol
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("nh,nkv", [(6, 2), (2, 2)])
+def test_attn_decode_split_matches_reference(dt, nh, nkv):
+    D, max_ctx, B = 128, 448, 4
+    lens = [1, 64, 65, 393]
+    kc = rnd(B, nkv, max_ctx, D, seed=40).to(dev(), dt)
+    vc = rnd(B, nkv, max_ctx, D, seed=41).to(dev(), dt)
+    qd = rnd(B, nh * D, seed=42).to(dev(), dt)
+    ctx = torch.tensor(lens, dtype=torch.int32, device=dev())
+    out = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    out1 = ops.attn_decode(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    for s, n in enumerate(lens):
+        ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
+        assert rel_err(out[s], ref[0]) < TOL[dt]
+        assert rel_err(out1[s], ref[0]) < TOL[dt]
