@@ -248,9 +248,28 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
   const float* row = logits + (int64_t)b * V;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = tid; i < V; i += 1024) {
-    const float v = row[i];
+  auto upd = [&](float v, int i) {
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }   // NaN never wins, like a strict '>' scan
+  };
+  if ((V & 3) == 0) {  // 16-byte loads, four in flight per thread: the scan is latency-bound otherwise
+    const float4* row4 = (const float4*)row;
+    const int n4 = V >> 2;
+    for (int i0 = tid; i0 < n4; i0 += 4096) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 1024;
+        v[u] = i < n4 ? row4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u * 1024 >= n4) continue;
+        const int i = (i0 + u * 1024) * 4;
+        upd(v[u].x, i); upd(v[u].y, i + 1); upd(v[u].z, i + 2); upd(v[u].w, i + 3);
+      }
+    }
+  } else {
+    for (int i = tid; i < V; i += 1024) upd(row[i], i);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
