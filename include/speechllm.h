@@ -95,6 +95,19 @@ typedef struct {
 } sl_gemm_fused;
 int sl_gemm_fused_decode(const sl_gemm_args* a, const sl_gemm_fused* fx, sl_stream stream);
 
+/* Backward-pass forms of sl_gemm (training; always the tiled MFMA kernel):
+ *   trans_a: A is stored as (K, M) with row stride lda  — C = A^T-stored . W^T   (e.g. dW = dY^T X)
+ *   trans_w: W is stored as (K, N) with row stride ldw  — C = A . W-stored       (e.g. dX = dY W)
+ *            transposed operands are read in 16-byte chunks along the OUTPUT index: lda/ldw must be
+ *            multiples of 8 (bf16) / 4 (f32) and each stored row readable up to that multiple.
+ *   aux_out: also store the pre-activation (after bias, before act) — what GELU's backward needs.
+ *   residual_f32: with out_f32, the residual is float: C = residual + A.W^T accumulates fp32 gradients. */
+typedef struct {
+  int32_t trans_a, trans_w, residual_f32, reserved;
+  void* aux_out;
+} sl_gemm_ex_args;
+int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);
+
 /* LayerNorm over the last dim, optional fused GELU (conv layers: hf:...hubert.py:144-150;
  * encoder LNs hf:...hubert.py:515,517,612; feature projection :226).  In-place allowed. */
 int sl_layernorm(const void* x, void* y, const void* gamma, const void* beta, int64_t rows, int32_t cols,
@@ -180,6 +193,58 @@ int sl_attn_decode_split(const void* q, int64_t q_stride, const void* k_cache, c
 int sl_greedy_select(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids_host, int32_t n_eos,
                      int32_t pad_id, int32_t use_eos, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
                      int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Knowledge-distillation step (ref:trainer.py:270-374): backward and loss kernels.  GEMM-shaped
+ * backward work (dgrad, wgrad, attention products) runs on sl_gemm_ex.
+ * ------------------------------------------------------------------------------------------- */
+/* dx = dy * gelu'(pre)  (pre = aux_out of the forward GEMM). */
+int sl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, sl_stream stream);
+/* y = a*x + b*y (gradient accumulation at residual joins). */
+int sl_axpby(const void* x, void* y, float a, float b, int64_t n, int32_t dtype, sl_stream stream);
+/* SwiGLU on the 16-row interleaved gate/up activation gu (M, 2F): out (M, F) = silu(g)*u; backward
+ * writes d gu in the same interleaved layout (hf:models/llama/modeling_llama.py:175). */
+int sl_silu_mul(const void* gu, void* out, int64_t M, int32_t F, int32_t dtype, sl_stream stream);
+int sl_silu_mul_bwd(const void* gu, const void* dy, void* dgu, int64_t M, int32_t F, int32_t dtype, sl_stream stream);
+/* RoPE in place on the first n_rot heads of (n_tok, heads*D) rows; inverse != 0 applies the transposed
+ * rotation (the backward of apply_rotary_pos_emb, hf:...llama.py:130-160). */
+int sl_rope_inplace(void* x, const int32_t* tok_pos, const float* cos, const float* sin, int64_t n_tok, int32_t heads,
+                    int32_t n_rot, int32_t D, int32_t inverse, int32_t dtype, sl_stream stream);
+/* LayerNorm backward, optionally through a fused GELU (HuBERT conv layers): dx (may alias dy) and
+ * fp32 dgamma/dbeta ACCUMULATED into the given buffers (may be NULL for input-only gradients). */
+int sl_layernorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma,
+                     float* dbeta, int64_t rows, int32_t cols, float eps, int32_t gelu, int32_t dtype, sl_stream stream);
+/* LlamaRMSNorm backward, data gradient only (the LLM is frozen, ref:trainer.py:63-64). */
+int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps,
+                   int32_t dtype, sl_stream stream);
+/* out[c] += sum_r x[r][c]  (bias gradients), fp32 accumulate. */
+int sl_colsum(const void* x, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t dtype, sl_stream stream);
+/* Explicit softmax over rows of fp32 scores (n_mats matrices of rows x cols, row stride ld):
+ * P = softmax(scale*S [+ causal mask: column j visible to row i iff j <= i + cols - rows]); columns
+ * [cols, ld) of P are zeroed.  Backward: dS = scale * P * (dP - rowsum(dP*P)). */
+int sl_softmax_rows(const float* S, void* P, int64_t n_mats, int32_t rows, int32_t cols, int64_t ld, float scale,
+                    int32_t causal, int32_t dtype, sl_stream stream);
+int sl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t nrows, int32_t cols, int64_t ld, float scale,
+                   int32_t dtype, sl_stream stream);
+/* Losses over rows of fp32 logits; *loss += coef * sum_rows(...), d logits (+)= coef * grad (dtype T):
+ *   ce:      lse(s) - s[label]                    (ref:model/audio_llama.py:72-101 with coef = w/(n-1))
+ *   soft-ce: -sum softmax(t) * log_softmax(s)     (ref:utils.py:167-178 with coef = w/n)
+ *   mse:     mean((a-b)^2)                        (ref:trainer.py:358-370) */
+int sl_ce_loss(const float* logits, const int32_t* labels, int64_t rows, int32_t V, float coef, float* loss, void* dlogits,
+               int32_t accumulate, int32_t dtype, sl_stream stream);
+int sl_soft_ce_loss(const float* student, const float* teacher, int64_t rows, int32_t V, float coef, float* loss,
+                    void* dstudent, int32_t accumulate, int32_t dtype, sl_stream stream);
+int sl_mse_loss(const void* a, const void* b, int64_t n, float coef, float* loss, void* da, int32_t accumulate,
+                int32_t dtype, sl_stream stream);
+/* HuBERT front-end backward: AvgPool1d, strided-conv data gradient (col2im of the dgrad GEMM output),
+ * fused conv0 (recomputes conv+LN, accumulates fp32 grads of w (C,k), bias, gamma, beta). */
+int sl_avgpool_bwd(const void* dy, void* dx, int64_t T, int32_t H, int32_t kernel, int32_t stride, int64_t P, int32_t dtype,
+                   sl_stream stream);
+int sl_col2im(const void* dcol, void* dx, int64_t Lin, int64_t Lout, int32_t C, int32_t k, int32_t s, int32_t dtype,
+              sl_stream stream);
+int sl_hubert_conv0_bwd(const float* wave, int64_t n_samples, const float* w, const float* bias, const float* gamma,
+                        const float* beta, const void* dy, int32_t C, int32_t k, int32_t stride, float eps, float* dw,
+                        float* dbias, float* dgamma, float* dbeta, int32_t dtype, sl_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-model entry points (C++ host runtime inside the library: layer loops, workspace carving,

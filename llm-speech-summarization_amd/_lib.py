@@ -40,6 +40,10 @@ class GemmFused(C.Structure):
                 ("k_cache", c_vp), ("v_cache", c_vp), ("n_heads", c_i32), ("n_kv_heads", c_i32), ("max_ctx", c_i32), ("reserved", c_i32)]
 
 
+class GemmEx(C.Structure):
+    _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("reserved", c_i32), ("aux_out", c_vp)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", c_vp), ("q_row_stride", c_i64), ("q_head_stride", c_i64),
                 ("k", c_vp), ("k_row_stride", c_i64), ("k_head_stride", c_i64),
@@ -98,6 +102,24 @@ _PROTOS = {
     "sl_gemm_fused_decode": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmFused), c_vp]),
     "sl_attn_decode_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "sl_attn_decode_split": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "sl_gemm_ex": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmEx), c_vp]),
+    "sl_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "sl_axpby": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_i64, c_i32, c_vp]),
+    "sl_silu_mul": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "sl_silu_mul_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "sl_rope_inplace": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sl_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32, c_vp]),
+    "sl_rmsnorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),
+    "sl_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "sl_softmax_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_f32, c_i32, c_i32, c_vp]),
+    "sl_softmax_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_i32, c_vp]),
+    "sl_ce_loss": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "sl_soft_ce_loss": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "sl_mse_loss": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "sl_avgpool_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
+    "sl_col2im": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sl_hubert_conv0_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                    c_i32, c_vp]),
     "sl_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32, c_vp]),
     "sl_rmsnorm": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),
     "sl_hubert_conv0": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),

@@ -17,6 +17,9 @@ struct GemmP {
   const void* res; int64_t ldr, sR;
   int M, N, K, out_f32;
   int tiles_m, tiles_n;
+  int ta, tw;          // operand stored transposed: A as (K, M) rows lda; W as (K, N) rows ldw
+  void* aux;           // optional: pre-activation values (after bias, before act), same layout/dtype as C
+  int res_f32;         // residual is float (fp32 gradient accumulation: C = C_old + A.W^T with out_f32)
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -24,7 +27,7 @@ struct GemmP {
 // ----------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void store_out(const GemmP& p, void* Cb, const void* Rb, int64_t row, int64_t col, float v) {
-  if (Rb) v += to_f32(((const T*)Rb)[row * p.ldr + col]);
+  if (Rb) v += p.res_f32 ? ((const float*)Rb)[row * p.ldr + col] : to_f32(((const T*)Rb)[row * p.ldr + col]);
   if (p.out_f32)
     ((float*)Cb)[row * p.ldc + col] = v;
   else
@@ -78,6 +81,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
     so[i] = lds_off(row, ch);
   }
   kc = (tid & 7) * VEC;
+  // transposed operands (backward GEMMs): 16-byte chunks run along the OUTPUT index, one reduction row each
+  constexpr int CPRT = 128 / VEC;  // chunks per reduction row of a 128-wide tile
+  const T* gat[4];
+  const T* gwt[4];
+  int tk[4], tcol[4];
+  bool aok[4], wok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    tk[i] = c / CPRT;
+    tcol[i] = (c % CPRT) * VEC;
+    const int am = bm * TBM + tcol[i], wn = bn * TBN + tcol[i];
+    aok[i] = am < p.M; wok[i] = wn < p.N;
+    gat[i] = A + (int64_t)tk[i] * p.lda + (aok[i] ? am : 0);
+    gwt[i] = W + (int64_t)tk[i] * p.ldw + (wok[i] ? wn : 0);
+  }
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -93,15 +112,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
     const bool ok = (k0 + kc) < p.K;  // K % VEC == 0, so a chunk is entirely in or out
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = ok ? *(const uint4*)(ga[i] + k0) : make_uint4(0, 0, 0, 0);
-      rw[i] = ok ? *(const uint4*)(gw[i] + k0) : make_uint4(0, 0, 0, 0);
+      if (p.ta) ra[i] = (aok[i] && k0 + tk[i] < p.K) ? *(const uint4*)(gat[i] + (int64_t)k0 * p.lda) : make_uint4(0, 0, 0, 0);
+      else ra[i] = ok ? *(const uint4*)(ga[i] + k0) : make_uint4(0, 0, 0, 0);
+      if (p.tw) rw[i] = (wok[i] && k0 + tk[i] < p.K) ? *(const uint4*)(gwt[i] + (int64_t)k0 * p.ldw) : make_uint4(0, 0, 0, 0);
+      else rw[i] = ok ? *(const uint4*)(gw[i] + k0) : make_uint4(0, 0, 0, 0);
     }
+  };
+  // transposed chunk -> LDS: element e belongs to tile row tcol+e, reduction index tk
+  auto scatter = [&](unsigned char* tile, const uint4& u, int col0, int k) {
+    T e[VEC];
+    *(uint4*)e = u;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) *(T*)(tile + lds_off(col0 + j, k / VEC) + (k % VEC) * (int)sizeof(T)) = e[j];
   };
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *(uint4*)(&smem[buf][0][so[i]]) = ra[i];
-      *(uint4*)(&smem[buf][1][so[i]]) = rw[i];
+      if (p.ta) scatter(&smem[buf][0][0], ra[i], tcol[i], tk[i]);
+      else *(uint4*)(&smem[buf][0][so[i]]) = ra[i];
+      if (p.tw) scatter(&smem[buf][1][0], rw[i], tcol[i], tk[i]);
+      else *(uint4*)(&smem[buf][1][so[i]]) = rw[i];
     }
   };
 
@@ -165,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
           const int row = row0 + m * 16 + i;
           if (row < p.M) {
             float v = acc[m][n][i] + b;
+            if (p.aux) ((T*)p.aux + (int64_t)z * p.sC)[(int64_t)row * p.ldc + col] = from_f32<T>(v);
             if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
             store_out<T>(p, Cb, Rb, row, col, v);
           }
@@ -449,7 +480,7 @@ static int launch_skinny(GemmP& p, const SkinnyX& sx, int batch, bool packed, hi
 
 template <typename T>
 static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStream_t st) {
-  const bool skinny = a->M <= 64;
+  const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32;  // backward features live in the tiled kernel
   const bool packed = a->w_layout == SL_W_PACKED;
   if (!skinny && (packed || a->act == SL_ACT_ROPE_KV || sx.fuse_rms)) {
     sl_set_error("sl_gemm: packed weights / ROPE_KV / fused RMSNorm are decode (M <= 64) features, M=%d", a->M);
@@ -465,7 +496,7 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
   return SL_ERR_ARG;
 }
 
-int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, hipStream_t st) {
+int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st) {
   SL_CHECK_ARG(a != nullptr, "sl_gemm: null args");
   SL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0, "sl_gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   SL_CHECK_ARG(a->dtype == SL_F32 || a->dtype == SL_BF16, "sl_gemm: bad dtype %d", a->dtype);
@@ -488,6 +519,13 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, hipStream_t st)
   p.res = a->residual; p.ldr = a->ldr; p.sR = a->strideR;
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
+  p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0;
+  if (ex) {
+    p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;
+    SL_CHECK_ARG(!(p.ta || p.tw || p.aux) || a->act != SL_ACT_SILU_MUL, "sl_gemm_ex: transposed operands / aux_out are not combined with SILU_MUL");
+    SL_CHECK_ARG(!p.res_f32 || a->out_f32, "sl_gemm_ex: residual_f32 needs out_f32");
+    SL_CHECK_ARG(!(p.ta || p.tw) || a->w_layout == SL_W_ROWMAJOR, "sl_gemm_ex: transposed operands need row-major storage");
+  }
   SkinnyX sx;
   memset(&sx, 0, sizeof(sx));
   if (fx) {
@@ -504,9 +542,14 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, hipStream_t st)
   return gemm_typed<bf16_t>(a, p, sx, st);
 }
 
-extern "C" int sl_gemm(const sl_gemm_args* a, sl_stream stream) { return sl_gemm_impl(a, nullptr, (hipStream_t)stream); }
+extern "C" int sl_gemm(const sl_gemm_args* a, sl_stream stream) { return sl_gemm_impl(a, nullptr, nullptr, (hipStream_t)stream); }
+
+extern "C" int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream) {
+  SL_CHECK_ARG(ex != nullptr, "sl_gemm_ex: null ex args");
+  return sl_gemm_impl(a, nullptr, ex, (hipStream_t)stream);
+}
 
 extern "C" int sl_gemm_fused_decode(const sl_gemm_args* a, const sl_gemm_fused* fx, sl_stream stream) {
   SL_CHECK_ARG(fx != nullptr, "sl_gemm_fused_decode: null fused args");
-  return sl_gemm_impl(a, fx, (hipStream_t)stream);
+  return sl_gemm_impl(a, fx, nullptr, (hipStream_t)stream);
 }

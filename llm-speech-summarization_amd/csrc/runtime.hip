@@ -16,7 +16,7 @@ int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cac
                               const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
                               float scale, int32_t dtype, hipStream_t st);
 size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx);
-int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, hipStream_t st);
+int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st);
 
 namespace {
 
@@ -277,7 +277,7 @@ static int dec_gemm(const sl_llama_model* m, const void* A, int64_t lda, const v
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = Wp; a.ldw = K; a.C = C; a.ldc = ldc; a.residual = res; a.ldr = ldc;
   a.M = M; a.N = N; a.K = K; a.batch = 1; a.dtype = m->dtype; a.act = act; a.out_f32 = out_f32; a.w_layout = SL_W_PACKED;
-  return sl_gemm_impl(&a, fx, st);
+  return sl_gemm_impl(&a, fx, nullptr, st);
 }
 
 // one decoder layer over `n` token rows; attention chosen by `decode`

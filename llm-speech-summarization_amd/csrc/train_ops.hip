@@ -1,0 +1,676 @@
+// train_ops.hip — kernels of the knowledge-distillation step (ref:trainer.py:270-374) that are not GEMMs:
+// activation / norm backward, explicit-softmax attention backward pieces, the KD losses with their
+// gradients (ref:model/audio_llama.py:72-101, ref:utils.py:167-178, ref:trainer.py:358-370), and the
+// HuBERT front-end backward (pool, strided-conv col2im, fused conv0).  All HBM-bound row kernels:
+// 16-byte accesses, fp32 math, one wave per row where a row reduction is needed.
+#include "common.h"
+
+constexpr int TR_MAXF = 64;  // floats per lane for row kernels (rows up to 4096 elements)
+
+__device__ __forceinline__ float gelu_grad(float u) {
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+
+// ----------------------------------------------------------------------------------------------
+// elementwise: GELU backward, axpby, SwiGLU on the 16-row interleaved gate/up layout
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ dx, int64_t n) {
+  constexpr int VEC = Vec16<T>::VEC;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * 256 * VEC) {
+    float a[VEC], u[VEC], o[VEC];
+    Vec16<T>::unpack(*(const uint4*)(dy + i), a);
+    Vec16<T>::unpack(*(const uint4*)(pre + i), u);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = a[e] * gelu_grad(u[e]);
+    *(uint4*)(dx + i) = Vec16<T>::pack(o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, T* __restrict__ y, float a, float b, int64_t n) {
+  constexpr int VEC = Vec16<T>::VEC;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * 256 * VEC) {
+    float xv[VEC], yv[VEC];
+    Vec16<T>::unpack(*(const uint4*)(x + i), xv);
+    Vec16<T>::unpack(*(const uint4*)(y + i), yv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) yv[e] = a * xv[e] + b * yv[e];
+    *(uint4*)(y + i) = Vec16<T>::pack(yv);
+  }
+}
+
+// gu: (M, 2F) with blocks [16 gate | 16 up];  out/dy: (M, F)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ gu, const T* __restrict__ dy, T* __restrict__ out, int64_t M, int F_) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int cpr = F_ / VEC;
+  const int64_t total = M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / cpr;
+    const int o = (int)(i % cpr) * VEC, p = o >> 4, c = o & 15;
+    const T* gp = gu + m * 2 * F_ + 32 * p + c;
+    float g[VEC], u[VEC], r[VEC];
+    Vec16<T>::unpack(*(const uint4*)gp, g);
+    Vec16<T>::unpack(*(const uint4*)(gp + 16), u);
+    if constexpr (!BWD) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) r[e] = silu(g[e]) * u[e];
+      *(uint4*)(out + m * F_ + o) = Vec16<T>::pack(r);
+    } else {
+      float d[VEC], r2[VEC];
+      Vec16<T>::unpack(*(const uint4*)(dy + m * F_ + o), d);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float sg = 1.0f / (1.0f + __expf(-g[e]));
+        r[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));  // d gate
+        r2[e] = d[e] * g[e] * sg;                                 // d up
+      }
+      T* op = out + m * 2 * F_ + 32 * p + c;
+      *(uint4*)op = Vec16<T>::pack(r);
+      *(uint4*)(op + 16) = Vec16<T>::pack(r2);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// RoPE in place on the first n_rot heads of (n_tok, heads*D) rows; sign = -1 is the backward (inverse) rotation
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_inplace_kernel(T* __restrict__ x, const int32_t* __restrict__ tok_pos, const float* __restrict__ cosT,
+                                                           const float* __restrict__ sinT, int64_t n_tok, int heads, int n_rot, int D, float sign) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int half = D / 2, cph = half / VEC;
+  const int64_t total = n_tok * n_rot * cph;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % cph);
+    const int h = (int)((i / cph) % n_rot);
+    const int64_t t = i / ((int64_t)cph * n_rot);
+    T* p = x + t * (int64_t)heads * D + (int64_t)h * D + j * VEC;
+    const int pos = tok_pos[t];
+    float a[VEC], b[VEC], o1[VEC], o2[VEC];
+    Vec16<T>::unpack(*(const uint4*)p, a);
+    Vec16<T>::unpack(*(const uint4*)(p + half), b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float c = cosT[(int64_t)pos * half + j * VEC + e], s = sign * sinT[(int64_t)pos * half + j * VEC + e];
+      o1[e] = a[e] * c - b[e] * s;
+      o2[e] = b[e] * c + a[e] * s;
+    }
+    *(uint4*)p = Vec16<T>::pack(o1);
+    *(uint4*)(p + half) = Vec16<T>::pack(o2);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm backward (optionally through a fused GELU): dx, and fp32 dgamma/dbeta accumulated with one
+// atomic per column per block.  RMSNorm backward: dx only (the LLM is frozen).
+// ----------------------------------------------------------------------------------------------
+template <typename T, bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ b,
+                                                       const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int64_t rows, int cols, float eps, int gelu, int rows_per_block) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int MAXCH = TR_MAXF / VEC;
+  __shared__ float red[4][64 * TR_MAXF / 4 + 4];  // per-wave column partials, folded in two passes (gamma, beta)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = cols / VEC;
+  float gg[MAXCH][VEC], bb[MAXCH][VEC], ag[MAXCH][VEC], ab[MAXCH][VEC];
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { gg[i][e] = 0.f; bb[i][e] = 0.f; ag[i][e] = 0.f; ab[i][e] = 0.f; }
+    if (ch < nch) {
+      Vec16<T>::unpack(*(const uint4*)(g + ch * VEC), gg[i]);
+      if (!RMS) Vec16<T>::unpack(*(const uint4*)(b + ch * VEC), bb[i]);
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block) < rows ? (r0 + rows_per_block) : rows;
+  for (int64_t row = r0 + wave; row < r1; row += 4) {
+    float xv[MAXCH][VEC], dv[MAXCH][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        Vec16<T>::unpack(*(const uint4*)(x + row * cols + ch * VEC), xv[i]);
+        Vec16<T>::unpack(*(const uint4*)(dy + row * cols + ch * VEC), dv[i]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += RMS ? xv[i][e] * xv[i][e] : xv[i][e];
+      }
+    }
+    s = wave_sum(s);
+    float mean = 0.f, rstd;
+    if constexpr (RMS) {
+      rstd = rsqrtf(s / (float)cols + eps);
+    } else {
+      mean = s / (float)cols;
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i)
+        if (lane + 64 * i < nch) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { const float d = xv[i][e] - mean; s2 += d * d; }
+        }
+      rstd = rsqrtf(wave_sum(s2) / (float)cols + eps);
+    }
+    // xhat in xv, dy*(gelu') in dv, accumulate parameter grads, row sums
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i)
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float xh = (xv[i][e] - mean) * rstd;
+          float d = dv[i][e];
+          if (!RMS && gelu) d *= gelu_grad(xh * gg[i][e] + bb[i][e]);
+          ag[i][e] += d * xh;
+          ab[i][e] += d;
+          const float dg = d * gg[i][e];
+          s1 += dg;
+          s2 += dg * xh;
+          xv[i][e] = xh;
+          dv[i][e] = dg;
+        }
+      }
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = RMS ? rstd * (dv[i][e] - xv[i][e] * s2) : rstd * (dv[i][e] - s1 - xv[i][e] * s2);
+        *(uint4*)(dx + row * cols + ch * VEC) = Vec16<T>::pack(o);
+      }
+    }
+  }
+  if (RMS || !dgamma) return;
+  // fold the four waves' column partials, then one atomic per column per block
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float* dst = pass == 0 ? dgamma : dbeta;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ch = lane + 64 * i;
+      __syncthreads();
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[wave][(lane * VEC + e)] = pass == 0 ? ag[i][e] : ab[i][e];
+      }
+      __syncthreads();
+      if (wave == 0 && ch < nch) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int k = lane * VEC + e;
+          atomicAdd(dst + ch * VEC + e, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+        }
+      }
+    }
+  }
+}
+
+// column sums of a (rows, cols) matrix into fp32 (bias gradients), one atomic per column per block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t rows, int cols,
+                                                     int rows_per_block) {
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block) < rows ? (r0 + rows_per_block) : rows;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += to_f32(x[r * ld + col]);
+  atomicAdd(out + col, s);
+}
+
+// ----------------------------------------------------------------------------------------------
+// explicit softmax (attention backward recomputes P): rows of fp32 scores -> P (T); and its backward
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, T* __restrict__ P, int64_t nrows, int rows_per_mat, int cols,
+                                                           int64_t ld, float scale, int causal_shift, int causal) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int qi = (int)(row % rows_per_mat);
+  const int lim = causal ? ((qi + causal_shift + 1) < cols ? (qi + causal_shift + 1) : cols) : cols;  // visible columns
+  const float* s = S + row * ld;
+  T* p = P + row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < lim; c += 64) m = fmaxf(m, s[c] * scale);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int c = lane; c < lim; c += 64) l += __expf(s[c] * scale - m);
+  l = wave_sum(l);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  for (int c = lane; c < ld; c += 64) p[c] = from_f32<T>(c < lim ? __expf(s[c] * scale - m) * inv : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, const float* __restrict__ dP, T* __restrict__ dS, int64_t nrows,
+                                                          int cols, int64_t ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const T* p = P + row * ld;
+  const float* dp = dP + row * ld;
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += to_f32(p[c]) * dp[c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < ld; c += 64) dS[row * ld + c] = from_f32<T>(c < cols ? scale * to_f32(p[c]) * (dp[c] - dot) : 0.f);
+}
+
+// ----------------------------------------------------------------------------------------------
+// KD losses with gradients.  One block per row of fp32 logits.
+//   ce:      loss += coef * (lse(s) - s[label]);           d s (+)= coef * (softmax(s) - onehot)
+//   soft-ce: loss += coef * (lse(s) - sum softmax(t) s);   d s (+)= coef * (softmax(s) - softmax(t))
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int w = 1; w < nw; ++w) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void logit_loss_kernel(const float* __restrict__ s, const float* __restrict__ t, const int32_t* __restrict__ labels,
+                                                          int V, float coef, float* __restrict__ loss, T* __restrict__ ds, int accumulate) {
+  __shared__ float sh[16];
+  const int64_t row = blockIdx.x;
+  const float* sr = s + row * V;
+  const float* tr = t ? t + row * V : nullptr;
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) { ms = fmaxf(ms, sr[i]); if (tr) mt = fmaxf(mt, tr[i]); }
+  ms = block_reduce(ms, true, sh);
+  if (tr) mt = block_reduce(mt, true, sh);
+  float ls = 0.f, lt = 0.f, cross = 0.f;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    ls += __expf(sr[i] - ms);
+    if (tr) { const float e = __expf(tr[i] - mt); lt += e; cross += e * sr[i]; }
+  }
+  ls = block_reduce(ls, false, sh);
+  if (tr) { lt = block_reduce(lt, false, sh); cross = block_reduce(cross, false, sh); }
+  const float lse = ms + logf(ls);
+  const int lab = labels ? labels[row] : -1;
+  if (threadIdx.x == 0) atomicAdd(loss, coef * (tr ? (lse - cross / lt) : (lse - sr[lab])));
+  if (!ds) return;
+  T* dr = ds + row * V;
+  const float inv_s = 1.0f / ls, inv_t = tr ? 1.0f / lt : 0.f;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    float gval = __expf(sr[i] - ms) * inv_s - (tr ? __expf(tr[i] - mt) * inv_t : (i == lab ? 1.0f : 0.f));
+    gval *= coef;
+    if (accumulate) gval += to_f32(dr[i]);
+    dr[i] = from_f32<T>(gval);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, float coef, float* __restrict__ loss,
+                                                  T* __restrict__ da, int accumulate) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const float gscale = 2.0f * coef / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = to_f32(a[i]) - to_f32(b[i]);
+    acc += d * d;
+    if (da) da[i] = from_f32<T>(gscale * d + (accumulate ? to_f32(da[i]) : 0.f));
+  }
+  acc = block_reduce(acc, false, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, coef * acc / (float)n);
+}
+
+// ----------------------------------------------------------------------------------------------
+// HuBERT front-end backward pieces
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int64_t T_, int H, int kernel, int stride, int64_t P) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int cpr = H / VEC;
+  const int64_t total = T_ * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % cpr);
+    const int64_t t = i / cpr;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    const int64_t first = t - kernel + 1;  // windows p with p*stride <= t < p*stride + kernel
+    const int64_t p_lo = first <= 0 ? 0 : (first + stride - 1) / stride;
+    for (int64_t p = p_lo; p < P && p * stride <= t; ++p) {
+      float f[VEC];
+      Vec16<T>::unpack(*(const uint4*)(dy + p * H + ch * VEC), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+    }
+    const float inv = 1.0f / (float)kernel;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] *= inv;
+    *(uint4*)(dx + t * H + ch * VEC) = Vec16<T>::pack(acc);
+  }
+}
+
+// strided-conv data gradient: dcol (Lout, k*C) -> dx (Lin, C), dx[t][c] = sum_{j, to*s + j == t} dcol[to][j*C + c]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int64_t Lin, int64_t Lout, int Cc, int k, int s) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int cpr = Cc / VEC;
+  const int64_t total = Lin * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % cpr);
+    const int64_t t = i / cpr;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int64_t d = t - j;
+      if (d < 0 || d % s) continue;
+      const int64_t to = d / s;
+      if (to >= Lout) continue;
+      float f[VEC];
+      Vec16<T>::unpack(*(const uint4*)(dcol + to * (int64_t)k * Cc + (int64_t)j * Cc + ch * VEC), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+    }
+    *(uint4*)(dx + t * Cc + ch * VEC) = Vec16<T>::pack(acc);
+  }
+}
+
+// conv0 backward: recompute conv + LN per time step, push dy through GELU and LN, accumulate fp32 grads
+// of (w, bias, gamma, beta).  Same wave-strip geometry as the forward kernel.
+template <typename T, int CPL, int K, int STRIDE>
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wave, int64_t n_samples, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const T* __restrict__ dy, int64_t L, float eps, float* __restrict__ dw, float* __restrict__ dbias,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  constexpr int C = 64 * CPL;
+  constexpr int TS = (128 - (K - STRIDE)) / STRIDE;
+  const int lane = threadIdx.x & 63;
+  const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t t0 = strip * TS;
+  if (t0 >= L) return;
+  float wr[CPL][K], br[CPL], gr[CPL], ber[CPL];
+  float aw[CPL][K], abias[CPL], ag[CPL], ab[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lane * CPL + c;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { wr[c][j] = w[ch * K + j]; aw[c][j] = 0.f; }
+    br[c] = bias[ch]; gr[c] = gamma[ch]; ber[c] = beta[ch];
+    abias[c] = 0.f; ag[c] = 0.f; ab[c] = 0.f;
+  }
+  const int64_t s0 = t0 * STRIDE;
+  const int64_t i0 = s0 + lane, i1 = s0 + 64 + lane;
+  const int b0 = __builtin_bit_cast(int, i0 < n_samples ? wave[i0] : 0.f), b1 = __builtin_bit_cast(int, i1 < n_samples ? wave[i1] : 0.f);
+  const int nt = (int)((L - t0) < TS ? (L - t0) : TS);
+  for (int tt = 0; tt < nt; ++tt) {
+    float xs[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int idx = tt * STRIDE + j;
+      const int lo = __builtin_amdgcn_readlane(b0, idx & 63), hi = __builtin_amdgcn_readlane(b1, idx & 63);
+      xs[j] = __builtin_bit_cast(float, idx < 64 ? lo : hi);
+    }
+    float y[CPL], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      float a = br[c];
+#pragma unroll
+      for (int j = 0; j < K; ++j) a = fmaf(wr[c][j], xs[j], a);
+      y[c] = a; s += a;
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { const float d = y[c] - mean; s2 += d * d; }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+    const T* drow = dy + (t0 + tt) * C + lane * CPL;
+    float dg[CPL], xh[CPL], r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      xh[c] = (y[c] - mean) * rstd;
+      const float d = to_f32(drow[c]) * gelu_grad(xh[c] * gr[c] + ber[c]);
+      ag[c] += d * xh[c];
+      ab[c] += d;
+      dg[c] = d * gr[c];
+      r1 += dg[c];
+      r2 += dg[c] * xh[c];
+    }
+    r1 = wave_sum(r1) / (float)C;
+    r2 = wave_sum(r2) / (float)C;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const float dc = rstd * (dg[c] - r1 - xh[c] * r2);
+      abias[c] += dc;
+#pragma unroll
+      for (int j = 0; j < K; ++j) aw[c][j] = fmaf(dc, xs[j], aw[c][j]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lane * CPL + c;
+#pragma unroll
+    for (int j = 0; j < K; ++j) atomicAdd(dw + ch * K + j, aw[c][j]);
+    atomicAdd(dbias + ch, abias[c]);
+    atomicAdd(dgamma + ch, ag[c]);
+    atomicAdd(dbeta + ch, ab[c]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------
+static inline unsigned grid_for(int64_t items, int cap = 8192) {
+  const int64_t g = ceil_div64(items, 256);
+  return (unsigned)(g < 1 ? 1 : (g < cap ? g : cap));
+}
+
+extern "C" int sl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(dy && pre && dx && n >= 0, "sl_gelu_bwd: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(n % vec == 0, "sl_gelu_bwd: n must be a multiple of %d", vec);
+  if (n == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, { hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)pre, (T*)dx, n); });
+  SL_CHECK_LAUNCH("gelu_bwd");
+  return 0;
+}
+
+extern "C" int sl_axpby(const void* x, void* y, float a, float b, int64_t n, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(x && y && n >= 0, "sl_axpby: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(n % vec == 0, "sl_axpby: n must be a multiple of %d", vec);
+  if (n == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, { hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, a, b, n); });
+  SL_CHECK_LAUNCH("axpby");
+  return 0;
+}
+
+extern "C" int sl_silu_mul(const void* gu, void* out, int64_t M, int32_t F_, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(gu && out && M >= 0 && F_ > 0 && F_ % 16 == 0, "sl_silu_mul: bad arguments");
+  if (M == 0) return 0;
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_DISPATCH_DTYPE(dtype, T, { hipLaunchKernelGGL((silu_mul_kernel<T, false>), dim3(grid_for(M * (F_ / vec))), dim3(256), 0, (hipStream_t)stream, (const T*)gu, (const T*)nullptr, (T*)out, M, F_); });
+  SL_CHECK_LAUNCH("silu_mul");
+  return 0;
+}
+
+extern "C" int sl_silu_mul_bwd(const void* gu, const void* dy, void* dgu, int64_t M, int32_t F_, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(gu && dy && dgu && M >= 0 && F_ > 0 && F_ % 16 == 0, "sl_silu_mul_bwd: bad arguments");
+  if (M == 0) return 0;
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_DISPATCH_DTYPE(dtype, T, { hipLaunchKernelGGL((silu_mul_kernel<T, true>), dim3(grid_for(M * (F_ / vec))), dim3(256), 0, (hipStream_t)stream, (const T*)gu, (const T*)dy, (T*)dgu, M, F_); });
+  SL_CHECK_LAUNCH("silu_mul_bwd");
+  return 0;
+}
+
+extern "C" int sl_rope_inplace(void* x, const int32_t* tok_pos, const float* cos, const float* sin, int64_t n_tok, int32_t heads, int32_t n_rot,
+                               int32_t D, int32_t inverse, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(x && tok_pos && cos && sin && n_rot <= heads, "sl_rope_inplace: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(D % (2 * vec) == 0, "sl_rope_inplace: head_dim=%d must be a multiple of %d", D, 2 * vec);
+  if (n_tok == 0 || n_rot == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((rope_inplace_kernel<T>), dim3(grid_for(n_tok * n_rot * (D / 2 / vec))), dim3(256), 0, (hipStream_t)stream, (T*)x, tok_pos, cos, sin,
+                       n_tok, heads, n_rot, D, inverse ? -1.0f : 1.0f);
+  });
+  SL_CHECK_LAUNCH("rope_inplace");
+  return 0;
+}
+
+extern "C" int sl_layernorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta,
+                                int64_t rows, int32_t cols, float eps, int32_t gelu, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(x && gamma && beta && dy && dx && rows >= 0 && cols > 0, "sl_layernorm_bwd: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_layernorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
+  if (rows == 0) return 0;
+  const int rpb = 64;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((norm_bwd_kernel<T, false>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
+                       (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb);
+  });
+  SL_CHECK_LAUNCH("layernorm_bwd");
+  return 0;
+}
+
+extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
+                              sl_stream stream) {
+  SL_CHECK_ARG(x && w && dy && dx && rows >= 0 && cols > 0, "sl_rmsnorm_bwd: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_rmsnorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
+  if (rows == 0) return 0;
+  const int rpb = 16;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((norm_bwd_kernel<T, true>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb);
+  });
+  SL_CHECK_LAUNCH("rmsnorm_bwd");
+  return 0;
+}
+
+extern "C" int sl_colsum(const void* x, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(x && out && rows >= 0 && cols > 0, "sl_colsum: bad arguments");
+  if (rows == 0) return 0;
+  const int rpb = 128;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3((unsigned)ceil_div64(rows, rpb), (cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, out,
+                       rows, cols, rpb);
+  });
+  SL_CHECK_LAUNCH("colsum");
+  return 0;
+}
+
+extern "C" int sl_softmax_rows(const float* S, void* P, int64_t n_mats, int32_t rows, int32_t cols, int64_t ld, float scale, int32_t causal,
+                               int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(S && P && n_mats > 0 && rows > 0 && cols > 0 && ld >= cols, "sl_softmax_rows: bad arguments");
+  const int64_t nrows = n_mats * rows;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)ceil_div64(nrows, 4)), dim3(256), 0, (hipStream_t)stream, S, (T*)P, nrows, rows, cols, ld,
+                       scale, cols - rows, causal);
+  });
+  SL_CHECK_LAUNCH("softmax_rows");
+  return 0;
+}
+
+extern "C" int sl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t nrows, int32_t cols, int64_t ld, float scale, int32_t dtype,
+                              sl_stream stream) {
+  SL_CHECK_ARG(P && dP && dS && nrows > 0 && cols > 0 && ld >= cols, "sl_softmax_bwd: bad arguments");
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3((unsigned)ceil_div64(nrows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)P, dP, (T*)dS, nrows, cols,
+                       ld, scale);
+  });
+  SL_CHECK_LAUNCH("softmax_bwd");
+  return 0;
+}
+
+extern "C" int sl_ce_loss(const float* logits, const int32_t* labels, int64_t rows, int32_t V, float coef, float* loss, void* dlogits,
+                          int32_t accumulate, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(logits && labels && loss && rows >= 0 && V > 0, "sl_ce_loss: bad arguments");
+  if (rows == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((logit_loss_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, logits, (const float*)nullptr, labels, V, coef, loss,
+                       (T*)dlogits, accumulate);
+  });
+  SL_CHECK_LAUNCH("ce_loss");
+  return 0;
+}
+
+extern "C" int sl_soft_ce_loss(const float* student, const float* teacher, int64_t rows, int32_t V, float coef, float* loss, void* dstudent,
+                               int32_t accumulate, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(student && teacher && loss && rows >= 0 && V > 0, "sl_soft_ce_loss: bad arguments");
+  if (rows == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((logit_loss_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, student, teacher, (const int32_t*)nullptr, V, coef,
+                       loss, (T*)dstudent, accumulate);
+  });
+  SL_CHECK_LAUNCH("soft_ce_loss");
+  return 0;
+}
+
+extern "C" int sl_mse_loss(const void* a, const void* b, int64_t n, float coef, float* loss, void* da, int32_t accumulate, int32_t dtype,
+                           sl_stream stream) {
+  SL_CHECK_ARG(a && b && loss && n > 0, "sl_mse_loss: bad arguments");
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((mse_kernel<T>), dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, n, coef, loss, (T*)da, accumulate);
+  });
+  SL_CHECK_LAUNCH("mse_loss");
+  return 0;
+}
+
+extern "C" int sl_avgpool_bwd(const void* dy, void* dx, int64_t T_, int32_t H, int32_t kernel, int32_t stride, int64_t P, int32_t dtype,
+                              sl_stream stream) {
+  SL_CHECK_ARG(dy && dx && T_ > 0 && H > 0 && kernel > 0 && stride > 0, "sl_avgpool_bwd: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(H % vec == 0, "sl_avgpool_bwd: H must be a multiple of %d", vec);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(grid_for(T_ * (H / vec))), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, T_, H, kernel, stride, P);
+  });
+  SL_CHECK_LAUNCH("avgpool_bwd");
+  return 0;
+}
+
+extern "C" int sl_col2im(const void* dcol, void* dx, int64_t Lin, int64_t Lout, int32_t Cc, int32_t k, int32_t s, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(dcol && dx && Lin > 0 && Lout > 0 && Cc > 0 && k > 0 && s > 0, "sl_col2im: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(Cc % vec == 0, "sl_col2im: C must be a multiple of %d", vec);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((col2im_kernel<T>), dim3(grid_for(Lin * (Cc / vec))), dim3(256), 0, (hipStream_t)stream, (const T*)dcol, (T*)dx, Lin, Lout, Cc, k, s);
+  });
+  SL_CHECK_LAUNCH("col2im");
+  return 0;
+}
+
+template <typename T, int CPL>
+static int launch_conv0_bwd(const float* wave, int64_t n, const float* w, const float* b, const float* g, const float* be, const void* dy, int64_t L,
+                            float eps, float* dw, float* db, float* dg, float* dbe, hipStream_t st) {
+  constexpr int TS = (128 - 5) / 5;
+  const int64_t strips = ceil_div64(L, TS);
+  hipLaunchKernelGGL((conv0_bwd_kernel<T, CPL, 10, 5>), dim3((unsigned)ceil_div64(strips, 4)), dim3(256), 0, st, wave, n, w, b, g, be, (const T*)dy, L, eps, dw,
+                     db, dg, dbe);
+  SL_CHECK_LAUNCH("conv0_bwd");
+  return 0;
+}
+
+extern "C" int sl_hubert_conv0_bwd(const float* wave, int64_t n_samples, const float* w, const float* bias, const float* gamma, const float* beta,
+                                   const void* dy, int32_t C, int32_t k, int32_t stride, float eps, float* dw, float* dbias, float* dgamma,
+                                   float* dbeta, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(wave && w && bias && gamma && beta && dy && dw && dbias && dgamma && dbeta, "sl_hubert_conv0_bwd: null pointer");
+  SL_CHECK_ARG(k == 10 && stride == 5 && n_samples >= k, "sl_hubert_conv0_bwd: only k=10, stride=5 is built");
+  const int64_t L = (n_samples - k) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    switch (C) {
+      case 64: return launch_conv0_bwd<T, 1>(wave, n_samples, w, bias, gamma, beta, dy, L, eps, dw, dbias, dgamma, dbeta, st);
+      case 128: return launch_conv0_bwd<T, 2>(wave, n_samples, w, bias, gamma, beta, dy, L, eps, dw, dbias, dgamma, dbeta, st);
+      case 256: return launch_conv0_bwd<T, 4>(wave, n_samples, w, bias, gamma, beta, dy, L, eps, dw, dbias, dgamma, dbeta, st);
+      case 512: return launch_conv0_bwd<T, 8>(wave, n_samples, w, bias, gamma, beta, dy, L, eps, dw, dbias, dgamma, dbeta, st);
+      default: sl_set_error("sl_hubert_conv0_bwd: C=%d must be 64, 128, 256 or 512", C); return SL_ERR_ARG;
+    }
+  });
+}

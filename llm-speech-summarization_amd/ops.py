@@ -199,3 +199,147 @@ def attn_decode_split(q, q_stride, k_cache, v_cache, ctx_len, n_heads, n_kv, D, 
     L.check(L.lib().sl_attn_decode_split(L.ptr(q), q_stride, L.ptr(k_cache), L.ptr(v_cache), L.ptr(out), L.ptr(ws), L.ptr(ctx_len), B,
                                          n_heads, n_kv, D, max_ctx, scale, L.dtype_code(q.dtype), L.stream_ptr()), "sl_attn_decode_split")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# training-side wrappers (sl_gemm_ex and train_ops.hip)
+# ---------------------------------------------------------------------------------------------
+def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tensor, ldc: Optional[int] = None, bias=None,
+            residual=None, ldr: int = 0, act: int = L.ACT_NONE, out_f32: bool = False, trans_a: bool = False, trans_w: bool = False,
+            residual_f32: bool = False, aux_out=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0,
+            strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, dtype: Optional[torch.dtype] = None):
+    """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors."""
+    dt = dtype or A.dtype
+    esz = 4 if dt == torch.float32 else 2
+    a = L.GemmArgs()
+    a.A, a.lda, a.strideA = A.data_ptr() + a_off * esz, lda, strideA
+    a.W, a.ldw, a.strideW = W.data_ptr() + w_off * esz, ldw, strideW
+    a.C, a.ldc, a.strideC = out.data_ptr() + c_off * (4 if out_f32 else esz), (ldc if ldc is not None else out.stride(0)), strideC
+    a.bias, a.strideBias = L.ptr(bias), strideBias
+    a.residual, a.ldr, a.strideR = L.ptr(residual), ldr, strideR
+    a.M, a.N, a.K, a.batch = M, N, K, batch
+    a.dtype, a.act, a.out_f32, a.w_layout = L.dtype_code(dt), act, int(out_f32), L.W_ROWMAJOR
+    e = L.GemmEx()
+    e.trans_a, e.trans_w, e.residual_f32, e.aux_out = int(trans_a), int(trans_w), int(residual_f32), L.ptr(aux_out)
+    L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(e), L.stream_ptr()), "sl_gemm_ex")
+    return out
+
+
+def dgrad(dY: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX (M, K_in) = dY (M, N_out) . W (N_out, K_in)."""
+    M, Nout = dY.shape
+    Kin = W.shape[1]
+    if out is None:
+        out = torch.empty((M, Kin), device=dY.device, dtype=dY.dtype)
+    return gemm_ex(dY, W, M=M, N=Kin, K=Nout, lda=dY.stride(0), ldw=W.stride(0), out=out, trans_w=True)
+
+
+def wgrad_acc(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, ldx: Optional[int] = None, Kin: Optional[int] = None,
+              M: Optional[int] = None) -> torch.Tensor:
+    """dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in); X rows may overlap (ldx < K_in: implicit-GEMM conv windows)."""
+    M = dY.shape[0] if M is None else M
+    Nout = dY.shape[1]
+    Kin = X.shape[1] if Kin is None else Kin
+    return gemm_ex(dY, X, M=Nout, N=Kin, K=M, lda=dY.stride(0), ldw=(X.stride(0) if ldx is None else ldx), out=dW, ldc=dW.stride(0),
+                   residual=dW, ldr=dW.stride(0), out_f32=True, residual_f32=True, trans_a=True, trans_w=True, dtype=dY.dtype)
+
+
+def gelu_bwd(dy, pre):
+    dx = torch.empty_like(dy)
+    L.check(L.lib().sl_gelu_bwd(L.ptr(dy), L.ptr(pre), L.ptr(dx), dy.numel(), L.dtype_code(dy.dtype), L.stream_ptr()), "sl_gelu_bwd")
+    return dx
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    L.check(L.lib().sl_axpby(L.ptr(x), L.ptr(y), a, b, y.numel(), L.dtype_code(y.dtype), L.stream_ptr()), "sl_axpby")
+    return y
+
+
+def silu_mul(gu):
+    M, F2 = gu.shape
+    out = torch.empty((M, F2 // 2), device=gu.device, dtype=gu.dtype)
+    L.check(L.lib().sl_silu_mul(L.ptr(gu), L.ptr(out), M, F2 // 2, L.dtype_code(gu.dtype), L.stream_ptr()), "sl_silu_mul")
+    return out
+
+
+def silu_mul_bwd(gu, dy):
+    dgu = torch.empty_like(gu)
+    L.check(L.lib().sl_silu_mul_bwd(L.ptr(gu), L.ptr(dy), L.ptr(dgu), gu.shape[0], gu.shape[1] // 2, L.dtype_code(gu.dtype), L.stream_ptr()),
+            "sl_silu_mul_bwd")
+    return dgu
+
+
+def rope_inplace(x, tok_pos, cos, sin, heads, n_rot, D, inverse=False):
+    L.check(L.lib().sl_rope_inplace(L.ptr(x), L.ptr(tok_pos), L.ptr(cos), L.ptr(sin), x.shape[0], heads, n_rot, D, int(inverse),
+                                    L.dtype_code(x.dtype), L.stream_ptr()), "sl_rope_inplace")
+    return x
+
+
+def layernorm_bwd(x, g, b, dy, eps, dgamma=None, dbeta=None, gelu=False):
+    dx = torch.empty_like(dy)
+    rows = x.numel() // x.shape[-1]
+    L.check(L.lib().sl_layernorm_bwd(L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(dy), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), rows, x.shape[-1], eps,
+                                     int(gelu), L.dtype_code(x.dtype), L.stream_ptr()), "sl_layernorm_bwd")
+    return dx
+
+
+def rmsnorm_bwd(x, w, dy, eps):
+    dx = torch.empty_like(dy)
+    rows = x.numel() // x.shape[-1]
+    L.check(L.lib().sl_rmsnorm_bwd(L.ptr(x), L.ptr(w), L.ptr(dy), L.ptr(dx), rows, x.shape[-1], eps, L.dtype_code(x.dtype), L.stream_ptr()),
+            "sl_rmsnorm_bwd")
+    return dx
+
+
+def colsum_acc(x, out_f32):
+    L.check(L.lib().sl_colsum(L.ptr(x), x.stride(0), L.ptr(out_f32), x.shape[0], x.shape[1], L.dtype_code(x.dtype), L.stream_ptr()), "sl_colsum")
+    return out_f32
+
+
+def softmax_rows(S, n_mats, rows, cols, ld, scale, causal, dtype):
+    P = torch.empty((n_mats, rows, ld), device=S.device, dtype=dtype)
+    L.check(L.lib().sl_softmax_rows(L.ptr(S), L.ptr(P), n_mats, rows, cols, ld, scale, int(causal), L.dtype_code(dtype), L.stream_ptr()),
+            "sl_softmax_rows")
+    return P
+
+
+def softmax_bwd(P, dP, cols, scale):
+    dS = torch.empty_like(P)
+    nrows = P.shape[0] * P.shape[1]
+    L.check(L.lib().sl_softmax_bwd(L.ptr(P), L.ptr(dP), L.ptr(dS), nrows, cols, P.shape[2], scale, L.dtype_code(P.dtype), L.stream_ptr()),
+            "sl_softmax_bwd")
+    return dS
+
+
+def ce_loss(logits, labels, coef, loss, dlogits=None, accumulate=False, dtype=torch.float32):
+    L.check(L.lib().sl_ce_loss(L.ptr(logits), L.ptr(labels), logits.shape[0], logits.shape[1], coef, L.ptr(loss), L.ptr(dlogits),
+                               int(accumulate), L.dtype_code(dtype), L.stream_ptr()), "sl_ce_loss")
+
+
+def soft_ce_loss(student, teacher, coef, loss, dstudent=None, accumulate=False, dtype=torch.float32):
+    L.check(L.lib().sl_soft_ce_loss(L.ptr(student), L.ptr(teacher), student.shape[0], student.shape[1], coef, L.ptr(loss), L.ptr(dstudent),
+                                    int(accumulate), L.dtype_code(dtype), L.stream_ptr()), "sl_soft_ce_loss")
+
+
+def mse_loss(a, b, coef, loss, da=None, accumulate=False):
+    L.check(L.lib().sl_mse_loss(L.ptr(a), L.ptr(b), a.numel(), coef, L.ptr(loss), L.ptr(da), int(accumulate), L.dtype_code(a.dtype),
+                                L.stream_ptr()), "sl_mse_loss")
+
+
+def avgpool_bwd(dy, T, kernel, stride):
+    P, H = dy.shape
+    dx = torch.empty((T, H), device=dy.device, dtype=dy.dtype)
+    L.check(L.lib().sl_avgpool_bwd(L.ptr(dy), L.ptr(dx), T, H, kernel, stride, P, L.dtype_code(dy.dtype), L.stream_ptr()), "sl_avgpool_bwd")
+    return dx
+
+
+def col2im(dcol, Lin, Cc, k, s):
+    dx = torch.empty((Lin, Cc), device=dcol.device, dtype=dcol.dtype)
+    L.check(L.lib().sl_col2im(L.ptr(dcol), L.ptr(dx), Lin, dcol.shape[0], Cc, k, s, L.dtype_code(dcol.dtype), L.stream_ptr()), "sl_col2im")
+    return dx
+
+
+def hubert_conv0_bwd(wave, w, bias, gamma, beta, dy, dw, dbias, dgamma, dbeta, k=10, stride=5, eps=1e-5):
+    L.check(L.lib().sl_hubert_conv0_bwd(L.ptr(wave), wave.numel(), L.ptr(w), L.ptr(bias), L.ptr(gamma), L.ptr(beta), L.ptr(dy), w.shape[0], k,
+                                        stride, eps, L.ptr(dw), L.ptr(dbias), L.ptr(dgamma), L.ptr(dbeta), L.dtype_code(dy.dtype),
+                                        L.stream_ptr()), "sl_hubert_conv0_bwd")

@@ -1,0 +1,187 @@
+"""GPU: backward / loss kernels of the KD step through the C ABI against PyTorch autograd (fp32 CPU reference).
+
+Tolerances: fp32 2e-5 relative L2 (3e-4 where fp32 atomics reorder a long reduction), bf16 2e-2.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+
+L = pkg("_lib")
+ops = pkg("ops")
+weights = pkg("weights")
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * std
+
+
+def q(x, dt):
+    return x.to(dt).float()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(137, 512, 256), (40, 96, 192), (300, 1024, 384)])
+def test_gemm_dgrad_and_wgrad(dt, M, N, K):
+    dY, W, X = rnd(M, N, seed=1), rnd(N, K, seed=2, std=N ** -0.5), rnd(M, K, seed=3)
+    dX = ops.dgrad(dY.to(DEV, dt), W.to(DEV, dt))
+    assert rel_err(dX.float().cpu(), q(dY, dt) @ q(W, dt)) < TOL[dt]
+    dW = torch.full((N, K), 0.5, device=DEV, dtype=torch.float32)
+    ops.wgrad_acc(dY.to(DEV, dt), X.to(DEV, dt), dW)
+    assert rel_err(dW.cpu(), 0.5 + q(dY, dt).T @ q(X, dt)) < 2e-5  # fp32 accumulate in both modes
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_wgrad_over_overlapping_conv_windows(dt):
+    Lin, Cc, C2, k, s = 101, 64, 96, 3, 2
+    Lo = (Lin - k) // s + 1
+    x, dy = rnd(Lin, Cc, seed=4), rnd(Lo, C2, seed=5)
+    xr = q(x, dt).T[None].requires_grad_()
+    w = torch.zeros(C2, Cc, k, requires_grad=True)
+    F.conv1d(xr, w, stride=s)[0].T.backward(q(dy, dt))
+    ref_dw = w.grad.permute(0, 2, 1).reshape(C2, k * Cc)
+    dW = torch.zeros(C2, k * Cc, device=DEV)
+    ops.wgrad_acc(dy.to(DEV, dt), x.to(DEV, dt), dW, ldx=s * Cc, Kin=k * Cc, M=Lo)
+    assert rel_err(dW.cpu(), ref_dw) < 2e-5
+    # data gradient: dgrad GEMM -> col2im
+    wt = rnd(C2, k * Cc, seed=6, std=0.1)
+    wr = q(wt, dt).view(C2, k, Cc).permute(0, 2, 1).contiguous()
+    xr2 = q(x, dt).T[None].requires_grad_()
+    F.conv1d(xr2, wr, stride=s)[0].T.backward(q(dy, dt))
+    dcol = ops.dgrad(dy.to(DEV, dt), wt.to(DEV, dt))
+    dx = ops.col2im(dcol, Lin, Cc, k, s)
+    assert rel_err(dx.float().cpu(), xr2.grad[0].T) < (TOL[dt] if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gelu_silu_rope_backward(dt):
+    u, dy = rnd(50, 256, seed=7), rnd(50, 256, seed=8)
+    ur = q(u, dt).requires_grad_()
+    F.gelu(ur).backward(q(dy, dt))
+    assert rel_err(ops.gelu_bwd(dy.to(DEV, dt), u.to(DEV, dt)).float().cpu(), ur.grad) < TOL[dt]
+    # SwiGLU on the interleaved layout
+    M, Fd = 33, 128
+    g, up, d = rnd(M, Fd, seed=9), rnd(M, Fd, seed=10), rnd(M, Fd, seed=11)
+    gu = torch.stack([g.view(M, Fd // 16, 16), up.view(M, Fd // 16, 16)], dim=2).reshape(M, 2 * Fd)
+    gr, ur2 = q(g, dt).requires_grad_(), q(up, dt).requires_grad_()
+    out_ref = F.silu(gr) * ur2
+    out_ref.backward(q(d, dt))
+    assert rel_err(ops.silu_mul(gu.to(DEV, dt)).float().cpu(), out_ref.detach()) < TOL[dt]
+    dgu = ops.silu_mul_bwd(gu.to(DEV, dt), d.to(DEV, dt)).float().cpu().view(M, Fd // 16, 2, 16)
+    assert rel_err(dgu[:, :, 0].reshape(M, Fd), gr.grad) < TOL[dt] and rel_err(dgu[:, :, 1].reshape(M, Fd), ur2.grad) < TOL[dt]
+    # RoPE: inverse rotation is the exact backward
+    arch = weights.LlamaArch(hidden_size=256, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
+    cos, sin = weights.rope_tables(arch, 64)
+    x = rnd(9, 4 * 128, seed=12)
+    pos = torch.arange(9, dtype=torch.int32) * 5
+    xd = x.to(DEV, dt).clone()
+    ops.rope_inplace(xd, pos.to(DEV), cos.to(DEV), sin.to(DEV), 4, 3, 128)
+    assert torch.equal(xd[:, 384:], x.to(DEV, dt)[:, 384:])  # 4th head untouched
+    ops.rope_inplace(xd, pos.to(DEV), cos.to(DEV), sin.to(DEV), 4, 3, 128, inverse=True)
+    assert rel_err(xd.float().cpu(), q(x, dt)) < (1e-6 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("rows,cols", [(131, 512), (70, 1024), (5, 128)])
+def test_layernorm_backward(dt, gelu, rows, cols):
+    x, g, b, dy = rnd(rows, cols, seed=13), 1 + rnd(cols, seed=14, std=0.1), rnd(cols, seed=15, std=0.1), rnd(rows, cols, seed=16)
+    xr, gr, br = q(x, dt).requires_grad_(), q(g, dt).requires_grad_(), q(b, dt).requires_grad_()
+    y = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    (F.gelu(y) if gelu else y).backward(q(dy, dt))
+    dg = torch.full((cols,), 1.0, device=DEV)
+    db = torch.zeros(cols, device=DEV)
+    dx = ops.layernorm_bwd(x.to(DEV, dt), g.to(DEV, dt), b.to(DEV, dt), dy.to(DEV, dt), 1e-5, dg, db, gelu=gelu)
+    assert rel_err(dx.float().cpu(), xr.grad) < TOL[dt]
+    assert rel_err(dg.cpu() - 1.0, gr.grad) < 3e-4 and rel_err(db.cpu(), br.grad) < 3e-4
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_rmsnorm_backward_and_colsum(dt):
+    x, w, dy = rnd(37, 768, seed=17), 1 + rnd(768, seed=18, std=0.1), rnd(37, 768, seed=19)
+    xr = q(x, dt).requires_grad_()
+    (q(w, dt) * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5))).backward(q(dy, dt))
+    assert rel_err(ops.rmsnorm_bwd(x.to(DEV, dt), w.to(DEV, dt), dy.to(DEV, dt), 1e-5).float().cpu(), xr.grad) < TOL[dt]
+    out = torch.zeros(768, device=DEV)
+    ops.colsum_acc(dy.to(DEV, dt), out)
+    assert rel_err(out.cpu(), q(dy, dt).sum(0)) < 3e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("causal", [False, True])
+def test_softmax_rows_and_backward(dt, causal):
+    n_mats, rows, cols, ld = 3, 37, 37, 40
+    S = rnd(n_mats, rows, ld, seed=20)
+    dP = rnd(n_mats, rows, ld, seed=21)
+    Sr = S[:, :, :cols].clone().requires_grad_()
+    sc = Sr * 0.3
+    if causal:
+        sc = sc.masked_fill(torch.arange(cols)[None, :] > torch.arange(rows)[:, None], float("-inf"))
+    Pref = F.softmax(sc, dim=-1)
+    P = ops.softmax_rows(S.to(DEV), n_mats, rows, cols, ld, 0.3, causal, dt)
+    assert rel_err(P[:, :, :cols].float().cpu(), Pref.detach()) < (1e-6 if dt == torch.float32 else 5e-3)
+    assert float(P[:, :, cols:].abs().max()) == 0
+    # backward at the kernel's own P (rounded to dt)
+    Pk = P[:, :, :cols].float().cpu()
+    ref = 0.3 * Pk * (dP[:, :, :cols] - (dP[:, :, :cols] * Pk).sum(-1, keepdim=True))
+    dS = ops.softmax_bwd(P, dP.to(DEV), cols, 0.3)
+    assert rel_err(dS[:, :, :cols].float().cpu(), ref) < (1e-5 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_kd_losses_and_gradients(dt):
+    n, V = 7, 5003
+    s, t = rnd(n, V, seed=22), rnd(n, V, seed=23)
+    labels = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(24))
+    sr = s.clone().requires_grad_()
+    ce = F.cross_entropy(sr, labels, reduction="sum") * 0.25
+    soft = (-(F.softmax(t, -1) * F.log_softmax(sr, -1)).sum(-1)).sum() * 0.5
+    (ce + soft).backward()
+    loss = torch.zeros(2, device=DEV)
+    ds = torch.empty(n, V, device=DEV, dtype=dt)
+    ops.ce_loss(s.to(DEV), labels.to(DEV, torch.int32), 0.25, loss[0:1], ds, accumulate=False, dtype=dt)
+    ops.soft_ce_loss(s.to(DEV), t.to(DEV), 0.5, loss[1:2], ds, accumulate=True, dtype=dt)
+    assert abs(float(loss[0]) - float(ce)) < 1e-4 * float(ce) and abs(float(loss[1]) - float(soft)) < 1e-4 * float(soft)
+    assert rel_err(ds.float().cpu(), sr.grad) < (1e-5 if dt == torch.float32 else 1e-2)
+    a, b = rnd(11, 256, seed=25), rnd(11, 256, seed=26)
+    ar = q(a, dt).requires_grad_()
+    m = F.mse_loss(ar, q(b, dt)) * 2.0
+    m.backward()
+    lm = torch.zeros(1, device=DEV)
+    da = torch.empty(11, 256, device=DEV, dtype=dt)
+    ops.mse_loss(a.to(DEV, dt), b.to(DEV, dt), 2.0, lm, da)
+    assert abs(float(lm) - float(m)) < 1e-5 * float(m) and rel_err(da.float().cpu(), ar.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_avgpool_backward(dt):
+    T, H = 49, 128
+    x, dy = rnd(T, H, seed=27), rnd(11, H, seed=28)
+    xr = q(x, dt).T[None].requires_grad_()
+    F.avg_pool1d(xr, 8, 4)[0].T.backward(q(dy, dt))
+    assert rel_err(ops.avgpool_bwd(dy.to(DEV, dt), T, 8, 4).float().cpu(), xr.grad[0].T) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Cc,n", [(64, 4000), (512, 16000)])
+def test_conv0_backward(dt, Cc, n):
+    wave = rnd(n, seed=29, std=0.1)
+    w, b = rnd(Cc, 1, 10, seed=30, std=0.4).requires_grad_(), rnd(Cc, seed=31, std=0.1).requires_grad_()
+    g, be = (1 + rnd(Cc, seed=32, std=0.1)).requires_grad_(), rnd(Cc, seed=33, std=0.1).requires_grad_()
+    Lo = (n - 10) // 5 + 1
+    dy = rnd(Lo, Cc, seed=34)
+    y = F.conv1d(wave[None, None], w, b, stride=5)[0].T
+    F.gelu(F.layer_norm(y, (Cc,), g, be, 1e-5)).backward(q(dy, dt))
+    dw, db, dg, dbe = [torch.zeros(s, device=DEV) for s in ((Cc, 10), (Cc,), (Cc,), (Cc,))]
+    ops.hubert_conv0_bwd(wave.to(DEV), w.detach().reshape(Cc, 10).to(DEV), b.detach().to(DEV), g.detach().to(DEV), be.detach().to(DEV),
+                         dy.to(DEV, dt), dw, db, dg, dbe)
+    for got, ref in ((dw, w.grad.reshape(Cc, 10)), (db, b.grad), (dg, g.grad), (dbe, be.grad)):
+        assert rel_err(got.cpu(), ref) < 5e-4
