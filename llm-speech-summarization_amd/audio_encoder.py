@@ -66,7 +66,7 @@ class AudioEncoder:
     # -- nn.Module-like surface the reference's callers use ------------------------------------
     def load_state_dict(self, state_dict, strict: bool = True):
         sd = normalize_encoder_state_dict(state_dict)
-        self._state = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self._state = {k: v.detach().float() for k, v in sd.items()}  # kept where they live (CPU checkpoints, GPU master weights)
         if self.device.type == "cuda":
             self._upload()
         return self

@@ -501,7 +501,9 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   SL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0, "sl_gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   SL_CHECK_ARG(a->dtype == SL_F32 || a->dtype == SL_BF16, "sl_gemm: bad dtype %d", a->dtype);
   const int vec = a->dtype == SL_F32 ? 4 : 8;
-  SL_CHECK_ARG(a->K % vec == 0, "sl_gemm: K=%d must be a multiple of %d", a->K, vec);
+  // a K-contiguous (non-transposed) operand is read in 16-byte chunks along K; transposed ones along the output index
+  const bool both_t = ex && ex->trans_a && ex->trans_w;
+  SL_CHECK_ARG(both_t || a->K % vec == 0, "sl_gemm: K=%d must be a multiple of %d", a->K, vec);
   SL_CHECK_ARG(a->lda % vec == 0 && a->strideA % vec == 0, "sl_gemm: lda/strideA must keep rows 16-byte aligned");
   SL_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "sl_gemm: A and W must be 16-byte aligned");
   if (a->w_layout == SL_W_PACKED) {

@@ -207,7 +207,8 @@ def attn_decode_split(q, q_stride, k_cache, v_cache, ctx_len, n_heads, n_kv, D, 
 def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tensor, ldc: Optional[int] = None, bias=None,
             residual=None, ldr: int = 0, act: int = L.ACT_NONE, out_f32: bool = False, trans_a: bool = False, trans_w: bool = False,
             residual_f32: bool = False, aux_out=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0,
-            strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, dtype: Optional[torch.dtype] = None):
+            strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, r_off: int = 0,
+            dtype: Optional[torch.dtype] = None):
     """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors."""
     dt = dtype or A.dtype
     esz = 4 if dt == torch.float32 else 2
@@ -216,7 +217,8 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     a.W, a.ldw, a.strideW = W.data_ptr() + w_off * esz, ldw, strideW
     a.C, a.ldc, a.strideC = out.data_ptr() + c_off * (4 if out_f32 else esz), (ldc if ldc is not None else out.stride(0)), strideC
     a.bias, a.strideBias = L.ptr(bias), strideBias
-    a.residual, a.ldr, a.strideR = L.ptr(residual), ldr, strideR
+    a.residual = 0 if residual is None else residual.data_ptr() + r_off * (4 if residual_f32 else esz)
+    a.ldr, a.strideR = ldr, strideR
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.dtype, a.act, a.out_f32, a.w_layout = L.dtype_code(dt), act, int(out_f32), L.W_ROWMAJOR
     e = L.GemmEx()

@@ -1,0 +1,468 @@
+"""Knowledge-distillation step on the HIP path: host-side mirror of ref:trainer.py:270-384.
+
+One micro-step = one utterance (the reference's batch-size-1 semantics, ref:README.md:86):
+    encoder(audio) -> [prefix | audio | suffix[1:] | response[1:]] -> frozen LLM (student pass, activations kept)
+    [prefix | text | suffix[1:] | response[1:]]                     -> frozen LLM (teacher pass, no grad)
+    total = w_ntp * CE(response-only) + w_ld * soft-CE(student, teacher) + w_fd * sum_taps MSE(hidden)
+    backward: dgrad-only through the LLM (its weights are frozen, ref:trainer.py:63-64), dgrad + wgrad
+    through the audio encoder; fp32 gradient accumulation over `grad_accum_interval` micro-steps.
+Every FLOP is a libspeechllm kernel (forward kernels of the inference path + sl_gemm_ex + train_ops.hip);
+this module is the tape: it decides what to keep from the forward and in which order to call the backward
+kernels.  torch supplies buffers, the optimizer (AdamW on fp32 master weights, ref:trainer.py:98-105) and the
+collective (RCCL all-reduce of the fp32 gradient buckets, overlapped with the remaining backward).
+
+Stochastic training-mode ops of the reference (dropout 0.1, LayerDrop 0.1, SpecAugment) are NOT applied:
+KD-step parity is defined with them off and they are left for a later round.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .audio_encoder import AudioEncoder
+from .audio_llama import AudioLlamaForCausalLM
+from .weights import HubertDeviceWeights, fold_pos_conv_weight
+
+
+def _vec(dt) -> int:
+    return 4 if dt == torch.float32 else 8
+
+
+def _rup(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+# attention backward from explicit probabilities (recomputed), all products on sl_gemm_ex
+# ------------------------------------------------------------------------------------------------
+def attention_backward(qkv: torch.Tensor, d_att: torch.Tensor, S: int, nh: int, nkv: int, D: int, causal: bool, scale: float,
+                       qkv_w: int) -> torch.Tensor:
+    """qkv: (>= roundup(S), qkv_w) rows [q heads | k heads | v heads], rows >= S zero;  d_att: (S, nh*D).
+    Returns d_qkv (S_pad, qkv_w) with the same layout."""
+    dt = qkv.dtype
+    rep = nh // nkv
+    ld = _rup(S, _vec(dt))
+    dev = qkv.device
+    d_qkv = torch.zeros((qkv.shape[0], qkv_w), device=dev, dtype=dt)
+    Sb = torch.empty((nkv, S, ld), device=dev, dtype=torch.float32)
+    dPb = torch.empty((nkv, S, ld), device=dev, dtype=torch.float32)
+    koff, voff = nh * D, (nh + nkv) * D
+    for r in range(rep):
+        # scores of q heads kvh*rep + r against kv head kvh
+        ops.gemm_ex(qkv, qkv, M=S, N=S, K=D, lda=qkv_w, ldw=qkv_w, out=Sb, ldc=ld, out_f32=True, batch=nkv, strideA=rep * D, strideW=D,
+                    strideC=S * ld, a_off=r * D, w_off=koff, dtype=dt)
+        P = ops.softmax_rows(Sb, nkv, S, S, ld, scale, causal, dt)
+        ops.gemm_ex(d_att, qkv, M=S, N=S, K=D, lda=nh * D, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nkv, strideA=rep * D, strideW=D,
+                    strideC=S * ld, a_off=r * D, w_off=voff, dtype=dt)
+        dS = ops.softmax_bwd(P, dPb, S, scale)
+        # dQ_h = dS . K   (reduction over keys; K = ld uses the zero-padded rows of qkv / zero columns of dS)
+        ops.gemm_ex(dS, qkv, M=S, N=D, K=ld, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_w=True, batch=nkv, strideA=S * ld, strideW=D,
+                    strideC=rep * D, w_off=koff, c_off=r * D, dtype=dt)
+        acc = r > 0  # GQA: the rep query heads of a group add into the same dK / dV
+        # dK = dS^T . Q_h
+        ops.gemm_ex(dS, qkv, M=S, N=D, K=S, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nkv, strideA=S * ld,
+                    strideW=rep * D, strideC=D, w_off=r * D, c_off=koff, residual=(d_qkv if acc else None), ldr=qkv_w, strideR=D,
+                    r_off=koff, dtype=dt)
+        # dV = P^T . dO_h
+        ops.gemm_ex(P, d_att, M=S, N=D, K=S, lda=ld, ldw=nh * D, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nkv, strideA=S * ld,
+                    strideW=rep * D, strideC=D, w_off=r * D, c_off=voff, residual=(d_qkv if acc else None), ldr=qkv_w, strideR=D,
+                    r_off=voff, dtype=dt)
+    return d_qkv
+
+
+# ------------------------------------------------------------------------------------------------
+# frozen LLM: forward with a tape, data-gradient backward
+# ------------------------------------------------------------------------------------------------
+class LlamaTape:
+    def __init__(self, llm: AudioLlamaForCausalLM):
+        self.llm = llm
+        self.w = llm._dev()
+        self.a = llm.arch
+
+    def forward(self, x: torch.Tensor):
+        """x: (S, H) prompt+response embeddings of ONE sequence.  Returns (hidden_states list of L+1 tensors
+        [hidden_states[l] = input of layer l, last = post-norm], tape)."""
+        a, w = self.a, self.w
+        S, H = x.shape
+        dt = x.dtype
+        nh, nkv, D = a.num_attention_heads, a.num_key_value_heads, a.head_dim
+        qkv_w = (nh + 2 * nkv) * D
+        S_pad = _rup(S, _vec(dt))
+        pos = torch.arange(S, dtype=torch.int32, device=x.device)
+        tape, hidden = [], []
+        scale = D ** -0.5
+        for li in range(a.num_hidden_layers):
+            lw = w.layer_t[li]
+            hidden.append(x)
+            h1 = ops.rmsnorm(x, lw["norm1"], a.rms_norm_eps)
+            qkv = torch.zeros((S_pad, qkv_w), device=x.device, dtype=dt)
+            ops.gemm(h1, lw["wqkv"], out=qkv[:S])
+            ops.rope_inplace(qkv[:S], pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D)
+            att = ops.attn_packed_qkv(qkv[:S], [S], nh, nkv, D, True, scale)
+            x2 = ops.gemm(att, lw["wo"], residual=x)
+            h2 = ops.rmsnorm(x2, lw["norm2"], a.rms_norm_eps)
+            gu = ops.gemm(h2, lw["wgu"])                      # interleaved gate/up pre-activations (S, 2F)
+            mid = ops.silu_mul(gu)
+            x3 = ops.gemm(mid, lw["wdown"], residual=x2)
+            tape.append((x, qkv, x2, gu))
+            x = x3
+        xn = ops.rmsnorm(x, w.final_norm, a.rms_norm_eps)
+        hidden.append(xn)
+        return hidden, dict(layers=tape, x_final=x, S=S, pos=pos)
+
+    def logits(self, xn_rows: torch.Tensor) -> torch.Tensor:
+        return ops.gemm(xn_rows, self.w.lm_head, out_f32=True)
+
+    def backward(self, tape, d_logits_tail: Optional[torch.Tensor], n_tail: int, d_taps: Dict[int, torch.Tensor]) -> torch.Tensor:
+        """d_logits_tail: (n_tail, V) gradient of the last n_tail logit rows (dtype T); d_taps[l]: (S, H) gradient
+        of hidden_states[l].  Returns the gradient of the input embeddings (S, H)."""
+        a, w = self.a, self.w
+        S, pos = tape["S"], tape["pos"]
+        nh, nkv, D = a.num_attention_heads, a.num_key_value_heads, a.head_dim
+        qkv_w = (nh + 2 * nkv) * D
+        x_final = tape["x_final"]
+        dx = torch.zeros_like(x_final)
+        if d_logits_tail is not None:
+            d_xn = ops.dgrad(d_logits_tail, w.lm_head)  # (n_tail, H)
+            if a.num_hidden_layers in d_taps:
+                ops.axpby(d_taps[a.num_hidden_layers][S - n_tail:], d_xn)
+            dx[S - n_tail:] = ops.rmsnorm_bwd(x_final[S - n_tail:].contiguous(), w.final_norm, d_xn, a.rms_norm_eps)
+        for li in reversed(range(a.num_hidden_layers)):
+            lw = w.layer_t[li]
+            x, qkv, x2, gu = tape["layers"][li]
+            d_mid = ops.dgrad(dx, lw["wdown"])
+            d_gu = ops.silu_mul_bwd(gu, d_mid)
+            d_h2 = ops.dgrad(d_gu, lw["wgu"])
+            dx2 = ops.rmsnorm_bwd(x2, lw["norm2"], d_h2, a.rms_norm_eps)
+            ops.axpby(dx, dx2)                                  # dx2 += dx (residual join)
+            d_att = ops.dgrad(dx2, lw["wo"])
+            d_qkv = attention_backward(qkv, d_att, S, nh, nkv, D, True, D ** -0.5, qkv_w)
+            ops.rope_inplace(d_qkv[:S], pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D, inverse=True)
+            d_h1 = ops.dgrad(d_qkv[:S], lw["wqkv"])
+            dxin = ops.rmsnorm_bwd(x, lw["norm1"], d_h1, a.rms_norm_eps)
+            ops.axpby(dx2, dxin)
+            if li in d_taps:
+                ops.axpby(d_taps[li], dxin)
+            dx = dxin
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# audio encoder: forward with a tape, full backward (data + parameter gradients)
+# ------------------------------------------------------------------------------------------------
+class EncoderTape:
+    """HuBERT + pool + projection for ONE utterance, composed op by op from the same kernels the fused
+    C runtime (sl_hubert_forward) launches, keeping what the backward needs."""
+
+    def __init__(self, enc: AudioEncoder):
+        if enc.downsample_method != "pool":
+            raise L.SpeechLLMError("the KD step is built for the `pool` downsample (all shipped configs use it)")
+        self.enc = enc
+
+    @property
+    def W(self) -> HubertDeviceWeights:
+        return self.enc.weights
+
+    # kernel-layout fp32 gradient buffers, one per weight tensor role
+    def new_grads(self) -> Dict[str, torch.Tensor]:
+        g = {k: torch.zeros(v.shape, device=v.device, dtype=torch.float32) for k, v in self.W.t.items()}
+        for li, lt in enumerate(self.W.layer_t):
+            for k, v in lt.items():
+                g[f"l{li}.{k}"] = torch.zeros(v.shape, device=v.device, dtype=torch.float32)
+        return g
+
+    def forward(self, wave: torch.Tensor):
+        W, a, enc = self.W, self.enc.arch, self.enc
+        t, dt, dev = W.t, enc.dtype, enc.device
+        wave = wave.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        tape = dict(wave=wave)
+        x = ops.hubert_conv0(wave, t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], dt)
+        acts, pres = [x], [None]
+        for i in range(1, len(a.conv_dim)):
+            Cin, Cout, k, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
+            Lo = (x.shape[0] - k) // s + 1
+            c = ops.gemm(x, t[f"conv{i}_w"], bias=t[f"conv{i}_b"], M=Lo, K=k * Cin, lda=s * Cin)
+            x = ops.layernorm(c, t[f"conv{i}_g"], t[f"conv{i}_beta"], 1e-5, gelu=True)
+            acts.append(x); pres.append(c)
+        tape.update(acts=acts, pres=pres)
+        T, H = x.shape[0], a.hidden_size
+        T_pad = _rup(T, _vec(dt))
+        fp_ln = ops.layernorm(x, t["fp_ln_g"], t["fp_ln_b"], a.layer_norm_eps)
+        x0 = ops.gemm(fp_ln, t["fp_w"], bias=t["fp_b"])
+        G, k = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
+        Hg = H // G
+        xg = ops.posconv_stage(x0, G, k)
+        pre_pos = torch.empty_like(x0)
+        x1 = torch.empty_like(x0)
+        ops.gemm_ex(xg, t["pos_w"], M=T, N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=x1, ldc=H, bias=t["pos_b"], residual=x0, ldr=H, act=L.ACT_GELU,
+                    aux_out=pre_pos, batch=G, strideA=(T + k) * Hg, strideW=Hg * k * Hg, strideC=Hg, strideBias=Hg, strideR=Hg, dtype=dt)
+        tape.update(fp_ln=fp_ln, x0=x0, xg=xg, pre_pos=pre_pos, T=T)
+        layers = []
+        x = x1
+        nh = a.num_attention_heads
+        for li in range(a.num_hidden_layers):
+            lt = W.layer_t[li]
+            ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], a.layer_norm_eps)
+            qkv = torch.zeros((T_pad, 3 * H), device=dev, dtype=dt)
+            ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"], out=qkv[:T])
+            att = ops.attn_packed_qkv(qkv[:T], [T], nh, nh, 64, False, 0.125)
+            x_mid = ops.gemm(att, lt["wo"], bias=lt["bo"], residual=x)
+            ln2 = ops.layernorm(x_mid, lt["ln2_g"], lt["ln2_b"], a.layer_norm_eps)
+            pre1 = torch.empty((T, a.intermediate_size), device=dev, dtype=dt)
+            mid = torch.empty_like(pre1)
+            ops.gemm_ex(ln2, lt["w1"], M=T, N=a.intermediate_size, K=H, lda=H, ldw=H, out=mid, bias=lt["b1"], act=L.ACT_GELU, aux_out=pre1, dtype=dt)
+            x_out = ops.gemm(mid, lt["w2"], bias=lt["b2"], residual=x_mid)
+            layers.append(dict(x=x, ln1=ln1, qkv=qkv, att=att, x_mid=x_mid, ln2=ln2, pre1=pre1, mid=mid))
+            x = x_out
+        lnf = ops.layernorm(x, t["final_ln_g"], t["final_ln_b"], a.layer_norm_eps)
+        pooled = ops.avgpool_rows(lnf, enc.pool_kernel, enc.pool_stride)
+        out = ops.gemm(pooled, t["proj_w"], bias=t["proj_b"])
+        tape.update(layers=layers, x_last=x, pooled=pooled)
+        return out, tape
+
+    def backward(self, tape, d_out: torch.Tensor, g: Dict[str, torch.Tensor], on_bucket=None) -> None:
+        """Accumulates fp32 parameter gradients into `g` (kernel layouts).  `on_bucket(names)` is called as soon as
+        a group of gradient buffers is final for this micro-step (used to launch their all-reduce early)."""
+        W, a, enc = self.W, self.enc.arch, self.enc
+        t, dt = W.t, enc.dtype
+        H, T = a.hidden_size, tape["T"]
+        nh = a.num_attention_heads
+        done = on_bucket or (lambda names: None)
+        # projection + pool + final LN
+        ops.wgrad_acc(d_out, tape["pooled"], g["proj_w"]); ops.colsum_acc(d_out, g["proj_b"])
+        d_pooled = ops.dgrad(d_out, t["proj_w"])
+        d_lnf = ops.avgpool_bwd(d_pooled, T, enc.pool_kernel, enc.pool_stride)
+        dx = ops.layernorm_bwd(tape["x_last"], t["final_ln_g"], t["final_ln_b"], d_lnf, a.layer_norm_eps, g["final_ln_g"], g["final_ln_b"])
+        done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
+        for li in reversed(range(a.num_hidden_layers)):
+            lt, c = W.layer_t[li], tape["layers"][li]
+            p = f"l{li}."
+            ops.wgrad_acc(dx, c["mid"], g[p + "w2"]); ops.colsum_acc(dx, g[p + "b2"])
+            d_mid = ops.dgrad(dx, lt["w2"])
+            d_pre1 = ops.gelu_bwd(d_mid, c["pre1"])
+            ops.wgrad_acc(d_pre1, c["ln2"], g[p + "w1"]); ops.colsum_acc(d_pre1, g[p + "b1"])
+            d_ln2 = ops.dgrad(d_pre1, lt["w1"])
+            dx_mid = ops.layernorm_bwd(c["x_mid"], lt["ln2_g"], lt["ln2_b"], d_ln2, a.layer_norm_eps, g[p + "ln2_g"], g[p + "ln2_b"])
+            ops.axpby(dx, dx_mid)
+            ops.wgrad_acc(dx_mid, c["att"], g[p + "wo"]); ops.colsum_acc(dx_mid, g[p + "bo"])
+            d_att = ops.dgrad(dx_mid, lt["wo"])
+            d_qkv = attention_backward(c["qkv"], d_att, T, nh, nh, 64, False, 0.125, 3 * H)[:T]
+            ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
+            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"])
+            dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, a.layer_norm_eps, g[p + "ln1_g"], g[p + "ln1_b"])
+            ops.axpby(dx_mid, dxin)
+            dx = dxin
+            done([p + n for n in lt])
+        # positional conv: x1 = x0 + gelu(conv(x0) + b)
+        G, k = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
+        Hg = H // G
+        d_pre = ops.gelu_bwd(dx, tape["pre_pos"])
+        ops.colsum_acc(d_pre, g["pos_b"])
+        # wgrad: dW[g][n][j*Hg + c] += sum_t d_pre[t][g*Hg + n] * xg[g][t + j][c]   (overlapping windows as the W operand)
+        ops.gemm_ex(d_pre, tape["xg"], M=Hg, N=k * Hg, K=T, lda=H, ldw=Hg, out=g["pos_w"], ldc=k * Hg, residual=g["pos_w"], ldr=k * Hg,
+                    out_f32=True, residual_f32=True, trans_a=True, trans_w=True, batch=G, strideA=Hg, strideW=(T + k) * Hg, strideC=Hg * k * Hg,
+                    strideR=Hg * k * Hg, dtype=dt)
+        # dgrad: correlation with the flipped, transposed weight over the staged d_pre (windows start one row later)
+        dpg = ops.posconv_stage(d_pre, G, k)
+        wd = t["pos_w"].view(G, Hg, k, Hg).flip(2).permute(0, 3, 2, 1).contiguous().view(G, Hg, k * Hg)  # [g][c][jj][n]
+        dx0 = torch.empty_like(dx)
+        ops.gemm_ex(dpg, wd, M=T, N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=dx0, ldc=H, residual=dx, ldr=H, batch=G, strideA=(T + k) * Hg,
+                    strideW=Hg * k * Hg, strideC=Hg, strideR=Hg, a_off=Hg, dtype=dt)
+        # feature projection
+        ops.wgrad_acc(dx0, tape["fp_ln"], g["fp_w"]); ops.colsum_acc(dx0, g["fp_b"])
+        d_fpln = ops.dgrad(dx0, t["fp_w"])
+        acts, pres = tape["acts"], tape["pres"]
+        d_act = ops.layernorm_bwd(acts[-1], t["fp_ln_g"], t["fp_ln_b"], d_fpln, a.layer_norm_eps, g["fp_ln_g"], g["fp_ln_b"])
+        done(["pos_w", "pos_b", "fp_w", "fp_b", "fp_ln_g", "fp_ln_b"])
+        # conv stack
+        for i in reversed(range(1, len(a.conv_dim))):
+            Cin, Cout, kk, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
+            Lo, Lin = pres[i].shape[0], acts[i - 1].shape[0]
+            d_c = ops.layernorm_bwd(pres[i], t[f"conv{i}_g"], t[f"conv{i}_beta"], d_act, 1e-5, g[f"conv{i}_g"], g[f"conv{i}_beta"], gelu=True)
+            ops.colsum_acc(d_c, g[f"conv{i}_b"])
+            ops.wgrad_acc(d_c, acts[i - 1], g[f"conv{i}_w"], ldx=s * Cin, Kin=kk * Cin, M=Lo)
+            dcol = ops.dgrad(d_c, t[f"conv{i}_w"])
+            d_act = ops.col2im(dcol, Lin, Cin, kk, s)
+            done([f"conv{i}_w", f"conv{i}_b", f"conv{i}_g", f"conv{i}_beta"])
+        ops.hubert_conv0_bwd(tape["wave"], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], d_act, g["conv0_w"], g["conv0_b"],
+                             g["conv0_g"], g["conv0_beta"], k=a.conv_kernel[0], stride=a.conv_stride[0])
+        done(["conv0_w", "conv0_b", "conv0_g", "conv0_beta"])
+
+
+def kernel_grads_to_state_dict(enc: AudioEncoder, g: Dict[str, torch.Tensor], master: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Map kernel-layout fp32 gradients back onto the reference's state-dict parameter names/shapes
+    (inverse of HubertDeviceWeights' re-layouts; weight-norm backward for the positional conv)."""
+    a = enc.arch
+    H, G, k = a.hidden_size, a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
+    Hg = H // G
+    out: Dict[str, torch.Tensor] = {}
+    p = "encoder.feature_extractor.conv_layers."
+    out[p + "0.conv.weight"] = g["conv0_w"].view(a.conv_dim[0], 1, -1)
+    out[p + "0.conv.bias"], out[p + "0.layer_norm.weight"], out[p + "0.layer_norm.bias"] = g["conv0_b"], g["conv0_g"], g["conv0_beta"]
+    for i in range(1, len(a.conv_dim)):
+        Cin, Cout, kk = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i]
+        out[p + f"{i}.conv.weight"] = g[f"conv{i}_w"].view(Cout, kk, Cin).permute(0, 2, 1).contiguous()
+        out[p + f"{i}.conv.bias"], out[p + f"{i}.layer_norm.weight"], out[p + f"{i}.layer_norm.bias"] = g[f"conv{i}_b"], g[f"conv{i}_g"], g[f"conv{i}_beta"]
+    p = "encoder.feature_projection."
+    out[p + "layer_norm.weight"], out[p + "layer_norm.bias"] = g["fp_ln_g"], g["fp_ln_b"]
+    out[p + "projection.weight"], out[p + "projection.bias"] = g["fp_w"], g["fp_b"]
+    # positional conv: d folded weight (H, Hg, k) -> weight-norm backward (g = original0 (1,1,k), v = original1)
+    p = "encoder.encoder.pos_conv_embed.conv."
+    dW = g["pos_w"].view(H, k, Hg).permute(0, 2, 1).contiguous()
+    k0 = p + "parametrizations.weight.original0" if p + "parametrizations.weight.original0" in master else p + "weight_g"
+    k1 = p + "parametrizations.weight.original1" if p + "parametrizations.weight.original1" in master else p + "weight_v"
+    gw, v = master[k0].float(), master[k1].float()
+    norm = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    dot = (dW * v).sum(dim=(0, 1), keepdim=True)
+    out[k0] = dot / norm
+    out[k1] = (gw / norm) * (dW - v * dot / norm.pow(2))
+    out[p + "bias"] = g["pos_b"]
+    for li in range(a.num_hidden_layers):
+        p, q = f"encoder.encoder.layers.{li}.", f"l{li}."
+        wq, wk, wv = g[q + "wqkv"].split(H, dim=0)
+        bq, bk, bv = g[q + "bqkv"].split(H, dim=0)
+        out[p + "attention.q_proj.weight"], out[p + "attention.k_proj.weight"], out[p + "attention.v_proj.weight"] = wq, wk, wv
+        out[p + "attention.q_proj.bias"], out[p + "attention.k_proj.bias"], out[p + "attention.v_proj.bias"] = bq, bk, bv
+        out[p + "attention.out_proj.weight"], out[p + "attention.out_proj.bias"] = g[q + "wo"], g[q + "bo"]
+        out[p + "layer_norm.weight"], out[p + "layer_norm.bias"] = g[q + "ln1_g"], g[q + "ln1_b"]
+        out[p + "final_layer_norm.weight"], out[p + "final_layer_norm.bias"] = g[q + "ln2_g"], g[q + "ln2_b"]
+        out[p + "feed_forward.intermediate_dense.weight"], out[p + "feed_forward.intermediate_dense.bias"] = g[q + "w1"], g[q + "b1"]
+        out[p + "feed_forward.output_dense.weight"], out[p + "feed_forward.output_dense.bias"] = g[q + "w2"], g[q + "b2"]
+    out["encoder.encoder.layer_norm.weight"], out["encoder.encoder.layer_norm.bias"] = g["final_ln_g"], g["final_ln_b"]
+    out["embed_projection.weight"], out["embed_projection.bias"] = g["proj_w"], g["proj_b"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the KD step
+# ------------------------------------------------------------------------------------------------
+class KDTrainer:
+    """ref:trainer.py:23-398 restricted to the optimisation step: losses, backward, accumulation, AdamW + PolynomialLR,
+    and (new) data parallelism: rank r runs `grad_accum_interval / world` micro-steps per optimizer step, gradients are
+    summed with an all-reduce of the fp32 buckets on a side stream while the rest of the backward still runs."""
+
+    def __init__(self, config, encoder: AudioEncoder, llm: AudioLlamaForCausalLM, prefix_ids: torch.Tensor, suffix_ids: torch.Tensor,
+                 total_optimizer_steps: int = 1000, process_group=None):
+        tr = config.train
+        self.enc, self.llm = encoder, llm
+        self.ntp_w, self.ld_w, self.fd_w = tr.ntp_loss_weight, tr.ld_loss_weight, tr.fd_loss_weight
+        self.use_ld, self.use_fd = bool(tr.use_ld_loss), bool(tr.use_fd_loss)
+        self.taps = list(tr.fd_loss_connector_layers)
+        self.accum = int(tr.grad_accum_interval)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        if self.accum % self.world:
+            raise L.SpeechLLMError(f"grad_accum_interval={self.accum} must be a multiple of the world size {self.world}")
+        self.local_accum = self.accum // self.world
+        dev = encoder.device
+        self.prefix_ids, self.suffix_ids = prefix_ids.to(dev), suffix_ids.to(dev)
+        self.enc_tape, self.llm_tape = EncoderTape(encoder), LlamaTape(llm)
+        # fp32 master weights (the reference keeps fp32 params under fp16 autocast, ref:trainer.py:252,270)
+        self.master = {k: v.detach().to(dev, torch.float32).clone() for k, v in encoder.state_dict().items()}
+        self.trainable = [k for k in self.master if k != "encoder.masked_spec_embed"]
+        self.params = [torch.nn.Parameter(self.master[k], requires_grad=True) for k in self.trainable]
+        opt = tr.optimizer
+        self.optimizer = torch.optim.AdamW(self.params, lr=float(opt.lr), betas=(float(opt.beta1), float(opt.beta2)))
+        self.scheduler = torch.optim.lr_scheduler.PolynomialLR(self.optimizer, total_iters=total_optimizer_steps, power=1.0)
+        self.grads = self.enc_tape.new_grads()
+        self.micro = 0
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self._pending = []
+
+    # -- one micro-step -------------------------------------------------------------------------
+    def micro_step(self, wave: torch.Tensor, text_ids: torch.Tensor, response_ids: torch.Tensor) -> Dict[str, float]:
+        """wave: 1-D audio; text_ids / response_ids: 1-D ids with the BOS already stripped by the collate
+        (ref:trainer.py:155-156).  Returns the three losses of ref:trainer.py:325-370 (python floats)."""
+        enc, llm = self.enc, self.llm
+        dev, dt = enc.device, enc.dtype
+        emb = llm.model.embed_tokens
+        response_ids = response_ids.to(dev)
+        n = int(response_ids.shape[0])
+        last = (self.micro + 1) % self.local_accum == 0
+        audio, etape = self.enc_tape.forward(wave)                                  # (P, H)
+        pre, suf, resp = emb(self.prefix_ids)[0], emb(self.suffix_ids)[0, 1:], emb(response_ids[None])[0, 1:]
+        n_pre, P = pre.shape[0], audio.shape[0]
+        a_seq = torch.cat([pre, audio, suf, resp], 0).contiguous()                   # ref:utils.py:36-45
+        hidden_a, ltape = self.llm_tape.forward(a_seq)
+        S = a_seq.shape[0]
+        logits_a = self.llm_tape.logits(hidden_a[-1][S - n:].contiguous())           # (n, V) fp32 — only the rows the losses read
+        losses = torch.zeros(3, device=dev, dtype=torch.float32)
+        d_logits = torch.empty((n, logits_a.shape[1]), device=dev, dtype=dt)
+        labels = response_ids[1:].to(torch.int32).contiguous()                       # logits[-n:-1] predict labels[1:]
+        inv_acc = 1.0 / self.accum                                                   # ref:trainer.py:373
+        d_logits.zero_()
+        ops.ce_loss(logits_a[: n - 1], labels, 1.0 / (n - 1), losses[0:1], None, dtype=dt)
+        ops.ce_loss(logits_a[: n - 1], labels, self.ntp_w * inv_acc / (n - 1), torch.zeros(1, device=dev), d_logits[: n - 1], accumulate=True, dtype=dt)
+        d_taps: Dict[int, torch.Tensor] = {}
+        if self.use_ld or self.use_fd:
+            t_seq = torch.cat([pre, emb(text_ids.to(dev)[None])[0], suf, resp], 0).contiguous()
+            t_out = llm(inputs_embeds=t_seq[None], output_hidden_states=True)       # teacher pass: inference kernels, no tape
+            if self.use_ld:
+                logits_t = t_out.logits[0, -n:].contiguous()
+                ops.soft_ce_loss(logits_a, logits_t, 1.0 / n, losses[1:2], None, dtype=dt)
+                ops.soft_ce_loss(logits_a, logits_t, self.ld_w * inv_acc / n, torch.zeros(1, device=dev), d_logits, accumulate=True, dtype=dt)
+            if self.use_fd:
+                for l in self.taps:
+                    ha, ht = hidden_a[l][S - n:].contiguous(), t_out.hidden_states[l][0, -n:].contiguous()
+                    d = torch.zeros((S, ha.shape[1]), device=dev, dtype=dt)
+                    ops.mse_loss(ha, ht, 1.0, losses[2:3], None)
+                    dtail = torch.empty_like(ha)
+                    ops.mse_loss(ha, ht, self.fd_w * inv_acc, torch.zeros(1, device=dev), dtail)
+                    d[S - n:] = dtail
+                    d_taps[l] = d
+        d_seq = self.llm_tape.backward(ltape, d_logits, n, d_taps)
+        d_audio = d_seq[n_pre:n_pre + P].contiguous()
+        self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self._reduce_bucket if (last and self.world > 1) else None)
+        self.micro += 1
+        self.last_d_audio = d_audio
+        ntp, ld, fd = [float(v) for v in losses.tolist()]
+        if last:
+            self.optimizer_step()
+        return dict(ntp_loss=ntp, ld_loss=ld, fd_loss=fd, total=self.ntp_w * ntp + self.ld_w * ld + self.fd_w * fd)
+
+    # -- data parallel gradient exchange ----------------------------------------------------------
+    def _reduce_bucket(self, names: Sequence[str]) -> None:
+        """All-reduce (sum) a group of finished fp32 gradient buffers on the side stream while backward continues."""
+        import torch.distributed as dist
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            flat = torch.cat([self.grads[n].reshape(-1) for n in names])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._pending.append((work, flat, list(names)))
+
+    def _finish_reduce(self) -> None:
+        if not self._pending:
+            return
+        with torch.cuda.stream(self.comm_stream):
+            for work, flat, names in self._pending:
+                work.wait()
+                off = 0
+                for n in names:
+                    g = self.grads[n]
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._pending = []
+
+    # -- optimizer step ---------------------------------------------------------------------------
+    def optimizer_step(self) -> None:
+        self._finish_reduce()
+        sd_grads = kernel_grads_to_state_dict(self.enc, self.grads, self.master)
+        for k, p in zip(self.trainable, self.params):
+            p.grad = sd_grads[k].reshape(p.shape).to(torch.float32)
+        self.last_grads = {k: p.grad.clone() for k, p in zip(self.trainable, self.params)}
+        self.optimizer.step()
+        self.scheduler.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        for gbuf in self.grads.values():
+            gbuf.zero_()
+        self.enc.load_state_dict({k: v.detach() for k, v in self.master.items()})   # refresh the compute-dtype kernel weights

@@ -160,6 +160,15 @@ class HubertDeviceWeights:
             self._keep.append(t)
             return t
 
+        self.t: Dict[str, torch.Tensor] = {}   # role -> device tensor (the training graph composes ops from these)
+        by_ptr: Dict[int, torch.Tensor] = {}
+        _dev0 = dev
+
+        def dev(t: torch.Tensor, dt=None) -> torch.Tensor:  # noqa: F811 - also index by pointer
+            r = _dev0(t, dt)
+            by_ptr[r.data_ptr()] = r
+            return r
+
         m = L.HubertModel()
         m.dtype = L.dtype_code(dtype)
         m.n_conv, m.hidden, m.n_layers = len(arch.conv_dim), H, arch.num_hidden_layers
@@ -210,6 +219,14 @@ class HubertDeviceWeights:
         else:  # stack / ctc_pool: the host composes the downsample from ops on last_hidden
             m.proj_w, m.proj_b = None, None
         self.struct = m
+        g = lambda p_: by_ptr[p_]
+        self.t.update(conv0_w=g(m.conv0_w), conv0_b=g(m.conv0_b), conv0_g=g(m.conv0_g), conv0_beta=g(m.conv0_beta),
+                      fp_ln_g=g(m.fp_ln_g), fp_ln_b=g(m.fp_ln_b), fp_w=g(m.fp_w), fp_b=g(m.fp_b), pos_w=g(m.pos_w), pos_b=g(m.pos_b),
+                      final_ln_g=g(m.final_ln_g), final_ln_b=g(m.final_ln_b), proj_w=self.proj_w, proj_b=self.proj_b)
+        for i in range(1, m.n_conv):
+            self.t.update({f"conv{i}_w": g(m.conv_w[i]), f"conv{i}_b": g(m.conv_b[i]), f"conv{i}_g": g(m.conv_g[i]),
+                           f"conv{i}_beta": g(m.conv_beta[i])})
+        self.layer_t = [{n: g(getattr(self._layers[li], n)) for n, _ in L.HubertLayer._fields_} for li in range(arch.num_hidden_layers)]
 
     def n_params(self) -> int:
         return sum(t.numel() for t in self._keep)
@@ -263,6 +280,11 @@ class LlamaDeviceWeights:
         m.layers = C.cast(self._layers, C.POINTER(L.LlamaLayer))
         self.struct = m
         self.decode_packed = False
+        by_ptr = {t.data_ptr(): t for t in self._keep}
+        self.layer_t = [{n: by_ptr[getattr(self._layers[li], n)] for n in ("norm1", "wqkv", "wo", "norm2", "wgu", "wdown")}
+                        for li in range(arch.num_hidden_layers)]
+        self.final_norm = by_ptr[m.final_norm]
+        self.rope_cos, self.rope_sin = by_ptr[m.rope_cos], by_ptr[m.rope_sin]
 
     def build_decode_weights(self, fuse_norm: Optional[bool] = None) -> None:
         """Second, decode-only copy of every matrix in the fragment-packed layout the weight-streaming kernel

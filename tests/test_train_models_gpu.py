@@ -1,0 +1,109 @@
+"""GPU: the KD step (ref:trainer.py:270-374) on the HIP path against the reference-generated fixture
+`pipeline_tiny.npz` (losses, gradient norms, d ntp / d audio_embeds) and against autograd through the CPU oracle."""
+import pytest
+import torch
+
+from conftest import golden, pkg, rel_err, t
+from oracle import hubert_oracle as ho
+from oracle import kd_oracle as ko
+from oracle import llama_oracle as lo
+from oracle.golden_cfgs import TINY_HUBERT, TINY_LLAMA
+from test_models_gpu import DEV, make_encoder, make_llama
+
+pytestmark = pytest.mark.gpu
+
+ri = pkg("random_init")
+cfgm = pkg("config")
+training = pkg("training")
+utils = pkg("utils")
+
+
+def kd_config(ntp=0.5, ld=0.5, fd=1.0, use_ld=True, use_fd=True, taps=(0, 1, 3), accum=16):
+    return cfgm.from_dict(dict(train=dict(optimizer=dict(lr=5e-5, beta1=0.9, beta2=0.999), grad_accum_interval=accum, use_ld_loss=use_ld,
+                                          use_fd_loss=use_fd, ntp_loss_weight=ntp, ld_loss_weight=ld, fd_loss_weight=fd,
+                                          fd_loss_connector_layers=list(taps))))
+
+
+def build(g, dtype, **kw):
+    enc, enc_sd = make_encoder(TINY_HUBERT, TINY_LLAMA.hidden_size, int(g["enc_seed"]), dtype)
+    llm, llm_sd = make_llama(TINY_LLAMA, int(g["llm_seed"]), dtype)
+    tr = training.KDTrainer(kd_config(**kw), enc, llm, t(g["prefix_ids"]), t(g["suffix_ids"]))
+    wave = ri.synthetic_waveform(int(g["n_samples"]), seed=int(g["wave_seed"]))
+    return tr, enc_sd, llm_sd, wave
+
+
+def test_llm_side_ntp_gradient_wrt_audio_embeddings_fp32():
+    g = golden("pipeline_tiny")
+    tr, _, _, wave = build(g, torch.float32, ntp=1.0, use_ld=False, use_fd=False, accum=1)
+    tr.optimizer_step = lambda: None   # inspect the raw gradient, do not update
+    losses = tr.micro_step(wave, t(g["text_ids"]), t(g["response_ids"]))
+    assert abs(losses["ntp_loss"] - float(g["ntp"])) < 1e-4
+    assert rel_err(tr.last_d_audio.cpu(), t(g["d_ntp_d_audio_embeds"])[0]) < 1e-4
+
+
+def test_kd_micro_step_losses_and_encoder_gradients_fp32_vs_reference_fixture():
+    g = golden("pipeline_tiny")
+    tr, enc_sd, _, wave = build(g, torch.float32, taps=tuple(g["connector_layers"].tolist()))
+    losses = tr.micro_step(wave, t(g["text_ids"]), t(g["response_ids"]))
+    for k, ref in (("ntp_loss", "ntp"), ("ld_loss", "ld"), ("fd_loss", "fd"), ("total", "total")):
+        assert abs(losses[k] - float(g[ref])) < 1e-4 * max(1.0, abs(float(g[ref]))), k
+    grads = training.kernel_grads_to_state_dict(tr.enc, tr.grads, tr.master)
+    n = lambda k: float(grads[k].norm())
+    assert abs(n("embed_projection.weight") - float(g["grad_norm_embed_projection_weight"])) < 2e-3 * float(g["grad_norm_embed_projection_weight"])
+    assert abs(n("encoder.encoder.layers.0.attention.q_proj.weight") - float(g["grad_norm_layer0_q"])) < 2e-3 * float(g["grad_norm_layer0_q"])
+    assert abs(n("encoder.feature_extractor.conv_layers.0.conv.weight") - float(g["grad_norm_conv0"])) < 2e-3 * float(g["grad_norm_conv0"])
+    total = torch.stack([grads[k].norm() for k in tr.trainable]).norm()
+    assert abs(float(total) - float(g["grad_norm_total"])) < 2e-3 * float(g["grad_norm_total"])
+    assert len(tr.trainable) == int(g["n_params_with_grad"])
+
+
+def test_every_encoder_parameter_gradient_matches_oracle_autograd_fp32():
+    g = golden("pipeline_tiny")
+    tr, enc_sd, llm_sd, wave = build(g, torch.float32, taps=(0, 1, 3))
+    tr.micro_step(wave, t(g["text_ids"]), t(g["response_ids"]))
+    grads = training.kernel_grads_to_state_dict(tr.enc, tr.grads, tr.master)
+    # CPU oracle with autograd over the same state dict
+    sd = {k: v.clone().requires_grad_(k != "encoder.masked_spec_embed") for k, v in enc_sd.items()}
+    audio = ho.audio_encoder_forward(sd, TINY_HUBERT, wave[None])
+    losses = ko.kd_losses(llm_sd, TINY_LLAMA, audio, t(g["text_ids"]), t(g["response_ids"]), t(g["prefix_ids"]), t(g["suffix_ids"]),
+                          connector_layers=(0, 1, 3))
+    (losses["total"] / 16).backward()
+    total = torch.stack([sd[k].grad.norm() for k in tr.trainable]).norm()
+    worst = 0.0
+    for k in tr.trainable:
+        ref = sd[k].grad
+        err = float((grads[k].cpu().reshape(ref.shape).double() - ref.double()).norm())
+        # k_proj.bias has an exactly-zero true gradient (softmax is shift invariant): judge it on the absolute scale
+        bound = 2e-3 * float(ref.norm()) + 1e-6 * float(total)
+        worst = max(worst, err / (float(ref.norm()) + 1e-6 * float(total)))
+        assert err < bound, (k, err, float(ref.norm()))
+    print("worst relative gradient error", worst)
+
+
+def test_optimizer_step_updates_master_and_kernel_weights():
+    g = golden("pipeline_tiny")
+    tr, enc_sd, _, wave = build(g, torch.float32, accum=2)
+    before = {k: v.clone() for k, v in tr.master.items()}
+    out0 = tr.enc(wave[None].to(DEV)).clone()
+    tr.micro_step(wave, t(g["text_ids"]), t(g["response_ids"]))
+    assert all(torch.equal(before[k], tr.master[k]) for k in before)           # accumulating, no update yet
+    tr.micro_step(wave, t(g["text_ids"]), t(g["response_ids"]))
+    changed = [k for k in tr.trainable if not torch.equal(before[k], tr.master[k])]
+    assert len(changed) == len(tr.trainable)
+    assert torch.equal(before["encoder.masked_spec_embed"], tr.master["encoder.masked_spec_embed"])
+    assert not torch.equal(out0, tr.enc(wave[None].to(DEV)))                    # kernel weights were refreshed
+    assert all(float(v.abs().max()) == 0 for v in tr.grads.values())            # accumulators cleared
+    # AdamW first step moves every weight by ~lr: |delta| <= lr * (1 + wd*|w|) + eps
+    k = "embed_projection.weight"
+    assert float((before[k] - tr.master[k]).abs().max()) <= 5e-5 * (1 + 0.01 * float(before[k].abs().max())) + 1e-7
+
+
+def test_kd_micro_step_bf16_runs_and_tracks_fp32():
+    g = golden("pipeline_tiny")
+    tr, _, _, wave = build(g, torch.bfloat16)
+    losses = tr.micro_step(wave, t(g["text_ids"]), t(g["response_ids"]))
+    for k, ref in (("ntp_loss", "ntp"), ("ld_loss", "ld")):
+        assert abs(losses[k] - float(g[ref])) < 3e-2 * abs(float(g[ref])), (k, losses[k], float(g[ref]))
+    grads = training.kernel_grads_to_state_dict(tr.enc, tr.grads, tr.master)
+    gn = float(grads["embed_projection.weight"].norm())
+    assert abs(gn - float(g["grad_norm_embed_projection_weight"])) < 0.15 * float(g["grad_norm_embed_projection_weight"])
