@@ -98,6 +98,51 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
                        f"{full_new_tokens} tokens per utterance at batch 1")}
 
 
+def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist):
+    """ref:trainer.py:270-384 on synthetic data: 10 s audio, 40 text ids, 64 response ids."""
+    training, ri = mod("training"), mod("random_init")
+    tr = training.KDTrainer(conf, enc, llm, prefix, suffix, total_optimizer_steps=1000)
+    g = torch.Generator().manual_seed(99 + rank)
+    text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g)
+    resp_ids = torch.randint(1, larch.vocab_size, (64,), generator=g)
+    wave = ri.synthetic_waveform(160000, seed=4321 + rank).to(dev)
+    n_micro = tr.local_accum * args.kd_optimizer_steps
+    tr.micro = 1 - tr.local_accum if tr.local_accum > 1 else 0   # warm-up micro-step that does not reach the optimizer
+    if tr.local_accum == 1:
+        saved = tr.optimizer_step
+        tr.optimizer_step = lambda: None
+        tr.micro_step(wave, text_ids, resp_ids)
+        tr.optimizer_step = saved
+        for gb in tr.grads.values():
+            gb.zero_()
+    else:
+        tr.micro_step(wave, text_ids, resp_ids)
+        for gb in tr.grads.values():
+            gb.zero_()
+    tr.micro = 0
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = None
+    for _ in range(n_micro):
+        losses = tr.micro_step(wave, text_ids, resp_ids)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt_ = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_ = float(tt.item())
+    n_params = sum(p.numel() for p in tr.params)
+    return {"samples_per_s": round(n_micro * world / dt_, 3), "ms_per_micro_step": round(dt_ / n_micro * 1e3, 2),
+            "optimizer_steps": args.kd_optimizer_steps, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
+            "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
+            "losses": {k: round(v, 4) for k, v in losses.items()}, "dtype": "bf16 compute, fp32 master/grads",
+            "note": "dropout/layerdrop/spec-augment off; python-driven op tape (launch overhead included)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +153,7 @@ def main():
     ap.add_argument("--max-new-tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=8)
+    ap.add_argument("--kd-optimizer-steps", type=int, default=1, help="optimizer steps of the KD training leg (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -217,6 +263,15 @@ def main():
         alg_bytes = 2 * F_ * H * 2 + B * H * 2 + B * F_ * 2  # weights once + activations in/out
         gemm_probe = (alg_bytes, dur_ms)
 
+    # ---- KD training leg (BASELINE configs[2]): one optimizer step = grad_accum_interval micro-steps shared by the ranks,
+    # fp32 gradient buckets all-reduced with RCCL on a side stream while backward still runs
+    kd = None
+    if args.kd_optimizer_steps > 0:
+        try:
+            kd = kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist)
+        except Exception as e:  # the inference line must survive a training-leg failure
+            kd = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -250,6 +305,8 @@ def main():
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(dur_ms * 1e3, 2)},
     }
+    if kd is not None:
+        result["kd_step"] = kd
     if not args.no_cpu_baseline:
         del llm, wts
         result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)

@@ -372,8 +372,8 @@ class KDTrainer:
         self.scheduler = torch.optim.lr_scheduler.PolynomialLR(self.optimizer, total_iters=total_optimizer_steps, power=1.0)
         self.grads = self.enc_tape.new_grads()
         self.micro = 0
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
-        self._pending = []
+        from .dist import BucketedAllReduce
+        self.reducer = BucketedAllReduce(self.grads, group=process_group) if self.world > 1 else None
 
     # -- one micro-step -------------------------------------------------------------------------
     def micro_step(self, wave: torch.Tensor, text_ids: torch.Tensor, response_ids: torch.Tensor) -> Dict[str, float]:
@@ -418,7 +418,7 @@ class KDTrainer:
                     d_taps[l] = d
         d_seq = self.llm_tape.backward(ltape, d_logits, n, d_taps)
         d_audio = d_seq[n_pre:n_pre + P].contiguous()
-        self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self._reduce_bucket if (last and self.world > 1) else None)
+        self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self.reducer.ready if (last and self.reducer is not None) else None)
         self.micro += 1
         self.last_d_audio = d_audio
         ntp, ld, fd = [float(v) for v in losses.tolist()]
@@ -426,36 +426,10 @@ class KDTrainer:
             self.optimizer_step()
         return dict(ntp_loss=ntp, ld_loss=ld, fd_loss=fd, total=self.ntp_w * ntp + self.ld_w * ld + self.fd_w * fd)
 
-    # -- data parallel gradient exchange ----------------------------------------------------------
-    def _reduce_bucket(self, names: Sequence[str]) -> None:
-        """All-reduce (sum) a group of finished fp32 gradient buffers on the side stream while backward continues."""
-        import torch.distributed as dist
-        cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(ev)
-            flat = torch.cat([self.grads[n].reshape(-1) for n in names])
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._pending.append((work, flat, list(names)))
-
-    def _finish_reduce(self) -> None:
-        if not self._pending:
-            return
-        with torch.cuda.stream(self.comm_stream):
-            for work, flat, names in self._pending:
-                work.wait()
-                off = 0
-                for n in names:
-                    g = self.grads[n]
-                    g.copy_(flat[off:off + g.numel()].view_as(g))
-                    off += g.numel()
-        torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self._pending = []
-
     # -- optimizer step ---------------------------------------------------------------------------
     def optimizer_step(self) -> None:
-        self._finish_reduce()
+        if self.reducer is not None:
+            self.reducer.finish()
         sd_grads = kernel_grads_to_state_dict(self.enc, self.grads, self.master)
         for k, p in zip(self.trainable, self.params):
             p.grad = sd_grads[k].reshape(p.shape).to(torch.float32)

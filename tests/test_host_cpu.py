@@ -163,3 +163,34 @@ def test_two_rank_report_plumbing_over_gloo():
     [p.join(timeout=60) for p in procs]
     for _, tokens, audio, slowest in res:
         assert tokens == 21 * 7.0 and audio == sum(range(1, 22)) and slowest == 2.0
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank holds the same named buffers; rank r's "micro-step gradients" are (r+1) * base
+    g = torch.Generator().manual_seed(0)
+    base = {f"p{i}": torch.randn(n, generator=g) for i, n in enumerate((1000, 7, 333, 4096, 1))}
+    grads = {k: v * (rank + 1) for k, v in base.items()}
+    red = distm.BucketedAllReduce(grads, min_bucket_bytes=4 * 1200)
+    red.ready(["p4", "p3"])      # "late layers first", like the backward pass
+    red.ready(["p2"])
+    red.ready(["p1", "p0"])
+    buckets = red.finish()
+    ok = all(torch.allclose(grads[k], base[k] * sum(range(1, world + 1))) for k in base)
+    q.put((rank, ok, buckets))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_two_ranks_over_gloo():
+    """DP invariant of the KD step: after the exchange every rank holds the SUM of all ranks' accumulated
+    gradients (each already divided by the global accumulation count), in >= 2 buckets launched in backward order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(ok for _, ok, _ in res) and all(b >= 2 for _, _, b in res)
