@@ -101,10 +101,16 @@ int sl_gemm_fused_decode(const sl_gemm_args* a, const sl_gemm_fused* fx, sl_stre
  *            transposed operands are read in 16-byte chunks along the OUTPUT index: lda/ldw must be
  *            multiples of 8 (bf16) / 4 (f32) and each stored row readable up to that multiple.
  *   aux_out: also store the pre-activation (after bias, before act) — what GELU's backward needs.
- *   residual_f32: with out_f32, the residual is float: C = residual + A.W^T accumulates fp32 gradients. */
+ *   residual_f32: with out_f32, the residual is float: C = residual + A.W^T accumulates fp32 gradients.
+ *   groups / w_mod: see below. */
 typedef struct {
-  int32_t trans_a, trans_w, residual_f32, reserved;
+  int32_t trans_a, trans_w, residual_f32, w_mod;
   void* aux_out;
+  /* grouped (ragged) batch: device array of `batch` records {M, a_off, c_off, r_off} (int64, element offsets).
+   * Batch z computes its own M rows from A + a_off into C + c_off (residual + r_off); W and bias are taken
+   * at index z % w_mod (strideW / strideBias).  args->M is the LARGEST group (sizes the grid).  One launch
+   * then covers e.g. a conv layer of every utterance of a ragged batch (hf:...hubert.py:141). */
+  const int64_t* groups;
 } sl_gemm_ex_args;
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);
 

@@ -41,7 +41,7 @@ class GemmFused(C.Structure):
 
 
 class GemmEx(C.Structure):
-    _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("reserved", c_i32), ("aux_out", c_vp)]
+    _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("w_mod", c_i32), ("aux_out", c_vp), ("groups", c_vp)]
 
 
 class AttnArgs(C.Structure):

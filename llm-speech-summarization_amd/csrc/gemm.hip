@@ -7,7 +7,11 @@
 //     one block owns 16 (or 32 gate/up) weight rows, its waves interleave 64-byte K steps, weight
 //     fragments go global -> VGPR -> MFMA with no LDS round trip, partial sums meet in LDS once.
 // A rows may overlap (lda < K): that is how the strided convolutions run without im2col.
+#include <stdlib.h>
+
 #include "common.h"
+
+static int g_disable_glds = 0;  // tuning switch (SL_DISABLE_GLDS=1): A/B the two staging paths in one process
 
 struct GemmP {
   const void* A; int64_t lda, sA;
@@ -20,7 +24,27 @@ struct GemmP {
   int ta, tw;          // operand stored transposed: A as (K, M) rows lda; W as (K, N) rows ldw
   void* aux;           // optional: pre-activation values (after bias, before act), same layout/dtype as C
   int res_f32;         // residual is float (fp32 gradient accumulation: C = C_old + A.W^T with out_f32)
+  const int64_t* grp;  // grouped (ragged) batch: per z {M, a_off, c_off, r_off} in elements; W/bias use z % w_mod
+  int w_mod;
+  int64_t cx, rx;      // per-block extra offsets resolved from grp
 };
+
+// resolve the per-batch descriptor: returns false when this block's tile lies outside batch z's rows
+__device__ __forceinline__ bool resolve_group(GemmP& p, int z, int bm, int64_t& a_off, int& wz) {
+  p.cx = 0; p.rx = 0;
+  wz = z;
+  a_off = (int64_t)z * p.sA;
+  if (p.grp) {
+    const int64_t* g = p.grp + 4 * (int64_t)z;
+    p.M = (int)g[0];
+    a_off = g[1];
+    p.cx = g[2] - (int64_t)z * p.sC;   // the epilogue adds z*sC back
+    p.rx = g[3] - (int64_t)z * p.sR;
+    wz = z % p.w_mod;
+    if (bm * 128 >= p.M) return false;
+  }
+  return true;
+}
 
 // ----------------------------------------------------------------------------------------------
 // epilogue helper: +bias, act, +residual, store (T or float)
@@ -41,6 +65,53 @@ constexpr int TBM = 128, TBN = 128, TROWB = 128;  // tile rows, tile cols, bytes
 
 // byte offset of 16-byte chunk `ch` (0..7) of tile row `row` in a [128][128 B] swizzled LDS tile
 __device__ __forceinline__ int lds_off(int row, int ch) { return row * TROWB + ((ch ^ (row & 7)) << 4); }
+
+// shared epilogue of the tiled kernels: +bias, [aux store], act, +residual, store
+template <typename T, int ACT>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[4][4], int bm, int bn, int wm, int wn, int q, int r, int z, int wz) {
+  const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
+  void* Cb = p.out_f32 ? (void*)((float*)p.C + co) : (void*)((T*)p.C + co);
+  const T* bias = p.bias ? (const T*)p.bias + (int64_t)wz * p.sBias : nullptr;
+  const void* Rb = p.res ? (p.res_f32 ? (const void*)((const float*)p.res + ro) : (const void*)((const T*)p.res + ro)) : nullptr;
+  const int row0 = bm * TBM + wm * 64 + q * 4;
+  const int col0 = bn * TBN + wn * 64 + r;
+  if constexpr (ACT == SL_ACT_SILU_MUL) {
+    const int nout = p.N >> 1;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int gcol = col0 + (2 * pr) * 16, ucol = gcol + 16;
+      const int ocol = ((bn * TBN + wn * 64) >> 1) + pr * 16 + r;
+      if (ocol >= nout) continue;
+      const float bg = bias ? to_f32(bias[gcol]) : 0.f, bu = bias ? to_f32(bias[ucol]) : 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + m * 16 + i;
+          if (row < p.M) store_out<T>(p, Cb, Rb, row, ocol, silu(acc[m][2 * pr][i] + bg) * (acc[m][2 * pr + 1][i] + bu));
+        }
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int col = col0 + n * 16;
+      if (col >= p.N) continue;
+      const float b = bias ? to_f32(bias[col]) : 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = row0 + m * 16 + i;
+          if (row < p.M) {
+            float v = acc[m][n][i] + b;
+            if (p.aux) ((T*)p.aux + co)[(int64_t)row * p.ldc + col] = from_f32<T>(v);
+            if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
+            store_out<T>(p, Cb, Rb, row, col, v);
+          }
+        }
+    }
+  }
+}
 
 template <typename T, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
@@ -63,8 +134,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
   const int bn = bid / p.tiles_m, bm = bid - bn * p.tiles_m;
   const int z = blockIdx.y;
 
-  const T* A = (const T*)p.A + (int64_t)z * p.sA;
-  const T* W = (const T*)p.W + (int64_t)z * p.sW;
+  int64_t a_off; int wz;
+  if (!resolve_group(p, z, bm, a_off, wz)) return;
+  const T* A = (const T*)p.A + a_off;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW;
 
   // staging assignment: 4 chunks of A and 4 of W per thread
   const T* ga[4];
@@ -160,48 +233,93 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
     __syncthreads();
   }
 
-  // epilogue
-  void* Cb = p.out_f32 ? (void*)((float*)p.C + (int64_t)z * p.sC) : (void*)((T*)p.C + (int64_t)z * p.sC);
-  const T* bias = p.bias ? (const T*)p.bias + (int64_t)z * p.sBias : nullptr;
-  const void* Rb = p.res ? (const void*)((const T*)p.res + (int64_t)z * p.sR) : nullptr;
-  const int row0 = bm * TBM + wm * 64 + q * 4;
-  const int col0 = bn * TBN + wn * 64 + r;
-  if constexpr (ACT == SL_ACT_SILU_MUL) {
-    const int nout = p.N >> 1;
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      const int gcol = col0 + (2 * pr) * 16, ucol = gcol + 16;
-      const int ocol = ((bn * TBN + wn * 64) >> 1) + pr * 16 + r;
-      if (ocol >= nout) continue;
-      const float bg = bias ? to_f32(bias[gcol]) : 0.f, bu = bias ? to_f32(bias[ucol]) : 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = row0 + m * 16 + i;
-          if (row < p.M) store_out<T>(p, Cb, Rb, row, ocol, silu(acc[m][2 * pr][i] + bg) * (acc[m][2 * pr + 1][i] + bu));
-        }
-    }
-  } else {
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int col = col0 + n * 16;
-      if (col >= p.N) continue;
-      const float b = bias ? to_f32(bias[col]) : 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = row0 + m * 16 + i;
-          if (row < p.M) {
-            float v = acc[m][n][i] + b;
-            if (p.aux) ((T*)p.aux + (int64_t)z * p.sC)[(int64_t)row * p.ldc + col] = from_f32<T>(v);
-            if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
-            store_out<T>(p, Cb, Rb, row, col, v);
-          }
-        }
-    }
+  tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, wz);
+}
+
+// ----------------------------------------------------------------------------------------------
+// tiled kernel, direct-to-LDS staging (global_load_lds_dwordx4): same tile, same swizzled LDS image — the
+// swizzle moves to the per-lane SOURCE address because the LDS side of an LDS-DMA is lane-linear — no
+// staging VGPRs, no ds_write pass.  Used when K is a whole number of 128-byte slabs and no operand is
+// transposed (every forward GEMM of the encoder / prefill at model shapes).
+// ----------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int BK = TROWB / (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * TROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, q = lane >> 4;
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   }
+  const int bn = bid / p.tiles_m, bm = bid - bn * p.tiles_m;
+  const int z = blockIdx.y;
+  int64_t a_off; int wz;
+  if (!resolve_group(p, z, bm, a_off, wz)) return;
+  const T* A = (const T*)p.A + a_off;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW;
+
+  // LDS chunk c = tid + 256 i sits at (row c>>3, physical chunk c&7) and must hold logical chunk (c&7)^(row&7)
+  const T* ga[4];
+  const T* gw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, ch = (c & 7) ^ (row & 7);
+    int ar = bm * TBM + row; ar = ar < p.M ? ar : p.M - 1;
+    int wr = bn * TBN + row; wr = wr < p.N ? wr : p.N - 1;
+    ga[i] = A + (int64_t)ar * p.lda + ch * VEC;
+    gw[i] = W + (int64_t)wr * p.ldw + ch * VEC;
+  }
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;  // this wave's 1 KiB piece inside a 4 KiB group
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = p.K / BK;
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[i] + k0), (lds_ptr_t)(&smem[buf][0][i * 4096 + wave_lds]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gw[i] + k0), (lds_ptr_t)(&smem[buf][1][i * 4096 + wave_lds]), 16, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+    const unsigned char* sa = &smem[buf][0][0];
+    const unsigned char* sw = &smem[buf][1][0];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 fa[4], fb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(sa + lds_off(wm * 64 + m * 16 + r, s * 4 + q));
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fb[n] = *(const uint4*)(sw + lds_off(wn * 64 + n * 16 + r, s * 4 + q));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], fa[m], fb[n]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, wz);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -429,7 +547,11 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   p.tiles_m = (p.M + TBM - 1) / TBM;
   p.tiles_n = (p.N + TBN - 1) / TBN;
   dim3 grid(p.tiles_m * p.tiles_n, batch);
-  hipLaunchKernelGGL((gemm_tiled_kernel<T, ACT>), grid, dim3(256), 0, st, p);
+  constexpr int BK = TROWB / (int)sizeof(T);
+  if (!p.ta && !p.tw && p.K % BK == 0 && !g_disable_glds)
+    hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_tiled_kernel<T, ACT>), grid, dim3(256), 0, st, p);
   SL_CHECK_LAUNCH("gemm_tiled");
   return 0;
 }
@@ -480,7 +602,7 @@ static int launch_skinny(GemmP& p, const SkinnyX& sx, int batch, bool packed, hi
 
 template <typename T>
 static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStream_t st) {
-  const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32;  // backward features live in the tiled kernel
+  const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32 && !p.grp;  // backward features live in the tiled kernel
   const bool packed = a->w_layout == SL_W_PACKED;
   if (!skinny && (packed || a->act == SL_ACT_ROPE_KV || sx.fuse_rms)) {
     sl_set_error("sl_gemm: packed weights / ROPE_KV / fused RMSNorm are decode (M <= 64) features, M=%d", a->M);
@@ -498,6 +620,10 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
 
 int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st) {
   SL_CHECK_ARG(a != nullptr, "sl_gemm: null args");
+  {
+    const char* e = getenv("SL_DISABLE_GLDS");
+    g_disable_glds = (e && e[0] == '1') ? 1 : 0;
+  }
   SL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0, "sl_gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   SL_CHECK_ARG(a->dtype == SL_F32 || a->dtype == SL_BF16, "sl_gemm: bad dtype %d", a->dtype);
   const int vec = a->dtype == SL_F32 ? 4 : 8;
@@ -521,9 +647,10 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.res = a->residual; p.ldr = a->ldr; p.sR = a->strideR;
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
-  p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0;
+  p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = 0;
   if (ex) {
     p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;
+    p.grp = ex->groups; p.w_mod = ex->w_mod > 0 ? ex->w_mod : 1;
     SL_CHECK_ARG(!(p.ta || p.tw || p.aux) || a->act != SL_ACT_SILU_MUL, "sl_gemm_ex: transposed operands / aux_out are not combined with SILU_MUL");
     SL_CHECK_ARG(!p.res_f32 || a->out_f32, "sl_gemm_ex: residual_f32 needs out_f32");
     SL_CHECK_ARG(!(p.ta || p.tw) || a->w_layout == SL_W_ROWMAJOR, "sl_gemm_ex: transposed operands need row-major storage");

@@ -61,6 +61,7 @@ extern "C" int sl_hubert_num_frames(const sl_hubert_model* m, int64_t n_samples)
 struct HubertPlan {
   int64_t max_conv_elems = 0;  // largest conv activation (elements) over layers and utterances
   int64_t total_T = 0, max_T = 0, total_P = 0;
+  int64_t conv_elems[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<int64_t> T, P, tok0;
 };
 
@@ -71,7 +72,8 @@ static int hubert_plan(const sl_hubert_model* m, const int64_t* offs, int n_utt,
     for (int i = 0; i < m->n_conv; ++i) {
       SL_CHECK_ARG(L >= m->conv_kernel[i], "sl_hubert_forward: utterance %d too short (%lld samples)", u, (long long)(offs[u + 1] - offs[u]));
       L = (L - m->conv_kernel[i]) / m->conv_stride[i] + 1;
-      if (L * m->conv_dim[i] > pl.max_conv_elems) pl.max_conv_elems = L * m->conv_dim[i];
+      pl.conv_elems[i] += L * m->conv_dim[i];   // conv activations of the whole batch are packed per layer
+      if (pl.conv_elems[i] > pl.max_conv_elems) pl.max_conv_elems = pl.conv_elems[i];
     }
     pl.T[u] = L;
     SL_CHECK_ARG(L >= m->pool_kernel, "sl_hubert_forward: utterance %d gives %lld frames < pool kernel %d", u, (long long)L, m->pool_kernel);
@@ -88,6 +90,7 @@ static int hubert_plan(const sl_hubert_model* m, const int64_t* offs, int n_utt,
 struct HubertWs {
   void *convA, *convB, *feat, *x, *ln, *qkv, *att, *mid, *xg, *pooled;
   int32_t *cu, *cuk, *klen;
+  int64_t* desc;
 };
 
 static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n_utt, void* base, size_t cap, HubertWs& w) {
@@ -102,7 +105,8 @@ static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n
   w.qkv = c.take(pl.total_T * 3 * H * sz);
   w.att = c.take(pl.total_T * H * sz);
   w.mid = c.take(pl.total_T * (int64_t)m->ffn * sz);
-  w.xg = c.take((pl.max_T + m->pos_k) * H * sz);
+  w.xg = c.take((pl.total_T + (int64_t)n_utt * m->pos_k) * H * sz);
+  w.desc = (int64_t*)c.take((size_t)((m->n_conv - 1) * n_utt + n_utt * m->pos_groups) * 4 * sizeof(int64_t));
   w.pooled = c.take(pl.total_P * H * sz);
   w.cu = (int32_t*)c.take((n_utt + 1) * sizeof(int32_t));
   w.cuk = (int32_t*)c.take(n_utt * sizeof(int32_t));
@@ -135,52 +139,32 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
   SL_CHECK_ARG(need <= workspace_bytes, "sl_hubert_forward: workspace %zu B < required %zu B", workspace_bytes, need);
   const int Cl = m->conv_dim[m->n_conv - 1];
 
-  // ---- per utterance: conv feature extractor -> feat rows [tok0, tok0+T)
+  // ---- descriptors of the ragged batch: row offsets of every utterance in each packed conv activation,
+  //      grouped-GEMM records {M, a_off, c_off, r_off} for conv layers 1.. and for the positional conv
+  const int nc = m->n_conv, G = m->pos_groups, Hg = H / G, kpos = m->pos_k;
+  std::vector<std::vector<int64_t>> row0(nc, std::vector<int64_t>(n_utt + 1, 0)), Lc(nc, std::vector<int64_t>(n_utt, 0));
   for (int u = 0; u < n_utt; ++u) {
-    const int64_t n = sample_offsets_host[u + 1] - sample_offsets_host[u];
-    int64_t L = (n - m->conv_kernel[0]) / m->conv_stride[0] + 1;
-    void* cur = w.convA;
-    void* nxt = w.convB;
-    SL_TRY(sl_hubert_conv0(waves + sample_offsets_host[u], n, m->conv0_w, m->conv0_b, m->conv0_g, m->conv0_beta, cur, m->conv_dim[0],
-                           m->conv_kernel[0], m->conv_stride[0], 1e-5f, dt, stream));
-    for (int i = 1; i < m->n_conv; ++i) {
-      const int Cin = m->conv_dim[i - 1], Cout = m->conv_dim[i], k = m->conv_kernel[i], s = m->conv_stride[i];
-      const int64_t Lo = (L - k) / s + 1;
-      void* dst = (i == m->n_conv - 1) ? (void*)(bptr(w.feat) + pl.tok0[u] * Cl * sz) : nxt;
-      // implicit GEMM: output row t reads the k*Cin contiguous elements starting at input row t*s
-      SL_TRY(gemm(dt, cur, (int64_t)s * Cin, m->conv_w[i], (int64_t)k * Cin, dst, Cout, m->conv_b[i], nullptr, 0, (int)Lo, Cout, k * Cin,
-                  SL_ACT_NONE, 0, st));
-      SL_TRY(sl_layernorm(dst, dst, m->conv_g[i], m->conv_beta[i], Lo, Cout, 1e-5f, 1, dt, stream));
-      cur = dst;
-      nxt = (cur == w.convA) ? w.convB : w.convA;
-      L = Lo;
-    }
+    int64_t L = sample_offsets_host[u + 1] - sample_offsets_host[u];
+    for (int i = 0; i < nc; ++i) { L = (L - m->conv_kernel[i]) / m->conv_stride[i] + 1; Lc[i][u] = L; }
   }
-  // ---- feature projection on the packed tokens
-  const int NT = (int)pl.total_T;
-  SL_TRY(sl_layernorm(w.feat, w.feat, m->fp_ln_g, m->fp_ln_b, NT, Cl, m->ln_eps, 0, dt, stream));
-  SL_TRY(gemm(dt, w.feat, Cl, m->fp_w, Cl, w.x, H, m->fp_b, nullptr, 0, NT, H, Cl, SL_ACT_NONE, 0, st));
-  // ---- positional conv embedding, per utterance: x += gelu(grouped_conv(x))  (written to w.ln, then swapped)
-  {
-    const int G = m->pos_groups, Hg = H / G, k = m->pos_k;
+  for (int i = 0; i < nc; ++i)
+    for (int u = 0; u < n_utt; ++u) row0[i][u + 1] = row0[i][u] + Lc[i][u];
+  std::vector<int64_t> desc((size_t)((nc - 1) * n_utt + n_utt * G) * 4);
+  std::vector<int64_t> max_rows(nc, 0);
+  for (int i = 1; i < nc; ++i)
     for (int u = 0; u < n_utt; ++u) {
-      const int64_t T = pl.T[u];
-      unsigned char* xu = bptr(w.x) + pl.tok0[u] * H * sz;
-      unsigned char* yu = bptr(w.ln) + pl.tok0[u] * H * sz;
-      SL_TRY(sl_posconv_stage(xu, w.xg, T, H, G, k, dt, stream));
-      sl_gemm_args a;
-      memset(&a, 0, sizeof(a));
-      a.A = w.xg; a.lda = Hg; a.strideA = (T + k) * Hg;
-      a.W = m->pos_w; a.ldw = (int64_t)k * Hg; a.strideW = (int64_t)Hg * k * Hg;
-      a.C = yu; a.ldc = H; a.strideC = Hg;
-      a.bias = m->pos_b; a.strideBias = Hg;
-      a.residual = xu; a.ldr = H; a.strideR = Hg;
-      a.M = (int)T; a.N = Hg; a.K = k * Hg; a.batch = G; a.dtype = dt; a.act = SL_ACT_GELU;
-      SL_TRY(sl_gemm(&a, stream));
+      int64_t* d = &desc[(size_t)((i - 1) * n_utt + u) * 4];
+      d[0] = Lc[i][u]; d[1] = row0[i - 1][u] * m->conv_dim[i - 1]; d[2] = row0[i][u] * m->conv_dim[i]; d[3] = 0;
+      if (Lc[i][u] > max_rows[i]) max_rows[i] = Lc[i][u];
     }
-    void* t = w.x; w.x = w.ln; w.ln = t;
-  }
-  // ---- transformer layers on packed tokens, varlen attention
+  std::vector<int64_t> xg_off(n_utt + 1, 0);
+  for (int u = 0; u < n_utt; ++u) xg_off[u + 1] = xg_off[u] + (pl.T[u] + kpos) * H;
+  const size_t pos_desc0 = (size_t)(nc - 1) * n_utt * 4;
+  for (int u = 0; u < n_utt; ++u)
+    for (int g = 0; g < G; ++g) {
+      int64_t* d = &desc[pos_desc0 + (size_t)(u * G + g) * 4];
+      d[0] = pl.T[u]; d[1] = xg_off[u] + (int64_t)g * (pl.T[u] + kpos) * Hg; d[2] = pl.tok0[u] * H + (int64_t)g * Hg; d[3] = d[2];
+    }
   {
     std::vector<int32_t> cu(n_utt + 1), kl(n_utt);
     for (int u = 0; u <= n_utt; ++u) cu[u] = (int32_t)pl.tok0[u];
@@ -188,8 +172,56 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
     SL_HIP(hipMemcpyAsync(w.cu, cu.data(), (n_utt + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipMemcpyAsync(w.cuk, cu.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipMemcpyAsync(w.klen, kl.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipMemcpyAsync(w.desc, desc.data(), desc.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipStreamSynchronize(st));  // host vectors go out of scope; pageable copies are staged but be explicit
   }
+  // ---- conv feature extractor: layer 0 per utterance (fused conv+LN+GELU), layers 1.. as ONE grouped implicit GEMM
+  //      + ONE LayerNorm+GELU over the packed rows of the whole batch
+  void* cur = w.convA;
+  for (int u = 0; u < n_utt; ++u) {
+    const int64_t n = sample_offsets_host[u + 1] - sample_offsets_host[u];
+    SL_TRY(sl_hubert_conv0(waves + sample_offsets_host[u], n, m->conv0_w, m->conv0_b, m->conv0_g, m->conv0_beta,
+                           bptr(cur) + row0[0][u] * m->conv_dim[0] * sz, m->conv_dim[0], m->conv_kernel[0], m->conv_stride[0], 1e-5f, dt, stream));
+  }
+  for (int i = 1; i < nc; ++i) {
+    const int Cin = m->conv_dim[i - 1], Cout = m->conv_dim[i], k = m->conv_kernel[i], s = m->conv_stride[i];
+    void* dst = (i == nc - 1) ? w.feat : (cur == w.convA ? w.convB : w.convA);
+    sl_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = cur; a.lda = (int64_t)s * Cin;   // implicit GEMM: output row t reads the k*Cin contiguous elements from input row t*s
+    a.W = m->conv_w[i]; a.ldw = (int64_t)k * Cin;
+    a.C = dst; a.ldc = Cout; a.bias = m->conv_b[i];
+    a.M = (int)max_rows[i]; a.N = Cout; a.K = k * Cin; a.batch = n_utt; a.dtype = dt; a.act = SL_ACT_NONE;
+    sl_gemm_ex_args ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.groups = w.desc + (size_t)(i - 1) * n_utt * 4; ex.w_mod = 1;
+    SL_TRY(sl_gemm_impl(&a, nullptr, &ex, st));
+    SL_TRY(sl_layernorm(dst, dst, m->conv_g[i], m->conv_beta[i], row0[i][n_utt], Cout, 1e-5f, 1, dt, stream));
+    cur = dst;
+  }
+  // ---- feature projection on the packed tokens
+  const int NT = (int)pl.total_T;
+  SL_TRY(sl_layernorm(w.feat, w.feat, m->fp_ln_g, m->fp_ln_b, NT, Cl, m->ln_eps, 0, dt, stream));
+  SL_TRY(gemm(dt, w.feat, Cl, m->fp_w, Cl, w.x, H, m->fp_b, nullptr, 0, NT, H, Cl, SL_ACT_NONE, 0, st));
+  // ---- positional conv embedding: x += gelu(grouped_conv(x)); every (utterance, group) is one record of ONE grouped GEMM
+  {
+    for (int u = 0; u < n_utt; ++u)
+      SL_TRY(sl_posconv_stage(bptr(w.x) + pl.tok0[u] * H * sz, bptr(w.xg) + xg_off[u] * sz, pl.T[u], H, G, kpos, dt, stream));
+    sl_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = w.xg; a.lda = Hg;
+    a.W = m->pos_w; a.ldw = (int64_t)kpos * Hg; a.strideW = (int64_t)Hg * kpos * Hg;
+    a.C = w.ln; a.ldc = H;
+    a.bias = m->pos_b; a.strideBias = Hg;
+    a.residual = w.x; a.ldr = H;
+    a.M = (int)pl.max_T; a.N = Hg; a.K = kpos * Hg; a.batch = n_utt * G; a.dtype = dt; a.act = SL_ACT_GELU;
+    sl_gemm_ex_args ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.groups = w.desc + pos_desc0; ex.w_mod = G;
+    SL_TRY(sl_gemm_impl(&a, nullptr, &ex, st));
+    void* t = w.x; w.x = w.ln; w.ln = t;
+  }
+  // ---- transformer layers on packed tokens, varlen attention
   for (int l = 0; l < m->n_layers; ++l) {
     const sl_hubert_layer& L = m->layers[l];
     SL_TRY(sl_layernorm(w.x, w.ln, L.ln1_g, L.ln1_b, NT, H, m->ln_eps, 0, dt, stream));
