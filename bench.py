@@ -106,27 +106,25 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g)
     resp_ids = torch.randint(1, larch.vocab_size, (64,), generator=g)
     wave = ri.synthetic_waveform(160000, seed=4321 + rank).to(dev)
-    n_micro = tr.local_accum * args.kd_optimizer_steps
-    tr.micro = 1 - tr.local_accum if tr.local_accum > 1 else 0   # warm-up micro-step that does not reach the optimizer
-    if tr.local_accum == 1:
-        saved = tr.optimizer_step
-        tr.optimizer_step = lambda: None
-        tr.micro_step(wave, text_ids, resp_ids)
-        tr.optimizer_step = saved
-        for gb in tr.grads.values():
-            gb.zero_()
-    else:
-        tr.micro_step(wave, text_ids, resp_ids)
-        for gb in tr.grads.values():
-            gb.zero_()
+    B = tr.local_accum                       # one accumulation window = one packed micro-batch per rank
+    n_micro = B * args.kd_optimizer_steps
+    waves, texts, resps = [wave] * B, [text_ids] * B, [resp_ids] * B
+    saved = tr.optimizer_step
+    tr.optimizer_step = lambda: None         # warm-up window: allocator + kernels, no update
+    tr.micro_batch(waves, texts, resps)
+    tr.optimizer_step = saved
+    for gb in tr.grads.values():
+        gb.zero_()
+    if tr.reducer is not None:
+        tr.reducer.finish()
     tr.micro = 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     losses = None
-    for _ in range(n_micro):
-        losses = tr.micro_step(wave, text_ids, resp_ids)
+    for _ in range(args.kd_optimizer_steps):
+        losses = tr.micro_batch(waves, texts, resps)[-1]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -140,7 +138,7 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
             "optimizer_steps": args.kd_optimizer_steps, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
             "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
             "losses": {k: round(v, 4) for k, v in losses.items()}, "dtype": "bf16 compute, fp32 master/grads",
-            "note": "dropout/layerdrop/spec-augment off; python-driven op tape (launch overhead included)"}
+            "note": "one packed micro-batch per accumulation window per rank; dropout/layerdrop/spec-augment off; python-driven op tape"}
 
 
 def main():

@@ -208,7 +208,7 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
             residual=None, ldr: int = 0, act: int = L.ACT_NONE, out_f32: bool = False, trans_a: bool = False, trans_w: bool = False,
             residual_f32: bool = False, aux_out=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0,
             strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, r_off: int = 0,
-            dtype: Optional[torch.dtype] = None):
+            dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1):
     """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors."""
     dt = dtype or A.dtype
     esz = 4 if dt == torch.float32 else 2
@@ -223,6 +223,7 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     a.dtype, a.act, a.out_f32, a.w_layout = L.dtype_code(dt), act, int(out_f32), L.W_ROWMAJOR
     e = L.GemmEx()
     e.trans_a, e.trans_w, e.residual_f32, e.aux_out = int(trans_a), int(trans_w), int(residual_f32), L.ptr(aux_out)
+    e.groups, e.w_mod = L.ptr(groups), w_mod
     L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(e), L.stream_ptr()), "sl_gemm_ex")
     return out
 

@@ -39,43 +39,52 @@ def _rup(n: int, m: int) -> int:
 # ------------------------------------------------------------------------------------------------
 # attention backward from explicit probabilities (recomputed), all products on sl_gemm_ex
 # ------------------------------------------------------------------------------------------------
-def attention_backward(qkv: torch.Tensor, d_att: torch.Tensor, S: int, nh: int, nkv: int, D: int, causal: bool, scale: float,
-                       qkv_w: int) -> torch.Tensor:
-    """qkv: (>= roundup(S), qkv_w) rows [q heads | k heads | v heads], rows >= S zero;  d_att: (S, nh*D).
-    Returns d_qkv (S_pad, qkv_w) with the same layout."""
+def attention_backward(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: torch.Tensor, nh: int, nkv: int, D: int, causal: bool, scale: float) -> None:
+    """One sequence.  qkv: (S, qkv_w) row view [q heads | k heads | v heads]; d_att: (S, nh*D) row view;
+    d_qkv: (S, qkv_w) row view that receives [dQ | dK | dV]."""
     dt = qkv.dtype
+    S, qkv_w = qkv.shape[0], qkv.stride(0)
     rep = nh // nkv
     ld = _rup(S, _vec(dt))
     dev = qkv.device
-    d_qkv = torch.zeros((qkv.shape[0], qkv_w), device=dev, dtype=dt)
     Sb = torch.empty((nkv, S, ld), device=dev, dtype=torch.float32)
     dPb = torch.empty((nkv, S, ld), device=dev, dtype=torch.float32)
     koff, voff = nh * D, (nh + nkv) * D
+    # K rows zero-padded to ld so that dQ = dS . K can reduce over a whole number of 16-byte chunks
+    kpad = torch.zeros((ld, nkv * D), device=dev, dtype=dt)
+    kpad[:S] = qkv[:, koff:voff]
+    ldo = d_att.stride(0)
     for r in range(rep):
         # scores of q heads kvh*rep + r against kv head kvh
         ops.gemm_ex(qkv, qkv, M=S, N=S, K=D, lda=qkv_w, ldw=qkv_w, out=Sb, ldc=ld, out_f32=True, batch=nkv, strideA=rep * D, strideW=D,
                     strideC=S * ld, a_off=r * D, w_off=koff, dtype=dt)
         P = ops.softmax_rows(Sb, nkv, S, S, ld, scale, causal, dt)
-        ops.gemm_ex(d_att, qkv, M=S, N=S, K=D, lda=nh * D, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nkv, strideA=rep * D, strideW=D,
+        ops.gemm_ex(d_att, qkv, M=S, N=S, K=D, lda=ldo, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nkv, strideA=rep * D, strideW=D,
                     strideC=S * ld, a_off=r * D, w_off=voff, dtype=dt)
         dS = ops.softmax_bwd(P, dPb, S, scale)
-        # dQ_h = dS . K   (reduction over keys; K = ld uses the zero-padded rows of qkv / zero columns of dS)
-        ops.gemm_ex(dS, qkv, M=S, N=D, K=ld, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_w=True, batch=nkv, strideA=S * ld, strideW=D,
-                    strideC=rep * D, w_off=koff, c_off=r * D, dtype=dt)
+        # dQ_h = dS . K
+        ops.gemm_ex(dS, kpad, M=S, N=D, K=ld, lda=ld, ldw=nkv * D, out=d_qkv, ldc=qkv_w, trans_w=True, batch=nkv, strideA=S * ld, strideW=D,
+                    strideC=rep * D, c_off=r * D, dtype=dt)
         acc = r > 0  # GQA: the rep query heads of a group add into the same dK / dV
         # dK = dS^T . Q_h
         ops.gemm_ex(dS, qkv, M=S, N=D, K=S, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nkv, strideA=S * ld,
                     strideW=rep * D, strideC=D, w_off=r * D, c_off=koff, residual=(d_qkv if acc else None), ldr=qkv_w, strideR=D,
                     r_off=koff, dtype=dt)
         # dV = P^T . dO_h
-        ops.gemm_ex(P, d_att, M=S, N=D, K=S, lda=ld, ldw=nh * D, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nkv, strideA=S * ld,
+        ops.gemm_ex(P, d_att, M=S, N=D, K=S, lda=ld, ldw=ldo, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nkv, strideA=S * ld,
                     strideW=rep * D, strideC=D, w_off=r * D, c_off=voff, residual=(d_qkv if acc else None), ldr=qkv_w, strideR=D,
                     r_off=voff, dtype=dt)
-    return d_qkv
+
+
+def _offsets(lens: Sequence[int]) -> List[int]:
+    o = [0]
+    for n in lens:
+        o.append(o[-1] + int(n))
+    return o
 
 
 # ------------------------------------------------------------------------------------------------
-# frozen LLM: forward with a tape, data-gradient backward
+# frozen LLM: forward with a tape, data-gradient backward — over a PACKED batch of sequences
 # ------------------------------------------------------------------------------------------------
 class LlamaTape:
     def __init__(self, llm: AudioLlamaForCausalLM):
@@ -83,54 +92,51 @@ class LlamaTape:
         self.w = llm._dev()
         self.a = llm.arch
 
-    def forward(self, x: torch.Tensor):
-        """x: (S, H) prompt+response embeddings of ONE sequence.  Returns (hidden_states list of L+1 tensors
-        [hidden_states[l] = input of layer l, last = post-norm], tape)."""
+    def forward(self, x: torch.Tensor, seqlens: Sequence[int], save: bool = True):
+        """x: (sum S_i, H) packed embeddings.  Returns (hidden_states: L+1 packed tensors [hidden_states[l] = input of
+        layer l, last = post-norm], tape).  With save=False nothing is kept for backward (teacher pass)."""
         a, w = self.a, self.w
-        S, H = x.shape
         dt = x.dtype
         nh, nkv, D = a.num_attention_heads, a.num_key_value_heads, a.head_dim
-        qkv_w = (nh + 2 * nkv) * D
-        S_pad = _rup(S, _vec(dt))
-        pos = torch.arange(S, dtype=torch.int32, device=x.device)
+        pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in seqlens]).to(x.device)
         tape, hidden = [], []
         scale = D ** -0.5
         for li in range(a.num_hidden_layers):
             lw = w.layer_t[li]
             hidden.append(x)
             h1 = ops.rmsnorm(x, lw["norm1"], a.rms_norm_eps)
-            qkv = torch.zeros((S_pad, qkv_w), device=x.device, dtype=dt)
-            ops.gemm(h1, lw["wqkv"], out=qkv[:S])
-            ops.rope_inplace(qkv[:S], pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D)
-            att = ops.attn_packed_qkv(qkv[:S], [S], nh, nkv, D, True, scale)
+            qkv = ops.gemm(h1, lw["wqkv"])
+            ops.rope_inplace(qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D)
+            att = ops.attn_packed_qkv(qkv, list(seqlens), nh, nkv, D, True, scale)
             x2 = ops.gemm(att, lw["wo"], residual=x)
             h2 = ops.rmsnorm(x2, lw["norm2"], a.rms_norm_eps)
-            gu = ops.gemm(h2, lw["wgu"])                      # interleaved gate/up pre-activations (S, 2F)
+            gu = ops.gemm(h2, lw["wgu"])                      # interleaved gate/up pre-activations (N, 2F)
             mid = ops.silu_mul(gu)
             x3 = ops.gemm(mid, lw["wdown"], residual=x2)
-            tape.append((x, qkv, x2, gu))
+            if save:
+                tape.append((x, qkv, x2, gu))
             x = x3
         xn = ops.rmsnorm(x, w.final_norm, a.rms_norm_eps)
         hidden.append(xn)
-        return hidden, dict(layers=tape, x_final=x, S=S, pos=pos)
+        return hidden, dict(layers=tape, x_final=x, seqlens=list(seqlens), pos=pos)
 
     def logits(self, xn_rows: torch.Tensor) -> torch.Tensor:
         return ops.gemm(xn_rows, self.w.lm_head, out_f32=True)
 
-    def backward(self, tape, d_logits_tail: Optional[torch.Tensor], n_tail: int, d_taps: Dict[int, torch.Tensor]) -> torch.Tensor:
-        """d_logits_tail: (n_tail, V) gradient of the last n_tail logit rows (dtype T); d_taps[l]: (S, H) gradient
-        of hidden_states[l].  Returns the gradient of the input embeddings (S, H)."""
+    def backward(self, tape, tail_rows: torch.Tensor, d_logits_tail: torch.Tensor, d_hidden: Dict[int, torch.Tensor]) -> torch.Tensor:
+        """tail_rows: int64 indices (packed) of the rows whose logits carry loss; d_logits_tail: (len(tail_rows), V)
+        gradient (dtype T); d_hidden[l]: (N, H) gradient of hidden_states[l].  Returns d(input embeddings) (N, H)."""
         a, w = self.a, self.w
-        S, pos = tape["S"], tape["pos"]
+        seqlens, pos = tape["seqlens"], tape["pos"]
+        offs = _offsets(seqlens)
         nh, nkv, D = a.num_attention_heads, a.num_key_value_heads, a.head_dim
         qkv_w = (nh + 2 * nkv) * D
         x_final = tape["x_final"]
         dx = torch.zeros_like(x_final)
-        if d_logits_tail is not None:
-            d_xn = ops.dgrad(d_logits_tail, w.lm_head)  # (n_tail, H)
-            if a.num_hidden_layers in d_taps:
-                ops.axpby(d_taps[a.num_hidden_layers][S - n_tail:], d_xn)
-            dx[S - n_tail:] = ops.rmsnorm_bwd(x_final[S - n_tail:].contiguous(), w.final_norm, d_xn, a.rms_norm_eps)
+        d_xn = ops.dgrad(d_logits_tail, w.lm_head)  # (n_tail, H)
+        if a.num_hidden_layers in d_hidden:
+            d_xn += d_hidden[a.num_hidden_layers].index_select(0, tail_rows)
+        dx.index_copy_(0, tail_rows, ops.rmsnorm_bwd(x_final.index_select(0, tail_rows), w.final_norm, d_xn, a.rms_norm_eps))
         for li in reversed(range(a.num_hidden_layers)):
             lw = w.layer_t[li]
             x, qkv, x2, gu = tape["layers"][li]
@@ -140,23 +146,27 @@ class LlamaTape:
             dx2 = ops.rmsnorm_bwd(x2, lw["norm2"], d_h2, a.rms_norm_eps)
             ops.axpby(dx, dx2)                                  # dx2 += dx (residual join)
             d_att = ops.dgrad(dx2, lw["wo"])
-            d_qkv = attention_backward(qkv, d_att, S, nh, nkv, D, True, D ** -0.5, qkv_w)
-            ops.rope_inplace(d_qkv[:S], pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D, inverse=True)
-            d_h1 = ops.dgrad(d_qkv[:S], lw["wqkv"])
+            d_qkv = torch.empty_like(qkv)
+            for s in range(len(seqlens)):
+                attention_backward(qkv[offs[s]:offs[s + 1]], d_att[offs[s]:offs[s + 1]], d_qkv[offs[s]:offs[s + 1]], nh, nkv, D, True, D ** -0.5)
+            ops.rope_inplace(d_qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D, inverse=True)
+            d_h1 = ops.dgrad(d_qkv, lw["wqkv"])
             dxin = ops.rmsnorm_bwd(x, lw["norm1"], d_h1, a.rms_norm_eps)
             ops.axpby(dx2, dxin)
-            if li in d_taps:
-                ops.axpby(d_taps[li], dxin)
+            if li in d_hidden:
+                ops.axpby(d_hidden[li], dxin)
             dx = dxin
         return dx
 
 
 # ------------------------------------------------------------------------------------------------
-# audio encoder: forward with a tape, full backward (data + parameter gradients)
+# audio encoder: forward with a tape, full backward (data + parameter gradients) — ragged batch of utterances
 # ------------------------------------------------------------------------------------------------
 class EncoderTape:
-    """HuBERT + pool + projection for ONE utterance, composed op by op from the same kernels the fused
-    C runtime (sl_hubert_forward) launches, keeping what the backward needs."""
+    """HuBERT + pool + projection for a batch of utterances of arbitrary lengths, composed op by op from the same
+    kernels the fused C runtime (sl_hubert_forward) launches, keeping what the backward needs.  Token-wise work
+    (norms, linear layers) runs on the packed frames of the whole batch; convolutions and attention respect
+    utterance boundaries (grouped GEMMs / varlen attention), so results equal per-utterance runs."""
 
     def __init__(self, enc: AudioEncoder):
         if enc.downsample_method != "pool":
@@ -175,67 +185,94 @@ class EncoderTape:
                 g[f"l{li}.{k}"] = torch.zeros(v.shape, device=v.device, dtype=torch.float32)
         return g
 
-    def forward(self, wave: torch.Tensor):
+    def forward(self, waves: Sequence[torch.Tensor]):
         W, a, enc = self.W, self.enc.arch, self.enc
         t, dt, dev = W.t, enc.dtype, enc.device
-        wave = wave.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
-        tape = dict(wave=wave)
-        x = ops.hubert_conv0(wave, t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], dt)
+        B = len(waves)
+        waves = [wv.reshape(-1).to(device=dev, dtype=torch.float32).contiguous() for wv in waves]
+        nc = len(a.conv_dim)
+        # per-layer lengths and packed row offsets
+        Ls = [[0] * B for _ in range(nc)]
+        for u, wv in enumerate(waves):
+            n = wv.numel()
+            for i in range(nc):
+                n = (n - a.conv_kernel[i]) // a.conv_stride[i] + 1
+                Ls[i][u] = n
+        offs = [_offsets(Ls[i]) for i in range(nc)]
+        tape = dict(waves=waves, Ls=Ls, offs=offs)
+        x = torch.empty((offs[0][B], a.conv_dim[0]), device=dev, dtype=dt)
+        for u, wv in enumerate(waves):
+            x[offs[0][u]:offs[0][u + 1]] = ops.hubert_conv0(wv, t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], dt)
         acts, pres = [x], [None]
-        for i in range(1, len(a.conv_dim)):
+        for i in range(1, nc):
             Cin, Cout, k, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
-            Lo = (x.shape[0] - k) // s + 1
-            c = ops.gemm(x, t[f"conv{i}_w"], bias=t[f"conv{i}_b"], M=Lo, K=k * Cin, lda=s * Cin)
+            grp = torch.tensor([[Ls[i][u], offs[i - 1][u] * Cin, offs[i][u] * Cout, 0] for u in range(B)], dtype=torch.int64, device=dev)
+            c = torch.empty((offs[i][B], Cout), device=dev, dtype=dt)
+            ops.gemm_ex(x, t[f"conv{i}_w"], M=max(Ls[i]), N=Cout, K=k * Cin, lda=s * Cin, ldw=k * Cin, out=c, bias=t[f"conv{i}_b"], batch=B,
+                        groups=grp, dtype=dt)
             x = ops.layernorm(c, t[f"conv{i}_g"], t[f"conv{i}_beta"], 1e-5, gelu=True)
             acts.append(x); pres.append(c)
         tape.update(acts=acts, pres=pres)
-        T, H = x.shape[0], a.hidden_size
-        T_pad = _rup(T, _vec(dt))
+        T = Ls[nc - 1]
+        toff = offs[nc - 1]
+        NT, H = toff[B], a.hidden_size
         fp_ln = ops.layernorm(x, t["fp_ln_g"], t["fp_ln_b"], a.layer_norm_eps)
         x0 = ops.gemm(fp_ln, t["fp_w"], bias=t["fp_b"])
         G, k = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
         Hg = H // G
-        xg = ops.posconv_stage(x0, G, k)
+        xg_off = _offsets([(T[u] + k) * H for u in range(B)])
+        xg = torch.empty(xg_off[B], device=dev, dtype=dt)
+        for u in range(B):
+            xg[xg_off[u]:xg_off[u + 1]] = ops.posconv_stage(x0[toff[u]:toff[u + 1]], G, k).reshape(-1)
+        pos_grp = torch.tensor([[T[u], xg_off[u] + g * (T[u] + k) * Hg, toff[u] * H + g * Hg, toff[u] * H + g * Hg] for u in range(B) for g in range(G)],
+                               dtype=torch.int64, device=dev)
         pre_pos = torch.empty_like(x0)
         x1 = torch.empty_like(x0)
-        ops.gemm_ex(xg, t["pos_w"], M=T, N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=x1, ldc=H, bias=t["pos_b"], residual=x0, ldr=H, act=L.ACT_GELU,
-                    aux_out=pre_pos, batch=G, strideA=(T + k) * Hg, strideW=Hg * k * Hg, strideC=Hg, strideBias=Hg, strideR=Hg, dtype=dt)
-        tape.update(fp_ln=fp_ln, x0=x0, xg=xg, pre_pos=pre_pos, T=T)
+        ops.gemm_ex(xg, t["pos_w"], M=max(T), N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=x1, ldc=H, bias=t["pos_b"], residual=x0, ldr=H, act=L.ACT_GELU,
+                    aux_out=pre_pos, batch=B * G, strideW=Hg * k * Hg, strideBias=Hg, groups=pos_grp, w_mod=G, dtype=dt)
+        tape.update(fp_ln=fp_ln, xg=xg, xg_off=xg_off, pre_pos=pre_pos, T=T, toff=toff)
         layers = []
         x = x1
         nh = a.num_attention_heads
         for li in range(a.num_hidden_layers):
             lt = W.layer_t[li]
             ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], a.layer_norm_eps)
-            qkv = torch.zeros((T_pad, 3 * H), device=dev, dtype=dt)
-            ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"], out=qkv[:T])
-            att = ops.attn_packed_qkv(qkv[:T], [T], nh, nh, 64, False, 0.125)
+            qkv = ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"])
+            att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125)
             x_mid = ops.gemm(att, lt["wo"], bias=lt["bo"], residual=x)
             ln2 = ops.layernorm(x_mid, lt["ln2_g"], lt["ln2_b"], a.layer_norm_eps)
-            pre1 = torch.empty((T, a.intermediate_size), device=dev, dtype=dt)
+            pre1 = torch.empty((NT, a.intermediate_size), device=dev, dtype=dt)
             mid = torch.empty_like(pre1)
-            ops.gemm_ex(ln2, lt["w1"], M=T, N=a.intermediate_size, K=H, lda=H, ldw=H, out=mid, bias=lt["b1"], act=L.ACT_GELU, aux_out=pre1, dtype=dt)
+            ops.gemm_ex(ln2, lt["w1"], M=NT, N=a.intermediate_size, K=H, lda=H, ldw=H, out=mid, bias=lt["b1"], act=L.ACT_GELU, aux_out=pre1, dtype=dt)
             x_out = ops.gemm(mid, lt["w2"], bias=lt["b2"], residual=x_mid)
             layers.append(dict(x=x, ln1=ln1, qkv=qkv, att=att, x_mid=x_mid, ln2=ln2, pre1=pre1, mid=mid))
             x = x_out
         lnf = ops.layernorm(x, t["final_ln_g"], t["final_ln_b"], a.layer_norm_eps)
-        pooled = ops.avgpool_rows(lnf, enc.pool_kernel, enc.pool_stride)
+        P = [(T[u] - enc.pool_kernel) // enc.pool_stride + 1 for u in range(B)]
+        poff = _offsets(P)
+        pooled = torch.empty((poff[B], H), device=dev, dtype=dt)
+        for u in range(B):
+            pooled[poff[u]:poff[u + 1]] = ops.avgpool_rows(lnf[toff[u]:toff[u + 1]], enc.pool_kernel, enc.pool_stride)
         out = ops.gemm(pooled, t["proj_w"], bias=t["proj_b"])
-        tape.update(layers=layers, x_last=x, pooled=pooled)
+        tape.update(layers=layers, x_last=x, pooled=pooled, P=P, poff=poff)
         return out, tape
 
     def backward(self, tape, d_out: torch.Tensor, g: Dict[str, torch.Tensor], on_bucket=None) -> None:
         """Accumulates fp32 parameter gradients into `g` (kernel layouts).  `on_bucket(names)` is called as soon as
-        a group of gradient buffers is final for this micro-step (used to launch their all-reduce early)."""
+        a group of gradient buffers is final for this optimizer step (used to launch their all-reduce early)."""
         W, a, enc = self.W, self.enc.arch, self.enc
         t, dt = W.t, enc.dtype
-        H, T = a.hidden_size, tape["T"]
+        H, T, toff, poff = a.hidden_size, tape["T"], tape["toff"], tape["poff"]
+        B = len(T)
+        NT = toff[B]
         nh = a.num_attention_heads
         done = on_bucket or (lambda names: None)
         # projection + pool + final LN
         ops.wgrad_acc(d_out, tape["pooled"], g["proj_w"]); ops.colsum_acc(d_out, g["proj_b"])
         d_pooled = ops.dgrad(d_out, t["proj_w"])
-        d_lnf = ops.avgpool_bwd(d_pooled, T, enc.pool_kernel, enc.pool_stride)
+        d_lnf = torch.empty((NT, H), device=d_out.device, dtype=dt)
+        for u in range(B):
+            d_lnf[toff[u]:toff[u + 1]] = ops.avgpool_bwd(d_pooled[poff[u]:poff[u + 1]], T[u], enc.pool_kernel, enc.pool_stride)
         dx = ops.layernorm_bwd(tape["x_last"], t["final_ln_g"], t["final_ln_b"], d_lnf, a.layer_norm_eps, g["final_ln_g"], g["final_ln_b"])
         done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
         for li in reversed(range(a.num_hidden_layers)):
@@ -250,7 +287,9 @@ class EncoderTape:
             ops.axpby(dx, dx_mid)
             ops.wgrad_acc(dx_mid, c["att"], g[p + "wo"]); ops.colsum_acc(dx_mid, g[p + "bo"])
             d_att = ops.dgrad(dx_mid, lt["wo"])
-            d_qkv = attention_backward(c["qkv"], d_att, T, nh, nh, 64, False, 0.125, 3 * H)[:T]
+            d_qkv = torch.empty_like(c["qkv"])
+            for u in range(B):
+                attention_backward(c["qkv"][toff[u]:toff[u + 1]], d_att[toff[u]:toff[u + 1]], d_qkv[toff[u]:toff[u + 1]], nh, nh, 64, False, 0.125)
             ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
             d_ln1 = ops.dgrad(d_qkv, lt["wqkv"])
             dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, a.layer_norm_eps, g[p + "ln1_g"], g[p + "ln1_b"])
@@ -262,34 +301,41 @@ class EncoderTape:
         Hg = H // G
         d_pre = ops.gelu_bwd(dx, tape["pre_pos"])
         ops.colsum_acc(d_pre, g["pos_b"])
-        # wgrad: dW[g][n][j*Hg + c] += sum_t d_pre[t][g*Hg + n] * xg[g][t + j][c]   (overlapping windows as the W operand)
-        ops.gemm_ex(d_pre, tape["xg"], M=Hg, N=k * Hg, K=T, lda=H, ldw=Hg, out=g["pos_w"], ldc=k * Hg, residual=g["pos_w"], ldr=k * Hg,
-                    out_f32=True, residual_f32=True, trans_a=True, trans_w=True, batch=G, strideA=Hg, strideW=(T + k) * Hg, strideC=Hg * k * Hg,
-                    strideR=Hg * k * Hg, dtype=dt)
-        # dgrad: correlation with the flipped, transposed weight over the staged d_pre (windows start one row later)
-        dpg = ops.posconv_stage(d_pre, G, k)
+        xg, xg_off = tape["xg"], tape["xg_off"]
         wd = t["pos_w"].view(G, Hg, k, Hg).flip(2).permute(0, 3, 2, 1).contiguous().view(G, Hg, k * Hg)  # [g][c][jj][n]
         dx0 = torch.empty_like(dx)
-        ops.gemm_ex(dpg, wd, M=T, N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=dx0, ldc=H, residual=dx, ldr=H, batch=G, strideA=(T + k) * Hg,
-                    strideW=Hg * k * Hg, strideC=Hg, strideR=Hg, a_off=Hg, dtype=dt)
+        for u in range(B):
+            Tu, r0 = T[u], toff[u]
+            # wgrad: dW[g][n][j*Hg + c] += sum_t d_pre[t][g*Hg + n] * xg[g][t + j][c]   (overlapping windows as the W operand)
+            ops.gemm_ex(d_pre, xg, M=Hg, N=k * Hg, K=Tu, lda=H, ldw=Hg, out=g["pos_w"], ldc=k * Hg, residual=g["pos_w"], ldr=k * Hg,
+                        out_f32=True, residual_f32=True, trans_a=True, trans_w=True, batch=G, strideA=Hg, strideW=(Tu + k) * Hg, strideC=Hg * k * Hg,
+                        strideR=Hg * k * Hg, a_off=r0 * H, w_off=xg_off[u], dtype=dt)
+            # dgrad: correlation with the flipped, transposed weight over the staged d_pre (windows start one row later)
+            dpg = ops.posconv_stage(d_pre[r0:r0 + Tu], G, k)
+            ops.gemm_ex(dpg, wd, M=Tu, N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=dx0, ldc=H, residual=dx, ldr=H, batch=G, strideA=(Tu + k) * Hg,
+                        strideW=Hg * k * Hg, strideC=Hg, strideR=Hg, a_off=Hg, c_off=r0 * H, r_off=r0 * H, dtype=dt)
         # feature projection
         ops.wgrad_acc(dx0, tape["fp_ln"], g["fp_w"]); ops.colsum_acc(dx0, g["fp_b"])
         d_fpln = ops.dgrad(dx0, t["fp_w"])
-        acts, pres = tape["acts"], tape["pres"]
+        acts, pres, offs, Ls = tape["acts"], tape["pres"], tape["offs"], tape["Ls"]
         d_act = ops.layernorm_bwd(acts[-1], t["fp_ln_g"], t["fp_ln_b"], d_fpln, a.layer_norm_eps, g["fp_ln_g"], g["fp_ln_b"])
         done(["pos_w", "pos_b", "fp_w", "fp_b", "fp_ln_g", "fp_ln_b"])
         # conv stack
         for i in reversed(range(1, len(a.conv_dim))):
             Cin, Cout, kk, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
-            Lo, Lin = pres[i].shape[0], acts[i - 1].shape[0]
             d_c = ops.layernorm_bwd(pres[i], t[f"conv{i}_g"], t[f"conv{i}_beta"], d_act, 1e-5, g[f"conv{i}_g"], g[f"conv{i}_beta"], gelu=True)
             ops.colsum_acc(d_c, g[f"conv{i}_b"])
-            ops.wgrad_acc(d_c, acts[i - 1], g[f"conv{i}_w"], ldx=s * Cin, Kin=kk * Cin, M=Lo)
             dcol = ops.dgrad(d_c, t[f"conv{i}_w"])
-            d_act = ops.col2im(dcol, Lin, Cin, kk, s)
+            d_prev = torch.empty((offs[i - 1][B], Cin), device=d_c.device, dtype=dt)
+            for u in range(B):
+                o0, o1, i0, i1 = offs[i][u], offs[i][u + 1], offs[i - 1][u], offs[i - 1][u + 1]
+                ops.wgrad_acc(d_c[o0:o1], acts[i - 1][i0:i1], g[f"conv{i}_w"], ldx=s * Cin, Kin=kk * Cin, M=o1 - o0)
+                d_prev[i0:i1] = ops.col2im(dcol[o0:o1], i1 - i0, Cin, kk, s)
+            d_act = d_prev
             done([f"conv{i}_w", f"conv{i}_b", f"conv{i}_g", f"conv{i}_beta"])
-        ops.hubert_conv0_bwd(tape["wave"], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], d_act, g["conv0_w"], g["conv0_b"],
-                             g["conv0_g"], g["conv0_beta"], k=a.conv_kernel[0], stride=a.conv_stride[0])
+        for u in range(B):
+            ops.hubert_conv0_bwd(tape["waves"][u], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], d_act[offs[0][u]:offs[0][u + 1]],
+                                 g["conv0_w"], g["conv0_b"], g["conv0_g"], g["conv0_beta"], k=a.conv_kernel[0], stride=a.conv_stride[0])
         done(["conv0_w", "conv0_b", "conv0_g", "conv0_beta"])
 
 
@@ -375,56 +421,91 @@ class KDTrainer:
         from .dist import BucketedAllReduce
         self.reducer = BucketedAllReduce(self.grads, group=process_group) if self.world > 1 else None
 
-    # -- one micro-step -------------------------------------------------------------------------
+    # -- micro-steps ----------------------------------------------------------------------------
     def micro_step(self, wave: torch.Tensor, text_ids: torch.Tensor, response_ids: torch.Tensor) -> Dict[str, float]:
-        """wave: 1-D audio; text_ids / response_ids: 1-D ids with the BOS already stripped by the collate
-        (ref:trainer.py:155-156).  Returns the three losses of ref:trainer.py:325-370 (python floats)."""
+        """One utterance (the reference's loop body, ref:trainer.py:261-384)."""
+        return self.micro_batch([wave], [text_ids], [response_ids])[0]
+
+    def micro_batch(self, waves: Sequence[torch.Tensor], text_ids: Sequence[torch.Tensor], response_ids: Sequence[torch.Tensor]) -> List[Dict[str, float]]:
+        """len(waves) micro-steps of ONE accumulation window processed together as a packed, ragged batch.  The encoder
+        weights do not change inside a window, so this is the same arithmetic as the reference's sequential batch-size-1
+        micro-steps (each loss still divided by grad_accum_interval, gradients summed) — but every GEMM sees all the
+        window's tokens at once instead of ~200 rows.  ids are 1-D with the BOS already stripped (ref:trainer.py:155-156).
+        Returns per-utterance losses (ref:trainer.py:325-370)."""
         enc, llm = self.enc, self.llm
         dev, dt = enc.device, enc.dtype
         emb = llm.model.embed_tokens
-        response_ids = response_ids.to(dev)
-        n = int(response_ids.shape[0])
-        last = (self.micro + 1) % self.local_accum == 0
-        audio, etape = self.enc_tape.forward(wave)                                  # (P, H)
-        pre, suf, resp = emb(self.prefix_ids)[0], emb(self.suffix_ids)[0, 1:], emb(response_ids[None])[0, 1:]
-        n_pre, P = pre.shape[0], audio.shape[0]
-        a_seq = torch.cat([pre, audio, suf, resp], 0).contiguous()                   # ref:utils.py:36-45
-        hidden_a, ltape = self.llm_tape.forward(a_seq)
-        S = a_seq.shape[0]
-        logits_a = self.llm_tape.logits(hidden_a[-1][S - n:].contiguous())           # (n, V) fp32 — only the rows the losses read
-        losses = torch.zeros(3, device=dev, dtype=torch.float32)
-        d_logits = torch.empty((n, logits_a.shape[1]), device=dev, dtype=dt)
-        labels = response_ids[1:].to(torch.int32).contiguous()                       # logits[-n:-1] predict labels[1:]
-        inv_acc = 1.0 / self.accum                                                   # ref:trainer.py:373
-        d_logits.zero_()
-        ops.ce_loss(logits_a[: n - 1], labels, 1.0 / (n - 1), losses[0:1], None, dtype=dt)
-        ops.ce_loss(logits_a[: n - 1], labels, self.ntp_w * inv_acc / (n - 1), torch.zeros(1, device=dev), d_logits[: n - 1], accumulate=True, dtype=dt)
-        d_taps: Dict[int, torch.Tensor] = {}
+        B = len(waves)
+        if self.micro % self.local_accum + B > self.local_accum:
+            raise L.SpeechLLMError("a micro-batch must not straddle an optimizer step")
+        last = (self.micro + B) % self.local_accum == 0
+        response_ids = [r.to(dev) for r in response_ids]
+        ns = [int(r.shape[0]) for r in response_ids]
+        audio, etape = self.enc_tape.forward(waves)                                   # (sum P, H) packed
+        poff = etape["poff"]
+        pre, suf = emb(self.prefix_ids)[0], emb(self.suffix_ids)[0, 1:]
+        n_pre = pre.shape[0]
+        resp = [emb(r[None])[0, 1:] for r in response_ids]
+        a_parts, a_lens = [], []
+        for u in range(B):                                                            # ref:utils.py:36-45
+            a_parts += [pre, audio[poff[u]:poff[u + 1]], suf, resp[u]]
+            a_lens.append(n_pre + (poff[u + 1] - poff[u]) + suf.shape[0] + resp[u].shape[0])
+        a_seq = torch.cat(a_parts, 0).contiguous()
+        aoff = _offsets(a_lens)
+        hidden_a, ltape = self.llm_tape.forward(a_seq, a_lens)
+        # rows whose logits / hidden states the losses read: the last n_u rows of every sequence
+        tail = torch.cat([torch.arange(aoff[u + 1] - ns[u], aoff[u + 1]) for u in range(B)]).to(dev)
+        toffs = _offsets(ns)
+        logits_a = self.llm_tape.logits(hidden_a[-1].index_select(0, tail))           # (sum n, V) fp32
+        V = logits_a.shape[1]
+        losses = torch.zeros((B, 3), device=dev, dtype=torch.float32)
+        scratch = torch.zeros(1, device=dev, dtype=torch.float32)
+        d_logits = torch.zeros((toffs[B], V), device=dev, dtype=dt)
+        inv_acc = 1.0 / self.accum                                                    # ref:trainer.py:373
+        for u in range(B):
+            n, r0 = ns[u], toffs[u]
+            labels = response_ids[u][1:].to(torch.int32).contiguous()                 # logits[-n:-1] predict labels[1:]
+            ops.ce_loss(logits_a[r0:r0 + n - 1], labels, 1.0 / (n - 1), losses[u, 0:1], None, dtype=dt)
+            ops.ce_loss(logits_a[r0:r0 + n - 1], labels, self.ntp_w * inv_acc / (n - 1), scratch, d_logits[r0:r0 + n - 1], accumulate=True, dtype=dt)
+        d_hidden: Dict[int, torch.Tensor] = {}
         if self.use_ld or self.use_fd:
-            t_seq = torch.cat([pre, emb(text_ids.to(dev)[None])[0], suf, resp], 0).contiguous()
-            t_out = llm(inputs_embeds=t_seq[None], output_hidden_states=True)       # teacher pass: inference kernels, no tape
+            t_parts, t_lens = [], []
+            for u in range(B):
+                te = emb(text_ids[u].to(dev)[None])[0]
+                t_parts += [pre, te, suf, resp[u]]
+                t_lens.append(n_pre + te.shape[0] + suf.shape[0] + resp[u].shape[0])
+            t_seq = torch.cat(t_parts, 0).contiguous()
+            tto = _offsets(t_lens)
+            hidden_t, _ = self.llm_tape.forward(t_seq, t_lens, save=False)            # teacher pass: same kernels, nothing kept
+            ttail = torch.cat([torch.arange(tto[u + 1] - ns[u], tto[u + 1]) for u in range(B)]).to(dev)
             if self.use_ld:
-                logits_t = t_out.logits[0, -n:].contiguous()
-                ops.soft_ce_loss(logits_a, logits_t, 1.0 / n, losses[1:2], None, dtype=dt)
-                ops.soft_ce_loss(logits_a, logits_t, self.ld_w * inv_acc / n, torch.zeros(1, device=dev), d_logits, accumulate=True, dtype=dt)
+                logits_t = self.llm_tape.logits(hidden_t[-1].index_select(0, ttail))
+                for u in range(B):
+                    n, r0 = ns[u], toffs[u]
+                    ops.soft_ce_loss(logits_a[r0:r0 + n], logits_t[r0:r0 + n], 1.0 / n, losses[u, 1:2], None, dtype=dt)
+                    ops.soft_ce_loss(logits_a[r0:r0 + n], logits_t[r0:r0 + n], self.ld_w * inv_acc / n, scratch, d_logits[r0:r0 + n], accumulate=True, dtype=dt)
             if self.use_fd:
                 for l in self.taps:
-                    ha, ht = hidden_a[l][S - n:].contiguous(), t_out.hidden_states[l][0, -n:].contiguous()
-                    d = torch.zeros((S, ha.shape[1]), device=dev, dtype=dt)
-                    ops.mse_loss(ha, ht, 1.0, losses[2:3], None)
+                    ha, ht = hidden_a[l].index_select(0, tail), hidden_t[l].index_select(0, ttail)
                     dtail = torch.empty_like(ha)
-                    ops.mse_loss(ha, ht, self.fd_w * inv_acc, torch.zeros(1, device=dev), dtail)
-                    d[S - n:] = dtail
-                    d_taps[l] = d
-        d_seq = self.llm_tape.backward(ltape, d_logits, n, d_taps)
-        d_audio = d_seq[n_pre:n_pre + P].contiguous()
+                    for u in range(B):
+                        r0, r1 = toffs[u], toffs[u + 1]
+                        ops.mse_loss(ha[r0:r1], ht[r0:r1], 1.0, losses[u, 2:3], None)
+                        ops.mse_loss(ha[r0:r1], ht[r0:r1], self.fd_w * inv_acc, scratch, dtail[r0:r1])
+                    d = torch.zeros_like(hidden_a[l])
+                    d.index_copy_(0, tail, dtail)
+                    d_hidden[l] = d
+        d_seq = self.llm_tape.backward(ltape, tail, d_logits, d_hidden)
+        d_audio = torch.cat([d_seq[aoff[u] + n_pre: aoff[u] + n_pre + (poff[u + 1] - poff[u])] for u in range(B)], 0).contiguous()
         self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self.reducer.ready if (last and self.reducer is not None) else None)
-        self.micro += 1
+        self.micro += B
         self.last_d_audio = d_audio
-        ntp, ld, fd = [float(v) for v in losses.tolist()]
+        out = []
+        for ntp, ld, fd in losses.tolist():
+            out.append(dict(ntp_loss=ntp, ld_loss=ld, fd_loss=fd, total=self.ntp_w * ntp + self.ld_w * ld + self.fd_w * fd))
         if last:
             self.optimizer_step()
-        return dict(ntp_loss=ntp, ld_loss=ld, fd_loss=fd, total=self.ntp_w * ntp + self.ld_w * ld + self.fd_w * fd)
+        return out
 
     # -- optimizer step ---------------------------------------------------------------------------
     def optimizer_step(self) -> None:

@@ -107,3 +107,23 @@ def test_kd_micro_step_bf16_runs_and_tracks_fp32():
     grads = training.kernel_grads_to_state_dict(tr.enc, tr.grads, tr.master)
     gn = float(grads["embed_projection.weight"].norm())
     assert abs(gn - float(g["grad_norm_embed_projection_weight"])) < 0.15 * float(g["grad_norm_embed_projection_weight"])
+
+
+def test_micro_batch_equals_sequential_micro_steps_fp32():
+    """A packed ragged batch of micro-steps accumulates the same gradients as the reference's sequential loop."""
+    g = golden("pipeline_tiny")
+    gen = torch.Generator().manual_seed(77)
+    waves = [ri.synthetic_waveform(n, seed=n) for n in (32000, 20000, 26000)]
+    texts = [torch.randint(1, TINY_LLAMA.vocab_size, (k,), generator=gen) for k in (11, 5, 8)]
+    resps = [torch.randint(1, TINY_LLAMA.vocab_size, (k,), generator=gen) for k in (8, 6, 9)]
+    tr1, _, _, _ = build(g, torch.float32, accum=4)
+    seq_losses = [tr1.micro_step(w, t_, r) for w, t_, r in zip(waves, texts, resps)]
+    tr2, _, _, _ = build(g, torch.float32, accum=4)
+    bat_losses = tr2.micro_batch(waves, texts, resps)
+    for a, b in zip(seq_losses, bat_losses):
+        for k in a:
+            assert abs(a[k] - b[k]) < 1e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    tot = torch.stack([v.norm() for v in tr1.grads.values()]).norm()
+    for k in tr1.grads:
+        err = float((tr1.grads[k].double() - tr2.grads[k].double()).norm())
+        assert err < 1e-4 * float(tr1.grads[k].norm()) + 1e-6 * float(tot), (k, err)
