@@ -264,7 +264,7 @@ typedef struct {
   int32_t dtype, n_conv, hidden, n_layers, n_heads, ffn, pos_k, pos_groups;
   int32_t conv_dim[8], conv_kernel[8], conv_stride[8];
   float ln_eps;   /* encoder / feature-projection LayerNorm eps; conv LayerNorms use 1e-5 */
-  int32_t pool_kernel, pool_stride, llm_dim, reserved;
+  int32_t pool_kernel, pool_stride, llm_dim, reserved;   /* reserved: 0 = HuBERT front end, 1 = Whisper (see sl_whisper_forward) */
   const float *conv0_w, *conv0_b, *conv0_g, *conv0_beta;       /* fp32: (C,k), (C), (C), (C) */
   const void *conv_w[8], *conv_b[8], *conv_g[8], *conv_beta[8]; /* i>=1: (C_out, k*C_in) tap-major */
   const void *fp_ln_g, *fp_ln_b, *fp_w, *fp_b;                  /* feature projection */
@@ -288,6 +288,24 @@ int sl_hubert_num_frames(const sl_hubert_model* m, int64_t n_samples);
 int sl_hubert_forward(const sl_hubert_model* m, const float* waves, const int64_t* sample_offsets_host, int32_t n_utt,
                       void* out, int64_t out_ld, const int64_t* out_row_offsets_host, void* last_hidden,
                       void* workspace, size_t workspace_bytes, sl_stream stream);
+
+/* Whisper path (BASELINE configs[3]; ref:model/audio_encoder.py:10-13, ref:trainer.py:168-199, 280-291).
+ * sl_whisper_logmel: WhisperFeatureExtractor's torch path (hf:models/whisper/feature_extraction_whisper.py:135-168)
+ *   for one utterance: zero-pad/trim to n_frames*hop samples, reflect pad, Hann STFT as an fp32 GEMM against
+ *   dft_basis ((n_fft/2+1)*2 rows [cos | sin] x n_fft, window folded in), power, mel_w (n_mel x roundup4(n_fft/2+1),
+ *   slaney), log10, max(x, max-8), (x+4)/4.  mel_out: (n_frames, n_mel) channel-last, dtype T.
+ * sl_whisper_forward: WhisperEncoder (hf:models/whisper/modeling_whisper.py:592-646) + AvgPool + projection for
+ *   n_utt mel inputs of exactly 2*max_source_positions frames each.  The model struct is sl_hubert_model with
+ *   reserved = 1, conv_dim[0] = n_mel, conv_w/b[1] = conv1 and conv_w/b[2] = conv2 (tap-major (C_out, 3*C_in)),
+ *   pos_w = embed_positions (pos_k = max_source_positions rows), layers' bqkv carrying zeros for the bias-less k_proj. */
+size_t sl_whisper_logmel_workspace_bytes(int32_t n_fft, int32_t hop, int32_t n_frames, int32_t n_mel);
+int sl_whisper_logmel(const float* audio, int64_t n_samples, const float* dft_basis, const float* mel_w, void* mel_out,
+                      int32_t n_fft, int32_t hop, int32_t n_frames, int32_t n_mel, void* workspace, size_t workspace_bytes,
+                      int32_t dtype, sl_stream stream);
+size_t sl_whisper_workspace_bytes(const sl_hubert_model* m, int32_t n_utt);
+int sl_whisper_forward(const sl_hubert_model* m, const void* mel, int32_t n_utt, void* out, int64_t out_ld,
+                       const int64_t* out_row_offsets_host, void* last_hidden, void* workspace, size_t workspace_bytes,
+                       sl_stream stream);
 
 typedef struct {
   const void *norm1, *wqkv, *wo, *norm2, *wgu, *wdown;   /* row-major (prefill); wgu: 16-row gate/up interleave */

@@ -135,6 +135,10 @@ _PROTOS = {
     "sl_hubert_num_frames": (c_i32, [C.POINTER(HubertModel), c_i64]),
     "sl_hubert_forward": (c_i32, [C.POINTER(HubertModel), c_vp, C.POINTER(c_i64), c_i32, c_vp, c_i64, C.POINTER(c_i64), c_vp,
                                   c_vp, c_sz, c_vp]),
+    "sl_whisper_logmel_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "sl_whisper_logmel": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_i32, c_vp]),
+    "sl_whisper_workspace_bytes": (c_sz, [C.POINTER(HubertModel), c_i32]),
+    "sl_whisper_forward": (c_i32, [C.POINTER(HubertModel), c_vp, c_i32, c_vp, c_i64, C.POINTER(c_i64), c_vp, c_vp, c_sz, c_vp]),
     "sl_llama_workspace_bytes": (c_sz, [C.POINTER(LlamaModel), c_i64, c_i32]),
     "sl_llama_prefill": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, C.POINTER(c_i32), c_i32, c_vp, c_vp, c_vp,
                                  c_vp, c_sz, c_vp]),

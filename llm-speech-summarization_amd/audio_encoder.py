@@ -9,7 +9,10 @@ Differences from the reference, all deliberate:
   * the encoder architecture comes from a local `config.json` or the built-in table of hub ids (no network);
   * `forward` also accepts a list of 1-D waveforms of different lengths (each encoded at its own length);
   * `stack` with T % factor == 0 keeps all frames instead of returning an empty sequence (Q5);
-  * Whisper is not built in this round -> explicit SpeechLLMError.
+  * Whisper (`base: whisper`): `forward` takes the (B, n_mel, 3000) log-mel features like the reference's trainer path
+    (ref:trainer.py:168-199) and `.feature_extractor(raw_audios, return_tensors="pt", sampling_rate=...)` computes them
+    on the GPU (sl_whisper_logmel) with the HF feature extractor's call shape; the crop to
+    `compute_num_audio_embeds` stays with the caller, as in ref:trainer.py:280-291.
 """
 from __future__ import annotations
 
@@ -22,7 +25,46 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .weights import KNOWN_HUBERT, HubertArch, HubertDeviceWeights, normalize_encoder_state_dict
+from .weights import (KNOWN_HUBERT, KNOWN_WHISPER, HubertArch, HubertDeviceWeights, WhisperArch, WhisperDeviceWeights,
+                      normalize_encoder_state_dict)
+
+
+def resolve_whisper_arch(type_str: str) -> WhisperArch:
+    cfg_path = os.path.join(type_str, "config.json")
+    if os.path.isdir(type_str) and os.path.exists(cfg_path):
+        with open(cfg_path) as f:
+            return WhisperArch.from_hf_config(json.load(f))
+    if type_str in KNOWN_WHISPER:
+        return KNOWN_WHISPER[type_str]
+    raise L.SpeechLLMError(f"unknown audio encoder '{type_str}': give a local directory with config.json or one of {list(KNOWN_WHISPER)}")
+
+
+class WhisperFeatures:
+    """GPU counterpart of HF's WhisperFeatureExtractor call used at ref:trainer.py:178-182."""
+
+    def __init__(self, owner: "AudioEncoder"):
+        self._o = owner
+        self.sampling_rate = 16000
+
+    def __call__(self, raw_audios, return_tensors="pt", sampling_rate=16000):
+        from types import SimpleNamespace
+        o = self._o
+        if sampling_rate != self.sampling_rate:
+            raise ValueError(f"The model corresponding to this feature extractor was trained using a sampling rate of {self.sampling_rate}")
+        if o.weights is None:
+            raise L.SpeechLLMError("AudioEncoder weights are not on the GPU: the log-mel front end runs on the HIP path only")
+        a, w, lib = o.arch, o.weights, L.lib()
+        if torch.is_tensor(raw_audios) and raw_audios.dim() == 1 or not isinstance(raw_audios, (list, tuple)) and getattr(raw_audios, "ndim", 2) == 1:
+            raw_audios = [raw_audios]
+        nbytes = lib.sl_whisper_logmel_workspace_bytes(a.n_fft, a.hop_length, a.n_frames, a.num_mel_bins)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=o.device)
+        feats = torch.empty((len(raw_audios), a.n_frames, a.num_mel_bins), device=o.device, dtype=torch.float32)
+        for i, wav in enumerate(raw_audios):
+            x = torch.as_tensor(wav, dtype=torch.float32).reshape(-1).to(o.device).contiguous()
+            L.check(lib.sl_whisper_logmel(x.data_ptr(), x.numel(), w.dft_basis.data_ptr(), w.mel_w.data_ptr(), feats[i].data_ptr(), a.n_fft,
+                                          a.hop_length, a.n_frames, a.num_mel_bins, ws.data_ptr(), ws.numel(), L.SL_F32, L.stream_ptr()),
+                    "sl_whisper_logmel")
+        return SimpleNamespace(input_features=feats.transpose(1, 2))   # (B, n_mel, n_frames) view, as HF returns
 
 
 def resolve_hubert_arch(type_str: str) -> HubertArch:
@@ -43,11 +85,13 @@ class AudioEncoder:
         base = self.config.model.audio_encoder.base
         if base == "hubert":
             self.encoder_base = "hubert"
+            self.arch = arch or resolve_hubert_arch(self.config.model.audio_encoder.type)
         elif base == "whisper":
-            raise L.SpeechLLMError("the Whisper encoder path (ref:model/audio_encoder.py:10-13) is not built yet (SURVEY.md §8 a12)")
+            self.encoder_base = "whisper"
+            self.arch = arch or resolve_whisper_arch(self.config.model.audio_encoder.type)
+            self.feature_extractor = WhisperFeatures(self)
         else:
             raise Exception("Unexpected encoder type in config.")
-        self.arch = arch or resolve_hubert_arch(self.config.model.audio_encoder.type)
         self.downsample_method = self.config.model.audio_encoder.downsample_method
         self.downsample_factor = self.config.model.audio_encoder.downsample_factor
         if self.downsample_method not in ("pool", "stack", "ctc_pool"):
@@ -92,6 +136,11 @@ class AudioEncoder:
         return self
 
     def _upload(self):
+        if self.encoder_base == "whisper":
+            self.weights = WhisperDeviceWeights(self.arch, self._state, self.llm_dim, self.device, self.dtype,
+                                                pool_kernel=max(self.pool_kernel, 1), pool_stride=max(self.pool_stride, 1),
+                                                downsample=self.downsample_method)
+            return
         self.weights = HubertDeviceWeights(self.arch, self._state, self.llm_dim, self.device, self.dtype,
                                            pool_kernel=max(self.pool_kernel, 1), pool_stride=max(self.pool_stride, 1),
                                            downsample=self.downsample_method)
@@ -157,6 +206,8 @@ class AudioEncoder:
         if self.weights is None:
             raise L.SpeechLLMError("AudioEncoder weights are not on the GPU: call load_state_dict(...).to('cuda') — "
                                    "the encoder runs on the HIP path only")
+        if self.encoder_base == "whisper":
+            return self._forward_whisper(input)
         if torch.is_tensor(input):
             if input.dim() == 1:
                 input = input[None]
@@ -184,5 +235,24 @@ class AudioEncoder:
             # the reference's stack / ctc_pool paths assume batch size 1 (ref:model/audio_encoder.py:68,77)
             raise L.SpeechLLMError("stack / ctc_pool downsampling assumes batch size 1, as the reference does")
         return outs[0][None]
+
+    def _forward_whisper(self, input_features: torch.Tensor) -> torch.Tensor:
+        """(B, n_mel, 2*max_source_positions) log-mel -> (B, P, llm_dim); WhisperEncoder raises on any other length
+        (hf:models/whisper/modeling_whisper.py:612-616) and so does this."""
+        a, lib = self.arch, L.lib()
+        if self.downsample_method != "pool":
+            raise L.SpeechLLMError("the Whisper path is built for the `pool` downsample (all shipped configs use it)")
+        if input_features.dim() != 3 or input_features.shape[1] != a.num_mel_bins or input_features.shape[2] != a.n_frames:
+            raise ValueError(f"Whisper expects the mel input features to be of length {a.n_frames}, but found {tuple(input_features.shape)}. "
+                             f"Make sure to pad the input mel features to {a.n_frames}.")
+        B = input_features.shape[0]
+        mel = input_features.to(self.device).transpose(1, 2).to(self.dtype).contiguous()       # channel-last rows for the implicit-GEMM convs
+        m = self.weights.struct
+        ws = self._workspace(lib.sl_whisper_workspace_bytes(C.byref(m), B))
+        P = (a.max_source_positions - self.pool_kernel) // self.pool_stride + 1
+        out = torch.empty((B * P, self.llm_dim), device=self.device, dtype=self.dtype)
+        L.check(lib.sl_whisper_forward(C.byref(m), mel.data_ptr(), B, out.data_ptr(), out.stride(0), None, None, ws.data_ptr(), ws.numel(),
+                                       L.stream_ptr()), "sl_whisper_forward")
+        return out.view(B, P, self.llm_dim)
 
     __call__ = forward

@@ -114,6 +114,50 @@ static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n
   return c.off + 256;
 }
 
+// transformer layers on the packed frames of the batch (varlen attention), final LayerNorm, AvgPool + projection.
+// Shared by the HuBERT and Whisper front ends (both are 16x64 pre-LN encoders: hf:...hubert.py:504-547,
+// hf:models/whisper/modeling_whisper.py:360-414).
+static int encoder_tail(const sl_hubert_model* m, HubertWs& w, const HubertPlan& pl, int n_utt, void* out, int64_t out_ld,
+                        const int64_t* out_row_offsets_host, void* last_hidden, hipStream_t st) {
+  sl_stream stream = (sl_stream)st;
+  const int dt = m->dtype, H = m->hidden, NT = (int)pl.total_T;
+  const size_t sz = sl_dtype_size(dt);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const sl_hubert_layer& L = m->layers[l];
+    SL_TRY(sl_layernorm(w.x, w.ln, L.ln1_g, L.ln1_b, NT, H, m->ln_eps, 0, dt, stream));
+    SL_TRY(gemm(dt, w.ln, H, L.wqkv, H, w.qkv, 3 * H, L.bqkv, nullptr, 0, NT, 3 * H, H, SL_ACT_NONE, 0, st));
+    sl_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.q = w.qkv; a.q_row_stride = 3 * H; a.q_head_stride = 64;
+    a.k = bptr(w.qkv) + (size_t)H * sz; a.k_row_stride = 3 * H; a.k_head_stride = 64;
+    a.v = bptr(w.qkv) + (size_t)2 * H * sz; a.v_row_stride = 3 * H; a.v_head_stride = 64;
+    a.out = w.att; a.o_row_stride = H; a.o_head_stride = 64;
+    a.cu_q = w.cu; a.cu_k = w.cuk; a.klen = w.klen;
+    a.nseq = n_utt; a.max_qlen = (int)pl.max_T; a.n_heads = m->n_heads; a.n_kv_heads = m->n_heads; a.head_dim = 64; a.causal = 0;
+    a.dtype = dt; a.scale = 0.125f;
+    SL_TRY(sl_attn_fwd(&a, stream));
+    SL_TRY(gemm(dt, w.att, H, L.wo, H, w.x, H, L.bo, w.x, H, NT, H, H, SL_ACT_NONE, 0, st));
+    SL_TRY(sl_layernorm(w.x, w.ln, L.ln2_g, L.ln2_b, NT, H, m->ln_eps, 0, dt, stream));
+    SL_TRY(gemm(dt, w.ln, H, L.w1, H, w.mid, m->ffn, L.b1, nullptr, 0, NT, m->ffn, H, SL_ACT_GELU, 0, st));
+    SL_TRY(gemm(dt, w.mid, m->ffn, L.w2, m->ffn, w.x, H, L.b2, w.x, H, NT, H, m->ffn, SL_ACT_NONE, 0, st));
+  }
+  void* lh = last_hidden ? last_hidden : w.ln;
+  SL_TRY(sl_layernorm(w.x, lh, m->final_ln_g, m->final_ln_b, NT, H, m->ln_eps, 0, dt, stream));
+  // ---- AvgPool over time + projection into the caller's (prompt) buffer
+  int64_t prow = 0;
+  if (!m->proj_w) return 0;  // stack / ctc_pool: the host finishes from last_hidden
+  for (int u = 0; u < n_utt; ++u) {
+    unsigned char* src = bptr(lh) + pl.tok0[u] * H * sz;
+    unsigned char* pooled = bptr(w.pooled) + prow * H * sz;
+    SL_TRY(sl_avgpool_rows(src, pooled, pl.T[u], H, m->pool_kernel, m->pool_stride, nullptr, pl.P[u], dt, stream));
+    const int64_t orow = out_row_offsets_host ? out_row_offsets_host[u] : prow;
+    SL_TRY(gemm(dt, pooled, H, m->proj_w, H, bptr(out) + orow * out_ld * sz, out_ld, m->proj_b, nullptr, 0, (int)pl.P[u], m->llm_dim, H,
+                SL_ACT_NONE, 0, st));
+    prow += pl.P[u];
+  }
+  return 0;
+}
+
 extern "C" size_t sl_hubert_workspace_bytes(const sl_hubert_model* m, const int64_t* sample_offsets_host, int32_t n_utt) {
   HubertPlan pl;
   if (hubert_plan(m, sample_offsets_host, n_utt, pl) != 0) return 0;
@@ -221,41 +265,80 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
     SL_TRY(sl_gemm_impl(&a, nullptr, &ex, st));
     void* t = w.x; w.x = w.ln; w.ln = t;
   }
-  // ---- transformer layers on packed tokens, varlen attention
-  for (int l = 0; l < m->n_layers; ++l) {
-    const sl_hubert_layer& L = m->layers[l];
-    SL_TRY(sl_layernorm(w.x, w.ln, L.ln1_g, L.ln1_b, NT, H, m->ln_eps, 0, dt, stream));
-    SL_TRY(gemm(dt, w.ln, H, L.wqkv, H, w.qkv, 3 * H, L.bqkv, nullptr, 0, NT, 3 * H, H, SL_ACT_NONE, 0, st));
-    sl_attn_args a;
-    memset(&a, 0, sizeof(a));
-    a.q = w.qkv; a.q_row_stride = 3 * H; a.q_head_stride = 64;
-    a.k = bptr(w.qkv) + (size_t)H * sz; a.k_row_stride = 3 * H; a.k_head_stride = 64;
-    a.v = bptr(w.qkv) + (size_t)2 * H * sz; a.v_row_stride = 3 * H; a.v_head_stride = 64;
-    a.out = w.att; a.o_row_stride = H; a.o_head_stride = 64;
-    a.cu_q = w.cu; a.cu_k = w.cuk; a.klen = w.klen;
-    a.nseq = n_utt; a.max_qlen = (int)pl.max_T; a.n_heads = m->n_heads; a.n_kv_heads = m->n_heads; a.head_dim = 64; a.causal = 0;
-    a.dtype = dt; a.scale = 0.125f;
-    SL_TRY(sl_attn_fwd(&a, stream));
-    SL_TRY(gemm(dt, w.att, H, L.wo, H, w.x, H, L.bo, w.x, H, NT, H, H, SL_ACT_NONE, 0, st));
-    SL_TRY(sl_layernorm(w.x, w.ln, L.ln2_g, L.ln2_b, NT, H, m->ln_eps, 0, dt, stream));
-    SL_TRY(gemm(dt, w.ln, H, L.w1, H, w.mid, m->ffn, L.b1, nullptr, 0, NT, m->ffn, H, SL_ACT_GELU, 0, st));
-    SL_TRY(gemm(dt, w.mid, m->ffn, L.w2, m->ffn, w.x, H, L.b2, w.x, H, NT, H, m->ffn, SL_ACT_NONE, 0, st));
-  }
-  void* lh = last_hidden ? last_hidden : w.ln;
-  SL_TRY(sl_layernorm(w.x, lh, m->final_ln_g, m->final_ln_b, NT, H, m->ln_eps, 0, dt, stream));
-  // ---- AvgPool over time + projection into the caller's (prompt) buffer
-  int64_t prow = 0;
-  if (!m->proj_w) return 0;  // stack / ctc_pool: the host finishes from last_hidden
-  for (int u = 0; u < n_utt; ++u) {
-    unsigned char* src = bptr(lh) + pl.tok0[u] * H * sz;
-    unsigned char* pooled = bptr(w.pooled) + prow * H * sz;
-    SL_TRY(sl_avgpool_rows(src, pooled, pl.T[u], H, m->pool_kernel, m->pool_stride, nullptr, pl.P[u], dt, stream));
-    const int64_t orow = out_row_offsets_host ? out_row_offsets_host[u] : prow;
-    SL_TRY(gemm(dt, pooled, H, m->proj_w, H, bptr(out) + orow * out_ld * sz, out_ld, m->proj_b, nullptr, 0, (int)pl.P[u], m->llm_dim, H,
-                SL_ACT_NONE, 0, st));
-    prow += pl.P[u];
-  }
+  return encoder_tail(m, w, pl, n_utt, out, out_ld, out_row_offsets_host, last_hidden, st);
+}
+
+// ================================================================================================
+// Whisper encoder (hf:models/whisper/modeling_whisper.py:592-646): conv1(k3,p1)+GELU, conv2(k3,s2,p1)+GELU as implicit
+// GEMMs over zero-haloed channel-last rows, + positional table, then the shared transformer tail.
+// Model struct reuse: conv_dim[0] = n_mel, conv_w/b[1] = conv1, conv_w/b[2] = conv2 (tap-major), pos_w = embed_positions
+// (pos_k rows = max_source_positions), frontend = 1.
+// ================================================================================================
+static int whisper_plan(const sl_hubert_model* m, int n_utt, HubertPlan& pl) {
+  const int64_t T = m->pos_k;
+  pl.T.assign(n_utt, T); pl.P.resize(n_utt); pl.tok0.resize(n_utt + 1);
+  SL_CHECK_ARG(T >= m->pool_kernel, "sl_whisper_forward: %lld frames < pool kernel %d", (long long)T, m->pool_kernel);
+  for (int u = 0; u < n_utt; ++u) { pl.P[u] = (T - m->pool_kernel) / m->pool_stride + 1; pl.tok0[u] = (int64_t)u * T; pl.total_P += pl.P[u]; }
+  pl.tok0[n_utt] = (int64_t)n_utt * T;
+  pl.total_T = (int64_t)n_utt * T; pl.max_T = T;
+  // conv buffers: haloed mel (2T+2, n_mel) and haloed conv1 output (2T+2, H) per utterance
+  pl.max_conv_elems = (int64_t)n_utt * (2 * T + 2) * (m->hidden > m->conv_dim[0] ? m->hidden : m->conv_dim[0]);
   return 0;
+}
+
+extern "C" size_t sl_whisper_workspace_bytes(const sl_hubert_model* m, int32_t n_utt) {
+  HubertPlan pl;
+  if (whisper_plan(m, n_utt, pl) != 0) return 0;
+  HubertWs w;
+  return hubert_carve(m, pl, n_utt, nullptr, 0, w);
+}
+
+extern "C" int sl_whisper_forward(const sl_hubert_model* m, const void* mel, int32_t n_utt, void* out, int64_t out_ld,
+                                  const int64_t* out_row_offsets_host, void* last_hidden, void* workspace, size_t workspace_bytes,
+                                  sl_stream stream) {
+  SL_CHECK_ARG(m && mel && workspace && n_utt > 0, "sl_whisper_forward: bad arguments");
+  SL_CHECK_ARG(m->reserved == 1, "sl_whisper_forward: model struct is not a Whisper front end");
+  SL_CHECK_ARG((m->proj_w && out) || (!m->proj_w && last_hidden), "sl_whisper_forward: need `out` (pool) or `last_hidden`");
+  SL_CHECK_ARG(m->hidden % m->n_heads == 0 && m->hidden / m->n_heads == 64, "sl_whisper_forward: head_dim must be 64");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = m->dtype, H = m->hidden, n_mel = m->conv_dim[0];
+  const size_t sz = sl_dtype_size(dt);
+  const int64_t T = m->pos_k, F = 2 * T;   // F mel frames in, T positions out
+  HubertPlan pl;
+  SL_TRY(whisper_plan(m, n_utt, pl));
+  HubertWs w;
+  const size_t need = hubert_carve(m, pl, n_utt, workspace, workspace_bytes, w);
+  SL_CHECK_ARG(need <= workspace_bytes, "sl_whisper_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+  {
+    std::vector<int32_t> cu(n_utt + 1), kl(n_utt, (int32_t)T);
+    for (int u = 0; u <= n_utt; ++u) cu[u] = (int32_t)(u * T);
+    SL_HIP(hipMemcpyAsync(w.cu, cu.data(), (n_utt + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipMemcpyAsync(w.cuk, cu.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipMemcpyAsync(w.klen, kl.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipStreamSynchronize(st));
+  }
+  // haloed inputs: one zero row before and after each utterance's frames (Conv1d padding=1)
+  SL_HIP(hipMemsetAsync(w.convA, 0, (size_t)n_utt * (F + 2) * n_mel * sz, st));
+  SL_HIP(hipMemsetAsync(w.convB, 0, (size_t)n_utt * (F + 2) * H * sz, st));
+  SL_HIP(hipMemcpy2DAsync(bptr(w.convA) + (size_t)n_mel * sz, (size_t)(F + 2) * n_mel * sz, mel, (size_t)F * n_mel * sz, (size_t)F * n_mel * sz, n_utt,
+                          hipMemcpyDeviceToDevice, st));
+  sl_gemm_args a;
+  memset(&a, 0, sizeof(a));   // conv1: out row t reads the 3*n_mel contiguous elements from haloed row t
+  a.A = w.convA; a.lda = n_mel; a.strideA = (F + 2) * n_mel;
+  a.W = m->conv_w[1]; a.ldw = 3 * n_mel;
+  a.C = bptr(w.convB) + (size_t)H * sz; a.ldc = H; a.strideC = (F + 2) * H;
+  a.bias = m->conv_b[1];
+  a.M = (int)F; a.N = H; a.K = 3 * n_mel; a.batch = n_utt; a.dtype = dt; a.act = SL_ACT_GELU;
+  SL_TRY(sl_gemm_impl(&a, nullptr, nullptr, st));
+  memset(&a, 0, sizeof(a));   // conv2 (stride 2): out row t reads haloed rows 2t .. 2t+2; + positional table after GELU
+  a.A = w.convB; a.lda = 2 * (int64_t)H; a.strideA = (F + 2) * H;
+  a.W = m->conv_w[2]; a.ldw = 3 * (int64_t)H;
+  a.C = w.x; a.ldc = H; a.strideC = T * H;
+  a.bias = m->conv_b[2];
+  a.residual = m->pos_w; a.ldr = H; a.strideR = 0;
+  a.M = (int)T; a.N = H; a.K = 3 * H; a.batch = n_utt; a.dtype = dt; a.act = SL_ACT_GELU;
+  SL_TRY(sl_gemm_impl(&a, nullptr, nullptr, st));
+  return encoder_tail(m, w, pl, n_utt, out, out_ld, out_row_offsets_host, last_hidden, st);
 }
 
 // ================================================================================================

@@ -111,3 +111,37 @@ def synthetic_ids(n: int, vocab: int, seed: int = 7, bos: int = 0) -> torch.Tens
     ids = torch.randint(0, vocab, (1, n), generator=_g(seed), dtype=torch.int64)
     ids[0, 0] = bos
     return ids
+
+
+def whisper_encoder_state_dict(cfg, llm_dim: int, seed: int = 0, lin_std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """AudioEncoder state-dict for the Whisper base (ref:model/audio_encoder.py:10-13): `encoder.*` = HF WhisperEncoder."""
+    g = _g(seed)
+    H, M = cfg.d_model, cfg.num_mel_bins
+    sd: Dict[str, torch.Tensor] = {}
+    sd["encoder.conv1.weight"] = _randn(g, H, M, 3, std=math.sqrt(2.0 / (3 * M)))
+    sd["encoder.conv1.bias"] = _randn(g, H, std=0.02)
+    sd["encoder.conv2.weight"] = _randn(g, H, H, 3, std=math.sqrt(2.0 / (3 * H)))
+    sd["encoder.conv2.bias"] = _randn(g, H, std=0.02)
+    half = H // 2
+    inv = torch.exp(-math.log(10000.0) / (half - 1) * torch.arange(half))
+    st = torch.arange(cfg.max_source_positions).view(-1, 1) * inv.view(1, -1)
+    sd["encoder.embed_positions.weight"] = torch.cat([st.sin(), st.cos()], dim=1)     # hf:...modeling_whisper.py:55-64
+    for li in range(cfg.encoder_layers):
+        p = f"encoder.layers.{li}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{n}.weight"] = _randn(g, H, H, std=lin_std)
+            if n != "k_proj":
+                sd[p + f"self_attn.{n}.bias"] = _randn(g, H, std=0.02)
+        sd[p + "self_attn_layer_norm.weight"] = 1.0 + _randn(g, H, std=0.1)
+        sd[p + "self_attn_layer_norm.bias"] = _randn(g, H, std=0.05)
+        sd[p + "fc1.weight"] = _randn(g, cfg.encoder_ffn_dim, H, std=lin_std)
+        sd[p + "fc1.bias"] = _randn(g, cfg.encoder_ffn_dim, std=0.02)
+        sd[p + "fc2.weight"] = _randn(g, H, cfg.encoder_ffn_dim, std=lin_std)
+        sd[p + "fc2.bias"] = _randn(g, H, std=0.02)
+        sd[p + "final_layer_norm.weight"] = 1.0 + _randn(g, H, std=0.1)
+        sd[p + "final_layer_norm.bias"] = _randn(g, H, std=0.05)
+    sd["encoder.layer_norm.weight"] = 1.0 + _randn(g, H, std=0.1)
+    sd["encoder.layer_norm.bias"] = _randn(g, H, std=0.05)
+    sd["embed_projection.weight"] = _randn(g, llm_dim, H, std=lin_std)
+    sd["embed_projection.bias"] = _randn(g, llm_dim, std=0.02)
+    return sd

@@ -343,3 +343,132 @@ class LlamaDeviceWeights:
             + a.num_attention_heads * a.head_dim * a.hidden_size + 3 * a.intermediate_size * a.hidden_size + 2 * a.hidden_size
         total = per_layer * a.num_hidden_layers + a.hidden_size + a.vocab_size * a.hidden_size
         return total * (2 if self.dtype == torch.bfloat16 else 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# Whisper (alternate encoder, ref:model/audio_encoder.py:10-13; BASELINE configs[3])
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class WhisperArch:
+    d_model: int = 1024
+    encoder_layers: int = 24
+    encoder_attention_heads: int = 16
+    encoder_ffn_dim: int = 4096
+    num_mel_bins: int = 80
+    max_source_positions: int = 1500
+    n_fft: int = 400
+    hop_length: int = 160
+    sampling_rate: int = 16000
+
+    @property
+    def hidden_size(self) -> int:   # common name used by the projector code
+        return self.d_model
+
+    @property
+    def n_frames(self) -> int:
+        return 2 * self.max_source_positions
+
+    @property
+    def n_samples(self) -> int:
+        return self.n_frames * self.hop_length
+
+    @staticmethod
+    def from_hf_config(d: dict) -> "WhisperArch":
+        return WhisperArch(d["d_model"], d["encoder_layers"], d["encoder_attention_heads"], d["encoder_ffn_dim"], d.get("num_mel_bins", 80),
+                           d.get("max_source_positions", 1500))
+
+
+KNOWN_WHISPER = {"openai/whisper-medium": WhisperArch(), "openai/whisper-medium.en": WhisperArch()}
+
+
+def slaney_mel_filters(n_freqs: int, n_mels: int, sr: int = 16000, fmin: float = 0.0, fmax: float = 8000.0) -> torch.Tensor:
+    """Slaney-scale, area-normalised triangular mel bank (n_freqs, n_mels), float64 -> float32: the published Auditory
+    Toolbox / librosa definition that hf:audio_utils.py:638-729 implements for norm="slaney", mel_scale="slaney"."""
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+
+    def hz_to_mel(f: torch.Tensor) -> torch.Tensor:
+        return torch.where(f >= min_log_hz, min_log_mel + torch.log(f.clamp(min=1e-10) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m: torch.Tensor) -> torch.Tensor:
+        return torch.where(m >= min_log_mel, min_log_hz * torch.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    d = torch.float64
+    mel_pts = torch.linspace(float(hz_to_mel(torch.tensor(fmin, dtype=d))), float(hz_to_mel(torch.tensor(fmax, dtype=d))), n_mels + 2, dtype=d)
+    hz_pts = mel_to_hz(mel_pts)
+    fft_freqs = torch.linspace(0, sr // 2, n_freqs, dtype=d)
+    diff = hz_pts[1:] - hz_pts[:-1]
+    slopes = hz_pts[None, :] - fft_freqs[:, None]
+    down, up = -slopes[:, :-2] / diff[:-1], slopes[:, 2:] / diff[1:]
+    fb = torch.clamp(torch.minimum(down, up), min=0.0)
+    fb = fb * (2.0 / (hz_pts[2:n_mels + 2] - hz_pts[:n_mels]))[None, :]
+    return fb.to(torch.float32)
+
+
+def windowed_dft_basis(n_fft: int) -> torch.Tensor:
+    """(2*(n_fft/2+1), n_fft) fp32: rows [hann*cos(2 pi k n / N)] then [hann*sin(...)] — torch.stft(window=hann_window(n_fft))
+    as a matrix (the sign of the imaginary part is irrelevant for the power spectrum)."""
+    d = torch.float64
+    n = torch.arange(n_fft, dtype=d)
+    k = torch.arange(n_fft // 2 + 1, dtype=d)
+    win = 0.5 - 0.5 * torch.cos(2 * math.pi * n / n_fft)          # periodic Hann, torch.hann_window default
+    ang = 2 * math.pi * k[:, None] * n[None, :] / n_fft
+    return torch.cat([torch.cos(ang) * win, torch.sin(ang) * win], 0).to(torch.float32).contiguous()
+
+
+class WhisperDeviceWeights:
+    """Device tensors + the sl_hubert_model struct in its Whisper layout (include/speechllm.h, sl_whisper_forward)."""
+
+    def __init__(self, arch: WhisperArch, sd: Dict[str, torch.Tensor], llm_dim: int, device, dtype: torch.dtype, pool_kernel: int = 8,
+                 pool_stride: int = 4, downsample: str = "pool"):
+        sd = normalize_encoder_state_dict(sd)
+        self.arch, self.dtype, self.device, self.llm_dim = arch, dtype, device, llm_dim
+        self._keep: List[torch.Tensor] = []
+        H = arch.d_model
+        if H // arch.encoder_attention_heads != 64:
+            raise L.SpeechLLMError("Whisper head_dim must be 64 for the built attention kernel")
+
+        def dev(t: torch.Tensor, dt=None) -> torch.Tensor:
+            t = t.detach().to(device=device, dtype=dt or dtype).contiguous()
+            self._keep.append(t)
+            return t
+
+        m = L.HubertModel()
+        m.dtype, m.reserved = L.dtype_code(dtype), 1
+        m.n_conv, m.hidden, m.n_layers, m.n_heads, m.ffn = 3, H, arch.encoder_layers, arch.encoder_attention_heads, arch.encoder_ffn_dim
+        m.pos_k, m.pos_groups = arch.max_source_positions, 1
+        m.conv_dim[0], m.conv_dim[1], m.conv_dim[2] = arch.num_mel_bins, H, H
+        m.conv_kernel[0] = m.conv_kernel[1] = m.conv_kernel[2] = 3
+        m.conv_stride[0], m.conv_stride[1], m.conv_stride[2] = 1, 1, 2
+        m.ln_eps, m.pool_kernel, m.pool_stride, m.llm_dim = 1e-5, pool_kernel, pool_stride, llm_dim
+        for i, name in ((1, "conv1"), (2, "conv2")):
+            w = sd[f"encoder.{name}.weight"]                     # (Cout, Cin, 3) -> (Cout, 3*Cin) tap-major
+            m.conv_w[i] = dev(w.permute(0, 2, 1).reshape(w.shape[0], -1)).data_ptr()
+            m.conv_b[i] = dev(sd[f"encoder.{name}.bias"]).data_ptr()
+        m.pos_w = dev(sd["encoder.embed_positions.weight"]).data_ptr()
+        self._layers = (L.HubertLayer * arch.encoder_layers)()
+        for li in range(arch.encoder_layers):
+            p = f"encoder.layers.{li}."
+            a = p + "self_attn."
+            lay = self._layers[li]
+            lay.ln1_g, lay.ln1_b = dev(sd[p + "self_attn_layer_norm.weight"]).data_ptr(), dev(sd[p + "self_attn_layer_norm.bias"]).data_ptr()
+            lay.wqkv = dev(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0)).data_ptr()
+            kb = sd.get(a + "k_proj.bias", torch.zeros_like(sd[a + "q_proj.bias"]))   # Whisper's k_proj has no bias
+            lay.bqkv = dev(torch.cat([sd[a + "q_proj.bias"], kb, sd[a + "v_proj.bias"]], 0)).data_ptr()
+            lay.wo, lay.bo = dev(sd[a + "out_proj.weight"]).data_ptr(), dev(sd[a + "out_proj.bias"]).data_ptr()
+            lay.ln2_g, lay.ln2_b = dev(sd[p + "final_layer_norm.weight"]).data_ptr(), dev(sd[p + "final_layer_norm.bias"]).data_ptr()
+            lay.w1, lay.b1 = dev(sd[p + "fc1.weight"]).data_ptr(), dev(sd[p + "fc1.bias"]).data_ptr()
+            lay.w2, lay.b2 = dev(sd[p + "fc2.weight"]).data_ptr(), dev(sd[p + "fc2.bias"]).data_ptr()
+        m.layers = C.cast(self._layers, C.POINTER(L.HubertLayer))
+        m.final_ln_g, m.final_ln_b = dev(sd["encoder.layer_norm.weight"]).data_ptr(), dev(sd["encoder.layer_norm.bias"]).data_ptr()
+        self.proj_w, self.proj_b = dev(sd["embed_projection.weight"]), dev(sd["embed_projection.bias"])
+        if downsample == "pool":
+            m.proj_w, m.proj_b = self.proj_w.data_ptr(), self.proj_b.data_ptr()
+        self.struct = m
+        # log-mel constants (fp32)
+        nb = arch.n_fft // 2 + 1
+        ld_pw = (nb + 3) // 4 * 4
+        mel = torch.zeros((arch.num_mel_bins, ld_pw), dtype=torch.float32)
+        mel[:, :nb] = slaney_mel_filters(nb, arch.num_mel_bins, arch.sampling_rate).T
+        self.mel_w = dev(mel, torch.float32)
+        self.dft_basis = dev(windowed_dft_basis(arch.n_fft), torch.float32)

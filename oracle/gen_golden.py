@@ -30,7 +30,7 @@ from oracle.hubert_oracle import HubertCfg  # noqa: E402
 from oracle.llama_oracle import LlamaCfg  # noqa: E402
 
 from oracle.golden_cfgs import (LLAMA_ID, MINICHAT_ID, TINY_HUBERT, WIDE_HUBERT, TINY_LLAMA, TINY_MHA,  # noqa: E402
-                                WIDE_LLAMA)
+                                WIDE_LLAMA, TINY_WHISPER)
 
 
 def import_reference():
@@ -38,10 +38,21 @@ def import_reference():
     import transformers.models.llama.modeling_llama as ml
     if not hasattr(ml, "KwargsForCausalLM"):  # renamed in transformers 5.x; annotation-only use
         ml.KwargsForCausalLM = transformers.utils.TransformersKwargs
-    sys.path.insert(0, REF)
-    enc = importlib.import_module("model.audio_encoder")
-    llama = importlib.import_module("model.audio_llama")
-    utils = importlib.import_module("utils")
+    # load by FILE PATH under private names: this repo ships same-named drop-in shims (model/, utils.py) that would
+    # otherwise shadow the reference's modules on sys.path
+    import importlib.util
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        assert os.path.realpath(mod.__file__).startswith(os.path.realpath(REF)), mod.__file__
+        return mod
+
+    enc = load("_ref_audio_encoder", "model/audio_encoder.py")
+    llama = load("_ref_audio_llama", "model/audio_llama.py")
+    utils = load("_ref_utils", "utils.py")
     return enc, llama, utils
 
 
@@ -287,17 +298,49 @@ def gen_pipeline(enc_mod, llama_mod, utils):
     save("num_audio_embeds", n_samples=ns, expected=[utils.compute_num_audio_embeds(n) for n in ns])
 
 
+@torch.no_grad()
+def gen_whisper(enc_mod):
+    """Whisper base through the reference AudioEncoder (ref:model/audio_encoder.py:10-13,25-27) and the HF feature
+    extractor exactly as ref:trainer.py:178-182 calls it; tiny config with 2 s chunks."""
+    from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperModel
+    c = TINY_WHISPER
+    tmp = tempfile.mkdtemp(prefix="whisper_cfg_")
+    hf_cfg = WhisperConfig(d_model=c.d_model, encoder_layers=c.encoder_layers, encoder_attention_heads=c.encoder_attention_heads,
+                           encoder_ffn_dim=c.encoder_ffn_dim, num_mel_bins=c.num_mel_bins, max_source_positions=c.max_source_positions,
+                           decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64, vocab_size=64, max_target_positions=16,
+                           dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, pad_token_id=0,
+                           bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+    WhisperModel(hf_cfg).save_pretrained(tmp)
+    fe = WhisperFeatureExtractor(feature_size=c.num_mel_bins, sampling_rate=16000, hop_length=c.hop_length, chunk_length=2, n_fft=c.n_fft)
+    fe.save_pretrained(tmp)
+    cfg = SimpleNamespace(model=SimpleNamespace(
+        audio_encoder=SimpleNamespace(base="whisper", type=tmp, downsample_method="pool", downsample_factor=4,
+                                      pooling=SimpleNamespace(kernel_size=8, stride=4)),
+        llm_embedding_channels=256))
+    m = enc_mod.AudioEncoder(cfg, torch.device("cpu"))
+    sd = ri.whisper_encoder_state_dict(c, 256, seed=61)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    waves = [ri.synthetic_waveform(n, seed=300 + n).numpy() for n in (20000, 32000, 40000)]   # shorter, equal, longer than the chunk
+    feats = m.feature_extractor(waves, return_tensors="pt", sampling_rate=16000).input_features
+    out = m(feats)
+    save("whisper_tiny", n_samples=[20000, 32000, 40000], wave_seeds=[300 + n for n in (20000, 32000, 40000)], weight_seed=61,
+         input_features=feats, audio_embeds=out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     enc_mod, llama_mod, utils = import_reference()
-    which = sys.argv[1:] or ["encoder", "llama", "pipeline"]
+    which = sys.argv[1:] or ["encoder", "llama", "pipeline", "whisper"]
     if "encoder" in which:
         gen_encoder(enc_mod)
     if "llama" in which:
         gen_llama(llama_mod)
     if "pipeline" in which:
         gen_pipeline(enc_mod, llama_mod, utils)
+    if "whisper" in which:
+        gen_whisper(enc_mod)
 
 
 if __name__ == "__main__":

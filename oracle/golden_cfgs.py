@@ -6,6 +6,7 @@ CPU and the HIP path on the GPU box.
 """
 from oracle.hubert_oracle import HubertCfg
 from oracle.llama_oracle import LlamaCfg
+from oracle.whisper_oracle import WhisperCfg
 
 LLAMA_ID = "meta-llama/Llama-3.2-3B-Instruct"
 MINICHAT_ID = "GeneZC/MiniChat-2-3B"
@@ -24,3 +25,6 @@ TINY_MHA = LlamaCfg(hidden_size=256, num_hidden_layers=2, num_attention_heads=2,
 WIDE_LLAMA = LlamaCfg(num_hidden_layers=2, eos_token_ids=(128001, 128008, 128009), pad_token_id=128001,
                       rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
                                         original_max_position_embeddings=8192))
+# tiny Whisper: 2 s chunks (200 mel frames -> 100 positions), head_dim 64
+TINY_WHISPER = WhisperCfg(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, num_mel_bins=80,
+                          max_source_positions=100)

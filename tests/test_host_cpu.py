@@ -63,9 +63,12 @@ def test_configs_follow_reference_schema(name):
     assert c.train.grad_accum_interval == 16 and c.train.fd_loss_connector_layers == [0, 5, 11, 17, 23]
     assert c.train.optimizer.lr == 5e-5 and c.log.validation_interval == 30000
     utils.prompt_template(c.model.llm_type)
+    enc = pkg("audio_encoder").AudioEncoder(c, "cpu")
+    assert enc.encoder_base == c.model.audio_encoder.base and enc.downsample_method == "pool"
     if c.model.audio_encoder.base == "whisper":
-        with pytest.raises(L.SpeechLLMError):
-            pkg("audio_encoder").AudioEncoder(c, "cpu")
+        assert enc.arch.n_frames == 3000 and enc.arch.n_samples == 480000 and hasattr(enc, "feature_extractor")
+        with pytest.raises(L.SpeechLLMError):           # the log-mel front end is HIP-only as well
+            enc.feature_extractor([torch.zeros(16000)], return_tensors="pt", sampling_rate=16000)
 
 
 def test_prompt_templates_and_errors():

@@ -214,3 +214,25 @@ def test_generate_audio_response_pipeline_fp32_ids_match_reference():
     assert text == " ".join(str(int(i)) for i in g["ids_audio"][0])
     inf.generate_audio_response(wave, additional_text_prompt="EXTRA", max_new_tokens=40)
     assert torch.equal(inf.last_generate_ids.cpu(), t(g["ids_text_audio"]))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_whisper_path_logmel_and_encoder_vs_reference_fixture(dtype, tol):
+    from oracle.golden_cfgs import TINY_WHISPER as WC
+    g = golden("whisper_tiny")
+    conf = cfgm.from_dict(dict(model=dict(audio_encoder=dict(base="whisper", type="synthetic", downsample_method="pool", downsample_factor=4,
+                                                             pooling=dict(kernel_size=8, stride=4)),
+                                          llm_embedding_channels=256, llm_type=utils.LLAMA_ID)))
+    arch = weights.WhisperArch(WC.d_model, WC.encoder_layers, WC.encoder_attention_heads, WC.encoder_ffn_dim, WC.num_mel_bins, WC.max_source_positions)
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=dtype, arch=arch)
+    enc.load_state_dict(ri.whisper_encoder_state_dict(WC, 256, seed=int(g["weight_seed"]))).eval().to(DEV)
+    waves = [ri.synthetic_waveform(int(n), seed=int(s)).numpy() for n, s in zip(g["n_samples"], g["wave_seeds"])]
+    feats = enc.feature_extractor(waves, return_tensors="pt", sampling_rate=16000).input_features
+    assert feats.shape == t(g["input_features"]).shape
+    assert float((feats.cpu() - t(g["input_features"])).abs().max()) < 2e-4      # fp32 DFT-as-GEMM vs torch.stft, after log10
+    out = enc(feats)
+    assert rel_err(out.float().cpu(), t(g["audio_embeds"])) < tol
+    with pytest.raises(ValueError):
+        enc(feats[:, :, :-2])
+    # the trainer-side crop (ref:trainer.py:280-291)
+    assert utils.compute_num_audio_embeds(20000) <= out.shape[1]

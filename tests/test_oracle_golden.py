@@ -159,3 +159,13 @@ def test_pipeline_order_of_operations_and_kd_losses():
     ntp = lo.response_only_loss(lo.llama_forward(sd, cfg, seq)["logits"], [t(g["response_ids"])])
     (d,) = torch.autograd.grad(ntp, audio2)
     assert rel_err(d, t(g["d_ntp_d_audio_embeds"])) < 1e-4
+
+
+def test_whisper_logmel_and_encoder_vs_reference_fixture():
+    from oracle import whisper_oracle as wo
+    from oracle.golden_cfgs import TINY_WHISPER
+    g = golden("whisper_tiny")
+    sd = ri.whisper_encoder_state_dict(TINY_WHISPER, 256, seed=int(g["weight_seed"]))
+    feats = torch.stack([wo.log_mel(TINY_WHISPER, ri.synthetic_waveform(int(n), seed=int(s))) for n, s in zip(g["n_samples"], g["wave_seeds"])])
+    assert float((feats - t(g["input_features"])).abs().max()) < 1e-5        # feature extractor (HF torch path)
+    assert rel_err(wo.audio_encoder_forward(sd, TINY_WHISPER, feats), t(g["audio_embeds"])) < TOL
