@@ -173,7 +173,14 @@ class AudioLlamaForCausalLM:
         hidden_states = tuple(unpack(taps[i]) for i in range(a.num_hidden_layers + 1)) if output_hidden_states else None
         loss = None
         if labels is not None:
-            raise L.SpeechLLMError("the response-only CE loss kernel (ref:model/audio_llama.py:72-101) is not built in this round")
+            # per-sample response-only next-token CE, batch mean (ref:model/audio_llama.py:72-101): logits[-n:-1] vs labels[1:]
+            acc = torch.zeros(1, device=self.device, dtype=torch.float32)
+            for b, lab in enumerate(labels):
+                lab = lab.reshape(-1).to(self.device)
+                n = int(lab.shape[0])
+                rows = logits_packed[cu[b + 1] - n: cu[b + 1] - 1]
+                ops.ce_loss(rows, lab[1:].to(torch.int32).contiguous(), 1.0 / ((n - 1) * B), acc, None, dtype=self.dtype)
+            loss = acc[0]
         return SimpleNamespace(loss=loss, logits=logits, hidden_states=hidden_states, past_key_values=None, attentions=None)
 
     __call__ = forward

@@ -1,0 +1,188 @@
+"""Trainer: host-side mirror of ref:trainer.py:23-545 around the HIP KD step, lifted to data parallel.
+
+Kept from the reference: constructor `Trainer(args, config, device)` (args: run_name, checkpoint_path, gpu_idx),
+`train()`, `validate(epoch)`, `load_checkpoint(path)`, the two collate functions, the dataset schema
+(`audio{array}`, `text`, `text_input_ids`, `response_input_ids` (nested [0]), `pool_ranges_4`; ref:trainer.py:134-199),
+the checkpoint format `{"audio_encoder","optimizer","lr_scheduler","epoch","step"}` under
+`checkpoints/<run>/epoch_{e}_step_{s}.pt` (ref:trainer.py:516-528) and the hyper-parameters read from the yaml.
+New: one process per GPU; rank r takes every world-th sample of a seeded per-epoch shuffle and
+`grad_accum_interval / world` micro-steps per optimizer step, processed as one packed micro-batch
+(`KDTrainer.micro_batch`); rank 0 alone logs (JSON lines instead of TensorBoard), validates and writes checkpoints.
+Datasets may be passed in as python sequences (tests, synthetic runs) instead of `datasets.load_from_disk` paths.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import random
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from .audio_encoder import AudioEncoder
+from .audio_llama import AudioLlamaForCausalLM
+from .training import KDTrainer
+from .utils import compute_num_audio_embeds, merge_prompt_tokens, prompt_template
+
+
+class Trainer():
+    def __init__(self, args, config, device, *, tokenizer=None, llm: Optional[AudioLlamaForCausalLM] = None,
+                 audio_encoder: Optional[AudioEncoder] = None, train_dataset: Optional[Sequence[dict]] = None,
+                 val_dataset: Optional[Sequence[dict]] = None, dtype: torch.dtype = torch.bfloat16) -> None:
+        self.args, self.config = args, config
+        self.run_name = args.run_name
+        self.device = torch.device(device)
+        import torch.distributed as dist
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        seed = int(config.seed_everything) + self.rank      # the reference seeds only the CUDA RNG
+        torch.manual_seed(seed); random.seed(seed)
+        self.checkpoint_save_dir = os.path.join(config.log.checkpoint_dir, self.run_name)
+        self.log_dir = os.path.join(config.log.log_dir, self.run_name)
+        if self.rank == 0:
+            os.makedirs(self.checkpoint_save_dir, exist_ok=True)
+            os.makedirs(self.log_dir, exist_ok=True)
+        self.encoder_base = config.model.audio_encoder.base
+        self.audio_encoder = audio_encoder or AudioEncoder(config, self.device, dtype=dtype)
+        self.llm_type = config.model.llm_type
+        if tokenizer is None:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(self.llm_type, use_fast=False, padding_side="left")
+            tokenizer.pad_token = tokenizer.eos_token
+        self.tokenizer = tokenizer
+        self.llm = (llm or AudioLlamaForCausalLM.from_pretrained(self.llm_type, use_cache=True, torch_dtype=dtype)).eval().to(self.device)
+        self.train_dataset, self.val_dataset = train_dataset, val_dataset
+        if self.train_dataset is None:
+            self.get_dataloaders()
+        self.step, self.start_epoch = 0, 0
+        self.grad_accum_interval = int(config.train.grad_accum_interval)
+        self.num_epochs = int(config.train.epochs)
+        prefix, suffix = prompt_template(self.llm_type)
+        self.prefix_ids = self.tokenizer(prefix, return_tensors="pt").input_ids
+        self.suffix_ids = self.tokenizer(suffix, return_tensors="pt").input_ids
+        total_iters = self.num_epochs * len(self.train_dataset) // self.grad_accum_interval     # ref:trainer.py:106-110 (global steps)
+        self.kd = KDTrainer(config, self.audio_encoder.to(self.device), self.llm, self.prefix_ids, self.suffix_ids,
+                            total_optimizer_steps=max(1, total_iters))
+        self.optimizer, self.lr_scheduler = self.kd.optimizer, self.kd.scheduler
+        if getattr(self.args, "checkpoint_path", None):
+            self.load_checkpoint(self.args.checkpoint_path)
+
+    # -- checkpoints (ref:trainer.py:116-132, 516-528) ---------------------------------------------
+    def load_checkpoint(self, checkpoint_path):
+        ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        for k, v in ck["audio_encoder"].items():
+            self.kd.master[k].copy_(v.to(self.kd.master[k].device, torch.float32))
+        self.audio_encoder.load_state_dict({k: v.detach() for k, v in self.kd.master.items()})
+        self.optimizer.load_state_dict(ck["optimizer"])
+        self.lr_scheduler.load_state_dict(ck["lr_scheduler"])
+        self.start_epoch, self.step = ck["epoch"], ck["step"]
+        if self.rank == 0:
+            print(f"Loaded checkpoint from {checkpoint_path}.\n")
+
+    def save_checkpoint(self, epoch) -> str:
+        save_path = os.path.join(self.checkpoint_save_dir, f"epoch_{epoch}_step_{self.step}.pt")
+        torch.save({"audio_encoder": {k: v.detach().cpu() for k, v in self.kd.master.items()},
+                    "optimizer": self.optimizer.state_dict(), "lr_scheduler": self.lr_scheduler.state_dict(),
+                    "epoch": epoch, "step": self.step}, save_path)
+        return save_path
+
+    # -- data (ref:trainer.py:134-248) --------------------------------------------------------------
+    def collate_audio_batch_hubert(self, data):
+        raw_audios = [torch.as_tensor(x['audio']['array']) for x in data]
+        audio_len_samples = [len(a) for a in raw_audios]
+        max_len = max(audio_len_samples)
+        padded = torch.stack([torch.nn.functional.pad(a, (0, max_len - len(a))) for a in raw_audios], dim=0).float()
+        text_input_ids = [torch.as_tensor(x['text_input_ids'])[1:] for x in data]               # strip BOS (ref:trainer.py:155)
+        response_input_ids = [torch.as_tensor(x['response_input_ids'][0])[1:] for x in data]    # nested [0] + strip BOS (:156)
+        return (raw_audios, padded, audio_len_samples, [x['text'] for x in data], text_input_ids, response_input_ids,
+                [x.get('pool_ranges_4') for x in data])
+
+    def collate_audio_batch_whisper(self, data):
+        raw_audios = [torch.as_tensor(x['audio']['array']).numpy() for x in data]
+        feats = self.audio_encoder.feature_extractor(raw_audios, return_tensors="pt", sampling_rate=self.config.audio.sampling_rate).input_features
+        text_input_ids = [torch.as_tensor(x['text_input_ids'])[1:] for x in data]
+        response_input_ids = [torch.as_tensor(x['response_input_ids'][0])[1:] for x in data]
+        return (raw_audios, feats, [len(a) for a in raw_audios], [x['text'] for x in data], text_input_ids, response_input_ids,
+                [x.get('pool_ranges_4') for x in data])
+
+    def get_dataloaders(self):
+        from datasets import concatenate_datasets, load_from_disk
+
+        def load(names):
+            parts = []
+            for name in names:
+                ds = load_from_disk(os.path.join(self.config.data.base_path, name))
+                ds.set_format(type='torch')
+                parts.append(ds)
+            return concatenate_datasets(parts)
+
+        self.train_dataset, self.val_dataset = load(self.config.data.train_set), load(self.config.data.val_set)
+
+    def _epoch_indices(self, epoch: int) -> List[int]:
+        """Seeded shuffle shared by all ranks, truncated to a whole number of optimizer steps, every world-th index here."""
+        g = torch.Generator().manual_seed(int(self.config.seed_everything) + epoch)
+        perm = torch.randperm(len(self.train_dataset), generator=g).tolist()
+        usable = len(perm) - len(perm) % self.grad_accum_interval
+        return perm[:usable][self.rank::self.world]
+
+    # -- training loop (ref:trainer.py:250-398) ------------------------------------------------------
+    def log(self, **kv):
+        if self.rank == 0:
+            line = json.dumps(kv)
+            print(line, flush=True)
+            with open(os.path.join(self.log_dir, "metrics.jsonl"), "a") as f:
+                f.write(line + "\n")
+
+    def train(self):
+        if self.encoder_base != "hubert":
+            raise L.SpeechLLMError("the KD training tape is built for the HuBERT encoder; the Whisper path is inference-only so far")
+        local = self.kd.local_accum
+        for epoch in range(self.start_epoch, self.start_epoch + self.num_epochs):       # resume quirk kept
+            idx = self._epoch_indices(epoch)
+            for w0 in range(0, len(idx), local):
+                batch = [self.train_dataset[i] for i in idx[w0:w0 + local]]
+                raw, _, _, _, text_ids, resp_ids, _ = self.collate_audio_batch_hubert(batch)
+                losses = self.kd.micro_batch(raw, text_ids, resp_ids)
+                self.step += len(batch) * self.world                                     # global micro-steps, like the reference's counter
+                if (self.step // self.grad_accum_interval) % max(1, self.config.log.log_interval // self.grad_accum_interval or 1) == 0:
+                    mean = {k: sum(l[k] for l in losses) / len(losses) for k in losses[0]}
+                    self.log(step=self.step, epoch=epoch, lr=self.lr_scheduler.get_last_lr()[0], **{f"train/{k}": v for k, v in mean.items()})
+                if self.step % self.config.log.validation_interval == 0:
+                    self.validate(epoch)
+            self.validate(epoch)
+
+    # -- validation (ref:trainer.py:400-528) ---------------------------------------------------------
+    @torch.no_grad()
+    def validate(self, epoch):
+        if self.rank != 0:
+            return None
+        emb = self.llm.model.embed_tokens
+        audio_nlls, text_nlls, samples = [], [], []
+        for sample_idx in range(len(self.val_dataset)):
+            raw, _, _, texts, text_ids, resp_ids, _ = self.collate_audio_batch_hubert([self.val_dataset[sample_idx]])
+            audio_embeds = self.audio_encoder(raw[0][None].to(self.device))
+            resp = resp_ids[0].to(self.device)
+            pre, suf = emb(self.prefix_ids.to(self.device)), emb(self.suffix_ids.to(self.device))[:, 1:]
+            r = emb(resp[None])[:, 1:]
+            a_seq = torch.cat([pre, audio_embeds, suf, r], dim=1)
+            t_seq = torch.cat([pre, emb(text_ids[0].to(self.device)[None]), suf, r], dim=1)
+            audio_nlls.append(float(self.llm(inputs_embeds=a_seq, labels=[resp]).loss))
+            text_nlls.append(float(self.llm(inputs_embeds=t_seq, labels=[resp]).loss))
+            if sample_idx < self.config.log.num_generate_samples:
+                a_prompt = merge_prompt_tokens(audio_embeds, self.tokenizer, emb, self.llm_type, self.device)
+                t_prompt = merge_prompt_tokens(emb(text_ids[0].to(self.device)[None]), self.tokenizer, emb, self.llm_type, self.device)
+                n_in = audio_embeds.shape[1]                                                # same budget for both prompts
+                samples.append(dict(text=texts[0], audio_response=self.generate_llm_response(a_prompt, n_in)[0],
+                                    text_response=self.generate_llm_response(t_prompt, n_in)[0]))
+        out = dict(step=self.step, epoch=epoch, **{"validation/audio_perplexity": math.exp(sum(audio_nlls) / max(1, len(audio_nlls))),
+                                                   "validation/text_perplexity": math.exp(sum(text_nlls) / max(1, len(text_nlls)))})
+        self.log(**out, samples=samples[:2])
+        path = self.save_checkpoint(epoch)
+        print(f"Saved checkpoint for epoch {epoch} to {path}.\n")
+        return out
+
+    def generate_llm_response(self, inputs_embeds, len_inputs=60):
+        generate_ids = self.llm.generate(input_ids=None, inputs_embeds=inputs_embeds, max_new_tokens=2 * len_inputs)
+        return self.tokenizer.batch_decode(generate_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)
