@@ -342,7 +342,7 @@ struct SkinnyX {
   float eps;
 };
 
-template <typename T, int MT, int ACT, int RF, int NW, int U, bool PACKED>
+template <typename T, int MT, int ACT, int RF, int NW, int U, bool PACKED, bool KCONT = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX sx) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int KSTEP = MMA<T>::KSTEP;
@@ -403,12 +403,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX s
     for (int j = 0; j < VEC; ++j) s = fmaf(e[j], e[j], s);
   };
 
-  int ks = wave;
-  for (; ks + (U - 1) * NW < nks_full; ks += U * NW) {
+  // K split over the block's waves: interleaved 64-byte steps (w, w+NW, ...) or one contiguous slice per wave
+  int ks, kend;
+  constexpr int KSTR = KCONT ? 1 : NW;
+  if constexpr (KCONT) {
+    const int per = (nks_full + NW - 1) / NW;
+    ks = wave * per;
+    kend = (ks + per) < nks_full ? (ks + per) : nks_full;
+  } else {
+    ks = wave;
+    kend = nks_full;
+  }
+  for (; ks + (U - 1) * KSTR < kend; ks += U * KSTR) {
     uint4 fw[U][RF], fx[U][MT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t kk = ks + u * NW;
+      const int64_t kk = ks + u * KSTR;
 #pragma unroll
       for (int f = 0; f < RF; ++f) fw[u][f] = ld_nt16(wp[f] + kk * wstep);
 #pragma unroll
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX s
       }
     }
   }
-  for (; ks < nks_full; ks += NW) {
+  for (; ks < kend; ks += KSTR) {
     uint4 fw[RF], fx[MT];
 #pragma unroll
     for (int f = 0; f < RF; ++f) fw[f] = ld_nt16(wp[f] + (int64_t)ks * wstep);
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX s
   }
   if constexpr (!PACKED) {
     // K tail (K % KSTEP != 0): one predicated step, taken by the wave whose turn it is
-    if (nks_full * KSTEP < p.K && (nks_full % NW) == wave) {
+    if (nks_full * KSTEP < p.K && wave == (KCONT ? NW - 1 : nks_full % NW)) {
       const int64_t k = (int64_t)nks_full * KSTEP;
       const bool ok = (k + q * VEC) < p.K;
       uint4 fw[RF], fx[MT];
@@ -556,25 +566,38 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int MT, int ACT, int RF, int NW, int U, bool PACKED>
+template <typename T, int MT, int ACT, int RF, int NW, int U, bool PACKED, bool KCONT = false>
 static int launch_skinny_cfg(GemmP& p, const SkinnyX& sx, int batch, hipStream_t st) {
   dim3 grid((p.N + 16 * RF - 1) / (16 * RF), batch);
-  hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, ACT, RF, NW, U, PACKED>), grid, dim3(NW * 64), 0, st, p, sx);
+  hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, ACT, RF, NW, U, PACKED, KCONT>), grid, dim3(NW * 64), 0, st, p, sx);
   SL_CHECK_LAUNCH("gemm_skinny");
   return 0;
 }
 
-// Structure per shape, from the sweep in tools/tune_skinny.hip (MI355X, bf16, M = 16):
-//   many fragments (gate/up, lm_head): 4 fragments x 4 waves  — x fragment reused 4x from registers
-//   mid (qkv, N = 5120):                2 fragments x 8 waves
-//   few (N = hidden: o, down):          1-2 fragments x 16 waves — K spread wide so 192 blocks still fill HBM
+// Structure per shape, from the sweeps in tools/tune_skinny.hip (MI355X, bf16, packed weights):
+//   M <= 16:  gate/up, lm_head (>= 1024 fragments): 4 fragments x 4 waves x 4 steps in flight   (5.3 / 6.2 TB/s)
+//             qkv (320 fragments):                   2 fragments x 8 waves x 4 steps            (2.9 TB/s)
+//             N = hidden (o, down; 192 fragments):   1 fragment x 16 waves x 2 steps            (2.7 / 3.3 TB/s)
+//             (2 x 16 x 4 and contiguous K slices looked 5-12 % better in the bare sweep but were slower inside the
+//              real kernel with its fused-norm / pair epilogues: decode step 2.19 vs 1.98 ms)
+//   M 17..64: activations are re-read per fragment from L2, so fewer fragments per wave and wide K splits win.
 template <typename T, int MT, int ACT, bool PACKED>
 static int launch_skinny_mt(GemmP& p, const SkinnyX& sx, int batch, hipStream_t st) {
   constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
-  const int nfrag = (p.N + 15) / 16;
-  if (nfrag * batch >= 1024 && MT <= 2) return launch_skinny_cfg<T, MT, ACT, 4, 4, 4, PACKED>(p, sx, batch, st);
-  if (nfrag * batch >= 256 || PAIRS) return launch_skinny_cfg<T, MT, ACT, 2, 8, (MT <= 2 ? 4 : 2), PACKED>(p, sx, batch, st);
-  if constexpr (!PAIRS) return launch_skinny_cfg<T, MT, ACT, 1, 16, 2, PACKED>(p, sx, batch, st);
+  const int nfrag = (p.N + 15) / 16 * batch;
+  if constexpr (MT == 1) {
+    if (nfrag >= 1024) return launch_skinny_cfg<T, MT, ACT, 4, 4, 4, PACKED>(p, sx, batch, st);
+    if (nfrag >= 256 || PAIRS) return launch_skinny_cfg<T, MT, ACT, 2, 8, 4, PACKED>(p, sx, batch, st);
+    if constexpr (!PAIRS) return launch_skinny_cfg<T, MT, ACT, 1, 16, 2, PACKED>(p, sx, batch, st);
+  } else if constexpr (MT == 2) {
+    if (nfrag >= 1024) return launch_skinny_cfg<T, MT, ACT, 2, 8, 4, PACKED>(p, sx, batch, st);
+    if (nfrag >= 256 || PAIRS) return launch_skinny_cfg<T, MT, ACT, 2, 16, 2, PACKED>(p, sx, batch, st);
+    if constexpr (!PAIRS) return launch_skinny_cfg<T, MT, ACT, 1, 16, 2, PACKED>(p, sx, batch, st);
+  } else {
+    if (nfrag >= 1024) return launch_skinny_cfg<T, MT, ACT, 4, 8, 2, PACKED>(p, sx, batch, st);
+    if (nfrag >= 256 || PAIRS) return launch_skinny_cfg<T, MT, ACT, 2, 16, 2, PACKED>(p, sx, batch, st);
+    if constexpr (!PAIRS) return launch_skinny_cfg<T, MT, ACT, 1, 16, 2, PACKED>(p, sx, batch, st);
+  }
   return 0;
 }
 

@@ -402,6 +402,16 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
 #pragma unroll
     for (int c = 0; c < CPLN; ++c) kraw[ps][c] = *(const uint4*)(kbase + (int64_t)key * D + gl * EPL + c * VEC);
   }
+  // V rows for phase 3 are requested now: their HBM latency hides behind the score / softmax phases
+  const int kg = tid >> 4, dc = tid & 15;
+  uint4 vraw[4][CPLN];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    int key = kg + 16 * ps;
+    key = key < nk ? key : nk - 1;
+#pragma unroll
+    for (int c = 0; c < CPLN; ++c) vraw[ps][c] = *(const uint4*)(vbase + (int64_t)key * D + dc * EPL + c * VEC);
+  }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int key = ps * 16 + wave * 4 + grp;
@@ -430,15 +440,6 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   __syncthreads();
   // phase 3: partial P.V
   {
-    const int kg = tid >> 4, dc = tid & 15;
-    uint4 vraw[4][CPLN];
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      int key = kg + 16 * ps;
-      key = key < nk ? key : nk - 1;
-#pragma unroll
-      for (int c = 0; c < CPLN; ++c) vraw[ps][c] = *(const uint4*)(vbase + (int64_t)key * D + dc * EPL + c * VEC);
-    }
     float acc[REP][EPL];
 #pragma unroll
     for (int h = 0; h < REP; ++h)

@@ -14,9 +14,9 @@ __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) 
 }
 // KMODE 0: wave w takes k-steps w, w+NW, ... ; 1: contiguous slice.  NT: nontemporal weight loads.
 // PACKED: W stored fragment-major [N/16][K/32][64 lanes][8] so one wave load = 1 KiB contiguous.
-template <int RF, int NW, int U, int KMODE, int NT, int PACKED>
+template <int RF, int NW, int U, int KMODE, int NT, int PACKED, int MT = 1>
 __global__ __launch_bounds__(NW * 64) void k(const uint16_t* __restrict__ W, const uint16_t* __restrict__ X, uint16_t* __restrict__ C, int M, int N, int K) {
-  __shared__ float red[NW][RF * 16][17];
+  __shared__ float red[NW][RF * 16][MT * 16 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * RF * 16;
   const int nks = K / 32;
@@ -26,36 +26,49 @@ __global__ __launch_bounds__(NW * 64) void k(const uint16_t* __restrict__ W, con
     if (PACKED) wp[f] = W + ((size_t)(n0 / 16 + f) * nks) * 512 + lane * 8;
     else wp[f] = W + (size_t)(n0 + f * 16 + r) * K + q * 8;
   }
-  int xr = r < M ? r : M - 1;
-  const uint16_t* xp = X + (size_t)xr * K + q * 8;
-  f32x4 acc[RF];
+  const uint16_t* xp[MT];
 #pragma unroll
-  for (int f = 0; f < RF; ++f) acc[f] = f32x4{0, 0, 0, 0};
+  for (int t = 0; t < MT; ++t) { int xr = t * 16 + r; xr = xr < M ? xr : M - 1; xp[t] = X + (size_t)xr * K + q * 8; }
+  f32x4 acc[RF][MT];
+#pragma unroll
+  for (int f = 0; f < RF; ++f)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[f][t] = f32x4{0, 0, 0, 0};
   int ks, kend, kstride;
   if (KMODE == 0) { ks = wave; kend = nks; kstride = NW; }
   else { const int per = (nks + NW - 1) / NW; ks = wave * per; kend = ks + per < nks ? ks + per : nks; kstride = 1; }
   for (; ks + (U - 1) * kstride < kend; ks += U * kstride) {
-    uint4 fw[U][RF], fx[U];
+    uint4 fw[U][RF], fx[U][MT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t kk = (size_t)(ks + u * kstride);
 #pragma unroll
       for (int f = 0; f < RF; ++f) { const uint16_t* a = PACKED ? wp[f] + kk * 512 : wp[f] + kk * 32; fw[u][f] = NT ? ld_nt16(a) : ld16(a); }
-      fx[u] = ld16(xp + kk * 32);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fx[u][t] = ld16(xp[t] + kk * 32);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int f = 0; f < RF; ++f) mma(acc[f], fw[u][f], fx[u]);
+      for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) mma(acc[f][t], fw[u][f], fx[u][t]);
   }
   for (; ks < kend; ks += kstride) {
 #pragma unroll
-    for (int f = 0; f < RF; ++f) { const uint16_t* a = PACKED ? wp[f] + (size_t)ks * 512 : wp[f] + (size_t)ks * 32; mma(acc[f], NT ? ld_nt16(a) : ld16(a), ld16(xp + (size_t)ks * 32)); }
+    for (int f = 0; f < RF; ++f) {
+      const uint16_t* a = PACKED ? wp[f] + (size_t)ks * 512 : wp[f] + (size_t)ks * 32;
+      const uint4 wv = NT ? ld_nt16(a) : ld16(a);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) mma(acc[f][t], wv, ld16(xp[t] + (size_t)ks * 32));
+    }
   }
 #pragma unroll
   for (int f = 0; f < RF; ++f)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave][f * 16 + q * 4 + i][r] = acc[f][i];
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wave][f * 16 + q * 4 + i][t * 16 + r] = acc[f][t][i];
   __syncthreads();
   for (int o = tid; o < RF * 16 * M; o += NW * 64) {
     const int m = o / (RF * 16), n = o % (RF * 16);
@@ -73,15 +86,15 @@ __global__ __launch_bounds__(256) void stream_read(const uint4* __restrict__ p, 
   if (acc.x == 0x12345678u) out[0] = acc;
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-template <int RF, int NW, int U, int KMODE, int NT, int PACKED>
+template <int RF, int NW, int U, int KMODE, int NT, int PACKED, int MT = 1>
 static void run(const char* name, const std::vector<uint16_t*>& Ws, uint16_t* X, uint16_t* C, int M, int N, int K) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 5, L = (int)Ws.size();
   dim3 grid(N / (RF * 16));
-  for (int i = 0; i < L; ++i) hipLaunchKernelGGL((k<RF, NW, U, KMODE, NT, PACKED>), grid, dim3(NW * 64), 0, 0, Ws[i], X, C, M, N, K);
+  for (int i = 0; i < L; ++i) hipLaunchKernelGGL((k<RF, NW, U, KMODE, NT, PACKED, MT>), grid, dim3(NW * 64), 0, 0, Ws[i], X, C, M, N, K);
   CK(hipEventRecord(e0, 0));
   for (int rp = 0; rp < reps; ++rp)
-    for (int i = 0; i < L; ++i) hipLaunchKernelGGL((k<RF, NW, U, KMODE, NT, PACKED>), grid, dim3(NW * 64), 0, 0, Ws[i], X, C, M, N, K);
+    for (int i = 0; i < L; ++i) hipLaunchKernelGGL((k<RF, NW, U, KMODE, NT, PACKED, MT>), grid, dim3(NW * 64), 0, 0, Ws[i], X, C, M, N, K);
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / (reps * L), gbs = (double)N * K * 2 / (us * 1e-6) / 1e9;
@@ -104,23 +117,21 @@ int main() {
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       printf("  %-34s %51.2f us  %7.1f GB/s\n", "plain nt stream read (2048 blocks)", ms * 1e3 / (5 * L), bytes / (ms * 1e-3 / (5 * L)) / 1e9);
     }
-    for (int M : {1, 16}) {
-      run<1, 8, 4, 0, 1, 0>("rf1 nw8 u4 interleaved nt", Ws, X, C, M, s.N, s.K);
-      run<1, 8, 4, 1, 1, 0>("rf1 nw8 u4 contiguous nt", Ws, X, C, M, s.N, s.K);
-      run<1, 8, 4, 0, 0, 0>("rf1 nw8 u4 interleaved plain", Ws, X, C, M, s.N, s.K);
-      run<1, 4, 8, 0, 1, 0>("rf1 nw4 u8 interleaved nt", Ws, X, C, M, s.N, s.K);
-      run<1, 4, 8, 1, 1, 0>("rf1 nw4 u8 contiguous nt", Ws, X, C, M, s.N, s.K);
-      run<2, 8, 4, 0, 1, 0>("rf2 nw8 u4 interleaved nt", Ws, X, C, M, s.N, s.K);
-      run<2, 4, 4, 0, 1, 0>("rf2 nw4 u4 interleaved nt", Ws, X, C, M, s.N, s.K);
-      run<2, 4, 8, 1, 1, 0>("rf2 nw4 u8 contiguous nt", Ws, X, C, M, s.N, s.K);
-      run<4, 4, 4, 0, 1, 0>("rf4 nw4 u4 interleaved nt", Ws, X, C, M, s.N, s.K);
-      run<4, 8, 2, 0, 1, 0>("rf4 nw8 u2 interleaved nt", Ws, X, C, M, s.N, s.K);
-      run<1, 8, 4, 0, 1, 1>("rf1 nw8 u4 PACKED nt", Ws, X, C, M, s.N, s.K);
-      run<2, 8, 4, 0, 1, 1>("rf2 nw8 u4 PACKED nt", Ws, X, C, M, s.N, s.K);
-      run<2, 4, 8, 0, 1, 1>("rf2 nw4 u8 PACKED nt", Ws, X, C, M, s.N, s.K);
-      run<4, 4, 4, 0, 1, 1>("rf4 nw4 u4 PACKED nt", Ws, X, C, M, s.N, s.K);
-      run<1, 16, 2, 0, 1, 1>("rf1 nw16 u2 PACKED nt", Ws, X, C, M, s.N, s.K);
-      run<1, 16, 2, 0, 1, 0>("rf1 nw16 u2 interleaved nt", Ws, X, C, M, s.N, s.K);
+    for (int M : {32}) {
+      run<1, 16, 2, 0, 1, 1, 2>("M32 rf1 nw16 u2", Ws, X, C, M, s.N, s.K);
+      run<2, 16, 2, 0, 1, 1, 2>("M32 rf2 nw16 u2", Ws, X, C, M, s.N, s.K);
+      run<2, 8, 4, 0, 1, 1, 2>("M32 rf2 nw8 u4 (current)", Ws, X, C, M, s.N, s.K);
+      run<4, 8, 2, 0, 1, 1, 2>("M32 rf4 nw8 u2", Ws, X, C, M, s.N, s.K);
+      run<4, 4, 4, 0, 1, 1, 2>("M32 rf4 nw4 u4 (current big)", Ws, X, C, M, s.N, s.K);
+      run<8, 4, 2, 0, 1, 1, 2>("M32 rf8 nw4 u2", Ws, X, C, M, s.N, s.K);
+      run<8, 8, 2, 0, 1, 1, 2>("M32 rf8 nw8 u2", Ws, X, C, M, s.N, s.K);
+    }
+    for (int M : {64}) {
+      run<1, 16, 2, 0, 1, 1, 4>("M64 rf1 nw16 u2", Ws, X, C, M, s.N, s.K);
+      run<2, 16, 2, 0, 1, 1, 4>("M64 rf2 nw16 u2", Ws, X, C, M, s.N, s.K);
+      run<2, 8, 2, 0, 1, 1, 4>("M64 rf2 nw8 u2 (current)", Ws, X, C, M, s.N, s.K);
+      run<4, 8, 2, 0, 1, 1, 4>("M64 rf4 nw8 u2", Ws, X, C, M, s.N, s.K);
+      run<8, 4, 1, 0, 1, 1, 4>("M64 rf8 nw4 u1", Ws, X, C, M, s.N, s.K);
     }
     for (auto w : Ws) CK(hipFree(w));
     CK(hipFree(X)); CK(hipFree(C));
