@@ -141,6 +141,53 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
             "note": "one packed micro-batch per accumulation window per rank; dropout/layerdrop/spec-augment off; python-driven op tape"}
 
 
+DEVCLEAN_MIX_SEC = (2, 4, 6, 8, 10, 12, 15, 20, 25, 32)  # dev-clean is ~1.3-33 s, mean ~7 s; cycled
+
+
+def mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx):
+    """Ragged batch (the dev-clean length mix of SURVEY.md §8d) through the same encode -> prefill -> decode path:
+    every utterance is encoded/prefilled at its own length (no padding frames)."""
+    B, new = args.batch, args.max_new_tokens
+    llm.max_ctx, llm._kv = mix_ctx, None       # re-size the KV cache for the longest utterance
+    secs = [DEVCLEAN_MIX_SEC[i % len(DEVCLEAN_MIX_SEC)] for i in range(B)]
+    waves = [ri.synthetic_waveform(s * 16000, seed=4321 + rank * 1000 + i).to(dev) for i, s in enumerate(secs)]
+    emb = llm.model.embed_tokens
+    pre_e, suf_e = emb(prefix.to(dev))[0], emb(suffix.to(dev))[0, 1:]
+    n_pre, n_suf = pre_e.shape[0], suf_e.shape[0]
+    Ps = [(harch.num_frames(s * 16000) - 8) // 4 + 1 for s in secs]
+    lens = [n_pre + p + n_suf for p in Ps]
+    starts = [0]
+    for n in lens:
+        starts.append(starts[-1] + n)
+    x = torch.empty((starts[-1], larch.hidden_size), device=dev, dtype=torch.bfloat16)
+    audio_rows = [starts[b] + n_pre for b in range(B)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    enc_ms = []
+
+    def step():
+        for b in range(B):
+            x[starts[b]:starts[b] + n_pre] = pre_e
+            x[starts[b] + n_pre + Ps[b]:starts[b + 1]] = suf_e
+        ev[0].record()
+        enc.encode_packed(waves, out=x, out_row_offsets=audio_rows)
+        ev[1].record()
+        return llm.generate_packed(x, lens, new, use_eos=False)
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, n_cols = step()
+        torch.cuda.synchronize()
+        enc_ms.append(ev[0].elapsed_time(ev[1]))
+    el = time.perf_counter() - t0
+    assert n_cols == new
+    return {"utterance_sec": secs, "audio_sec_total": sum(secs), "prompt_tokens_total": starts[-1],
+            "tokens_per_s": round(B * new * args.steps / el, 1),
+            "audio_sec_per_s": round(sum(secs) / (sum(enc_ms) / len(enc_ms) * 1e-3), 1),
+            "ms_per_step": round(el / args.steps * 1e3, 2), "note": "per-rank figures (rank 0)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +199,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=8)
     ap.add_argument("--kd-optimizer-steps", type=int, default=1, help="optimizer steps of the KD training leg (0 = skip)")
+    ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,11 +232,14 @@ def main():
     T = harch.num_frames(n_samples)
     P = (T - 8) // 4 + 1
     S = prefix.shape[1] + P + suffix.shape[1] - 1
+    S_mix = prefix.shape[1] + (harch.num_frames(max(DEVCLEAN_MIX_SEC) * 16000) - 8) // 4 + 1 + suffix.shape[1] - 1
     max_ctx = ((S + new + 63) // 64) * 64
+    mix_ctx = max_ctx if args.no_length_mix else ((max(S, S_mix) + new + 63) // 64) * 64
     keep_sd = dict(llm_sd) if (rank == 0 and not args.no_cpu_baseline) else None
-    llm = llama_mod.AudioLlamaForCausalLM(larch, llm_sd, torch_dtype=torch.bfloat16, device=dev, max_ctx=max_ctx, max_batch=B)
+    llm = llama_mod.AudioLlamaForCausalLM(larch, llm_sd, torch_dtype=torch.bfloat16, device=dev, max_ctx=mix_ctx, max_batch=B)
     del llm_sd
-    wts = llm._dev()
+    wts = llm._dev()          # rope tables / split-attention workspace sized for mix_ctx
+    llm.max_ctx = max_ctx     # the headline's KV cache (and split-attention grid) is sized for its own context
 
     # ---- synthetic inputs, resident in HBM -------------------------------------------------------------
     waves = [ri.synthetic_waveform(n_samples, seed=1234 + rank * 1000 + i).to(dev) for i in range(B)]
@@ -305,6 +356,11 @@ def main():
     }
     if kd is not None:
         result["kd_step"] = kd
+    if not args.no_length_mix:
+        try:
+            result["devclean_length_mix"] = mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx)
+        except Exception as e:
+            result["devclean_length_mix"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_cpu_baseline:
         del llm, wts
         result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)

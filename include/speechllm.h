@@ -77,7 +77,8 @@ int sl_gemm(const sl_gemm_args* a, sl_stream stream);
  *   dst holds ceil(N/16)*16*K elements.  Pass it to sl_gemm with w_layout = SL_W_PACKED. */
 int sl_pack_weight(const void* src, int64_t ld_src, void* dst, int32_t N, int32_t K, int32_t dtype, sl_stream stream);
 
-/* Decode-only fusions on top of sl_gemm (M <= 64, packed weights):
+/* Decode-only fusions on top of sl_gemm (packed weights; M <= 16 rows run the skinny kernel, more rows the
+ * LDS-staged streaming kernel of gemm_stream.hip):
  *   fuse_rms  — the consuming Linear absorbs the preceding LlamaRMSNorm (hf:...llama.py:62-67): the
  *               gain is pre-multiplied into W on the host and out[m] *= rsqrt(mean(x[m]^2) + rms_eps),
  *               with the mean taken from the activation fragments the kernel streams anyway;
@@ -92,7 +93,11 @@ typedef struct {
   const int32_t* tok_pos; const int32_t* tok_seq;
   void* k_cache; void* v_cache;
   int32_t n_heads, n_kv_heads, max_ctx, reserved;
+  /* optional scratch for K-split partial sums (M > 16 rows against few weight rows cannot fill 256 CUs
+   * otherwise): sl_gemm_split_workspace_bytes(M, N, K, dtype) bytes, or NULL to disable the split */
+  void* split_ws; size_t split_ws_bytes;
 } sl_gemm_fused;
+size_t sl_gemm_split_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype);
 int sl_gemm_fused_decode(const sl_gemm_args* a, const sl_gemm_fused* fx, sl_stream stream);
 
 /* Backward-pass forms of sl_gemm (training; always the tiled MFMA kernel):

@@ -10,62 +10,20 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_internal.h"
 
 static int g_disable_glds = 0;  // tuning switch (SL_DISABLE_GLDS=1): A/B the two staging paths in one process
 
-struct GemmP {
-  const void* A; int64_t lda, sA;
-  const void* W; int64_t ldw, sW;
-  void* C; int64_t ldc, sC;
-  const void* bias; int64_t sBias;
-  const void* res; int64_t ldr, sR;
-  int M, N, K, out_f32;
-  int tiles_m, tiles_n;
-  int ta, tw;          // operand stored transposed: A as (K, M) rows lda; W as (K, N) rows ldw
-  void* aux;           // optional: pre-activation values (after bias, before act), same layout/dtype as C
-  int res_f32;         // residual is float (fp32 gradient accumulation: C = C_old + A.W^T with out_f32)
-  const int64_t* grp;  // grouped (ragged) batch: per z {M, a_off, c_off, r_off} in elements; W/bias use z % w_mod
-  int w_mod;
-  int64_t cx, rx;      // per-block extra offsets resolved from grp
-};
-
-// resolve the per-batch descriptor: returns false when this block's tile lies outside batch z's rows
-__device__ __forceinline__ bool resolve_group(GemmP& p, int z, int bm, int64_t& a_off, int& wz) {
-  p.cx = 0; p.rx = 0;
-  wz = z;
-  a_off = (int64_t)z * p.sA;
-  if (p.grp) {
-    const int64_t* g = p.grp + 4 * (int64_t)z;
-    p.M = (int)g[0];
-    a_off = g[1];
-    p.cx = g[2] - (int64_t)z * p.sC;   // the epilogue adds z*sC back
-    p.rx = g[3] - (int64_t)z * p.sR;
-    wz = z % p.w_mod;
-    if (bm * 128 >= p.M) return false;
-  }
-  return true;
-}
-
-// ----------------------------------------------------------------------------------------------
-// epilogue helper: +bias, act, +residual, store (T or float)
-// ----------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void store_out(const GemmP& p, void* Cb, const void* Rb, int64_t row, int64_t col, float v) {
-  if (Rb) v += p.res_f32 ? ((const float*)Rb)[row * p.ldr + col] : to_f32(((const T*)Rb)[row * p.ldr + col]);
-  if (p.out_f32)
-    ((float*)Cb)[row * p.ldc + col] = v;
-  else
-    ((T*)Cb)[row * p.ldc + col] = from_f32<T>(v);
+// packed-weight GEMMs with more rows than this run the streaming kernel; SL_STREAM_MIN_M overrides (tuning)
+static int stream_min_m() {
+  const char* e = getenv("SL_STREAM_MIN_M");
+  if (e && e[0]) { const int v = atoi(e); if (v >= 16) return v; }
+  return 32;
 }
 
 // ----------------------------------------------------------------------------------------------
 // tiled kernel
 // ----------------------------------------------------------------------------------------------
-constexpr int TBM = 128, TBN = 128, TROWB = 128;  // tile rows, tile cols, bytes of K per LDS row
-
-// byte offset of 16-byte chunk `ch` (0..7) of tile row `row` in a [128][128 B] swizzled LDS tile
-__device__ __forceinline__ int lds_off(int row, int ch) { return row * TROWB + ((ch ^ (row & 7)) << 4); }
-
 // shared epilogue of the tiled kernels: +bias, [aux store], act, +residual, store
 template <typename T, int ACT>
 __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[4][4], int bm, int bn, int wm, int wn, int q, int r, int z, int wz) {
@@ -242,8 +200,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
 // staging VGPRs, no ds_write pass.  Used when K is a whole number of 128-byte slabs and no operand is
 // transposed (every forward GEMM of the encoder / prefill at model shapes).
 // ----------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <typename T, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
@@ -334,13 +290,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 //   fuse_rms: the RMSNorm gain is pre-folded into W and the per-row rsqrt(mean(x^2)+eps) is computed
 //   from the x fragments the block loads anyway, then applied to the accumulators.
 // ----------------------------------------------------------------------------------------------
-struct SkinnyX {
-  const float* cos; const float* sin;      // (rope_len, 64) tables
-  const int32_t* pos; const int32_t* seq;  // per activation row: position / cache slot
-  void* kc; void* vc;                      // this layer's caches (slots, n_kv, max_ctx, 128)
-  int nh, nkv, max_ctx, fuse_rms;
-  float eps;
-};
 
 template <typename T, int MT, int ACT, int RF, int NW, int U, bool PACKED, bool KCONT = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX sx) {
@@ -628,7 +577,7 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
   const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32 && !p.grp;  // backward features live in the tiled kernel
   const bool packed = a->w_layout == SL_W_PACKED;
   if (!skinny && (packed || a->act == SL_ACT_ROPE_KV || sx.fuse_rms)) {
-    sl_set_error("sl_gemm: packed weights / ROPE_KV / fused RMSNorm are decode (M <= 64) features, M=%d", a->M);
+    sl_set_error("sl_gemm: packed weights / ROPE_KV / fused RMSNorm need plain operands (no transposes / groups), M=%d", a->M);
     return SL_ERR_UNSUPPORTED;
   }
   switch (a->act) {
@@ -690,8 +639,18 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
                  "sl_gemm: ROPE_KV epilogue needs the sl_gemm_fused tables");
     SL_CHECK_ARG(a->N == (fx->n_heads + 2 * fx->n_kv_heads) * 128 && a->batch == 1, "sl_gemm: ROPE_KV expects N = (n_heads + 2 n_kv) * 128");
   }
+  // packed weights with more than g_stream_min_m rows: LDS-staged streaming kernel (gemm_stream.hip)
+  if (a->w_layout == SL_W_PACKED && a->M > stream_min_m() && a->batch == 1 && !ex && a->act != SL_ACT_GELU &&
+      a->K % (a->dtype == SL_F32 ? 32 : 64) == 0)
+    return sl_gemm_stream_launch(p, sx, a->dtype, a->act, fx ? fx->split_ws : nullptr, fx ? fx->split_ws_bytes : 0, st);
+  SL_CHECK_ARG(a->w_layout != SL_W_PACKED || a->M <= 64, "sl_gemm: packed weights with M=%d > 64 need batch 1 and K %% 64 == 0", a->M);
   if (a->dtype == SL_F32) return gemm_typed<float>(a, p, sx, st);
   return gemm_typed<bf16_t>(a, p, sx, st);
+}
+
+extern "C" size_t sl_gemm_split_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype) {
+  if (M <= stream_min_m() || M <= 0 || N <= 0 || K <= 0) return 0;
+  return sl_gemm_stream_ws_bytes(M, N, K, dtype);
 }
 
 extern "C" int sl_gemm(const sl_gemm_args* a, sl_stream stream) { return sl_gemm_impl(a, nullptr, nullptr, (hipStream_t)stream); }

@@ -1,0 +1,418 @@
+// gemm_stream.hip — C = epilogue(x . W^T) for mid-size row counts (large-batch decode: 16 < M <= a few hundred
+// activation rows against the fragment-packed decode weights).  Still HBM-bound (ridge is ~300 rows on MI355X),
+// but unlike the skinny kernel the activations no longer fit the "re-read them per fragment from L2" model:
+//   * block = NWV compute waves + 1 loader wave.  The compute waves walk the SAME k-range over different weight
+//     fragments (RF fragments = 16*RF weight rows each), so one x slab serves 16*RF*NWV weight rows.
+//   * the loader wave prefetches x slabs ([16*MT rows][128 B of K], XOR-swizzled as in the tiled kernel) two stages
+//     ahead into registers and writes them to a double-buffered LDS slab one stage ahead of the MFMAs.  (LDS-DMA
+//     was tried first: the compiler fences every barrier and LDS read after a global_load_lds with vmcnt(0), which
+//     drains the weight prefetch each stage; plain loads keep exact in-order vmcnt tracking.)
+//   * weight fragments go global -> VGPR -> MFMA (one contiguous 1 KiB per wave-load, packed layout), D stages
+//     ahead in a register ring; nothing of W ever touches LDS.
+//   * when the grid would not fill the CUs, K is split over `splits` blocks: those write fp32 partials and
+//     gemm_stream_reduce_kernel applies the epilogue.
+// Epilogues are the decode ones of gemm.hip: +bias/+residual, SILU_MUL (fragment pairs gate/up), ROPE_KV (q rotated,
+// k/v appended to the cache), and the fused RMSNorm row scale (sum of squares taken from the staged x slabs).
+#include <stdlib.h>
+
+#include "gemm_internal.h"
+
+struct StreamX {
+  float* part;     // [splits][M][np] fp32 partial sums
+  float* part_ss;  // [splits][M] partial sums of squares (fused RMSNorm)
+  int splits, sps; // K splits over blocks, 128-byte stages per split
+  int np;          // row stride of `part` in floats (fragments * 16)
+};
+
+// final values for 4 consecutive output columns n4..n4+3 of fragment gf (pairs: gf = first fragment), row m
+template <typename T, int ACT>
+__device__ __forceinline__ void stream_epilogue4(const GemmP& p, const SkinnyX& sx, int m, int gf, int n4, const float (&a)[4], const float (&b)[4]) {
+  const T* bias = (const T*)p.bias;
+  if constexpr (ACT == SL_ACT_SILU_MUL) {
+    const int ocol = (gf >> 1) * 16 + n4;
+    if (ocol >= (p.N >> 1)) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float g = a[i], u = b[i];
+      if (bias) { g += to_f32(bias[gf * 16 + n4 + i]); u += to_f32(bias[(gf + 1) * 16 + n4 + i]); }
+      store_out<T>(p, p.C, p.res, m, ocol + i, silu(g) * u);
+    }
+  } else if constexpr (ACT == SL_ACT_ROPE_KV) {
+    if (gf * 16 >= p.N) return;
+    const int hh = gf >> 3, j = (gf & 7) >> 1;   // a head is 8 fragments (D = 128); pair (2j, 2j+1) = dims d, d+64
+    const int pos = sx.pos[m];
+    if (hh < sx.nh + sx.nkv) {
+      T* dst = hh < sx.nh ? (T*)p.C + (int64_t)m * p.ldc + hh * 128
+                          : (T*)sx.kc + (((int64_t)sx.seq[m] * sx.nkv + (hh - sx.nh)) * sx.max_ctx + pos) * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = j * 16 + n4 + i;
+        const float c = sx.cos[(int64_t)pos * 64 + d], s = sx.sin[(int64_t)pos * 64 + d];
+        dst[d] = from_f32<T>(a[i] * c - b[i] * s);
+        dst[d + 64] = from_f32<T>(b[i] * c + a[i] * s);
+      }
+    } else {  // v rows are in natural order: fragments 2j, 2j+1 = dims d, d+16
+      T* dst = (T*)sx.vc + (((int64_t)sx.seq[m] * sx.nkv + (hh - sx.nh - sx.nkv)) * sx.max_ctx + pos) * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = (gf & 7) * 16 + n4 + i;
+        dst[d] = from_f32<T>(a[i]);
+        dst[d + 16] = from_f32<T>(b[i]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = gf * 16 + n4 + i;
+      if (col >= p.N) continue;
+      float v = a[i];
+      if (bias) v += to_f32(bias[col]);
+      if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
+      store_out<T>(p, p.C, p.res, m, col, v);
+    }
+  }
+}
+
+template <typename T, int MT, int ACT, int RF, int NWV, int D>
+__global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_kernel(GemmP p, SkinnyX sx, StreamX s) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int KSTEP = MMA<T>::KSTEP;
+  constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+  static_assert(!PAIRS || RF % 2 == 0, "pair epilogues need an even number of fragments");
+  static_assert(MT <= 16 && D % 2 == 0, "ring turns are unrolled; the x ring is 2 deep");
+  constexpr int NL = MT > 8 ? 2 : 1;          // loader waves: each stages up to 128 rows
+  constexpr int MTL = MT / NL;                // row tiles per loader
+  constexpr int SLAB = MT * 16 * TROWB;       // bytes of one x slab
+  constexpr int NXL = 2 * MTL;                // 16-byte x chunks per loader lane per stage
+  constexpr int DX = 2;                       // loader ring depth (x slabs are L2 hits)
+  constexpr int NSS = (MT + NWV - 1) / NWV;   // row tiles whose RMSNorm statistics a compute wave owns
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SLAB];
+  __shared__ float ssl[MT * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave;                        // compute waves 0..NWV-1; wave NWV stages x
+  const int r = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * (MT * 16);
+  const int sp = blockIdx.z;
+  const int nfrag = (p.N + 15) >> 4;
+  const int nks = p.K / KSTEP;                // 64-byte k-steps; a stage is two of them
+  const int fi0 = (blockIdx.x * NWV + wn) * RF;
+
+  const int g_lo = sp * s.sps;
+  const int g_hi = min(nks >> 1, g_lo + s.sps);
+  const int per = g_hi - g_lo;
+  const int n_it = (per + D - 1) / D * D;     // whole ring turns: the extra iterations re-read the last stage, no MFMAs
+  const int g_last = g_hi - 1;
+
+  f32x4 acc[RF][MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int f = 0; f < RF; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool fuse = sx.fuse_rms != 0;
+
+  if (wave >= NWV) {
+    // ---- x loader.  Its vmcnt queue holds only x loads: a wave that also streamed weights would, waiting for an
+    // x slab issued two stages ago, drain every older weight load with it (vmcnt completes in issue order), which caps
+    // the weight prefetch at ~3 stages whatever the ring depth (measured: D = 4, 6, 8 identical at 23 GB/s per CU).
+    const T* A = (const T*)p.A;
+    const int lw = wave - NWV;                        // loader index: rows [128 lw, 128 lw + 128) of the block
+    const int ch = (lane & 7) ^ ((lane >> 3) & 7);   // LDS chunk c = lane + 64 i: row (lane >> 3) + 8 i, logical chunk ch
+    int64_t xo[NXL];
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      int xr_ = m0 + lw * 128 + (lane >> 3) + 8 * i; xr_ = xr_ < p.M ? xr_ : p.M - 1;
+      xo[i] = (int64_t)xr_ * p.lda + ch * VEC;
+    }
+    unsigned char* lbase = smem + lw * (MTL * 16 * TROWB) + lane * 16;
+    u32x4_t xr[DX][NXL];   // ext-vector type: stays in SSA registers (HIP's uint4 struct copies went through scratch)
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+      int stg = g_lo + d; stg = stg < g_last ? stg : g_last;
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) xr[d][i] = *(const u32x4_t*)(A + xo[i] + (int64_t)stg * (2 * KSTEP));
+    }
+    {
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) *(u32x4_t*)(lbase + i * 1024) = xr[0][i];
+      int stg = g_lo + DX; stg = stg < g_last ? stg : g_last;
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) xr[0][i] = *(const u32x4_t*)(A + xo[i] + (int64_t)stg * (2 * KSTEP));
+    }
+    __syncthreads();
+    for (int it0 = 0; it0 < n_it; it0 += DX) {
+#pragma unroll
+      for (int d = 0; d < DX; ++d) {
+        const int it = it0 + d;
+        const int d1 = (d + 1) % DX;
+        unsigned char* dst = lbase + ((it + 1) & 1) * SLAB;   // the slot every wave finished reading one barrier ago
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) *(u32x4_t*)(dst + i * 1024) = xr[d1][i];
+        int stg = g_lo + it + 1 + DX; stg = stg < g_last ? stg : g_last;
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) xr[d1][i] = *(const u32x4_t*)(A + xo[i] + (int64_t)stg * (2 * KSTEP));
+        __syncthreads();
+      }
+    }
+  } else {
+    // ---- compute waves: weight fragments global -> VGPR ring (D stages = D * RF * 2 KiB per wave in flight) -> MFMA
+    const T* W = (const T*)p.W;
+    const T* wp[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+      int fi = fi0 + f; fi = fi < nfrag ? fi : nfrag - 1;
+      wp[f] = W + (int64_t)fi * nks * (64 * VEC) + lane * VEC;
+    }
+    f32x4 ssacc[NSS];
+#pragma unroll
+    for (int j = 0; j < NSS; ++j) ssacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 wr[D][2][RF];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      int stg = g_lo + d; stg = stg < g_last ? stg : g_last;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int f = 0; f < RF; ++f) wr[d][s2][f] = ld_nt16(wp[f] + (int64_t)(stg * 2 + s2) * (64 * VEC));
+    }
+    __syncthreads();
+    for (int it0 = 0; it0 < n_it; it0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int it = it0 + d;
+        if (g_lo + it < g_hi) {
+          const unsigned char* sl_ = smem + (it & 1) * SLAB;
+          // the MT activation fragments of a k-step are requested together, ahead of its MFMAs (left alone, the
+          // scheduler pairs each ds_read with its two MFMAs and exposes the LDS latency 2*MT times per stage)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 fx[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) fx[t] = *(const uint4*)(sl_ + lds_off(t * 16 + r, s2 * 4 + q));
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+              for (int f = 0; f < RF; ++f) MMA<T>::step(acc[f][t], wr[d][s2][f], fx[t]);
+            if constexpr (sizeof(T) == 2) {
+              __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);       // DS reads
+              __builtin_amdgcn_sched_group_barrier(0x008, MT * RF, 0);  // MFMAs
+            }
+            // fused-RMSNorm statistics on the matrix core: diag(X_t X_t^T) = the row sums of squares of row tile t.
+            // Wave w owns tiles w, w + NWV, ...; it re-reads them from LDS at a wave-dependent address (selecting
+            // among the fx registers instead needs per-wave branches, which made the compiler shuttle the
+            // accumulators between AGPRs and VGPRs around every group: +40 % kernel time)
+            if (fuse) {
+#pragma unroll
+              for (int j = 0; j < NSS; ++j) {
+                const int t = (j * NWV + wn) < MT ? (j * NWV + wn) : MT - 1;
+                const uint4 fs = *(const uint4*)(sl_ + lds_off(t * 16 + r, s2 * 4 + q));
+                MMA<T>::step(ssacc[j], fs, fs);
+              }
+            }
+          }
+        }
+        {
+          int stg = g_lo + it + D; stg = stg < g_last ? stg : g_last;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int f = 0; f < RF; ++f) wr[d][s2][f] = ld_nt16(wp[f] + (int64_t)(stg * 2 + s2) * (64 * VEC));
+        }
+        __syncthreads();
+      }
+    }
+    if (fuse) {   // lane (c = r, q) holds D[4q + i][c]: the diagonal element of row r sits in lane q == r >> 2, i = r & 3
+#pragma unroll
+      for (int j = 0; j < NSS; ++j) {
+        const int t = j * NWV + wn;
+        if (t < MT && (r >> 2) == q) ssl[t * 16 + r] = ssacc[j][r & 3];
+      }
+    }
+  }
+  __syncthreads();
+  if (wave >= NWV) return;
+
+  float ssum[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    ssum[t] = 0.f;
+    if (fuse) ssum[t] = ssl[t * 16 + r];
+  }
+
+  if (s.splits > 1) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+        if (fi0 + f < nfrag) *(f32x4*)(s.part + ((int64_t)sp * p.M + m) * s.np + (fi0 + f) * 16 + 4 * q) = acc[f][t];
+      if (fuse && blockIdx.x == 0 && wn == 0 && q == 0) s.part_ss[(int64_t)sp * p.M + m] = ssum[t];
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = m0 + t * 16 + r;
+    if (m >= p.M) continue;
+    const float rs = fuse ? rsqrtf(ssum[t] / (float)p.K + sx.eps) : 1.0f;
+    if constexpr (PAIRS) {
+#pragma unroll
+      for (int pr = 0; pr < RF / 2; ++pr) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = acc[2 * pr][t][i] * rs; b[i] = acc[2 * pr + 1][t][i] * rs; }
+        stream_epilogue4<T, ACT>(p, sx, m, fi0 + 2 * pr, 4 * q, a, b);
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        float a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = acc[f][t][i] * rs;
+        stream_epilogue4<T, ACT>(p, sx, m, fi0 + f, 4 * q, a, a);
+      }
+    }
+  }
+}
+
+// sums the K-split partials and applies the epilogue: one thread per (row, fragment or fragment pair, 4-column group)
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gemm_stream_reduce_kernel(GemmP p, SkinnyX sx, StreamX s) {
+  constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+  const int nfrag = (p.N + 15) >> 4;
+  const int nunits = PAIRS ? (nfrag + 1) / 2 : nfrag;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int q = (int)(idx & 3);
+  const int unit = (int)((idx >> 2) % nunits);
+  const int m = (int)(idx / (4 * (int64_t)nunits));
+  if (m >= p.M) return;
+  const int gf = PAIRS ? 2 * unit : unit;
+  f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.f;
+  for (int sp = 0; sp < s.splits; ++sp) {
+    const float* row = s.part + ((int64_t)sp * p.M + m) * s.np + gf * 16 + 4 * q;
+    a4 += *(const f32x4*)row;
+    if constexpr (PAIRS) b4 += *(const f32x4*)(row + 16);
+    if (sx.fuse_rms) ssum += s.part_ss[(int64_t)sp * p.M + m];
+  }
+  const float rs = sx.fuse_rms ? rsqrtf(ssum / (float)p.K + sx.eps) : 1.0f;
+  float a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = a4[i] * rs; b[i] = b4[i] * rs; }
+  stream_epilogue4<T, ACT>(p, sx, m, gf, 4 * q, a, b);
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------
+struct StreamCfg { int mt, splits, nwv; };
+
+// Measured on MI355X (tools/tune_stream.py, bf16, M = 64..256): one CU pulls at most ~23 GB/s from HBM (plus the x
+// slabs it re-reads from L2 through the same miss queue) whatever the prefetch depth, so the only lever is how many
+// CUs stream.  Wide matrices (>= 512 blocks of 128 weight rows: lm_head) use 4 compute waves x 32 rows; the layer
+// projections use 2 compute waves x 32 rows (64-row blocks) and split K until ~200 blocks exist — beyond that the
+// fp32 partials (written, then re-read by the reduce kernel) cost more than the extra CUs bring.
+static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
+  StreamCfg c;
+  c.mt = M <= 32 ? 2 : (M <= 64 ? 4 : (M <= 128 ? 8 : 16));
+  const int mblocks = (M + c.mt * 16 - 1) / (c.mt * 16);
+  const int nfrag = (N + 15) / 16;
+  const int nst = K / (2 * kstep);
+  c.nwv = (nfrag + 7) / 8 * mblocks >= 512 ? 4 : 2;
+  int sp_env = 0;
+  const char* e = getenv("SL_STREAM_CFG");  // tuning override "splits,nwv" (tools/tune_stream.py)
+  if (e && e[0]) {
+    int sp = 0, nwv = 0;
+    if (sscanf(e, "%d,%d", &sp, &nwv) == 2) {
+      if (sp >= 1 && sp <= 64) sp_env = sp;
+      if (nwv == 2 || nwv == 4) c.nwv = nwv;
+    }
+  }
+  const int base = mblocks * ((nfrag + c.nwv * 2 - 1) / (c.nwv * 2));
+  int splits = 1;
+  if (have_ws) {
+    splits = 208 / base;
+    const int max_splits = nst / 4 > 0 ? nst / 4 : 1;   // >= 4 stages (512 B of K per row) per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+  }
+  if (sp_env && (have_ws || sp_env == 1)) splits = sp_env < nst ? sp_env : nst;
+  c.splits = splits;
+  return c;
+}
+
+size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype) {
+  const size_t np = (size_t)((N + 15) / 16) * 16;
+  const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true);
+  size_t splits = c.splits > 1 ? (size_t)c.splits : 0;
+  return splits * ((size_t)M * np + (size_t)M) * sizeof(float) + 256;
+}
+
+template <typename T, int MT, int ACT, int RF, int NWV, int D>
+static int launch_stream_cfg(GemmP& p, const SkinnyX& sx, const StreamX& s, hipStream_t st) {
+  const int nfrag = (p.N + 15) / 16;
+  dim3 grid((nfrag + NWV * RF - 1) / (NWV * RF), (p.M + MT * 16 - 1) / (MT * 16), s.splits);
+  hipLaunchKernelGGL((gemm_stream_kernel<T, MT, ACT, RF, NWV, D>), grid, dim3(64 * (NWV + (MT > 8 ? 2 : 1))), 0, st, p, sx, s);
+  SL_CHECK_LAUNCH("gemm_stream");
+  if (s.splits > 1) {
+    constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+    const int64_t nunits = PAIRS ? (nfrag + 1) / 2 : nfrag;
+    const int64_t threads = (int64_t)p.M * nunits * 4;
+    hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, sx, s);
+    SL_CHECK_LAUNCH("gemm_stream_reduce");
+  }
+  return 0;
+}
+
+template <typename T, int MT, int ACT>
+static int launch_stream_mt(GemmP& p, const SkinnyX& sx, const StreamX& s, const StreamCfg& c, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    return launch_stream_cfg<T, MT, ACT, 2, 4, 2>(p, sx, s, st);   // fp32 parity mode: one structure
+  } else {
+    return c.nwv == 2 ? launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st) : launch_stream_cfg<T, MT, ACT, 2, 4, 4>(p, sx, s, st);
+  }
+}
+
+template <typename T, int ACT>
+static int launch_stream(GemmP& p, const SkinnyX& sx, const StreamX& s, const StreamCfg& c, hipStream_t st) {
+  switch (c.mt) {
+    case 2: return launch_stream_mt<T, 2, ACT>(p, sx, s, c, st);
+    case 4: return launch_stream_mt<T, 4, ACT>(p, sx, s, c, st);
+    case 8: return launch_stream_mt<T, 8, ACT>(p, sx, s, c, st);
+    default: return launch_stream_mt<T, 16, ACT>(p, sx, s, c, st);
+  }
+}
+
+template <typename T>
+static int stream_typed(GemmP& p, const SkinnyX& sx, int act, const StreamX& s, const StreamCfg& c, hipStream_t st) {
+  switch (act) {
+    case SL_ACT_NONE: return launch_stream<T, SL_ACT_NONE>(p, sx, s, c, st);
+    case SL_ACT_SILU_MUL: return launch_stream<T, SL_ACT_SILU_MUL>(p, sx, s, c, st);
+    case SL_ACT_ROPE_KV: return launch_stream<T, SL_ACT_ROPE_KV>(p, sx, s, c, st);
+  }
+  sl_set_error("sl_gemm: packed weights are not built with act %d for M > 16 streaming", act);
+  return SL_ERR_UNSUPPORTED;
+}
+
+int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void* split_ws, size_t split_ws_bytes, hipStream_t st) {
+  const int kstep = dtype == SL_F32 ? 16 : 32;
+  SL_CHECK_ARG(p.K % (2 * kstep) == 0, "sl_gemm: streaming path needs K %% %d == 0 (K=%d)", 2 * kstep, p.K);
+  StreamCfg c = stream_cfg(p.M, p.N, p.K, kstep, split_ws != nullptr);
+  StreamX s;
+  s.np = (p.N + 15) / 16 * 16;
+  const size_t per_split = ((size_t)p.M * s.np + (size_t)p.M) * sizeof(float);
+  if (c.splits > 1 && (size_t)c.splits * per_split > split_ws_bytes) c.splits = (int)(split_ws_bytes / per_split);
+  if (c.splits < 1) c.splits = 1;
+  const int nst = p.K / (2 * kstep);
+  s.sps = (nst + c.splits - 1) / c.splits;
+  s.splits = (nst + s.sps - 1) / s.sps;   // no empty splits
+  c.splits = s.splits;
+  s.part = (float*)split_ws;
+  s.part_ss = s.part ? s.part + (size_t)s.splits * p.M * s.np : nullptr;
+  if (dtype == SL_F32) return stream_typed<float>(p, sx, act, s, c, st);
+  return stream_typed<bf16_t>(p, sx, act, s, c, st);
+}

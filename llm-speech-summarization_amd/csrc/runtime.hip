@@ -344,8 +344,11 @@ extern "C" int sl_whisper_forward(const sl_hubert_model* m, const void* mel, int
 // ================================================================================================
 // Llama
 // ================================================================================================
+constexpr int SL_MAX_DECODE_BATCH = 512;   // rows of one decode step (M of the weight-streaming GEMMs)
+
 struct LlamaWs {
-  void *h, *qkv, *att, *mid, *last, *part;
+  void *h, *qkv, *att, *mid, *last, *part, *split;
+  size_t split_bytes;
   int32_t *tok_seq, *tok_pos, *cu, *cuk, *klen;
 };
 
@@ -358,7 +361,17 @@ static size_t llama_carve(const sl_llama_model* m, int64_t n_tok, int nseq, void
   w.att = c.take(n_tok * (int64_t)m->n_heads * m->head_dim * sz);
   w.mid = c.take(n_tok * (int64_t)m->ffn * sz);
   w.last = c.take((size_t)nseq * m->hidden * sz);
-  w.part = c.take(nseq <= 64 ? sl_attn_decode_split_ws(nseq, m->n_heads, m->n_kv_heads, m->rope_len) : 0);  // rope_len >= max_ctx
+  w.part = c.take(sl_attn_decode_split_ws(nseq, m->n_heads, m->n_kv_heads, m->rope_len));  // rope_len >= max_ctx
+  {  // K-split partial sums of the decode GEMMs (batches above the skinny kernel's range)
+    size_t sb = 0;
+    const int shapes[5][2] = {{qkv_w, m->hidden}, {m->hidden, m->n_heads * m->head_dim}, {2 * m->ffn, m->hidden}, {m->hidden, m->ffn}, {m->vocab, m->hidden}};
+    for (auto& sh : shapes) {
+      const size_t b = sl_gemm_split_workspace_bytes(nseq, sh[0], sh[1], m->dtype);
+      if (b > sb) sb = b;
+    }
+    w.split_bytes = sb;
+    w.split = c.take(sb);
+  }
   w.tok_seq = (int32_t*)c.take(n_tok * sizeof(int32_t));
   w.tok_pos = (int32_t*)c.take(n_tok * sizeof(int32_t));
   w.cu = (int32_t*)c.take((nseq + 1) * sizeof(int32_t));
@@ -386,8 +399,12 @@ static inline size_t kv_layer_bytes(const sl_llama_model* m, const sl_kv_cache* 
 
 // one decoder layer over `n` token rows; attention chosen by `decode`
 // decode GEMM on the fragment-packed weights, optionally absorbing the preceding RMSNorm / RoPE+KV-append
-static int dec_gemm(const sl_llama_model* m, const void* A, int64_t lda, const void* Wp, void* C, int64_t ldc, const void* res, int M, int N,
-                    int K, int act, int out_f32, const sl_gemm_fused* fx, hipStream_t st) {
+static int dec_gemm(const sl_llama_model* m, const LlamaWs& w, const void* A, int64_t lda, const void* Wp, void* C, int64_t ldc, const void* res,
+                    int M, int N, int K, int act, int out_f32, const sl_gemm_fused* fx_in, hipStream_t st) {
+  sl_gemm_fused fxl;
+  if (fx_in) fxl = *fx_in; else memset(&fxl, 0, sizeof(fxl));
+  fxl.split_ws = w.split; fxl.split_ws_bytes = w.split_bytes;
+  const sl_gemm_fused* fx = &fxl;
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = Wp; a.ldw = K; a.C = C; a.ldc = ldc; a.residual = res; a.ldr = ldc;
@@ -413,16 +430,16 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
     fx.k_cache = kc; fx.v_cache = vc; fx.n_heads = nh; fx.n_kv_heads = nkv; fx.max_ctx = kv->max_ctx;
     const void* a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
-    SL_TRY(dec_gemm(m, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st));
+    SL_TRY(dec_gemm(m, w, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st));
     SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
-    SL_TRY(dec_gemm(m, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st));
+    SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st));
     sl_gemm_fused fn;
     memset(&fn, 0, sizeof(fn));
     fn.fuse_rms = m->dec_fused_norm; fn.rms_eps = m->rms_eps;
     a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
-    SL_TRY(dec_gemm(m, a_in, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st));
-    SL_TRY(dec_gemm(m, w.mid, m->ffn, L.wdown_dec, x, H, x, (int)n, H, m->ffn, SL_ACT_NONE, 0, nullptr, st));
+    SL_TRY(dec_gemm(m, w, a_in, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st));
+    SL_TRY(dec_gemm(m, w, w.mid, m->ffn, L.wdown_dec, x, H, x, (int)n, H, m->ffn, SL_ACT_NONE, 0, nullptr, st));
     return 0;
   }
   SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st));
@@ -506,7 +523,7 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
     fx.fuse_rms = m->dec_fused_norm; fx.rms_eps = m->rms_eps;
     const void* a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.last; }
-    return dec_gemm(m, a_in, H, m->lm_head_dec, logits, m->vocab, nullptr, B, m->vocab, H, SL_ACT_NONE, 1, &fx, st);
+    return dec_gemm(m, w, a_in, H, m->lm_head_dec, logits, m->vocab, nullptr, B, m->vocab, H, SL_ACT_NONE, 1, &fx, st);
   }
   SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st));
   SL_TRY(gemm(dt, w.last, H, m->lm_head, H, logits, m->vocab, nullptr, nullptr, 0, B, m->vocab, H, SL_ACT_NONE, 1, st));
@@ -521,7 +538,7 @@ __global__ void iota_kernel(int32_t* p, int n) {
 extern "C" int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids_dev, const int32_t* ctx_len_dev,
                                     int32_t B, float* logits, void* workspace, size_t workspace_bytes, sl_stream stream) {
   SL_TRY(llama_check(m, kv));
-  SL_CHECK_ARG(next_ids_dev && ctx_len_dev && logits && workspace && B > 0 && B <= kv->slots && B <= 64, "sl_llama_decode_step: bad arguments (B<=64)");
+  SL_CHECK_ARG(next_ids_dev && ctx_len_dev && logits && workspace && B > 0 && B <= kv->slots && B <= SL_MAX_DECODE_BATCH, "sl_llama_decode_step: bad arguments (B<=%d)", SL_MAX_DECODE_BATCH);
   hipStream_t st = (hipStream_t)stream;
   LlamaWs w;
   Carver c(workspace, workspace_bytes);
@@ -550,8 +567,8 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
                                   int32_t check_every, int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host,
                                   void* workspace, size_t workspace_bytes, sl_stream stream) {
   SL_TRY(llama_check(m, kv));
-  SL_CHECK_ARG(x && cu_seqlens_host && out_ids_host && n_steps_host && workspace && nseq > 0 && nseq <= 64 && max_new_tokens > 0,
-               "sl_greedy_generate: bad arguments (nseq<=64)");
+  SL_CHECK_ARG(x && cu_seqlens_host && out_ids_host && n_steps_host && workspace && nseq > 0 && nseq <= SL_MAX_DECODE_BATCH && max_new_tokens > 0,
+               "sl_greedy_generate: bad arguments (nseq<=%d)", SL_MAX_DECODE_BATCH);
   hipStream_t st = (hipStream_t)stream;
   const int64_t n_tok = cu_seqlens_host[nseq];
   const int B = nseq;

@@ -164,8 +164,10 @@ def pack_weight(W: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_decode(A: torch.Tensor, Wp: torch.Tensor, N: int, *, residual=None, act: int = L.ACT_NONE, out_f32: bool = False,
-                fuse_rms: bool = False, eps: float = 1e-5, rope=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Decode GEMM on packed weights.  rope = dict(cos, sin, pos, seq, k_cache, v_cache, n_heads, n_kv, max_ctx) for ACT_ROPE_KV."""
+                fuse_rms: bool = False, eps: float = 1e-5, rope=None, out: Optional[torch.Tensor] = None,
+                split_k: bool = True) -> torch.Tensor:
+    """Decode GEMM on packed weights.  rope = dict(cos, sin, pos, seq, k_cache, v_cache, n_heads, n_kv, max_ctx) for ACT_ROPE_KV.
+    split_k: hand the kernel a scratch buffer so that row counts > 64 may split K over blocks (gemm_stream.hip)."""
     M, K = A.shape
     if act == L.ACT_SILU_MUL:
         n_out = N // 2
@@ -188,8 +190,24 @@ def gemm_decode(A: torch.Tensor, Wp: torch.Tensor, N: int, *, residual=None, act
         f.rope_cos, f.rope_sin, f.tok_pos, f.tok_seq = L.ptr(rope["cos"]), L.ptr(rope["sin"]), L.ptr(rope["pos"]), L.ptr(rope["seq"])
         f.k_cache, f.v_cache = L.ptr(rope["k_cache"]), L.ptr(rope["v_cache"])
         f.n_heads, f.n_kv_heads, f.max_ctx = rope["n_heads"], rope["n_kv"], rope["max_ctx"]
+    if split_k:
+        need = int(L.lib().sl_gemm_split_workspace_bytes(M, N, K, a.dtype))
+        if need > 0:
+            ws = _split_ws(A.device, need)
+            f.split_ws, f.split_ws_bytes = L.ptr(ws), ws.numel()
     L.check(L.lib().sl_gemm_fused_decode(C.byref(a), C.byref(f), L.stream_ptr()), "sl_gemm_fused_decode")
     return out
+
+
+_SPLIT_WS = {}
+
+
+def _split_ws(device, nbytes: int) -> torch.Tensor:
+    ws = _SPLIT_WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _SPLIT_WS[device] = ws
+    return ws
 
 
 def attn_decode_split(q, q_stride, k_cache, v_cache, ctx_len, n_heads, n_kv, D, max_ctx, scale) -> torch.Tensor:

@@ -279,7 +279,7 @@ def test_greedy_select_semantics():
 
 # ---- decode-path kernels: packed weights, fused RMSNorm, fused RoPE + KV append, flash-decoding ----------
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M", [1, 16, 17, 40])
+@pytest.mark.parametrize("M", [1, 16, 17, 40, 64, 100, 128, 200, 256])   # <= 32 rows: skinny kernel, above: gemm_stream.hip
 @pytest.mark.parametrize("N,K", [(3072, 3072), (5120, 1024), (1000, 256), (33000, 512)])
 def test_gemm_packed_matches_rowmajor_reference(dt, M, N, K):
     A, W, R = rnd(M, K, seed=31), rnd(N, K, seed=32, std=K ** -0.5), rnd(M, N, seed=33)
@@ -290,10 +290,13 @@ def test_gemm_packed_matches_rowmajor_reference(dt, M, N, K):
     out = ops.gemm_decode(A.to(dev(), dt), Wp, N, residual=R.to(dev(), dt))
     assert rel_err(out.float().cpu(), ref) < TOL[dt]
     assert rel_err(ops.gemm_decode(A.to(dev(), dt), Wp, N, out_f32=True).cpu(), q(A, dt) @ q(W, dt).T) < 2e-5
+    # without the K-split scratch buffer the streaming kernel applies the epilogue itself
+    out = ops.gemm_decode(A.to(dev(), dt), Wp, N, residual=R.to(dev(), dt), split_k=False)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M", [1, 16, 33])
+@pytest.mark.parametrize("M", [1, 16, 33, 64, 130])
 def test_gemm_packed_fused_rmsnorm_and_silu(dt, M):
     H, Fd = 512, 1024
     x, gain = rnd(M, H, seed=34), 1 + rnd(H, seed=35, std=0.1)
@@ -306,10 +309,12 @@ def test_gemm_packed_fused_rmsnorm_and_silu(dt, M):
     out = ops.gemm_decode(x.to(dev(), dt), ops.pack_weight(wgu), 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5)
     assert out.shape == (M, Fd)
     assert rel_err(out.float().cpu(), ref) < TOL[dt]
+    out = ops.gemm_decode(x.to(dev(), dt), ops.pack_weight(wgu), 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, split_k=False)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M", [1, 5, 16])
+@pytest.mark.parametrize("M", [1, 5, 16, 40, 130])
 def test_gemm_packed_rope_kv_epilogue_equals_separate_kernels(dt, M):
     arch = weights.LlamaArch(hidden_size=256, num_attention_heads=6, num_key_value_heads=2, head_dim=128,
                              rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
