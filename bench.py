@@ -182,7 +182,7 @@ def mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx
         enc_ms.append(ev[0].elapsed_time(ev[1]))
     el = time.perf_counter() - t0
     assert n_cols == new
-    return {"utterance_sec": secs, "audio_sec_total": sum(secs), "prompt_tokens_total": starts[-1],
+    return {"utterance_sec_cycle": list(DEVCLEAN_MIX_SEC), "utterances": B, "audio_sec_total": sum(secs), "prompt_tokens_total": starts[-1],
             "tokens_per_s": round(B * new * args.steps / el, 1),
             "audio_sec_per_s": round(sum(secs) / (sum(enc_ms) / len(enc_ms) * 1e-3), 1),
             "ms_per_step": round(el / args.steps * 1e3, 2), "note": "per-rank figures (rank 0)"}
@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="utterances per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="utterances per step per GPU")
     ap.add_argument("--audio-sec", type=float, default=10.0)
     ap.add_argument("--max-new-tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -331,8 +331,10 @@ def main():
     alg_bytes, dur_ms = gemm_probe
     achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
     traffic = None
-    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_gateup.json")
-    if os.path.exists(pmc_path):
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md) of the kernel this batch runs
+    streaming = B > 32
+    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_gateup_stream.json" if streaming else "r01_pmc_gateup.json")
+    if os.path.exists(pmc_path) and B in (16, 128):   # measured at M = 16 (skinny) and M = 128 (streaming) only
         with open(pmc_path) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
     dec_step_ms = mean(decode_ms) / max(1, new - 1)
@@ -350,7 +352,7 @@ def main():
                      "decode_per_step": round(dec_step_ms, 4)},
         "decode_step_hbm": {"algorithmic_GB": round(step_bytes / 1e9, 3), "achieved_GBps": round(step_bytes / (dec_step_ms * 1e-3) / 1e9, 1),
                             "frac_of_peak": round(step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "roofline": {"kernel": "gemm_skinny_kernel<bf16, SILU_MUL> (gate/up projection, decode)", "bound": "hbm",
+        "roofline": {"kernel": ("gemm_stream_kernel" if streaming else "gemm_skinny_kernel") + "<bf16, SILU_MUL> (gate/up projection, decode)", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(dur_ms * 1e3, 2)},
     }

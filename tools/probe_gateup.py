@@ -1,10 +1,12 @@
-"""Launch the dominant decode kernel (packed gate/up weight-streaming GEMM, M=16) as decode does, for rocprofv3 --pmc runs."""
+"""Launch the dominant decode kernel (packed gate/up weight-streaming GEMM, M = argv[1] rows, default 128) as decode does,
+for rocprofv3 --pmc runs."""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("llm-speech-summarization_amd.ops")
 L = importlib.import_module("llm-speech-summarization_amd._lib")
 dev = "cuda:0"
-H, F_, B, NL = 3072, 8192, 16, 28
+H, F_, NL = 3072, 8192, 28
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 ws = [ops.pack_weight((torch.randn(2 * F_, H, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(NL)]
 x = torch.randn(B, H, device=dev).to(torch.bfloat16)
 out = torch.empty(B, F_, device=dev, dtype=torch.bfloat16)
