@@ -201,7 +201,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
 // transposed (every forward GEMM of the encoder / prefill at model shapes).
 // ----------------------------------------------------------------------------------------------
 
-template <typename T, int ACT>
+// ds_read_b128 the compiler cannot see: after a global_load_lds it guards every LDS read it knows about with
+// s_waitcnt vmcnt(0) (it cannot prove the DMA and the read do not alias), which made the "prefetch" of the next K slab
+// synchronous.  The consumer waits with lds_wait<N>(regs...) — the registers are tied to the wait so no use moves above it.
+#define SL_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+template <int N>
+__device__ __forceinline__ void lds_wait8(u32x4_t& a, u32x4_t& b, u32x4_t& c, u32x4_t& d, u32x4_t& e, u32x4_t& f, u32x4_t& g, u32x4_t& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N));
+}
+__device__ __forceinline__ uint4 as_uint4(const u32x4_t& v) { return make_uint4(v.x, v.y, v.z, v.w); }
+
+template <typename T, int ACT, bool ASMLDS = false>
 __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int BK = TROWB / (int)sizeof(T);
@@ -258,22 +268,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
-    const unsigned char* sa = &smem[buf][0][0];
-    const unsigned char* sw = &smem[buf][1][0];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 fa[4], fb[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(sa + lds_off(wm * 64 + m * 16 + r, s * 4 + q));
-#pragma unroll
-      for (int n = 0; n < 4; ++n) fb[n] = *(const uint4*)(sw + lds_off(wn * 64 + n * 16 + r, s * 4 + q));
+    if constexpr (ASMLDS) {
+      // both 64-byte k-steps of the slab are requested up front; the MFMAs of step 0 run under the reads of step 1,
+      // and the DMA of slab kt+1 (issued above) runs under all of it
+      const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(&smem[buf][0][0]);
+      const uint32_t x0 = (uint32_t)((q ^ (r & 7)) << 4), x1 = (uint32_t)(((4 + q) ^ (r & 7)) << 4);
+      const uint32_t ra = sb + (uint32_t)((wm * 64 + r) * TROWB), rb = sb + (uint32_t)(TBM * TROWB + (wn * 64 + r) * TROWB);
+      u32x4_t a0[4], b0[4], a1[4], b1[4];
+      SL_LDS_RD(a0[0], ra + x0, 0); SL_LDS_RD(a0[1], ra + x0, 2048); SL_LDS_RD(a0[2], ra + x0, 4096); SL_LDS_RD(a0[3], ra + x0, 6144);
+      SL_LDS_RD(b0[0], rb + x0, 0); SL_LDS_RD(b0[1], rb + x0, 2048); SL_LDS_RD(b0[2], rb + x0, 4096); SL_LDS_RD(b0[3], rb + x0, 6144);
+      SL_LDS_RD(a1[0], ra + x1, 0); SL_LDS_RD(a1[1], ra + x1, 2048); SL_LDS_RD(a1[2], ra + x1, 4096); SL_LDS_RD(a1[3], ra + x1, 6144);
+      SL_LDS_RD(b1[0], rb + x1, 0); SL_LDS_RD(b1[1], rb + x1, 2048); SL_LDS_RD(b1[2], rb + x1, 4096); SL_LDS_RD(b1[3], rb + x1, 6144);
+      lds_wait8<8>(a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3]);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], fa[m], fb[n]);
+        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], as_uint4(a0[m]), as_uint4(b0[n]));
+      __builtin_amdgcn_sched_barrier(0);
+      lds_wait8<0>(a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], as_uint4(a1[m]), as_uint4(b1[n]));
+      __builtin_amdgcn_sched_barrier(0);   // keep the DMA wait and the barrier BELOW the MFMAs (they carry no data dependence)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      const unsigned char* sa = &smem[buf][0][0];
+      const unsigned char* sw = &smem[buf][1][0];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint4 fa[4], fb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(sa + lds_off(wm * 64 + m * 16 + r, s * 4 + q));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[n] = *(const uint4*)(sw + lds_off(wn * 64 + n * 16 + r, s * 4 + q));
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], fa[m], fb[n]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
   tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, wz);
 }
@@ -507,8 +544,10 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   p.tiles_n = (p.N + TBN - 1) / TBN;
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   constexpr int BK = TROWB / (int)sizeof(T);
-  if (!p.ta && !p.tw && p.K % BK == 0 && !g_disable_glds)
-    hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT>), grid, dim3(256), 0, st, p);
+  if (!p.ta && !p.tw && p.K % BK == 0 && g_disable_glds == 2)
+    hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, false>), grid, dim3(256), 0, st, p);
+  else if (!p.ta && !p.tw && p.K % BK == 0 && !g_disable_glds)
+    hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, true>), grid, dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_tiled_kernel<T, ACT>), grid, dim3(256), 0, st, p);
   SL_CHECK_LAUNCH("gemm_tiled");
@@ -594,7 +633,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   SL_CHECK_ARG(a != nullptr, "sl_gemm: null args");
   {
     const char* e = getenv("SL_DISABLE_GLDS");
-    g_disable_glds = (e && e[0] == '1') ? 1 : 0;
+    g_disable_glds = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0);   // 1: register staging, 2: glds with compiler-visible LDS reads
   }
   SL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0, "sl_gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   SL_CHECK_ARG(a->dtype == SL_F32 || a->dtype == SL_BF16, "sl_gemm: bad dtype %d", a->dtype);
