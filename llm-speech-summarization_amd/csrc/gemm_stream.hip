@@ -3,10 +3,10 @@
 // but unlike the skinny kernel the activations no longer fit the "re-read them per fragment from L2" model:
 //   * block = NWV compute waves + 1 loader wave.  The compute waves walk the SAME k-range over different weight
 //     fragments (RF fragments = 16*RF weight rows each), so one x slab serves 16*RF*NWV weight rows.
-//   * the loader wave prefetches x slabs ([16*MT rows][128 B of K], XOR-swizzled as in the tiled kernel) two stages
-//     ahead into registers and writes them to a double-buffered LDS slab one stage ahead of the MFMAs.  (LDS-DMA
-//     was tried first: the compiler fences every barrier and LDS read after a global_load_lds with vmcnt(0), which
-//     drains the weight prefetch each stage; plain loads keep exact in-order vmcnt tracking.)
+//   * the loader wave DMAs x slabs ([16*MT rows][128 B of K], XOR-swizzled as in the tiled kernel) straight into a
+//     ring of three LDS slabs, two stages ahead of the MFMAs.  LDS-DMA lives in the loader wave only: in a wave that
+//     also reads LDS or streams weights the compiler guards every LDS read and barrier after a global_load_lds with
+//     vmcnt(0), which drains the weight prefetch each stage.
 //   * weight fragments go global -> VGPR -> MFMA (one contiguous 1 KiB per wave-load, packed layout), D stages
 //     ahead in a register ring; nothing of W ever touches LDS.
 //   * when the grid would not fill the CUs, K is split over `splits` blocks: those write fp32 partials and
@@ -79,14 +79,14 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
   constexpr int KSTEP = MMA<T>::KSTEP;
   constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
   static_assert(!PAIRS || RF % 2 == 0, "pair epilogues need an even number of fragments");
-  static_assert(MT <= 16 && D % 2 == 0, "ring turns are unrolled; the x ring is 2 deep");
+  static_assert(MT <= 16, "two loader waves stage at most 256 rows");
   constexpr int NL = MT > 8 ? 2 : 1;          // loader waves: each stages up to 128 rows
   constexpr int MTL = MT / NL;                // row tiles per loader
   constexpr int SLAB = MT * 16 * TROWB;       // bytes of one x slab
   constexpr int NXL = 2 * MTL;                // 16-byte x chunks per loader lane per stage
-  constexpr int DX = 2;                       // loader ring depth (x slabs are L2 hits)
+  constexpr int NSLOT = 3;                    // LDS slabs: one being read, two being filled
   constexpr int NSS = (MT + NWV - 1) / NWV;   // row tiles whose RMSNorm statistics a compute wave owns
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SLAB];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLAB];
   __shared__ float ssl[MT * 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,45 +116,35 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
     // ---- x loader.  Its vmcnt queue holds only x loads: a wave that also streamed weights would, waiting for an
     // x slab issued two stages ago, drain every older weight load with it (vmcnt completes in issue order), which caps
     // the weight prefetch at ~3 stages whatever the ring depth (measured: D = 4, 6, 8 identical at 23 GB/s per CU).
+    // The slabs go global -> LDS by LDS-DMA (no staging VGPRs, no ds_write pass: a single wave moving 16 KiB per stage
+    // through registers was the critical path at ~0.5 us per stage); three LDS slots keep two stages of DMA in flight.
     const T* A = (const T*)p.A;
     const int lw = wave - NWV;                        // loader index: rows [128 lw, 128 lw + 128) of the block
     const int ch = (lane & 7) ^ ((lane >> 3) & 7);   // LDS chunk c = lane + 64 i: row (lane >> 3) + 8 i, logical chunk ch
-    int64_t xo[NXL];
+    const T* gx[NXL];
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       int xr_ = m0 + lw * 128 + (lane >> 3) + 8 * i; xr_ = xr_ < p.M ? xr_ : p.M - 1;
-      xo[i] = (int64_t)xr_ * p.lda + ch * VEC;
+      gx[i] = A + (int64_t)xr_ * p.lda + ch * VEC;
     }
-    unsigned char* lbase = smem + lw * (MTL * 16 * TROWB) + lane * 16;
-    u32x4_t xr[DX][NXL];   // ext-vector type: stays in SSA registers (HIP's uint4 struct copies went through scratch)
+    unsigned char* lbase = smem + lw * (MTL * 16 * TROWB);
+    auto dma = [&](int it) {   // x slab of stage g_lo + it -> slot it % NSLOT
+      int stg = g_lo + it; stg = stg < g_last ? stg : g_last;
+      unsigned char* dst = lbase + (it % NSLOT) * SLAB;
 #pragma unroll
-    for (int d = 0; d < DX; ++d) {
-      int stg = g_lo + d; stg = stg < g_last ? stg : g_last;
-#pragma unroll
-      for (int i = 0; i < NXL; ++i) xr[d][i] = *(const u32x4_t*)(A + xo[i] + (int64_t)stg * (2 * KSTEP));
+      for (int i = 0; i < NXL; ++i)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gx[i] + (int64_t)stg * (2 * KSTEP)), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+    };
+    dma(0);
+    dma(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXL) : "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < n_it; ++it) {
+      dma(it + 2);             // into the slot every wave finished reading one barrier ago
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXL) : "memory");   // stage it+1 has landed
+      __builtin_amdgcn_s_barrier();
     }
-    {
-#pragma unroll
-      for (int i = 0; i < NXL; ++i) *(u32x4_t*)(lbase + i * 1024) = xr[0][i];
-      int stg = g_lo + DX; stg = stg < g_last ? stg : g_last;
-#pragma unroll
-      for (int i = 0; i < NXL; ++i) xr[0][i] = *(const u32x4_t*)(A + xo[i] + (int64_t)stg * (2 * KSTEP));
-    }
-    __syncthreads();
-    for (int it0 = 0; it0 < n_it; it0 += DX) {
-#pragma unroll
-      for (int d = 0; d < DX; ++d) {
-        const int it = it0 + d;
-        const int d1 = (d + 1) % DX;
-        unsigned char* dst = lbase + ((it + 1) & 1) * SLAB;   // the slot every wave finished reading one barrier ago
-#pragma unroll
-        for (int i = 0; i < NXL; ++i) *(u32x4_t*)(dst + i * 1024) = xr[d1][i];
-        int stg = g_lo + it + 1 + DX; stg = stg < g_last ? stg : g_last;
-#pragma unroll
-        for (int i = 0; i < NXL; ++i) xr[d1][i] = *(const u32x4_t*)(A + xo[i] + (int64_t)stg * (2 * KSTEP));
-        __syncthreads();
-      }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     // ---- compute waves: weight fragments global -> VGPR ring (D stages = D * RF * 2 KiB per wave in flight) -> MFMA
     const T* W = (const T*)p.W;
@@ -182,7 +172,7 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
       for (int d = 0; d < D; ++d) {
         const int it = it0 + d;
         if (g_lo + it < g_hi) {
-          const unsigned char* sl_ = smem + (it & 1) * SLAB;
+          const unsigned char* sl_ = smem + (it % NSLOT) * SLAB;
           // the MT activation fragments of a k-step are requested together, ahead of its MFMAs (left alone, the
           // scheduler pairs each ds_read with its two MFMAs and exposes the LDS latency 2*MT times per stage)
 #pragma unroll
@@ -308,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_stream_reduce_kernel(GemmP p, Skinny
 // ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
-struct StreamCfg { int mt, splits, nwv; };
+struct StreamCfg { int mt, splits, nwv, d; };
 
 // Measured on MI355X (tools/tune_stream.py, bf16, M = 64..256): one CU pulls at most ~23 GB/s from HBM (plus the x
 // slabs it re-reads from L2 through the same miss queue) whatever the prefetch depth, so the only lever is how many
@@ -322,14 +312,17 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
   const int nfrag = (N + 15) / 16;
   const int nst = K / (2 * kstep);
   c.nwv = (nfrag + 7) / 8 * mblocks >= 512 ? 4 : 2;
+  c.d = 4;
   int sp_env = 0;
   const char* e = getenv("SL_STREAM_CFG");  // tuning override "splits,nwv" (tools/tune_stream.py)
   if (e && e[0]) {
-    int sp = 0, nwv = 0;
-    if (sscanf(e, "%d,%d", &sp, &nwv) == 2) {
+    int sp = 0, nwv = 0, d = 0;
+    const int n = sscanf(e, "%d,%d,%d", &sp, &nwv, &d);
+    if (n >= 2) {
       if (sp >= 1 && sp <= 64) sp_env = sp;
       if (nwv == 2 || nwv == 4) c.nwv = nwv;
     }
+    if (n == 3 && (d == 4 || d == 8)) c.d = d;
   }
   const int base = mblocks * ((nfrag + c.nwv * 2 - 1) / (c.nwv * 2));
   int splits = 1;
@@ -373,7 +366,8 @@ static int launch_stream_mt(GemmP& p, const SkinnyX& sx, const StreamX& s, const
   if constexpr (sizeof(T) == 4) {
     return launch_stream_cfg<T, MT, ACT, 2, 4, 2>(p, sx, s, st);   // fp32 parity mode: one structure
   } else {
-    return c.nwv == 2 ? launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st) : launch_stream_cfg<T, MT, ACT, 2, 4, 4>(p, sx, s, st);
+    if (c.nwv == 2) return c.d == 8 ? launch_stream_cfg<T, MT, ACT, 2, 2, 8>(p, sx, s, st) : launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st);
+    return launch_stream_cfg<T, MT, ACT, 2, 4, 4>(p, sx, s, st);
   }
 }
 
