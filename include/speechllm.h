@@ -96,8 +96,15 @@ typedef struct {
   /* optional scratch for K-split partial sums (M > 16 rows against few weight rows cannot fill 256 CUs
    * otherwise): sl_gemm_split_workspace_bytes(M, N, K, dtype) bytes, or NULL to disable the split */
   void* split_ws; size_t split_ws_bytes;
+  /* RMSNorm statistics handed from one GEMM to the next (streaming path only):
+   *   rstd_out — with the plain epilogue and a K-split, the reduce kernel also writes, per output row,
+   *              rsqrt(mean(row^2) + rms_eps) of the values it stores (N <= 4096);
+   *   rstd_in  — with fuse_rms, multiply by rstd_in[m] instead of recomputing the statistics of A's rows. */
+  const float* rstd_in; float* rstd_out;
 } sl_gemm_fused;
 size_t sl_gemm_split_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype);
+/* K splits sl_gemm_fused_decode will use for this shape when split_ws is supplied (1: no reduce pass, so no rstd_out) */
+int32_t sl_gemm_split_count(int32_t M, int32_t N, int32_t K, int32_t dtype);
 int sl_gemm_fused_decode(const sl_gemm_args* a, const sl_gemm_fused* fx, sl_stream stream);
 
 /* Backward-pass forms of sl_gemm (training; always the tiled MFMA kernel):

@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
 class GemmFused(C.Structure):
     _fields_ = [("fuse_rms", c_i32), ("rms_eps", c_f32), ("rope_cos", c_vp), ("rope_sin", c_vp), ("tok_pos", c_vp), ("tok_seq", c_vp),
                 ("k_cache", c_vp), ("v_cache", c_vp), ("n_heads", c_i32), ("n_kv_heads", c_i32), ("max_ctx", c_i32), ("reserved", c_i32),
-                ("split_ws", c_vp), ("split_ws_bytes", C.c_size_t)]
+                ("split_ws", c_vp), ("split_ws_bytes", C.c_size_t), ("rstd_in", c_vp), ("rstd_out", c_vp)]
 
 
 class GemmEx(C.Structure):
@@ -102,6 +102,7 @@ _PROTOS = {
     "sl_pack_weight": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "sl_gemm_fused_decode": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmFused), c_vp]),
     "sl_gemm_split_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "sl_gemm_split_count": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "sl_attn_decode_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "sl_attn_decode_split": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sl_gemm_ex": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmEx), c_vp]),

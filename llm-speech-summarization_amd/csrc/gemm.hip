@@ -672,6 +672,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     sx.fuse_rms = fx->fuse_rms; sx.eps = fx->rms_eps;
     sx.cos = fx->rope_cos; sx.sin = fx->rope_sin; sx.pos = fx->tok_pos; sx.seq = fx->tok_seq;
     sx.kc = fx->k_cache; sx.vc = fx->v_cache; sx.nh = fx->n_heads; sx.nkv = fx->n_kv_heads; sx.max_ctx = fx->max_ctx;
+    sx.rstd_in = fx->rstd_in; sx.rstd_out = fx->rstd_out;
   }
   if (a->act == SL_ACT_ROPE_KV) {
     SL_CHECK_ARG(fx && fx->rope_cos && fx->rope_sin && fx->tok_pos && fx->tok_seq && fx->k_cache && fx->v_cache,
@@ -683,8 +684,14 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
       a->K % (a->dtype == SL_F32 ? 32 : 64) == 0)
     return sl_gemm_stream_launch(p, sx, a->dtype, a->act, fx ? fx->split_ws : nullptr, fx ? fx->split_ws_bytes : 0, st);
   SL_CHECK_ARG(a->w_layout != SL_W_PACKED || a->M <= 64, "sl_gemm: packed weights with M=%d > 64 need batch 1 and K %% 64 == 0", a->M);
+  SL_CHECK_ARG(!sx.rstd_in && !sx.rstd_out, "sl_gemm: rstd_in / rstd_out are features of the streaming path (M > %d rows, packed weights)", stream_min_m());
   if (a->dtype == SL_F32) return gemm_typed<float>(a, p, sx, st);
   return gemm_typed<bf16_t>(a, p, sx, st);
+}
+
+extern "C" int32_t sl_gemm_split_count(int32_t M, int32_t N, int32_t K, int32_t dtype) {
+  if (M <= stream_min_m() || M <= 0 || N <= 0 || K <= 0 || K % (dtype == SL_F32 ? 32 : 64) != 0) return 1;
+  return sl_gemm_stream_splits(M, N, K, dtype);
 }
 
 extern "C" size_t sl_gemm_split_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype) {

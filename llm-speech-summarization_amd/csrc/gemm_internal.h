@@ -65,8 +65,11 @@ struct SkinnyX {
   void* kc; void* vc;                      // this layer's caches (slots, n_kv, max_ctx, 128)
   int nh, nkv, max_ctx, fuse_rms;
   float eps;
+  const float* rstd_in;   // per-row RMSNorm scale computed by the producer of A (replaces the in-kernel statistics)
+  float* rstd_out;        // K-split reduce kernel: also emit rsqrt(mean(out_row^2) + eps) of the rows it stores
 };
 
 // gemm_stream.hip: packed-weight streaming GEMM for 16 < M <= 256 (large-batch decode)
 int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void* split_ws, size_t split_ws_bytes, hipStream_t st);
 size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype);
+int sl_gemm_stream_splits(int M, int N, int K, int dtype);   // K splits the heuristic picks when a workspace is supplied

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int f = 0; f < RF; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool fuse = sx.fuse_rms != 0;
+  const bool fuse = sx.fuse_rms != 0 && sx.rstd_in == nullptr;   // statistics taken here unless the producer of A supplied them
 
   if (wave >= NWV) {
     // ---- x loader.  Its vmcnt queue holds only x loads: a wave that also streamed weights would, waiting for an
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
   for (int t = 0; t < MT; ++t) {
     const int m = m0 + t * 16 + r;
     if (m >= p.M) continue;
-    const float rs = fuse ? rsqrtf(ssum[t] / (float)p.K + sx.eps) : 1.0f;
+    const float rs = sx.rstd_in ? sx.rstd_in[m] : (fuse ? rsqrtf(ssum[t] / (float)p.K + sx.eps) : 1.0f);
     if constexpr (PAIRS) {
 #pragma unroll
       for (int pr = 0; pr < RF / 2; ++pr) {
@@ -268,31 +268,76 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
   }
 }
 
-// sums the K-split partials and applies the epilogue: one thread per (row, fragment or fragment pair, 4-column group)
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void gemm_stream_reduce_kernel(GemmP p, SkinnyX sx, StreamX s) {
+// sums the K-split partials and applies the epilogue: one thread per (row, fragment or fragment pair, 4-column group).
+// ROWSTAT: one block per output row (blockDim = 4 * fragments <= 1024); the block also reduces the squares of the values
+// it stores (as rounded to T) and emits the row's RMSNorm scale for the GEMM that consumes these rows next.
+template <typename T, int ACT, bool ROWSTAT>
+__global__ __launch_bounds__(ROWSTAT ? 1024 : 256) void gemm_stream_reduce_kernel(GemmP p, SkinnyX sx, StreamX s) {
   constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+  static_assert(!ROWSTAT || ACT == SL_ACT_NONE, "row statistics ride on the plain (+residual) epilogue");
   const int nfrag = (p.N + 15) >> 4;
   const int nunits = PAIRS ? (nfrag + 1) / 2 : nfrag;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int q = (int)(idx & 3);
-  const int unit = (int)((idx >> 2) % nunits);
-  const int m = (int)(idx / (4 * (int64_t)nunits));
-  if (m >= p.M) return;
+  int q, unit, m;
+  if constexpr (ROWSTAT) {
+    m = blockIdx.x; q = threadIdx.x & 3; unit = threadIdx.x >> 2;
+  } else {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    q = (int)(idx & 3);
+    unit = (int)((idx >> 2) % nunits);
+    m = (int)(idx / (4 * (int64_t)nunits));
+    if (m >= p.M) return;
+  }
+  const bool live = unit < nunits;
   const int gf = PAIRS ? 2 * unit : unit;
   f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
   float ssum = 0.f;
-  for (int sp = 0; sp < s.splits; ++sp) {
-    const float* row = s.part + ((int64_t)sp * p.M + m) * s.np + gf * 16 + 4 * q;
-    a4 += *(const f32x4*)row;
-    if constexpr (PAIRS) b4 += *(const f32x4*)(row + 16);
-    if (sx.fuse_rms) ssum += s.part_ss[(int64_t)sp * p.M + m];
+  const bool stats_here = sx.fuse_rms && !sx.rstd_in;
+  if (live) {
+    for (int sp = 0; sp < s.splits; ++sp) {
+      const float* row = s.part + ((int64_t)sp * p.M + m) * s.np + gf * 16 + 4 * q;
+      a4 += *(const f32x4*)row;
+      if constexpr (PAIRS) b4 += *(const f32x4*)(row + 16);
+      if (stats_here) ssum += s.part_ss[(int64_t)sp * p.M + m];
+    }
   }
-  const float rs = sx.fuse_rms ? rsqrtf(ssum / (float)p.K + sx.eps) : 1.0f;
+  const float rs = sx.rstd_in ? sx.rstd_in[m] : (stats_here ? rsqrtf(ssum / (float)p.K + sx.eps) : 1.0f);
   float a[4], b[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { a[i] = a4[i] * rs; b[i] = b4[i] * rs; }
-  stream_epilogue4<T, ACT>(p, sx, m, gf, 4 * q, a, b);
+  if constexpr (ROWSTAT) {
+    // same arithmetic as stream_epilogue4's plain branch, keeping the stored values for the statistics
+    __shared__ float wsum[16];
+    float sq = 0.f;
+    if (live) {
+      const T* bias = (const T*)p.bias;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = gf * 16 + 4 * q + i;
+        if (col >= p.N) continue;
+        float v = a[i];
+        if (bias) v += to_f32(bias[col]);
+        if (p.res) v += p.res_f32 ? ((const float*)p.res)[(int64_t)m * p.ldr + col] : to_f32(((const T*)p.res)[(int64_t)m * p.ldr + col]);
+        if (p.out_f32) {
+          ((float*)p.C)[(int64_t)m * p.ldc + col] = v;
+        } else {
+          const T o = from_f32<T>(v);
+          ((T*)p.C)[(int64_t)m * p.ldc + col] = o;
+          v = to_f32(o);
+        }
+        sq = fmaf(v, v, sq);
+      }
+    }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+      sx.rstd_out[m] = rsqrtf(t / (float)p.N + sx.eps);
+    }
+  } else {
+    if (live) stream_epilogue4<T, ACT>(p, sx, m, gf, 4 * q, a, b);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -338,6 +383,10 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
   return c;
 }
 
+int sl_gemm_stream_splits(int M, int N, int K, int dtype) {
+  return stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true).splits;
+}
+
 size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype) {
   const size_t np = (size_t)((N + 15) / 16) * 16;
   const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true);
@@ -355,7 +404,14 @@ static int launch_stream_cfg(GemmP& p, const SkinnyX& sx, const StreamX& s, hipS
     constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
     const int64_t nunits = PAIRS ? (nfrag + 1) / 2 : nfrag;
     const int64_t threads = (int64_t)p.M * nunits * 4;
-    hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, sx, s);
+    if constexpr (ACT == SL_ACT_NONE) {
+      if (sx.rstd_out) {   // checked by the caller: 4 * fragments <= 1024
+        hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT, true>), dim3(p.M), dim3((unsigned)((nunits * 4 + 63) / 64 * 64)), 0, st, p, sx, s);
+        SL_CHECK_LAUNCH("gemm_stream_reduce(rowstat)");
+        return 0;
+      }
+    }
+    hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, sx, s);
     SL_CHECK_LAUNCH("gemm_stream_reduce");
   }
   return 0;
@@ -397,6 +453,7 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
   SL_CHECK_ARG(p.K % (2 * kstep) == 0, "sl_gemm: streaming path needs K %% %d == 0 (K=%d)", 2 * kstep, p.K);
   StreamCfg c = stream_cfg(p.M, p.N, p.K, kstep, split_ws != nullptr);
   StreamX s;
+
   s.np = (p.N + 15) / 16 * 16;
   const size_t per_split = ((size_t)p.M * s.np + (size_t)p.M) * sizeof(float);
   if (c.splits > 1 && (size_t)c.splits * per_split > split_ws_bytes) c.splits = (int)(split_ws_bytes / per_split);
@@ -405,6 +462,10 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
   s.sps = (nst + c.splits - 1) / c.splits;
   s.splits = (nst + s.sps - 1) / s.sps;   // no empty splits
   c.splits = s.splits;
+  if (sx.rstd_out) {
+    SL_CHECK_ARG(act == SL_ACT_NONE && (p.N + 15) / 16 * 4 <= 1024 && s.splits > 1,
+                 "sl_gemm: rstd_out needs the plain epilogue, N <= 4096 and a K-split (splits=%d; see sl_gemm_split_count)", s.splits);
+  }
   s.part = (float*)split_ws;
   s.part_ss = s.part ? s.part + (size_t)s.splits * p.M * s.np : nullptr;
   if (dtype == SL_F32) return stream_typed<float>(p, sx, act, s, c, st);

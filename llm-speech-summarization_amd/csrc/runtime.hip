@@ -349,6 +349,7 @@ constexpr int SL_MAX_DECODE_BATCH = 512;   // rows of one decode step (M of the 
 struct LlamaWs {
   void *h, *qkv, *att, *mid, *last, *part, *split;
   size_t split_bytes;
+  float *rstd_a, *rstd_b;   // RMSNorm scales handed from the o / down projection's reduce pass to the next fused GEMM
   int32_t *tok_seq, *tok_pos, *cu, *cuk, *klen;
 };
 
@@ -372,6 +373,8 @@ static size_t llama_carve(const sl_llama_model* m, int64_t n_tok, int nseq, void
     w.split_bytes = sb;
     w.split = c.take(sb);
   }
+  w.rstd_a = (float*)c.take((size_t)nseq * sizeof(float));
+  w.rstd_b = (float*)c.take((size_t)nseq * sizeof(float));
   w.tok_seq = (int32_t*)c.take(n_tok * sizeof(int32_t));
   w.tok_pos = (int32_t*)c.take(n_tok * sizeof(int32_t));
   w.cu = (int32_t*)c.take((nseq + 1) * sizeof(int32_t));
@@ -400,10 +403,12 @@ static inline size_t kv_layer_bytes(const sl_llama_model* m, const sl_kv_cache* 
 // one decoder layer over `n` token rows; attention chosen by `decode`
 // decode GEMM on the fragment-packed weights, optionally absorbing the preceding RMSNorm / RoPE+KV-append
 static int dec_gemm(const sl_llama_model* m, const LlamaWs& w, const void* A, int64_t lda, const void* Wp, void* C, int64_t ldc, const void* res,
-                    int M, int N, int K, int act, int out_f32, const sl_gemm_fused* fx_in, hipStream_t st) {
+                    int M, int N, int K, int act, int out_f32, const sl_gemm_fused* fx_in, hipStream_t st, const float* rstd_in = nullptr,
+                    float* rstd_out = nullptr) {
   sl_gemm_fused fxl;
   if (fx_in) fxl = *fx_in; else memset(&fxl, 0, sizeof(fxl));
   fxl.split_ws = w.split; fxl.split_ws_bytes = w.split_bytes;
+  fxl.rstd_in = rstd_in; fxl.rstd_out = rstd_out; fxl.rms_eps = m->rms_eps;
   const sl_gemm_fused* fx = &fxl;
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
@@ -413,8 +418,11 @@ static int dec_gemm(const sl_llama_model* m, const LlamaWs& w, const void* A, in
 }
 
 // one decoder layer over `n` token rows; attention chosen by `decode`
+// rstd_chain (decode): the o / down projections run K-split, so their reduce passes emit the RMSNorm scale of the rows
+// they store and the next fused GEMM (gate/up, next layer's qkv, lm_head) takes it instead of recomputing it per block;
+// rstd_qkv = scale of x on entry (NULL: this layer's qkv takes its own statistics)
 static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, void* x, int64_t n, LlamaWs& w, bool decode, int nseq,
-                       int max_qlen, const int32_t* ctx_len_dev, hipStream_t st) {
+                       int max_qlen, const int32_t* ctx_len_dev, hipStream_t st, bool rstd_chain = false, const float* rstd_qkv = nullptr) {
   const sl_llama_layer& L = m->layers[l];
   const int dt = m->dtype, H = m->hidden, D = m->head_dim, nh = m->n_heads, nkv = m->n_kv_heads;
   const int qkv_w = (nh + 2 * nkv) * D;
@@ -430,16 +438,19 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
     fx.k_cache = kc; fx.v_cache = vc; fx.n_heads = nh; fx.n_kv_heads = nkv; fx.max_ctx = kv->max_ctx;
     const void* a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
-    SL_TRY(dec_gemm(m, w, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st));
+    SL_TRY(dec_gemm(m, w, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st, rstd_qkv));
     SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
-    SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st));
+    SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st, nullptr,
+                    rstd_chain ? w.rstd_a : nullptr));
     sl_gemm_fused fn;
     memset(&fn, 0, sizeof(fn));
     fn.fuse_rms = m->dec_fused_norm; fn.rms_eps = m->rms_eps;
     a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
-    SL_TRY(dec_gemm(m, w, a_in, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st));
-    SL_TRY(dec_gemm(m, w, w.mid, m->ffn, L.wdown_dec, x, H, x, (int)n, H, m->ffn, SL_ACT_NONE, 0, nullptr, st));
+    SL_TRY(dec_gemm(m, w, a_in, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st,
+                    rstd_chain ? w.rstd_a : nullptr));
+    SL_TRY(dec_gemm(m, w, w.mid, m->ffn, L.wdown_dec, x, H, x, (int)n, H, m->ffn, SL_ACT_NONE, 0, nullptr, st, nullptr,
+                    rstd_chain ? w.rstd_b : nullptr));
     return 0;
   }
   SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st));
@@ -516,14 +527,23 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
                        void* x, LlamaWs& w, hipStream_t st) {
   const int dt = m->dtype, H = m->hidden;
   SL_TRY(sl_embed_gather(m->embed, next_ids, x, B, H, dt, (sl_stream)st));
-  for (int l = 0; l < m->n_layers; ++l) SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st));
+  // hand RMSNorm scales along the chain when every o / down projection has a reduce pass to compute them in
+  bool chain = m->dec_fused_norm && m->lm_head_dec && H / 16 * 4 <= 1024 && H % 16 == 0 &&
+               sl_gemm_split_count(B, H, m->n_heads * m->head_dim, dt) > 1 && sl_gemm_split_count(B, H, m->ffn, dt) > 1 && w.split != nullptr;
+  for (int l = 0; l < m->n_layers && chain; ++l) {
+    const sl_llama_layer& L = m->layers[l];
+    chain = L.wqkv_dec && L.wo_dec && L.wgu_dec && L.wdown_dec;
+  }
+  for (int l = 0; l < m->n_layers; ++l)
+    SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st, chain, (chain && l > 0) ? w.rstd_b : nullptr));
   if (m->lm_head_dec) {
     sl_gemm_fused fx;
     memset(&fx, 0, sizeof(fx));
     fx.fuse_rms = m->dec_fused_norm; fx.rms_eps = m->rms_eps;
     const void* a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.last; }
-    return dec_gemm(m, w, a_in, H, m->lm_head_dec, logits, m->vocab, nullptr, B, m->vocab, H, SL_ACT_NONE, 1, &fx, st);
+    return dec_gemm(m, w, a_in, H, m->lm_head_dec, logits, m->vocab, nullptr, B, m->vocab, H, SL_ACT_NONE, 1, &fx, st,
+                    (chain && m->n_layers > 0) ? w.rstd_b : nullptr);
   }
   SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st));
   SL_TRY(gemm(dt, w.last, H, m->lm_head, H, logits, m->vocab, nullptr, nullptr, 0, B, m->vocab, H, SL_ACT_NONE, 1, st));

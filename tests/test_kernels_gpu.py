@@ -314,6 +314,29 @@ def test_gemm_packed_fused_rmsnorm_and_silu(dt, M):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [40, 128])
+def test_gemm_packed_rstd_handoff(dt, M):
+    """K-split reduce pass emits the RMSNorm scale of the rows it stores; the next fused GEMM takes it (rstd_in)
+    instead of recomputing it: same result as the in-kernel statistics."""
+    H, Fd, K1 = 512, 1024, 2048
+    a, wo, res = rnd(M, K1, seed=40), rnd(H, K1, seed=41, std=K1 ** -0.5), rnd(M, H, seed=42)
+    assert L.lib().sl_gemm_split_count(M, H, K1, L.dtype_code(dt)) > 1
+    rstd = torch.empty(M, device=dev(), dtype=torch.float32)
+    x = ops.gemm_decode(a.to(dev(), dt), ops.pack_weight(wo.to(dev(), dt)), H, residual=res.to(dev(), dt), rstd_out=rstd, eps=1e-5)
+    xr = q(a, dt) @ q(wo, dt).T + q(res, dt)
+    assert rel_err(x.float().cpu(), xr) < TOL[dt]
+    xf = x.float().cpu()
+    assert rel_err(rstd.cpu(), torch.rsqrt(xf.pow(2).mean(-1) + 1e-5)) < 1e-5
+    g, u = rnd(Fd, H, seed=43, std=H ** -0.5), rnd(Fd, H, seed=44, std=H ** -0.5)
+    wp = ops.pack_weight(weights.interleave_gate_up(g, u).to(dev(), dt))
+    y0 = ops.gemm_decode(x, wp, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5)
+    y1 = ops.gemm_decode(x, wp, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, rstd_in=rstd)
+    y2 = ops.gemm_decode(x, wp, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, rstd_in=rstd, split_k=False)
+    assert rel_err(y1.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
+    assert rel_err(y2.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [1, 5, 16, 40, 130])
 def test_gemm_packed_rope_kv_epilogue_equals_separate_kernels(dt, M):
     arch = weights.LlamaArch(hidden_size=256, num_attention_heads=6, num_key_value_heads=2, head_dim=128,

@@ -164,6 +164,24 @@ def test_llama_batched_generate_equals_single():
         assert bool((ids[b, r.shape[0]:] == cfg.pad_token_id).all())
 
 
+@pytest.mark.parametrize("B", [40, 72, 130])
+def test_llama_large_batch_decode_equals_single(B):
+    """Batches above 32 rows decode through gemm_stream.hip (loader wave, K-split + reduce, RMSNorm scales handed down the
+    chain); every sequence must still produce exactly the ids it produces alone (fp32: bit-exact vs the oracle)."""
+    cfg = TINY_LLAMA
+    llm, sd = make_llama(cfg, 31, torch.float32)
+    gen = torch.Generator().manual_seed(6)
+    base = [torch.randn(n, cfg.hidden_size, generator=gen) * 0.05 for n in (9, 21, 14, 5, 30)]
+    llm.generation_config.eos_token_id = list(cfg.eos_token_ids)
+    refs = [lo.greedy_generate(sd, cfg, p[None], 20, use_eos=True)[0] for p in base]
+    ids = llm.generate(inputs_embeds=[base[b % 5].to(DEV) for b in range(B)], max_new_tokens=20).cpu()
+    assert ids.shape[0] == B and ids.shape[1] == max(r.shape[0] for r in refs)
+    for b in range(B):
+        r = refs[b % 5]
+        assert torch.equal(ids[b, :r.shape[0]], r), b
+        assert bool((ids[b, r.shape[0]:] == cfg.pad_token_id).all())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_llama_wide_llama32_width(dtype):
     g = golden("llama_wide")
