@@ -8,7 +8,8 @@ ref:inference.py:95-137), random-init weights of the true shapes, inputs residen
 
 Prints ONE JSON line (rank 0).  value = generated tokens/s of the whole job (all ranks, all pipeline
 stages inside the timed region); audio_sec_per_s = encoder-stage throughput from HIP events in the same
-steps.  roofline = the dominant decode kernel (gate/up weight-streaming GEMM) against the HBM peak.
+steps.  roofline = the decode kernel with the largest share of the step (split attention over the KV cache at
+the default batch of 256, the gate/up weight-streaming GEMM below ~128) against the HBM peak; roofline_other = the other.
 cpu_baseline = the CPU oracle (oracle/*.py, a port of the reference's HF path) on a bounded sample.
 Multi-GPU: inference shards by utterance, replicas only, no data-path collective (weak scaling).
 """
@@ -193,7 +194,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="utterances per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="utterances per step per GPU")
     ap.add_argument("--audio-sec", type=float, default=10.0)
     ap.add_argument("--max-new-tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -286,31 +287,53 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- roofline probe: the dominant decode kernel, launched as decode launches it, HIP events on its stream
-    gemm_probe = None
+    # ---- roofline probes: the two kernels that carry the decode step (gate/up weight-streaming GEMM, split attention over
+    # the KV cache), launched as the decode graph launches them, timed with HIP events on the stream they run on
+    probes = None
     if rank == 0:
         ops = mod("ops")
         H, F_ = larch.hidden_size, larch.intermediate_size
+        nh, nkv, D = larch.num_attention_heads, larch.num_key_value_heads, larch.head_dim
         xin = torch.randn(B, H, device=dev, dtype=torch.float32).to(torch.bfloat16)
         out = torch.empty(B, F_, device=dev, dtype=torch.bfloat16)
         wgu = wts.dec_wgu  # the fragment-packed, RMSNorm-folded gate/up matrices the decode graph streams
         assert len(wgu) == larch.num_hidden_layers
+        # above 32 rows the o projection's reduce pass hands the RMSNorm scale down (runtime.hip decode_step): same here
+        chain = bool(wts.struct.dec_fused_norm) and L.lib().sl_gemm_split_count(B, H, nh * D, L.dtype_code(torch.bfloat16)) > 1
+        rstd = torch.rsqrt(xin.float().pow(2).mean(-1) + larch.rms_norm_eps) if chain else None
 
-        def probe(w):
-            ops.gemm_decode(xin, w, 2 * F_, act=L.ACT_SILU_MUL, fuse_rms=bool(wts.struct.dec_fused_norm), eps=larch.rms_norm_eps, out=out)
+        def probe_gemm(i):
+            ops.gemm_decode(xin, wgu[i % len(wgu)], 2 * F_, act=L.ACT_SILU_MUL, fuse_rms=bool(wts.struct.dec_fused_norm), eps=larch.rms_norm_eps,
+                            out=out, rstd_in=rstd)
 
-        for w in wgu:
-            probe(w)
+        kc, vc = llm._kv                       # (layers, slots, n_kv, max_ctx, D): the caches the timed steps filled
+        ctx_mid = S + new // 2                  # mean context of the decode phase
+        ctx = torch.full((B,), ctx_mid, device=dev, dtype=torch.int32)
+        qp = torch.randn(B, nh * D, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        ao = torch.empty(B, nh * D, device=dev, dtype=torch.bfloat16)
+        aws = torch.empty(int(L.lib().sl_attn_decode_workspace_bytes(B, nh, nkv, llm.max_ctx)), dtype=torch.uint8, device=dev)
+
+        def probe_attn(i):
+            l = i % kc.shape[0]
+            ops.attn_decode_split(qp, nh * D, kc[l], vc[l], ctx, nh, nkv, D, llm.max_ctx, D ** -0.5, out=ao, ws=aws)
+
+        def timed(fn, n):
+            for i in range(len(wgu)):
+                fn(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+
         n_probe = 8 * len(wgu)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(n_probe):
-            probe(wgu[i % len(wgu)])
-        e1.record()
-        torch.cuda.synchronize()
-        dur_ms = e0.elapsed_time(e1) / n_probe
-        alg_bytes = 2 * F_ * H * 2 + B * H * 2 + B * F_ * 2  # weights once + activations in/out
-        gemm_probe = (alg_bytes, dur_ms)
+        gemm_ms = timed(probe_gemm, n_probe)
+        attn_ms = timed(probe_attn, n_probe)     # split + merge launches together
+        gemm_bytes = 2 * F_ * H * 2 + B * H * 2 + B * F_ * 2            # weights once + activations in/out
+        attn_bytes = B * nkv * ctx_mid * D * 2 * 2 + 2 * B * nh * D * 2  # K and V rows once + q in / o out
+        probes = {"gemm": (gemm_bytes, gemm_ms), "attn": (attn_bytes, attn_ms)}
 
     # ---- KD training leg (BASELINE configs[2]): one optimizer step = grad_accum_interval micro-steps shared by the ranks,
     # fp32 gradient buckets all-reduced with RCCL on a side stream while backward still runs
@@ -328,15 +351,23 @@ def main():
 
     tokens = B * new * args.steps * world
     mean = lambda v: sum(v) / max(1, len(v))
-    alg_bytes, dur_ms = gemm_probe
-    achieved = alg_bytes / (dur_ms * 1e-3) / 1e9
-    traffic = None
-    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md) of the kernel this batch runs
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md), where measured for this batch
     streaming = B > 32
-    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_gateup_stream.json" if streaming else "r01_pmc_gateup.json")
-    if os.path.exists(pmc_path) and B in (16, 128):   # measured at M = 16 (skinny) and M = 128 (streaming) only
+    pmc = {}
+    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_decode_kernels.json")
+    if os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            pmc = json.load(f).get(str(B), {})
+
+    def roof(name, key):
+        alg, ms = probes[key]
+        ach = alg / (ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": pmc.get(key), "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2)}
+
+    r_gemm = roof(("gemm_stream_kernel" if streaming else "gemm_skinny_kernel") + "<bf16, SILU_MUL> (gate/up projection, decode)", "gemm")
+    r_attn = roof("attn_decode_split_kernel<bf16> + merge (one-token GQA attention over the KV cache, decode)", "attn")
+    dominant, other = (r_attn, r_gemm) if probes["attn"][1] > probes["gemm"][1] else (r_gemm, r_attn)
     dec_step_ms = mean(decode_ms) / max(1, new - 1)
     step_bytes = wts.weight_bytes_per_token() + B * (S + new / 2) * 2 * larch.num_key_value_heads * larch.head_dim * 2 * larch.num_hidden_layers
     result = {
@@ -352,9 +383,7 @@ def main():
                      "decode_per_step": round(dec_step_ms, 4)},
         "decode_step_hbm": {"algorithmic_GB": round(step_bytes / 1e9, 3), "achieved_GBps": round(step_bytes / (dec_step_ms * 1e-3) / 1e9, 1),
                             "frac_of_peak": round(step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "roofline": {"kernel": ("gemm_stream_kernel" if streaming else "gemm_skinny_kernel") + "<bf16, SILU_MUL> (gate/up projection, decode)", "bound": "hbm",
-                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(dur_ms * 1e3, 2)},
+        "roofline": dominant, "roofline_other": other,
     }
     if kd is not None:
         result["kd_step"] = kd

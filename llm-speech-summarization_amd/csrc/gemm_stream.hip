@@ -356,7 +356,7 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
   const int mblocks = (M + c.mt * 16 - 1) / (c.mt * 16);
   const int nfrag = (N + 15) / 16;
   const int nst = K / (2 * kstep);
-  c.nwv = (nfrag + 7) / 8 * mblocks >= 512 ? 4 : 2;
+  c.nwv = ((nfrag + 7) / 8 * mblocks >= 512 && c.mt <= 8) ? 4 : 2;   // 4 compute + 2 loader waves of 256-row blocks spill
   c.d = 4;
   int sp_env = 0;
   const char* e = getenv("SL_STREAM_CFG");  // tuning override "splits,nwv" (tools/tune_stream.py)

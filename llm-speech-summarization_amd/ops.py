@@ -211,10 +211,12 @@ def _split_ws(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def attn_decode_split(q, q_stride, k_cache, v_cache, ctx_len, n_heads, n_kv, D, max_ctx, scale) -> torch.Tensor:
+def attn_decode_split(q, q_stride, k_cache, v_cache, ctx_len, n_heads, n_kv, D, max_ctx, scale, out=None, ws=None) -> torch.Tensor:
     B = ctx_len.shape[0]
-    out = torch.empty((B, n_heads * D), device=q.device, dtype=q.dtype)
-    ws = torch.empty(int(L.lib().sl_attn_decode_workspace_bytes(B, n_heads, n_kv, max_ctx)), dtype=torch.uint8, device=q.device)
+    if out is None:
+        out = torch.empty((B, n_heads * D), device=q.device, dtype=q.dtype)
+    if ws is None:
+        ws = torch.empty(int(L.lib().sl_attn_decode_workspace_bytes(B, n_heads, n_kv, max_ctx)), dtype=torch.uint8, device=q.device)
     L.check(L.lib().sl_attn_decode_split(L.ptr(q), q_stride, L.ptr(k_cache), L.ptr(v_cache), L.ptr(out), L.ptr(ws), L.ptr(ctx_len), B,
                                          n_heads, n_kv, D, max_ctx, scale, L.dtype_code(q.dtype), L.stream_ptr()), "sl_attn_decode_split")
     return out
