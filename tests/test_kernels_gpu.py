@@ -381,3 +381,23 @@ def test_attn_decode_split_matches_reference(dt, nh, nkv):
         ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
         assert rel_err(out[s], ref[0]) < TOL[dt]
         assert rel_err(out1[s], ref[0]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("nh,nkv", [(6, 2), (2, 2)])
+def test_attn_decode_split_large_batch(dt, nh, nkv):
+    """Decode batches in the hundreds: split + merge against the per-sequence single-pass kernel and the reference."""
+    D, max_ctx, B = 128, 200, 512
+    lens = [1 + (37 * i) % max_ctx for i in range(B)]
+    lens[:6] = [1, 63, 64, 65, 128, 200]
+    kc = rnd(B, nkv, max_ctx, D, seed=43).to(dev(), dt)
+    vc = rnd(B, nkv, max_ctx, D, seed=44).to(dev(), dt)
+    qd = rnd(B, nh * D, seed=45).to(dev(), dt)
+    ctx = torch.tensor(lens, dtype=torch.int32, device=dev())
+    out = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    out1 = ops.attn_decode(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()   # per-sequence single-pass kernel
+    assert rel_err(out, out1) < TOL[dt]
+    for s in list(range(8)) + [100, 311, 511]:
+        n = lens[s]
+        ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
+        assert rel_err(out[s], ref[0]) < TOL[dt]
