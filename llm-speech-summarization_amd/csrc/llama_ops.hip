@@ -365,9 +365,9 @@ extern "C" int sl_pack_weight(const void* src, int64_t ld_src, void* dst, int32_
 //   context in 64-key chunks with an online softmax and the next chunk prefetched — no partial records, no merge launch —
 //   was 20 % slower than split + merge at B = 128 and 256: the serial chunk chain exposes three barriers per 32 KiB.)
 // ----------------------------------------------------------------------------------------------
-constexpr int DSPLIT = 64;  // keys per block
+constexpr int DSPLIT = 64;  // keys per block (KS = 128 for batches that fill the chip anyway: half the records to merge)
 
-template <typename T, int REP>
+template <typename T, int REP, int KS>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restrict__ q, int64_t q_stride, const T* __restrict__ kc,
                                                                 const T* __restrict__ vc, float* __restrict__ part,
                                                                 const int32_t* __restrict__ ctx_len, int ctx_add, int nkv, int max_ctx,
@@ -376,18 +376,19 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int EPL = D / 16, CPLN = EPL / VEC;
   constexpr int PSTRIDE = REP * D + 2 * REP;  // floats per partial record
-  __shared__ float sc[REP][DSPLIT];
+  constexpr int NPS = KS / 16;   // passes of 16 keys
+  __shared__ float sc[REP][KS];
   __shared__ float red[16][REP][D];
   const int kvh = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, gl = lane & 15;
   const int n_keys = ctx_len[b] + ctx_add;
-  const int k0 = sp * DSPLIT;
+  const int k0 = sp * KS;
   float* rec = part + (((int64_t)b * nkv + kvh) * nsplit + sp) * PSTRIDE;
   if (k0 >= n_keys) {  // empty split: neutral record
     if (tid < REP) { rec[REP * D + tid] = -INFINITY; rec[REP * D + REP + tid] = 0.f; }
     return;
   }
-  const int nk = (n_keys - k0) < DSPLIT ? (n_keys - k0) : DSPLIT;
+  const int nk = (n_keys - k0) < KS ? (n_keys - k0) : KS;
   const T* kbase = kc + (((int64_t)b * nkv + kvh) * max_ctx + k0) * D;
   const T* vbase = vc + (((int64_t)b * nkv + kvh) * max_ctx + k0) * D;
 
@@ -399,9 +400,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
 #pragma unroll
     for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(*(const uint4*)(qp + c * VEC), &qr[h][c * VEC]);
   }
-  uint4 kraw[4][CPLN];
+  uint4 kraw[NPS][CPLN];
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     int key = ps * 16 + wave * 4 + grp;
     key = key < nk ? key : nk - 1;
 #pragma unroll
@@ -409,16 +410,16 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   }
   // V rows for phase 3 are requested now: their HBM latency hides behind the score / softmax phases
   const int kg = tid >> 4, dc = tid & 15;
-  uint4 vraw[4][CPLN];
+  uint4 vraw[NPS][CPLN];
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     int key = kg + 16 * ps;
     key = key < nk ? key : nk - 1;
 #pragma unroll
     for (int c = 0; c < CPLN; ++c) vraw[ps][c] = *(const uint4*)(vbase + (int64_t)key * D + dc * EPL + c * VEC);
   }
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     const int key = ps * 16 + wave * 4 + grp;
     float kf[EPL];
 #pragma unroll
@@ -435,11 +436,18 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   __syncthreads();
   // phase 2: local softmax, one wave per head, one key per lane
   for (int h = wave; h < REP; h += 4) {
-    const float s = sc[h][lane];
-    const float m = wave_max(s);
-    const float p = __expf(s - m);  // masked keys: exp(-inf) = 0
-    const float l = wave_sum(p);
-    sc[h][lane] = p;
+    float sv[KS / 64], m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KS / 64; ++j) { sv[j] = sc[h][lane + 64 * j]; m = fmaxf(m, sv[j]); }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS / 64; ++j) {
+      const float p = __expf(sv[j] - m);  // masked keys: exp(-inf) = 0
+      sc[h][lane + 64 * j] = p;
+      l += p;
+    }
+    l = wave_sum(l);
     if (lane == 0) { rec[REP * D + h] = m; rec[REP * D + REP + h] = l; }
   }
   __syncthreads();
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
 #pragma unroll
       for (int e = 0; e < EPL; ++e) acc[h][e] = 0.f;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < NPS; ++ps) {
       const int key = kg + 16 * ps;
       float vf[EPL];
 #pragma unroll
@@ -501,16 +509,23 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 }
 
 size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx) {
-  const int rep = n_heads / n_kv, nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;
+  const int rep = n_heads / n_kv, nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;   // sized for the finer split
   return (size_t)B * n_kv * nsplit * (rep * 128 + 2 * rep) * sizeof(float);
 }
 
 template <typename T, int REP>
 static int launch_attn_decode_split(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, float* part,
                                     const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
-  const int nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;
-  hipLaunchKernelGGL((attn_decode_split_kernel<T, REP>), dim3(nkv, B, nsplit), dim3(256), 0, st, (const T*)q, q_stride, (const T*)kc,
-                     (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale);
+  int nsplit;
+  if ((int64_t)B * nkv >= 512) {
+    nsplit = (max_ctx + 127) / 128;
+    hipLaunchKernelGGL((attn_decode_split_kernel<T, REP, 128>), dim3(nkv, B, nsplit), dim3(256), 0, st, (const T*)q, q_stride, (const T*)kc,
+                       (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale);
+  } else {
+    nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;
+    hipLaunchKernelGGL((attn_decode_split_kernel<T, REP, DSPLIT>), dim3(nkv, B, nsplit), dim3(256), 0, st, (const T*)q, q_stride, (const T*)kc,
+                       (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale);
+  }
   SL_CHECK_LAUNCH("attn_decode_split");
   hipLaunchKernelGGL((attn_decode_combine_kernel<T>), dim3(nh, B), dim3(128), 0, st, part, (T*)out, nh, nkv, nsplit);
   SL_CHECK_LAUNCH("attn_decode_combine");
