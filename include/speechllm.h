@@ -57,7 +57,8 @@ int sl_device_arch(char* buf, int n);  /* gcnArchName of the current device, e.g
  *   bias (N) and residual (M, Nout; row stride ldr) may be NULL.  Order: +bias, act, +residual.
  *   out_f32 != 0 writes C as float regardless of dtype (logits).
  *   Requirements: K % 8 == 0 (bf16) / K % 4 == 0 (f32); A, W 16-byte aligned rows.
- *   M <= 64 dispatches to the weight-streaming (HBM-bound) skinny kernel used by decode.
+ *   M <= 64 with row-major weights dispatches to the weight-streaming (HBM-bound) skinny kernel; packed weights
+ *   (sl_pack_weight) run the skinny kernel up to 32 rows and the LDS-staged streaming kernel (gemm_stream.hip) above.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   const void* A; int64_t lda; int64_t strideA;
@@ -70,7 +71,7 @@ typedef struct {
 } sl_gemm_args;
 int sl_gemm(const sl_gemm_args* a, sl_stream stream);
 
-/* Fragment-major weight packing for the decode (M <= 64) weight-streaming kernel:
+/* Fragment-major weight packing for the decode weight-streaming kernels:
  *   dst[f][s][lane][e] = src[16 f + (lane & 15)][KSTEP s + VEC (lane >> 4) + e],  VEC = 8 (bf16) / 4 (f32),
  *   KSTEP = 4 VEC, f < ceil(N/16) (rows past N are zero), so one wave-level weight load is 1 KiB contiguous
  *   (+25..45 % HBM throughput over 16 x 64-byte row segments, tools/tune_skinny.hip).  K %% KSTEP == 0.
@@ -354,7 +355,7 @@ int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, void* x, co
                      size_t workspace_bytes, sl_stream stream);
 
 /* One KV-cached decode step for B sequences: embeds next_ids, runs all layers with M = B, writes
- * logits (B, vocab) fp32 (B <= 64).  The new token's K/V are appended at position ctx_len[b] and
+ * logits (B, vocab) fp32 (B <= 512).  The new token's K/V are appended at position ctx_len[b] and
  * ctx_len[b]+1 keys are attended; ctx_len itself is advanced by sl_greedy_select.  Reads/writes only
  * device state, so the call is hipGraph-capturable.  Workspace: sl_llama_workspace_bytes(m, B, B) + B*hidden. */
 int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids_dev,
