@@ -24,25 +24,27 @@ static int stream_min_m() {
 // ----------------------------------------------------------------------------------------------
 // tiled kernel
 // ----------------------------------------------------------------------------------------------
-// shared epilogue of the tiled kernels: +bias, [aux store], act, +residual, store
-template <typename T, int ACT>
-__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[4][4], int bm, int bn, int wm, int wn, int q, int r, int z, int wz) {
+// shared epilogue of the tiled kernels: +bias, [aux store], act, +residual, store.  The wave owns MT x NT 16x16 fragments
+// whose first row / column in the output are row_base / col_base (lane (r, q) holds rows 4q..4q+3 of column r of each).
+template <typename T, int ACT, int MT, int NT>
+__device__ __forceinline__ void tile_epilogue_g(const GemmP& p, f32x4 (&acc)[MT][NT], int row_base, int col_base, int q, int r, int z, int wz) {
   const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
   void* Cb = p.out_f32 ? (void*)((float*)p.C + co) : (void*)((T*)p.C + co);
   const T* bias = p.bias ? (const T*)p.bias + (int64_t)wz * p.sBias : nullptr;
   const void* Rb = p.res ? (p.res_f32 ? (const void*)((const float*)p.res + ro) : (const void*)((const T*)p.res + ro)) : nullptr;
-  const int row0 = bm * TBM + wm * 64 + q * 4;
-  const int col0 = bn * TBN + wn * 64 + r;
+  const int row0 = row_base + q * 4;
+  const int col0 = col_base + r;
   if constexpr (ACT == SL_ACT_SILU_MUL) {
+    static_assert(NT % 2 == 0, "gate/up fragments come in pairs");
     const int nout = p.N >> 1;
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
+    for (int pr = 0; pr < NT / 2; ++pr) {
       const int gcol = col0 + (2 * pr) * 16, ucol = gcol + 16;
-      const int ocol = ((bn * TBN + wn * 64) >> 1) + pr * 16 + r;
+      const int ocol = (col_base >> 1) + pr * 16 + r;
       if (ocol >= nout) continue;
       const float bg = bias ? to_f32(bias[gcol]) : 0.f, bu = bias ? to_f32(bias[ucol]) : 0.f;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = row0 + m * 16 + i;
@@ -51,12 +53,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
     }
   } else {
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < NT; ++n) {
       const int col = col0 + n * 16;
       if (col >= p.N) continue;
       const float b = bias ? to_f32(bias[col]) : 0.f;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = row0 + m * 16 + i;
@@ -69,6 +71,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
         }
     }
   }
+}
+
+template <typename T, int ACT>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[4][4], int bm, int bn, int wm, int wn, int q, int r, int z, int wz) {
+  tile_epilogue_g<T, ACT, 4, 4>(p, acc, bm * TBM + wm * 64, bn * TBN + wn * 64, q, r, z, wz);
 }
 
 template <typename T, int ACT>
@@ -316,6 +323,99 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each), same K slabs / swizzled LDS image / LDS-DMA staging as above.
+// Why: measured, a CU sustains only ~40 GB/s of operand fetches (L2 hits + HBM through one miss queue) — the 128^2 tile
+// needs 32 KiB per 2*128*128*64 FLOP and tops out at 600-980 TF/s on that, not on the MFMA pipe.  The 256^2 tile halves
+// the bytes per FLOP; one block per CU (128 KiB of LDS), two waves per SIMD.
+// ----------------------------------------------------------------------------------------------
+constexpr int XBM = 256, XBN = 256;
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int BK = TROWB / (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][XBM * TROWB];   // [buf][A|W], 32 KiB each
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int bn = bid / p.tiles_m, bm = bid - bn * p.tiles_m;
+  const int z = blockIdx.y;
+  int64_t a_off; int wz;
+  if (!resolve_group(p, z, bm, a_off, wz, XBM)) return;
+  const T* A = (const T*)p.A + a_off;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW;
+
+  // LDS chunk c = tid + 512 i sits at (row c>>3, physical chunk c&7) and must hold logical chunk (c&7)^(row&7)
+  const T* ga[4];
+  const T* gw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 512 * i, row = c >> 3, ch = (c & 7) ^ (row & 7);
+    int ar = bm * XBM + row; ar = ar < p.M ? ar : p.M - 1;
+    int wr = bn * XBN + row; wr = wr < p.N ? wr : p.N - 1;
+    ga[i] = A + (int64_t)ar * p.lda + ch * VEC;
+    gw[i] = W + (int64_t)wr * p.ldw + ch * VEC;
+  }
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;  // this wave's 1 KiB piece inside an 8 KiB group
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = p.K / BK;
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[i] + k0), (lds_ptr_t)(&smem[buf][0][i * 8192 + wave_lds]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(gw[i] + k0), (lds_ptr_t)(&smem[buf][1][i * 8192 + wave_lds]), 16, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+    const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(&smem[buf][0][0]);
+    const uint32_t ra = sb + (uint32_t)((wm * 128 + r) * TROWB), rb = sb + (uint32_t)(XBM * TROWB + (wn * 64 + r) * TROWB);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint32_t xs = (uint32_t)(((s * 4 + q) ^ (r & 7)) << 4);
+      u32x4_t a[8], b[4];
+      SL_LDS_RD(a[0], ra + xs, 0); SL_LDS_RD(a[1], ra + xs, 2048); SL_LDS_RD(a[2], ra + xs, 4096); SL_LDS_RD(a[3], ra + xs, 6144);
+      SL_LDS_RD(b[0], rb + xs, 0); SL_LDS_RD(b[1], rb + xs, 2048); SL_LDS_RD(b[2], rb + xs, 4096); SL_LDS_RD(b[3], rb + xs, 6144);
+      SL_LDS_RD(a[4], ra + xs, 8192); SL_LDS_RD(a[5], ra + xs, 10240); SL_LDS_RD(a[6], ra + xs, 12288); SL_LDS_RD(a[7], ra + xs, 14336);
+      lds_wait8<4>(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], as_uint4(a[m]), as_uint4(b[n]));
+      __builtin_amdgcn_sched_barrier(0);
+      lds_wait8<0>(a[4], a[5], a[6], a[7], b[0], b[1], b[2], b[3]);
+#pragma unroll
+      for (int m = 4; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], as_uint4(a[m]), as_uint4(b[n]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, q, r, z, wz);
+}
+
+// ----------------------------------------------------------------------------------------------
 // skinny kernel (M <= 16*MT): HBM-bound weight streaming for decode.
 //   block = RF 16-row weight fragments x NW waves; wave w takes 64-byte k-steps w, w+NW, ... with U steps
 //   of loads in flight; W fragments go global -> VGPR -> MFMA (A operand), the M activation rows are the
@@ -540,6 +640,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX s
 // ----------------------------------------------------------------------------------------------
 template <typename T, int ACT>
 static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
+  constexpr int BK_ = TROWB / (int)sizeof(T);
+  // large products: 256^2 tiles once they alone give every CU >= 2 tiles (ragged batches: sized by the largest group)
+  if (!p.ta && !p.tw && p.K % BK_ == 0 && g_disable_glds == 0 && !getenv("SL_DISABLE_T256")) {
+    const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
+    if (t256 >= 512 && p.N >= 192) {
+      p.tiles_m = (p.M + XBM - 1) / XBM;
+      p.tiles_n = (p.N + XBN - 1) / XBN;
+      hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+      SL_CHECK_LAUNCH("gemm_tiled256");
+      return 0;
+    }
+  }
   p.tiles_m = (p.M + TBM - 1) / TBM;
   p.tiles_n = (p.N + TBN - 1) / TBN;
   dim3 grid(p.tiles_m * p.tiles_n, batch);

@@ -19,7 +19,7 @@ struct GemmP {
 };
 
 // resolve the per-batch descriptor: returns false when this block's tile lies outside batch z's rows
-__device__ __forceinline__ bool resolve_group(GemmP& p, int z, int bm, int64_t& a_off, int& wz) {
+__device__ __forceinline__ bool resolve_group(GemmP& p, int z, int bm, int64_t& a_off, int& wz, int tile_rows = 128) {
   p.cx = 0; p.rx = 0;
   wz = z;
   a_off = (int64_t)z * p.sA;
@@ -30,7 +30,7 @@ __device__ __forceinline__ bool resolve_group(GemmP& p, int z, int bm, int64_t& 
     p.cx = g[2] - (int64_t)z * p.sC;   // the epilogue adds z*sC back
     p.rx = g[3] - (int64_t)z * p.sR;
     wz = z % p.w_mod;
-    if (bm * 128 >= p.M) return false;
+    if (bm * tile_rows >= p.M) return false;
   }
   return true;
 }

@@ -57,6 +57,40 @@ def test_gemm_tiled_bias_gelu_residual(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(40000, 1000, 128), (16500, 2050, 192), (131072, 256, 64)])
+def test_gemm_tiled_256_tile(dt, M, N, K):
+    """>= 512 tiles of 256 x 256: the 8-wave kernel (ragged M / N edges, every epilogue)."""
+    A, W, b, R = rnd(M, K, seed=51), rnd(N, K, seed=52, std=K ** -0.5), rnd(N, seed=53), rnd(M, N, seed=54)
+    Ad, Wd = A.to(dev(), dt), W.to(dev(), dt)
+    ref = F.gelu(q(A, dt) @ q(W, dt).T + q(b, dt)) + q(R, dt)
+    out = ops.gemm(Ad, Wd, bias=b.to(dev(), dt), residual=R.to(dev(), dt), act=L.ACT_GELU)
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+    out2 = ops.gemm(Ad, Wd, out_f32=True)
+    assert rel_err(out2.cpu(), q(A, dt) @ q(W, dt).T) < 2e-5
+    if N % 32 == 0:
+        g, u = W[: N // 2], W[N // 2:]
+        wgu = weights.interleave_gate_up(g, u).to(dev(), dt)
+        ref3 = F.silu(q(A, dt) @ q(g, dt).T) * (q(A, dt) @ q(u, dt).T)
+        assert rel_err(ops.gemm(Ad, wgu, act=L.ACT_SILU_MUL).float().cpu(), ref3) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_tiled_256_tile_grouped_ragged(dt):
+    """Ragged batch (per-group row counts and offsets) through the 256-tile kernel: one launch for all groups."""
+    Ms, N, K = [30000, 70001, 257, 45000], 512, 128
+    offs = [0]
+    for m in Ms:
+        offs.append(offs[-1] + m)
+    A, W, b = rnd(offs[-1], K, seed=55), rnd(N, K, seed=56, std=K ** -0.5), rnd(N, seed=57)
+    Ad, Wd, bd = A.to(dev(), dt), W.to(dev(), dt), b.to(dev(), dt)
+    out = torch.zeros(offs[-1], N, device=dev(), dtype=dt)
+    grp = torch.tensor([[m, offs[i] * K, offs[i] * N, 0] for i, m in enumerate(Ms)], dtype=torch.int64, device=dev())
+    ops.gemm_ex(Ad, Wd, M=max(Ms), N=N, K=K, lda=K, ldw=K, out=out, ldc=N, bias=bd, act=L.ACT_GELU, batch=len(Ms), groups=grp, w_mod=1)
+    ref = F.gelu(q(A, dt) @ q(W, dt).T + q(b, dt))
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [1, 3, 16, 17, 32, 50, 64])
 @pytest.mark.parametrize("N,K", [(3072, 3072), (160, 8192), (1000, 256), (48, 40)])
 def test_gemm_skinny(dt, M, N, K):
