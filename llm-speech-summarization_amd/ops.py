@@ -249,8 +249,11 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     return out
 
 
-def dgrad(dY: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dX (M, K_in) = dY (M, N_out) . W (N_out, K_in)."""
+def dgrad(dY: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None, wt: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX (M, K_in) = dY (M, N_out) . W (N_out, K_in).  wt: W stored transposed (K_in, N_out), contiguous — then the
+    product is a plain K-contiguous GEMM and runs the LDS-DMA tiled kernels instead of the transposed-operand loader."""
+    if wt is not None:
+        return gemm(dY, wt, out=out)
     M, Nout = dY.shape
     Kin = W.shape[1]
     if out is None:

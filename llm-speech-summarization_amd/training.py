@@ -91,6 +91,13 @@ class LlamaTape:
         self.llm = llm
         self.w = llm._dev()
         self.a = llm.arch
+        self._wt: Dict[tuple, torch.Tensor] = {}   # frozen weights stored transposed for the data-gradient GEMMs (+1 copy)
+
+    def _t(self, li: int, name: str) -> torch.Tensor:
+        key = (li, name)
+        if key not in self._wt:
+            self._wt[key] = self.w.layer_t[li][name].t().contiguous()
+        return self._wt[key]
 
     def forward(self, x: torch.Tensor, seqlens: Sequence[int], save: bool = True):
         """x: (sum S_i, H) packed embeddings.  Returns (hidden_states: L+1 packed tensors [hidden_states[l] = input of
@@ -140,17 +147,17 @@ class LlamaTape:
         for li in reversed(range(a.num_hidden_layers)):
             lw = w.layer_t[li]
             x, qkv, x2, gu = tape["layers"][li]
-            d_mid = ops.dgrad(dx, lw["wdown"])
+            d_mid = ops.dgrad(dx, lw["wdown"], wt=self._t(li, "wdown"))
             d_gu = ops.silu_mul_bwd(gu, d_mid)
-            d_h2 = ops.dgrad(d_gu, lw["wgu"])
+            d_h2 = ops.dgrad(d_gu, lw["wgu"], wt=self._t(li, "wgu"))
             dx2 = ops.rmsnorm_bwd(x2, lw["norm2"], d_h2, a.rms_norm_eps)
             ops.axpby(dx, dx2)                                  # dx2 += dx (residual join)
-            d_att = ops.dgrad(dx2, lw["wo"])
+            d_att = ops.dgrad(dx2, lw["wo"], wt=self._t(li, "wo"))
             d_qkv = torch.empty_like(qkv)
             for s in range(len(seqlens)):
                 attention_backward(qkv[offs[s]:offs[s + 1]], d_att[offs[s]:offs[s + 1]], d_qkv[offs[s]:offs[s + 1]], nh, nkv, D, True, D ** -0.5)
             ops.rope_inplace(d_qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D, inverse=True)
-            d_h1 = ops.dgrad(d_qkv, lw["wqkv"])
+            d_h1 = ops.dgrad(d_qkv, lw["wqkv"], wt=self._t(li, "wqkv"))
             dxin = ops.rmsnorm_bwd(x, lw["norm1"], d_h1, a.rms_norm_eps)
             ops.axpby(dx2, dxin)
             if li in d_hidden:
@@ -279,19 +286,19 @@ class EncoderTape:
             lt, c = W.layer_t[li], tape["layers"][li]
             p = f"l{li}."
             ops.wgrad_acc(dx, c["mid"], g[p + "w2"]); ops.colsum_acc(dx, g[p + "b2"])
-            d_mid = ops.dgrad(dx, lt["w2"])
+            d_mid = ops.dgrad(dx, lt["w2"], wt=lt["w2"].t().contiguous())   # weights move every optimizer step: transposed on the fly
             d_pre1 = ops.gelu_bwd(d_mid, c["pre1"])
             ops.wgrad_acc(d_pre1, c["ln2"], g[p + "w1"]); ops.colsum_acc(d_pre1, g[p + "b1"])
-            d_ln2 = ops.dgrad(d_pre1, lt["w1"])
+            d_ln2 = ops.dgrad(d_pre1, lt["w1"], wt=lt["w1"].t().contiguous())
             dx_mid = ops.layernorm_bwd(c["x_mid"], lt["ln2_g"], lt["ln2_b"], d_ln2, a.layer_norm_eps, g[p + "ln2_g"], g[p + "ln2_b"])
             ops.axpby(dx, dx_mid)
             ops.wgrad_acc(dx_mid, c["att"], g[p + "wo"]); ops.colsum_acc(dx_mid, g[p + "bo"])
-            d_att = ops.dgrad(dx_mid, lt["wo"])
+            d_att = ops.dgrad(dx_mid, lt["wo"], wt=lt["wo"].t().contiguous())
             d_qkv = torch.empty_like(c["qkv"])
             for u in range(B):
                 attention_backward(c["qkv"][toff[u]:toff[u + 1]], d_att[toff[u]:toff[u + 1]], d_qkv[toff[u]:toff[u + 1]], nh, nh, 64, False, 0.125)
             ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
-            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"])
+            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=lt["wqkv"].t().contiguous())
             dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, a.layer_norm_eps, g[p + "ln1_g"], g[p + "ln1_b"])
             ops.axpby(dx_mid, dxin)
             dx = dxin
