@@ -233,7 +233,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
     const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   }
-  const int bn = bid / p.tiles_m, bm = bid - bn * p.tiles_m;
+  int bm, bn;   // 8 x 8 patches of tiles per XCD at a time (see gemm_tiled256_kernel)
+  {
+    constexpr int GM = 8;
+    const int per = GM * p.tiles_n, grp = bid / per, first = grp * GM;
+    const int gsz = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
+    const int in = bid - grp * per;
+    bm = first + in % gsz;
+    bn = in / gsz;
+  }
   const int z = blockIdx.y;
   int64_t a_off; int wz;
   if (!resolve_group(p, z, bm, a_off, wz)) return;
@@ -326,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 // 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each), same K slabs / swizzled LDS image / LDS-DMA staging as above.
 // Why: measured, a CU sustains only ~40 GB/s of operand fetches (L2 hits + HBM through one miss queue) — the 128^2 tile
 // needs 32 KiB per 2*128*128*64 FLOP and tops out at 600-980 TF/s on that, not on the MFMA pipe.  The 256^2 tile halves
-// the bytes per FLOP; one block per CU (128 KiB of LDS), two waves per SIMD.
+// the bytes per FLOP; one block per CU (128 KiB of LDS), two waves per SIMD.  (A four-stage ring of 64-byte slabs with
+// three slabs of DMA in flight — swizzle c ^ ((row >> 2) & 2) for conflict-free reads of 64-byte rows — measured 5-8 %
+// SLOWER: the limit is the fetch rate per CU, not its latency; what helped is sharing slabs in L2, below.)
 // ----------------------------------------------------------------------------------------------
 constexpr int XBM = 256, XBN = 256;
 
@@ -345,7 +355,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
     const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   }
-  const int bn = bid / p.tiles_m, bm = bid - bn * p.tiles_m;
+  // blocks that run together on an XCD (consecutive ids) cover an 8 x 4 patch of tiles, so they share A and W slabs in
+  // that XCD's L2 (walking M only shares W: 33 slab streams per 32 blocks from beyond L2 instead of 12)
+  int bm, bn;
+  {
+    constexpr int GM = 8;
+    const int per = GM * p.tiles_n, grp = bid / per, first = grp * GM;
+    const int gsz = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
+    const int in = bid - grp * per;
+    bm = first + in % gsz;
+    bn = in / gsz;
+  }
   const int z = blockIdx.y;
   int64_t a_off; int wz;
   if (!resolve_group(p, z, bm, a_off, wz, XBM)) return;
@@ -644,7 +664,7 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   // large products: 256^2 tiles once they alone give every CU >= 2 tiles (ragged batches: sized by the largest group)
   if (!p.ta && !p.tw && p.K % BK_ == 0 && g_disable_glds == 0 && !getenv("SL_DISABLE_T256")) {
     const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
-    if (t256 >= 512 && p.N >= 192) {
+    if (t256 >= 512 && p.N >= 192 && p.K >= 2048) {   // short K: the 128 tile's two blocks per CU hide the pro/epilogue better
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
       hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);

@@ -57,7 +57,7 @@ def test_gemm_tiled_bias_gelu_residual(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,N,K", [(40000, 1000, 128), (16500, 2050, 192), (131072, 256, 64)])
+@pytest.mark.parametrize("M,N,K", [(40000, 1000, 2048), (16500, 2050, 2112), (131072, 256, 2048), (20000, 1000, 192)])
 def test_gemm_tiled_256_tile(dt, M, N, K):
     """>= 512 tiles of 256 x 256: the 8-wave kernel (ragged M / N edges, every epilogue)."""
     A, W, b, R = rnd(M, K, seed=51), rnd(N, K, seed=52, std=K ** -0.5), rnd(N, seed=53), rnd(M, N, seed=54)
@@ -77,7 +77,7 @@ def test_gemm_tiled_256_tile(dt, M, N, K):
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_tiled_256_tile_grouped_ragged(dt):
     """Ragged batch (per-group row counts and offsets) through the 256-tile kernel: one launch for all groups."""
-    Ms, N, K = [30000, 70001, 257, 45000], 512, 128
+    Ms, N, K = [30000, 70001, 257, 45000], 512, 2048
     offs = [0]
     for m in Ms:
         offs.append(offs[-1] + m)
