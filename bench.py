@@ -189,6 +189,82 @@ def mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx
             "ms_per_step": round(el / args.steps * 1e3, 2), "note": "per-rank figures (rank 0)"}
 
 
+LONGFORM_SEC = (30, 60, 120)   # long-form utterances of BASELINE configs[4]
+
+
+def longform_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, ctx_cap):
+    """BASELINE configs[4]: long-form utterances with an interleaved text prompt,
+    [prefix | additional_text_prompt[1:] | audio | suffix[1:]] (ref:inference.py:108-131), ragged batch of 16."""
+    B, new = 16, args.max_new_tokens
+    secs = [LONGFORM_SEC[i % len(LONGFORM_SEC)] for i in range(B)]
+    waves = [ri.synthetic_waveform(s * 16000, seed=9876 + rank * 1000 + i).to(dev) for i, s in enumerate(secs)]
+    text = ri.synthetic_ids(16, larch.vocab_size, seed=9, bos=larch.bos_token_id or 0)
+    emb = llm.model.embed_tokens
+    head = torch.cat([emb(prefix.to(dev))[0], emb(text.to(dev))[0, 1:]])
+    suf_e = emb(suffix.to(dev))[0, 1:]
+    n_head, n_suf = head.shape[0], suf_e.shape[0]
+    Ps = [(harch.num_frames(s * 16000) - 8) // 4 + 1 for s in secs]
+    lens = [n_head + p + n_suf for p in Ps]
+    llm.max_ctx, llm._kv = ctx_cap, None
+    starts = [0]
+    for n in lens:
+        starts.append(starts[-1] + n)
+    x = torch.empty((starts[-1], larch.hidden_size), device=dev, dtype=torch.bfloat16)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def step():
+        for b in range(B):
+            x[starts[b]:starts[b] + n_head] = head
+            x[starts[b] + n_head + Ps[b]:starts[b + 1]] = suf_e
+        ev[0].record()
+        enc.encode_packed(waves, out=x, out_row_offsets=[starts[b] + n_head for b in range(B)])
+        ev[1].record()
+        return llm.generate_packed(x, lens, new, use_eos=False)
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids, n_cols = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert n_cols == new
+    return {"utterance_sec_cycle": list(LONGFORM_SEC), "utterances": B, "additional_text_prompt_tokens": 16, "audio_sec_total": sum(secs),
+            "prompt_tokens_total": starts[-1], "tokens_per_s": round(B * new / el, 1),
+            "audio_sec_per_s": round(sum(secs) / (ev[0].elapsed_time(ev[1]) * 1e-3), 1), "ms_per_step": round(el * 1e3, 2),
+            "stage_ms": {"encode": round(ev[0].elapsed_time(ev[1]), 2), "prefill": round(llm.last_timings_ms[0], 2),
+                         "decode": round(llm.last_timings_ms[1], 2)}}
+
+
+def whisper_leg(args, mod, larch, dev, rank):
+    """BASELINE configs[3]: the alternate encoder — Whisper-medium shape, log-mel front end + encoder + pool + projector on
+    30 s windows (ref:trainer.py:168-199,280-291), random init; windows/s and audio-s/s of the encoder stage."""
+    cfgm, weights, enc_mod, ri = mod("config"), mod("weights"), mod("audio_encoder"), mod("random_init")
+    conf = cfgm.load_config(os.path.join(REPO, "config", "llama3_whisper.yaml"))
+    warch = weights.KNOWN_WHISPER["openai/whisper-medium"]
+    enc = enc_mod.AudioEncoder(conf, dev, dtype=torch.bfloat16, arch=warch)
+    enc.load_state_dict(ri.whisper_encoder_state_dict(warch, larch.hidden_size, seed=3)).eval().to(dev)
+    B = 32
+    waves = [ri.synthetic_waveform(30 * 16000, seed=555 + rank * 100 + i).to(dev) for i in range(B)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step():
+        ev[0].record()
+        feats = enc.feature_extractor(waves, return_tensors="pt", sampling_rate=16000).input_features
+        ev[1].record()
+        out = enc(feats)
+        ev[2].record()
+        return out
+
+    step()
+    out = step()
+    torch.cuda.synchronize()
+    mel_ms, enc_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    flops = B * 1.14e12   # SURVEY.md §8d: ~1.14 TFLOP per 30 s window
+    return {"model": "whisper-medium encoder shape (24 x 1024, 80 mel)", "windows": B, "window_sec": 30, "out_shape": list(out.shape),
+            "logmel_ms": round(mel_ms, 2), "encoder_ms": round(enc_ms, 2), "windows_per_s": round(B / ((mel_ms + enc_ms) * 1e-3), 1),
+            "audio_sec_per_s": round(B * 30 / ((mel_ms + enc_ms) * 1e-3), 1), "encoder_TFLOPs": round(flops / (enc_ms * 1e-3) / 1e12, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +277,7 @@ def main():
     ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (≈0.45 s each)")
     ap.add_argument("--kd-optimizer-steps", type=int, default=1, help="optimizer steps of the KD training leg (0 = skip)")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,10 +313,13 @@ def main():
     S_mix = prefix.shape[1] + (harch.num_frames(max(DEVCLEAN_MIX_SEC) * 16000) - 8) // 4 + 1 + suffix.shape[1] - 1
     max_ctx = ((S + new + 63) // 64) * 64
     mix_ctx = max_ctx if args.no_length_mix else ((max(S, S_mix) + new + 63) // 64) * 64
+    S_long = prefix.shape[1] + 15 + (harch.num_frames(max(LONGFORM_SEC) * 16000) - 8) // 4 + 1 + suffix.shape[1] - 1
+    long_ctx = ((S_long + new + 63) // 64) * 64
+    rope_ctx = mix_ctx if args.no_extra_legs else max(mix_ctx, long_ctx)
     keep_sd = dict(llm_sd) if (rank == 0 and not args.no_cpu_baseline) else None
-    llm = llama_mod.AudioLlamaForCausalLM(larch, llm_sd, torch_dtype=torch.bfloat16, device=dev, max_ctx=mix_ctx, max_batch=B)
+    llm = llama_mod.AudioLlamaForCausalLM(larch, llm_sd, torch_dtype=torch.bfloat16, device=dev, max_ctx=rope_ctx, max_batch=B)
     del llm_sd
-    wts = llm._dev()          # rope tables / split-attention workspace sized for mix_ctx
+    wts = llm._dev()          # rope tables / split-attention workspace sized for the longest leg
     llm.max_ctx = max_ctx     # the headline's KV cache (and split-attention grid) is sized for its own context
 
     # ---- synthetic inputs, resident in HBM -------------------------------------------------------------
@@ -392,6 +472,15 @@ def main():
             result["devclean_length_mix"] = mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx)
         except Exception as e:
             result["devclean_length_mix"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if not args.no_extra_legs:
+        try:
+            result["longform_text_prompt"] = longform_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, long_ctx)
+        except Exception as e:
+            result["longform_text_prompt"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            result["whisper_encoder"] = whisper_leg(args, mod, larch, dev, rank)
+        except Exception as e:
+            result["whisper_encoder"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_cpu_baseline:
         del llm, wts
         result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)
