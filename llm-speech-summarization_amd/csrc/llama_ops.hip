@@ -365,6 +365,8 @@ extern "C" int sl_pack_weight(const void* src, int64_t ld_src, void* dst, int32_
 //   context in 64-key chunks with an online softmax and the next chunk prefetched — no partial records, no merge launch —
 //   was 20 % slower than split + merge at B = 128 and 256: the serial chunk chain exposes three barriers per 32 KiB.)
 // ----------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr3_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 constexpr int DSPLIT = 64;  // keys per block (KS = 128 for batches that fill the chip anyway: half the records to merge)
 
 template <typename T, int REP, int KS>
@@ -377,8 +379,15 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   constexpr int EPL = D / 16, CPLN = EPL / VEC;
   constexpr int PSTRIDE = REP * D + 2 * REP;  // floats per partial record
   constexpr int NPS = KS / 16;   // passes of 16 keys
+  constexpr bool MFMA_QK = sizeof(T) == 2;   // bf16: scores on the matrix core (the VALU form was ~75 % VALU-busy at B = 256)
+  constexpr int KT_BYTES = MFMA_QK ? KS * D * (int)sizeof(T) : 16, RED_BYTES = 16 * REP * D * (int)sizeof(float);
   __shared__ float sc[REP][KS];
-  __shared__ float red[16][REP][D];
+  // bf16: K tile of the score MFMAs ([KS rows][256 B], chunk c of row r at c ^ (r & 15)), then — same bytes — the V tile of
+  // the P.V MFMAs ([KS rows][256 B], chunk c of row r at voff()); fp32: the cross-thread reduction buffer of the VALU form
+  __shared__ __attribute__((aligned(16))) unsigned char un[KT_BYTES > RED_BYTES ? KT_BYTES : RED_BYTES];
+  constexpr int PROW = KS * 2 + 16;   // bytes per row of the bf16 probability tile (padded: rows land on different banks)
+  __shared__ __attribute__((aligned(16))) unsigned char pt[MFMA_QK ? 16 * PROW : 16];
+  float (*red)[REP][D] = (float (*)[REP][D])un;
   const int kvh = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, gl = lane & 15;
   const int n_keys = ctx_len[b] + ctx_add;
@@ -392,45 +401,77 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   const T* kbase = kc + (((int64_t)b * nkv + kvh) * max_ctx + k0) * D;
   const T* vbase = vc + (((int64_t)b * nkv + kvh) * max_ctx + k0) * D;
 
-  // phase 1: scores, 4 passes of 16 keys, all loads issued first
-  float qr[REP][EPL];
-#pragma unroll
-  for (int h = 0; h < REP; ++h) {
-    const T* qp = q + (int64_t)b * q_stride + (int64_t)(kvh * REP + h) * D + gl * EPL;
-#pragma unroll
-    for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(*(const uint4*)(qp + c * VEC), &qr[h][c * VEC]);
-  }
-  uint4 kraw[NPS][CPLN];
+  // phase 1: scores; every K and V row of the split is requested up front (16-byte chunks, 256-byte rows coalesced)
+  u32x4_t kraw[NPS][CPLN];   // ext-vector type: HIP's uint4 struct copies to LDS went through scratch
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
     int key = ps * 16 + wave * 4 + grp;
     key = key < nk ? key : nk - 1;
 #pragma unroll
-    for (int c = 0; c < CPLN; ++c) kraw[ps][c] = *(const uint4*)(kbase + (int64_t)key * D + gl * EPL + c * VEC);
+    for (int c = 0; c < CPLN; ++c) kraw[ps][c] = *(const u32x4_t*)(kbase + (int64_t)key * D + gl * EPL + c * VEC);
   }
   // V rows for phase 3 are requested now: their HBM latency hides behind the score / softmax phases
   const int kg = tid >> 4, dc = tid & 15;
-  uint4 vraw[NPS][CPLN];
+  u32x4_t vraw[NPS][CPLN];
 #pragma unroll
   for (int ps = 0; ps < NPS; ++ps) {
     int key = kg + 16 * ps;
     key = key < nk ? key : nk - 1;
 #pragma unroll
-    for (int c = 0; c < CPLN; ++c) vraw[ps][c] = *(const uint4*)(vbase + (int64_t)key * D + dc * EPL + c * VEC);
+    for (int c = 0; c < CPLN; ++c) vraw[ps][c] = *(const u32x4_t*)(vbase + (int64_t)key * D + dc * EPL + c * VEC);
   }
+  if constexpr (MFMA_QK) {
+    // S[head][key] = Q . K^T on the matrix core: A = the REP query heads of this kv head (rows REP..15 zero), B = 16 keys
+    // from the LDS tile; wave w scores keys [w KS/4, (w+1) KS/4).  Lanes 0..15 end up holding heads 0..3 of their key.
+    const int r = lane & 15, q4 = lane >> 4;
+    uint4 qf[4];
 #pragma unroll
-  for (int ps = 0; ps < NPS; ++ps) {
-    const int key = ps * 16 + wave * 4 + grp;
-    float kf[EPL];
+    for (int s4 = 0; s4 < 4; ++s4)
+      qf[s4] = r < REP ? *(const uint4*)(q + (int64_t)b * q_stride + (int64_t)(kvh * REP + r) * D + 32 * s4 + 8 * q4) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(kraw[ps][c], &kf[c * VEC]);
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int kl = ps * 16 + wave * 4 + grp;
+      *(u32x4_t*)(un + kl * 256 + ((gl ^ (kl & 15)) << 4)) = kraw[ps][0];
+    }
+    __syncthreads();
+    constexpr int NF = KS / 64;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      const int rowbase = wave * (KS / 4) + n * 16;
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const uint4 kf = *(const uint4*)(un + (rowbase + r) * 256 + (((4 * s4 + q4) ^ r) << 4));
+        MMA<T>::step(sacc, qf[s4], kf);
+      }
+      if (q4 == 0) {
+        const int key = rowbase + r;
+#pragma unroll
+        for (int h = 0; h < REP; ++h) sc[h][key] = key < nk ? sacc[h] * scale : -INFINITY;
+      }
+    }
+  } else {
+    float qr[REP][EPL];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
-      float d = 0.f;
+      const T* qp = q + (int64_t)b * q_stride + (int64_t)(kvh * REP + h) * D + gl * EPL;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) d = fmaf(qr[h][e], kf[e], d);
-      d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
-      if (gl == 0) sc[h][key] = key < nk ? d * scale : -INFINITY;
+      for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(*(const uint4*)(qp + c * VEC), &qr[h][c * VEC]);
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int key = ps * 16 + wave * 4 + grp;
+      float kf[EPL];
+#pragma unroll
+      for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(make_uint4(kraw[ps][c].x, kraw[ps][c].y, kraw[ps][c].z, kraw[ps][c].w), &kf[c * VEC]);
+#pragma unroll
+      for (int h = 0; h < REP; ++h) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) d = fmaf(qr[h][e], kf[e], d);
+        d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+        if (gl == 0) sc[h][key] = key < nk ? d * scale : -INFINITY;
+      }
     }
   }
   __syncthreads();
@@ -444,11 +485,45 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
 #pragma unroll
     for (int j = 0; j < KS / 64; ++j) {
       const float p = __expf(sv[j] - m);  // masked keys: exp(-inf) = 0
-      sc[h][lane + 64 * j] = p;
+      if constexpr (MFMA_QK) *(T*)(pt + h * PROW + (lane + 64 * j) * 2) = from_f32<T>(p);   // P rounded to bf16, as HF eager does
+      else sc[h][lane + 64 * j] = p;
       l += p;
     }
     l = wave_sum(l);
     if (lane == 0) { rec[REP * D + h] = m; rec[REP * D + REP + h] = l; }
+  }
+  if constexpr (MFMA_QK) {
+    // phase 3 on the matrix core: O[head][dim] = P . V with V consumed column-wise by ds_read_b64_tr_b16 (a 16-lane group
+    // reads a 4-key x 16-dim block and receives it transposed: lane i gets the 4 keys of dim i).  V tile image: chunk c of
+    // row r at c ^ (((r & 3) << 2) | ((r >> 2) & 3)) — conflict-free for these reads (guide T10, image (b)).
+    auto voff = [](int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); };
+    for (int o = tid; o < (16 - REP) * (KS / 8); o += 256)   // zero the padding rows of P (heads REP..15)
+      *(uint4*)(pt + (REP + o / (KS / 8)) * PROW + (o % (KS / 8)) * 16) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) *(u32x4_t*)(un + voff(kg + 16 * ps, dc)) = vraw[ps][0];   // K tile is dead: scores are in sc
+    __syncthreads();
+    const int r = lane & 15, q4 = lane >> 4, qq = r >> 2, pp = r & 3;
+    const uint32_t ub = (uint32_t)(uintptr_t)(lds_ptr3_t)un;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int df = 2 * wave + j;   // 16-dim fragment of the head dimension
+      f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS / 32; ++ks) {
+        const uint4 pa = *(const uint4*)(pt + r * PROW + (32 * ks + 8 * q4) * 2);
+        const int r0 = 32 * ks + 8 * q4 + qq;
+        u32x2_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ub + (uint32_t)(voff(r0, 2 * df + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ub + (uint32_t)(voff(r0 + 4, 2 * df + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+        MMA<T>::step(oacc, pa, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+      if (q4 == 0) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) rec[h * D + df * 16 + r] = oacc[h];
+      }
+    }
+    return;
   }
   __syncthreads();
   // phase 3: partial P.V
@@ -463,7 +538,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
       const int key = kg + 16 * ps;
       float vf[EPL];
 #pragma unroll
-      for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(vraw[ps][c], &vf[c * VEC]);
+      for (int c = 0; c < CPLN; ++c) Vec16<T>::unpack(make_uint4(vraw[ps][c].x, vraw[ps][c].y, vraw[ps][c].z, vraw[ps][c].w), &vf[c * VEC]);
 #pragma unroll
       for (int h = 0; h < REP; ++h) {
         const float p = sc[h][key];  // 0 for keys past nk
