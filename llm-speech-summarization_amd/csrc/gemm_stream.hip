@@ -93,11 +93,16 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave;                        // compute waves 0..NWV-1; wave NWV stages x
   const int r = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * (MT * 16);
+  // block id -> (n-block, row block): the row blocks of one n-block sit 8 ids apart, i.e. on the same XCD (ids round-robin
+  // over the 8 XCDs), so the second row block's weight stream hits that XCD's L2 instead of going back to HBM / MALL
+  const int mblocks = (p.M + MT * 16 - 1) / (MT * 16);
+  const int xj = blockIdx.x >> 3, nb = (xj / mblocks) * 8 + (blockIdx.x & 7);
+  if (nb * NWV * RF >= ((p.N + 15) >> 4)) return;       // padding of the n-block count to a multiple of 8
+  const int m0 = (xj % mblocks) * (MT * 16);
   const int sp = blockIdx.z;
   const int nfrag = (p.N + 15) >> 4;
   const int nks = p.K / KSTEP;                // 64-byte k-steps; a stage is two of them
-  const int fi0 = (blockIdx.x * NWV + wn) * RF;
+  const int fi0 = (nb * NWV + wn) * RF;
 
   const int g_lo = sp * s.sps;
   const int g_hi = min(nks >> 1, g_lo + s.sps);
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
 #pragma unroll
       for (int f = 0; f < RF; ++f)
         if (fi0 + f < nfrag) *(f32x4*)(s.part + ((int64_t)sp * p.M + m) * s.np + (fi0 + f) * 16 + 4 * q) = acc[f][t];
-      if (fuse && blockIdx.x == 0 && wn == 0 && q == 0) s.part_ss[(int64_t)sp * p.M + m] = ssum[t];
+      if (fuse && nb == 0 && wn == 0 && q == 0) s.part_ss[(int64_t)sp * p.M + m] = ssum[t];
     }
     return;
   }
@@ -352,23 +357,26 @@ struct StreamCfg { int mt, splits, nwv, d; };
 // fp32 partials (written, then re-read by the reduce kernel) cost more than the extra CUs bring.
 static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
   StreamCfg c;
-  c.mt = M <= 32 ? 2 : (M <= 64 ? 4 : (M <= 128 ? 8 : 16));
-  const int mblocks = (M + c.mt * 16 - 1) / (c.mt * 16);
+  // above 128 rows: 128-row blocks x 4 compute waves (128 weight rows): the row blocks of an n-block re-read its weights
+  // from L2, and each CU stages half the activation bytes of a 256-row block (measured at M = 256: gate/up 38 vs 50 us)
+  c.mt = M <= 32 ? 2 : (M <= 64 ? 4 : 8);
   const int nfrag = (N + 15) / 16;
   const int nst = K / (2 * kstep);
-  c.nwv = ((nfrag + 7) / 8 * mblocks >= 512 && c.mt <= 8) ? 4 : 2;   // 4 compute + 2 loader waves of 256-row blocks spill
   c.d = 4;
-  int sp_env = 0;
-  const char* e = getenv("SL_STREAM_CFG");  // tuning override "splits,nwv" (tools/tune_stream.py)
+  int sp_env = 0, nwv_env = 0;
+  const char* e = getenv("SL_STREAM_CFG");  // tuning override "splits,nwv[,mt]" (tools/tune_stream.py)
   if (e && e[0]) {
-    int sp = 0, nwv = 0, d = 0;
-    const int n = sscanf(e, "%d,%d,%d", &sp, &nwv, &d);
+    int sp = 0, nwv = 0, mt = 0;
+    const int n = sscanf(e, "%d,%d,%d", &sp, &nwv, &mt);
     if (n >= 2) {
       if (sp >= 1 && sp <= 64) sp_env = sp;
-      if (nwv == 2 || nwv == 4) c.nwv = nwv;
+      if (nwv == 2 || nwv == 4) nwv_env = nwv;
     }
-    if (n == 3 && (d == 4 || d == 8)) c.d = d;
+    if (n == 3 && (mt == 8 || mt == 16) && M > 64) c.mt = mt;
   }
+  const int mblocks = (M + c.mt * 16 - 1) / (c.mt * 16);
+  c.nwv = ((nfrag + 7) / 8 * mblocks >= 512 || M > 128) && c.mt <= 8 ? 4 : 2;   // 4 compute + 2 loader waves of 256-row blocks spill
+  if (nwv_env && c.mt <= 8) c.nwv = nwv_env;
   const int base = mblocks * ((nfrag + c.nwv * 2 - 1) / (c.nwv * 2));
   int splits = 1;
   if (have_ws) {
@@ -397,7 +405,8 @@ size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype) {
 template <typename T, int MT, int ACT, int RF, int NWV, int D>
 static int launch_stream_cfg(GemmP& p, const SkinnyX& sx, const StreamX& s, hipStream_t st) {
   const int nfrag = (p.N + 15) / 16;
-  dim3 grid((nfrag + NWV * RF - 1) / (NWV * RF), (p.M + MT * 16 - 1) / (MT * 16), s.splits);
+  const int nblocks = (nfrag + NWV * RF - 1) / (NWV * RF), mblocks = (p.M + MT * 16 - 1) / (MT * 16);
+  dim3 grid((nblocks + 7) / 8 * 8 * mblocks, 1, s.splits);
   hipLaunchKernelGGL((gemm_stream_kernel<T, MT, ACT, RF, NWV, D>), grid, dim3(64 * (NWV + (MT > 8 ? 2 : 1))), 0, st, p, sx, s);
   SL_CHECK_LAUNCH("gemm_stream");
   if (s.splits > 1) {
@@ -422,8 +431,12 @@ static int launch_stream_mt(GemmP& p, const SkinnyX& sx, const StreamX& s, const
   if constexpr (sizeof(T) == 4) {
     return launch_stream_cfg<T, MT, ACT, 2, 4, 2>(p, sx, s, st);   // fp32 parity mode: one structure
   } else {
-    if (c.nwv == 2) return c.d == 8 ? launch_stream_cfg<T, MT, ACT, 2, 2, 8>(p, sx, s, st) : launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st);
-    return launch_stream_cfg<T, MT, ACT, 2, 4, 4>(p, sx, s, st);
+    if constexpr (MT > 8) {
+      return launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st);   // 256-row blocks: 4 compute + 2 loader waves would spill
+    } else {
+      if (c.nwv == 2) return launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st);
+      return launch_stream_cfg<T, MT, ACT, 2, 4, 4>(p, sx, s, st);
+    }
   }
 }
 
