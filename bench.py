@@ -9,7 +9,7 @@ ref:inference.py:95-137), random-init weights of the true shapes, inputs residen
 Prints ONE JSON line (rank 0).  value = generated tokens/s of the whole job (all ranks, all pipeline
 stages inside the timed region); audio_sec_per_s = encoder-stage throughput from HIP events in the same
 steps.  roofline = the decode kernel with the largest share of the step (split attention over the KV cache at
-the default batch of 256, the gate/up weight-streaming GEMM below ~128) against the HBM peak; roofline_other = the other.
+the default batch of 512, the gate/up weight-streaming GEMM below ~128) against the HBM peak; roofline_other = the other.
 cpu_baseline = the CPU oracle (oracle/*.py, a port of the reference's HF path) on a bounded sample.
 Multi-GPU: inference shards by utterance, replicas only, no data-path collective (weak scaling).
 """
@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="utterances per step per GPU")
     ap.add_argument("--audio-sec", type=float, default=10.0)
     ap.add_argument("--max-new-tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")

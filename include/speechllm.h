@@ -355,7 +355,7 @@ int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, void* x, co
                      size_t workspace_bytes, sl_stream stream);
 
 /* One KV-cached decode step for B sequences: embeds next_ids, runs all layers with M = B, writes
- * logits (B, vocab) fp32 (B <= 512).  The new token's K/V are appended at position ctx_len[b] and
+ * logits (B, vocab) fp32 (B <= 1024).  The new token's K/V are appended at position ctx_len[b] and
  * ctx_len[b]+1 keys are attended; ctx_len itself is advanced by sl_greedy_select.  Reads/writes only
  * device state, so the call is hipGraph-capturable.  Workspace: sl_llama_workspace_bytes(m, B, B) + B*hidden. */
 int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids_dev,

@@ -344,7 +344,7 @@ extern "C" int sl_whisper_forward(const sl_hubert_model* m, const void* mel, int
 // ================================================================================================
 // Llama
 // ================================================================================================
-constexpr int SL_MAX_DECODE_BATCH = 512;   // rows of one decode step (M of the weight-streaming GEMMs)
+constexpr int SL_MAX_DECODE_BATCH = 1024;   // rows of one decode step (M of the weight-streaming GEMMs)
 
 struct LlamaWs {
   void *h, *qkv, *att, *mid, *last, *part, *split;
