@@ -536,7 +536,9 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
   }
   for (int l = 0; l < m->n_layers; ++l)
     SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st, chain, (chain && l > 0) ? w.rstd_b : nullptr));
-  if (m->lm_head_dec) {
+  // lm_head: above ~256 rows the 128-tile MFMA kernel on the row-major matrix beats the streaming kernel on the packed one
+  // (M=512: 439 vs 632 us; the 263 MB of fp32 logits dominate either way)
+  if (m->lm_head_dec && B < 256) {
     sl_gemm_fused fx;
     memset(&fx, 0, sizeof(fx));
     fx.fuse_rms = m->dec_fused_norm; fx.rms_eps = m->rms_eps;
