@@ -11,6 +11,8 @@ stages inside the timed region); audio_sec_per_s = encoder-stage throughput from
 steps.  roofline = the decode kernel with the largest share of the step (split attention over the KV cache at
 the default batch of 512, the gate/up weight-streaming GEMM below ~128) against the HBM peak; roofline_other = the other.
 cpu_baseline = the CPU oracle (oracle/*.py, a port of the reference's HF path) on a bounded sample.
+Two batches are in flight per GPU by default (`--pipelines`): host threads with their own HIP stream / KV cache pull
+steps from one counter, so one batch's encode + prefill (MFMA-bound) overlaps another's decode (HBM-bound).
 Multi-GPU: inference shards by utterance, replicas only, no data-path collective (weak scaling).
 """
 from __future__ import annotations
@@ -273,6 +275,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="utterances per step per GPU")
     ap.add_argument("--audio-sec", type=float, default=10.0)
     ap.add_argument("--max-new-tokens", type=int, default=256)
+    ap.add_argument("--pipelines", type=int, default=2, help="batches in flight per GPU (host threads x HIP streams; 1 = strictly sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (≈0.45 s each)")
     ap.add_argument("--kd-optimizer-steps", type=int, default=1, help="optimizer steps of the KD training leg (0 = skip)")
@@ -327,41 +330,81 @@ def main():
     emb = llm.model.embed_tokens
     pre_e, suf_e = emb(prefix.to(dev))[0], emb(suffix.to(dev))[0, 1:]
     n_pre = pre_e.shape[0]
-    x = torch.empty((B * S, larch.hidden_size), device=dev, dtype=torch.bfloat16)
     audio_rows = [b * S + n_pre for b in range(B)]
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     enc_ms, prefill_ms, decode_ms = [], [], []
 
-    def step(record):
-        # prompt assembly: prefix/suffix rows are copied, the encoder writes the audio rows in place
-        xv = x.view(B, S, -1)
-        xv[:, :n_pre] = pre_e
-        xv[:, n_pre + P:] = suf_e
-        ev[0].record()
-        enc.encode_packed(waves, out=x, out_row_offsets=audio_rows)
-        ev[1].record()
-        ids, n_cols = llm.generate_packed(x, [S] * B, new, use_eos=False)
-        if record:
-            enc_ms.append(ev[0].elapsed_time(ev[1]))
-            prefill_ms.append(llm.last_timings_ms[0])
-            decode_ms.append(llm.last_timings_ms[1])
-        return ids, n_cols
+    # Software pipelining across batches: `--pipelines P` host threads, each with its own HIP stream, KV cache and
+    # workspaces (weights shared), pull steps from one counter — while one batch decodes (HBM-bound) the next one is
+    # encoded and prefilled (MFMA-bound) on the same GPU.  A step is still one whole batch through the whole path.
+    import copy, threading
+    n_pipe = max(1, min(args.pipelines, args.steps))
 
+    class Pipe:
+        def __init__(self, idx):
+            self.enc, self.llm = (enc, llm) if idx == 0 else (copy.copy(enc), copy.copy(llm))
+            if idx > 0:
+                self.enc._ws, self.llm._ws, self.llm._kv = None, None, None
+            self.stream = torch.cuda.Stream(device=dev)
+            self.x = torch.empty((B * S, larch.hidden_size), device=dev, dtype=torch.bfloat16)
+            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            self.last = None
+
+        def step(self, record):
+            with torch.cuda.stream(self.stream):
+                # prompt assembly: prefix/suffix rows are copied, the encoder writes the audio rows in place
+                xv = self.x.view(B, S, -1)
+                xv[:, :n_pre] = pre_e
+                xv[:, n_pre + P:] = suf_e
+                self.ev[0].record()
+                self.enc.encode_packed(waves, out=self.x, out_row_offsets=audio_rows)
+                self.ev[1].record()
+                ids, n_cols = self.llm.generate_packed(self.x, [S] * B, new, use_eos=False)   # syncs this stream at its end
+                if record:
+                    enc_ms.append(self.ev[0].elapsed_time(self.ev[1]))
+                    prefill_ms.append(self.llm.last_timings_ms[0])
+                    decode_ms.append(self.llm.last_timings_ms[1])
+                self.last = (ids, n_cols)
+
+    pipes = [Pipe(i) for i in range(n_pipe)]
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step(False)
+        for pp in pipes:
+            pp.step(False)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    counter = {"next": 0}
+    lock = threading.Lock()
+
+    def worker(pp):
+        torch.cuda.set_device(dev)
+        while True:
+            with lock:
+                k = counter["next"]
+                counter["next"] += 1
+            if k >= args.steps:
+                return
+            pp.step(True)
+
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ids, n_cols = step(True)
+    if n_pipe == 1:
+        worker(pipes[0])
+    else:
+        threads = [threading.Thread(target=worker, args=(pp,)) for pp in pipes]
+        for t_ in threads:
+            t_.start()
+        for t_ in threads:
+            t_.join()
     barrier()
     elapsed = time.perf_counter() - t0
-    assert n_cols == new and ids.shape == (B, new)
+    for pp in pipes:
+        if pp.last is not None:
+            ids, n_cols = pp.last
+            assert n_cols == new and ids.shape == (B, new)
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -457,12 +500,14 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: HuBERT-large + Llama-3.2-3B bf16 inference, batch of synthetic 16 kHz utterances",
                    "utterances_per_gpu": B, "audio_sec": args.audio_sec, "prompt_tokens": S, "max_new_tokens": new,
-                   "parallelism": f"replicas x{world} (sharded by utterance, no collective)"},
+                   "parallelism": f"replicas x{world} (sharded by utterance, no collective)", "batches_in_flight_per_gpu": n_pipe},
         "audio_sec_per_s": round(B * args.audio_sec * world / (mean(enc_ms) * 1e-3), 1),
         "stage_ms": {"encode": round(mean(enc_ms), 3), "prefill": round(mean(prefill_ms), 3), "decode": round(mean(decode_ms), 3),
                      "decode_per_step": round(dec_step_ms, 4)},
-        "decode_step_hbm": {"algorithmic_GB": round(step_bytes / 1e9, 3), "achieved_GBps": round(step_bytes / (dec_step_ms * 1e-3) / 1e9, 1),
-                            "frac_of_peak": round(step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "stage_note": f"per-batch wall times; {n_pipe} batch(es) share the GPU, so stages of different batches overlap",
+        "decode_step_hbm": {"algorithmic_GB": round(step_bytes / 1e9, 3), "concurrent_batches": n_pipe,
+                            "achieved_GBps": round(n_pipe * step_bytes / (dec_step_ms * 1e-3) / 1e9, 1),
+                            "frac_of_peak": round(n_pipe * step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": dominant, "roofline_other": other,
     }
     if kd is not None:

@@ -664,7 +664,9 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   // large products: 256^2 tiles once they alone give every CU >= 2 tiles (ragged batches: sized by the largest group)
   if (!p.ta && !p.tw && p.K % BK_ == 0 && g_disable_glds == 0 && !getenv("SL_DISABLE_T256")) {
     const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
-    if (t256 >= 512 && p.N >= 192 && p.K >= 2048) {   // short K: the 128 tile's two blocks per CU hide the pro/epilogue better
+    const char* te = getenv("SL_T256_MIN_TILES");   // tuning switch
+    const int64_t min_tiles = (te && te[0]) ? atoi(te) : 512;
+    if (t256 >= min_tiles && p.N >= 192 && p.K >= 2048) {   // short K: the 128 tile's two blocks per CU hide the pro/epilogue better
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
       hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
