@@ -267,6 +267,16 @@ def wgrad_acc(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, ldx: Optio
     M = dY.shape[0] if M is None else M
     Nout = dY.shape[1]
     Kin = X.shape[1] if Kin is None else Kin
+    if ldx is None and M >= 256:
+        # plain Linear: contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to a whole number of K slabs) so
+        # the product runs the LDS-DMA tiled kernels; the doubly-transposed register loader measured ~100 TF/s on these shapes
+        Mp = (M + 63) // 64 * 64
+        dYT = torch.zeros((Nout, Mp), device=dY.device, dtype=dY.dtype)
+        dYT[:, :M] = dY[:M].t()
+        XT = torch.zeros((Kin, Mp), device=X.device, dtype=X.dtype)
+        XT[:, :M] = X[:M, :Kin].t()
+        return gemm_ex(dYT, XT, M=Nout, N=Kin, K=Mp, lda=Mp, ldw=Mp, out=dW, ldc=dW.stride(0), residual=dW, ldr=dW.stride(0), out_f32=True,
+                       residual_f32=True, dtype=dY.dtype)
     return gemm_ex(dY, X, M=Nout, N=Kin, K=M, lda=dY.stride(0), ldw=(X.stride(0) if ldx is None else ldx), out=dW, ldc=dW.stride(0),
                    residual=dW, ldr=dW.stride(0), out_f32=True, residual_f32=True, trans_a=True, trans_w=True, dtype=dY.dtype)
 
