@@ -124,6 +124,10 @@ typedef struct {
    * at index z % w_mod (strideW / strideBias).  args->M is the LARGEST group (sizes the grid).  One launch
    * then covers e.g. a conv layer of every utterance of a ragged batch (hf:...hubert.py:141). */
   const int64_t* groups;
+  /* groups_ext != 0: records are 8 int64 wide, {M, a_off, c_off, r_off, w_off, N, K, 0}: every group also has its own
+   * weight offset, column count and reduction length (args->N / args->K are then the LARGEST ones).  One launch covers
+   * e.g. one product of the attention backward over every (sequence, head) of a ragged batch. */
+  int32_t groups_ext, reserved;
 } sl_gemm_ex_args;
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);
 
@@ -245,6 +249,12 @@ int sl_softmax_rows(const float* S, void* P, int64_t n_mats, int32_t rows, int32
                     int32_t causal, int32_t dtype, sl_stream stream);
 int sl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t nrows, int32_t cols, int64_t ld, float scale,
                    int32_t dtype, sl_stream stream);
+/* The same over n_mats square matrices of different sizes stored at a common pitch (rows_per_mat rows of ld elements
+ * each): matrix i is mat_dim[i] x mat_dim[i]; rows / columns past it are left alone / written as zeros. */
+int sl_softmax_rows_var(const float* S, void* P, int64_t n_mats, int32_t rows_per_mat, const int32_t* mat_dim, int64_t ld, float scale,
+                        int32_t causal, int32_t dtype, sl_stream stream);
+int sl_softmax_bwd_var(const void* P, const float* dP, void* dS, int64_t n_mats, int32_t rows_per_mat, const int32_t* mat_dim, int64_t ld,
+                       float scale, int32_t dtype, sl_stream stream);
 /* Losses over rows of fp32 logits; *loss += coef * sum_rows(...), d logits (+)= coef * grad (dtype T):
  *   ce:      lse(s) - s[label]                    (ref:model/audio_llama.py:72-101 with coef = w/(n-1))
  *   soft-ce: -sum softmax(t) * log_softmax(s)     (ref:utils.py:167-178 with coef = w/n)

@@ -42,7 +42,8 @@ class GemmFused(C.Structure):
 
 
 class GemmEx(C.Structure):
-    _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("w_mod", c_i32), ("aux_out", c_vp), ("groups", c_vp)]
+    _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("w_mod", c_i32), ("aux_out", c_vp), ("groups", c_vp),
+                ("groups_ext", c_i32), ("reserved", c_i32)]
 
 
 class AttnArgs(C.Structure):
@@ -116,6 +117,8 @@ _PROTOS = {
     "sl_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "sl_softmax_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_f32, c_i32, c_i32, c_vp]),
     "sl_softmax_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_i32, c_vp]),
+    "sl_softmax_rows_var": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_f32, c_i32, c_i32, c_vp]),
+    "sl_softmax_bwd_var": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_f32, c_i32, c_vp]),
     "sl_ce_loss": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sl_soft_ce_loss": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sl_mse_loss": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
   int64_t a_off; int wz;
   if (!resolve_group(p, z, bm, a_off, wz)) return;
   const T* A = (const T*)p.A + a_off;
-  const T* W = (const T*)p.W + (int64_t)wz * p.sW;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW + p.wx;
+  if (p.grp_ext && bn * TBN >= p.N) return;
 
   // staging assignment: 4 chunks of A and 4 of W per thread
   const T* ga[4];
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
   int64_t a_off; int wz;
   if (!resolve_group(p, z, bm, a_off, wz)) return;
   const T* A = (const T*)p.A + a_off;
-  const T* W = (const T*)p.W + (int64_t)wz * p.sW;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW + p.wx;
+  if (p.grp_ext && bn * TBN >= p.N) return;
 
   // LDS chunk c = tid + 256 i sits at (row c>>3, physical chunk c&7) and must hold logical chunk (c&7)^(row&7)
   const T* ga[4];
@@ -370,7 +372,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
   int64_t a_off; int wz;
   if (!resolve_group(p, z, bm, a_off, wz, XBM)) return;
   const T* A = (const T*)p.A + a_off;
-  const T* W = (const T*)p.W + (int64_t)wz * p.sW;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW + p.wx;
+  if (p.grp_ext && bn * XBN >= p.N) return;
 
   // LDS chunk c = tid + 512 i sits at (row c>>3, physical chunk c&7) and must hold logical chunk (c&7)^(row&7)
   const T* ga[4];
@@ -662,7 +665,7 @@ template <typename T, int ACT>
 static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   constexpr int BK_ = TROWB / (int)sizeof(T);
   // large products: 256^2 tiles once they alone give every CU >= 2 tiles (ragged batches: sized by the largest group)
-  if (!p.ta && !p.tw && p.K % BK_ == 0 && g_disable_glds == 0 && !getenv("SL_DISABLE_T256")) {
+  if (!p.ta && !p.tw && p.K % BK_ == 0 && !p.grp_ext && g_disable_glds == 0 && !getenv("SL_DISABLE_T256")) {
     const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
     const char* te = getenv("SL_T256_MIN_TILES");   // tuning switch
     const int64_t min_tiles = (te && te[0]) ? atoi(te) : 512;
@@ -678,9 +681,9 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   p.tiles_n = (p.N + TBN - 1) / TBN;
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   constexpr int BK = TROWB / (int)sizeof(T);
-  if (!p.ta && !p.tw && p.K % BK == 0 && g_disable_glds == 2)
+  if (!p.ta && !p.tw && p.K % BK == 0 && !p.grp_ext && g_disable_glds == 2)
     hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, false>), grid, dim3(256), 0, st, p);
-  else if (!p.ta && !p.tw && p.K % BK == 0 && !g_disable_glds)
+  else if (!p.ta && !p.tw && p.K % BK == 0 && !p.grp_ext && !g_disable_glds)   // per-group K: only the register path handles K tails
     hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, true>), grid, dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_tiled_kernel<T, ACT>), grid, dim3(256), 0, st, p);
@@ -792,10 +795,11 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.res = a->residual; p.ldr = a->ldr; p.sR = a->strideR;
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
-  p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = 0;
+  p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0;
   if (ex) {
     p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;
     p.grp = ex->groups; p.w_mod = ex->w_mod > 0 ? ex->w_mod : 1;
+    p.grp_ext = ex->groups && ex->groups_ext;
     SL_CHECK_ARG(!(p.ta || p.tw || p.aux) || a->act != SL_ACT_SILU_MUL, "sl_gemm_ex: transposed operands / aux_out are not combined with SILU_MUL");
     SL_CHECK_ARG(!p.res_f32 || a->out_f32, "sl_gemm_ex: residual_f32 needs out_f32");
     SL_CHECK_ARG(!(p.ta || p.tw) || a->w_layout == SL_W_ROWMAJOR, "sl_gemm_ex: transposed operands need row-major storage");

@@ -15,17 +15,19 @@ struct GemmP {
   int res_f32;         // residual is float (fp32 gradient accumulation: C = C_old + A.W^T with out_f32)
   const int64_t* grp;  // grouped (ragged) batch: per z {M, a_off, c_off, r_off} in elements; W/bias use z % w_mod
   int w_mod;
-  int64_t cx, rx;      // per-block extra offsets resolved from grp
+  int64_t cx, rx, wx;  // per-block extra offsets resolved from grp
+  int grp_ext;         // records are {M, a_off, c_off, r_off, w_off, N, K, 0}
 };
 
 // resolve the per-batch descriptor: returns false when this block's tile lies outside batch z's rows
 __device__ __forceinline__ bool resolve_group(GemmP& p, int z, int bm, int64_t& a_off, int& wz, int tile_rows = 128) {
-  p.cx = 0; p.rx = 0;
+  p.cx = 0; p.rx = 0; p.wx = 0;
   wz = z;
   a_off = (int64_t)z * p.sA;
   if (p.grp) {
-    const int64_t* g = p.grp + 4 * (int64_t)z;
+    const int64_t* g = p.grp + (p.grp_ext ? 8 : 4) * (int64_t)z;
     p.M = (int)g[0];
+    if (p.grp_ext) { p.wx = g[4]; p.N = (int)g[5]; p.K = (int)g[6]; }
     a_off = g[1];
     p.cx = g[2] - (int64_t)z * p.sC;   // the epilogue adds z*sC back
     p.rx = g[3] - (int64_t)z * p.sR;

@@ -265,6 +265,44 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
   for (int c = lane; c < ld; c += 64) dS[row * ld + c] = from_f32<T>(c < cols ? scale * to_f32(p[c]) * (dp[c] - dot) : 0.f);
 }
 
+// ragged forms: n_mats square matrices of sizes mat_dim[i] at a common pitch (rows_per_mat x ld)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_var_kernel(const float* __restrict__ S, T* __restrict__ P, int64_t nrows, int rows_per_mat,
+                                                               const int32_t* __restrict__ mat_dim, int64_t ld, float scale, int causal) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int qi = (int)(row % rows_per_mat), n = mat_dim[row / rows_per_mat];
+  if (qi >= n) return;
+  const int lim = causal ? ((qi + 1) < n ? (qi + 1) : n) : n;
+  const float* s = S + row * ld;
+  T* p = P + row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < lim; c += 64) m = fmaxf(m, s[c] * scale);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int c = lane; c < lim; c += 64) l += __expf(s[c] * scale - m);
+  l = wave_sum(l);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  for (int c = lane; c < ld; c += 64) p[c] = from_f32<T>(c < lim ? __expf(s[c] * scale - m) * inv : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_var_kernel(const T* __restrict__ P, const float* __restrict__ dP, T* __restrict__ dS, int64_t nrows,
+                                                              int rows_per_mat, const int32_t* __restrict__ mat_dim, int64_t ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int qi = (int)(row % rows_per_mat), n = mat_dim[row / rows_per_mat];
+  if (qi >= n) return;
+  const T* p = P + row * ld;
+  const float* dp = dP + row * ld;
+  float dot = 0.f;
+  for (int c = lane; c < n; c += 64) dot += to_f32(p[c]) * dp[c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < ld; c += 64) dS[row * ld + c] = from_f32<T>(c < n ? scale * to_f32(p[c]) * (dp[c] - dot) : 0.f);
+}
+
 // ----------------------------------------------------------------------------------------------
 // KD losses with gradients.  One block per row of fp32 logits.
 //   ce:      loss += coef * (lse(s) - s[label]);           d s (+)= coef * (softmax(s) - onehot)
@@ -586,6 +624,30 @@ extern "C" int sl_softmax_bwd(const void* P, const float* dP, void* dS, int64_t 
                        ld, scale);
   });
   SL_CHECK_LAUNCH("softmax_bwd");
+  return 0;
+}
+
+extern "C" int sl_softmax_rows_var(const float* S, void* P, int64_t n_mats, int32_t rows_per_mat, const int32_t* mat_dim, int64_t ld, float scale,
+                                   int32_t causal, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(S && P && mat_dim && n_mats > 0 && rows_per_mat > 0 && ld >= rows_per_mat, "sl_softmax_rows_var: bad arguments");
+  const int64_t nrows = n_mats * rows_per_mat;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((softmax_rows_var_kernel<T>), dim3((unsigned)ceil_div64(nrows, 4)), dim3(256), 0, (hipStream_t)stream, S, (T*)P, nrows,
+                       rows_per_mat, mat_dim, ld, scale, causal);
+  });
+  SL_CHECK_LAUNCH("softmax_rows_var");
+  return 0;
+}
+
+extern "C" int sl_softmax_bwd_var(const void* P, const float* dP, void* dS, int64_t n_mats, int32_t rows_per_mat, const int32_t* mat_dim,
+                                  int64_t ld, float scale, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(P && dP && dS && mat_dim && n_mats > 0 && rows_per_mat > 0 && ld >= rows_per_mat, "sl_softmax_bwd_var: bad arguments");
+  const int64_t nrows = n_mats * rows_per_mat;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((softmax_bwd_var_kernel<T>), dim3((unsigned)ceil_div64(nrows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)P, dP, (T*)dS,
+                       nrows, rows_per_mat, mat_dim, ld, scale);
+  });
+  SL_CHECK_LAUNCH("softmax_bwd_var");
   return 0;
 }
 

@@ -229,7 +229,7 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
             residual=None, ldr: int = 0, act: int = L.ACT_NONE, out_f32: bool = False, trans_a: bool = False, trans_w: bool = False,
             residual_f32: bool = False, aux_out=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0,
             strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, r_off: int = 0,
-            dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1):
+            dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1, groups_ext: bool = False):
     """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors."""
     dt = dtype or A.dtype
     esz = 4 if dt == torch.float32 else 2
@@ -244,7 +244,7 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     a.dtype, a.act, a.out_f32, a.w_layout = L.dtype_code(dt), act, int(out_f32), L.W_ROWMAJOR
     e = L.GemmEx()
     e.trans_a, e.trans_w, e.residual_f32, e.aux_out = int(trans_a), int(trans_w), int(residual_f32), L.ptr(aux_out)
-    e.groups, e.w_mod = L.ptr(groups), w_mod
+    e.groups, e.w_mod, e.groups_ext = L.ptr(groups), w_mod, int(groups_ext)
     L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(e), L.stream_ptr()), "sl_gemm_ex")
     return out
 
@@ -345,6 +345,18 @@ def softmax_bwd(P, dP, cols, scale):
     nrows = P.shape[0] * P.shape[1]
     L.check(L.lib().sl_softmax_bwd(L.ptr(P), L.ptr(dP), L.ptr(dS), nrows, cols, P.shape[2], scale, L.dtype_code(P.dtype), L.stream_ptr()),
             "sl_softmax_bwd")
+    return dS
+
+
+def softmax_rows_var(S, P, n_mats, rows_per_mat, mat_dim, ld, scale, causal, dtype):
+    L.check(L.lib().sl_softmax_rows_var(L.ptr(S), L.ptr(P), n_mats, rows_per_mat, L.ptr(mat_dim), ld, scale, int(causal), L.dtype_code(dtype),
+                                        L.stream_ptr()), "sl_softmax_rows_var")
+    return P
+
+
+def softmax_bwd_var(P, dP, dS, n_mats, rows_per_mat, mat_dim, ld, scale):
+    L.check(L.lib().sl_softmax_bwd_var(L.ptr(P), L.ptr(dP), L.ptr(dS), n_mats, rows_per_mat, L.ptr(mat_dim), ld, scale, L.dtype_code(P.dtype),
+                                       L.stream_ptr()), "sl_softmax_bwd_var")
     return dS
 
 

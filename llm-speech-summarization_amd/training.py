@@ -76,6 +76,79 @@ def attention_backward(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: torch.Tens
                     r_off=voff, dtype=dt)
 
 
+_ATT_PLANS: Dict[tuple, dict] = {}
+
+
+def _attention_plan(seqlens, qkv_w: int, ldo: int, nh: int, nkv: int, D: int, vec: int, device) -> dict:
+    """Group records ({M, a_off, c_off, r_off, w_off, N, K, 0}, sl_gemm_ex groups_ext) of the five products of the attention
+    backward for every (sequence, kv head) of a packed batch, one set per query head of a GQA group."""
+    key = (tuple(int(n) for n in seqlens), qkv_w, ldo, nh, nkv, D, vec, str(device))
+    plan = _ATT_PLANS.get(key)
+    if plan is not None:
+        return plan
+    rep = nh // nkv
+    offs = _offsets(seqlens)
+    smax = max(int(n) for n in seqlens)
+    ld = _rup(smax, max(vec, 8))
+    koff, voff = nh * D, (nh + nkv) * D
+    mat = smax * ld                       # pitch of one (sequence, head) score matrix
+    recs = {k: [] for k in ("s", "dp", "dq", "dk", "dv")}
+    for r in range(rep):
+        for k in recs:
+            recs[k].append([])
+        for si, S in enumerate(int(n) for n in seqlens):
+            o = offs[si]
+            for h in range(nkv):
+                z = si * nkv + h
+                qh = (h * rep + r) * D
+                recs["s"][r].append([S, o * qkv_w + qh, z * mat, 0, o * qkv_w + koff + h * D, S, D, 0])
+                recs["dp"][r].append([S, o * ldo + qh, z * mat, 0, o * qkv_w + voff + h * D, S, D, 0])
+                recs["dq"][r].append([S, z * mat, o * qkv_w + qh, 0, si * ld * nkv * D + h * D, D, ld, 0])
+                kc = o * qkv_w + koff + h * D
+                recs["dk"][r].append([S, z * mat, kc, kc, o * qkv_w + qh, D, S, 0])
+                vc = o * qkv_w + voff + h * D
+                recs["dv"][r].append([S, z * mat, vc, vc, o * ldo + qh, D, S, 0])
+    plan = {k: [torch.tensor(v[r], dtype=torch.int64, device=device) for r in range(rep)] for k, v in recs.items()}
+    plan.update(smax=smax, ld=ld, nmat=len(seqlens) * nkv, offs=offs,
+                dims=torch.tensor([int(n) for n in seqlens for _ in range(nkv)], dtype=torch.int32, device=device))
+    _ATT_PLANS[key] = plan
+    return plan
+
+
+def attention_backward_packed(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: torch.Tensor, seqlens, nh: int, nkv: int, D: int, causal: bool,
+                              scale: float) -> None:
+    """attention_backward for every sequence of a packed batch at once: each of the five products is ONE grouped launch over
+    all (sequence, kv head) pairs (the per-sequence form spent 27 % of the KD step in 29-42 us launch-bound GEMMs)."""
+    dt = qkv.dtype
+    dev = qkv.device
+    qkv_w, ldo = qkv.stride(0), d_att.stride(0)
+    rep = nh // nkv
+    pl = _attention_plan(seqlens, qkv_w, ldo, nh, nkv, D, _vec(dt), dev)
+    smax, ld, nmat, offs = pl["smax"], pl["ld"], pl["nmat"], pl["offs"]
+    koff, voff = nh * D, (nh + nkv) * D
+    Sb = torch.empty((nmat, smax, ld), device=dev, dtype=torch.float32)
+    dPb = torch.empty((nmat, smax, ld), device=dev, dtype=torch.float32)
+    P = torch.zeros((nmat, smax, ld), device=dev, dtype=dt)
+    dS = torch.zeros((nmat, smax, ld), device=dev, dtype=dt)
+    kpad = torch.zeros((len(seqlens), ld, nkv * D), device=dev, dtype=dt)   # K rows zero-padded: dQ = dS . K reduces over ld
+    for si, S in enumerate(seqlens):
+        kpad[si, :S] = qkv[offs[si]:offs[si] + S, koff:voff]
+    for r in range(rep):
+        ops.gemm_ex(qkv, qkv, M=smax, N=smax, K=D, lda=qkv_w, ldw=qkv_w, out=Sb, ldc=ld, out_f32=True, batch=nmat, dtype=dt,
+                    groups=pl["s"][r], groups_ext=True)
+        ops.softmax_rows_var(Sb, P, nmat, smax, pl["dims"], ld, scale, causal, dt)
+        ops.gemm_ex(d_att, qkv, M=smax, N=smax, K=D, lda=ldo, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nmat, dtype=dt,
+                    groups=pl["dp"][r], groups_ext=True)
+        ops.softmax_bwd_var(P, dPb, dS, nmat, smax, pl["dims"], ld, scale)
+        ops.gemm_ex(dS, kpad, M=smax, N=D, K=ld, lda=ld, ldw=nkv * D, out=d_qkv, ldc=qkv_w, trans_w=True, batch=nmat, dtype=dt,
+                    groups=pl["dq"][r], groups_ext=True)
+        acc = r > 0   # GQA: the rep query heads of a group add into the same dK / dV
+        ops.gemm_ex(dS, qkv, M=smax, N=D, K=smax, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nmat, dtype=dt,
+                    residual=(d_qkv if acc else None), ldr=qkv_w, groups=pl["dk"][r], groups_ext=True)
+        ops.gemm_ex(P, d_att, M=smax, N=D, K=smax, lda=ld, ldw=ldo, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nmat, dtype=dt,
+                    residual=(d_qkv if acc else None), ldr=qkv_w, groups=pl["dv"][r], groups_ext=True)
+
+
 def _offsets(lens: Sequence[int]) -> List[int]:
     o = [0]
     for n in lens:
@@ -154,8 +227,7 @@ class LlamaTape:
             ops.axpby(dx, dx2)                                  # dx2 += dx (residual join)
             d_att = ops.dgrad(dx2, lw["wo"], wt=self._t(li, "wo"))
             d_qkv = torch.empty_like(qkv)
-            for s in range(len(seqlens)):
-                attention_backward(qkv[offs[s]:offs[s + 1]], d_att[offs[s]:offs[s + 1]], d_qkv[offs[s]:offs[s + 1]], nh, nkv, D, True, D ** -0.5)
+            attention_backward_packed(qkv, d_att, d_qkv, seqlens, nh, nkv, D, True, D ** -0.5)
             ops.rope_inplace(d_qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D, inverse=True)
             d_h1 = ops.dgrad(d_qkv, lw["wqkv"], wt=self._t(li, "wqkv"))
             dxin = ops.rmsnorm_bwd(x, lw["norm1"], d_h1, a.rms_norm_eps)
@@ -295,8 +367,7 @@ class EncoderTape:
             ops.wgrad_acc(dx_mid, c["att"], g[p + "wo"]); ops.colsum_acc(dx_mid, g[p + "bo"])
             d_att = ops.dgrad(dx_mid, lt["wo"], wt=lt["wo"].t().contiguous())
             d_qkv = torch.empty_like(c["qkv"])
-            for u in range(B):
-                attention_backward(c["qkv"][toff[u]:toff[u + 1]], d_att[toff[u]:toff[u + 1]], d_qkv[toff[u]:toff[u + 1]], nh, nh, 64, False, 0.125)
+            attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125)
             ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
             d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=lt["wqkv"].t().contiguous())
             dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, a.layer_norm_eps, g[p + "ln1_g"], g[p + "ln1_b"])

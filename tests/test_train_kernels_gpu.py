@@ -185,3 +185,42 @@ def test_conv0_backward(dt, Cc, n):
                          dy.to(DEV, dt), dw, db, dg, dbe)
     for got, ref in ((dw, w.grad.reshape(Cc, 10)), (db, b.grad), (dg, g.grad), (dbe, be.grad)):
         assert rel_err(got.cpu(), ref) < 5e-4
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("nh,nkv,D,causal", [(6, 2, 128, True), (4, 4, 64, False)])
+def test_attention_backward_packed_ragged(dt, nh, nkv, D, causal):
+    """One grouped launch per product over all (sequence, kv head) pairs of a ragged packed batch (sl_gemm_ex groups_ext,
+    sl_softmax_*_var) against the per-sequence form and against autograd through an fp32 softmax attention."""
+    training = pkg("training")
+    seqlens = [37, 5, 130, 64]
+    N = sum(seqlens)
+    qkv_w = (nh + 2 * nkv) * D
+    qkv = rnd(N, qkv_w, seed=71, std=0.5)
+    d_att = rnd(N, nh * D, seed=72)
+    scale = D ** -0.5
+    qd, dd = qkv.to(DEV, dt), d_att.to(DEV, dt)
+    d_packed = torch.full_like(qd, float("nan"))
+    training.attention_backward_packed(qd, dd, d_packed, seqlens, nh, nkv, D, causal, scale)
+    d_seq = torch.empty_like(qd)
+    o = 0
+    for S in seqlens:
+        training.attention_backward(qd[o:o + S], dd[o:o + S], d_seq[o:o + S], nh, nkv, D, causal, scale)
+        o += S
+    assert bool(torch.isfinite(d_packed.float()).all())
+    assert rel_err(d_packed.float().cpu(), d_seq.float().cpu()) < (1e-5 if dt == torch.float32 else 2e-2)
+    # autograd reference (fp32 math on the values the kernels see)
+    x = q(qkv, dt).clone().requires_grad_(True)
+    outs, o = [], 0
+    rep = nh // nkv
+    for S in seqlens:
+        qh = x[o:o + S, :nh * D].view(S, nh, D).transpose(0, 1)
+        kh = x[o:o + S, nh * D:(nh + nkv) * D].view(S, nkv, D).transpose(0, 1).repeat_interleave(rep, 0)
+        vh = x[o:o + S, (nh + nkv) * D:].view(S, nkv, D).transpose(0, 1).repeat_interleave(rep, 0)
+        sc = qh @ kh.transpose(1, 2) * scale
+        if causal:
+            sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+        outs.append((torch.softmax(sc, -1) @ vh).transpose(0, 1).reshape(S, nh * D))
+        o += S
+    torch.cat(outs).backward(q(d_att, dt))
+    assert rel_err(d_packed.float().cpu(), x.grad) < (2e-5 if dt == torch.float32 else 3e-2)
