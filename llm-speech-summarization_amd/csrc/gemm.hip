@@ -96,7 +96,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
     const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   }
-  const int bn = bid / p.tiles_m, bm = bid - bn * p.tiles_m;
+  int bm, bn;   // 8 x 8 patches of tiles per XCD at a time (see gemm_tiled256_kernel)
+  {
+    constexpr int GM = 8;
+    const int per = GM * p.tiles_n, grp = bid / per, first = grp * GM;
+    const int gsz = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
+    const int in = bid - grp * per;
+    bm = first + in % gsz;
+    bn = in / gsz;
+  }
   const int z = blockIdx.y;
 
   int64_t a_off; int wz;

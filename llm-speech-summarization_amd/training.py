@@ -403,11 +403,19 @@ class EncoderTape:
             Cin, Cout, kk, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
             d_c = ops.layernorm_bwd(pres[i], t[f"conv{i}_g"], t[f"conv{i}_beta"], d_act, 1e-5, g[f"conv{i}_g"], g[f"conv{i}_beta"], gelu=True)
             ops.colsum_acc(d_c, g[f"conv{i}_b"])
-            dcol = ops.dgrad(d_c, t[f"conv{i}_w"])
+            dcol = ops.dgrad(d_c, t[f"conv{i}_w"], wt=t[f"conv{i}_w"].t().contiguous())
             d_prev = torch.empty((offs[i - 1][B], Cin), device=d_c.device, dtype=dt)
+            # weight gradient: every utterance's windows in ONE grouped launch (per-group reduction length = its frame count),
+            # fp32 partials per utterance summed afterwards — per-utterance launches had 48 tiles each and ran 0.6 ms apiece
+            Kin = kk * Cin
+            part = torch.empty((B, Cout, Kin), device=d_c.device, dtype=torch.float32)
+            recs = [[Cout, offs[i][u] * Cout, u * Cout * Kin, 0, offs[i - 1][u] * Cin, Kin, offs[i][u + 1] - offs[i][u], 0] for u in range(B)]
+            grp = torch.tensor(recs, dtype=torch.int64, device=d_c.device)
+            ops.gemm_ex(d_c, acts[i - 1], M=Cout, N=Kin, K=max(r_[6] for r_ in recs), lda=Cout, ldw=s * Cin, out=part, ldc=Kin, out_f32=True,
+                        trans_a=True, trans_w=True, batch=B, dtype=dt, groups=grp, groups_ext=True)
+            g[f"conv{i}_w"] += part.sum(0)
             for u in range(B):
                 o0, o1, i0, i1 = offs[i][u], offs[i][u + 1], offs[i - 1][u], offs[i - 1][u + 1]
-                ops.wgrad_acc(d_c[o0:o1], acts[i - 1][i0:i1], g[f"conv{i}_w"], ldx=s * Cin, Kin=kk * Cin, M=o1 - o0)
                 d_prev[i0:i1] = ops.col2im(dcol[o0:o1], i1 - i0, Cin, kk, s)
             d_act = d_prev
             done([f"conv{i}_w", f"conv{i}_b", f"conv{i}_g", f"conv{i}_beta"])
