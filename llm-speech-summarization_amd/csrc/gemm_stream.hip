@@ -11,6 +11,9 @@
 //     ahead in a register ring; nothing of W ever touches LDS.
 //   * when the grid would not fill the CUs, K is split over `splits` blocks: those write fp32 partials and
 //     gemm_stream_reduce_kernel applies the epilogue.
+// (Tried at 384+ rows against 8192+ weight rows: 256-weight-row blocks — 4 waves x 4 fragments, all waves DMA-ing the slab
+// and reading it with compiler-invisible ds_read_b128, no loader wave — to halve the activation bytes per CU: 74 vs 67 us
+// at M = 512, 137 vs 102 us at M = 768; dropped.)
 // Epilogues are the decode ones of gemm.hip: +bias/+residual, SILU_MUL (fragment pairs gate/up), ROPE_KV (q rotated,
 // k/v appended to the cache), and the fused RMSNorm row scale (sum of squares taken from the staged x slabs).
 #include <stdlib.h>
@@ -69,6 +72,49 @@ __device__ __forceinline__ void stream_epilogue4(const GemmP& p, const SkinnyX& 
       if (bias) v += to_f32(bias[col]);
       if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
       store_out<T>(p, p.C, p.res, m, col, v);
+    }
+  }
+}
+
+// what a compute wave does with its accumulators: K-split partial records, or scale + epilogue.
+// acc[f][t][i] = D[weight row (fi0 + f) * 16 + 4q + i][x row m0 + t * 16 + r]
+template <typename T, int MT, int ACT, int RF>
+__device__ __forceinline__ void stream_finish(const GemmP& p, const SkinnyX& sx, const StreamX& s, f32x4 (&acc)[RF][MT], const float (&ssum)[MT],
+                                              bool fuse, int m0, int sp, int fi0, int nfrag, bool writes_ss, int q, int r) {
+  constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+  if (s.splits > 1) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int f = 0; f < RF; ++f)
+        if (fi0 + f < nfrag) *(f32x4*)(s.part + ((int64_t)sp * p.M + m) * s.np + (fi0 + f) * 16 + 4 * q) = acc[f][t];
+      if (fuse && writes_ss && q == 0) s.part_ss[(int64_t)sp * p.M + m] = ssum[t];
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = m0 + t * 16 + r;
+    if (m >= p.M) continue;
+    const float rs = sx.rstd_in ? sx.rstd_in[m] : (fuse ? rsqrtf(ssum[t] / (float)p.K + sx.eps) : 1.0f);
+    if constexpr (PAIRS) {
+#pragma unroll
+      for (int pr = 0; pr < RF / 2; ++pr) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = acc[2 * pr][t][i] * rs; b[i] = acc[2 * pr + 1][t][i] * rs; }
+        stream_epilogue4<T, ACT>(p, sx, m, fi0 + 2 * pr, 4 * q, a, b);
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < RF; ++f) {
+        float a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = acc[f][t][i] * rs;
+        stream_epilogue4<T, ACT>(p, sx, m, fi0 + f, 4 * q, a, a);
+      }
     }
   }
 }
@@ -234,43 +280,7 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
     ssum[t] = 0.f;
     if (fuse) ssum[t] = ssl[t * 16 + r];
   }
-
-  if (s.splits > 1) {
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int m = m0 + t * 16 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int f = 0; f < RF; ++f)
-        if (fi0 + f < nfrag) *(f32x4*)(s.part + ((int64_t)sp * p.M + m) * s.np + (fi0 + f) * 16 + 4 * q) = acc[f][t];
-      if (fuse && nb == 0 && wn == 0 && q == 0) s.part_ss[(int64_t)sp * p.M + m] = ssum[t];
-    }
-    return;
-  }
-
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const int m = m0 + t * 16 + r;
-    if (m >= p.M) continue;
-    const float rs = sx.rstd_in ? sx.rstd_in[m] : (fuse ? rsqrtf(ssum[t] / (float)p.K + sx.eps) : 1.0f);
-    if constexpr (PAIRS) {
-#pragma unroll
-      for (int pr = 0; pr < RF / 2; ++pr) {
-        float a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = acc[2 * pr][t][i] * rs; b[i] = acc[2 * pr + 1][t][i] * rs; }
-        stream_epilogue4<T, ACT>(p, sx, m, fi0 + 2 * pr, 4 * q, a, b);
-      }
-    } else {
-#pragma unroll
-      for (int f = 0; f < RF; ++f) {
-        float a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = acc[f][t][i] * rs;
-        stream_epilogue4<T, ACT>(p, sx, m, fi0 + f, 4 * q, a, a);
-      }
-    }
-  }
+  stream_finish<T, MT, ACT, RF>(p, sx, s, acc, ssum, fuse, m0, sp, fi0, nfrag, nb == 0 && wn == 0, q, r);
 }
 
 // sums the K-split partials and applies the epilogue: one thread per (row, fragment or fragment pair, 4-column group).

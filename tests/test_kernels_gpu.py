@@ -347,6 +347,26 @@ def test_gemm_packed_fused_rmsnorm_and_silu(dt, M):
     assert rel_err(out.float().cpu(), ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("M", [384, 500, 513])
+def test_gemm_packed_many_rows_wide_matrix(M):
+    """384+ rows (three to five 128-row blocks per n-block, placed on one XCD) against 8192+ weight rows, bf16."""
+    dt = torch.bfloat16
+    H, Fd = 512, 4608
+    x = rnd(M, H, seed=61)
+    g, u = rnd(Fd, H, seed=62, std=H ** -0.5), rnd(Fd, H, seed=63, std=H ** -0.5)
+    xd = x.to(dev(), dt)
+    xf = q(x, dt)
+    rstd = torch.rsqrt(xf.pow(2).mean(-1) + 1e-5)
+    wgu = weights.interleave_gate_up(g, u).to(dev(), dt)
+    ref = F.silu((xf * rstd[:, None]) @ q(g, dt).T) * ((xf * rstd[:, None]) @ q(u, dt).T)
+    out = ops.gemm_decode(xd, ops.pack_weight(wgu), 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, rstd_in=rstd.to(dev()))
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+    W = rnd(8200, H, seed=64, std=H ** -0.5)
+    R = rnd(M, 8200, seed=65)
+    out2 = ops.gemm_decode(xd, ops.pack_weight(W.to(dev(), dt)), 8200, residual=R.to(dev(), dt))
+    assert rel_err(out2.float().cpu(), xf @ q(W, dt).T + q(R, dt)) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [40, 128])
 def test_gemm_packed_rstd_handoff(dt, M):
