@@ -561,6 +561,131 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   }
 }
 
+// Single-pass form for batches that fill the chip on their own (B * n_kv >= 1024), bf16: one block per (sequence, kv head)
+// walks the context in 128-key chunks with an online softmax, all products on the matrix core as in the split kernel, the
+// next chunk's K / V rows requested while the current one is processed.  No partial records, no merge launch.
+template <int REP>
+__global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __restrict__ q, int64_t q_stride, const bf16_t* __restrict__ kc,
+                                                               const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
+                                                               const int32_t* __restrict__ ctx_len, int ctx_add, int nh, int nkv, int max_ctx,
+                                                               float scale) {
+  using T = bf16_t;
+  constexpr int D = 128, KS = 128, NPS = KS / 16;
+  constexpr int PROW = KS * 2 + 16;
+  __shared__ float sc[REP][KS];
+  __shared__ float alpha[4], linv[4];
+  __shared__ __attribute__((aligned(16))) unsigned char un[KS * D * 2];   // K tile, then V tile
+  __shared__ __attribute__((aligned(16))) unsigned char pt[16 * PROW];
+  const int kvh = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, gl = lane & 15;
+  const int kg = tid >> 4, dc = tid & 15;
+  const int r = lane & 15, q4 = lane >> 4, qq = r >> 2, pp = r & 3;
+  const int n_keys = ctx_len[b] + ctx_add;
+  const T* kbase = kc + ((int64_t)b * nkv + kvh) * max_ctx * D;
+  const T* vbase = vc + ((int64_t)b * nkv + kvh) * max_ctx * D;
+  auto voff = [](int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); };
+
+  uint4 qf[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+    qf[s4] = r < REP ? *(const uint4*)(q + (int64_t)b * q_stride + (int64_t)(kvh * REP + r) * D + 32 * s4 + 8 * q4) : make_uint4(0, 0, 0, 0);
+  for (int o = tid; o < (16 - REP) * (KS / 8); o += 256)   // padding rows of P (heads REP..15) stay zero
+    *(uint4*)(pt + (REP + o / (KS / 8)) * PROW + (o % (KS / 8)) * 16) = make_uint4(0, 0, 0, 0);
+
+  u32x4_t kraw[2][NPS], vraw[2][NPS];
+  auto fetch = [&](int buf, int k0) {   // rows past the context are clamped (their scores are masked)
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      int key = k0 + ps * 16 + wave * 4 + grp; key = key < n_keys ? key : n_keys - 1;
+      kraw[buf][ps] = *(const u32x4_t*)(kbase + (int64_t)key * D + gl * 8);
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      int key = k0 + kg + 16 * ps; key = key < n_keys ? key : n_keys - 1;
+      vraw[buf][ps] = *(const u32x4_t*)(vbase + (int64_t)key * D + dc * 8);
+    }
+  };
+  f32x4 oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float m_run = -INFINITY, l_run = 0.f;   // live in wave h (< REP), replicated over its lanes
+  const uint32_t ub = (uint32_t)(uintptr_t)(lds_ptr3_t)un;
+  const int nchunk = (n_keys + KS - 1) / KS;
+  fetch(0, 0);
+  for (int c0 = 0; c0 < nchunk; c0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ci = c0 + u;
+      if (ci >= nchunk) break;
+      const int k0 = ci * KS;
+      if (ci + 1 < nchunk) fetch(u ^ 1, k0 + KS);
+      // K tile -> LDS -> scores on the matrix core
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int kl = ps * 16 + wave * 4 + grp;
+        *(u32x4_t*)(un + kl * 256 + ((gl ^ (kl & 15)) << 4)) = kraw[u][ps];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < KS / 64; ++n) {
+        const int rowbase = wave * (KS / 4) + n * 16;
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const uint4 kf = *(const uint4*)(un + (rowbase + r) * 256 + (((4 * s4 + q4) ^ r) << 4));
+          MMA<T>::step(sacc, qf[s4], kf);
+        }
+        if (q4 == 0) {
+          const int key = rowbase + r;
+#pragma unroll
+          for (int h = 0; h < REP; ++h) sc[h][key] = (k0 + key) < n_keys ? sacc[h] * scale : -INFINITY;
+        }
+      }
+      __syncthreads();
+      // online softmax: wave h owns head h (two keys per lane); P rounded to bf16 as HF eager does
+      if (wave < REP) {
+        const float s0 = sc[wave][lane], s1 = sc[wave][lane + 64];
+        const float m_new = fmaxf(m_run, wave_max(fmaxf(s0, s1)));   // finite: key k0 is inside the context
+        const float p0 = __expf(s0 - m_new), p1 = __expf(s1 - m_new);
+        const float a = __expf(m_run - m_new);                        // first chunk: exp(-inf) = 0
+        l_run = l_run * a + wave_sum(p0 + p1);
+        m_run = m_new;
+        *(T*)(pt + wave * PROW + lane * 2) = from_f32<T>(p0);
+        *(T*)(pt + wave * PROW + (lane + 64) * 2) = from_f32<T>(p1);
+        if (lane == 0) alpha[wave] = a;
+      }
+      // V tile over the (dead) K tile
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) *(u32x4_t*)(un + voff(kg + 16 * ps, dc)) = vraw[u][ps];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int df = 2 * wave + j;
+#pragma unroll
+        for (int h = 0; h < REP; ++h) oacc[j][h] *= alpha[h];
+#pragma unroll
+        for (int ks = 0; ks < KS / 32; ++ks) {
+          const uint4 pa = *(const uint4*)(pt + r * PROW + (32 * ks + 8 * q4) * 2);
+          const int r0 = 32 * ks + 8 * q4 + qq;
+          u32x2_t lo, hi;
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ub + (uint32_t)(voff(r0, 2 * df + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ub + (uint32_t)(voff(r0 + 4, 2 * df + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+          MMA<T>::step(oacc[j], pa, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+      }
+      __syncthreads();   // un / pt / sc / alpha are rewritten by the next chunk
+    }
+  }
+  if (wave < REP && lane == 0) linv[wave] = l_run > 0.f ? 1.0f / l_run : 0.f;
+  __syncthreads();
+  if (q4 == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < REP; ++h)
+        out[(int64_t)b * nh * D + (int64_t)(kvh * REP + h) * D + (2 * wave + j) * 16 + r] = from_f32<T>(oacc[j][h] * linv[h]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ out, int nh, int nkv,
                                                                   int nsplit) {
@@ -591,6 +716,14 @@ size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx) {
 template <typename T, int REP>
 static int launch_attn_decode_split(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, float* part,
                                     const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if ((int64_t)B * nkv >= 1024 && !getenv("SL_ATTN_FORCE_SPLIT")) {
+      hipLaunchKernelGGL((attn_decode_full_kernel<REP>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
+                         (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale);
+      SL_CHECK_LAUNCH("attn_decode_full");
+      return 0;
+    }
+  }
   int nsplit;
   if ((int64_t)B * nkv >= 512) {
     nsplit = (max_ctx + 127) / 128;
