@@ -562,9 +562,11 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
 }
 
 // Single-pass form for batches that fill the chip on their own (B * n_kv >= 1024), bf16: one block per (sequence, kv head)
-// walks the context in 128-key chunks with an online softmax, all products on the matrix core as in the split kernel, the
-// next chunk's K / V rows requested while the current one is processed.  No partial records, no merge launch.
-template <int REP>
+// walks the context in 128-key chunks with an online softmax, all products on the matrix core as in the split kernel.  No
+// partial records, no merge launch.  PREFETCH = false (used): a chunk's K rows are requested at its start and its V rows as
+// soon as the K registers are free (138 VGPRs, 3 blocks per CU, other blocks cover the latency): 97 us per layer at B = 512;
+// PREFETCH = true holds the next chunk's K and V rows in a second register set (239 VGPRs, 2 blocks per CU): 104 us.
+template <int REP, bool PREFETCH>
 __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __restrict__ q, int64_t q_stride, const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
                                                                const int32_t* __restrict__ ctx_len, int ctx_add, int nh, int nkv, int max_ctx,
@@ -592,37 +594,44 @@ __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __r
   for (int o = tid; o < (16 - REP) * (KS / 8); o += 256)   // padding rows of P (heads REP..15) stay zero
     *(uint4*)(pt + (REP + o / (KS / 8)) * PROW + (o % (KS / 8)) * 16) = make_uint4(0, 0, 0, 0);
 
-  u32x4_t kraw[2][NPS], vraw[2][NPS];
-  auto fetch = [&](int buf, int k0) {   // rows past the context are clamped (their scores are masked)
+  u32x4_t kraw[PREFETCH ? 2 : 1][NPS], vraw[PREFETCH ? 2 : 1][NPS];
+  auto fetch_k = [&](int buf, int k0) {   // rows past the context are clamped (their scores are masked)
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int key = k0 + ps * 16 + wave * 4 + grp; key = key < n_keys ? key : n_keys - 1;
       kraw[buf][ps] = *(const u32x4_t*)(kbase + (int64_t)key * D + gl * 8);
     }
+  };
+  auto fetch_v = [&](int buf, int k0) {
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int key = k0 + kg + 16 * ps; key = key < n_keys ? key : n_keys - 1;
       vraw[buf][ps] = *(const u32x4_t*)(vbase + (int64_t)key * D + dc * 8);
     }
   };
+  auto fetch = [&](int buf, int k0) { fetch_k(buf, k0); fetch_v(buf, k0); };
   f32x4 oacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float m_run = -INFINITY, l_run = 0.f;   // live in wave h (< REP), replicated over its lanes
   const uint32_t ub = (uint32_t)(uintptr_t)(lds_ptr3_t)un;
   const int nchunk = (n_keys + KS - 1) / KS;
-  fetch(0, 0);
+  if constexpr (PREFETCH) fetch(0, 0);
   for (int c0 = 0; c0 < nchunk; c0 += 2) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int ci = c0 + u;
+    for (int u2 = 0; u2 < 2; ++u2) {
+      constexpr int dummy = 0; (void)dummy;
+      const int u = PREFETCH ? u2 : 0;
+      const int ci = c0 + u2;
       if (ci >= nchunk) break;
       const int k0 = ci * KS;
-      if (ci + 1 < nchunk) fetch(u ^ 1, k0 + KS);
+      if constexpr (PREFETCH) { if (ci + 1 < nchunk) fetch(u ^ 1, k0 + KS); }
+      else fetch_k(0, k0);
       // K tile -> LDS -> scores on the matrix core
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
         const int kl = ps * 16 + wave * 4 + grp;
         *(u32x4_t*)(un + kl * 256 + ((gl ^ (kl & 15)) << 4)) = kraw[u][ps];
       }
+      if constexpr (!PREFETCH) fetch_v(0, k0);   // K registers are free again: V rows fly under the score / softmax phases
       __syncthreads();
 #pragma unroll
       for (int n = 0; n < KS / 64; ++n) {
@@ -718,7 +727,7 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
                                     const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if ((int64_t)B * nkv >= 1024 && !getenv("SL_ATTN_FORCE_SPLIT")) {
-      hipLaunchKernelGGL((attn_decode_full_kernel<REP>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
+      hipLaunchKernelGGL((attn_decode_full_kernel<REP, false>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
                          (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale);
       SL_CHECK_LAUNCH("attn_decode_full");
       return 0;
