@@ -164,7 +164,44 @@ def test_llama_batched_generate_equals_single():
         assert bool((ids[b, r.shape[0]:] == cfg.pad_token_id).all())
 
 
-@pytest.mark.parametrize("B", [40, 72, 130])
+def _decode_step_logits(llm, prompts, next_ids):
+    """prefill + ONE decode step through the C ABI (sl_llama_prefill, sl_llama_decode_step): fp32 logits of the new position."""
+    import ctypes as C
+    L = pkg("_lib")
+    w, lib, B = llm._dev(), L.lib(), len(prompts)
+    x = torch.cat([p.to(DEV, llm.dtype) for p in prompts]).contiguous()
+    cu = [0]
+    for p in prompts:
+        cu.append(cu[-1] + p.shape[0])
+    kv = llm._kv_cache(B)
+    ws = llm._workspace(lib.sl_generate_workspace_bytes(C.byref(w.struct), x.shape[0], B, 1))
+    logits = torch.empty((B, llm.arch.vocab_size), device=DEV, dtype=torch.float32)
+    ctx = torch.empty(B, device=DEV, dtype=torch.int32)
+    L.check(lib.sl_llama_prefill(C.byref(w.struct), C.byref(kv), x.data_ptr(), (C.c_int32 * (B + 1))(*cu), B, logits.data_ptr(), ctx.data_ptr(),
+                                 None, ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_llama_prefill")
+    nid = torch.tensor(next_ids, dtype=torch.int32, device=DEV)
+    L.check(lib.sl_llama_decode_step(C.byref(w.struct), C.byref(kv), nid.data_ptr(), ctx.data_ptr(), B, logits.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), L.stream_ptr()), "sl_llama_decode_step")
+    return logits.cpu()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, BF16_TOL)])
+def test_llama_decode_step_large_batch_matches_small_batch(dtype, tol):
+    """One decode step at 520 sequences (streaming GEMMs in 128-row blocks, tiled lm_head, single-pass attention in bf16) against
+    the same sequences five at a time (skinny GEMMs, split attention): the two kernel families must agree."""
+    cfg = TINY_LLAMA
+    llm, _ = make_llama(cfg, 33, dtype)
+    gen = torch.Generator().manual_seed(8)
+    base = [torch.randn(n, cfg.hidden_size, generator=gen) * 0.05 for n in (9, 150, 14, 5, 77)]
+    nxt = [11, 222, 3, 444, 55]
+    small = _decode_step_logits(llm, base, nxt)
+    B = 520
+    big = _decode_step_logits(llm, [base[b % 5] for b in range(B)], [nxt[b % 5] for b in range(B)])
+    for b in range(B):
+        assert rel_err(big[b], small[b % 5]) < tol, b
+
+
+@pytest.mark.parametrize("B", [40, 72, 130, 260])
 def test_llama_large_batch_decode_equals_single(B):
     """Batches above 32 rows decode through gemm_stream.hip (loader wave, K-split + reduce, RMSNorm scales handed down the
     chain); every sequence must still produce exactly the ids it produces alone (fp32: bit-exact vs the oracle)."""
