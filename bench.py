@@ -498,7 +498,7 @@ def main():
                 "traffic": pmc.get(key), "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2)}
 
     r_gemm = roof(("gemm_stream_kernel" if streaming else "gemm_skinny_kernel") + "<bf16, SILU_MUL> (gate/up projection, decode)", "gemm")
-    single_pass = B * larch.num_key_value_heads >= 1024
+    single_pass = B * larch.num_key_value_heads >= 32
     r_attn = roof(("attn_decode_full_kernel<bf16> (single-pass" if single_pass else "attn_decode_split_kernel<bf16> + merge (split") +
                   " one-token GQA attention over the KV cache, decode)", "attn")
     dominant, other = (r_attn, r_gemm) if probes["attn"][1] > probes["gemm"][1] else (r_gemm, r_attn)

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   }
 }
 
-// Single-pass form for batches that fill the chip on their own (B * n_kv >= 1024), bf16: one block per (sequence, kv head)
+// Single-pass form (bf16, B * n_kv >= 32): one block per (sequence, kv head)
 // walks the context in 128-key chunks with an online softmax, all products on the matrix core as in the split kernel.  No
 // partial records, no merge launch.  PREFETCH = false (used): a chunk's K rows are requested at its start and its V rows as
 // soon as the K registers are free (138 VGPRs, 3 blocks per CU, other blocks cover the latency): 97 us per layer at B = 512;
@@ -726,7 +726,9 @@ template <typename T, int REP>
 static int launch_attn_decode_split(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, float* part,
                                     const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    if ((int64_t)B * nkv >= 1024 && !getenv("SL_ATTN_FORCE_SPLIT")) {
+    const char* fm = getenv("SL_ATTN_FULL_MIN");   // tuning switch: (sequence, kv head) pairs from which the single-pass form runs
+    const int64_t full_min = (fm && fm[0]) ? atoi(fm) : 32;   // measured faster than split + merge from B = 4 up (9.1 vs 11.4 us), 97 vs 127 us at B = 512
+    if ((int64_t)B * nkv >= full_min && !getenv("SL_ATTN_FORCE_SPLIT")) {
       hipLaunchKernelGGL((attn_decode_full_kernel<REP, false>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
                          (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale);
       SL_CHECK_LAUNCH("attn_decode_full");
