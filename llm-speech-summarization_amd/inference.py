@@ -86,3 +86,43 @@ class LLMSpeechTextInference():
                                                   embed_tokens=self.llm.model.embed_tokens, llm_type=self.llm_type,
                                                   device=self.device)
         return self.generate_llm_response(prompt_emb_sequence, max_new_tokens)[0]
+
+    def generate_audio_responses(self, audios, additional_text_prompts=None, max_new_tokens=256) -> List[str]:
+        """Batched form of generate_audio_response (an extension: the reference answers one utterance per call).
+        Every utterance is encoded and prefilled at its own length in ONE ragged batch — the encoder writes its embeddings
+        straight into the packed prompt buffer `[prefix | text[1:] | audio | suffix[1:]]` — and decoded together, so that the
+        weights are streamed once per step for the whole batch.  Results equal per-utterance calls (tests)."""
+        if self.audio_encoder.downsample_method != "pool" or self.audio_encoder.encoder_base != "hubert":
+            return [self.generate_audio_response(a, (additional_text_prompts or [""] * len(audios))[i], max_new_tokens)
+                    for i, a in enumerate(audios)]
+        from .utils import prompt_template
+        n = len(audios)
+        texts = list(additional_text_prompts) if additional_text_prompts is not None else [""] * n
+        emb = self.llm.model.embed_tokens
+        prefix, suffix = prompt_template(self.llm_type)
+        pre_e = emb(self.llm_tokenizer(prefix, return_tensors="pt").input_ids.to(self.device))[0]
+        suf_e = emb(self.llm_tokenizer(suffix, return_tensors="pt").input_ids.to(self.device))[0, 1:]
+        txt_e = [emb(self.llm_tokenizer(t_, return_tensors="pt").input_ids[:, 1:].to(self.device))[0] if len(t_) > 0 else None for t_ in texts]
+        waves = [torch.as_tensor(a, dtype=torch.float32).reshape(-1) for a in audios]
+        enc = self.audio_encoder
+        Ps = [(enc.arch.num_frames(int(w.numel())) - enc.pool_kernel) // enc.pool_stride + 1 for w in waves]
+        lens, heads = [], []
+        for i in range(n):
+            n_head = pre_e.shape[0] + (txt_e[i].shape[0] if txt_e[i] is not None else 0)
+            heads.append(n_head)
+            lens.append(n_head + Ps[i] + suf_e.shape[0])
+        starts = [0]
+        for ln in lens:
+            starts.append(starts[-1] + ln)
+        x = torch.empty((starts[-1], pre_e.shape[1]), device=self.device, dtype=self.llm.dtype)
+        for i in range(n):
+            o = starts[i]
+            x[o:o + pre_e.shape[0]] = pre_e
+            if txt_e[i] is not None:
+                x[o + pre_e.shape[0]:o + heads[i]] = txt_e[i]
+            x[o + heads[i] + Ps[i]:starts[i + 1]] = suf_e
+        enc.encode_packed(waves, out=x, out_row_offsets=[starts[i] + heads[i] for i in range(n)])
+        ids, n_cols = self.llm.generate_packed(x, lens, max_new_tokens, use_eos=True)
+        generate_ids = ids[:, :n_cols].to(torch.int64)
+        self.last_generate_ids = generate_ids
+        return self.llm_tokenizer.batch_decode(generate_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)

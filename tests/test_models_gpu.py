@@ -269,6 +269,18 @@ def test_generate_audio_response_pipeline_fp32_ids_match_reference():
     assert text == " ".join(str(int(i)) for i in g["ids_audio"][0])
     inf.generate_audio_response(wave, additional_text_prompt="EXTRA", max_new_tokens=40)
     assert torch.equal(inf.last_generate_ids.cpu(), t(g["ids_text_audio"]))
+    # batched extension: the reference utterance with and without the text prompt plus two other lengths, one ragged batch
+    w2 = ri.synthetic_waveform(21000, seed=77).numpy()
+    w3 = ri.synthetic_waveform(9000, seed=78).numpy()
+    singles = []
+    for a_, t_ in ((w2, ""), (w3, "EXTRA")):
+        inf.generate_audio_response(a_, additional_text_prompt=t_, max_new_tokens=40)
+        singles.append(inf.last_generate_ids.cpu()[0])
+    texts = inf.generate_audio_responses([wave, wave, w2, w3], ["", "EXTRA", "", "EXTRA"], max_new_tokens=40)
+    ids = inf.last_generate_ids.cpu()
+    assert len(texts) == 4
+    for row, ref in zip(ids, [t(g["ids_audio"])[0], t(g["ids_text_audio"])[0], singles[0], singles[1]]):
+        assert torch.equal(row[:ref.shape[0]], ref) and bool((row[ref.shape[0]:] == cfg.pad_token_id).all())
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
