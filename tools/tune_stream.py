@@ -1,5 +1,8 @@
 """Streaming decode GEMM (gemm_stream.hip) sweep: the Llama-3.2-3B projections at batch M over the packed weights,
-checked against a torch fp32 product and timed over rotating weight buffers.  SL_STREAM_CFG = "kw,d,splits"."""
+checked against a torch fp32 product and timed over rotating weight buffers.
+
+    python tools/tune_stream.py 128,256,512 "default;1,4;2,4;4,2"      # SL_STREAM_CFG = "splits,nwv[,mt]" per config
+"""
 import importlib, itertools, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("llm-speech-summarization_amd.ops")
