@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (≈0.45 s each)")
     ap.add_argument("--kd-optimizer-steps", type=int, default=1, help="optimizer steps of the KD training leg (0 = skip)")
+    ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")
     args = ap.parse_args()
@@ -469,16 +470,36 @@ def main():
 
     # ---- KD training leg (BASELINE configs[2]): one optimizer step = grad_accum_interval micro-steps shared by the ranks,
     # fp32 gradient buckets all-reduced with RCCL on a side stream while backward still runs
-    kd = None
+    kd, kd_hung = None, False
     if args.kd_optimizer_steps > 0:
-        try:
-            kd = kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist)
-        except Exception as e:  # the inference line must survive a training-leg failure
-            kd = {"error": f"{type(e).__name__}: {e}"[:300]}
+        box = {}
 
-    if rank != 0:
+        def run_kd():
+            torch.cuda.set_device(dev)
+            try:
+                box["kd"] = kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist)
+            except Exception as e:  # the inference line must survive a training-leg failure
+                box["kd"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        if dist is None:
+            run_kd()
+        else:
+            # the only leg with collectives on its path: bounded, so a rank that failed alone cannot hang the headline line
+            th = threading.Thread(target=run_kd, daemon=True)
+            th.start()
+            th.join(args.kd_timeout)
+            kd_hung = th.is_alive()
+        kd = box.get("kd", {"error": f"no result after {args.kd_timeout} s (a collective did not complete)"})
+
+    def leave():
+        sys.stdout.flush()
+        if kd_hung:
+            os._exit(0)        # a stuck collective cannot be torn down cleanly
         if dist is not None:
             dist.destroy_process_group()
+
+    if rank != 0:
+        leave()
         return
 
     tokens = B * new * args.steps * world
@@ -542,8 +563,7 @@ def main():
         del llm, wts
         result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)
     print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    leave()
 
 
 if __name__ == "__main__":

@@ -57,20 +57,124 @@ __device__ __forceinline__ void tile_epilogue_g(const GemmP& p, f32x4 (&acc)[MT]
       const int col = col0 + n * 16;
       if (col >= p.N) continue;
       const float b = bias ? to_f32(bias[col]) : 0.f;
+      // residual column first, all rows at once on clamped addresses: loads under the per-row bounds test are issued
+      // and waited for one by one (MT*4 memory latencies in a chain per column, measured 2x on K = 1024 products)
+      constexpr int MG = ACT == SL_ACT_GELU ? 1 : (MT < 4 ? MT : 4);   // 16 residual loads in flight per column (4 beside erf: more spills the 256-row tile)
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int mg = 0; mg < MT; mg += MG) {
+        float rv[MG][4];
+        if (Rb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = row0 + m * 16 + i;
-          if (row < p.M) {
-            float v = acc[m][n][i] + b;
-            if (p.aux) ((T*)p.aux + co)[(int64_t)row * p.ldc + col] = from_f32<T>(v);
-            if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
-            store_out<T>(p, Cb, Rb, row, col, v);
-          }
+          for (int m = 0; m < MG; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              int row = row0 + (mg + m) * 16 + i;
+              row = row < p.M ? row : p.M - 1;
+              rv[m][i] = p.res_f32 ? ((const float*)Rb)[(int64_t)row * p.ldr + col] : to_f32(((const T*)Rb)[(int64_t)row * p.ldr + col]);
+            }
         }
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = row0 + (mg + m) * 16 + i;
+            if (row < p.M) {
+              float v = acc[mg + m][n][i] + b;
+              if (p.aux) ((T*)p.aux + co)[(int64_t)row * p.ldc + col] = from_f32<T>(v);
+              if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
+              if (Rb) v += rv[m][i];
+              store_out<T>(p, Cb, nullptr, row, col, v);
+            }
+          }
+      }
     }
   }
+}
+
+// four consecutive output elements <-> registers: 8-byte (bf16) / 16-byte (f32) accesses
+__device__ __forceinline__ void ld4(const float* ptr, float (&f)[4]) {
+  const f32x4 v = *(const f32x4*)ptr;
+  f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+}
+__device__ __forceinline__ void ld4(const bf16_t* ptr, float (&f)[4]) {
+  const uint2 u = *(const uint2*)ptr;
+  f[0] = bf16_bits_to_f32(u.x & 0xffffu); f[1] = bf16_bits_to_f32(u.x >> 16);
+  f[2] = bf16_bits_to_f32(u.y & 0xffffu); f[3] = bf16_bits_to_f32(u.y >> 16);
+}
+__device__ __forceinline__ void st4(float* ptr, const float (&f)[4]) { *(f32x4*)ptr = f32x4{f[0], f[1], f[2], f[3]}; }
+__device__ __forceinline__ void st4(bf16_t* ptr, const float (&f)[4]) { *(uint2*)ptr = make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])); }
+
+// Row-contiguous epilogue: the MFMA accumulator layout gives a lane ONE column of four rows, so the direct epilogue
+// above moves 2-byte elements (a wave-level access = 4 rows x 32 B; the residual read alone doubled the time of the
+// K = 1024 encoder products).  Here each wave turns its 64 x 64 sub-tile through its own 16 KiB of the (now idle)
+// staging LDS — written in accumulator layout, column index XOR 16*(row/4 % 4) so the four row groups of a store hit
+// different banks, read back as rows — and 16 lanes then cover 128 contiguous bytes of one output row: bias, residual,
+// pre-activation copy and result all move as 8/16-byte vectors.  Returns false (nothing done) when the operands do
+// not allow 4-element vectors; the caller falls back to the direct epilogue.
+template <typename T, int ACT, int MT>
+__device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int z, int wz, float* wsm) {
+  static_assert(MT % 4 == 0 && ACT != SL_ACT_SILU_MUL, "64-row passes; the gate/up pairing keeps the direct epilogue");
+  const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
+  const uintptr_t ca = p.out_f32 ? 15 : (4 * sizeof(T) - 1), ra = p.res_f32 ? 15 : (4 * sizeof(T) - 1);
+  if ((p.N & 3) || (p.ldc & 3) || (co & 3) || ((uintptr_t)p.C & ca) || (p.aux && ((uintptr_t)p.aux & (4 * sizeof(T) - 1))) ||
+      (p.res && ((p.ldr & 3) || (ro & 3) || ((uintptr_t)p.res & ra))))
+    return false;
+  const int q = lane >> 4, r = lane & 15;
+  const int c4 = r * 4;                       // read phase: lane = (row within a 4-row pass, 4-column group)
+  const int col = col_base + c4;
+  const bool col_ok = col < p.N;
+  const int colc = col_ok ? col : 0;
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && col_ok) {
+    const T* bias = (const T*)p.bias + (int64_t)wz * p.sBias + col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = to_f32(bias[j]);
+  }
+#pragma unroll
+  for (int mg = 0; mg < MT; mg += 4) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wsm[(m * 16 + 4 * q + i) * 64 + ((n * 16 + r) ^ (q << 4))] = acc[mg + m][n][i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0 += 4) {
+      float rv[4][4];
+      if (p.res) {   // the whole group's residual rows first, on clamped addresses, so the loads overlap
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int64_t row = row_base + mg * 16 + (t0 + u) * 4 + q;
+          row = row < p.M ? row : p.M - 1;
+          if (p.res_f32) ld4((const float*)p.res + ro + row * p.ldr + colc, rv[u]);
+          else ld4((const T*)p.res + ro + row * p.ldr + colc, rv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u, lr = t * 4 + q;
+        const int64_t row = row_base + mg * 16 + lr;
+        const f32x4 a = *(const f32x4*)&wsm[lr * 64 + (c4 ^ ((t & 3) << 4))];
+        float v[4] = {a[0] + b4[0], a[1] + b4[1], a[2] + b4[2], a[3] + b4[3]};
+        if (row < p.M && col_ok) {
+          if (p.aux) st4((T*)p.aux + co + row * p.ldc + col, v);
+          if constexpr (ACT == SL_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+          }
+          if (p.res) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rv[u][j];
+          }
+          if (p.out_f32) st4((float*)p.C + co + row * p.ldc + col, v);
+          else st4((T*)p.C + co + row * p.ldc + col, v);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  return true;
 }
 
 template <typename T, int ACT>
@@ -207,6 +311,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
     __syncthreads();
   }
 
+  if constexpr (ACT != SL_ACT_SILU_MUL) {
+    if (!p.direct_epi && tile_epilogue_rows<T, ACT, 4>(p, acc, bm * TBM + wm * 64, bn * TBN + wn * 64, lane, z, wz, (float*)&smem[0][0][0] + wave * 4096)) return;
+  }
   tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, wz);
 }
 
@@ -337,6 +444,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
       __syncthreads();
     }
   }
+  if constexpr (ACT != SL_ACT_SILU_MUL) {
+    if (!p.direct_epi && tile_epilogue_rows<T, ACT, 4>(p, acc, bm * TBM + wm * 64, bn * TBN + wn * 64, lane, z, wz, (float*)&smem[0][0][0] + wave * 4096)) return;
+  }
   tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, wz);
 }
 
@@ -442,6 +552,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
+  if constexpr (ACT != SL_ACT_SILU_MUL) {
+    if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)&smem[0][0][0] + wave * 4096)) return;
   }
   tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, q, r, z, wz);
 }
@@ -804,6 +917,8 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0;
+  static const int direct_epi = getenv("SL_DIRECT_EPILOGUE") ? atoi(getenv("SL_DIRECT_EPILOGUE")) : 0;
+  p.direct_epi = direct_epi;
   if (ex) {
     p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;
     p.grp = ex->groups; p.w_mod = ex->w_mod > 0 ? ex->w_mod : 1;
