@@ -101,6 +101,11 @@ __device__ __forceinline__ void ld4(const bf16_t* ptr, float (&f)[4]) {
   f[0] = bf16_bits_to_f32(u.x & 0xffffu); f[1] = bf16_bits_to_f32(u.x >> 16);
   f[2] = bf16_bits_to_f32(u.y & 0xffffu); f[3] = bf16_bits_to_f32(u.y >> 16);
 }
+__device__ __forceinline__ void unpack4(const f32x4& v, float (&f)[4]) { f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
+__device__ __forceinline__ void unpack4(const uint2& u, float (&f)[4]) {
+  f[0] = bf16_bits_to_f32(u.x & 0xffffu); f[1] = bf16_bits_to_f32(u.x >> 16);
+  f[2] = bf16_bits_to_f32(u.y & 0xffffu); f[3] = bf16_bits_to_f32(u.y >> 16);
+}
 __device__ __forceinline__ void st4(float* ptr, const float (&f)[4]) { *(f32x4*)ptr = f32x4{f[0], f[1], f[2], f[3]}; }
 __device__ __forceinline__ void st4(bf16_t* ptr, const float (&f)[4]) { *(uint2*)ptr = make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])); }
 
@@ -130,8 +135,22 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
     for (int j = 0; j < 4; ++j) b4[j] = to_f32(bias[j]);
   }
+  using RawT = typename std::conditional<sizeof(T) == 2, uint2, f32x4>::type;   // four residual elements of type T as loaded
+  const bool res_t = p.res && !p.res_f32;
 #pragma unroll
   for (int mg = 0; mg < MT; mg += 4) {
+    // residual in the output's type (the encoder / prefill form): all 16 row passes of this 64-row group are requested
+    // before the tile is turned through LDS, on clamped addresses, so one memory latency is exposed per group (issued
+    // pass by pass under the bounds test they cost ~45 % on the K = 1024 products)
+    RawT raw[16];
+    if (res_t) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        int64_t row = row_base + mg * 16 + t * 4 + q;
+        row = row < p.M ? row : p.M - 1;
+        raw[t] = *(const RawT*)((const T*)p.res + ro + row * p.ldr + colc);
+      }
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -142,13 +161,12 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
     for (int t0 = 0; t0 < 16; t0 += 4) {
       float rv[4][4];
-      if (p.res) {   // the whole group's residual rows first, on clamped addresses, so the loads overlap
+      if (p.res_f32 && p.res) {   // fp32 accumulation targets (weight gradients): four passes at a time
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           int64_t row = row_base + mg * 16 + (t0 + u) * 4 + q;
           row = row < p.M ? row : p.M - 1;
-          if (p.res_f32) ld4((const float*)p.res + ro + row * p.ldr + colc, rv[u]);
-          else ld4((const T*)p.res + ro + row * p.ldr + colc, rv[u]);
+          ld4((const float*)p.res + ro + row * p.ldr + colc, rv[u]);
         }
       }
 #pragma unroll
@@ -163,7 +181,12 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
           }
-          if (p.res) {
+          if (res_t) {
+            float rr[4];
+            unpack4(raw[t], rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rr[j];
+          } else if (p.res) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += rv[u][j];
           }
@@ -790,7 +813,8 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
     const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
     const char* te = getenv("SL_T256_MIN_TILES");   // tuning switch
     const int64_t min_tiles = (te && te[0]) ? atoi(te) : 512;
-    if (t256 >= min_tiles && p.N >= 192 && p.K >= 2048) {   // short K: the 128 tile's two blocks per CU hide the pro/epilogue better
+    static const int min_k = getenv("SL_T256_MIN_K") ? atoi(getenv("SL_T256_MIN_K")) : 1024;
+    if (t256 >= min_tiles && p.N >= 192 && p.K >= min_k) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
       hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);

@@ -3,7 +3,10 @@ import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("llm-speech-summarization_amd.ops")
 dev = "cuda:0"
-for M, N, K in [(255488, 1024, 1024), (255488, 1024, 4096), (63872, 3072, 1024), (17408, 3072, 8192)]:
+shapes = [(255488, 1024, 1024), (255488, 1024, 4096), (63872, 3072, 1024), (17408, 3072, 8192)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
+for M, N, K in shapes:
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
     W = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     bias = torch.randn(N, device=dev).to(torch.bfloat16)
