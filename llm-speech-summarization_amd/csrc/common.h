@@ -67,8 +67,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(uint16_t, h);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// one v_cvt_pk_bf16_f32 (converting the halves separately and OR-ing them costs four instructions per pair)
 __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
