@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
     T* orow = out + (t0 + tt) * C + lane * CPL;
     float o[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) o[c] = gelu_erf((y[c] - mean) * rstd * gr[c] + ber[c]);
+    for (int c = 0; c < CPL; ++c) o[c] = gelu_act<T>((y[c] - mean) * rstd * gr[c] + ber[c]);
     constexpr int VEC = Vec16<T>::VEC;
     if constexpr (CPL % VEC == 0) {
 #pragma unroll

@@ -81,7 +81,7 @@ __device__ __forceinline__ void tile_epilogue_g(const GemmP& p, f32x4 (&acc)[MT]
             if (row < p.M) {
               float v = acc[mg + m][n][i] + b;
               if (p.aux) ((T*)p.aux + co)[(int64_t)row * p.ldc + col] = from_f32<T>(v);
-              if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
+              if constexpr (ACT == SL_ACT_GELU) v = gelu_act<T>(v);
               if (Rb) v += rv[m][i];
               store_out<T>(p, Cb, nullptr, row, col, v);
             }
@@ -179,7 +179,7 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
           if (p.aux) st4((T*)p.aux + co + row * p.ldc + col, v);
           if constexpr (ACT == SL_ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = gelu_act<T>(v[j]);
           }
           if (res_t) {
             float rr[4];
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX s
       if (col >= p.N) continue;
       float v = rsum(n, m) * row_scale(m);
       if (bias) v += to_f32(bias[col]);
-      if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
+      if constexpr (ACT == SL_ACT_GELU) v = gelu_act<T>(v);
       store_out<T>(p, Cb, Rb, m, col, v);
     }
   }

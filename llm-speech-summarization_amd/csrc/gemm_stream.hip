@@ -70,7 +70,7 @@ __device__ __forceinline__ void stream_epilogue4(const GemmP& p, const SkinnyX& 
       if (col >= p.N) continue;
       float v = a[i];
       if (bias) v += to_f32(bias[col]);
-      if constexpr (ACT == SL_ACT_GELU) v = gelu_erf(v);
+      if constexpr (ACT == SL_ACT_GELU) v = gelu_act<T>(v);
       store_out<T>(p, p.C, p.res, m, col, v);
     }
   }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T* __restrict__ x,
           o[e] = gg[e] * t;
         } else {
           float t = (v[i][e] - mean) * rstd * gg[e] + bb[e];
-          o[e] = gelu ? gelu_erf(t) : t;
+          o[e] = gelu ? gelu_act<T>(t) : t;
         }
       }
       *(uint4*)(yr + ch * VEC) = Vec16<T>::pack(o);
