@@ -123,6 +123,43 @@ __global__ __launch_bounds__(256) void posconv_stage_kernel(const T* __restrict_
   }
 }
 
+// whole ragged batch in one launch: utterance u = blockIdx.y, frames cu[u] .. cu[u] + klen[u]; its staged rows follow
+// those of the utterances before it, each with k rows of padding ((cu[u] + u k) rows in)
+template <typename T>
+__global__ __launch_bounds__(256) void posconv_stage_batch_kernel(const T* __restrict__ x, T* __restrict__ xg, const int32_t* __restrict__ cu,
+                                                                  const int32_t* __restrict__ klen, int H, int groups, int k) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int u = blockIdx.y;
+  const int64_t T_ = klen[u], tok0 = cu[u];
+  x += tok0 * H;
+  xg += (tok0 + (int64_t)u * k) * H;
+  const int Hg = H / groups, cpr = Hg / VEC;
+  const int64_t rows = T_ + k;
+  const int64_t total = (int64_t)groups * rows * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % cpr);
+    const int64_t rr = (i / cpr) % rows;
+    const int g = (int)(i / (cpr * rows));
+    const int64_t t = rr - k / 2;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t >= 0 && t < T_) v = *(const uint4*)(x + t * H + g * Hg + ch * VEC);
+    *(uint4*)(xg + ((int64_t)g * rows + rr) * Hg + ch * VEC) = v;
+  }
+}
+
+int sl_posconv_stage_batch(const void* x, void* xg, const int32_t* cu, const int32_t* klen, int32_t n_utt, int64_t max_T, int32_t H,
+                           int32_t groups, int32_t k, int32_t dtype, sl_stream stream) {
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(x && xg && cu && klen && n_utt > 0 && groups > 0 && H % groups == 0 && (H / groups) % vec == 0, "sl_posconv_stage_batch: bad arguments");
+  const int64_t total = (int64_t)groups * (max_T + k) * (H / groups / vec);
+  const unsigned gx = (unsigned)(ceil_div64(total, 256) < 64 ? ceil_div64(total, 256) : 64);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((posconv_stage_batch_kernel<T>), dim3(gx, n_utt), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)xg, cu, klen, H, groups, k);
+  });
+  SL_CHECK_LAUNCH("posconv_stage_batch");
+  return 0;
+}
+
 extern "C" int sl_posconv_stage(const void* x, void* xg, int64_t T_, int32_t H, int32_t groups, int32_t k, int32_t dtype,
                                 sl_stream stream) {
   SL_CHECK_ARG(x && xg && T_ > 0 && groups > 0 && H % groups == 0, "sl_posconv_stage: bad arguments");
@@ -164,6 +201,55 @@ __global__ __launch_bounds__(256) void avgpool_rows_kernel(const T* __restrict__
     for (int j = 0; j < VEC; ++j) acc[j] *= inv;
     *(uint4*)(y + p * H + ch * VEC) = Vec16<T>::pack(acc);
   }
+}
+
+// AvgPool1d over time for the whole ragged batch: utterance u = blockIdx.y pools its klen[u] frames (rows cu[u]..) into
+// rec[4u] rows that start rec[4u+1] ELEMENTS into y (the records of the grouped projector GEMM that follows)
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_batch_kernel(const T* __restrict__ x, T* __restrict__ y, const int32_t* __restrict__ cu,
+                                                            const int32_t* __restrict__ klen, const int64_t* __restrict__ rec, int H, int kernel,
+                                                            int stride) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int u = blockIdx.y;
+  const int64_t T_ = klen[u], P = rec[4 * u];
+  x += (int64_t)cu[u] * H;
+  y += rec[4 * u + 1];
+  const int cpr = H / VEC;
+  const int64_t total = P * cpr;
+  const float inv = 1.0f / (float)kernel;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % cpr);
+    const int64_t pi = i / cpr;
+    const int64_t s0 = pi * stride;
+    int64_t e = s0 + kernel;
+    if (e > T_) e = T_;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int64_t t = s0; t < e; ++t) {
+      float f[VEC];
+      Vec16<T>::unpack(*(const uint4*)(x + t * H + ch * VEC), f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] *= inv;
+    *(uint4*)(y + pi * H + ch * VEC) = Vec16<T>::pack(acc);
+  }
+}
+
+int sl_avgpool_batch(const void* x, void* y, const int32_t* cu, const int32_t* klen, const int64_t* rec, int32_t n_utt, int64_t max_P, int32_t H,
+                     int32_t kernel, int32_t stride, int32_t dtype, sl_stream stream) {
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(x && y && cu && klen && rec && n_utt > 0 && H % vec == 0 && kernel > 0 && stride > 0, "sl_avgpool_batch: bad arguments");
+  if (max_P <= 0) return 0;
+  const int64_t total = max_P * (H / vec);
+  const unsigned gx = (unsigned)(ceil_div64(total, 256) < 64 ? ceil_div64(total, 256) : 64);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((avgpool_batch_kernel<T>), dim3(gx, n_utt), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, cu, klen, rec, H, kernel, stride);
+  });
+  SL_CHECK_LAUNCH("avgpool_batch");
+  return 0;
 }
 
 extern "C" int sl_avgpool_rows(const void* x, void* y, int64_t T_, int32_t H, int32_t kernel, int32_t stride, const int32_t* ranges,

@@ -814,7 +814,9 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
     const char* te = getenv("SL_T256_MIN_TILES");   // tuning switch
     const int64_t min_tiles = (te && te[0]) ? atoi(te) : 512;
     static const int min_k = getenv("SL_T256_MIN_K") ? atoi(getenv("SL_T256_MIN_K")) : 1024;
-    if (t256 >= min_tiles && p.N >= 192 && p.K >= min_k) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
+    // rows padded to 256 vs to 128: short (grouped) products such as the 123-row projector would half-fill the big tile
+    const int64_t m128 = (int64_t)((p.M + TBM - 1) / TBM) * TBM, m256 = (int64_t)((p.M + XBM - 1) / XBM) * XBM;
+    if (t256 >= min_tiles && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
       hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);

@@ -91,6 +91,7 @@ struct HubertWs {
   void *convA, *convB, *feat, *x, *ln, *qkv, *att, *mid, *xg, *pooled;
   int32_t *cu, *cuk, *klen;
   int64_t* desc;
+  int64_t* pdesc;   // per utterance {pooled rows, element offset into `pooled`, element offset into `out`, 0}: AvgPool + grouped projector
 };
 
 static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n_utt, void* base, size_t cap, HubertWs& w) {
@@ -108,10 +109,24 @@ static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n
   w.xg = c.take((pl.total_T + (int64_t)n_utt * m->pos_k) * H * sz);
   w.desc = (int64_t*)c.take((size_t)((m->n_conv - 1) * n_utt + n_utt * m->pos_groups) * 4 * sizeof(int64_t));
   w.pooled = c.take(pl.total_P * H * sz);
+  w.pdesc = (int64_t*)c.take((size_t)n_utt * 4 * sizeof(int64_t));
   w.cu = (int32_t*)c.take((n_utt + 1) * sizeof(int32_t));
   w.cuk = (int32_t*)c.take(n_utt * sizeof(int32_t));
   w.klen = (int32_t*)c.take(n_utt * sizeof(int32_t));
   return c.off + 256;
+}
+
+// records of the pooled rows / projector output rows of every utterance (see HubertWs::pdesc)
+static void proj_records(const sl_hubert_model* m, const HubertPlan& pl, int n_utt, int64_t out_ld, const int64_t* out_row_offsets_host,
+                         std::vector<int64_t>& rec) {
+  rec.assign((size_t)n_utt * 4, 0);
+  int64_t prow = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    rec[4 * u] = pl.P[u];
+    rec[4 * u + 1] = prow * m->hidden;
+    rec[4 * u + 2] = (out_row_offsets_host ? out_row_offsets_host[u] : prow) * out_ld;
+    prow += pl.P[u];
+  }
 }
 
 // transformer layers on the packed frames of the batch (varlen attention), final LayerNorm, AvgPool + projection.
@@ -144,17 +159,22 @@ static int encoder_tail(const sl_hubert_model* m, HubertWs& w, const HubertPlan&
   void* lh = last_hidden ? last_hidden : w.ln;
   SL_TRY(sl_layernorm(w.x, lh, m->final_ln_g, m->final_ln_b, NT, H, m->ln_eps, 0, dt, stream));
   // ---- AvgPool over time + projection into the caller's (prompt) buffer
-  int64_t prow = 0;
   if (!m->proj_w) return 0;  // stack / ctc_pool: the host finishes from last_hidden
-  for (int u = 0; u < n_utt; ++u) {
-    unsigned char* src = bptr(lh) + pl.tok0[u] * H * sz;
-    unsigned char* pooled = bptr(w.pooled) + prow * H * sz;
-    SL_TRY(sl_avgpool_rows(src, pooled, pl.T[u], H, m->pool_kernel, m->pool_stride, nullptr, pl.P[u], dt, stream));
-    const int64_t orow = out_row_offsets_host ? out_row_offsets_host[u] : prow;
-    SL_TRY(gemm(dt, pooled, H, m->proj_w, H, bptr(out) + orow * out_ld * sz, out_ld, m->proj_b, nullptr, 0, (int)pl.P[u], m->llm_dim, H,
-                SL_ACT_NONE, 0, st));
-    prow += pl.P[u];
-  }
+  // one AvgPool launch and one grouped projector GEMM for the whole ragged batch (records uploaded by the caller: w.pdesc)
+  int64_t max_P = 0;
+  for (int u = 0; u < n_utt; ++u) max_P = pl.P[u] > max_P ? pl.P[u] : max_P;
+  SL_TRY(sl_avgpool_batch(lh, w.pooled, w.cu, w.klen, w.pdesc, n_utt, max_P, H, m->pool_kernel, m->pool_stride, dt, stream));
+  sl_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = w.pooled; a.lda = H;
+  a.W = m->proj_w; a.ldw = H;
+  a.C = out; a.ldc = out_ld;
+  a.bias = m->proj_b;
+  a.M = (int)max_P; a.N = m->llm_dim; a.K = H; a.batch = n_utt; a.dtype = dt; a.act = SL_ACT_NONE;
+  sl_gemm_ex_args ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.groups = w.pdesc; ex.w_mod = 1;
+  SL_TRY(sl_gemm_impl(&a, nullptr, &ex, st));
   return 0;
 }
 
@@ -217,6 +237,9 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
     SL_HIP(hipMemcpyAsync(w.cuk, cu.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipMemcpyAsync(w.klen, kl.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipMemcpyAsync(w.desc, desc.data(), desc.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    std::vector<int64_t> prec;
+    proj_records(m, pl, n_utt, out_ld, out_row_offsets_host, prec);
+    SL_HIP(hipMemcpyAsync(w.pdesc, prec.data(), prec.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipStreamSynchronize(st));  // host vectors go out of scope; pageable copies are staged but be explicit
   }
   // ---- conv feature extractor: layer 0 per utterance (fused conv+LN+GELU), layers 1.. as ONE grouped implicit GEMM
@@ -249,8 +272,7 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
   SL_TRY(gemm(dt, w.feat, Cl, m->fp_w, Cl, w.x, H, m->fp_b, nullptr, 0, NT, H, Cl, SL_ACT_NONE, 0, st));
   // ---- positional conv embedding: x += gelu(grouped_conv(x)); every (utterance, group) is one record of ONE grouped GEMM
   {
-    for (int u = 0; u < n_utt; ++u)
-      SL_TRY(sl_posconv_stage(bptr(w.x) + pl.tok0[u] * H * sz, bptr(w.xg) + xg_off[u] * sz, pl.T[u], H, G, kpos, dt, stream));
+    SL_TRY(sl_posconv_stage_batch(w.x, w.xg, w.cu, w.klen, n_utt, pl.max_T, H, G, kpos, dt, stream));
     sl_gemm_args a;
     memset(&a, 0, sizeof(a));
     a.A = w.xg; a.lda = Hg;
@@ -315,6 +337,9 @@ extern "C" int sl_whisper_forward(const sl_hubert_model* m, const void* mel, int
     SL_HIP(hipMemcpyAsync(w.cu, cu.data(), (n_utt + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipMemcpyAsync(w.cuk, cu.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipMemcpyAsync(w.klen, kl.data(), n_utt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    std::vector<int64_t> prec;
+    proj_records(m, pl, n_utt, out_ld, out_row_offsets_host, prec);
+    SL_HIP(hipMemcpyAsync(w.pdesc, prec.data(), prec.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipStreamSynchronize(st));
   }
   // haloed inputs: one zero row before and after each utterance's frames (Conv1d padding=1)
