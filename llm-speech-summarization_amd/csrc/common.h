@@ -194,3 +194,6 @@ int sl_posconv_stage_batch(const void* x, void* xg, const int32_t* cu, const int
                            int32_t groups, int32_t k, int32_t dtype, sl_stream stream);
 int sl_avgpool_batch(const void* x, void* y, const int32_t* cu, const int32_t* klen, const int64_t* rec, int32_t n_utt, int64_t max_P, int32_t H,
                      int32_t kernel, int32_t stride, int32_t dtype, sl_stream stream);
+int sl_hubert_conv0_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev, int32_t n_utt, int64_t max_L,
+                          const float* w, const float* bias, const float* gamma, const float* beta, void* out, int32_t C, int32_t k,
+                          int32_t stride, float eps, int32_t dtype, sl_stream stream);

@@ -9,14 +9,12 @@
 #include "common.h"
 
 template <typename T, int CPL, int K, int STRIDE>
-__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ wave, int64_t n_samples,
-                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            T* __restrict__ out, int64_t L, float eps) {
+__device__ __forceinline__ void conv0_strip(const float* __restrict__ wave, int64_t n_samples, const float* __restrict__ w,
+                                            const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            T* __restrict__ out, int64_t L, float eps, int64_t strip) {
   constexpr int C = 64 * CPL;
   constexpr int TS = (128 - (K - STRIDE)) / STRIDE;  // time steps per wave strip (24 for k=10, s=5)
   const int lane = threadIdx.x & 63;
-  const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t t0 = strip * TS;
   if (t0 >= L) return;
 
@@ -72,6 +70,55 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
       for (int c = 0; c < CPL; ++c) orow[c] = from_f32<T>(o[c]);
     }
   }
+}
+
+template <typename T, int CPL, int K, int STRIDE>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ wave, int64_t n_samples,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ out, int64_t L, float eps) {
+  conv0_strip<T, CPL, K, STRIDE>(wave, n_samples, w, bias, gamma, beta, out, L, eps, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// the whole ragged batch in one launch (utterance = blockIdx.y): one utterance alone is ~1300 waves, i.e. one or two
+// per SIMD — nothing hides the LayerNorm reductions' latency and the second round of waves doubles the makespan
+template <typename T, int CPL, int K, int STRIDE>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_batch_kernel(const float* __restrict__ waves, const int64_t* __restrict__ soff,
+                                                                  const int64_t* __restrict__ row0, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, T* __restrict__ out, float eps) {
+  const int u = blockIdx.y;
+  const int64_t s0 = soff[u], r0 = row0[u];
+  conv0_strip<T, CPL, K, STRIDE>(waves + s0, soff[u + 1] - s0, w, bias, gamma, beta, out + r0 * (64 * CPL), row0[u + 1] - r0, eps,
+                                 (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+template <typename T, int CPL>
+static int launch_conv0_batch(const float* waves, const int64_t* soff, const int64_t* row0, int n_utt, int64_t max_L, const float* w,
+                              const float* b, const float* g, const float* be, void* out, float eps, hipStream_t st) {
+  constexpr int TS = (128 - 5) / 5;
+  const int64_t strips = ceil_div64(max_L, TS);
+  hipLaunchKernelGGL((conv0_ln_gelu_batch_kernel<T, CPL, 10, 5>), dim3((unsigned)ceil_div64(strips, 4), n_utt), dim3(256), 0, st, waves, soff,
+                     row0, w, b, g, be, (T*)out, eps);
+  SL_CHECK_LAUNCH("conv0_ln_gelu_batch");
+  return 0;
+}
+
+int sl_hubert_conv0_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev, int32_t n_utt, int64_t max_L,
+                          const float* w, const float* bias, const float* gamma, const float* beta, void* out, int32_t C, int32_t k,
+                          int32_t stride, float eps, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(waves && sample_offsets_dev && row_offsets_dev && w && bias && gamma && beta && out && n_utt > 0, "sl_hubert_conv0_batch: bad arguments");
+  SL_CHECK_ARG(k == 10 && stride == 5, "sl_hubert_conv0_batch: only the HuBERT layer-0 geometry k=10, stride=5 is built (got k=%d s=%d)", k, stride);
+  hipStream_t st = (hipStream_t)stream;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    switch (C) {
+      case 64: return launch_conv0_batch<T, 1>(waves, sample_offsets_dev, row_offsets_dev, n_utt, max_L, w, bias, gamma, beta, out, eps, st);
+      case 128: return launch_conv0_batch<T, 2>(waves, sample_offsets_dev, row_offsets_dev, n_utt, max_L, w, bias, gamma, beta, out, eps, st);
+      case 256: return launch_conv0_batch<T, 4>(waves, sample_offsets_dev, row_offsets_dev, n_utt, max_L, w, bias, gamma, beta, out, eps, st);
+      case 512: return launch_conv0_batch<T, 8>(waves, sample_offsets_dev, row_offsets_dev, n_utt, max_L, w, bias, gamma, beta, out, eps, st);
+      default: sl_set_error("sl_hubert_conv0_batch: C=%d must be 64, 128, 256 or 512", C); return SL_ERR_ARG;
+    }
+  });
 }
 
 template <typename T, int CPL>

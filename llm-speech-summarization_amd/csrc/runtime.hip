@@ -91,6 +91,7 @@ struct HubertWs {
   void *convA, *convB, *feat, *x, *ln, *qkv, *att, *mid, *xg, *pooled;
   int32_t *cu, *cuk, *klen;
   int64_t* desc;
+  int64_t* c0desc;  // n_utt + 1 sample offsets, then n_utt + 1 row offsets of the conv0 output (batched conv0 launch)
   int64_t* pdesc;   // per utterance {pooled rows, element offset into `pooled`, element offset into `out`, 0}: AvgPool + grouped projector
 };
 
@@ -110,6 +111,7 @@ static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n
   w.desc = (int64_t*)c.take((size_t)((m->n_conv - 1) * n_utt + n_utt * m->pos_groups) * 4 * sizeof(int64_t));
   w.pooled = c.take(pl.total_P * H * sz);
   w.pdesc = (int64_t*)c.take((size_t)n_utt * 4 * sizeof(int64_t));
+  w.c0desc = (int64_t*)c.take((size_t)(n_utt + 1) * 2 * sizeof(int64_t));
   w.cu = (int32_t*)c.take((n_utt + 1) * sizeof(int32_t));
   w.cuk = (int32_t*)c.take(n_utt * sizeof(int32_t));
   w.klen = (int32_t*)c.take(n_utt * sizeof(int32_t));
@@ -240,15 +242,19 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
     std::vector<int64_t> prec;
     proj_records(m, pl, n_utt, out_ld, out_row_offsets_host, prec);
     SL_HIP(hipMemcpyAsync(w.pdesc, prec.data(), prec.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    std::vector<int64_t> c0(2 * (size_t)(n_utt + 1));
+    for (int u = 0; u <= n_utt; ++u) { c0[u] = sample_offsets_host[u] - sample_offsets_host[0]; c0[n_utt + 1 + u] = row0[0][u]; }
+    SL_HIP(hipMemcpyAsync(w.c0desc, c0.data(), c0.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipStreamSynchronize(st));  // host vectors go out of scope; pageable copies are staged but be explicit
   }
   // ---- conv feature extractor: layer 0 per utterance (fused conv+LN+GELU), layers 1.. as ONE grouped implicit GEMM
   //      + ONE LayerNorm+GELU over the packed rows of the whole batch
   void* cur = w.convA;
-  for (int u = 0; u < n_utt; ++u) {
-    const int64_t n = sample_offsets_host[u + 1] - sample_offsets_host[u];
-    SL_TRY(sl_hubert_conv0(waves + sample_offsets_host[u], n, m->conv0_w, m->conv0_b, m->conv0_g, m->conv0_beta,
-                           bptr(cur) + row0[0][u] * m->conv_dim[0] * sz, m->conv_dim[0], m->conv_kernel[0], m->conv_stride[0], 1e-5f, dt, stream));
+  {
+    int64_t max_L0 = 0;
+    for (int u = 0; u < n_utt; ++u) max_L0 = Lc[0][u] > max_L0 ? Lc[0][u] : max_L0;
+    SL_TRY(sl_hubert_conv0_batch(waves + sample_offsets_host[0], w.c0desc, w.c0desc + n_utt + 1, n_utt, max_L0, m->conv0_w, m->conv0_b, m->conv0_g,
+                                 m->conv0_beta, cur, m->conv_dim[0], m->conv_kernel[0], m->conv_stride[0], 1e-5f, dt, stream));
   }
   for (int i = 1; i < nc; ++i) {
     const int Cin = m->conv_dim[i - 1], Cout = m->conv_dim[i], k = m->conv_kernel[i], s = m->conv_stride[i];
