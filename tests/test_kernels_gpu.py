@@ -246,6 +246,35 @@ def test_attention_causal_gqa_d128(dt, seqlens, nh, nkv):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("D,nh,nkv", [(64, 4, 4), (128, 6, 2)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_keys_longer_than_queries(dt, D, nh, nkv, causal):
+    """Separate q / k / v buffers with more keys than queries per sequence (a prompt continued against cached keys): causal
+    visibility is j <= i + (klen - qlen); covers both query-tile widths of the bf16 kernel and ragged tails."""
+    qlens, klens = [70, 1, 260, 33], [200, 64, 300, 33]
+    gq, gk = torch.Generator().manual_seed(41), torch.Generator().manual_seed(42)
+    qt = torch.randn(sum(qlens), nh * D, generator=gq)
+    kt = torch.randn(sum(klens), nkv * D, generator=gk)
+    vt = torch.randn(sum(klens), nkv * D, generator=gk)
+    cu_q = torch.tensor([0] + list(torch.tensor(qlens).cumsum(0)), dtype=torch.int32, device=dev())
+    cu_k = torch.tensor([0] + list(torch.tensor(klens).cumsum(0)), dtype=torch.int32, device=dev())
+    kl = torch.tensor(klens, dtype=torch.int32, device=dev())
+    out = torch.empty(sum(qlens), nh * D, device=dev(), dtype=dt)
+    ops.attn_fwd(qt.to(dev(), dt), kt.to(dev(), dt), vt.to(dev(), dt), out, cu_q, cu_k, kl, q_strides=(nh * D, D), k_strides=(nkv * D, D),
+                 v_strides=(nkv * D, D), o_strides=(nh * D, D), nseq=len(qlens), max_qlen=max(qlens), n_heads=nh, n_kv_heads=nkv, head_dim=D,
+                 causal=causal, scale=D ** -0.5)
+    out = out.float().cpu()
+    q0 = k0 = 0
+    for nq, nk in zip(qlens, klens):
+        qh = q(qt[q0:q0 + nq], dt).view(nq, nh, D).transpose(0, 1)
+        kh = q(kt[k0:k0 + nk], dt).view(nk, nkv, D).transpose(0, 1)
+        vh = q(vt[k0:k0 + nk], dt).view(nk, nkv, D).transpose(0, 1)
+        assert rel_err(out[q0:q0 + nq], ref_attention(qh, kh, vh, causal, D ** -0.5, dt)) < TOL[dt], (nq, nk)
+        q0 += nq
+        k0 += nk
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_rope_kv_append_and_decode_attention(dt):
     arch = weights.LlamaArch(hidden_size=256, num_attention_heads=6, num_key_value_heads=2, head_dim=128,
                              rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
