@@ -32,6 +32,7 @@ sys.path.insert(0, REPO)
 PKG = "llm-speech-summarization_amd"
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md)
 
 
 def mod(name):
@@ -519,6 +520,10 @@ def main():
                 "traffic": pmc.get(key), "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2)}
 
     r_gemm = roof(("gemm_stream_kernel" if streaming else "gemm_skinny_kernel") + "<bf16, SILU_MUL> (gate/up projection, decode)", "gemm")
+    # the same launch against the matrix-core roof: above ~256 rows the projection is nearer to it than to the HBM one
+    gemm_flops = 2.0 * B * 2 * larch.intermediate_size * larch.hidden_size
+    r_gemm["mfma"] = {"achieved": round(gemm_flops / (probes["gemm"][1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(gemm_flops / (probes["gemm"][1] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
     single_pass = B * larch.num_key_value_heads >= 32
     r_attn = roof(("attn_decode_full_kernel<bf16> (single-pass" if single_pass else "attn_decode_split_kernel<bf16> + merge (split") +
                   " one-token GQA attention over the KV cache, decode)", "attn")
