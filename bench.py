@@ -271,7 +271,7 @@ def whisper_leg(args, mod, larch, dev, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4, help="timed steps (batches); an even count keeps both in-flight batches busy to the end")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=512, help="utterances per step per GPU")
     ap.add_argument("--audio-sec", type=float, default=10.0)
