@@ -480,6 +480,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 // the bytes per FLOP; one block per CU (128 KiB of LDS), two waves per SIMD.  (A four-stage ring of 64-byte slabs with
 // three slabs of DMA in flight — swizzle c ^ ((row >> 2) & 2) for conflict-free reads of 64-byte rows — measured 5-8 %
 // SLOWER: the limit is the fetch rate per CU, not its latency; what helped is sharing slabs in L2, below.)
+// Also measured slower (-4..-7 %): issuing the DMA of slab k+2 in the middle of slab k behind an extra bare barrier (1.25-1.5
+// product phases of cover instead of one).  PMC on 17408x16384x3072: MFMA busy 46 %, waves 30 % parked (vmcnt/barrier), 50 %
+// issue-stalled behind the MFMA pipe, 20 % issuing; no LDS bank conflicts.
 // ----------------------------------------------------------------------------------------------
 constexpr int XBM = 256, XBN = 256;
 
