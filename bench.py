@@ -279,7 +279,7 @@ def main():
     ap.add_argument("--pipelines", type=int, default=2, help="batches in flight per GPU (host threads x HIP streams; 1 = strictly sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (≈0.45 s each)")
-    ap.add_argument("--kd-optimizer-steps", type=int, default=1, help="optimizer steps of the KD training leg (0 = skip)")
+    ap.add_argument("--kd-optimizer-steps", type=int, default=2, help="optimizer steps of the KD training leg (0 = skip)")
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")
