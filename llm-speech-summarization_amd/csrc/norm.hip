@@ -1,6 +1,7 @@
 // norm.hip — LayerNorm (+optional GELU) and Llama RMSNorm.  HBM-bound row kernels: one wave per row,
 // 16-byte loads, the whole row lives in registers between the statistics and the write (one read, one
 // write of HBM per element).  Statistics in fp32 as the reference's fp32 / autocast-to-fp32 path does.
+#include <stdlib.h>
 #include "common.h"
 
 constexpr int NORM_MAXF = 64;  // floats per lane -> rows of up to 4096 elements
@@ -70,12 +71,110 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T* __restrict__ x,
   }
 }
 
+// Short rows (cols = CH * 64 lanes * 16 bytes: 512 / 1024 bf16 — the conv stack's and the encoder's LayerNorms): one
+// row per wave leaves 1-2 KiB in flight per wave and pays two dependent 6-step wave reductions, the gain/bias loads
+// and the wave launch per row (2.5 TB/s at 512 columns).  Here a wave keeps gain / bias in registers, walks the rows
+// in groups of R with all R rows requested up front, and runs the R reductions interleaved.
+template <typename T, bool RMS, int CH, int R>
+__global__ __launch_bounds__(256) void norm_rows_multi_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ g,
+                                                              const T* __restrict__ b, int64_t rows, float eps, int gelu) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int cols = CH * 64 * VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  float gg[CH][VEC], bb[CH][VEC];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    Vec16<T>::unpack(*(const uint4*)(g + (lane + 64 * c) * VEC), gg[c]);
+    if constexpr (!RMS) Vec16<T>::unpack(*(const uint4*)(b + (lane + 64 * c) * VEC), bb[c]);
+  }
+  for (int64_t r0 = wave_id * R; r0 < rows; r0 += n_waves * R) {
+    float v[R][CH][VEC];
+    float s[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int64_t row = r0 + j < rows ? r0 + j : rows - 1;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) Vec16<T>::unpack(ld_nt16(x + row * cols + (lane + 64 * c) * VEC), v[j][c]);   // streamed once
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      s[j] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[j] += RMS ? v[j][c][e] * v[j][c][e] : v[j][c][e];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < R; ++j) s[j] += __shfl_xor(s[j], o, 64);
+    float mean[R], rstd[R];
+    if constexpr (RMS) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) { mean[j] = 0.f; rstd[j] = rsqrtf(s[j] / (float)cols + eps); }
+    } else {
+      float s2[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        mean[j] = s[j] / (float)cols;
+        s2[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { const float d = v[j][c][e] - mean[j]; s2[j] += d * d; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < R; ++j) s2[j] += __shfl_xor(s2[j], o, 64);
+#pragma unroll
+      for (int j = 0; j < R; ++j) rstd[j] = rsqrtf(s2[j] / (float)cols + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      if (r0 + j >= rows) break;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if constexpr (RMS) {
+            const float t = to_f32(from_f32<T>(v[j][c][e] * rstd[j]));
+            o[e] = gg[c][e] * t;
+          } else {
+            const float t = (v[j][c][e] - mean[j]) * rstd[j] * gg[c][e] + bb[c][e];
+            o[e] = gelu ? gelu_act<T>(t) : t;
+          }
+        }
+        const uint4 pk = Vec16<T>::pack(o);
+        __builtin_nontemporal_store(u32x4_t{pk.x, pk.y, pk.z, pk.w}, (u32x4_t*)(y + (r0 + j) * cols + (lane + 64 * c) * VEC));
+      }
+    }
+  }
+}
+
+template <typename T, bool RMS, int CH, int R>
+static int launch_norm_multi(const void* x, void* y, const void* g, const void* b, int64_t rows, float eps, int gelu, hipStream_t st) {
+  const int64_t groups = ceil_div64(rows, R);
+  const unsigned grid = (unsigned)(ceil_div64(groups, 4) < 8192 ? ceil_div64(groups, 4) : 8192);   // <= 32 blocks per CU, rows strided over waves
+  hipLaunchKernelGGL((norm_rows_multi_kernel<T, RMS, CH, R>), dim3(grid), dim3(256), 0, st, (const T*)x, (T*)y, (const T*)g, (const T*)b, rows,
+                     eps, gelu);
+  SL_CHECK_LAUNCH("norm_rows_multi");
+  return 0;
+}
+
 template <typename T, bool RMS>
 static int launch_norm(const void* x, void* y, const void* g, const void* b, int64_t rows, int cols, float eps, int gelu,
                        hipStream_t st) {
   constexpr int VEC = Vec16<T>::VEC;
   SL_CHECK_ARG(cols % VEC == 0 && cols <= 64 * NORM_MAXF, "norm: cols=%d must be a multiple of %d and <= %d", cols, VEC, 64 * NORM_MAXF);
   if (rows == 0) return 0;
+  static const int single = getenv("SL_NORM_SINGLE_ROW") ? atoi(getenv("SL_NORM_SINGLE_ROW")) : 0;   // A/B switch
+  if (!single && rows >= 4096) {
+    if (cols == 64 * VEC) return launch_norm_multi<T, RMS, 1, 8>(x, y, g, b, rows, eps, gelu, st);
+    if (cols == 128 * VEC) return launch_norm_multi<T, RMS, 2, 4>(x, y, g, b, rows, eps, gelu, st);
+  }
   hipLaunchKernelGGL((norm_rows_kernel<T, RMS>), dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, (const T*)x, (T*)y,
                      (const T*)g, (const T*)b, rows, cols, eps, gelu);
   SL_CHECK_LAUNCH("norm_rows");
