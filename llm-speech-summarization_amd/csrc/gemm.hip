@@ -483,6 +483,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 // Also measured slower (-4..-7 %): issuing the DMA of slab k+2 in the middle of slab k behind an extra bare barrier (1.25-1.5
 // product phases of cover instead of one).  PMC on 17408x16384x3072: MFMA busy 46 %, waves 30 % parked (vmcnt/barrier), 50 %
 // issue-stalled behind the MFMA pipe, 20 % issuing; no LDS bank conflicts.
+// A persistent form (one block per CU walking its tiles, the next tile's first slab requested before the current tile's
+// epilogue, which then turns 32-row groups through the other staging buffer) measured within +-2 % of this kernel at
+// K = 1024..8192: the vmcnt(0) that admits the prefetched slab also drains the epilogue's stores (one counter on gfx9).
 // ----------------------------------------------------------------------------------------------
 constexpr int XBM = 256, XBN = 256;
 
