@@ -508,7 +508,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
   // that XCD's L2 (walking M only shares W: 33 slab streams per 32 blocks from beyond L2 instead of 12)
   int bm, bn;
   {
-    constexpr int GM = 8;
+    const int GM = p.gm;
     const int per = GM * p.tiles_n, grp = bid / per, first = grp * GM;
     const int gsz = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
     const int in = bid - grp * per;
@@ -951,6 +951,8 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0;
   static const int direct_epi = getenv("SL_DIRECT_EPILOGUE") ? atoi(getenv("SL_DIRECT_EPILOGUE")) : 0;
   p.direct_epi = direct_epi;
+  static const int gm_env = getenv("SL_GEMM_GM") ? atoi(getenv("SL_GEMM_GM")) : 8;
+  p.gm = gm_env;
   if (ex) {
     p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;
     p.grp = ex->groups; p.w_mod = ex->w_mod > 0 ? ex->w_mod : 1;
