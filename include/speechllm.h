@@ -225,6 +225,12 @@ int sl_greedy_select(const float* logits, int32_t B, int32_t V, const int32_t* e
 int sl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, sl_stream stream);
 /* y = a*x + b*y (gradient accumulation at residual joins). */
 int sl_axpby(const void* x, void* y, float a, float b, int64_t n, int32_t dtype, sl_stream stream);
+
+/* Training-mode dropout (hf:models/hubert/modeling_hubert.py feature-projection / hidden / activation dropouts of the
+ * encoder the reference puts in train() mode, ref:trainer.py:258):  y = (residual ? residual : 0) + keep(i) * x / (1 - p).
+ * keep(i) is a counter-based hash of (element index, seed) — no mask tensor; the backward pass calls the same entry
+ * point on the gradient with the same seed.  n must be a multiple of 16 bytes' worth of elements; in place allowed. */
+int sl_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, int32_t dtype, sl_stream stream);
 /* SwiGLU on the 16-row interleaved gate/up activation gu (M, 2F): out (M, F) = silu(g)*u; backward
  * writes d gu in the same interleaved layout (hf:models/llama/modeling_llama.py:175). */
 int sl_silu_mul(const void* gu, void* out, int64_t M, int32_t F, int32_t dtype, sl_stream stream);

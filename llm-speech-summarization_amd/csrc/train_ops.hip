@@ -42,6 +42,36 @@ __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, T* 
   }
 }
 
+// Dropout with a counter-based mask: element i of a site is kept iff u24(mix(i, seed)) >= p * 2^24, where mix is two rounds
+// of the 32-bit "lowbias" integer hash over (low word ^ hash(high word ^ seed_lo)) ^ seed_hi.  No mask tensor is stored:
+// the backward pass applies the same function to the gradient (same seed), and the test oracle rebuilds the mask in numpy.
+// y = (res ? res : 0) + keep * x / (1 - p)  (the residual form is HuBERT's  h = residual + dropout(sublayer(h))).
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(int64_t i, uint64_t seed, uint32_t thr24) {
+  const uint32_t h = lowbias32((uint32_t)i ^ lowbias32((uint32_t)((uint64_t)i >> 32) ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  return (h >> 8) >= thr24;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t n, float scale,
+                                                      uint32_t thr24, uint64_t seed) {
+  constexpr int VEC = Vec16<T>::VEC;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * 256 * VEC) {
+    float xv[VEC], rv[VEC];
+    Vec16<T>::unpack(*(const uint4*)(x + i), xv);
+    if (res) Vec16<T>::unpack(*(const uint4*)(res + i), rv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = dropout_keep(i + e, seed, thr24) ? xv[e] * scale : 0.f;
+      xv[e] = res ? rv[e] + d : d;
+    }
+    *(uint4*)(y + i) = Vec16<T>::pack(xv);
+  }
+}
+
 // gu: (M, 2F) with blocks [16 gate | 16 up];  out/dy: (M, F)
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ gu, const T* __restrict__ dy, T* __restrict__ out, int64_t M, int F_) {
@@ -527,6 +557,21 @@ extern "C" int sl_axpby(const void* x, void* y, float a, float b, int64_t n, int
   if (n == 0) return 0;
   SL_DISPATCH_DTYPE(dtype, T, { hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, a, b, n); });
   SL_CHECK_LAUNCH("axpby");
+  return 0;
+}
+
+extern "C" int sl_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint64_t seed, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, "sl_dropout: bad arguments (p=%f)", (double)p);
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(n % vec == 0, "sl_dropout: n must be a multiple of %d", vec);
+  if (n == 0) return 0;
+  const uint32_t thr24 = (uint32_t)((double)p * 16777216.0);
+  const float scale = 1.0f / (1.0f - p);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)residual, (T*)y, n, scale,
+                       thr24, (uint64_t)seed);
+  });
+  SL_CHECK_LAUNCH("dropout");
   return 0;
 }
 

@@ -292,6 +292,35 @@ def axpby(x, y, a=1.0, b=1.0):
     return y
 
 
+def dropout(x: torch.Tensor, p: float, seed: int, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = (residual or 0) + keep * x / (1 - p) with the counter-based mask of sl_dropout (same seed -> same mask: the
+    backward pass calls this on the gradient).  `out` may alias x."""
+    L.require_gpu(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().sl_dropout(L.ptr(x), L.ptr(residual), L.ptr(out), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, L.dtype_code(x.dtype),
+                               L.stream_ptr()), "sl_dropout")
+    return out
+
+
+def dropout_keep_mask(n: int, p: float, seed: int) -> "torch.Tensor":
+    """Host restatement of sl_dropout's mask (bool, n elements) — used by the tests' oracle to apply identical masks."""
+    import numpy as np
+    m32 = np.uint64(0xFFFFFFFF)
+
+    def lowbias32(v):
+        v = v & m32
+        v ^= v >> np.uint64(16); v = (v * np.uint64(0x7feb352d)) & m32
+        v ^= v >> np.uint64(15); v = (v * np.uint64(0x846ca68b)) & m32
+        v ^= v >> np.uint64(16)
+        return v
+
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    i = np.arange(n, dtype=np.uint64)
+    h = lowbias32((i & m32) ^ lowbias32((i >> np.uint64(32)) ^ np.uint64(seed & 0xFFFFFFFF)) ^ np.uint64(seed >> 32))
+    thr = np.uint64(int(float(np.float32(p)) * 16777216.0))
+    return torch.from_numpy((h >> np.uint64(8)) >= thr)
+
+
 def silu_mul(gu):
     M, F2 = gu.shape
     out = torch.empty((M, F2 // 2), device=gu.device, dtype=gu.dtype)

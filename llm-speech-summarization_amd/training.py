@@ -11,14 +11,20 @@ this module is the tape: it decides what to keep from the forward and in which o
 kernels.  torch supplies buffers, the optimizer (AdamW on fp32 master weights, ref:trainer.py:98-105) and the
 collective (RCCL all-reduce of the fp32 gradient buckets, overlapped with the remaining backward).
 
-Stochastic training-mode ops of the reference (dropout 0.1, LayerDrop 0.1, SpecAugment) are NOT applied:
-KD-step parity is defined with them off and they are left for a later round.
+Training-mode regularisers (the reference trains with `audio_encoder.train()`, ref:trainer.py:258, so HF's HuBERT applies
+feature-projection / hidden / activation dropout, LayerDrop and SpecAugment time masking): `TrainRegularizers` switches
+them on (`KDTrainer(..., regularizers=...)`).  Masks come from a counter-based hash (sl_dropout), so forward and backward
+agree without stored masks and the test oracle can rebuild them; SpecAugment spans follow HF's `_compute_mask_indices`
+on numpy's global RNG.  Deterministic KD-step parity (golden fixtures) is defined with them off.  Attention-probability
+dropout is the one stochastic op not applied yet (the forward attention never materialises the probabilities).
 """
 from __future__ import annotations
 
 import math
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -26,6 +32,81 @@ from . import ops
 from .audio_encoder import AudioEncoder
 from .audio_llama import AudioLlamaForCausalLM
 from .weights import HubertDeviceWeights, fold_pos_conv_weight
+
+
+# ------------------------------------------------------------------------------------------------
+# training-mode regularisers of the HF HuBERT encoder (hf:models/hubert/modeling_hubert.py: feature projection dropout,
+# _mask_hidden_states, encoder dropout + LayerDrop, layer dropouts)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class TrainRegularizers:
+    """hubert-large-ls960-ft config values (SURVEY.md §8 model constants)."""
+    feat_proj_dropout: float = 0.1
+    hidden_dropout: float = 0.1
+    activation_dropout: float = 0.1
+    layerdrop: float = 0.1
+    apply_spec_augment: bool = True
+    mask_time_prob: float = 0.05
+    mask_time_length: int = 10
+    mask_time_min_masks: int = 2
+    seed: int = 1234                      # base of the dropout / LayerDrop counters (ref:config/llama3_hubert.yaml:1 seed_everything)
+
+    @staticmethod
+    def from_hf_config(d: dict, seed: int = 1234) -> "TrainRegularizers":
+        return TrainRegularizers(d.get("feat_proj_dropout", 0.0), d.get("hidden_dropout", 0.1), d.get("activation_dropout", 0.1),
+                                 d.get("layerdrop", 0.1), d.get("apply_spec_augment", True), d.get("mask_time_prob", 0.05),
+                                 d.get("mask_time_length", 10), d.get("mask_time_min_masks", 2), seed)
+
+
+def compute_mask_indices(shape: Tuple[int, int], mask_prob: float, mask_length: int, min_masks: int = 0) -> np.ndarray:
+    """SpecAugment span mask, restating transformers 4.47 `_compute_mask_indices` (hf:models/hubert/modeling_hubert.py,
+    no attention mask) call for call on numpy's GLOBAL RNG, so a seeded run picks the spans the reference would."""
+    batch_size, sequence_length = shape
+    if mask_length < 1:
+        raise ValueError("`mask_length` has to be bigger than 0.")
+    if mask_length > sequence_length:
+        raise ValueError(f"`mask_length` has to be smaller than `sequence_length`, but got `mask_length`: {mask_length}"
+                         f" and `sequence_length`: {sequence_length}`")
+    epsilon = np.random.rand(1).item()
+
+    def num_spans(input_length):
+        n = int(mask_prob * input_length / mask_length + epsilon)
+        n = max(n, min_masks)
+        if n * mask_length > sequence_length:
+            n = sequence_length // mask_length
+        if input_length - (mask_length - 1) < n:
+            n = max(input_length - (mask_length - 1), 0)
+        return n
+
+    mask = np.zeros((batch_size, sequence_length), dtype=bool)
+    max_spans = num_spans(sequence_length)
+    if max_spans == 0:
+        return mask
+    idxs = []
+    for _ in range(batch_size):
+        n = num_spans(sequence_length)
+        idx = np.random.choice(np.arange(sequence_length - (mask_length - 1)), n, replace=False)
+        dummy = sequence_length - 1 if len(idx) == 0 else idx[0]
+        idxs.append(np.concatenate([idx, np.ones(max_spans - n, dtype=np.int32) * dummy]))
+    idxs = np.array(idxs)
+    idxs = np.broadcast_to(idxs[:, :, None], (batch_size, max_spans, mask_length)).reshape(batch_size, max_spans * mask_length)
+    offsets = np.broadcast_to(np.arange(mask_length)[None, None, :], (batch_size, max_spans, mask_length)).reshape(batch_size, max_spans * mask_length)
+    idxs = idxs + offsets
+    if idxs.max() > sequence_length - 1:
+        idxs[idxs > sequence_length - 1] = sequence_length - 1
+    np.put_along_axis(mask, idxs, 1, -1)
+    return mask
+
+
+_SITES = {"fp": 1, "pos": 2, "attn_out": 3, "act": 4, "ffn_out": 5, "layerdrop": 6}
+
+
+def _site_seed(base: int, site: str, layer: int = 0) -> int:
+    """64-bit seed of one dropout site of one micro-batch (splitmix-style mixing of (base, site, layer))."""
+    z = (base * 0x9E3779B97F4A7C15 + _SITES[site] * 0xBF58476D1CE4E5B9 + (layer + 1) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    z ^= z >> 30; z = (z * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z ^= z >> 27; z = (z * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
 
 
 def _vec(dt) -> int:
@@ -262,9 +343,12 @@ class EncoderTape:
         for li, lt in enumerate(self.W.layer_t):
             for k, v in lt.items():
                 g[f"l{li}.{k}"] = torch.zeros(v.shape, device=v.device, dtype=torch.float32)
+        g["masked_spec_embed"] = torch.zeros(self.enc.arch.hidden_size, device=self.enc.device, dtype=torch.float32)
         return g
 
-    def forward(self, waves: Sequence[torch.Tensor]):
+    def forward(self, waves: Sequence[torch.Tensor], reg: Optional[TrainRegularizers] = None, step: int = 0,
+                masked_spec_embed: Optional[torch.Tensor] = None):
+        """`reg` switches the training-mode regularisers on; `step` (micro-batch counter) salts their seeds."""
         W, a, enc = self.W, self.enc.arch, self.enc
         t, dt, dev = W.t, enc.dtype, enc.device
         B = len(waves)
@@ -297,6 +381,21 @@ class EncoderTape:
         NT, H = toff[B], a.hidden_size
         fp_ln = ops.layernorm(x, t["fp_ln_g"], t["fp_ln_b"], a.layer_norm_eps)
         x0 = ops.gemm(fp_ln, t["fp_w"], bias=t["fp_b"])
+        base = None if reg is None else (int(reg.seed) * 1000003 + int(step)) & 0xFFFFFFFFFFFFFFFF
+        spec_rows = None
+        if reg is not None:
+            if reg.feat_proj_dropout > 0:
+                ops.dropout(x0, reg.feat_proj_dropout, _site_seed(base, "fp"), out=x0)
+            if reg.apply_spec_augment and reg.mask_time_prob > 0:          # hf `_mask_hidden_states`: one (1, T) draw per utterance
+                rows = []
+                for u in range(B):
+                    m = compute_mask_indices((1, T[u]), reg.mask_time_prob, reg.mask_time_length, reg.mask_time_min_masks)[0]
+                    rows.append(torch.from_numpy(np.nonzero(m)[0]) + toff[u])
+                spec_rows = torch.cat(rows).to(dev)
+                if spec_rows.numel():
+                    if masked_spec_embed is None:
+                        raise L.SpeechLLMError("SpecAugment needs the encoder's masked_spec_embed")
+                    x0.index_copy_(0, spec_rows, masked_spec_embed.to(device=dev, dtype=dt).reshape(1, -1).expand(spec_rows.numel(), -1).contiguous())
         G, k = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
         Hg = H // G
         xg_off = _offsets([(T[u] + k) * H for u in range(B)])
@@ -309,21 +408,36 @@ class EncoderTape:
         x1 = torch.empty_like(x0)
         ops.gemm_ex(xg, t["pos_w"], M=max(T), N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=x1, ldc=H, bias=t["pos_b"], residual=x0, ldr=H, act=L.ACT_GELU,
                     aux_out=pre_pos, batch=B * G, strideW=Hg * k * Hg, strideBias=Hg, groups=pos_grp, w_mod=G, dtype=dt)
-        tape.update(fp_ln=fp_ln, xg=xg, xg_off=xg_off, pre_pos=pre_pos, T=T, toff=toff)
+        if reg is not None and reg.hidden_dropout > 0:                     # encoder: hidden_states = dropout(hidden_states + pos_conv_embed(...))
+            ops.dropout(x1, reg.hidden_dropout, _site_seed(base, "pos"), out=x1)
+        tape.update(fp_ln=fp_ln, xg=xg, xg_off=xg_off, pre_pos=pre_pos, T=T, toff=toff, reg=reg, base=base, spec_rows=spec_rows)
         layers = []
         x = x1
         nh = a.num_attention_heads
         for li in range(a.num_hidden_layers):
             lt = W.layer_t[li]
+            if reg is not None and reg.layerdrop > 0:                      # hf: skip the layer when a uniform draw < layerdrop
+                u01 = (_site_seed(base, "layerdrop", li) >> 11) * (1.0 / 9007199254740992.0)
+                if u01 < reg.layerdrop:
+                    layers.append(None)
+                    continue
             ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], a.layer_norm_eps)
             qkv = ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"])
             att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125)
-            x_mid = ops.gemm(att, lt["wo"], bias=lt["bo"], residual=x)
+            if reg is not None and reg.hidden_dropout > 0:                 # h = residual + dropout(attention(layer_norm(h)))
+                x_mid = ops.dropout(ops.gemm(att, lt["wo"], bias=lt["bo"]), reg.hidden_dropout, _site_seed(base, "attn_out", li), residual=x)
+            else:
+                x_mid = ops.gemm(att, lt["wo"], bias=lt["bo"], residual=x)
             ln2 = ops.layernorm(x_mid, lt["ln2_g"], lt["ln2_b"], a.layer_norm_eps)
             pre1 = torch.empty((NT, a.intermediate_size), device=dev, dtype=dt)
             mid = torch.empty_like(pre1)
             ops.gemm_ex(ln2, lt["w1"], M=NT, N=a.intermediate_size, K=H, lda=H, ldw=H, out=mid, bias=lt["b1"], act=L.ACT_GELU, aux_out=pre1, dtype=dt)
-            x_out = ops.gemm(mid, lt["w2"], bias=lt["b2"], residual=x_mid)
+            if reg is not None and reg.activation_dropout > 0:             # intermediate_dropout(act(dense(h)))
+                ops.dropout(mid, reg.activation_dropout, _site_seed(base, "act", li), out=mid)
+            if reg is not None and reg.hidden_dropout > 0:                 # h = h + output_dropout(output_dense(...))
+                x_out = ops.dropout(ops.gemm(mid, lt["w2"], bias=lt["b2"]), reg.hidden_dropout, _site_seed(base, "ffn_out", li), residual=x_mid)
+            else:
+                x_out = ops.gemm(mid, lt["w2"], bias=lt["b2"], residual=x_mid)
             layers.append(dict(x=x, ln1=ln1, qkv=qkv, att=att, x_mid=x_mid, ln2=ln2, pre1=pre1, mid=mid))
             x = x_out
         lnf = ops.layernorm(x, t["final_ln_g"], t["final_ln_b"], a.layer_norm_eps)
@@ -354,18 +468,28 @@ class EncoderTape:
             d_lnf[toff[u]:toff[u + 1]] = ops.avgpool_bwd(d_pooled[poff[u]:poff[u + 1]], T[u], enc.pool_kernel, enc.pool_stride)
         dx = ops.layernorm_bwd(tape["x_last"], t["final_ln_g"], t["final_ln_b"], d_lnf, a.layer_norm_eps, g["final_ln_g"], g["final_ln_b"])
         done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
+        reg, base = tape.get("reg"), tape.get("base")
+        p_h = reg.hidden_dropout if reg is not None else 0.0
+        p_act = reg.activation_dropout if reg is not None else 0.0
         for li in reversed(range(a.num_hidden_layers)):
             lt, c = W.layer_t[li], tape["layers"][li]
             p = f"l{li}."
-            ops.wgrad_acc(dx, c["mid"], g[p + "w2"]); ops.colsum_acc(dx, g[p + "b2"])
-            d_mid = ops.dgrad(dx, lt["w2"], wt=lt["w2"].t().contiguous())   # weights move every optimizer step: transposed on the fly
+            if c is None:                                                    # LayerDrop: identity in both directions
+                done([p + n for n in lt])
+                continue
+            d_o2 = ops.dropout(dx, p_h, _site_seed(base, "ffn_out", li)) if p_h > 0 else dx
+            ops.wgrad_acc(d_o2, c["mid"], g[p + "w2"]); ops.colsum_acc(d_o2, g[p + "b2"])
+            d_mid = ops.dgrad(d_o2, lt["w2"], wt=lt["w2"].t().contiguous())   # weights move every optimizer step: transposed on the fly
+            if p_act > 0:
+                ops.dropout(d_mid, p_act, _site_seed(base, "act", li), out=d_mid)
             d_pre1 = ops.gelu_bwd(d_mid, c["pre1"])
             ops.wgrad_acc(d_pre1, c["ln2"], g[p + "w1"]); ops.colsum_acc(d_pre1, g[p + "b1"])
             d_ln2 = ops.dgrad(d_pre1, lt["w1"], wt=lt["w1"].t().contiguous())
             dx_mid = ops.layernorm_bwd(c["x_mid"], lt["ln2_g"], lt["ln2_b"], d_ln2, a.layer_norm_eps, g[p + "ln2_g"], g[p + "ln2_b"])
             ops.axpby(dx, dx_mid)
-            ops.wgrad_acc(dx_mid, c["att"], g[p + "wo"]); ops.colsum_acc(dx_mid, g[p + "bo"])
-            d_att = ops.dgrad(dx_mid, lt["wo"], wt=lt["wo"].t().contiguous())
+            d_o1 = ops.dropout(dx_mid, p_h, _site_seed(base, "attn_out", li)) if p_h > 0 else dx_mid
+            ops.wgrad_acc(d_o1, c["att"], g[p + "wo"]); ops.colsum_acc(d_o1, g[p + "bo"])
+            d_att = ops.dgrad(d_o1, lt["wo"], wt=lt["wo"].t().contiguous())
             d_qkv = torch.empty_like(c["qkv"])
             attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125)
             ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
@@ -377,6 +501,8 @@ class EncoderTape:
         # positional conv: x1 = x0 + gelu(conv(x0) + b)
         G, k = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
         Hg = H // G
+        if p_h > 0:
+            dx = ops.dropout(dx, p_h, _site_seed(base, "pos"))
         d_pre = ops.gelu_bwd(dx, tape["pre_pos"])
         ops.colsum_acc(d_pre, g["pos_b"])
         xg, xg_off = tape["xg"], tape["xg_off"]
@@ -392,12 +518,19 @@ class EncoderTape:
             dpg = ops.posconv_stage(d_pre[r0:r0 + Tu], G, k)
             ops.gemm_ex(dpg, wd, M=Tu, N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=dx0, ldc=H, residual=dx, ldr=H, batch=G, strideA=(Tu + k) * Hg,
                         strideW=Hg * k * Hg, strideC=Hg, strideR=Hg, a_off=Hg, c_off=r0 * H, r_off=r0 * H, dtype=dt)
+        # SpecAugment rows took the learned mask embedding; feature-projection dropout
+        spec_rows = tape.get("spec_rows")
+        if spec_rows is not None and spec_rows.numel():
+            g["masked_spec_embed"] += dx0.index_select(0, spec_rows).float().sum(0)
+            dx0.index_fill_(0, spec_rows, 0.0)
+        if reg is not None and reg.feat_proj_dropout > 0:
+            ops.dropout(dx0, reg.feat_proj_dropout, _site_seed(base, "fp"), out=dx0)
         # feature projection
         ops.wgrad_acc(dx0, tape["fp_ln"], g["fp_w"]); ops.colsum_acc(dx0, g["fp_b"])
         d_fpln = ops.dgrad(dx0, t["fp_w"])
         acts, pres, offs, Ls = tape["acts"], tape["pres"], tape["offs"], tape["Ls"]
         d_act = ops.layernorm_bwd(acts[-1], t["fp_ln_g"], t["fp_ln_b"], d_fpln, a.layer_norm_eps, g["fp_ln_g"], g["fp_ln_b"])
-        done(["pos_w", "pos_b", "fp_w", "fp_b", "fp_ln_g", "fp_ln_b"])
+        done(["pos_w", "pos_b", "fp_w", "fp_b", "fp_ln_g", "fp_ln_b", "masked_spec_embed"])
         # conv stack
         for i in reversed(range(1, len(a.conv_dim))):
             Cin, Cout, kk, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
@@ -466,6 +599,7 @@ def kernel_grads_to_state_dict(enc: AudioEncoder, g: Dict[str, torch.Tensor], ma
         out[p + "feed_forward.output_dense.weight"], out[p + "feed_forward.output_dense.bias"] = g[q + "w2"], g[q + "b2"]
     out["encoder.encoder.layer_norm.weight"], out["encoder.encoder.layer_norm.bias"] = g["final_ln_g"], g["final_ln_b"]
     out["embed_projection.weight"], out["embed_projection.bias"] = g["proj_w"], g["proj_b"]
+    out["encoder.masked_spec_embed"] = g["masked_spec_embed"]
     return out
 
 
@@ -478,7 +612,7 @@ class KDTrainer:
     summed with an all-reduce of the fp32 buckets on a side stream while the rest of the backward still runs."""
 
     def __init__(self, config, encoder: AudioEncoder, llm: AudioLlamaForCausalLM, prefix_ids: torch.Tensor, suffix_ids: torch.Tensor,
-                 total_optimizer_steps: int = 1000, process_group=None):
+                 total_optimizer_steps: int = 1000, process_group=None, regularizers: Optional[TrainRegularizers] = None):
         tr = config.train
         self.enc, self.llm = encoder, llm
         self.ntp_w, self.ld_w, self.fd_w = tr.ntp_loss_weight, tr.ld_loss_weight, tr.fd_loss_weight
@@ -497,13 +631,18 @@ class KDTrainer:
         self.enc_tape, self.llm_tape = EncoderTape(encoder), LlamaTape(llm)
         # fp32 master weights (the reference keeps fp32 params under fp16 autocast, ref:trainer.py:252,270)
         self.master = {k: v.detach().to(dev, torch.float32).clone() for k, v in encoder.state_dict().items()}
-        self.trainable = [k for k in self.master if k != "encoder.masked_spec_embed"]
+        self.reg = regularizers
+        # masked_spec_embed only receives a gradient under SpecAugment (the reference's train() mode); with the regularisers
+        # off it stays out of the optimizer, as its gradient is identically zero
+        spec = regularizers is not None and regularizers.apply_spec_augment and regularizers.mask_time_prob > 0
+        self.trainable = [k for k in self.master if spec or k != "encoder.masked_spec_embed"]
         self.params = [torch.nn.Parameter(self.master[k], requires_grad=True) for k in self.trainable]
         opt = tr.optimizer
         self.optimizer = torch.optim.AdamW(self.params, lr=float(opt.lr), betas=(float(opt.beta1), float(opt.beta2)))
         self.scheduler = torch.optim.lr_scheduler.PolynomialLR(self.optimizer, total_iters=total_optimizer_steps, power=1.0)
         self.grads = self.enc_tape.new_grads()
         self.micro = 0
+        self.micro_batches = 0
         from .dist import BucketedAllReduce
         self.reducer = BucketedAllReduce(self.grads, group=process_group) if self.world > 1 else None
 
@@ -527,7 +666,9 @@ class KDTrainer:
         last = (self.micro + B) % self.local_accum == 0
         response_ids = [r.to(dev) for r in response_ids]
         ns = [int(r.shape[0]) for r in response_ids]
-        audio, etape = self.enc_tape.forward(waves)                                   # (sum P, H) packed
+        audio, etape = self.enc_tape.forward(waves, self.reg, step=self.micro_batches,
+                                             masked_spec_embed=self.master.get("encoder.masked_spec_embed"))   # (sum P, H) packed
+        self.micro_batches += 1
         poff = etape["poff"]
         pre, suf = emb(self.prefix_ids)[0], emb(self.suffix_ids)[0, 1:]
         n_pre = pre.shape[0]

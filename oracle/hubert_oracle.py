@@ -75,8 +75,16 @@ def hubert_forward(
     wave: torch.Tensor,
     prefix: str = "encoder.",
     taps: Optional[dict] = None,
+    train: Optional[dict] = None,
 ) -> torch.Tensor:
-    """HubertModel.forward(...).last_hidden_state in eval mode, no attention mask.
+    """HubertModel.forward(...).last_hidden_state, no attention mask; eval mode unless `train` is given.
+
+    `train` (training-mode regularisers of hf:models/hubert/modeling_hubert.py with the random draws SUPPLIED by the
+    caller, so a test can replay the masks of the kernel path): {"drop": callable(site, layer, tensor) -> tensor applying
+    that site's dropout (sites "fp" feature-projection dropout, "pos" encoder dropout after the positional embedding,
+    "attn_out" / "ffn_out" hidden dropouts of a layer, "act" intermediate dropout), "skip": set of LayerDrop-skipped
+    layers, "spec_mask": (B, T) bool SpecAugment mask (rows replaced by `masked_spec_embed`)}.  Attention-probability
+    dropout is not modelled (the build does not apply it yet).
 
     wave: (B, N) float32 raw 16 kHz samples (the reference feeds un-normalised audio and no mask:
     ref:model/audio_encoder.py:57).  Returns (B, T, hidden).  `taps`, if given, is filled with the
@@ -100,6 +108,11 @@ def hubert_forward(
     x = F.layer_norm(x, (x.shape[-1],), sd[q + "layer_norm.weight"].float(),
                      sd[q + "layer_norm.bias"].float(), cfg.layer_norm_eps)
     x = F.linear(x, sd[q + "projection.weight"].float(), sd[q + "projection.bias"].float())
+    drop = (lambda site, layer, v: v) if train is None else train["drop"]
+    x = drop("fp", 0, x)                                   # HubertFeatureProjection.dropout
+    if train is not None and train.get("spec_mask") is not None:   # HubertModel._mask_hidden_states
+        m = train["spec_mask"].to(torch.bool)
+        x = torch.where(m[..., None], sd[f"{p}masked_spec_embed"].float().expand_as(x), x)
     if taps is not None:
         taps["feature_projection"] = x
 
@@ -113,6 +126,7 @@ def hubert_forward(
         pos = pos[:, :, :-1]
     pos = F.gelu(pos).transpose(1, 2)
     x = x + pos
+    x = drop("pos", 0, x)                                  # HubertEncoderStableLayerNorm: dropout(hidden + pos_conv_embed(hidden))
     if taps is not None:
         taps["pos_conv"] = x
 
@@ -120,6 +134,8 @@ def hubert_forward(
     nh, hd = cfg.num_attention_heads, cfg.head_dim
     for li in range(cfg.num_hidden_layers):
         q = f"{p}encoder.layers.{li}."
+        if train is not None and li in train.get("skip", ()):   # LayerDrop
+            continue
         res = x
         h = F.layer_norm(x, (H,), sd[q + "layer_norm.weight"].float(), sd[q + "layer_norm.bias"].float(),
                          cfg.layer_norm_eps)
@@ -131,13 +147,14 @@ def hubert_forward(
         att = F.softmax(att, dim=-1)
         o = torch.matmul(att, vs).transpose(1, 2).reshape(B, T, H)
         o = F.linear(o, sd[a + "out_proj.weight"].float(), sd[a + "out_proj.bias"].float())
-        x = res + o
+        x = res + drop("attn_out", li, o)
         h = F.layer_norm(x, (H,), sd[q + "final_layer_norm.weight"].float(),
                          sd[q + "final_layer_norm.bias"].float(), cfg.layer_norm_eps)
         f = q + "feed_forward."
         h = F.gelu(F.linear(h, sd[f + "intermediate_dense.weight"].float(), sd[f + "intermediate_dense.bias"].float()))
+        h = drop("act", li, h)
         h = F.linear(h, sd[f + "output_dense.weight"].float(), sd[f + "output_dense.bias"].float())
-        x = x + h
+        x = x + drop("ffn_out", li, h)
         if taps is not None:
             taps[f"layer{li}"] = x
     q = f"{p}encoder."
@@ -185,10 +202,11 @@ def audio_encoder_forward(
     wave: torch.Tensor,
     method: str = "pool",
     taps: Optional[dict] = None,
+    train: Optional[dict] = None,
     **ds_kwargs,
 ) -> torch.Tensor:
     """ref:model/audio_encoder.py:56-88 -> (B, P, llm_dim)."""
-    enc = hubert_forward(sd, cfg, wave, prefix="encoder.", taps=taps)
+    enc = hubert_forward(sd, cfg, wave, prefix="encoder.", taps=taps, train=train)
     pooled = downsample(enc, method, **ds_kwargs)
     if taps is not None:
         taps["pooled"] = pooled

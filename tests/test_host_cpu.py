@@ -197,3 +197,25 @@ def test_bucketed_gradient_allreduce_two_ranks_over_gloo():
     res = [q.get(timeout=120) for _ in procs]
     [p.join(timeout=60) for p in procs]
     assert all(ok for _, ok, _ in res) and all(b >= 2 for _, _, b in res)
+
+
+def test_spec_augment_spans_follow_hf_compute_mask_indices():
+    """training.compute_mask_indices restates transformers' `_compute_mask_indices` (the SpecAugment span picker HuBERT
+    runs in train() mode, ref:trainer.py:258) on numpy's global RNG: known answer for a seeded draw, and — where the
+    installed transformers still ships the function — equality with it on several shapes."""
+    import numpy as np
+    training = pkg("training")
+    np.random.seed(0)
+    m = training.compute_mask_indices((1, 499), 0.05, 10, 2)
+    assert m.shape == (1, 499) and int(m.sum()) == 30
+    assert np.nonzero(m)[1][:12].tolist() == [96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 320, 321]
+    assert not training.compute_mask_indices((1, 12), 0.0, 10, 0).any()          # no spans asked for
+    try:
+        from transformers.models.hubert.modeling_hubert import _compute_mask_indices as hf
+    except Exception:
+        return
+    for seed, shape, prob, length, mn in [(1, (1, 499), 0.05, 10, 2), (2, (3, 1999), 0.05, 10, 2), (3, (2, 40), 0.5, 4, 0), (4, (1, 25), 0.05, 10, 2)]:
+        np.random.seed(seed)
+        ref = hf(shape, prob, length, min_masks=mn)
+        np.random.seed(seed)
+        assert (training.compute_mask_indices(shape, prob, length, mn) == ref).all(), (seed, shape)

@@ -224,3 +224,24 @@ def test_attention_backward_packed_ragged(dt, nh, nkv, D, causal):
         o += S
     torch.cat(outs).backward(q(d_att, dt))
     assert rel_err(d_packed.float().cpu(), x.grad) < (2e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_dropout_kernel_matches_host_mask(dt):
+    """sl_dropout: counter-based mask = its host restatement; scaling, residual form, in-place, seeds beyond 32 bits."""
+    n, p, seed = 4096 * 24, 0.1, 0xA5A5_1234_5678_9ABC
+    x = torch.randn(n, generator=torch.Generator().manual_seed(3)).to(DEV, dt)
+    res = torch.randn(n, generator=torch.Generator().manual_seed(4)).to(DEV, dt)
+    keep = ops.dropout_keep_mask(n, p, seed).to(DEV)
+    assert abs(float(keep.float().mean()) - 0.9) < 0.01
+    y = ops.dropout(x, p, seed)
+    scale = 1.0 / (1.0 - float(torch.tensor(p, dtype=torch.float32)))
+    ref = torch.where(keep, x.float() * scale, torch.zeros_like(x.float()))
+    assert torch.equal(y == 0, ~keep | (x == 0))
+    assert rel_err(y.float().cpu(), ref.cpu()) < TOL[dt]
+    y2 = ops.dropout(x, p, seed, residual=res)
+    assert rel_err(y2.float().cpu(), (res.float() + ref).cpu()) < TOL[dt]
+    z = x.clone()
+    ops.dropout(z, p, seed, out=z)
+    assert torch.equal(z, y)
+    assert not torch.equal(ops.dropout(x, p, seed + (1 << 40)) == 0, y == 0)   # the high word of the seed matters

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 ri = pkg("random_init")
 cfgm = pkg("config")
 training = pkg("training")
+ops = pkg("ops")
 utils = pkg("utils")
 
 
@@ -78,6 +79,55 @@ def test_every_encoder_parameter_gradient_matches_oracle_autograd_fp32():
         worst = max(worst, err / (float(ref.norm()) + 1e-6 * float(total)))
         assert err < bound, (k, err, float(ref.norm()))
     print("worst relative gradient error", worst)
+
+
+def test_training_mode_regularizers_match_oracle_with_replayed_masks_fp32():
+    """Dropout (feature projection / hidden / activation), LayerDrop and SpecAugment of the reference's train() mode
+    (ref:trainer.py:258): the oracle replays the kernel path's masks (counter-based hash, host restatement) and its
+    SpecAugment rows; losses and every parameter gradient — masked_spec_embed included — must agree."""
+    import numpy as np
+    g = golden("pipeline_tiny")
+    reg = training.TrainRegularizers(feat_proj_dropout=0.1, hidden_dropout=0.1, activation_dropout=0.1, layerdrop=0.34, apply_spec_augment=True,
+                                     mask_time_prob=0.3, mask_time_length=3, mask_time_min_masks=2, seed=77)
+    enc, enc_sd = make_encoder(TINY_HUBERT, TINY_LLAMA.hidden_size, int(g["enc_seed"]), torch.float32)
+    enc_sd = dict(enc_sd)
+    llm, llm_sd = make_llama(TINY_LLAMA, int(g["llm_seed"]), torch.float32)
+    tr = training.KDTrainer(kd_config(taps=(0, 1, 3)), enc, llm, t(g["prefix_ids"]), t(g["suffix_ids"]), regularizers=reg)
+    assert "encoder.masked_spec_embed" in tr.trainable
+    wave = ri.synthetic_waveform(int(g["n_samples"]), seed=int(g["wave_seed"]))
+    T, H = TINY_HUBERT.num_frames(wave.numel()), TINY_HUBERT.hidden_size
+    np.random.seed(11)
+    state = np.random.get_state()
+    spec = training.compute_mask_indices((1, T), reg.mask_time_prob, reg.mask_time_length, reg.mask_time_min_masks)
+    np.random.set_state(state)                         # the tape draws the same spans from the global RNG
+    losses = tr.micro_step(wave, t(g["text_ids"]), t(g["response_ids"]))
+    grads = training.kernel_grads_to_state_dict(tr.enc, tr.grads, tr.master)
+    base = (reg.seed * 1000003 + 0) & 0xFFFFFFFFFFFFFFFF
+    probs = {"fp": reg.feat_proj_dropout, "pos": reg.hidden_dropout, "attn_out": reg.hidden_dropout, "ffn_out": reg.hidden_dropout,
+             "act": reg.activation_dropout}
+
+    def drop(site, layer, v):
+        keep = ops.dropout_keep_mask(v.numel(), probs[site], training._site_seed(base, site, layer)).view(v.shape)
+        return torch.where(keep, v / (1.0 - float(np.float32(probs[site]))), torch.zeros_like(v))
+
+    skip = {li for li in range(TINY_HUBERT.num_hidden_layers)
+            if (training._site_seed(base, "layerdrop", li) >> 11) * (1.0 / 9007199254740992.0) < reg.layerdrop}
+    assert 0 < len(skip) < TINY_HUBERT.num_hidden_layers, "pick a seed that drops some but not all layers of the tiny model"
+    assert spec.any()
+    sd = {k: v.clone().requires_grad_(True) for k, v in enc_sd.items()}
+    audio = ho.audio_encoder_forward(sd, TINY_HUBERT, wave[None], train=dict(drop=drop, skip=skip, spec_mask=torch.from_numpy(spec)))
+    ref = ko.kd_losses(llm_sd, TINY_LLAMA, audio, t(g["text_ids"]), t(g["response_ids"]), t(g["prefix_ids"]), t(g["suffix_ids"]), connector_layers=(0, 1, 3))
+    for k, r in (("ntp_loss", "ntp"), ("ld_loss", "ld"), ("fd_loss", "fd"), ("total", "total")):
+        assert abs(losses[k] - float(ref[r])) < 1e-4 * max(1.0, abs(float(ref[r]))), k
+    (ref["total"] / 16).backward()
+    total = torch.stack([sd[k].grad.norm() for k in tr.trainable if sd[k].grad is not None]).norm()
+    for k in tr.trainable:
+        rg = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        err = float((grads[k].cpu().reshape(rg.shape).double() - rg.double()).norm())
+        assert err < 2e-3 * float(rg.norm()) + 1e-6 * float(total), (k, err, float(rg.norm()))
+    skipped = next(iter(skip))
+    assert float(grads[f"encoder.encoder.layers.{skipped}.attention.out_proj.weight"].abs().max()) == 0.0
+    assert float(grads["encoder.masked_spec_embed"].norm()) > 0.0
 
 
 def test_optimizer_step_updates_master_and_kernel_weights():
