@@ -105,7 +105,9 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
 def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist):
     """ref:trainer.py:270-384 on synthetic data: 10 s audio, 40 text ids, 64 response ids."""
     training, ri = mod("training"), mod("random_init")
-    tr = training.KDTrainer(conf, enc, llm, prefix, suffix, total_optimizer_steps=1000)
+    # the reference trains with the encoder in train() mode (ref:trainer.py:258): dropouts, LayerDrop and SpecAugment on
+    reg = None if args.kd_eval_mode else training.TrainRegularizers()
+    tr = training.KDTrainer(conf, enc, llm, prefix, suffix, total_optimizer_steps=1000, regularizers=reg)
     g = torch.Generator().manual_seed(99 + rank)
     text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g)
     resp_ids = torch.randint(1, larch.vocab_size, (64,), generator=g)
@@ -142,7 +144,8 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
             "optimizer_steps": args.kd_optimizer_steps, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
             "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
             "losses": {k: round(v, 4) for k, v in losses.items()}, "dtype": "bf16 compute, fp32 master/grads",
-            "note": "one packed micro-batch per accumulation window per rank; dropout/layerdrop/spec-augment off; python-driven op tape"}
+            "encoder_mode": "eval (regularisers off)" if reg is None else "train(): dropout 0.1 (feature projection, hidden, activation, attention probabilities), LayerDrop 0.1, SpecAugment 0.05 x 10",
+            "note": "one packed micro-batch per accumulation window per rank; python-driven op tape"}
 
 
 DEVCLEAN_MIX_SEC = (2, 4, 6, 8, 10, 12, 15, 20, 25, 32)  # dev-clean is ~1.3-33 s, mean ~7 s; cycled
@@ -280,6 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (≈0.45 s each)")
     ap.add_argument("--kd-optimizer-steps", type=int, default=2, help="optimizer steps of the KD training leg (0 = skip)")
+    ap.add_argument("--kd-eval-mode", action="store_true", help="KD leg with the encoder's training-mode regularisers off")
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")

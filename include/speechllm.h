@@ -179,8 +179,21 @@ typedef struct {
   const int32_t* klen;   /* (nseq)   device: number of keys of each sequence */
   int32_t nseq, max_qlen, n_heads, n_kv_heads, head_dim, causal, dtype, reserved;
   float scale;
+  /* training mode (hf HubertAttention: dropout on the attention probabilities): probability (0 = off) and the seed of
+   * the counter-based mask of sl_dropout; the element index of probability (query row t of the packed batch, head h,
+   * key j of its sequence) is ((t * n_heads + h) << 16) | j, so sequences are limited to 65 536 keys in this mode.
+   * The softmax normaliser is the undropped sum. */
+  float dropout_p;
+  uint64_t dropout_seed;
 } sl_attn_args;
 int sl_attn_fwd(const sl_attn_args* a, sl_stream stream);
+
+/* Backward-side companion of sl_attn_args.dropout_p for the explicit-probability backward: for every score matrix
+ * z = seq * n_kv + kv_head of a packed batch ((n_mat, smax, ld) buffers, dims[z] valid rows / columns, query head
+ * kv_head * rep + r) writes p_dropped = keep * p / (1-p) and masks the fp32 d(probabilities) in place. */
+int sl_attn_dropout_bwd(const void* p, void* p_dropped, float* d_p, int64_t n_mat, int32_t smax, const int32_t* dims, int32_t ld,
+                        const int32_t* cu_q, int32_t n_heads, int32_t n_kv_heads, int32_t r, float dropout_p, uint64_t seed, int32_t dtype,
+                        sl_stream stream);
 
 /* RoPE (rotate_half form, hf:...llama.py:130-160) on the q and k slices of a fused QKV activation,
  * then KV-cache append (hf:cache_utils.py:127-145 restated as write-at-position).

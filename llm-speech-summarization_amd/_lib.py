@@ -54,7 +54,7 @@ class AttnArgs(C.Structure):
                 ("cu_q", c_vp), ("cu_k", c_vp), ("klen", c_vp),
                 ("nseq", c_i32), ("max_qlen", c_i32), ("n_heads", c_i32), ("n_kv_heads", c_i32),
                 ("head_dim", c_i32), ("causal", c_i32), ("dtype", c_i32), ("reserved", c_i32),
-                ("scale", c_f32)]
+                ("scale", c_f32), ("dropout_p", c_f32), ("dropout_seed", C.c_uint64)]
 
 
 class HubertLayer(C.Structure):
@@ -109,6 +109,7 @@ _PROTOS = {
     "sl_gemm_ex": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmEx), c_vp]),
     "sl_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "sl_axpby": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_i64, c_i32, c_vp]),
+    "sl_attn_dropout_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_f32, C.c_uint64, c_i32, c_vp]),
     "sl_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, C.c_uint64, c_i32, c_vp]),
     "sl_silu_mul": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "sl_silu_mul_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),

@@ -15,6 +15,9 @@ struct AttnP {
   const int32_t* cu_q; const int32_t* cu_k; const int32_t* klen;
   int n_heads, n_kv;
   float scale;
+  uint32_t drop_thr;     // training mode: keep iff u24(hash) >= drop_thr (0 = no dropout); see sl_attn_args.dropout_p
+  float drop_scale;
+  uint64_t drop_seed;
 };
 
 // swizzled byte offset of 16-byte chunk `ch` of row `row`; rows hold `cpr` chunks (8, 16 or 32)
@@ -151,9 +154,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       const int col = n * 16 + r;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float pv = __expf(s[n][i] - mx[i]);
-        rs[i] += pv;
+        float pv = __expf(s[n][i] - mx[i]);
+        rs[i] += pv;                                    // the normaliser is the undropped sum (dropout follows the softmax)
         const int row = qd * 4 + i;
+        if (p.drop_thr) {
+          const int64_t qg = (int64_t)q0 + qt0 + wave * 16 + row;
+          pv = dropout_keep((((qg * p.n_heads + head) << 16) | (int64_t)(key0 + col)), p.drop_seed, p.drop_thr) ? pv * p.drop_scale : 0.f;
+        }
         *(T*)(Ps + swz_off<CPR_V>(row, col / VEC) + (col % VEC) * SZ) = from_f32<T>(pv);
       }
     }
@@ -221,7 +228,7 @@ __device__ __forceinline__ int v_img_off(int row, int ch) {
   }
 }
 
-template <int D, bool CAUSAL, int QT>
+template <int D, bool CAUSAL, int QT, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
   using T = bf16_t;
   constexpr int KS_D = D / 32;             // 32-wide steps across the head dim (S^T)
@@ -354,9 +361,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
         for (int n = 0; n < 4; ++n)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][n][i], c, -m_use));
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][n][i], c, -m_use));
+            ls += pv;                                   // undropped normaliser
+            if constexpr (DROP) {
+              const int64_t qg = (int64_t)q0 + (qi < qlen ? qi : qlen - 1);
+              pv = dropout_keep((((qg * p.n_heads + head) << 16) | (int64_t)(key0 + n * 16 + 4 * q + i)), p.drop_seed, p.drop_thr) ? pv * p.drop_scale : 0.f;
+            }
             s[t][n][i] = pv;
-            ls += pv;
           }
         l_run[t] = l_run[t] * alpha + ls;   // per-lane partial sum; the four q lanes of a query meet in the epilogue
 #pragma unroll
@@ -427,10 +438,21 @@ static int launch_attn(const sl_attn_args* a, hipStream_t st) {
   p.o = a->out; p.o_rs = a->o_row_stride; p.o_hs = a->o_head_stride;
   p.cu_q = a->cu_q; p.cu_k = a->cu_k; p.klen = a->klen;
   p.n_heads = a->n_heads; p.n_kv = a->n_kv_heads; p.scale = a->scale;
+  p.drop_thr = 0; p.drop_scale = 1.f; p.drop_seed = a->dropout_seed;
+  if (a->dropout_p > 0.f) {
+    p.drop_thr = (uint32_t)((double)a->dropout_p * 16777216.0);
+    p.drop_scale = 1.0f / (1.0f - a->dropout_p);
+  }
   if constexpr (sizeof(T) == 2) {
     // bf16: transposed-score kernel (8-byte output vectors need 4-element strides / an 8-byte aligned base)
     static const int generic = getenv("SL_ATTN_GENERIC") ? atoi(getenv("SL_ATTN_GENERIC")) : 0;
     if (!generic && a->o_row_stride % 4 == 0 && a->o_head_stride % 4 == 0 && ((uintptr_t)a->out & 7) == 0) {
+      if (p.drop_thr) {   // training mode: one variant (32 queries per wave) with the mask applied to the packed probabilities
+        dim3 grid((a->max_qlen + 127) / 128, a->n_heads, a->nseq);
+        hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 2, true>), grid, dim3(256), 0, st, p);
+        SL_CHECK_LAUNCH("attn_fwd_tr");
+        return 0;
+      }
       static const int qt_env = getenv("SL_ATTN_QT") ? atoi(getenv("SL_ATTN_QT")) : 0;   // tuning switch
       if constexpr (D == 64) {
         // 64 queries per wave where the sequences are long enough to fill such blocks: K / V fragments read once per 4 query tiles
@@ -458,6 +480,7 @@ extern "C" int sl_attn_fwd(const sl_attn_args* a, sl_stream stream) {
   SL_CHECK_ARG(a && a->q && a->k && a->v && a->out && a->cu_q && a->cu_k && a->klen, "sl_attn_fwd: null pointer");
   SL_CHECK_ARG(a->nseq > 0 && a->max_qlen > 0 && a->n_heads > 0 && a->n_kv_heads > 0 && a->n_heads % a->n_kv_heads == 0,
                "sl_attn_fwd: bad shape");
+  SL_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "sl_attn_fwd: dropout_p=%f outside [0, 1)", (double)a->dropout_p);
   const int vec = a->dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(a->q_row_stride % vec == 0 && a->k_row_stride % vec == 0 && a->v_row_stride % vec == 0 && a->q_head_stride % vec == 0 &&
                    a->k_head_stride % vec == 0 && a->v_head_stride % vec == 0,

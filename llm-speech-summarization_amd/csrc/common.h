@@ -153,6 +153,15 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float xw = x * w;
   return x >= 0.f ? x - xw : xw;
 }
+// counter-based dropout mask shared by sl_dropout, the attention kernels and sl_attn_dropout_bwd (train_ops.hip has the story)
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(int64_t i, uint64_t seed, uint32_t thr24) {
+  const uint32_t h = lowbias32((uint32_t)i ^ lowbias32((uint32_t)((uint64_t)i >> 32) ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  return (h >> 8) >= thr24;
+}
 template <typename T> __device__ __forceinline__ float gelu_act(float x) {
   if constexpr (sizeof(T) == 2) return gelu_fast(x);
   else return gelu_erf(x);

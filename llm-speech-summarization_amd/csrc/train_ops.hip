@@ -46,15 +46,6 @@ __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, T* 
 // of the 32-bit "lowbias" integer hash over (low word ^ hash(high word ^ seed_lo)) ^ seed_hi.  No mask tensor is stored:
 // the backward pass applies the same function to the gradient (same seed), and the test oracle rebuilds the mask in numpy.
 // y = (res ? res : 0) + keep * x / (1 - p)  (the residual form is HuBERT's  h = residual + dropout(sublayer(h))).
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ bool dropout_keep(int64_t i, uint64_t seed, uint32_t thr24) {
-  const uint32_t h = lowbias32((uint32_t)i ^ lowbias32((uint32_t)((uint64_t)i >> 32) ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
-  return (h >> 8) >= thr24;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t n, float scale,
                                                       uint32_t thr24, uint64_t seed) {
@@ -69,6 +60,24 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
       xv[e] = res ? rv[e] + d : d;
     }
     *(uint4*)(y + i) = Vec16<T>::pack(xv);
+  }
+}
+
+// attention-probability dropout, backward side: same mask index as the forward kernels (attention.hip)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dropout_bwd_kernel(const T* __restrict__ p, T* __restrict__ pd, float* __restrict__ dp, int smax,
+                                                               const int32_t* __restrict__ dims, int ld, const int32_t* __restrict__ cu_q, int nh,
+                                                               int nkv, int r, float scale, uint32_t thr24, uint64_t seed) {
+  const int z = blockIdx.y, si = z / nkv, head = (z % nkv) * (nh / nkv) + r;
+  const int n = dims[z];
+  const int64_t base = (int64_t)z * smax * ld;
+  const int64_t q0 = cu_q[si];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)n * n; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / n), col = (int)(i % n);
+    const bool keep = dropout_keep((((q0 + row) * nh + head) << 16) | col, seed, thr24);
+    const int64_t o = base + (int64_t)row * ld + col;
+    pd[o] = keep ? from_f32<T>(to_f32(p[o]) * scale) : from_f32<T>(0.f);
+    dp[o] = keep ? dp[o] * scale : 0.f;
   }
 }
 
@@ -572,6 +581,24 @@ extern "C" int sl_dropout(const void* x, const void* residual, void* y, int64_t 
                        thr24, (uint64_t)seed);
   });
   SL_CHECK_LAUNCH("dropout");
+  return 0;
+}
+
+extern "C" int sl_attn_dropout_bwd(const void* p, void* p_dropped, float* d_p, int64_t n_mat, int32_t smax, const int32_t* dims, int32_t ld,
+                                   const int32_t* cu_q, int32_t n_heads, int32_t n_kv_heads, int32_t r, float dropout_p, uint64_t seed, int32_t dtype,
+                                   sl_stream stream) {
+  SL_CHECK_ARG(p && p_dropped && d_p && dims && cu_q && n_mat > 0 && smax > 0 && smax <= 65536 && ld >= smax && n_heads > 0 && n_kv_heads > 0 &&
+                   n_heads % n_kv_heads == 0 && r >= 0 && r < n_heads / n_kv_heads && dropout_p >= 0.f && dropout_p < 1.f,
+               "sl_attn_dropout_bwd: bad arguments");
+  const uint32_t thr24 = (uint32_t)((double)dropout_p * 16777216.0);
+  const float scale = 1.0f / (1.0f - dropout_p);
+  const int64_t cells = (int64_t)smax * smax;
+  const unsigned gx = (unsigned)(ceil_div64(cells, 256) < 256 ? ceil_div64(cells, 256) : 256);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((attn_dropout_bwd_kernel<T>), dim3(gx, (unsigned)n_mat), dim3(256), 0, (hipStream_t)stream, (const T*)p, (T*)p_dropped, d_p, smax,
+                       dims, ld, cu_q, n_heads, n_kv_heads, r, scale, thr24, (uint64_t)seed);
+  });
+  SL_CHECK_LAUNCH("attn_dropout_bwd");
   return 0;
 }
 

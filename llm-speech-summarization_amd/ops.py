@@ -109,8 +109,9 @@ def attn_fwd(q, k, v, out, cu_q, cu_k, klen, *, q_strides, k_strides, v_strides,
 
 
 def attn_packed_qkv(qkv: torch.Tensor, seqlens: Sequence[int], n_heads: int, n_kv_heads: int, head_dim: int, causal: bool,
-                    scale: float) -> torch.Tensor:
-    """Attention over a packed fused (tokens, (nh+2nkv)*D) activation (the HuBERT layout)."""
+                    scale: float, dropout_p: float = 0.0, dropout_seed: int = 0) -> torch.Tensor:
+    """Attention over a packed fused (tokens, (nh+2nkv)*D) activation (the HuBERT layout).  dropout_p > 0: training-mode
+    dropout of the attention probabilities (mask index ((token * nh + head) << 16) | key, see sl_attn_args)."""
     dev = qkv.device
     cu = torch.tensor([0] + list(torch.tensor(seqlens).cumsum(0).tolist()), dtype=torch.int32, device=dev)
     klen = torch.tensor(list(seqlens), dtype=torch.int32, device=dev)
@@ -128,8 +129,15 @@ def attn_packed_qkv(qkv: torch.Tensor, seqlens: Sequence[int], n_heads: int, n_k
     a.cu_q, a.cu_k, a.klen = cu.data_ptr(), cu.data_ptr(), klen.data_ptr()
     a.nseq, a.max_qlen, a.n_heads, a.n_kv_heads = len(seqlens), max(seqlens), n_heads, n_kv_heads
     a.head_dim, a.causal, a.dtype, a.scale = head_dim, int(causal), L.dtype_code(qkv.dtype), scale
+    a.dropout_p, a.dropout_seed = float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
     L.check(L.lib().sl_attn_fwd(C.byref(a), L.stream_ptr()), "sl_attn_fwd")
     return out
+
+
+def attn_dropout_bwd(P: torch.Tensor, Pd: torch.Tensor, dP: torch.Tensor, n_mat: int, smax: int, dims: torch.Tensor, ld: int, cu_q: torch.Tensor,
+                     n_heads: int, n_kv_heads: int, r: int, p: float, seed: int) -> None:
+    L.check(L.lib().sl_attn_dropout_bwd(L.ptr(P), L.ptr(Pd), L.ptr(dP), n_mat, smax, L.ptr(dims), ld, L.ptr(cu_q), n_heads, n_kv_heads, r, float(p),
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, L.dtype_code(P.dtype), L.stream_ptr()), "sl_attn_dropout_bwd")
 
 
 def rope_kv_append(qkv, k_cache, v_cache, tok_seq, tok_pos, cos, sin, n_heads, n_kv, D, max_ctx) -> None:

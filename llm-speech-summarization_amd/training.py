@@ -15,8 +15,9 @@ Training-mode regularisers (the reference trains with `audio_encoder.train()`, r
 feature-projection / hidden / activation dropout, LayerDrop and SpecAugment time masking): `TrainRegularizers` switches
 them on (`KDTrainer(..., regularizers=...)`).  Masks come from a counter-based hash (sl_dropout), so forward and backward
 agree without stored masks and the test oracle can rebuild them; SpecAugment spans follow HF's `_compute_mask_indices`
-on numpy's global RNG.  Deterministic KD-step parity (golden fixtures) is defined with them off.  Attention-probability
-dropout is the one stochastic op not applied yet (the forward attention never materialises the probabilities).
+on numpy's global RNG.  Attention-probability dropout is applied inside the attention kernels (the mask index is a
+function of (token, head, key), so the explicit-probability backward rebuilds it).  Deterministic KD-step parity
+(golden fixtures) is defined with the regularisers off.
 """
 from __future__ import annotations
 
@@ -44,6 +45,7 @@ class TrainRegularizers:
     feat_proj_dropout: float = 0.1
     hidden_dropout: float = 0.1
     activation_dropout: float = 0.1
+    attention_dropout: float = 0.1
     layerdrop: float = 0.1
     apply_spec_augment: bool = True
     mask_time_prob: float = 0.05
@@ -54,7 +56,7 @@ class TrainRegularizers:
     @staticmethod
     def from_hf_config(d: dict, seed: int = 1234) -> "TrainRegularizers":
         return TrainRegularizers(d.get("feat_proj_dropout", 0.0), d.get("hidden_dropout", 0.1), d.get("activation_dropout", 0.1),
-                                 d.get("layerdrop", 0.1), d.get("apply_spec_augment", True), d.get("mask_time_prob", 0.05),
+                                 d.get("attention_dropout", 0.1), d.get("layerdrop", 0.1), d.get("apply_spec_augment", True), d.get("mask_time_prob", 0.05),
                                  d.get("mask_time_length", 10), d.get("mask_time_min_masks", 2), seed)
 
 
@@ -98,7 +100,7 @@ def compute_mask_indices(shape: Tuple[int, int], mask_prob: float, mask_length: 
     return mask
 
 
-_SITES = {"fp": 1, "pos": 2, "attn_out": 3, "act": 4, "ffn_out": 5, "layerdrop": 6}
+_SITES = {"fp": 1, "pos": 2, "attn_out": 3, "act": 4, "ffn_out": 5, "layerdrop": 6, "attn_prob": 7}
 
 
 def _site_seed(base: int, site: str, layer: int = 0) -> int:
@@ -197,7 +199,7 @@ def _attention_plan(seqlens, qkv_w: int, ldo: int, nh: int, nkv: int, D: int, ve
 
 
 def attention_backward_packed(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: torch.Tensor, seqlens, nh: int, nkv: int, D: int, causal: bool,
-                              scale: float) -> None:
+                              scale: float, dropout_p: float = 0.0, dropout_seed: int = 0) -> None:
     """attention_backward for every sequence of a packed batch at once: each of the five products is ONE grouped launch over
     all (sequence, kv head) pairs (the per-sequence form spent 27 % of the KD step in 29-42 us launch-bound GEMMs)."""
     dt = qkv.dtype
@@ -211,6 +213,9 @@ def attention_backward_packed(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: tor
     dPb = torch.empty((nmat, smax, ld), device=dev, dtype=torch.float32)
     P = torch.zeros((nmat, smax, ld), device=dev, dtype=dt)
     dS = torch.zeros((nmat, smax, ld), device=dev, dtype=dt)
+    drop = dropout_p > 0
+    Pd = torch.zeros((nmat, smax, ld), device=dev, dtype=dt) if drop else P    # dropped probabilities (what multiplied V in the forward)
+    cu = torch.tensor(offs, dtype=torch.int32, device=dev) if drop else None
     kpad = torch.zeros((len(seqlens), ld, nkv * D), device=dev, dtype=dt)   # K rows zero-padded: dQ = dS . K reduces over ld
     for si, S in enumerate(seqlens):
         kpad[si, :S] = qkv[offs[si]:offs[si] + S, koff:voff]
@@ -220,13 +225,15 @@ def attention_backward_packed(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: tor
         ops.softmax_rows_var(Sb, P, nmat, smax, pl["dims"], ld, scale, causal, dt)
         ops.gemm_ex(d_att, qkv, M=smax, N=smax, K=D, lda=ldo, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nmat, dtype=dt,
                     groups=pl["dp"][r], groups_ext=True)
+        if drop:   # d probabilities = mask / (1-p) * d(dropped probabilities); dV below sees the dropped probabilities
+            ops.attn_dropout_bwd(P, Pd, dPb, nmat, smax, pl["dims"], ld, cu, nh, nkv, r, dropout_p, dropout_seed)
         ops.softmax_bwd_var(P, dPb, dS, nmat, smax, pl["dims"], ld, scale)
         ops.gemm_ex(dS, kpad, M=smax, N=D, K=ld, lda=ld, ldw=nkv * D, out=d_qkv, ldc=qkv_w, trans_w=True, batch=nmat, dtype=dt,
                     groups=pl["dq"][r], groups_ext=True)
         acc = r > 0   # GQA: the rep query heads of a group add into the same dK / dV
         ops.gemm_ex(dS, qkv, M=smax, N=D, K=smax, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nmat, dtype=dt,
                     residual=(d_qkv if acc else None), ldr=qkv_w, groups=pl["dk"][r], groups_ext=True)
-        ops.gemm_ex(P, d_att, M=smax, N=D, K=smax, lda=ld, ldw=ldo, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nmat, dtype=dt,
+        ops.gemm_ex(Pd, d_att, M=smax, N=D, K=smax, lda=ld, ldw=ldo, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nmat, dtype=dt,
                     residual=(d_qkv if acc else None), ldr=qkv_w, groups=pl["dv"][r], groups_ext=True)
 
 
@@ -423,7 +430,8 @@ class EncoderTape:
                     continue
             ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], a.layer_norm_eps)
             qkv = ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"])
-            att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125)
+            p_att = reg.attention_dropout if reg is not None else 0.0
+            att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att, dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
             if reg is not None and reg.hidden_dropout > 0:                 # h = residual + dropout(attention(layer_norm(h)))
                 x_mid = ops.dropout(ops.gemm(att, lt["wo"], bias=lt["bo"]), reg.hidden_dropout, _site_seed(base, "attn_out", li), residual=x)
             else:
@@ -491,7 +499,9 @@ class EncoderTape:
             ops.wgrad_acc(d_o1, c["att"], g[p + "wo"]); ops.colsum_acc(d_o1, g[p + "bo"])
             d_att = ops.dgrad(d_o1, lt["wo"], wt=lt["wo"].t().contiguous())
             d_qkv = torch.empty_like(c["qkv"])
-            attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125)
+            p_att = reg.attention_dropout if reg is not None else 0.0
+            attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att,
+                                      dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
             ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
             d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=lt["wqkv"].t().contiguous())
             dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, a.layer_norm_eps, g[p + "ln1_g"], g[p + "ln1_b"])

@@ -83,8 +83,8 @@ def hubert_forward(
     caller, so a test can replay the masks of the kernel path): {"drop": callable(site, layer, tensor) -> tensor applying
     that site's dropout (sites "fp" feature-projection dropout, "pos" encoder dropout after the positional embedding,
     "attn_out" / "ffn_out" hidden dropouts of a layer, "act" intermediate dropout), "skip": set of LayerDrop-skipped
-    layers, "spec_mask": (B, T) bool SpecAugment mask (rows replaced by `masked_spec_embed`)}.  Attention-probability
-    dropout is not modelled (the build does not apply it yet).
+    layers, "spec_mask": (B, T) bool SpecAugment mask (rows replaced by `masked_spec_embed`), "attn_drop":
+    callable(layer, probabilities (B, nh, T, T)) -> dropped probabilities}.
 
     wave: (B, N) float32 raw 16 kHz samples (the reference feeds un-normalised audio and no mask:
     ref:model/audio_encoder.py:57).  Returns (B, T, hidden).  `taps`, if given, is filled with the
@@ -145,6 +145,8 @@ def hubert_forward(
         vs = F.linear(h, sd[a + "v_proj.weight"].float(), sd[a + "v_proj.bias"].float()).view(B, T, nh, hd).transpose(1, 2)
         att = torch.matmul(qs, ks.transpose(2, 3)) * (hd ** -0.5)  # hf:...hubert.py:248
         att = F.softmax(att, dim=-1)
+        if train is not None and train.get("attn_drop") is not None:   # HubertAttention: dropout on the probabilities
+            att = train["attn_drop"](li, att)                           # (B, nh, T, T)
         o = torch.matmul(att, vs).transpose(1, 2).reshape(B, T, H)
         o = F.linear(o, sd[a + "out_proj.weight"].float(), sd[a + "out_proj.bias"].float())
         x = res + drop("attn_out", li, o)

@@ -275,6 +275,31 @@ def test_attention_keys_longer_than_queries(dt, D, nh, nkv, causal):
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_attention_probability_dropout_matches_host_mask(dt):
+    """Training-mode attention (sl_attn_args.dropout_p): probabilities are dropped after the softmax (undropped normaliser)
+    with the counter-based mask at index ((token * heads + head) << 16) | key; both forward kernels against a torch
+    restatement that rebuilds the mask on the host."""
+    nh, D, p_drop, seed = 4, 64, 0.25, 0x1234_5678_9ABC_DEF1
+    seqlens = [70, 133]
+    ntok = sum(seqlens)
+    qkv = rnd(ntok, 3 * nh * D, seed=31)
+    out = ops.attn_packed_qkv(qkv.to(dev(), dt), seqlens, nh, nh, D, False, D ** -0.5, dropout_p=p_drop, dropout_seed=seed).float().cpu()
+    keep_all = ops.dropout_keep_mask((ntok * nh) << 16, p_drop, seed).view(ntok, nh, 1 << 16)
+    t0 = 0
+    for n in seqlens:
+        blk = q(qkv[t0:t0 + n], dt).view(n, 3, nh, D)
+        qh, kh, vh = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)
+        pr = F.softmax(qh @ kh.transpose(1, 2) * D ** -0.5, dim=-1)                      # (nh, n, n)
+        keep = keep_all[t0:t0 + n, :, :n].permute(1, 0, 2)
+        pr = torch.where(keep, pr / (1.0 - p_drop), torch.zeros_like(pr))
+        ref = (pr @ vh).transpose(0, 1).reshape(n, nh * D)
+        assert rel_err(out[t0:t0 + n], ref) < TOL[dt], n
+        t0 += n
+    plain = ops.attn_packed_qkv(qkv.to(dev(), dt), seqlens, nh, nh, D, False, D ** -0.5).float().cpu()
+    assert rel_err(out, plain) > 0.05          # the mask did something
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_rope_kv_append_and_decode_attention(dt):
     arch = weights.LlamaArch(hidden_size=256, num_attention_heads=6, num_key_value_heads=2, head_dim=128,
                              rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,

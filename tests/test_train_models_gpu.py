@@ -87,7 +87,7 @@ def test_training_mode_regularizers_match_oracle_with_replayed_masks_fp32():
     SpecAugment rows; losses and every parameter gradient — masked_spec_embed included — must agree."""
     import numpy as np
     g = golden("pipeline_tiny")
-    reg = training.TrainRegularizers(feat_proj_dropout=0.1, hidden_dropout=0.1, activation_dropout=0.1, layerdrop=0.34, apply_spec_augment=True,
+    reg = training.TrainRegularizers(feat_proj_dropout=0.1, hidden_dropout=0.1, activation_dropout=0.1, attention_dropout=0.1, layerdrop=0.34, apply_spec_augment=True,
                                      mask_time_prob=0.3, mask_time_length=3, mask_time_min_masks=2, seed=77)
     enc, enc_sd = make_encoder(TINY_HUBERT, TINY_LLAMA.hidden_size, int(g["enc_seed"]), torch.float32)
     enc_sd = dict(enc_sd)
@@ -110,12 +110,20 @@ def test_training_mode_regularizers_match_oracle_with_replayed_masks_fp32():
         keep = ops.dropout_keep_mask(v.numel(), probs[site], training._site_seed(base, site, layer)).view(v.shape)
         return torch.where(keep, v / (1.0 - float(np.float32(probs[site]))), torch.zeros_like(v))
 
+    nh = TINY_HUBERT.num_attention_heads
+
+    def attn_drop(layer, probs):     # (1, nh, T, T): mask index ((token * nh + head) << 16) | key — one utterance, so token = query row
+        n = (T * nh) << 16
+        keep = ops.dropout_keep_mask(n, reg.attention_dropout, training._site_seed(base, "attn_prob", layer)).view(T, nh, 1 << 16)[:, :, :T]
+        keep = keep.permute(1, 0, 2)[None]
+        return torch.where(keep, probs / (1.0 - float(np.float32(reg.attention_dropout))), torch.zeros_like(probs))
+
     skip = {li for li in range(TINY_HUBERT.num_hidden_layers)
             if (training._site_seed(base, "layerdrop", li) >> 11) * (1.0 / 9007199254740992.0) < reg.layerdrop}
     assert 0 < len(skip) < TINY_HUBERT.num_hidden_layers, "pick a seed that drops some but not all layers of the tiny model"
     assert spec.any()
     sd = {k: v.clone().requires_grad_(True) for k, v in enc_sd.items()}
-    audio = ho.audio_encoder_forward(sd, TINY_HUBERT, wave[None], train=dict(drop=drop, skip=skip, spec_mask=torch.from_numpy(spec)))
+    audio = ho.audio_encoder_forward(sd, TINY_HUBERT, wave[None], train=dict(drop=drop, skip=skip, spec_mask=torch.from_numpy(spec), attn_drop=attn_drop))
     ref = ko.kd_losses(llm_sd, TINY_LLAMA, audio, t(g["text_ids"]), t(g["response_ids"]), t(g["prefix_ids"]), t(g["suffix_ids"]), connector_layers=(0, 1, 3))
     for k, r in (("ntp_loss", "ntp"), ("ld_loss", "ld"), ("fd_loss", "fd"), ("total", "total")):
         assert abs(losses[k] - float(ref[r])) < 1e-4 * max(1.0, abs(float(ref[r]))), k
