@@ -23,7 +23,7 @@ import torch
 from . import _lib as L
 from .audio_encoder import AudioEncoder
 from .audio_llama import AudioLlamaForCausalLM
-from .training import KDTrainer
+from .training import KDTrainer, TrainRegularizers
 from .utils import compute_num_audio_embeds, merge_prompt_tokens, prompt_template
 
 
@@ -63,8 +63,11 @@ class Trainer():
         self.prefix_ids = self.tokenizer(prefix, return_tensors="pt").input_ids
         self.suffix_ids = self.tokenizer(suffix, return_tensors="pt").input_ids
         total_iters = self.num_epochs * len(self.train_dataset) // self.grad_accum_interval     # ref:trainer.py:106-110 (global steps)
+        # ref:trainer.py:258 puts the encoder in train() mode: HF's dropouts, LayerDrop and SpecAugment are active during the
+        # optimisation step (validate() runs the inference path, i.e. eval mode, ref:trainer.py:402)
+        reg = None if getattr(args, "no_regularizers", False) else TrainRegularizers(seed=seed)
         self.kd = KDTrainer(config, self.audio_encoder.to(self.device), self.llm, self.prefix_ids, self.suffix_ids,
-                            total_optimizer_steps=max(1, total_iters))
+                            total_optimizer_steps=max(1, total_iters), regularizers=reg)
         self.optimizer, self.lr_scheduler = self.kd.optimizer, self.kd.scheduler
         if getattr(self.args, "checkpoint_path", None):
             self.load_checkpoint(self.args.checkpoint_path)
