@@ -139,14 +139,15 @@ class Trainer():
                 f.write(line + "\n")
 
     def train(self):
-        if self.encoder_base != "hubert":
-            raise L.SpeechLLMError("the KD training tape is built for the HuBERT encoder; the Whisper path is inference-only so far")
         local = self.kd.local_accum
         for epoch in range(self.start_epoch, self.start_epoch + self.num_epochs):       # resume quirk kept
             idx = self._epoch_indices(epoch)
             for w0 in range(0, len(idx), local):
                 batch = [self.train_dataset[i] for i in idx[w0:w0 + local]]
-                raw, _, _, _, text_ids, resp_ids, _ = self.collate_audio_batch_hubert(batch)
+                if self.encoder_base == "whisper":      # ref:trainer.py:168-199: the tape computes the log-mel itself from the raw audio
+                    raw, _, _, _, text_ids, resp_ids, _ = self.collate_audio_batch_whisper(batch)
+                else:
+                    raw, _, _, _, text_ids, resp_ids, _ = self.collate_audio_batch_hubert(batch)
                 losses = self.kd.micro_batch(raw, text_ids, resp_ids)
                 self.step += len(batch) * self.world                                     # global micro-steps, like the reference's counter
                 if (self.step // self.grad_accum_interval) % max(1, self.config.log.log_interval // self.grad_accum_interval or 1) == 0:

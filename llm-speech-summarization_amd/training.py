@@ -344,6 +344,23 @@ class EncoderTape:
     def W(self) -> HubertDeviceWeights:
         return self.enc.weights
 
+    # encoder geometry under the names both architectures' tapes use
+    @property
+    def hidden(self) -> int:
+        return self.enc.arch.hidden_size
+
+    @property
+    def n_heads(self) -> int:
+        return self.enc.arch.num_attention_heads
+
+    @property
+    def ffn(self) -> int:
+        return self.enc.arch.intermediate_size
+
+    @property
+    def ln_eps(self) -> float:
+        return self.enc.arch.layer_norm_eps
+
     # kernel-layout fp32 gradient buffers, one per weight tensor role
     def new_grads(self) -> Dict[str, torch.Tensor]:
         g = {k: torch.zeros(v.shape, device=v.device, dtype=torch.float32) for k, v in self.W.t.items()}
@@ -418,17 +435,27 @@ class EncoderTape:
         if reg is not None and reg.hidden_dropout > 0:                     # encoder: hidden_states = dropout(hidden_states + pos_conv_embed(...))
             ops.dropout(x1, reg.hidden_dropout, _site_seed(base, "pos"), out=x1)
         tape.update(fp_ln=fp_ln, xg=xg, xg_off=xg_off, pre_pos=pre_pos, T=T, toff=toff, reg=reg, base=base, spec_rows=spec_rows)
+        x, layers = self._stack_forward(x1, T, reg, base)
+        out, head = self._head_forward(x, T, toff)
+        tape.update(layers=layers, x_last=x, **head)
+        return out, tape
+
+    # -- the pre-LN transformer layers shared by the HuBERT and Whisper encoders (hf:...hubert.py:504-547 stable-LN layer,
+    #    hf:models/whisper/modeling_whisper.py:360-414), on the packed frames of the batch
+    def _stack_forward(self, x: torch.Tensor, T: Sequence[int], reg: Optional[TrainRegularizers], base: Optional[int]):
+        W, enc = self.W, self.enc
+        dt, dev = enc.dtype, enc.device
+        H, nh, F_, eps = self.hidden, self.n_heads, self.ffn, self.ln_eps
+        NT = x.shape[0]
         layers = []
-        x = x1
-        nh = a.num_attention_heads
-        for li in range(a.num_hidden_layers):
+        for li in range(len(W.layer_t)):
             lt = W.layer_t[li]
             if reg is not None and reg.layerdrop > 0:                      # hf: skip the layer when a uniform draw < layerdrop
                 u01 = (_site_seed(base, "layerdrop", li) >> 11) * (1.0 / 9007199254740992.0)
                 if u01 < reg.layerdrop:
                     layers.append(None)
                     continue
-            ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], a.layer_norm_eps)
+            ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], eps)
             qkv = ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"])
             p_att = reg.attention_dropout if reg is not None else 0.0
             att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att, dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
@@ -436,10 +463,10 @@ class EncoderTape:
                 x_mid = ops.dropout(ops.gemm(att, lt["wo"], bias=lt["bo"]), reg.hidden_dropout, _site_seed(base, "attn_out", li), residual=x)
             else:
                 x_mid = ops.gemm(att, lt["wo"], bias=lt["bo"], residual=x)
-            ln2 = ops.layernorm(x_mid, lt["ln2_g"], lt["ln2_b"], a.layer_norm_eps)
-            pre1 = torch.empty((NT, a.intermediate_size), device=dev, dtype=dt)
+            ln2 = ops.layernorm(x_mid, lt["ln2_g"], lt["ln2_b"], eps)
+            pre1 = torch.empty((NT, F_), device=dev, dtype=dt)
             mid = torch.empty_like(pre1)
-            ops.gemm_ex(ln2, lt["w1"], M=NT, N=a.intermediate_size, K=H, lda=H, ldw=H, out=mid, bias=lt["b1"], act=L.ACT_GELU, aux_out=pre1, dtype=dt)
+            ops.gemm_ex(ln2, lt["w1"], M=NT, N=F_, K=H, lda=H, ldw=H, out=mid, bias=lt["b1"], act=L.ACT_GELU, aux_out=pre1, dtype=dt)
             if reg is not None and reg.activation_dropout > 0:             # intermediate_dropout(act(dense(h)))
                 ops.dropout(mid, reg.activation_dropout, _site_seed(base, "act", li), out=mid)
             if reg is not None and reg.hidden_dropout > 0:                 # h = h + output_dropout(output_dense(...))
@@ -448,15 +475,21 @@ class EncoderTape:
                 x_out = ops.gemm(mid, lt["w2"], bias=lt["b2"], residual=x_mid)
             layers.append(dict(x=x, ln1=ln1, qkv=qkv, att=att, x_mid=x_mid, ln2=ln2, pre1=pre1, mid=mid))
             x = x_out
-        lnf = ops.layernorm(x, t["final_ln_g"], t["final_ln_b"], a.layer_norm_eps)
+        return x, layers
+
+    # -- final LayerNorm, AvgPool1d over time, projection (ref:model/audio_encoder.py:56-63,87)
+    def _head_forward(self, x: torch.Tensor, T: Sequence[int], toff: Sequence[int]):
+        W, enc = self.W, self.enc
+        t, dt, dev = W.t, enc.dtype, enc.device
+        B, H = len(T), self.hidden
+        lnf = ops.layernorm(x, t["final_ln_g"], t["final_ln_b"], self.ln_eps)
         P = [(T[u] - enc.pool_kernel) // enc.pool_stride + 1 for u in range(B)]
         poff = _offsets(P)
         pooled = torch.empty((poff[B], H), device=dev, dtype=dt)
         for u in range(B):
             pooled[poff[u]:poff[u + 1]] = ops.avgpool_rows(lnf[toff[u]:toff[u + 1]], enc.pool_kernel, enc.pool_stride)
         out = ops.gemm(pooled, t["proj_w"], bias=t["proj_b"])
-        tape.update(layers=layers, x_last=x, pooled=pooled, P=P, poff=poff)
-        return out, tape
+        return out, dict(pooled=pooled, P=P, poff=poff)
 
     def backward(self, tape, d_out: torch.Tensor, g: Dict[str, torch.Tensor], on_bucket=None) -> None:
         """Accumulates fp32 parameter gradients into `g` (kernel layouts).  `on_bucket(names)` is called as soon as
@@ -468,46 +501,10 @@ class EncoderTape:
         NT = toff[B]
         nh = a.num_attention_heads
         done = on_bucket or (lambda names: None)
-        # projection + pool + final LN
-        ops.wgrad_acc(d_out, tape["pooled"], g["proj_w"]); ops.colsum_acc(d_out, g["proj_b"])
-        d_pooled = ops.dgrad(d_out, t["proj_w"])
-        d_lnf = torch.empty((NT, H), device=d_out.device, dtype=dt)
-        for u in range(B):
-            d_lnf[toff[u]:toff[u + 1]] = ops.avgpool_bwd(d_pooled[poff[u]:poff[u + 1]], T[u], enc.pool_kernel, enc.pool_stride)
-        dx = ops.layernorm_bwd(tape["x_last"], t["final_ln_g"], t["final_ln_b"], d_lnf, a.layer_norm_eps, g["final_ln_g"], g["final_ln_b"])
-        done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
+        dx = self._head_backward(tape, d_out, g, done)
+        dx = self._stack_backward(tape, dx, g, done)
         reg, base = tape.get("reg"), tape.get("base")
         p_h = reg.hidden_dropout if reg is not None else 0.0
-        p_act = reg.activation_dropout if reg is not None else 0.0
-        for li in reversed(range(a.num_hidden_layers)):
-            lt, c = W.layer_t[li], tape["layers"][li]
-            p = f"l{li}."
-            if c is None:                                                    # LayerDrop: identity in both directions
-                done([p + n for n in lt])
-                continue
-            d_o2 = ops.dropout(dx, p_h, _site_seed(base, "ffn_out", li)) if p_h > 0 else dx
-            ops.wgrad_acc(d_o2, c["mid"], g[p + "w2"]); ops.colsum_acc(d_o2, g[p + "b2"])
-            d_mid = ops.dgrad(d_o2, lt["w2"], wt=lt["w2"].t().contiguous())   # weights move every optimizer step: transposed on the fly
-            if p_act > 0:
-                ops.dropout(d_mid, p_act, _site_seed(base, "act", li), out=d_mid)
-            d_pre1 = ops.gelu_bwd(d_mid, c["pre1"])
-            ops.wgrad_acc(d_pre1, c["ln2"], g[p + "w1"]); ops.colsum_acc(d_pre1, g[p + "b1"])
-            d_ln2 = ops.dgrad(d_pre1, lt["w1"], wt=lt["w1"].t().contiguous())
-            dx_mid = ops.layernorm_bwd(c["x_mid"], lt["ln2_g"], lt["ln2_b"], d_ln2, a.layer_norm_eps, g[p + "ln2_g"], g[p + "ln2_b"])
-            ops.axpby(dx, dx_mid)
-            d_o1 = ops.dropout(dx_mid, p_h, _site_seed(base, "attn_out", li)) if p_h > 0 else dx_mid
-            ops.wgrad_acc(d_o1, c["att"], g[p + "wo"]); ops.colsum_acc(d_o1, g[p + "bo"])
-            d_att = ops.dgrad(d_o1, lt["wo"], wt=lt["wo"].t().contiguous())
-            d_qkv = torch.empty_like(c["qkv"])
-            p_att = reg.attention_dropout if reg is not None else 0.0
-            attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att,
-                                      dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
-            ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
-            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=lt["wqkv"].t().contiguous())
-            dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, a.layer_norm_eps, g[p + "ln1_g"], g[p + "ln1_b"])
-            ops.axpby(dx_mid, dxin)
-            dx = dxin
-            done([p + n for n in lt])
         # positional conv: x1 = x0 + gelu(conv(x0) + b)
         G, k = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
         Hg = H // G
@@ -568,6 +565,58 @@ class EncoderTape:
         done(["conv0_w", "conv0_b", "conv0_g", "conv0_beta"])
 
 
+    def _head_backward(self, tape, d_out: torch.Tensor, g: Dict[str, torch.Tensor], done) -> torch.Tensor:
+        W, enc = self.W, self.enc
+        t, dt = W.t, enc.dtype
+        H, T, toff, poff = self.hidden, tape["T"], tape["toff"], tape["poff"]
+        B, NT = len(T), tape["toff"][len(T)]
+        ops.wgrad_acc(d_out, tape["pooled"], g["proj_w"]); ops.colsum_acc(d_out, g["proj_b"])
+        d_pooled = ops.dgrad(d_out, t["proj_w"])
+        d_lnf = torch.empty((NT, H), device=d_out.device, dtype=dt)
+        for u in range(B):
+            d_lnf[toff[u]:toff[u + 1]] = ops.avgpool_bwd(d_pooled[poff[u]:poff[u + 1]], T[u], enc.pool_kernel, enc.pool_stride)
+        dx = ops.layernorm_bwd(tape["x_last"], t["final_ln_g"], t["final_ln_b"], d_lnf, self.ln_eps, g["final_ln_g"], g["final_ln_b"])
+        done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
+        return dx
+
+    def _stack_backward(self, tape, dx: torch.Tensor, g: Dict[str, torch.Tensor], done) -> torch.Tensor:
+        W = self.W
+        T, nh, eps = tape["T"], self.n_heads, self.ln_eps
+        reg, base = tape.get("reg"), tape.get("base")
+        p_h = reg.hidden_dropout if reg is not None else 0.0
+        p_act = reg.activation_dropout if reg is not None else 0.0
+        for li in reversed(range(len(W.layer_t))):
+            lt, c = W.layer_t[li], tape["layers"][li]
+            p = f"l{li}."
+            if c is None:                                                    # LayerDrop: identity in both directions
+                done([p + n for n in lt])
+                continue
+            d_o2 = ops.dropout(dx, p_h, _site_seed(base, "ffn_out", li)) if p_h > 0 else dx
+            ops.wgrad_acc(d_o2, c["mid"], g[p + "w2"]); ops.colsum_acc(d_o2, g[p + "b2"])
+            d_mid = ops.dgrad(d_o2, lt["w2"], wt=lt["w2"].t().contiguous())   # weights move every optimizer step: transposed on the fly
+            if p_act > 0:
+                ops.dropout(d_mid, p_act, _site_seed(base, "act", li), out=d_mid)
+            d_pre1 = ops.gelu_bwd(d_mid, c["pre1"])
+            ops.wgrad_acc(d_pre1, c["ln2"], g[p + "w1"]); ops.colsum_acc(d_pre1, g[p + "b1"])
+            d_ln2 = ops.dgrad(d_pre1, lt["w1"], wt=lt["w1"].t().contiguous())
+            dx_mid = ops.layernorm_bwd(c["x_mid"], lt["ln2_g"], lt["ln2_b"], d_ln2, eps, g[p + "ln2_g"], g[p + "ln2_b"])
+            ops.axpby(dx, dx_mid)
+            d_o1 = ops.dropout(dx_mid, p_h, _site_seed(base, "attn_out", li)) if p_h > 0 else dx_mid
+            ops.wgrad_acc(d_o1, c["att"], g[p + "wo"]); ops.colsum_acc(d_o1, g[p + "bo"])
+            d_att = ops.dgrad(d_o1, lt["wo"], wt=lt["wo"].t().contiguous())
+            d_qkv = torch.empty_like(c["qkv"])
+            p_att = reg.attention_dropout if reg is not None else 0.0
+            attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att,
+                                      dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
+            ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
+            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=lt["wqkv"].t().contiguous())
+            dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, eps, g[p + "ln1_g"], g[p + "ln1_b"])
+            ops.axpby(dx_mid, dxin)
+            dx = dxin
+            done([p + n for n in lt])
+        return dx
+
+
 def kernel_grads_to_state_dict(enc: AudioEncoder, g: Dict[str, torch.Tensor], master: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Map kernel-layout fp32 gradients back onto the reference's state-dict parameter names/shapes
     (inverse of HubertDeviceWeights' re-layouts; weight-norm backward for the positional conv)."""
@@ -613,6 +662,128 @@ def kernel_grads_to_state_dict(enc: AudioEncoder, g: Dict[str, torch.Tensor], ma
     return out
 
 
+class WhisperEncoderTape(EncoderTape):
+    """Whisper encoder + pool + projection with a tape (hf:models/whisper/modeling_whisper.py:592-646; the reference trains
+    it through the same loop, ref:trainer.py:168-199, 278-291): log-mel on the GPU (no gradient), conv1(k3,p1)+GELU and
+    conv2(k3,s2,p1)+GELU as implicit GEMMs over zero-haloed channel-last rows, + the fixed positional table, then the shared
+    pre-LN layer stack.  Whisper's own dropouts / LayerDrop / SpecAugment are 0 / off in the shipped configs, so train() and
+    eval() coincide; `reg` is still honoured by the layer stack.  Every utterance is one padded 30 s window; the embeddings
+    are cropped to `compute_num_audio_embeds(len(audio))` rows as the reference does."""
+
+    def __init__(self, enc: AudioEncoder):
+        if enc.downsample_method != "pool":
+            raise L.SpeechLLMError("the KD step is built for the `pool` downsample (all shipped configs use it)")
+        self.enc = enc
+
+    @property
+    def hidden(self) -> int:
+        return self.enc.arch.d_model
+
+    @property
+    def n_heads(self) -> int:
+        return self.enc.arch.encoder_attention_heads
+
+    @property
+    def ffn(self) -> int:
+        return self.enc.arch.encoder_ffn_dim
+
+    @property
+    def ln_eps(self) -> float:
+        return 1e-5
+
+    def new_grads(self) -> Dict[str, torch.Tensor]:
+        g = {k: torch.zeros(v.shape, device=v.device, dtype=torch.float32) for k, v in self.W.t.items() if k != "pos"}
+        for li, lt in enumerate(self.W.layer_t):
+            for k, v in lt.items():
+                g[f"l{li}.{k}"] = torch.zeros(v.shape, device=v.device, dtype=torch.float32)
+        return g
+
+    def forward(self, waves: Sequence[torch.Tensor], reg: Optional[TrainRegularizers] = None, step: int = 0, masked_spec_embed=None):
+        from .utils import compute_num_audio_embeds
+        W, a, enc = self.W, self.enc.arch, self.enc
+        t, dt, dev = W.t, enc.dtype, enc.device
+        B, H, nm, F_, T1 = len(waves), a.d_model, a.num_mel_bins, a.n_frames, a.max_source_positions
+        lens = [int(torch.as_tensor(wv).numel()) for wv in waves]
+        feats = enc.feature_extractor(list(waves), return_tensors="pt", sampling_rate=a.sampling_rate).input_features   # (B, nm, F) view of (B, F, nm)
+        a1 = torch.zeros((B, F_ + 2, nm), device=dev, dtype=dt)                 # one zero row before / after each window: Conv1d padding=1
+        a1[:, 1:F_ + 1] = feats.transpose(1, 2).to(dt)
+        b1 = torch.zeros((B, F_ + 2, H), device=dev, dtype=dt)
+        pre1 = torch.empty((B, F_ + 2, H), device=dev, dtype=dt)
+        ops.gemm_ex(a1, t["conv1_w"], M=F_, N=H, K=3 * nm, lda=nm, ldw=3 * nm, out=b1, ldc=H, bias=t["conv1_b"], act=L.ACT_GELU,
+                    aux_out=pre1.view(-1)[H:], batch=B, strideA=(F_ + 2) * nm, strideC=(F_ + 2) * H, c_off=H, dtype=dt)
+        x0 = torch.empty((B * T1, H), device=dev, dtype=dt)
+        pre2 = torch.empty_like(x0)
+        ops.gemm_ex(b1, t["conv2_w"], M=T1, N=H, K=3 * H, lda=2 * H, ldw=3 * H, out=x0, ldc=H, bias=t["conv2_b"], act=L.ACT_GELU, aux_out=pre2,
+                    residual=t["pos"], ldr=H, batch=B, strideA=(F_ + 2) * H, strideC=T1 * H, strideR=0, dtype=dt)
+        T = [T1] * B
+        toff = _offsets(T)
+        base = None if reg is None else (int(reg.seed) * 1000003 + int(step)) & 0xFFFFFFFFFFFFFFFF
+        tape = dict(a1=a1, b1=b1, pre1=pre1, pre2=pre2, T=T, toff=toff, reg=reg, base=base)
+        x, layers = self._stack_forward(x0, T, reg, base)
+        full, head = self._head_forward(x, T, toff)
+        Pfull = head["P"][0]
+        keep = [min(Pfull, max(0, compute_num_audio_embeds(n, sr=a.sampling_rate))) for n in lens]       # ref:trainer.py:283-289
+        rows = torch.cat([torch.arange(u * Pfull, u * Pfull + keep[u]) for u in range(B)]).to(dev)
+        out = full.index_select(0, rows)
+        tape.update(layers=layers, x_last=x, pooled=head["pooled"], P=keep, poff=_offsets(keep), P_full=head["P"], poff_full=head["poff"], rows=rows)
+        return out, tape
+
+    def backward(self, tape, d_out: torch.Tensor, g: Dict[str, torch.Tensor], on_bucket=None) -> None:
+        W, a, enc = self.W, self.enc.arch, self.enc
+        t, dt = W.t, enc.dtype
+        B, H, nm, F_, T1 = len(tape["T"]), a.d_model, a.num_mel_bins, a.n_frames, a.max_source_positions
+        done = on_bucket or (lambda names: None)
+        d_full = torch.zeros((tape["poff_full"][B], d_out.shape[1]), device=d_out.device, dtype=dt)      # cropped rows carry the gradient
+        d_full.index_copy_(0, tape["rows"], d_out)
+        full = dict(tape, P=tape["P_full"], poff=tape["poff_full"])
+        dx = self._head_backward(full, d_full, g, done)
+        dx = self._stack_backward(tape, dx, g, done)
+        # x0 = gelu(conv2(b1) + bias) + pos  (the positional table is frozen, hf:...whisper.py:606)
+        d_pre2 = ops.gelu_bwd(dx, tape["pre2"])
+        ops.colsum_acc(d_pre2, g["conv2_b"])
+        b1, a1 = tape["b1"], tape["a1"]
+        part = torch.empty((B, H, 3 * H), device=dx.device, dtype=torch.float32)
+        ops.gemm_ex(d_pre2, b1, M=H, N=3 * H, K=T1, lda=H, ldw=2 * H, out=part, ldc=3 * H, out_f32=True, trans_a=True, trans_w=True, batch=B,
+                    strideA=T1 * H, strideW=(F_ + 2) * H, strideC=H * 3 * H, dtype=dt)
+        g["conv2_w"] += part.sum(0)
+        dcol = ops.dgrad(d_pre2, t["conv2_w"], wt=t["conv2_w"].t().contiguous())                        # (B*T1, 3H): windows of the haloed rows
+        d_b1 = torch.empty((B, F_, H), device=dx.device, dtype=dt)
+        for u in range(B):
+            d_b1[u] = ops.col2im(dcol[u * T1:(u + 1) * T1], F_ + 2, H, 3, 2)[1:F_ + 1]
+        d_pre1 = ops.gelu_bwd(d_b1.view(B * F_, H), tape["pre1"][:, 1:F_ + 1].reshape(B * F_, H))
+        ops.colsum_acc(d_pre1, g["conv1_b"])
+        part1 = torch.empty((B, H, 3 * nm), device=dx.device, dtype=torch.float32)
+        ops.gemm_ex(d_pre1, a1, M=H, N=3 * nm, K=F_, lda=H, ldw=nm, out=part1, ldc=3 * nm, out_f32=True, trans_a=True, trans_w=True, batch=B,
+                    strideA=F_ * H, strideW=(F_ + 2) * nm, strideC=H * 3 * nm, dtype=dt)
+        g["conv1_w"] += part1.sum(0)
+        done(["conv1_w", "conv1_b", "conv2_w", "conv2_b"])
+
+
+def whisper_grads_to_state_dict(enc: AudioEncoder, g: Dict[str, torch.Tensor], master: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Kernel-layout gradients -> the reference's Whisper state-dict names (inverse of WhisperDeviceWeights' re-layouts).
+    k_proj has no bias (its slot of the fused qkv bias is dropped); embed_positions is frozen in HF."""
+    a = enc.arch
+    H = a.d_model
+    out: Dict[str, torch.Tensor] = {}
+    for name, cin in (("conv1", a.num_mel_bins), ("conv2", H)):
+        out[f"encoder.{name}.weight"] = g[f"{name}_w"].view(H, 3, cin).permute(0, 2, 1).contiguous()
+        out[f"encoder.{name}.bias"] = g[f"{name}_b"]
+    for li in range(a.encoder_layers):
+        p, q = f"encoder.layers.{li}.", f"l{li}."
+        wq, wk, wv = g[q + "wqkv"].split(H, dim=0)
+        bq, _, bv = g[q + "bqkv"].split(H, dim=0)
+        out[p + "self_attn.q_proj.weight"], out[p + "self_attn.k_proj.weight"], out[p + "self_attn.v_proj.weight"] = wq, wk, wv
+        out[p + "self_attn.q_proj.bias"], out[p + "self_attn.v_proj.bias"] = bq, bv
+        out[p + "self_attn.out_proj.weight"], out[p + "self_attn.out_proj.bias"] = g[q + "wo"], g[q + "bo"]
+        out[p + "self_attn_layer_norm.weight"], out[p + "self_attn_layer_norm.bias"] = g[q + "ln1_g"], g[q + "ln1_b"]
+        out[p + "final_layer_norm.weight"], out[p + "final_layer_norm.bias"] = g[q + "ln2_g"], g[q + "ln2_b"]
+        out[p + "fc1.weight"], out[p + "fc1.bias"] = g[q + "w1"], g[q + "b1"]
+        out[p + "fc2.weight"], out[p + "fc2.bias"] = g[q + "w2"], g[q + "b2"]
+    out["encoder.layer_norm.weight"], out["encoder.layer_norm.bias"] = g["final_ln_g"], g["final_ln_b"]
+    out["embed_projection.weight"], out["embed_projection.bias"] = g["proj_w"], g["proj_b"]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # the KD step
 # ------------------------------------------------------------------------------------------------
@@ -638,14 +809,18 @@ class KDTrainer:
         self.local_accum = self.accum // self.world
         dev = encoder.device
         self.prefix_ids, self.suffix_ids = prefix_ids.to(dev), suffix_ids.to(dev)
-        self.enc_tape, self.llm_tape = EncoderTape(encoder), LlamaTape(llm)
+        self.is_whisper = getattr(encoder, "encoder_base", "hubert") == "whisper"
+        self.enc_tape = WhisperEncoderTape(encoder) if self.is_whisper else EncoderTape(encoder)
+        self.llm_tape = LlamaTape(llm)
+        self.to_state_dict = whisper_grads_to_state_dict if self.is_whisper else kernel_grads_to_state_dict
         # fp32 master weights (the reference keeps fp32 params under fp16 autocast, ref:trainer.py:252,270)
         self.master = {k: v.detach().to(dev, torch.float32).clone() for k, v in encoder.state_dict().items()}
         self.reg = regularizers
         # masked_spec_embed only receives a gradient under SpecAugment (the reference's train() mode); with the regularisers
         # off it stays out of the optimizer, as its gradient is identically zero
         spec = regularizers is not None and regularizers.apply_spec_augment and regularizers.mask_time_prob > 0
-        self.trainable = [k for k in self.master if spec or k != "encoder.masked_spec_embed"]
+        frozen = {"encoder.embed_positions.weight"} if self.is_whisper else (set() if spec else {"encoder.masked_spec_embed"})
+        self.trainable = [k for k in self.master if k not in frozen]
         self.params = [torch.nn.Parameter(self.master[k], requires_grad=True) for k in self.trainable]
         opt = tr.optimizer
         self.optimizer = torch.optim.AdamW(self.params, lr=float(opt.lr), betas=(float(opt.beta1), float(opt.beta2)))
@@ -748,7 +923,7 @@ class KDTrainer:
     def optimizer_step(self) -> None:
         if self.reducer is not None:
             self.reducer.finish()
-        sd_grads = kernel_grads_to_state_dict(self.enc, self.grads, self.master)
+        sd_grads = self.to_state_dict(self.enc, self.grads, self.master)
         for k, p in zip(self.trainable, self.params):
             p.grad = sd_grads[k].reshape(p.shape).to(torch.float32)
         self.last_grads = {k: p.grad.clone() for k, p in zip(self.trainable, self.params)}

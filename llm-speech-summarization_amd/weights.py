@@ -428,9 +428,12 @@ class WhisperDeviceWeights:
         if H // arch.encoder_attention_heads != 64:
             raise L.SpeechLLMError("Whisper head_dim must be 64 for the built attention kernel")
 
+        by_ptr: Dict[int, torch.Tensor] = {}
+
         def dev(t: torch.Tensor, dt=None) -> torch.Tensor:
             t = t.detach().to(device=device, dtype=dt or dtype).contiguous()
             self._keep.append(t)
+            by_ptr[t.data_ptr()] = t
             return t
 
         m = L.HubertModel()
@@ -465,6 +468,11 @@ class WhisperDeviceWeights:
         if downsample == "pool":
             m.proj_w, m.proj_b = self.proj_w.data_ptr(), self.proj_b.data_ptr()
         self.struct = m
+        # role -> device tensor, as HubertDeviceWeights does (the training tape composes ops from these)
+        g = lambda ptr: by_ptr[ptr]
+        self.t = dict(conv1_w=g(m.conv_w[1]), conv1_b=g(m.conv_b[1]), conv2_w=g(m.conv_w[2]), conv2_b=g(m.conv_b[2]), pos=g(m.pos_w),
+                      final_ln_g=g(m.final_ln_g), final_ln_b=g(m.final_ln_b), proj_w=self.proj_w, proj_b=self.proj_b)
+        self.layer_t = [{n: g(getattr(self._layers[li], n)) for n, _ in L.HubertLayer._fields_} for li in range(arch.encoder_layers)]
         # log-mel constants (fp32)
         nb = arch.n_fft // 2 + 1
         ld_pw = (nb + 3) // 4 * 4

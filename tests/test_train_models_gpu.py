@@ -138,6 +138,49 @@ def test_training_mode_regularizers_match_oracle_with_replayed_masks_fp32():
     assert float(grads["encoder.masked_spec_embed"].norm()) > 0.0
 
 
+def test_whisper_kd_step_losses_and_every_gradient_match_oracle_autograd_fp32():
+    """KD micro-steps through the Whisper encoder tape (log-mel on the GPU, conv1 / conv2 implicit GEMMs, shared layer stack,
+    crop to compute_num_audio_embeds) against autograd through the CPU oracle — two utterances of different lengths packed
+    in one window, so the crop and the per-utterance loss scaling are exercised."""
+    from oracle import whisper_oracle as wo
+    from oracle.golden_cfgs import TINY_WHISPER as WC
+    weights = pkg("weights")
+    enc_mod = pkg("audio_encoder")
+    g = golden("pipeline_tiny")
+    conf = cfgm.from_dict(dict(model=dict(audio_encoder=dict(base="whisper", type="synthetic", downsample_method="pool", downsample_factor=4,
+                                                             pooling=dict(kernel_size=8, stride=4)), llm_embedding_channels=TINY_LLAMA.hidden_size)))
+    arch = weights.WhisperArch(WC.d_model, WC.encoder_layers, WC.encoder_attention_heads, WC.encoder_ffn_dim, WC.num_mel_bins, WC.max_source_positions)
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=torch.float32, arch=arch)
+    enc_sd = ri.whisper_encoder_state_dict(WC, TINY_LLAMA.hidden_size, seed=3)
+    enc.load_state_dict(enc_sd).eval().to(DEV)
+    llm, llm_sd = make_llama(TINY_LLAMA, int(g["llm_seed"]), torch.float32)
+    tr = training.KDTrainer(kd_config(taps=(0, 1, 3)), enc, llm, t(g["prefix_ids"]), t(g["suffix_ids"]))
+    assert "encoder.embed_positions.weight" not in tr.trainable and "encoder.conv1.weight" in tr.trainable
+    waves = [ri.synthetic_waveform(24000, seed=5), ri.synthetic_waveform(17000, seed=6)]        # 1.5 s and ~1.06 s inside the 2 s window
+    text_ids, resp_ids = [t(g["text_ids"]), t(g["text_ids"])[:7]], [t(g["response_ids"]), t(g["response_ids"])[:9]]
+    losses = tr.micro_batch(waves, text_ids, resp_ids)
+    grads = tr.to_state_dict(tr.enc, tr.grads, tr.master)
+    sd = {k: v.clone().requires_grad_(k != "encoder.embed_positions.weight") for k, v in enc_sd.items()}
+    total_loss = 0.0
+    for u, wave in enumerate(waves):
+        feats = wo.log_mel(WC, wave)[None]
+        n_emb = utils.compute_num_audio_embeds(wave.numel())
+        audio = wo.audio_encoder_forward(sd, WC, feats)[:, :n_emb]
+        ref = ko.kd_losses(llm_sd, TINY_LLAMA, audio, text_ids[u], resp_ids[u], t(g["prefix_ids"]), t(g["suffix_ids"]), connector_layers=(0, 1, 3))
+        for k, r in (("ntp_loss", "ntp"), ("ld_loss", "ld"), ("fd_loss", "fd"), ("total", "total")):
+            assert abs(losses[u][k] - float(ref[r])) < 2e-4 * max(1.0, abs(float(ref[r]))), (u, k, losses[u][k], float(ref[r]))
+        total_loss = total_loss + ref["total"] / 16
+    total_loss.backward()
+    total = torch.stack([sd[k].grad.norm() for k in tr.trainable]).norm()
+    for k in tr.trainable:
+        rg = sd[k].grad
+        err = float((grads[k].cpu().reshape(rg.shape).double() - rg.double()).norm())
+        assert err < 3e-3 * float(rg.norm()) + 1e-6 * float(total), (k, err, float(rg.norm()))
+    tr.optimizer_step()                                   # AdamW over the Whisper parameter set, kernel weights refreshed
+    assert not torch.equal(tr.master["encoder.conv1.weight"].cpu(), enc_sd["encoder.conv1.weight"])
+    assert torch.equal(tr.master["encoder.embed_positions.weight"].cpu(), enc_sd["encoder.embed_positions.weight"])
+
+
 def test_optimizer_step_updates_master_and_kernel_weights():
     g = golden("pipeline_tiny")
     tr, enc_sd, _, wave = build(g, torch.float32, accum=2)
