@@ -165,8 +165,12 @@ class Trainer():
         emb = self.llm.model.embed_tokens
         audio_nlls, text_nlls, samples = [], [], []
         for sample_idx in range(len(self.val_dataset)):
-            raw, _, _, texts, text_ids, resp_ids, _ = self.collate_audio_batch_hubert([self.val_dataset[sample_idx]])
-            audio_embeds = self.audio_encoder(raw[0][None].to(self.device))
+            if self.encoder_base == "whisper":   # ref:trainer.py:417-419 feeds the padded 30 s window and does NOT crop here
+                _, feats, _, texts, text_ids, resp_ids, _ = self.collate_audio_batch_whisper([self.val_dataset[sample_idx]])
+                audio_embeds = self.audio_encoder(feats.to(self.device))
+            else:
+                raw, _, _, texts, text_ids, resp_ids, _ = self.collate_audio_batch_hubert([self.val_dataset[sample_idx]])
+                audio_embeds = self.audio_encoder(raw[0][None].to(self.device))
             resp = resp_ids[0].to(self.device)
             pre, suf = emb(self.prefix_ids.to(self.device)), emb(self.suffix_ids.to(self.device))[:, 1:]
             r = emb(resp[None])[:, 1:]

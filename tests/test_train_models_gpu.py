@@ -283,3 +283,46 @@ def test_trainer_loop_validate_checkpoint_roundtrip(tmp_path):
     tr2 = trainer_mod.Trainer(args2, conf, DEV, tokenizer=tok, llm=llm, audio_encoder=enc3, train_dataset=train_ds, val_dataset=val_ds,
                               dtype=torch.float32)
     assert tr2.step == 8 and tr2.start_epoch == 0 and torch.equal(tr2.kd.master["embed_projection.weight"], tr.kd.master["embed_projection.weight"])
+
+
+def test_trainer_loop_whisper_base(tmp_path):
+    """The same Trainer surface with `base: whisper` (ref:config/llama3_whisper.yaml): collate through the GPU log-mel,
+    KD steps through the Whisper tape, validation on the uncropped window as the reference does, checkpoint."""
+    from types import SimpleNamespace
+    from oracle.golden_cfgs import TINY_WHISPER as WC
+    from test_models_gpu import StubTokenizer
+    trainer_mod, weights, enc_mod = pkg("trainer"), pkg("weights"), pkg("audio_encoder")
+    g = golden("pipeline_tiny")
+    gen = torch.Generator().manual_seed(6)
+    V = TINY_LLAMA.vocab_size
+
+    def row(n, nt, nr):
+        return {"audio": {"array": ri.synthetic_waveform(n, seed=n)}, "text": f"utt{n}",
+                "text_input_ids": torch.cat([torch.zeros(1, dtype=torch.long), torch.randint(1, V, (nt,), generator=gen)]),
+                "response_input_ids": torch.cat([torch.zeros(1, dtype=torch.long), torch.randint(1, V, (nr,), generator=gen)])[None],
+                "pool_ranges_4": []}
+
+    train_ds = [row(14000 + 2000 * i, 5 + i % 3, 6 + i % 4) for i in range(4)]
+    val_ds = [row(20000, 6, 7)]
+    conf = cfgm.from_dict(dict(seed_everything=1234, audio=dict(sampling_rate=16000),
+                               model=dict(audio_encoder=dict(base="whisper", type="synthetic", downsample_method="pool", downsample_factor=4,
+                                                             pooling=dict(kernel_size=8, stride=4)),
+                                          llm_embedding_channels=TINY_LLAMA.hidden_size, llm_type=utils.LLAMA_ID),
+                               train=dict(optimizer=dict(lr=5e-5, beta1=0.9, beta2=0.999), batch_size=1, grad_accum_interval=2, epochs=1,
+                                          use_ld_loss=True, use_fd_loss=True, ntp_loss_weight=0.5, ld_loss_weight=0.5, fd_loss_weight=1.0,
+                                          fd_loss_connector_layers=[0, 1, 3]),
+                               log=dict(checkpoint_dir=str(tmp_path / "ckpt"), log_dir=str(tmp_path / "logs"), log_interval=2,
+                                        validation_interval=1000, num_generate_samples=1)))
+    arch = weights.WhisperArch(WC.d_model, WC.encoder_layers, WC.encoder_attention_heads, WC.encoder_ffn_dim, WC.num_mel_bins, WC.max_source_positions)
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=torch.float32, arch=arch)
+    enc.load_state_dict(ri.whisper_encoder_state_dict(WC, TINY_LLAMA.hidden_size, seed=9)).eval().to(DEV)
+    llm, _ = make_llama(TINY_LLAMA, 52, torch.float32)
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: t(g["prefix_ids"]), utils.LLAMA_PROMPT_SUFFIX: t(g["suffix_ids"])})
+    tr = trainer_mod.Trainer(SimpleNamespace(run_name="w", checkpoint_path=None, gpu_idx=0), conf, DEV, tokenizer=tok, llm=llm, audio_encoder=enc,
+                             train_dataset=train_ds, val_dataset=val_ds, dtype=torch.float32)
+    w0 = tr.kd.master["encoder.conv2.weight"].clone()
+    tr.train()
+    assert tr.step == 4 and not torch.equal(w0, tr.kd.master["encoder.conv2.weight"])
+    ck = torch.load(tmp_path / "ckpt" / "w" / "epoch_0_step_4.pt", map_location="cpu", weights_only=False)
+    assert torch.equal(ck["audio_encoder"]["encoder.conv2.weight"], tr.kd.master["encoder.conv2.weight"].cpu())
+    assert any("validation/audio_perplexity" in l for l in open(tmp_path / "logs" / "w" / "metrics.jsonl"))
