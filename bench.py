@@ -106,7 +106,7 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     """ref:trainer.py:270-384 on synthetic data: 10 s audio, 40 text ids, 64 response ids."""
     training, ri = mod("training"), mod("random_init")
     # the reference trains with the encoder in train() mode (ref:trainer.py:258): dropouts, LayerDrop and SpecAugment on
-    reg = None if args.kd_eval_mode else training.TrainRegularizers()
+    reg = None if args.kd_eval_mode else training.TrainRegularizers(seed=1234 + rank)   # ranks draw different masks, as seed_everything + rank does in Trainer
     tr = training.KDTrainer(conf, enc, llm, prefix, suffix, total_optimizer_steps=1000, regularizers=reg)
     g = torch.Generator().manual_seed(99 + rank)
     text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g)
