@@ -239,6 +239,12 @@ int sl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dt
 /* y = a*x + b*y (gradient accumulation at residual joins). */
 int sl_axpby(const void* x, void* y, float a, float b, int64_t n, int32_t dtype, sl_stream stream);
 
+/* y (cols, ld_out) = x (rows, cols)^T with columns rows..ld_out-1 zero-filled (row strides ldx / ldy in elements): the
+ * K-contiguous operand copies of the backward products (torch's autograd transposes implicitly inside its GEMM calls,
+ * hf training under ref:trainer.py:374-378 loss.backward()). */
+int sl_transpose_pad(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t ld_out, int32_t dtype,
+                     sl_stream stream);
+
 /* Training-mode dropout (hf:models/hubert/modeling_hubert.py feature-projection / hidden / activation dropouts of the
  * encoder the reference puts in train() mode, ref:trainer.py:258):  y = (residual ? residual : 0) + keep(i) * x / (1 - p).
  * keep(i) is a counter-based hash of (element index, seed) — no mask tensor; the backward pass calls the same entry

@@ -81,6 +81,43 @@ __global__ __launch_bounds__(256) void attn_dropout_bwd_kernel(const T* __restri
   }
 }
 
+// y (cols, ld_out) = x (rows, cols)^T, columns rows..ld_out-1 of y zero-filled: the K-contiguous operand copies of the weight-
+// gradient products (dY^T, X^T padded to whole K slabs) and of the data-gradient products (W^T).  64 x 64 tiles through LDS,
+// 16-byte global accesses on both sides.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int cols,
+                                                            int ld_out) {
+  constexpr int VEC = Vec16<T>::VEC, TS = 64;
+  __shared__ T tile[TS][TS + 2];
+  const int r0 = blockIdx.x * TS, c0 = blockIdx.y * TS;
+  const int tid = threadIdx.x;
+  constexpr int CPR = TS / VEC;                       // 16-byte chunks per 64-element row
+  for (int i = tid; i < TS * CPR; i += 256) {
+    const int r = i / CPR, ch = i % CPR;
+    T e[VEC];
+    if (r0 + r < rows && c0 + ch * VEC + VEC <= cols) {
+      *(uint4*)e = *(const uint4*)(x + (int64_t)(r0 + r) * ldx + c0 + ch * VEC);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) e[j] = (r0 + r < rows && c0 + ch * VEC + j < cols) ? x[(int64_t)(r0 + r) * ldx + c0 + ch * VEC + j] : from_f32<T>(0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) tile[r][ch * VEC + j] = e[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < TS * CPR; i += 256) {
+    const int c = i / CPR, ch = i % CPR;              // output row c0 + c, elements r0 + ch*VEC ..
+    if (c0 + c >= cols) continue;
+    T e[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) e[j] = tile[ch * VEC + j][c];     // rows past `rows` were loaded as zeros
+    const int o = r0 + ch * VEC;
+    if (o + VEC <= ld_out) *(uint4*)(y + (int64_t)(c0 + c) * ldy + o) = *(const uint4*)e;
+    else
+      for (int j = 0; j < VEC && o + j < ld_out; ++j) y[(int64_t)(c0 + c) * ldy + o + j] = e[j];
+  }
+}
+
 // gu: (M, 2F) with blocks [16 gate | 16 up];  out/dy: (M, F)
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ gu, const T* __restrict__ dy, T* __restrict__ out, int64_t M, int F_) {
@@ -599,6 +636,19 @@ extern "C" int sl_attn_dropout_bwd(const void* p, void* p_dropped, float* d_p, i
                        dims, ld, cu_q, n_heads, n_kv_heads, r, scale, thr24, (uint64_t)seed);
   });
   SL_CHECK_LAUNCH("attn_dropout_bwd");
+  return 0;
+}
+
+extern "C" int sl_transpose_pad(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t ld_out, int32_t dtype,
+                                sl_stream stream) {
+  SL_CHECK_ARG(x && y && rows > 0 && cols > 0 && ld_out >= rows && ldy >= ld_out && ldx >= cols, "sl_transpose_pad: bad shape");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(ldx % vec == 0 && ldy % vec == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "sl_transpose_pad: rows must stay 16-byte aligned");
+  dim3 grid((ld_out + 63) / 64, (cols + 63) / 64);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((transpose_pad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, rows, cols, ld_out);
+  });
+  SL_CHECK_LAUNCH("transpose_pad");
   return 0;
 }
 

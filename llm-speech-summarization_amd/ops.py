@@ -257,6 +257,16 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     return out
 
 
+def transpose_pad(x: torch.Tensor, rows: int, cols: int, ld_out: Optional[int] = None) -> torch.Tensor:
+    """(cols, ld_out) = x[:rows, :cols]^T, zero-filled beyond `rows` (sl_transpose_pad)."""
+    ld_out = rows if ld_out is None else ld_out
+    vec = 4 if x.dtype == torch.float32 else 8
+    ldy = (ld_out + vec - 1) // vec * vec
+    y = torch.empty((cols, ldy), device=x.device, dtype=x.dtype)
+    L.check(L.lib().sl_transpose_pad(L.ptr(x), x.stride(0), L.ptr(y), ldy, rows, cols, ld_out, L.dtype_code(x.dtype), L.stream_ptr()), "sl_transpose_pad")
+    return y if ldy == ld_out else y[:, :ld_out]
+
+
 def dgrad(dY: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None, wt: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dX (M, K_in) = dY (M, N_out) . W (N_out, K_in).  wt: W stored transposed (K_in, N_out), contiguous — then the
     product is a plain K-contiguous GEMM and runs the LDS-DMA tiled kernels instead of the transposed-operand loader."""
@@ -279,10 +289,8 @@ def wgrad_acc(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, ldx: Optio
         # plain Linear: contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to a whole number of K slabs) so
         # the product runs the LDS-DMA tiled kernels; the doubly-transposed register loader measured ~100 TF/s on these shapes
         Mp = (M + 63) // 64 * 64
-        dYT = torch.zeros((Nout, Mp), device=dY.device, dtype=dY.dtype)
-        dYT[:, :M] = dY[:M].t()
-        XT = torch.zeros((Kin, Mp), device=X.device, dtype=X.dtype)
-        XT[:, :M] = X[:M, :Kin].t()
+        dYT = transpose_pad(dY, M, Nout, Mp)
+        XT = transpose_pad(X, M, Kin, Mp)
         return gemm_ex(dYT, XT, M=Nout, N=Kin, K=Mp, lda=Mp, ldw=Mp, out=dW, ldc=dW.stride(0), residual=dW, ldr=dW.stride(0), out_f32=True,
                        residual_f32=True, dtype=dY.dtype)
     return gemm_ex(dY, X, M=Nout, N=Kin, K=M, lda=dY.stride(0), ldw=(X.stride(0) if ldx is None else ldx), out=dW, ldc=dW.stride(0),

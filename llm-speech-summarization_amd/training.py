@@ -543,7 +543,7 @@ class EncoderTape:
             Cin, Cout, kk, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
             d_c = ops.layernorm_bwd(pres[i], t[f"conv{i}_g"], t[f"conv{i}_beta"], d_act, 1e-5, g[f"conv{i}_g"], g[f"conv{i}_beta"], gelu=True)
             ops.colsum_acc(d_c, g[f"conv{i}_b"])
-            dcol = ops.dgrad(d_c, t[f"conv{i}_w"], wt=t[f"conv{i}_w"].t().contiguous())
+            dcol = ops.dgrad(d_c, t[f"conv{i}_w"], wt=ops.transpose_pad(t[f"conv{i}_w"], t[f"conv{i}_w"].shape[0], t[f"conv{i}_w"].shape[1]))
             d_prev = torch.empty((offs[i - 1][B], Cin), device=d_c.device, dtype=dt)
             # weight gradient: every utterance's windows in ONE grouped launch (per-group reduction length = its frame count),
             # fp32 partials per utterance summed afterwards — per-utterance launches had 48 tiles each and ran 0.6 ms apiece
@@ -593,23 +593,23 @@ class EncoderTape:
                 continue
             d_o2 = ops.dropout(dx, p_h, _site_seed(base, "ffn_out", li)) if p_h > 0 else dx
             ops.wgrad_acc(d_o2, c["mid"], g[p + "w2"]); ops.colsum_acc(d_o2, g[p + "b2"])
-            d_mid = ops.dgrad(d_o2, lt["w2"], wt=lt["w2"].t().contiguous())   # weights move every optimizer step: transposed on the fly
+            d_mid = ops.dgrad(d_o2, lt["w2"], wt=ops.transpose_pad(lt["w2"], lt["w2"].shape[0], lt["w2"].shape[1]))   # weights move every optimizer step: transposed on the fly
             if p_act > 0:
                 ops.dropout(d_mid, p_act, _site_seed(base, "act", li), out=d_mid)
             d_pre1 = ops.gelu_bwd(d_mid, c["pre1"])
             ops.wgrad_acc(d_pre1, c["ln2"], g[p + "w1"]); ops.colsum_acc(d_pre1, g[p + "b1"])
-            d_ln2 = ops.dgrad(d_pre1, lt["w1"], wt=lt["w1"].t().contiguous())
+            d_ln2 = ops.dgrad(d_pre1, lt["w1"], wt=ops.transpose_pad(lt["w1"], lt["w1"].shape[0], lt["w1"].shape[1]))
             dx_mid = ops.layernorm_bwd(c["x_mid"], lt["ln2_g"], lt["ln2_b"], d_ln2, eps, g[p + "ln2_g"], g[p + "ln2_b"])
             ops.axpby(dx, dx_mid)
             d_o1 = ops.dropout(dx_mid, p_h, _site_seed(base, "attn_out", li)) if p_h > 0 else dx_mid
             ops.wgrad_acc(d_o1, c["att"], g[p + "wo"]); ops.colsum_acc(d_o1, g[p + "bo"])
-            d_att = ops.dgrad(d_o1, lt["wo"], wt=lt["wo"].t().contiguous())
+            d_att = ops.dgrad(d_o1, lt["wo"], wt=ops.transpose_pad(lt["wo"], lt["wo"].shape[0], lt["wo"].shape[1]))
             d_qkv = torch.empty_like(c["qkv"])
             p_att = reg.attention_dropout if reg is not None else 0.0
             attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att,
                                       dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
             ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
-            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=lt["wqkv"].t().contiguous())
+            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=ops.transpose_pad(lt["wqkv"], lt["wqkv"].shape[0], lt["wqkv"].shape[1]))
             dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, eps, g[p + "ln1_g"], g[p + "ln1_b"])
             ops.axpby(dx_mid, dxin)
             dx = dxin
@@ -746,7 +746,7 @@ class WhisperEncoderTape(EncoderTape):
         ops.gemm_ex(d_pre2, b1, M=H, N=3 * H, K=T1, lda=H, ldw=2 * H, out=part, ldc=3 * H, out_f32=True, trans_a=True, trans_w=True, batch=B,
                     strideA=T1 * H, strideW=(F_ + 2) * H, strideC=H * 3 * H, dtype=dt)
         g["conv2_w"] += part.sum(0)
-        dcol = ops.dgrad(d_pre2, t["conv2_w"], wt=t["conv2_w"].t().contiguous())                        # (B*T1, 3H): windows of the haloed rows
+        dcol = ops.dgrad(d_pre2, t["conv2_w"], wt=ops.transpose_pad(t["conv2_w"], t["conv2_w"].shape[0], t["conv2_w"].shape[1]))                        # (B*T1, 3H): windows of the haloed rows
         d_b1 = torch.empty((B, F_, H), device=dx.device, dtype=dt)
         for u in range(B):
             d_b1[u] = ops.col2im(dcol[u * T1:(u + 1) * T1], F_ + 2, H, 3, 2)[1:F_ + 1]

@@ -245,3 +245,14 @@ def test_dropout_kernel_matches_host_mask(dt):
     ops.dropout(z, p, seed, out=z)
     assert torch.equal(z, y)
     assert not torch.equal(ops.dropout(x, p, seed + (1 << 40)) == 0, y == 0)   # the high word of the seed matters
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows,cols,ld_out", [(100, 72, 128), (257, 64, 257), (64, 200, 64), (7984, 1024, 8000)])
+def test_transpose_pad(dt, rows, cols, ld_out):
+    vec = 4 if dt == torch.float32 else 8
+    x = torch.randn(rows + 3, cols + vec, generator=torch.Generator().manual_seed(rows)).to(DEV, dt)     # a view with a wider row stride
+    y = ops.transpose_pad(x[:, :cols], rows, cols, ld_out)
+    assert y.shape == (cols, ld_out)
+    assert torch.equal(y[:, :rows], x[:rows, :cols].t())
+    assert not bool(y[:, rows:].any())
