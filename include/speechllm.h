@@ -300,6 +300,14 @@ int sl_hubert_conv0_bwd(const float* wave, int64_t n_samples, const float* w, co
                         const float* beta, const void* dy, int32_t C, int32_t k, int32_t stride, float eps, float* dw,
                         float* dbias, float* dgamma, float* dbeta, int32_t dtype, sl_stream stream);
 
+/* sl_hubert_conv0_bwd for a whole ragged batch in one launch: utterance u has samples [sample_offsets[u], sample_offsets[u+1])
+ * of `waves`, rows [row_offsets[u], row_offsets[u+1]) of dy, and strips strip_prefix[u] .. strip_prefix[u+1]-1 of 24 time
+ * steps (all three arrays on the device, n_utt + 1 entries).  A fixed grid walks the strips and flushes its sums once. */
+int sl_hubert_conv0_bwd_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev,
+                              const int64_t* strip_prefix_dev, int32_t n_utt, int64_t total_strips, const float* w, const float* bias,
+                              const float* gamma, const float* beta, const void* dy, int32_t C, int32_t k, int32_t stride, float eps,
+                              float* dw, float* dbias, float* dgamma, float* dbeta, int32_t dtype, sl_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole-model entry points (C++ host runtime inside the library: layer loops, workspace carving,
  * hipGraph capture of the decode step).  Weight tables are plain structs of device pointers.

@@ -499,27 +499,42 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol,
 
 // conv0 backward: recompute conv + LN per time step, push dy through GELU and LN, accumulate fp32 grads
 // of (w, bias, gamma, beta).  Same wave-strip geometry as the forward kernel.
-template <typename T, int CPL, int K, int STRIDE>
-__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wave, int64_t n_samples, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const T* __restrict__ dy, int64_t L, float eps, float* __restrict__ dw, float* __restrict__ dbias,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  constexpr int C = 64 * CPL;
-  constexpr int TS = (128 - (K - STRIDE)) / STRIDE;
-  const int lane = threadIdx.x & 63;
-  const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t t0 = strip * TS;
-  if (t0 >= L) return;
+// per-wave state of the conv0 backward: taps / LN parameters of the lane's CPL channels and their fp32 gradient sums
+template <int CPL, int K>
+struct Conv0Acc {
   float wr[CPL][K], br[CPL], gr[CPL], ber[CPL];
   float aw[CPL][K], abias[CPL], ag[CPL], ab[CPL];
+  __device__ __forceinline__ void load(const float* w, const float* bias, const float* gamma, const float* beta, int lane) {
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int ch = lane * CPL + c;
+    for (int c = 0; c < CPL; ++c) {
+      const int ch = lane * CPL + c;
 #pragma unroll
-    for (int j = 0; j < K; ++j) { wr[c][j] = w[ch * K + j]; aw[c][j] = 0.f; }
-    br[c] = bias[ch]; gr[c] = gamma[ch]; ber[c] = beta[ch];
-    abias[c] = 0.f; ag[c] = 0.f; ab[c] = 0.f;
+      for (int j = 0; j < K; ++j) { wr[c][j] = w[ch * K + j]; aw[c][j] = 0.f; }
+      br[c] = bias[ch]; gr[c] = gamma[ch]; ber[c] = beta[ch];
+      abias[c] = 0.f; ag[c] = 0.f; ab[c] = 0.f;
+    }
   }
+  __device__ __forceinline__ void flush(float* dw, float* dbias, float* dgamma, float* dbeta, int lane) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ch = lane * CPL + c;
+#pragma unroll
+      for (int j = 0; j < K; ++j) atomicAdd(dw + ch * K + j, aw[c][j]);
+      atomicAdd(dbias + ch, abias[c]);
+      atomicAdd(dgamma + ch, ag[c]);
+      atomicAdd(dbeta + ch, ab[c]);
+    }
+  }
+};
+
+// one strip of TS time steps of one utterance: recompute conv + LN, push dy through GELU and LN, add into the wave's sums
+template <typename T, int CPL, int K, int STRIDE>
+__device__ __forceinline__ void conv0_bwd_strip(Conv0Acc<CPL, K>& A, const float* __restrict__ wave, int64_t n_samples, const T* __restrict__ dy,
+                                                int64_t L, float eps, int64_t strip, int lane) {
+  constexpr int C = 64 * CPL;
+  constexpr int TS = (128 - (K - STRIDE)) / STRIDE;
+  const int64_t t0 = strip * TS;
+  if (t0 >= L) return;
   const int64_t s0 = t0 * STRIDE;
   const int64_t i0 = s0 + lane, i1 = s0 + 64 + lane;
   const int b0 = __builtin_bit_cast(int, i0 < n_samples ? wave[i0] : 0.f), b1 = __builtin_bit_cast(int, i1 < n_samples ? wave[i1] : 0.f);
@@ -535,9 +550,9 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
     float y[CPL], s = 0.f;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      float a = br[c];
+      float a = A.br[c];
 #pragma unroll
-      for (int j = 0; j < K; ++j) a = fmaf(wr[c][j], xs[j], a);
+      for (int j = 0; j < K; ++j) a = fmaf(A.wr[c][j], xs[j], a);
       y[c] = a; s += a;
     }
     const float mean = wave_sum(s) / (float)C;
@@ -550,10 +565,10 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       xh[c] = (y[c] - mean) * rstd;
-      const float d = to_f32(drow[c]) * gelu_grad(xh[c] * gr[c] + ber[c]);
-      ag[c] += d * xh[c];
-      ab[c] += d;
-      dg[c] = d * gr[c];
+      const float d = to_f32(drow[c]) * gelu_grad(xh[c] * A.gr[c] + A.ber[c]);
+      A.ag[c] += d * xh[c];
+      A.ab[c] += d;
+      dg[c] = d * A.gr[c];
       r1 += dg[c];
       r2 += dg[c] * xh[c];
     }
@@ -562,20 +577,54 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const float dc = rstd * (dg[c] - r1 - xh[c] * r2);
-      abias[c] += dc;
+      A.abias[c] += dc;
 #pragma unroll
-      for (int j = 0; j < K; ++j) aw[c][j] = fmaf(dc, xs[j], aw[c][j]);
+      for (int j = 0; j < K; ++j) A.aw[c][j] = fmaf(dc, xs[j], A.aw[c][j]);
     }
   }
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int ch = lane * CPL + c;
-#pragma unroll
-    for (int j = 0; j < K; ++j) atomicAdd(dw + ch * K + j, aw[c][j]);
-    atomicAdd(dbias + ch, abias[c]);
-    atomicAdd(dgamma + ch, ag[c]);
-    atomicAdd(dbeta + ch, ab[c]);
+}
+
+template <typename T, int CPL, int K, int STRIDE>
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wave, int64_t n_samples, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const T* __restrict__ dy, int64_t L, float eps, float* __restrict__ dw, float* __restrict__ dbias,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  constexpr int TS = (128 - (K - STRIDE)) / STRIDE;
+  const int lane = threadIdx.x & 63;
+  const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (strip * TS >= L) return;
+  Conv0Acc<CPL, K> A;
+  A.load(w, bias, gamma, beta, lane);
+  conv0_bwd_strip<T, CPL, K, STRIDE>(A, wave, n_samples, dy, L, eps, strip, lane);
+  A.flush(dw, dbias, dgamma, dbeta, lane);
+}
+
+// The whole ragged batch with a fixed number of waves: a wave walks (utterance, strip) pairs spref[u] + strip with a
+// stride of the grid and flushes its sums ONCE.  One launch per utterance had every wave end in 104 atomic instructions
+// on the same 6.6 k addresses after only 24 time steps (0.9 ms per 10 s clip, almost all of it atomic traffic).
+template <typename T, int CPL, int K, int STRIDE>
+__global__ __launch_bounds__(256) void conv0_bwd_batch_kernel(const float* __restrict__ waves, const int64_t* __restrict__ soff,
+                                                              const int64_t* __restrict__ row0, const int64_t* __restrict__ spref, int n_utt,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ dy,
+                                                              float eps, float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  const int64_t total = spref[n_utt];
+  if (wave_id >= total) return;
+  Conv0Acc<CPL, K> A;
+  A.load(w, bias, gamma, beta, lane);
+  for (int64_t gs = wave_id; gs < total; gs += n_waves) {
+    int lo = 0, hi = n_utt - 1;                      // utterance u with spref[u] <= gs < spref[u + 1]
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (spref[mid] <= gs) lo = mid; else hi = mid - 1;
+    }
+    const int64_t s0 = soff[lo], r0 = row0[lo];
+    conv0_bwd_strip<T, CPL, K, STRIDE>(A, waves + s0, soff[lo + 1] - s0, dy + r0 * (64 * CPL), row0[lo + 1] - r0, eps, gs - spref[lo], lane);
   }
+  A.flush(dw, dbias, dgamma, dbeta, lane);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -839,6 +888,36 @@ static int launch_conv0_bwd(const float* wave, int64_t n, const float* w, const 
                      db, dg, dbe);
   SL_CHECK_LAUNCH("conv0_bwd");
   return 0;
+}
+
+template <typename T, int CPL>
+static int launch_conv0_bwd_batch(const float* waves, const int64_t* soff, const int64_t* row0, const int64_t* spref, int n_utt, int64_t total_strips,
+                                  const float* w, const float* b, const float* g, const float* be, const void* dy, float eps, float* dw, float* db,
+                                  float* dg, float* dbe, hipStream_t st) {
+  const int64_t blocks = ceil_div64(total_strips, 4);
+  hipLaunchKernelGGL((conv0_bwd_batch_kernel<T, CPL, 10, 5>), dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, st, waves, soff, row0, spref, n_utt,
+                     w, b, g, be, (const T*)dy, eps, dw, db, dg, dbe);
+  SL_CHECK_LAUNCH("conv0_bwd_batch");
+  return 0;
+}
+
+extern "C" int sl_hubert_conv0_bwd_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev,
+                                         const int64_t* strip_prefix_dev, int32_t n_utt, int64_t total_strips, const float* w, const float* bias,
+                                         const float* gamma, const float* beta, const void* dy, int32_t C, int32_t k, int32_t stride, float eps,
+                                         float* dw, float* dbias, float* dgamma, float* dbeta, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(waves && sample_offsets_dev && row_offsets_dev && strip_prefix_dev && w && bias && gamma && beta && dy && dw && dbias && dgamma && dbeta &&
+                   n_utt > 0 && total_strips > 0, "sl_hubert_conv0_bwd_batch: bad arguments");
+  SL_CHECK_ARG(k == 10 && stride == 5, "sl_hubert_conv0_bwd_batch: only k=10, stride=5 is built");
+  hipStream_t st = (hipStream_t)stream;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    switch (C) {
+      case 64: return launch_conv0_bwd_batch<T, 1>(waves, sample_offsets_dev, row_offsets_dev, strip_prefix_dev, n_utt, total_strips, w, bias, gamma, beta, dy, eps, dw, dbias, dgamma, dbeta, st);
+      case 128: return launch_conv0_bwd_batch<T, 2>(waves, sample_offsets_dev, row_offsets_dev, strip_prefix_dev, n_utt, total_strips, w, bias, gamma, beta, dy, eps, dw, dbias, dgamma, dbeta, st);
+      case 256: return launch_conv0_bwd_batch<T, 4>(waves, sample_offsets_dev, row_offsets_dev, strip_prefix_dev, n_utt, total_strips, w, bias, gamma, beta, dy, eps, dw, dbias, dgamma, dbeta, st);
+      case 512: return launch_conv0_bwd_batch<T, 8>(waves, sample_offsets_dev, row_offsets_dev, strip_prefix_dev, n_utt, total_strips, w, bias, gamma, beta, dy, eps, dw, dbias, dgamma, dbeta, st);
+      default: sl_set_error("sl_hubert_conv0_bwd_batch: C=%d must be 64, 128, 256 or 512", C); return SL_ERR_ARG;
+    }
+  });
 }
 
 extern "C" int sl_hubert_conv0_bwd(const float* wave, int64_t n_samples, const float* w, const float* bias, const float* gamma, const float* beta,

@@ -433,6 +433,21 @@ def col2im(dcol, Lin, Cc, k, s):
     return dx
 
 
+def hubert_conv0_bwd_batch(waves: Sequence[torch.Tensor], w, bias, gamma, beta, dy, row_offsets: Sequence[int], dw, dbias, dgamma, dbeta, k=10, stride=5,
+                           eps=1e-5):
+    """conv0 + LayerNorm + GELU backward of every utterance of a packed batch in ONE launch (dy rows row_offsets[u]..)."""
+    dev = dy.device
+    flat = torch.cat([wv.reshape(-1) for wv in waves]).contiguous()
+    soff, spref = [0], [0]
+    for u, wv in enumerate(waves):
+        soff.append(soff[-1] + wv.numel())
+        spref.append(spref[-1] + (row_offsets[u + 1] - row_offsets[u] + 23) // 24)        # strips of 24 time steps (k=10, s=5)
+    desc = torch.tensor([soff, list(row_offsets), spref], dtype=torch.int64, device=dev)
+    L.check(L.lib().sl_hubert_conv0_bwd_batch(L.ptr(flat), desc[0].data_ptr(), desc[1].data_ptr(), desc[2].data_ptr(), len(waves), spref[-1], L.ptr(w),
+                                              L.ptr(bias), L.ptr(gamma), L.ptr(beta), L.ptr(dy), w.shape[0], k, stride, eps, L.ptr(dw), L.ptr(dbias),
+                                              L.ptr(dgamma), L.ptr(dbeta), L.dtype_code(dy.dtype), L.stream_ptr()), "sl_hubert_conv0_bwd_batch")
+
+
 def hubert_conv0_bwd(wave, w, bias, gamma, beta, dy, dw, dbias, dgamma, dbeta, k=10, stride=5, eps=1e-5):
     L.check(L.lib().sl_hubert_conv0_bwd(L.ptr(wave), wave.numel(), L.ptr(w), L.ptr(bias), L.ptr(gamma), L.ptr(beta), L.ptr(dy), w.shape[0], k,
                                         stride, eps, L.ptr(dw), L.ptr(dbias), L.ptr(dgamma), L.ptr(dbeta), L.dtype_code(dy.dtype),

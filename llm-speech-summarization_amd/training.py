@@ -559,9 +559,8 @@ class EncoderTape:
                 d_prev[i0:i1] = ops.col2im(dcol[o0:o1], i1 - i0, Cin, kk, s)
             d_act = d_prev
             done([f"conv{i}_w", f"conv{i}_b", f"conv{i}_g", f"conv{i}_beta"])
-        for u in range(B):
-            ops.hubert_conv0_bwd(tape["waves"][u], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], d_act[offs[0][u]:offs[0][u + 1]],
-                                 g["conv0_w"], g["conv0_b"], g["conv0_g"], g["conv0_beta"], k=a.conv_kernel[0], stride=a.conv_stride[0])
+        ops.hubert_conv0_bwd_batch(tape["waves"], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], d_act, offs[0], g["conv0_w"], g["conv0_b"],
+                                   g["conv0_g"], g["conv0_beta"], k=a.conv_kernel[0], stride=a.conv_stride[0])
         done(["conv0_w", "conv0_b", "conv0_g", "conv0_beta"])
 
 
