@@ -126,7 +126,9 @@ typedef struct {
   const int64_t* groups;
   /* groups_ext != 0: records are 8 int64 wide, {M, a_off, c_off, r_off, w_off, N, K, 0}: every group also has its own
    * weight offset, column count and reduction length (args->N / args->K are then the LARGEST ones).  One launch covers
-   * e.g. one product of the attention backward over every (sequence, head) of a ragged batch. */
+   * e.g. one product of the attention backward over every (sequence, head) of a ragged batch.
+   * groups_ext == 2: as 1, and the caller vouches that every group's K is a multiple of 64 bf16 / 32 f32 elements
+   * (whole 128-byte slabs), which admits the LDS-DMA tiled kernel. */
   int32_t groups_ext, reserved;
 } sl_gemm_ex_args;
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);

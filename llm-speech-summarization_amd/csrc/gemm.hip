@@ -836,7 +836,7 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   constexpr int BK = TROWB / (int)sizeof(T);
   if (!p.ta && !p.tw && p.K % BK == 0 && !p.grp_ext && g_disable_glds == 2)
     hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, false>), grid, dim3(256), 0, st, p);
-  else if (!p.ta && !p.tw && p.K % BK == 0 && !p.grp_ext && !g_disable_glds)   // per-group K: only the register path handles K tails
+  else if (!p.ta && !p.tw && p.K % BK == 0 && (!p.grp_ext || p.grp_kslab) && !g_disable_glds)   // per-group K: only the register path handles K tails (groups_ext = 2: the caller vouches for whole slabs)
     hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, true>), grid, dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_tiled_kernel<T, ACT>), grid, dim3(256), 0, st, p);
@@ -948,7 +948,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.res = a->residual; p.ldr = a->ldr; p.sR = a->strideR;
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
-  p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0;
+  p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
   static const int direct_epi = getenv("SL_DIRECT_EPILOGUE") ? atoi(getenv("SL_DIRECT_EPILOGUE")) : 0;
   p.direct_epi = direct_epi;
   static const int gm_env = getenv("SL_GEMM_GM") ? atoi(getenv("SL_GEMM_GM")) : 8;
@@ -957,6 +957,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;
     p.grp = ex->groups; p.w_mod = ex->w_mod > 0 ? ex->w_mod : 1;
     p.grp_ext = ex->groups && ex->groups_ext;
+    p.grp_kslab = ex->groups && ex->groups_ext == 2;
     SL_CHECK_ARG(!(p.ta || p.tw || p.aux) || a->act != SL_ACT_SILU_MUL, "sl_gemm_ex: transposed operands / aux_out are not combined with SILU_MUL");
     SL_CHECK_ARG(!p.res_f32 || a->out_f32, "sl_gemm_ex: residual_f32 needs out_f32");
     SL_CHECK_ARG(!(p.ta || p.tw) || a->w_layout == SL_W_ROWMAJOR, "sl_gemm_ex: transposed operands need row-major storage");

@@ -17,6 +17,7 @@ struct GemmP {
   int w_mod;
   int64_t cx, rx, wx;  // per-block extra offsets resolved from grp
   int grp_ext;         // records are {M, a_off, c_off, r_off, w_off, N, K, 0}
+  int grp_kslab;       // groups_ext == 2: every group's K is a whole number of 128-byte slabs (LDS-DMA kernel allowed)
   int gm;              // 256-tile kernel: tile rows per XCD patch (SL_GEMM_GM, default 8)
   int direct_epi;      // tiled kernels: skip the LDS-staged row epilogue (SL_DIRECT_EPILOGUE=1, for A/B measurements)
 };

@@ -220,11 +220,12 @@ def attention_backward_packed(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: tor
     for si, S in enumerate(seqlens):
         kpad[si, :S] = qkv[offs[si]:offs[si] + S, koff:voff]
     for r in range(rep):
+        kslab = 2 if D % (64 if dt != torch.float32 else 32) == 0 else True     # K = head_dim for these two: whole slabs -> LDS-DMA kernel
         ops.gemm_ex(qkv, qkv, M=smax, N=smax, K=D, lda=qkv_w, ldw=qkv_w, out=Sb, ldc=ld, out_f32=True, batch=nmat, dtype=dt,
-                    groups=pl["s"][r], groups_ext=True)
+                    groups=pl["s"][r], groups_ext=kslab)
         ops.softmax_rows_var(Sb, P, nmat, smax, pl["dims"], ld, scale, causal, dt)
         ops.gemm_ex(d_att, qkv, M=smax, N=smax, K=D, lda=ldo, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nmat, dtype=dt,
-                    groups=pl["dp"][r], groups_ext=True)
+                    groups=pl["dp"][r], groups_ext=kslab)
         if drop:   # d probabilities = mask / (1-p) * d(dropped probabilities); dV below sees the dropped probabilities
             ops.attn_dropout_bwd(P, Pd, dPb, nmat, smax, pl["dims"], ld, cu, nh, nkv, r, dropout_p, dropout_seed)
         ops.softmax_bwd_var(P, dPb, dS, nmat, smax, pl["dims"], ld, scale)
