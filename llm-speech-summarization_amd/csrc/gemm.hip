@@ -299,14 +299,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) *(T*)(tile + lds_off(col0 + j, k / VEC) + (k % VEC) * (int)sizeof(T)) = e[j];
   };
+  // bf16: a transposed operand keeps its [reduction row][128 outputs] shape in LDS (256-byte rows, the guide's image (b):
+  // chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) — one 16-byte store per chunk instead of eight 2-byte scatters — and
+  // the MFMA fragments are gathered column-wise by ds_read_b64_tr_b16 (conflict-free: a 32-lane half reads two 4-row
+  // blocks 8 rows apart).  The 2-byte scatter remains for fp32 (no 32-bit transposed read).
+  constexpr bool TRT = sizeof(T) == 2;
+  auto t_off = [](int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); };
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (p.ta) scatter(&smem[buf][0][0], ra[i], tcol[i], tk[i]);
-      else *(uint4*)(&smem[buf][0][so[i]]) = ra[i];
-      if (p.tw) scatter(&smem[buf][1][0], rw[i], tcol[i], tk[i]);
-      else *(uint4*)(&smem[buf][1][so[i]]) = rw[i];
+      if (p.ta) {
+        if constexpr (TRT) *(uint4*)(&smem[buf][0][t_off(tk[i], tcol[i] / VEC)]) = ra[i];
+        else scatter(&smem[buf][0][0], ra[i], tcol[i], tk[i]);
+      } else *(uint4*)(&smem[buf][0][so[i]]) = ra[i];
+      if (p.tw) {
+        if constexpr (TRT) *(uint4*)(&smem[buf][1][t_off(tk[i], tcol[i] / VEC)]) = rw[i];
+        else scatter(&smem[buf][1][0], rw[i], tcol[i], tk[i]);
+      } else *(uint4*)(&smem[buf][1][so[i]]) = rw[i];
     }
+  };
+  // fragment of 16 outputs x 32 reduction steps out of a transposed-image tile: rows s*32 + 8q .. +7, columns col0 + r
+  const int qq = r >> 2, pp = r & 3;
+  auto tr_frag = [&](const unsigned char* tile, int s_, int col0) -> uint4 {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_g_t;
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_ptr_t)tile;
+    const int r0 = s_ * 32 + 8 * q + qq, ch0 = col0 / 8;
+    u32x2_g_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(base + (uint32_t)(t_off(r0, ch0 + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(base + (uint32_t)(t_off(r0 + 4, ch0 + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
 
   gload(0);
@@ -321,10 +343,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint4 fa[4], fb[4];
+      if (TRT && p.ta) {
+        if constexpr (TRT) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(sa + lds_off(wm * 64 + m * 16 + r, s * 4 + q));
+          for (int m = 0; m < 4; ++m) fa[m] = tr_frag(sa, s, wm * 64 + m * 16);
+        }
+      } else {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) fb[n] = *(const uint4*)(sw + lds_off(wn * 64 + n * 16 + r, s * 4 + q));
+        for (int m = 0; m < 4; ++m) fa[m] = *(const uint4*)(sa + lds_off(wm * 64 + m * 16 + r, s * 4 + q));
+      }
+      if (TRT && p.tw) {
+        if constexpr (TRT) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) fb[n] = tr_frag(sw, s, wn * 64 + n * 16);
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[n] = *(const uint4*)(sw + lds_off(wn * 64 + n * 16 + r, s * 4 + q));
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
