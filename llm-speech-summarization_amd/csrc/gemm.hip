@@ -320,15 +320,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
   };
   // fragment of 16 outputs x 32 reduction steps out of a transposed-image tile: rows s*32 + 8q .. +7, columns col0 + r
   const int qq = r >> 2, pp = r & 3;
-  auto tr_frag = [&](const unsigned char* tile, int s_, int col0) -> uint4 {
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_g_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_g_t;
+  // the four 16-output fragments of a wave's 64 outputs: all eight reads in flight, one wait
+  auto tr_frags = [&](const unsigned char* tile, int s_, int col0, uint4 (&f)[4]) {
     const uint32_t base = (uint32_t)(uintptr_t)(lds_ptr_t)tile;
-    const int r0 = s_ * 32 + 8 * q + qq, ch0 = col0 / 8;
-    u32x2_g_t lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(base + (uint32_t)(t_off(r0, ch0 + (pp >> 1)) + 8 * (pp & 1))) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(base + (uint32_t)(t_off(r0 + 4, ch0 + (pp >> 1)) + 8 * (pp & 1))) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
-    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    const int r0 = s_ * 32 + 8 * q + qq;
+    u32x2_g_t lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch0 = (col0 + 16 * j) / 8;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[j]) : "v"(base + (uint32_t)(t_off(r0, ch0 + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[j]) : "v"(base + (uint32_t)(t_off(r0 + 4, ch0 + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = make_uint4(lo[j].x, lo[j].y, hi[j].x, hi[j].y);
   };
 
   gload(0);
@@ -345,8 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
       uint4 fa[4], fb[4];
       if (TRT && p.ta) {
         if constexpr (TRT) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) fa[m] = tr_frag(sa, s, wm * 64 + m * 16);
+          tr_frags(sa, s, wm * 64, fa);
         }
       } else {
 #pragma unroll
@@ -354,8 +359,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
       }
       if (TRT && p.tw) {
         if constexpr (TRT) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n) fb[n] = tr_frag(sw, s, wn * 64 + n * 16);
+          tr_frags(sw, s, wn * 64, fb);
         }
       } else {
 #pragma unroll
