@@ -196,7 +196,6 @@ extern "C" int sl_hubert_forward(const sl_hubert_model* m, const float* waves, c
                "sl_hubert_forward: need 2..8 conv layers and head_dim 64 (hidden=%d heads=%d)", m->hidden, m->n_heads);
   hipStream_t st = (hipStream_t)stream;
   const int dt = m->dtype;
-  const size_t sz = sl_dtype_size(dt);
   const int H = m->hidden;
   HubertPlan pl;
   SL_TRY(hubert_plan(m, sample_offsets_host, n_utt, pl));
@@ -680,7 +679,7 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
       rc = sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
                                  out_ids, max_new_tokens, cap);
     hipError_t ce = hipStreamEndCapture(cap, &graph);
-    if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ce != hipSuccess) { sl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce)); return SL_ERR_LAUNCH; }
     SL_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     if (check_every <= 0) check_every = 16;
@@ -697,8 +696,8 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
     }
     SL_HIP(hipEventRecord(ev[2], st));
     SL_HIP(hipStreamSynchronize(st));
-    hipGraphExecDestroy(exec);
-    hipGraphDestroy(graph);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
   } else {
     SL_HIP(hipEventRecord(ev[2], st));
     SL_HIP(hipStreamSynchronize(st));
@@ -720,6 +719,6 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
     SL_HIP(hipEventElapsedTime(&timings_ms_host[0], ev[0], ev[1]));
     SL_HIP(hipEventElapsedTime(&timings_ms_host[1], ev[1], ev[2]));
   }
-  for (auto& e : ev) hipEventDestroy(e);
+  for (auto& e : ev) (void)hipEventDestroy(e);
   return 0;
 }
