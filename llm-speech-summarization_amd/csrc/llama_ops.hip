@@ -566,6 +566,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
 // partial records, no merge launch.  PREFETCH = false (used): a chunk's K rows are requested at its start and its V rows as
 // soon as the K registers are free (138 VGPRs, 3 blocks per CU, other blocks cover the latency): 97 us per layer at B = 512;
 // PREFETCH = true holds the next chunk's K and V rows in a second register set (239 VGPRs, 2 blocks per CU): 104 us.
+// Four blocks per CU (query fragments and a shared zero row in LDS: 128 VGPRs + 16 B of scratch, 36 KiB) would make 4096 blocks exactly
+// four rounds instead of 5.33 on 768 slots, but measured 117 us: the extra LDS reads per MFMA and the fourth block's traffic cost more
+// than the idle third of the last round.
 template <int REP, bool PREFETCH>
 __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __restrict__ q, int64_t q_stride, const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
