@@ -125,8 +125,10 @@ class AudioEncoder:
         return self
 
     def train(self, mode: bool = True):
-        if mode:
-            raise L.SpeechLLMError("training mode (dropout/layerdrop/spec-augment + backward) is not built in this round")
+        """nn.Module surface (ref:trainer.py:258 calls audio_encoder.train()).  The flag is recorded; the differentiable,
+        regularised forward of the optimisation step lives in the training tape (training.EncoderTape / WhisperEncoderTape,
+        driven by KDTrainer / Trainer), `forward()` itself stays the inference path and refuses to run while the flag is set."""
+        self.training = bool(mode)
         return self
 
     def to(self, device):
@@ -206,6 +208,9 @@ class AudioEncoder:
         if self.weights is None:
             raise L.SpeechLLMError("AudioEncoder weights are not on the GPU: call load_state_dict(...).to('cuda') — "
                                    "the encoder runs on the HIP path only")
+        if getattr(self, "training", False):
+            raise L.SpeechLLMError("AudioEncoder.forward is the inference path; in train() mode run the step through training.KDTrainer "
+                                   "(or Trainer), whose tape applies the dropouts / LayerDrop / SpecAugment and the backward — or call eval()")
         if self.encoder_base == "whisper":
             return self._forward_whisper(input)
         if torch.is_tensor(input):
