@@ -295,8 +295,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist  # RCCL: only the timing barrier / max-reduce, never on the data path
+        # dry-run switches for boxes with fewer GPUs than ranks (the N > 1 control flow on one device): SL_BENCH_SHARE_GPU=1
+        # puts every rank on cuda:0, SL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks per device)
+        if os.environ.get("SL_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
+        backend = os.environ.get("SL_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
