@@ -88,33 +88,90 @@ template <typename T>
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int cols,
                                                             int ld_out) {
   constexpr int VEC = Vec16<T>::VEC, TS = 64;
-  __shared__ T tile[TS][TS + 2];
   const int r0 = blockIdx.x * TS, c0 = blockIdx.y * TS;
   const int tid = threadIdx.x;
   constexpr int CPR = TS / VEC;                       // 16-byte chunks per 64-element row
-  for (int i = tid; i < TS * CPR; i += 256) {
-    const int r = i / CPR, ch = i % CPR;
-    T e[VEC];
-    if (r0 + r < rows && c0 + ch * VEC + VEC <= cols) {
-      *(uint4*)e = *(const uint4*)(x + (int64_t)(r0 + r) * ldx + c0 + ch * VEC);
-    } else {
+  if constexpr (sizeof(T) == 2) {
+    // bf16: the tile stays row-major in LDS (128-byte rows, 16-byte stores) and is read back COLUMN-wise by
+    // ds_read_b64_tr_b16: a 16-lane group gathers a 4-row x 16-column block, lane i receives column i — i.e. four
+    // consecutive elements of OUTPUT row c0 + i.  Two reads give a 16-byte output chunk; the four groups of a wave take
+    // the r-chunks 0-7 / 8-15 / 16-23 / 24-31 of the same 16 output rows (64 contiguous bytes per row and instruction).
+    // Swizzle: chunk ^ (f(row) << 1), f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1): the rows a 32-lane half touches in
+    // one read ({R..R+3, R+8..R+11}) land on distinct banks.  (The 2-byte LDS form below ran at 1.5 TB/s.)
+    __shared__ __attribute__((aligned(16))) unsigned char tile[TS * 128];
+    auto off = [](int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)); };
+    for (int i = tid; i < TS * CPR; i += 256) {
+      const int r = i / CPR, ch = i % CPR;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r0 + r < rows) {
+        if (c0 + ch * VEC + VEC <= cols) v = *(const uint4*)(x + (int64_t)(r0 + r) * ldx + c0 + ch * VEC);
+        else {
+          uint32_t w4[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) e[j] = (r0 + r < rows && c0 + ch * VEC + j < cols) ? x[(int64_t)(r0 + r) * ldx + c0 + ch * VEC + j] : from_f32<T>(0.f);
+          for (int j = 0; j < VEC; ++j)
+            if (c0 + ch * VEC + j < cols) w4[j >> 1] |= (uint32_t)((const uint16_t*)x)[(int64_t)(r0 + r) * ldx + c0 + ch * VEC + j] << (16 * (j & 1));
+          v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+      }
+      *(uint4*)(tile + off(r, ch)) = v;
     }
+    __syncthreads();
+    typedef __attribute__((address_space(3))) void* lds_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_tt;
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_t)tile;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+    const int cb = 16 * wave;                          // this wave's 16 output rows (tile columns cb .. cb + 15)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) tile[r][ch * VEC + j] = e[j];
-  }
-  __syncthreads();
-  for (int i = tid; i < TS * CPR; i += 256) {
-    const int c = i / CPR, ch = i % CPR;              // output row c0 + c, elements r0 + ch*VEC ..
-    if (c0 + c >= cols) continue;
-    T e[VEC];
+    for (int half = 0; half < 2; ++half) {
+      const int R = 32 * half + 8 * g;                 // first of the 8 tile rows (= output columns) of this lane's chunk
+      u32x2_tt lo, hi;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(base + (uint32_t)(off(R + qq, 2 * wave + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(base + (uint32_t)(off(R + 4 + qq, 2 * wave + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+      const int oc = c0 + cb + li, o = r0 + R;         // output row, first output column of the chunk
+      if (oc < cols) {
+        const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (o + VEC <= ld_out) *(uint4*)(y + (int64_t)oc * ldy + o) = v;
+        else {   // ragged tail of the output row: element j = half (j & 1) of word j / 2 (no address of a register: that costs scratch)
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) e[j] = tile[ch * VEC + j][c];     // rows past `rows` were loaded as zeros
-    const int o = r0 + ch * VEC;
-    if (o + VEC <= ld_out) *(uint4*)(y + (int64_t)(c0 + c) * ldy + o) = *(const uint4*)e;
-    else
-      for (int j = 0; j < VEC && o + j < ld_out; ++j) y[(int64_t)(c0 + c) * ldy + o + j] = e[j];
+          for (int j = 0; j < VEC; ++j)
+            if (o + j < ld_out) ((uint16_t*)y)[(int64_t)oc * ldy + o + j] = (uint16_t)(w4[j >> 1] >> (16 * (j & 1)));
+        }
+      }
+    }
+  } else {
+    static_assert(sizeof(T) == 4 && VEC == 4, "the generic branch is the fp32 one");
+    __shared__ float tile[TS][TS + 1];
+    for (int i = tid; i < TS * CPR; i += 256) {
+      const int r = i / CPR, ch = i % CPR;
+      f32x4 e = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < rows) {
+        if (c0 + ch * VEC + VEC <= cols) e = *(const f32x4*)(x + (int64_t)(r0 + r) * ldx + c0 + ch * VEC);
+        else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (c0 + ch * VEC + j < cols) e[j] = x[(int64_t)(r0 + r) * ldx + c0 + ch * VEC + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) tile[r][ch * VEC + j] = e[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < TS * CPR; i += 256) {
+      const int c = i / CPR, ch = i % CPR;              // output row c0 + c, elements r0 + ch*VEC ..
+      if (c0 + c >= cols) continue;
+      f32x4 e;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) e[j] = tile[ch * VEC + j][c];     // rows past `rows` were loaded as zeros
+      const int o = r0 + ch * VEC;
+      if (o + VEC <= ld_out) *(f32x4*)(y + (int64_t)(c0 + c) * ldy + o) = e;
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (o + j < ld_out) y[(int64_t)(c0 + c) * ldy + o + j] = e[j];
+      }
+    }
   }
 }
 
