@@ -447,27 +447,31 @@ static int launch_attn(const sl_attn_args* a, hipStream_t st) {
     // bf16: transposed-score kernel (8-byte output vectors need 4-element strides / an 8-byte aligned base)
     static const int generic = getenv("SL_ATTN_GENERIC") ? atoi(getenv("SL_ATTN_GENERIC")) : 0;
     if (!generic && a->o_row_stride % 4 == 0 && a->o_head_stride % 4 == 0 && ((uintptr_t)a->out & 7) == 0) {
-      if (p.drop_thr) {   // training mode: one variant (32 queries per wave) with the mask applied to the packed probabilities
-        dim3 grid((a->max_qlen + 127) / 128, a->n_heads, a->nseq);
-        hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 2, true>), grid, dim3(256), 0, st, p);
-        SL_CHECK_LAUNCH("attn_fwd_tr");
-        return 0;
-      }
-      static const int qt_env = getenv("SL_ATTN_QT") ? atoi(getenv("SL_ATTN_QT")) : 0;   // tuning switch
-      if constexpr (D == 64) {
-        // 64 queries per wave where the sequences are long enough to fill such blocks: K / V fragments read once per 4 query tiles
-        if (qt_env ? qt_env == 4 : a->max_qlen > 192) {
-          dim3 grid((a->max_qlen + 255) / 256, a->n_heads, a->nseq);
-          hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 4>), grid, dim3(256), 0, st, p);
+      if (p.drop_thr) {   // training mode (HuBERT's attention dropout): one variant (32 queries per wave) with the mask applied to
+                          // the packed probabilities; other shapes take the generic kernel, which applies the same mask
+        if constexpr (D == 64 && !CAUSAL) {
+          dim3 grid((a->max_qlen + 127) / 128, a->n_heads, a->nseq);
+          hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 2, true>), grid, dim3(256), 0, st, p);
           SL_CHECK_LAUNCH("attn_fwd_tr");
           return 0;
         }
+      } else {
+        static const int qt_env = getenv("SL_ATTN_QT") ? atoi(getenv("SL_ATTN_QT")) : 0;   // tuning switch
+        if constexpr (D == 64) {
+          // 64 queries per wave where the sequences are long enough to fill such blocks: K / V fragments read once per 4 query tiles
+          if (qt_env ? qt_env == 4 : a->max_qlen > 192) {
+            dim3 grid((a->max_qlen + 255) / 256, a->n_heads, a->nseq);
+            hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 4>), grid, dim3(256), 0, st, p);
+            SL_CHECK_LAUNCH("attn_fwd_tr");
+            return 0;
+          }
+        }
+        constexpr int QT = 2;
+        dim3 grid((a->max_qlen + QT * 64 - 1) / (QT * 64), a->n_heads, a->nseq);
+        hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, QT>), grid, dim3(256), 0, st, p);
+        SL_CHECK_LAUNCH("attn_fwd_tr");
+        return 0;
       }
-      constexpr int QT = 2;
-      dim3 grid((a->max_qlen + QT * 64 - 1) / (QT * 64), a->n_heads, a->nseq);
-      hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, QT>), grid, dim3(256), 0, st, p);
-      SL_CHECK_LAUNCH("attn_fwd_tr");
-      return 0;
     }
   }
   dim3 grid((a->max_qlen + 63) / 64, a->n_heads, a->nseq);
