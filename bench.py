@@ -105,6 +105,7 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
 def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist):
     """ref:trainer.py:270-384 on synthetic data: 10 s audio, 40 text ids, 64 response ids."""
     training, ri = mod("training"), mod("random_init")
+    torch.cuda.empty_cache()     # the inference legs leave a fragmented block cache behind; the warm-up window below repopulates it
     # the reference trains with the encoder in train() mode (ref:trainer.py:258): dropouts, LayerDrop and SpecAugment on
     reg = None if args.kd_eval_mode else training.TrainRegularizers(seed=1234 + rank)   # ranks draw different masks, as seed_everything + rank does in Trainer
     tr = training.KDTrainer(conf, enc, llm, prefix, suffix, total_optimizer_steps=1000, regularizers=reg)
