@@ -219,3 +219,38 @@ def test_spec_augment_spans_follow_hf_compute_mask_indices():
         ref = hf(shape, prob, length, min_masks=mn)
         np.random.seed(seed)
         assert (training.compute_mask_indices(shape, prob, length, mn) == ref).all(), (seed, shape)
+
+
+def test_dataset_reader_and_hubert_collate_on_the_reference_row_schema(tmp_path):
+    """the preprocessed HF `datasets` rows (ref:preprocess_data/preprocess_llama3.py:113-128: audio{array,
+    sampling_rate}, text, text_input_ids, llm_response, response_input_ids (nested), pool_ranges_4) saved with
+    save_to_disk are read back by Trainer.get_dataloaders (set_format torch, several shards concatenated) and collated as
+    ref:trainer.py:134-166 does: right-zero-padded float audio, BOS stripped from both id lists, the nested [0]."""
+    import datasets
+    from types import SimpleNamespace
+    trainer_mod = pkg("trainer")
+    g = torch.Generator().manual_seed(0)
+
+    def shard(lens):
+        return datasets.Dataset.from_dict({
+            "audio": [{"array": torch.randn(n, generator=g).tolist(), "sampling_rate": 16000} for n in lens],
+            "text": [f"utt {n}" for n in lens],
+            "text_input_ids": [[128000] + list(range(10, 10 + 3 + i)) for i, _ in enumerate(lens)],
+            "llm_response": [f"resp {n}" for n in lens],
+            "response_input_ids": [[[128000] + list(range(50, 50 + 4 + i))] for i, _ in enumerate(lens)],
+            "pool_ranges_4": [[[0, 2], [2, 5]] for _ in lens],
+        })
+
+    shard([1600, 2400]).save_to_disk(str(tmp_path / "train-a"))
+    shard([800]).save_to_disk(str(tmp_path / "train-b"))
+    shard([1000]).save_to_disk(str(tmp_path / "val"))
+    stub = SimpleNamespace(config=SimpleNamespace(data=SimpleNamespace(base_path=str(tmp_path), train_set=["train-a", "train-b"], val_set=["val"])))
+    trainer_mod.Trainer.get_dataloaders(stub)
+    assert len(stub.train_dataset) == 3 and len(stub.val_dataset) == 1
+    rows = [stub.train_dataset[i] for i in range(3)]
+    raw, padded, lens, texts, text_ids, resp_ids, ranges = trainer_mod.Trainer.collate_audio_batch_hubert(stub, rows)
+    assert lens == [1600, 2400, 800] and padded.shape == (3, 2400) and padded.dtype == torch.float32
+    assert torch.equal(padded[0, :1600], raw[0].float()) and not bool(padded[0, 1600:].any()) and not bool(padded[2, 800:].any())
+    assert texts == ["utt 1600", "utt 2400", "utt 800"]
+    assert text_ids[1].tolist() == list(range(10, 14)) and resp_ids[1].tolist() == list(range(50, 55))      # BOS stripped, [0] un-nested
+    assert [list(map(int, r)) for r in ranges[0]] == [[0, 2], [2, 5]]
