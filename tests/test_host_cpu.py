@@ -254,3 +254,32 @@ def test_dataset_reader_and_hubert_collate_on_the_reference_row_schema(tmp_path)
     assert texts == ["utt 1600", "utt 2400", "utt 800"]
     assert text_ids[1].tolist() == list(range(10, 14)) and resp_ids[1].tolist() == list(range(50, 55))      # BOS stripped, [0] un-nested
     assert [list(map(int, r)) for r in ranges[0]] == [[0, 2], [2, 5]]
+
+
+def test_ctypes_struct_mirrors_match_the_c_header(tmp_path):
+    """The host side passes plain structs across the C ABI: every ctypes mirror in _lib.py must have the size and the field
+    offsets a C compiler gives the struct of include/speechllm.h (compiled here with gcc; field NAMES must exist in both)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    L = pkg("_lib")
+    pairs = [("sl_gemm_args", L.GemmArgs), ("sl_gemm_fused", L.GemmFused), ("sl_gemm_ex_args", L.GemmEx), ("sl_attn_args", L.AttnArgs),
+             ("sl_hubert_layer", L.HubertLayer), ("sl_hubert_model", L.HubertModel), ("sl_llama_layer", L.LlamaLayer),
+             ("sl_llama_model", L.LlamaModel), ("sl_kv_cache", L.KVCache)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "speechllm.h")}"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True, capture_output=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(out[cname]) == C.sizeof(cls), (cname, out[cname], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
