@@ -283,3 +283,24 @@ def test_ctypes_struct_mirrors_match_the_c_header(tmp_path):
         assert int(out[cname]) == C.sizeof(cls), (cname, out[cname], C.sizeof(cls))
         for fname, _ in cls._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_ctypes_prototypes_have_the_header_arity_and_scalar_widths():
+    """Every ctypes prototype in _lib.py takes as many arguments as the declaration in include/speechllm.h, with the same
+    width for the scalar ones (int32_t / int64_t / size_t / uint64_t / float) and a pointer type where the header has one."""
+    import ctypes as C
+    hdr = open(os.path.join(REPO, "include", "speechllm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    decls = dict(re.findall(r"\b(?:int|size_t|int32_t|const char\s*\*)\s+(sl_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S))
+    assert set(decls) == set(L._PROTOS), set(decls) ^ set(L._PROTOS)
+    width = {"int32_t": 4, "int": 4, "int64_t": 8, "uint64_t": 8, "size_t": 8, "float": 4}
+    for name, (_, argtypes) in L._PROTOS.items():
+        params = [p_.strip() for p_ in decls[name].split(",")] if decls[name].strip() not in ("", "void") else []
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+        for prm, at in zip(params, argtypes):
+            is_ptr = "*" in prm or prm.split()[0] == "sl_stream"
+            if is_ptr:
+                assert at in (C.c_void_p, C.c_char_p) or hasattr(at, "contents") or issubclass(at, C._Pointer), (name, prm, at)
+            else:
+                ctype = next(t for t in width if re.search(rf"\b{t}\b", prm))
+                assert C.sizeof(at) == width[ctype] and (at is C.c_float) == (ctype == "float"), (name, prm, at)
