@@ -120,10 +120,9 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     tr.optimizer_step = lambda: None         # warm-up window: allocator + kernels, no update
     tr.micro_batch(waves, texts, resps)
     tr.optimizer_step = saved
-    for gb in tr.grads.values():
-        gb.zero_()
     if tr.reducer is not None:
-        tr.reducer.finish()
+        tr.reducer.finish()                  # the warm-up window's buckets (also warms RCCL up); then discard the sums
+    tr.enc_tape.arena.zero_()
     tr.micro = 0
     if dist is not None:
         dist.barrier()

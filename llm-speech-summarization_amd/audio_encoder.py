@@ -115,6 +115,16 @@ class AudioEncoder:
             self._upload()
         return self
 
+    def refresh_weights(self, state_dict) -> "AudioEncoder":
+        """load_state_dict for weights that only changed VALUE (an optimizer step): the device tensors are updated in place
+        (weights.*DeviceWeights.refresh) instead of being rebuilt."""
+        if self.weights is None:
+            return self.load_state_dict(state_dict)
+        sd = normalize_encoder_state_dict(state_dict)
+        self._state = {k: v.detach().float() for k, v in sd.items()}
+        self.weights.refresh(self._state)
+        return self
+
     def state_dict(self):
         if self._state is None:
             raise L.SpeechLLMError("AudioEncoder has no weights yet: call load_state_dict first")

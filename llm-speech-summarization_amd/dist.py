@@ -48,75 +48,117 @@ def sum_over_ranks(values: Sequence[float], device) -> List[float]:
     return t.tolist()
 
 
-class BucketedAllReduce:
-    """Sum-all-reduce of named fp32 gradient buffers in buckets, launched as soon as a bucket is final so the
-    exchange overlaps the rest of the backward pass (KD step).
+class GradArena:
+    """All fp32 gradient buffers of one optimizer step as views into ONE flat allocation, laid out in the order the backward
+    pass finishes them (projector, layer N-1 ... 0, positional conv / feature projection, conv stack).  A bucket of the
+    all-reduce is then a contiguous slice of `flat`: the collective runs in place on it, no gather copy before and no scatter
+    copy after (the round-1 reducer moved 2 x 1.27 GB per optimizer step through torch.cat / copy_)."""
 
-    On GPUs the collective is RCCL (`backend="nccl"`) issued on a side HIP stream behind an event recorded on
-    the compute stream; xGMI is point-to-point, so buckets are kept large (>= `min_bucket_bytes`) — a ring
-    all-reduce is bound by one ~153 GB/s link whatever the bucket count, while tiny buckets only add launch
+    ALIGN = 64   # elements: every view starts on a 256-byte boundary
+
+    def __init__(self, named_shapes, device):
+        self.order: List[str] = []
+        self.span = {}
+        off = 0
+        for name, shape in named_shapes:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            self.order.append(name)
+            self.span[name] = (off, n, tuple(int(d) for d in shape))
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.views = {name: self.flat[o:o + n].view(shape) for name, (o, n, shape) in self.span.items()}
+        self.index = {name: i for i, name in enumerate(self.order)}
+
+    def end_offset(self, i: int) -> int:
+        """Offset just past the i-th buffer's padded slot (== start of buffer i+1)."""
+        if i + 1 < len(self.order):
+            return self.span[self.order[i + 1]][0]
+        return self.flat.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+
+class BucketedAllReduce:
+    """Sum-all-reduce of the gradient arena in buckets, launched as soon as a bucket is final so the exchange overlaps the
+    rest of the backward pass (KD step).
+
+    `ready(names)` marks buffers final; whenever the final PREFIX of the arena (in backward order) has grown by at least
+    `min_bucket_bytes`, that contiguous slice is all-reduced in place.  On GPUs the collective is RCCL (`backend="nccl"`)
+    issued on a side HIP stream behind an event recorded on the compute stream; xGMI is point-to-point, so buckets are kept
+    large — a ring all-reduce is bound by one ~153 GB/s link whatever the bucket count, while tiny buckets only add launch
     latency.  On CPU tensors (gloo, used by the tests) the same code runs without streams.
     """
 
-    def __init__(self, grads, group=None, min_bucket_bytes: int = 32 << 20):
+    def __init__(self, arena: GradArena, group=None, min_bucket_bytes: int = 32 << 20):
         import torch.distributed as dist
         self.dist = dist
-        self.grads = grads
+        self.arena = arena
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.min_bytes = min_bucket_bytes
-        self._names: List[str] = []
-        self._bytes = 0
+        self._final = [False] * len(arena.order)
+        self._n_final = 0          # buffers [0, _n_final) are final
+        self._sent = 0             # element offset up to which the arena has been handed to the collective
         self._pending = []
-        any_t = next(iter(grads.values()))
-        self.cuda = any_t.is_cuda
-        self.stream = torch.cuda.Stream(device=any_t.device) if (self.cuda and self.world > 1) else None
+        self.cuda = arena.flat.is_cuda
+        self.stream = torch.cuda.Stream(device=arena.flat.device) if (self.cuda and self.world > 1) else None
+        self.bucket_log: List[tuple] = []     # (start, end) element ranges of the buckets launched so far in this step
+        self.last_buckets: List[tuple] = []   # ... of the previous optimizer step
 
     def ready(self, names: Sequence[str]) -> None:
-        """Mark gradient buffers as final for this optimizer step; flushes a bucket once it is large enough."""
+        """Mark gradient buffers as final for this optimizer step; launches a bucket once the final prefix is large enough."""
         if self.world == 1:
             return
         for n in names:
-            self._names.append(n)
-            self._bytes += self.grads[n].numel() * 4
-        if self._bytes >= self.min_bytes:
-            self.flush()
+            self._final[self.arena.index[n]] = True
+        while self._n_final < len(self._final) and self._final[self._n_final]:
+            self._n_final += 1
+        upto = self.arena.end_offset(self._n_final - 1) if self._n_final > 0 else 0
+        if (upto - self._sent) * 4 >= self.min_bytes:
+            self._launch(upto)
 
-    def flush(self) -> None:
-        if self.world == 1 or not self._names:
+    def _launch(self, upto: int) -> None:
+        if upto <= self._sent:
             return
-        names, self._names, self._bytes = self._names, [], 0
+        chunk = self.arena.flat[self._sent:upto]
+        self.bucket_log.append((self._sent, upto))
+        self._sent = upto
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                flat = torch.cat([self.grads[n].reshape(-1) for n in names])
-                work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work = self.dist.all_reduce(chunk, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            flat = torch.cat([self.grads[n].reshape(-1) for n in names])
-            work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, flat, names))
+            work = self.dist.all_reduce(chunk, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append(work)
+
+    def flush(self) -> None:
+        """Launch whatever part of the final prefix has not been sent yet."""
+        if self.world == 1:
+            return
+        self._launch(self.arena.end_offset(self._n_final - 1) if self._n_final > 0 else 0)
 
     def finish(self) -> int:
-        """Wait for every bucket, scatter the sums back into the gradient buffers.  Returns the bucket count."""
-        self.flush()
+        """Called after the backward pass: everything is final.  Sends the rest of the arena, waits for every bucket (the
+        compute stream waits on the side stream; nothing is copied).  Returns the bucket count."""
+        if self.world == 1:
+            return 0
+        self._launch(self.arena.flat.numel())
         n = len(self._pending)
-
-        def scatter():
-            for work, flat, names in self._pending:
-                work.wait()
-                off = 0
-                for name in names:
-                    g = self.grads[name]
-                    g.copy_(flat[off:off + g.numel()].view_as(g))
-                    off += g.numel()
-
         if self.cuda and self.stream is not None:
             with torch.cuda.stream(self.stream):
-                scatter()
+                for work in self._pending:
+                    work.wait()
             torch.cuda.current_stream().wait_stream(self.stream)
         else:
-            scatter()
+            for work in self._pending:
+                work.wait()
         self._pending = []
+        self._final = [False] * len(self._final)
+        self._n_final, self._sent = 0, 0
+        self.last_buckets, self.bucket_log = self.bucket_log, []
         return n

@@ -10,6 +10,7 @@ already-built models where hub downloads are impossible; when omitted the refere
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -28,6 +29,8 @@ class LLMSpeechTextInference():
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.SpeechLLMError("LLMSpeechTextInference runs on the MI355X HIP path only (device must be cuda:N)")
+        # libspeechllm launches on the CURRENT HIP device and stream: a `-g N` run must not execute cuda:N's pointers on GPU 0
+        torch.cuda.set_device(self.device)
 
         # Audio encoder (ref:inference.py:24-28): flat state-dict checkpoint, strict load.
         if audio_encoder is None:
@@ -46,7 +49,9 @@ class LLMSpeechTextInference():
             tokenizer.pad_token = tokenizer.eos_token
         self.llm_tokenizer = tokenizer
 
-        if "llama" in self.llm_type.lower():  # ref:inference.py:39-44 (substring test)
+        # ref:inference.py:39-44 tests the substring "llama" in the hub id; a local checkpoint directory is judged by its own
+        # name, not by whatever its parent directories are called
+        if "llama" in os.path.basename(os.path.normpath(self.llm_type)).lower() or (not os.path.isdir(self.llm_type) and "llama" in self.llm_type.lower()):
             self.prompt_prefix, self.prompt_suffix = LLAMA_PROMPT_PREFIX, LLAMA_PROMPT_SUFFIX
         else:
             self.prompt_prefix, self.prompt_suffix = MINICHAT_PROMPT_PREFIX, MINICHAT_PROMPT_SUFFIX
@@ -73,7 +78,10 @@ class LLMSpeechTextInference():
         if self.audio_encoder.downsample_method == "ctc_pool":
             # the reference calls an undefined self.get_ctc_pool_ranges here
             raise AttributeError("'LLMSpeechTextInference' object has no attribute 'get_ctc_pool_ranges'")
-        audio_embeds = self.audio_encoder(audio_tensor, ctc_pool_ranges=None)
+        if self.audio_encoder.encoder_base == "whisper":
+            audio_embeds = self._whisper_audio_embeds(audio)
+        else:
+            audio_embeds = self.audio_encoder(audio_tensor, ctc_pool_ranges=None)
 
         if len(additional_text_prompt) > 0:  # text prompt goes before the audio, BOS dropped (ref:inference.py:113-122)
             additional_text_input_ids = self.llm_tokenizer(additional_text_prompt, return_tensors='pt').input_ids[:, 1:].to(self.device)
@@ -86,6 +94,19 @@ class LLMSpeechTextInference():
                                                   embed_tokens=self.llm.model.embed_tokens, llm_type=self.llm_type,
                                                   device=self.device)
         return self.generate_llm_response(prompt_emb_sequence, max_new_tokens)[0]
+
+    def _whisper_audio_embeds(self, audio) -> torch.Tensor:
+        """Whisper base (ref:config/llama3_whisper.yaml).  ref:inference.py:97-107 hands the raw waveform to the Whisper encoder,
+        which cannot run; the working order of operations is the trainer's (ref:trainer.py:168-199, 278-291)
+        and is what this follows: log-mel of the utterance padded / cut to the 30 s window (sl_whisper_logmel) -> encoder ->
+        pool -> projector (sl_whisper_forward) -> crop to compute_num_audio_embeds(n_samples) rows."""
+        from .utils import compute_num_audio_embeds
+        wave = torch.as_tensor(audio, dtype=torch.float32).reshape(-1)
+        sr = int(getattr(getattr(self.config, "audio", None), "sampling_rate", 16000) or 16000)
+        feats = self.audio_encoder.feature_extractor([wave], return_tensors="pt", sampling_rate=sr).input_features
+        padded = self.audio_encoder(feats)                                    # (1, P_window, llm_dim)
+        keep = max(0, min(int(padded.shape[1]), compute_num_audio_embeds(int(wave.numel()), sr=sr)))
+        return padded[:, :keep]
 
     def generate_audio_responses(self, audios, additional_text_prompts=None, max_new_tokens=256) -> List[str]:
         """Batched form of generate_audio_response (an extension: the reference answers one utterance per call).

@@ -362,14 +362,28 @@ class EncoderTape:
     def ln_eps(self) -> float:
         return self.enc.arch.layer_norm_eps
 
-    # kernel-layout fp32 gradient buffers, one per weight tensor role
+    # kernel-layout fp32 gradient buffers, one per weight tensor role: views into ONE flat arena laid out in the order the
+    # backward pass finishes them, so that the data-parallel all-reduce runs in place on contiguous slices (dist.GradArena)
+    def grad_order(self) -> List[Tuple[str, tuple]]:
+        a, W = self.enc.arch, self.W
+        names = ["proj_w", "proj_b", "final_ln_g", "final_ln_b"]
+        for li in reversed(range(len(W.layer_t))):
+            names += [f"l{li}.{k}" for k in W.layer_t[li]]
+        names += ["pos_w", "pos_b", "fp_w", "fp_b", "fp_ln_g", "fp_ln_b", "masked_spec_embed"]
+        for i in reversed(range(1, len(a.conv_dim))):
+            names += [f"conv{i}_w", f"conv{i}_b", f"conv{i}_g", f"conv{i}_beta"]
+        names += ["conv0_w", "conv0_b", "conv0_g", "conv0_beta"]
+        shapes = {k: tuple(v.shape) for k, v in W.t.items()}
+        for li, lt in enumerate(W.layer_t):
+            shapes.update({f"l{li}.{k}": tuple(v.shape) for k, v in lt.items()})
+        shapes["masked_spec_embed"] = (a.hidden_size,)
+        names += [k for k in shapes if k not in names]
+        return [(n, shapes[n]) for n in names]
+
     def new_grads(self) -> Dict[str, torch.Tensor]:
-        g = {k: torch.zeros(v.shape, device=v.device, dtype=torch.float32) for k, v in self.W.t.items()}
-        for li, lt in enumerate(self.W.layer_t):
-            for k, v in lt.items():
-                g[f"l{li}.{k}"] = torch.zeros(v.shape, device=v.device, dtype=torch.float32)
-        g["masked_spec_embed"] = torch.zeros(self.enc.arch.hidden_size, device=self.enc.device, dtype=torch.float32)
-        return g
+        from .dist import GradArena
+        self.arena = GradArena(self.grad_order(), self.enc.device)
+        return self.arena.views
 
     def forward(self, waves: Sequence[torch.Tensor], reg: Optional[TrainRegularizers] = None, step: int = 0,
                 masked_spec_embed: Optional[torch.Tensor] = None):
@@ -691,12 +705,17 @@ class WhisperEncoderTape(EncoderTape):
     def ln_eps(self) -> float:
         return 1e-5
 
-    def new_grads(self) -> Dict[str, torch.Tensor]:
-        g = {k: torch.zeros(v.shape, device=v.device, dtype=torch.float32) for k, v in self.W.t.items() if k != "pos"}
-        for li, lt in enumerate(self.W.layer_t):
-            for k, v in lt.items():
-                g[f"l{li}.{k}"] = torch.zeros(v.shape, device=v.device, dtype=torch.float32)
-        return g
+    def grad_order(self) -> List[Tuple[str, tuple]]:
+        W = self.W
+        names = ["proj_w", "proj_b", "final_ln_g", "final_ln_b"]
+        for li in reversed(range(len(W.layer_t))):
+            names += [f"l{li}.{k}" for k in W.layer_t[li]]
+        names += ["conv1_w", "conv1_b", "conv2_w", "conv2_b"]
+        shapes = {k: tuple(v.shape) for k, v in W.t.items() if k != "pos"}
+        for li, lt in enumerate(W.layer_t):
+            shapes.update({f"l{li}.{k}": tuple(v.shape) for k, v in lt.items()})
+        names += [k for k in shapes if k not in names]
+        return [(n, shapes[n]) for n in names]
 
     def forward(self, waves: Sequence[torch.Tensor], reg: Optional[TrainRegularizers] = None, step: int = 0, masked_spec_embed=None):
         from .utils import compute_num_audio_embeds
@@ -820,23 +839,33 @@ class KDTrainer:
         # off it stays out of the optimizer, as its gradient is identically zero
         spec = regularizers is not None and regularizers.apply_spec_augment and regularizers.mask_time_prob > 0
         frozen = {"encoder.embed_positions.weight"} if self.is_whisper else (set() if spec else {"encoder.masked_spec_embed"})
-        self.trainable = [k for k in self.master if k not in frozen]
-        self.params = [torch.nn.Parameter(self.master[k], requires_grad=True) for k in self.trainable]
+        # every encoder parameter, in the order the reference's optimizer indexes them (ref:trainer.py:98-105, first param group =
+        # audio_encoder.parameters()); the ones frozen here never get a .grad, which AdamW skips, exactly like the reference's
+        # requires_grad=False / never-touched parameters
+        from .weights import reference_param_order
+        self.param_names = reference_param_order(self.master.keys())
+        self.trainable = [k for k in self.param_names if k not in frozen]
+        self._param = {k: torch.nn.Parameter(self.master[k], requires_grad=(k not in frozen)) for k in self.param_names}
+        self.params = [self._param[k] for k in self.trainable]
         opt = tr.optimizer
-        self.optimizer = torch.optim.AdamW(self.params, lr=float(opt.lr), betas=(float(opt.beta1), float(opt.beta2)))
+        self.optimizer = torch.optim.AdamW([self._param[k] for k in self.param_names], lr=float(opt.lr), betas=(float(opt.beta1), float(opt.beta2)))
         self.scheduler = torch.optim.lr_scheduler.PolynomialLR(self.optimizer, total_iters=total_optimizer_steps, power=1.0)
         self.grads = self.enc_tape.new_grads()
-        self.micro = 0
+        self.micro = 0                 # micro-steps of the open accumulation window on this rank
+        self.micro_total = 0
         self.micro_batches = 0
+        self.optimizer_steps = 0
+        self.keep_last_grads = False
         from .dist import BucketedAllReduce
-        self.reducer = BucketedAllReduce(self.grads, group=process_group) if self.world > 1 else None
+        self.reducer = BucketedAllReduce(self.enc_tape.arena, group=process_group) if self.world > 1 else None
 
     # -- micro-steps ----------------------------------------------------------------------------
     def micro_step(self, wave: torch.Tensor, text_ids: torch.Tensor, response_ids: torch.Tensor) -> Dict[str, float]:
         """One utterance (the reference's loop body, ref:trainer.py:261-384)."""
         return self.micro_batch([wave], [text_ids], [response_ids])[0]
 
-    def micro_batch(self, waves: Sequence[torch.Tensor], text_ids: Sequence[torch.Tensor], response_ids: Sequence[torch.Tensor]) -> List[Dict[str, float]]:
+    def micro_batch(self, waves: Sequence[torch.Tensor], text_ids: Sequence[torch.Tensor], response_ids: Sequence[torch.Tensor],
+                    close_window: Optional[bool] = None) -> List[Dict[str, float]]:
         """len(waves) micro-steps of ONE accumulation window processed together as a packed, ragged batch.  The encoder
         weights do not change inside a window, so this is the same arithmetic as the reference's sequential batch-size-1
         micro-steps (each loss still divided by grad_accum_interval, gradients summed) — but every GEMM sees all the
@@ -846,9 +875,13 @@ class KDTrainer:
         dev, dt = enc.device, enc.dtype
         emb = llm.model.embed_tokens
         B = len(waves)
-        if self.micro % self.local_accum + B > self.local_accum:
+        if self.micro + B > self.local_accum:
             raise L.SpeechLLMError("a micro-batch must not straddle an optimizer step")
-        last = (self.micro + B) % self.local_accum == 0
+        # close_window=True: the epoch's last, partial accumulation window (the reference steps on the last batch too,
+        # ref:trainer.py:377); every rank then exchanges the whole arena in one piece (ranks may hold different sample counts,
+        # so the early per-bucket launches, whose sequence must be identical on all ranks, are skipped)
+        last = (self.micro + B) == self.local_accum if close_window is None else bool(close_window)
+        early_buckets = last and close_window is None and self.reducer is not None
         response_ids = [r.to(dev) for r in response_ids]
         ns = [int(r.shape[0]) for r in response_ids]
         audio, etape = self.enc_tape.forward(waves, self.reg, step=self.micro_batches,
@@ -909,8 +942,9 @@ class KDTrainer:
                     d_hidden[l] = d
         d_seq = self.llm_tape.backward(ltape, tail, d_logits, d_hidden)
         d_audio = torch.cat([d_seq[aoff[u] + n_pre: aoff[u] + n_pre + (poff[u + 1] - poff[u])] for u in range(B)], 0).contiguous()
-        self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self.reducer.ready if (last and self.reducer is not None) else None)
+        self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self.reducer.ready if early_buckets else None)
         self.micro += B
+        self.micro_total += B
         self.last_d_audio = d_audio
         out = []
         for ntp, ld, fd in losses.tolist():
@@ -919,17 +953,57 @@ class KDTrainer:
             self.optimizer_step()
         return out
 
+    def close_window(self) -> None:
+        """Optimizer step of a window in which THIS rank held no sample (the tail of an epoch under data parallel): its
+        gradients are zero, the all-reduce still has to be joined."""
+        self.optimizer_step()
+
     # -- optimizer step ---------------------------------------------------------------------------
     def optimizer_step(self) -> None:
         if self.reducer is not None:
-            self.reducer.finish()
+            self.reducer.finish()                  # in place on the arena: nothing to scatter back
         sd_grads = self.to_state_dict(self.enc, self.grads, self.master)
         for k, p in zip(self.trainable, self.params):
-            p.grad = sd_grads[k].reshape(p.shape).to(torch.float32)
-        self.last_grads = {k: p.grad.clone() for k, p in zip(self.trainable, self.params)}
+            p.grad = sd_grads[k].reshape(p.shape)  # views of the arena wherever kernel and state-dict layouts coincide
+        if self.keep_last_grads:                   # tests / debugging only: a 1.27 GB clone per step otherwise
+            self.last_grads = {k: p.grad.clone() for k, p in zip(self.trainable, self.params)}
         self.optimizer.step()
         self.scheduler.step()
         self.optimizer.zero_grad(set_to_none=True)
-        for gbuf in self.grads.values():
-            gbuf.zero_()
-        self.enc.load_state_dict({k: v.detach() for k, v in self.master.items()})   # refresh the compute-dtype kernel weights
+        self.enc_tape.arena.zero_()
+        self.enc.refresh_weights(self.master)      # compute-dtype kernel weights follow the fp32 master, in place
+        self.optimizer_steps += 1
+        self.micro = 0
+
+    # -- optimizer state in the reference's checkpoint layout ------------------------------------------
+    def _n_llm_params(self) -> int:
+        a = self.llm.arch            # LlamaForCausalLM.parameters(): embed, 9 per layer, final norm (+ lm_head when untied)
+        return 2 + 9 * a.num_hidden_layers + (0 if a.tie_word_embeddings else 1)
+
+    def optimizer_state_dict(self) -> dict:
+        """torch.optim.AdamW.state_dict() as the REFERENCE's optimizer would write it (ref:trainer.py:98-105, 516-528): two
+        param groups — every encoder parameter in `audio_encoder.parameters()` order, then the (frozen, stateless) LLM's."""
+        sd = self.optimizer.state_dict()
+        g0 = dict(sd["param_groups"][0])
+        n_enc = len(self.param_names)
+        g0["params"] = list(range(n_enc))
+        g1 = dict(g0)
+        g1["params"] = list(range(n_enc, n_enc + self._n_llm_params()))
+        return {"state": sd["state"], "param_groups": [g0, g1]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Accepts the reference's two-group layout (or this build's): per-parameter state is taken by index for the encoder
+        group; the LLM group carries no state (its parameters never had gradients)."""
+        groups = sd["param_groups"]
+        n_enc = len(self.param_names)
+        if len(groups[0]["params"]) != n_enc:
+            raise L.SpeechLLMError(f"optimizer checkpoint has {len(groups[0]['params'])} encoder parameters, this encoder has {n_enc}")
+        g0 = dict(groups[0])
+        g0["params"] = list(range(n_enc))
+        state = {int(i): v for i, v in sd["state"].items() if int(i) < n_enc}
+        self.optimizer.load_state_dict({"state": state, "param_groups": [g0]})
+        dev = self.enc.device
+        for st in self.optimizer.state.values():          # ref:trainer.py:124-130 moves the state to the GPU by hand
+            for k, v in st.items():
+                if torch.is_tensor(v) and k != "step":
+                    st[k] = v.to(dev)

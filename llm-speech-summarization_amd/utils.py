@@ -78,3 +78,25 @@ def batch_full_embed_sequence(all_audio_embeds, all_text_input_ids, all_response
     a, am = pad(audio_seqs)
     t, tm = pad(text_seqs) if process_text else (None, None)
     return a, am, t, tm
+
+
+def soft_cross_entropy(input, target, reduction="mean"):
+    """ref:utils.py:167-178 — mean over positions of -sum_v softmax(target)_v * log_softmax(input)_v — on the HIP path
+    (sl_soft_ce_loss, fp32 statistics).  Inputs are GPU tensors (..., V); returns a 0-d tensor (`reduction="mean"`) or the
+    per-position values.  The KD step itself calls the same kernel with its gradient output (training.KDTrainer); this
+    entry point is the reference's forward-only helper."""
+    from . import _lib as L
+    from . import ops
+    L.require_gpu(input.contiguous(), "input")
+    V = input.shape[-1]
+    s = input.reshape(-1, V).float().contiguous()
+    t = target.reshape(-1, V).float().contiguous()
+    rows = s.shape[0]
+    if reduction == "mean":
+        loss = torch.zeros(1, device=s.device, dtype=torch.float32)
+        ops.soft_ce_loss(s, t, 1.0 / rows, loss, None)
+        return loss[0]
+    out = torch.zeros(rows, device=s.device, dtype=torch.float32)
+    for r in range(rows):
+        ops.soft_ce_loss(s[r:r + 1], t[r:r + 1], 1.0, out[r:r + 1], None)
+    return out.view(input.shape[:-1])

@@ -132,6 +132,73 @@ def normalize_encoder_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch
     return sd
 
 
+_WN_PAIRS = (("parametrizations.weight.original0", "weight_g"), ("parametrizations.weight.original1", "weight_v"))
+
+
+def rename_weight_norm_keys(sd: Dict[str, torch.Tensor], like: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Checkpoint keys -> the weight-norm spelling `like` uses (`...conv.weight_g/weight_v` written by torch < 2.1, what the
+    released checkpoint carries, vs `...conv.parametrizations.weight.original0/1`; SURVEY.md §5 checkpoint row).  The
+    tensors are the same under both spellings (g: (1,1,k), v: (H, H/G, k))."""
+    out = {}
+    for k, v in sd.items():
+        k2 = k
+        for new, old in _WN_PAIRS:
+            if k.endswith(old) and k not in like and k[:-len(old)] + new in like:
+                k2 = k[:-len(old)] + new
+            elif k.endswith(new) and k not in like and k[:-len(new)] + old in like:
+                k2 = k[:-len(new)] + old
+        out[k2] = v
+    return out
+
+
+def reference_param_order(keys) -> List[str]:
+    """Encoder state-dict keys in the order `AudioEncoder.parameters()` yields them in the reference (module registration
+    order of ref:model/audio_encoder.py:17-54 over HF's HubertModel / WhisperEncoder): this is the index space of the
+    reference's optimizer state (ref:trainer.py:98-105, first param group), so checkpoints written here load there and back.
+    HubertModel's own parameter (masked_spec_embed) comes before its children's; HF attention registers k, v, q, out."""
+    keys = list(keys)
+
+    def rank(k: str):
+        if k.startswith("embed_projection."):
+            return (9, 0, 0, k.endswith("bias"))
+        if k == "encoder.masked_spec_embed":
+            return (0, 0, 0, 0)
+        body = k[len("encoder."):] if k.startswith("encoder.") else k
+        wb = 1 if body.endswith("bias") else 0
+        if body.startswith("feature_extractor.conv_layers."):
+            i = int(body.split(".")[2])
+            return (1, i, 0 if ".conv." in body else 1, wb)
+        if body.startswith("feature_projection."):
+            return (2, 0, 0 if "layer_norm" in body else 1, wb)
+        if body.startswith("encoder.pos_conv_embed."):
+            sub = 0 if body.endswith("conv.bias") else (1 if body.endswith(("original0", "weight_g")) else 2)
+            return (3, 0, sub, 0)
+        if body.startswith("encoder.layer_norm."):
+            return (4, 0, 0, wb)
+        if body.startswith("encoder.layers."):            # HuBERT
+            li = int(body.split(".")[2])
+            tail = body.split(".", 3)[3]
+            order = ["attention.k_proj", "attention.v_proj", "attention.q_proj", "attention.out_proj", "layer_norm",
+                     "feed_forward.intermediate_dense", "feed_forward.output_dense", "final_layer_norm"]
+            return (5, li, next(j for j, o in enumerate(order) if tail.startswith(o + ".")), wb)
+        # Whisper encoder (hf:models/whisper/modeling_whisper.py): conv1, conv2, embed_positions, layers, layer_norm
+        if body.startswith(("conv1.", "conv2.")):
+            return (1, int(body[4]), 0, wb)
+        if body.startswith("embed_positions."):
+            return (2, 0, 0, 0)
+        if body.startswith("layers."):
+            li = int(body.split(".")[1])
+            tail = body.split(".", 2)[2]
+            order = ["self_attn.k_proj", "self_attn.v_proj", "self_attn.q_proj", "self_attn.out_proj", "self_attn_layer_norm", "fc1", "fc2",
+                     "final_layer_norm"]
+            return (5, li, next(j for j, o in enumerate(order) if tail.startswith(o + ".")), wb)
+        if body.startswith("layer_norm."):
+            return (6, 0, 0, wb)
+        raise L.SpeechLLMError(f"reference_param_order: unexpected encoder parameter '{k}'")
+
+    return sorted(keys, key=rank)
+
+
 def fold_pos_conv_weight(sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
     if prefix + "parametrizations.weight.original0" in sd:
         g, v = sd[prefix + "parametrizations.weight.original0"], sd[prefix + "parametrizations.weight.original1"]
@@ -151,24 +218,38 @@ class HubertDeviceWeights:
         sd = normalize_encoder_state_dict(sd)
         self.arch, self.dtype, self.device, self.llm_dim = arch, dtype, device, llm_dim
         self._keep: List[torch.Tensor] = []
-        H, G, kpos = arch.hidden_size, arch.num_conv_pos_embedding_groups, arch.num_conv_pos_embeddings
-        if H // arch.num_attention_heads != 64:
+        self._pool, self._downsample = (pool_kernel, pool_stride), downsample
+        if arch.hidden_size // arch.num_attention_heads != 64:
             raise L.SpeechLLMError("HuBERT head_dim must be 64 for the built attention kernel")
+        self.t: Dict[str, torch.Tensor] = {}   # role -> device tensor (the training graph composes ops from these)
+        by_ptr: Dict[int, torch.Tensor] = {}
 
         def dev(t: torch.Tensor, dt=None) -> torch.Tensor:
             t = t.detach().to(device=device, dtype=dt or dtype).contiguous()
             self._keep.append(t)
+            by_ptr[t.data_ptr()] = t
             return t
 
-        self.t: Dict[str, torch.Tensor] = {}   # role -> device tensor (the training graph composes ops from these)
-        by_ptr: Dict[int, torch.Tensor] = {}
-        _dev0 = dev
+        self._populate(sd, dev, by_ptr)
 
-        def dev(t: torch.Tensor, dt=None) -> torch.Tensor:  # noqa: F811 - also index by pointer
-            r = _dev0(t, dt)
-            by_ptr[r.data_ptr()] = r
-            return r
+    def refresh(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Re-derive every device tensor from `sd` IN PLACE (the optimizer step of the KD trainer: the fp32 master weights
+        moved, the compute-dtype kernel copies follow).  Same expressions, same order as construction; no device tensor, struct
+        or pointer changes, so captured launches / cached descriptors stay valid and nothing is re-allocated."""
+        sd = normalize_encoder_state_dict(sd)
+        it = iter(self._keep)
 
+        def dev(t: torch.Tensor, dt=None) -> torch.Tensor:
+            dst = next(it)
+            dst.copy_(t.detach().reshape(dst.shape))
+            return dst
+
+        self._populate(sd, dev, None)
+
+    def _populate(self, sd, dev, by_ptr) -> None:
+        arch, dtype, llm_dim = self.arch, self.dtype, self.llm_dim
+        (pool_kernel, pool_stride), downsample = self._pool, self._downsample
+        H, G, kpos = arch.hidden_size, arch.num_conv_pos_embedding_groups, arch.num_conv_pos_embeddings
         m = L.HubertModel()
         m.dtype = L.dtype_code(dtype)
         m.n_conv, m.hidden, m.n_layers = len(arch.conv_dim), H, arch.num_hidden_layers
@@ -195,11 +276,13 @@ class HubertDeviceWeights:
         Hg = H // G
         m.pos_w = dev(wpos.permute(0, 2, 1).reshape(G, Hg, kpos * Hg)).data_ptr()
         m.pos_b = dev(sd[p + "bias"]).data_ptr()
-        self._layers = (L.HubertLayer * arch.num_hidden_layers)()
+        layers = (L.HubertLayer * arch.num_hidden_layers)()
+        if by_ptr is not None:
+            self._layers = layers
         for li in range(arch.num_hidden_layers):
             p = f"encoder.encoder.layers.{li}."
             a = p + "attention."
-            lay = self._layers[li]
+            lay = layers[li]
             lay.ln1_g, lay.ln1_b = dev(sd[p + "layer_norm.weight"]).data_ptr(), dev(sd[p + "layer_norm.bias"]).data_ptr()
             lay.wqkv = dev(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0)).data_ptr()
             lay.bqkv = dev(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0)).data_ptr()
@@ -209,15 +292,19 @@ class HubertDeviceWeights:
             f = p + "feed_forward."
             lay.w1, lay.b1 = dev(sd[f + "intermediate_dense.weight"]).data_ptr(), dev(sd[f + "intermediate_dense.bias"]).data_ptr()
             lay.w2, lay.b2 = dev(sd[f + "output_dense.weight"]).data_ptr(), dev(sd[f + "output_dense.bias"]).data_ptr()
-        m.layers = C.cast(self._layers, C.POINTER(L.HubertLayer))
+        m.layers = C.cast(layers, C.POINTER(L.HubertLayer))
         m.final_ln_g = dev(sd["encoder.encoder.layer_norm.weight"]).data_ptr()
         m.final_ln_b = dev(sd["encoder.encoder.layer_norm.bias"]).data_ptr()
-        self.proj_w = dev(sd["embed_projection.weight"])
-        self.proj_b = dev(sd["embed_projection.bias"])
+        proj_w = dev(sd["embed_projection.weight"])
+        proj_b = dev(sd["embed_projection.bias"])
+        if by_ptr is not None:
+            self.proj_w, self.proj_b = proj_w, proj_b
         if downsample == "pool":
-            m.proj_w, m.proj_b = self.proj_w.data_ptr(), self.proj_b.data_ptr()
+            m.proj_w, m.proj_b = proj_w.data_ptr(), proj_b.data_ptr()
         else:  # stack / ctc_pool: the host composes the downsample from ops on last_hidden
             m.proj_w, m.proj_b = None, None
+        if by_ptr is None:      # refresh(): tensors, struct and role tables stay as built
+            return
         self.struct = m
         g = lambda p_: by_ptr[p_]
         self.t.update(conv0_w=g(m.conv0_w), conv0_b=g(m.conv0_b), conv0_g=g(m.conv0_g), conv0_beta=g(m.conv0_beta),
@@ -424,8 +511,8 @@ class WhisperDeviceWeights:
         sd = normalize_encoder_state_dict(sd)
         self.arch, self.dtype, self.device, self.llm_dim = arch, dtype, device, llm_dim
         self._keep: List[torch.Tensor] = []
-        H = arch.d_model
-        if H // arch.encoder_attention_heads != 64:
+        self._pool, self._downsample = (pool_kernel, pool_stride), downsample
+        if arch.d_model // arch.encoder_attention_heads != 64:
             raise L.SpeechLLMError("Whisper head_dim must be 64 for the built attention kernel")
 
         by_ptr: Dict[int, torch.Tensor] = {}
@@ -436,6 +523,24 @@ class WhisperDeviceWeights:
             by_ptr[t.data_ptr()] = t
             return t
 
+        self._populate(sd, dev, by_ptr)
+
+    def refresh(self, sd: Dict[str, torch.Tensor]) -> None:
+        """In-place update of every device tensor from `sd` (see HubertDeviceWeights.refresh)."""
+        sd = normalize_encoder_state_dict(sd)
+        it = iter(self._keep)
+
+        def dev(t: torch.Tensor, dt=None) -> torch.Tensor:
+            dst = next(it)
+            dst.copy_(t.detach().reshape(dst.shape))
+            return dst
+
+        self._populate(sd, dev, None)
+
+    def _populate(self, sd, dev, by_ptr) -> None:
+        arch, dtype, llm_dim = self.arch, self.dtype, self.llm_dim
+        (pool_kernel, pool_stride), downsample = self._pool, self._downsample
+        H = arch.d_model
         m = L.HubertModel()
         m.dtype, m.reserved = L.dtype_code(dtype), 1
         m.n_conv, m.hidden, m.n_layers, m.n_heads, m.ffn = 3, H, arch.encoder_layers, arch.encoder_attention_heads, arch.encoder_ffn_dim
@@ -449,11 +554,13 @@ class WhisperDeviceWeights:
             m.conv_w[i] = dev(w.permute(0, 2, 1).reshape(w.shape[0], -1)).data_ptr()
             m.conv_b[i] = dev(sd[f"encoder.{name}.bias"]).data_ptr()
         m.pos_w = dev(sd["encoder.embed_positions.weight"]).data_ptr()
-        self._layers = (L.HubertLayer * arch.encoder_layers)()
+        layers = (L.HubertLayer * arch.encoder_layers)()
+        if by_ptr is not None:
+            self._layers = layers
         for li in range(arch.encoder_layers):
             p = f"encoder.layers.{li}."
             a = p + "self_attn."
-            lay = self._layers[li]
+            lay = layers[li]
             lay.ln1_g, lay.ln1_b = dev(sd[p + "self_attn_layer_norm.weight"]).data_ptr(), dev(sd[p + "self_attn_layer_norm.bias"]).data_ptr()
             lay.wqkv = dev(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0)).data_ptr()
             kb = sd.get(a + "k_proj.bias", torch.zeros_like(sd[a + "q_proj.bias"]))   # Whisper's k_proj has no bias
@@ -462,11 +569,14 @@ class WhisperDeviceWeights:
             lay.ln2_g, lay.ln2_b = dev(sd[p + "final_layer_norm.weight"]).data_ptr(), dev(sd[p + "final_layer_norm.bias"]).data_ptr()
             lay.w1, lay.b1 = dev(sd[p + "fc1.weight"]).data_ptr(), dev(sd[p + "fc1.bias"]).data_ptr()
             lay.w2, lay.b2 = dev(sd[p + "fc2.weight"]).data_ptr(), dev(sd[p + "fc2.bias"]).data_ptr()
-        m.layers = C.cast(self._layers, C.POINTER(L.HubertLayer))
+        m.layers = C.cast(layers, C.POINTER(L.HubertLayer))
         m.final_ln_g, m.final_ln_b = dev(sd["encoder.layer_norm.weight"]).data_ptr(), dev(sd["encoder.layer_norm.bias"]).data_ptr()
-        self.proj_w, self.proj_b = dev(sd["embed_projection.weight"]), dev(sd["embed_projection.bias"])
+        proj_w, proj_b = dev(sd["embed_projection.weight"]), dev(sd["embed_projection.bias"])
         if downsample == "pool":
-            m.proj_w, m.proj_b = self.proj_w.data_ptr(), self.proj_b.data_ptr()
+            m.proj_w, m.proj_b = proj_w.data_ptr(), proj_b.data_ptr()
+        if by_ptr is None:      # refresh(): the log-mel constants below never change
+            return
+        self.proj_w, self.proj_b = proj_w, proj_b
         self.struct = m
         # role -> device tensor, as HubertDeviceWeights does (the training tape composes ops from these)
         g = lambda ptr: by_ptr[ptr]

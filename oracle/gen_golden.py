@@ -328,11 +328,94 @@ def gen_whisper(enc_mod):
          input_features=feats, audio_embeds=out)
 
 
+def _ref_whisper_encoder(enc_mod, llm_dim, seed):
+    from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperModel
+    c = TINY_WHISPER
+    tmp = tempfile.mkdtemp(prefix="whisper_cfg_")
+    hf_cfg = WhisperConfig(d_model=c.d_model, encoder_layers=c.encoder_layers, encoder_attention_heads=c.encoder_attention_heads,
+                           encoder_ffn_dim=c.encoder_ffn_dim, num_mel_bins=c.num_mel_bins, max_source_positions=c.max_source_positions,
+                           decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64, vocab_size=64, max_target_positions=16,
+                           dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, pad_token_id=0,
+                           bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+    WhisperModel(hf_cfg).save_pretrained(tmp)
+    WhisperFeatureExtractor(feature_size=c.num_mel_bins, sampling_rate=16000, hop_length=c.hop_length, chunk_length=2, n_fft=c.n_fft).save_pretrained(tmp)
+    cfg = SimpleNamespace(model=SimpleNamespace(
+        audio_encoder=SimpleNamespace(base="whisper", type=tmp, downsample_method="pool", downsample_factor=4,
+                                      pooling=SimpleNamespace(kernel_size=8, stride=4)),
+        llm_embedding_channels=llm_dim))
+    m = enc_mod.AudioEncoder(cfg, torch.device("cpu"))
+    m.load_state_dict(ri.whisper_encoder_state_dict(c, llm_dim, seed=seed), strict=True)
+    return m.eval()
+
+
+def gen_whisper_pipeline(enc_mod, llama_mod, utils):
+    """BASELINE configs[3] end to end.  The reference's own Whisper INFERENCE is broken (ref:inference.py:97-107
+    feeds the raw waveform to the Whisper encoder), so the pinned order of operations is the trainer's (ref:trainer.py:168-199,
+    278-291), which is what a working generate_audio_response has to do: HF log-mel of the utterance padded to the window ->
+    reference AudioEncoder -> crop to compute_num_audio_embeds(n_samples) rows -> merge_prompt_tokens -> greedy generate."""
+    c = TINY_LLAMA
+    enc = _ref_whisper_encoder(enc_mod, c.hidden_size, seed=71)
+    llm, _ = build_ref_llama(llama_mod, c, 72)
+    prefix_ids = ri.synthetic_ids(7, c.vocab_size, seed=7, bos=0)
+    suffix_ids = ri.synthetic_ids(6, c.vocab_size, seed=8, bos=0)
+    text_prompt_ids = ri.synthetic_ids(9, c.vocab_size, seed=9, bos=0)
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: prefix_ids, utils.LLAMA_PROMPT_SUFFIX: suffix_ids})
+    arrays = dict(enc_seed=71, llm_seed=72, prefix_ids=prefix_ids, suffix_ids=suffix_ids, text_prompt_ids=text_prompt_ids)
+    ns = [20000, 30000]
+    arrays.update(n_samples=ns, wave_seeds=[400 + n for n in ns])
+    llm.generation_config.eos_token_id = list(c.eos_token_ids)
+    with torch.no_grad():
+        for i, n in enumerate(ns):
+            wave = ri.synthetic_waveform(n, seed=400 + n).numpy()
+            feats = enc.feature_extractor([wave], return_tensors="pt", sampling_rate=16000).input_features
+            padded = enc(feats)
+            keep = utils.compute_num_audio_embeds(n, sr=16000)                 # ref:trainer.py:283-289
+            audio_embeds = padded[:, :keep]
+            arrays[f"num_audio_embeds_{i}"] = keep
+            for tag, extra in (("audio", None), ("text_audio", text_prompt_ids)):
+                combined = audio_embeds if extra is None else torch.cat([llm.model.embed_tokens(extra[:, 1:]), audio_embeds], dim=1)
+                seq = utils.merge_prompt_tokens(inputs_embeds=combined, tokenizer=tok, embed_tokens=llm.model.embed_tokens, llm_type=LLAMA_ID,
+                                                device=torch.device("cpu"))
+                ids = llm.generate(input_ids=None, inputs_embeds=seq, max_new_tokens=32, do_sample=False)
+                arrays[f"ids_{tag}_{i}"] = ids
+                arrays[f"prompt_len_{tag}_{i}"] = seq.shape[1]
+    save("whisper_pipeline_tiny", **arrays)
+
+
+def gen_validation(enc_mod, llama_mod, utils):
+    """ref:trainer.py:400-514 on a 5-sample synthetic validation set (tiny HuBERT + tiny Llama, the dataset tests/dp_worker.py
+    builds): per-sample audio / text next-token losses and the two perplexities exp(mean(nll))."""
+    c = TINY_LLAMA
+    enc, _ = build_ref_encoder(enc_mod, TINY_HUBERT, c.hidden_size, seed=51, method="pool")
+    llm, _ = build_ref_llama(llama_mod, c, 52)
+    z = np.load(os.path.join(OUT, "pipeline_tiny.npz"))
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: torch.from_numpy(z["prefix_ids"]), utils.LLAMA_PROMPT_SUFFIX: torch.from_numpy(z["suffix_ids"])})
+    gen = torch.Generator().manual_seed(2718)
+    V = c.vocab_size
+    rows = []
+    for i in range(5):
+        n = 20000 + 1500 * i
+        rows.append((n, torch.randint(1, V, (6 - i % 2,), generator=gen), torch.randint(1, V, (7 + i % 3,), generator=gen)))
+    a_nll, t_nll = [], []
+    with torch.no_grad():
+        for n, text_ids, resp_ids in rows:                                   # ids: BOS already stripped, as the collate leaves them
+            audio_embeds = enc(ri.synthetic_waveform(n, seed=n)[None], None)
+            a_seq, _, t_seq, _ = utils.batch_full_embed_sequence(all_audio_embeds=audio_embeds, all_text_input_ids=[text_ids],
+                                                                 all_response_input_ids=[resp_ids], tokenizer=tok, embed_tokens=llm.model.embed_tokens,
+                                                                 llm_type=LLAMA_ID, device=torch.device("cpu"), process_text=True)
+            a_nll.append(llm(inputs_embeds=a_seq, labels=resp_ids.unsqueeze(0)).loss)
+            t_nll.append(llm(inputs_embeds=t_seq, labels=resp_ids.unsqueeze(0)).loss)
+    save("validation_tiny", enc_seed=51, llm_seed=52, gen_seed=2718, n_samples=[r[0] for r in rows],
+         text_lens=[len(r[1]) for r in rows], resp_lens=[len(r[2]) for r in rows], audio_nll=torch.stack(a_nll), text_nll=torch.stack(t_nll),
+         audio_perplexity=torch.exp(torch.stack(a_nll).mean()), text_perplexity=torch.exp(torch.stack(t_nll).mean()))
+
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     enc_mod, llama_mod, utils = import_reference()
-    which = sys.argv[1:] or ["encoder", "llama", "pipeline", "whisper"]
+    which = sys.argv[1:] or ["encoder", "llama", "pipeline", "whisper", "whisper_pipeline", "validation"]
     if "encoder" in which:
         gen_encoder(enc_mod)
     if "llama" in which:
@@ -341,6 +424,10 @@ def main():
         gen_pipeline(enc_mod, llama_mod, utils)
     if "whisper" in which:
         gen_whisper(enc_mod)
+    if "whisper_pipeline" in which:
+        gen_whisper_pipeline(enc_mod, llama_mod, utils)
+    if "validation" in which:
+        gen_validation(enc_mod, llama_mod, utils)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,83 @@
+"""GPU: data-parallel KD training equals single-process training (ref:trainer.py:373-384 lifted to N ranks).
+
+Two processes share cuda:0 and exchange gradients through gloo (RCCL refuses two ranks on one device; on a multi-GPU node the
+same code runs with backend "nccl"): rank-sharded `Trainer` (2 ranks x 8 micro-steps per optimizer step) must hand AdamW the
+same gradients, end with the same fp32 master weights and report the same validation perplexities as 1 rank x 16 — including
+the epoch's partial tail window, where one rank holds no sample at all and only joins the exchange (`close_window`).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(REPO, "tests", "dp_worker.py")
+GRAD_TOL = 2e-6     # fp32: the two runs sum the same per-utterance terms in a different order (8 + 8 vs 16 rows per reduction)
+MASTER_TOL = 1e-6
+
+
+def _run(world, out_dir, n_rows, accum, port):
+    procs, outs = [], []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = os.path.join(out_dir, f"w{world}_r{r}.pt")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, WORKER, out, str(n_rows), str(accum), out_dir], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(log)
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return [torch.load(o, map_location="cpu", weights_only=False) for o in outs]
+
+
+def test_two_rank_trainer_equals_single_rank(tmp_path):
+    n_rows, accum = 17, 16          # one full window (2 x 8) + a tail window of ONE sample (rank 1 holds none)
+    port = 29900 + os.getpid() % 500
+    (one,) = _run(1, str(tmp_path), n_rows, accum, port)
+    two = _run(2, str(tmp_path), n_rows, accum, port + 1)
+    # sharding: every window is dealt round-robin; the ranks' samples are disjoint and cover the epoch, in window order
+    windows = one["windows"]
+    assert [len(w) for w in windows] == [16, 1] and two[0]["windows"] == windows == two[1]["windows"]
+    assert sorted(two[0]["indices"] + two[1]["indices"]) == list(range(n_rows))
+    assert not set(two[0]["indices"]) & set(two[1]["indices"])
+    assert two[0]["indices"] == windows[0][0::2] + windows[1][0::2] and two[1]["indices"] == windows[0][1::2] + windows[1][1::2]
+    assert len(two[0]["indices"]) == 9 and len(two[1]["indices"]) == 8
+    for r in two:
+        assert r["optimizer_steps"] == one["optimizer_steps"] == 2 and r["step"] == one["step"] == n_rows and r["lr"] == one["lr"]
+        # the full window went out in several buckets that tile the arena in order; the tail window in one piece
+        assert len(r["buckets"][0]) >= 2 and len(r["buckets"][1]) == 1
+        assert r["buckets"] == two[0]["buckets"]
+    # gradients after the all-reduce == single-rank accumulation, both optimizer steps, every parameter
+    for s in range(2):
+        for r in two:
+            num = sum(float((r["grads"][s][k].double() - one["grads"][s][k].double()).pow(2).sum()) for k in one["grads"][s])
+            den = sum(float(one["grads"][s][k].double().pow(2).sum()) for k in one["grads"][s])
+            assert (num / den) ** 0.5 < GRAD_TOL, (s, r["rank"], (num / den) ** 0.5)
+            worst = max(rel_err(r["grads"][s][k], one["grads"][s][k]) for k in one["grads"][s] if float(one["grads"][s][k].norm()) > 1e-8)
+            assert worst < 50 * GRAD_TOL, (s, r["rank"], worst)
+    # both ranks hold bit-identical gradients and weights (same all-reduced sums, same AdamW)
+    for k in one["master"]:
+        assert torch.equal(two[0]["master"][k], two[1]["master"][k]), k
+        assert rel_err(two[0]["master"][k], one["master"][k]) < MASTER_TOL, k
+    for s in range(2):
+        for k in two[0]["grads"][s]:
+            assert torch.equal(two[0]["grads"][s][k], two[1]["grads"][s][k]), (s, k)
+    # sharded validation: NLL sums all-reduced -> the single-process perplexities on every rank
+    for key in ("validation/audio_perplexity", "validation/text_perplexity"):
+        for r in two:
+            assert abs(r["val"][key] - one["val"][key]) < 1e-5 * one["val"][key], (key, r["val"][key], one["val"][key])

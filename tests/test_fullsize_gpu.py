@@ -1,0 +1,303 @@
+"""GPU: the BENCHMARKED configurations at full depth and size (BASELINE.json configs[1], configs[0]'s model family,
+configs[4] long-form), so that what bench.py times is also what the parity suite checks.
+
+* configs[1]: HuBERT-large (24 layers) -> Llama-3.2-3B (28 layers), bf16, random init of the true shapes (bench.py's weights),
+  512 sequences per step: (a) every copy of an utterance inside the batch gives bit-identical embedding rows and id rows
+  (64-bit indexing, row independence of every kernel); (b) the 3-utterance batch gives the same embeddings and the same
+  first tokens; (c) one utterance against the CPU oracle on the same bf16-rounded weights: audio embeddings and all 29
+  hidden-state taps within the stated tolerance (FULL_TOL: 28 layers of bf16 rounding, vs 3e-2 for the 2-layer fixtures).
+* MiniChat-2-3B shapes (24-layer MHA, untied head, vocab 49 216): same checks at a ragged batch of 16.
+* long-form: 60 s and 120 s utterances (T = 2 999 / 5 999 frames) through HuBERT-large width against the oracle; a 1 560-token
+  causal prompt through Llama-3.2-3B width (fp32: greedy ids identical on margin-qualified steps).
+The oracle needs fp32 host copies of the weights (12.9 GB for Llama-3.2-3B): these tests are sized for the GPU box's host.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import pkg, rel_err
+from oracle import hubert_oracle as ho
+from oracle import llama_oracle as lo
+from oracle.golden_cfgs import WIDE_HUBERT, WIDE_LLAMA
+
+pytestmark = pytest.mark.gpu
+
+ri = pkg("random_init")
+cfgm = pkg("config")
+enc_mod = pkg("audio_encoder")
+llama_mod = pkg("audio_llama")
+weights = pkg("weights")
+utils = pkg("utils")
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+BF16_TOL = 3e-2    # 2-layer fixtures (tests/test_models_gpu.py)
+FULL_TOL = 6e-2    # full depth: bf16 rounding of 24 / 28 residual layers accumulates (measured 1.5-3.5e-2)
+N_PRE, N_SUF = 9, 5
+
+
+def _oracle_cfgs(harch, larch):
+    hc = ho.HubertCfg(harch.conv_dim, harch.conv_kernel, harch.conv_stride, harch.hidden_size, harch.num_hidden_layers,
+                      harch.num_attention_heads, harch.intermediate_size, harch.num_conv_pos_embeddings,
+                      harch.num_conv_pos_embedding_groups, harch.layer_norm_eps)
+    lc = lo.LlamaCfg(larch.hidden_size, larch.num_hidden_layers, larch.num_attention_heads, larch.num_key_value_heads,
+                     larch.head_dim, larch.intermediate_size, larch.vocab_size, larch.rms_norm_eps, larch.rope_theta,
+                     larch.rope_scaling, larch.tie_word_embeddings, tuple(larch.eos_token_ids), larch.pad_token_id)
+    return hc, lc
+
+
+def _bf16_round_encoder_sd(sd):
+    # conv0 stays fp32 in the kernel (weights.py), everything else is stored in bf16
+    return {k: (v if "conv_layers.0." in k else v.to(torch.bfloat16).float()) for k, v in sd.items()}
+
+
+class FullModels:
+    """HuBERT-large + a 3 B Llama-family decoder, random init (bench.py's generator), bf16, built once per module."""
+
+    def __init__(self, llm_id: str, yaml_name: str, untied: bool):
+        import bench
+        self.harch = weights.KNOWN_HUBERT["facebook/hubert-large-ls960-ft"]
+        self.larch = weights.KNOWN_LLAMA[llm_id]
+        conf = cfgm.load_config(os.path.join(REPO, "config", yaml_name))
+        self.enc_sd = ri.hubert_encoder_state_dict(self.harch, self.larch.hidden_size, seed=0)
+        self.enc = enc_mod.AudioEncoder(conf, DEV, dtype=torch.bfloat16, arch=self.harch)
+        self.enc.load_state_dict(self.enc_sd).eval().to(DEV)
+        sd = bench.gpu_llama_state_dict(self.larch, 0, torch.device(DEV))
+        if untied:
+            g = torch.Generator(device=DEV)
+            g.manual_seed(99)
+            sd["lm_head.weight"] = (torch.randn(self.larch.vocab_size, self.larch.hidden_size, generator=g, device=DEV) * 0.02).to(torch.bfloat16)
+        self.llm_sd_host = {k: v.float().cpu() for k, v in sd.items()}        # the oracle's weights: bf16 values held in fp32
+        self.llm = llama_mod.AudioLlamaForCausalLM(self.larch, sd, torch_dtype=torch.bfloat16, device=DEV, max_ctx=448, max_batch=512)
+        bos = self.larch.bos_token_id or 0
+        self.prefix = ri.synthetic_ids(N_PRE, self.larch.vocab_size, seed=7, bos=bos)
+        self.suffix = ri.synthetic_ids(N_SUF, self.larch.vocab_size, seed=8, bos=bos)
+        emb = self.llm.model.embed_tokens
+        self.pre_e, self.suf_e = emb(self.prefix.to(DEV))[0], emb(self.suffix.to(DEV))[0, 1:]
+
+    def P(self, n_samples: int) -> int:
+        return (self.harch.num_frames(n_samples) - 8) // 4 + 1
+
+    def prompts(self, waves):
+        """[prefix | audio | suffix[1:]] of every utterance in one packed buffer, the encoder writing the audio rows in place
+        (ref:utils.py:49-73 through the packed path bench.py times).  Returns (x, lens, starts)."""
+        Ps = [self.P(w.numel()) for w in waves]
+        lens = [N_PRE + p + N_SUF - 1 for p in Ps]
+        starts = [0]
+        for n in lens:
+            starts.append(starts[-1] + n)
+        x = torch.empty((starts[-1], self.larch.hidden_size), device=DEV, dtype=torch.bfloat16)
+        for b in range(len(waves)):
+            x[starts[b]:starts[b] + N_PRE] = self.pre_e
+            x[starts[b] + N_PRE + Ps[b]:starts[b + 1]] = self.suf_e
+        self.enc.encode_packed(waves, out=x, out_row_offsets=[starts[b] + N_PRE for b in range(len(waves))])
+        return x, lens, starts
+
+
+_SLOT = {}
+
+
+def _models(kind: str) -> FullModels:
+    """One full-size model pair alive at a time (each holds 13 GB of host fp32 oracle weights + its GPU copies)."""
+    if _SLOT.get("kind") != kind:
+        _SLOT.clear()
+        torch.cuda.empty_cache()
+        _SLOT["m"] = (FullModels(utils.LLAMA_ID, "llama3_hubert.yaml", untied=False) if kind == "llama3"
+                      else FullModels("GeneZC/MiniChat-2-3B", "minichat_hubert.yaml", untied=True))
+        _SLOT["kind"] = kind
+    return _SLOT["m"]
+
+
+@pytest.fixture()
+def llama3():
+    return _models("llama3")
+
+
+@pytest.fixture()
+def minichat():
+    return _models("minichat")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _release_models():
+    yield
+    _SLOT.clear()
+    torch.cuda.empty_cache()
+
+
+def _agreeing_prefix(a, b):
+    neq = (a != b).nonzero()
+    return int(neq[0]) if neq.numel() else int(a.shape[0])
+
+
+def test_configs1_full_depth_batch512_copies_identical_and_equal_small_batch(llama3):
+    """bench.py's default step (512 sequences, HuBERT-large 24 L + Llama-3.2-3B 28 L, bf16) on copies of 3 distinct utterances."""
+    m, B, new = llama3, 512, 24
+    base = [ri.synthetic_waveform(n, seed=1234 + i).to(DEV) for i, n in enumerate((160000, 112000, 160000))]
+    x3, lens3, st3 = m.prompts(base)
+    x3 = x3.clone()
+    xb, lensb, stb = m.prompts([base[b % 3] for b in range(B)])
+    # (a) + (b): every copy's prompt rows (prefix, audio embeddings, suffix) are bit-identical to the 3-utterance run's
+    for b in range(B):
+        assert torch.equal(xb[stb[b]:stb[b + 1]], x3[st3[b % 3]:st3[b % 3 + 1]]), f"prompt rows of sequence {b} differ"
+    xb_keep = xb.clone()
+    ids, n_cols = m.llm.generate_packed(xb, lensb, new, use_eos=False)
+    assert n_cols == new and ids.shape == (B, new)
+    for b in range(3, B):
+        assert torch.equal(ids[b], ids[b % 3]), f"id row {b} differs from its utterance's first copy"
+    # the same three sequences alone take the small-batch kernel family (skinny GEMMs / split attention): in bf16 near-tied
+    # random-init logits may flip a LATER token between kernel families (fp32 mode: never, tests/test_models_gpu.py), the first
+    # tokens must agree
+    ids3, _ = m.llm.generate_packed(x3.clone(), lens3, new, use_eos=False)
+    agree = [_agreeing_prefix(ids3[i], ids[i]) for i in range(3)]
+    assert min(agree) >= 1, agree
+    # prefill logits of the big batch against the small one (both through sl_llama_prefill)
+    import ctypes as C
+    L = pkg("_lib")
+    w, lib = m.llm._dev(), L.lib()
+
+    def last_logits(x, lens):
+        nb = len(lens)
+        cu = [0]
+        for n in lens:
+            cu.append(cu[-1] + n)
+        kv = m.llm._kv_cache(nb)
+        ws = m.llm._workspace(lib.sl_generate_workspace_bytes(C.byref(w.struct), x.shape[0], nb, 1))
+        logits = torch.empty((nb, m.larch.vocab_size), device=DEV, dtype=torch.float32)
+        ctx = torch.empty(nb, device=DEV, dtype=torch.int32)
+        L.check(lib.sl_llama_prefill(C.byref(w.struct), C.byref(kv), x.data_ptr(), (C.c_int32 * (nb + 1))(*cu), nb, logits.data_ptr(),
+                                     ctx.data_ptr(), None, ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_llama_prefill")
+        return logits
+
+    lg_big = last_logits(xb_keep, lensb)
+    lg_small = last_logits(x3.clone(), lens3)
+    for b in range(B):
+        assert rel_err(lg_big[b].cpu(), lg_small[b % 3].cpu()) < 1e-2, b
+
+
+def test_configs1_full_depth_one_utterance_vs_oracle(llama3):
+    """One 10 s utterance through all 24 + 28 layers against the CPU oracle on the same (bf16-rounded) weights."""
+    m = llama3
+    hc, lc = _oracle_cfgs(m.harch, m.larch)
+    wave = ri.synthetic_waveform(160000, seed=1234)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    out, P, last_hidden, T = m.enc.encode_packed([wave.to(DEV)], want_last_hidden=True)
+    taps = {}
+    with torch.no_grad():
+        ref_audio = ho.audio_encoder_forward(_bf16_round_encoder_sd(m.enc_sd), hc, wave[None], taps=taps)[0]
+    assert T[0] == 499 and P[0] == 123 == ref_audio.shape[0]
+    e_h = rel_err(last_hidden.float().cpu(), taps["last_hidden_state"][0])
+    e_o = rel_err(out.float().cpu(), ref_audio)
+    assert e_h < FULL_TOL and e_o < FULL_TOL, (e_h, e_o)
+    # LLM: the prompt assembled from the GPU's embeddings, all 29 taps + last-row logits
+    x, lens, _ = m.prompts([wave.to(DEV)])
+    assert lens[0] == 136
+    res = m.llm(inputs_embeds=x[None].clone(), output_hidden_states=True)
+    with torch.no_grad():
+        ref = lo.llama_forward(m.llm_sd_host, lc, x[None].float().cpu(), output_hidden_states=True, last_logits_only=True)
+    errs = [rel_err(res.hidden_states[i].float().cpu(), ref["hidden_states"][i]) for i in range(m.larch.num_hidden_layers + 1)]
+    assert max(errs) < FULL_TOL, errs
+    e_l = rel_err(res.logits[:, -1].cpu(), ref["logits"][:, -1])
+    assert e_l < FULL_TOL, e_l
+    # the first greedy token: the oracle's argmax must be among the GPU's top candidates within the oracle's own top-2 margin
+    top_ref = ref["logits"][0, -1].topk(2)
+    gpu_first = int(res.logits[0, -1].argmax())
+    margin = float(top_ref.values[0] - top_ref.values[1])
+    if margin > 4 * e_l * float(ref["logits"][0, -1].abs().max()):
+        assert gpu_first == int(top_ref.indices[0])
+
+
+def test_minichat_full_depth_ragged_batch_and_oracle(minichat):
+    """BASELINE configs[0]'s model family (MiniChat-2-3B shapes) at full size through the same path."""
+    m, B, new = minichat, 16, 24
+    secs = [4 + (i % 5) * 2 for i in range(B)]
+    waves = [ri.synthetic_waveform(s * 16000, seed=100 + i).to(DEV) for i, s in enumerate(secs)]
+    x, lens, st = m.prompts(waves)
+    keep = x.clone()
+    ids, n_cols = m.llm.generate_packed(x, lens, new, use_eos=False)
+    assert n_cols == new
+    for i in range(4):      # the reference's own use: one utterance per call
+        x1, l1, _ = m.prompts([waves[i]])
+        assert torch.equal(x1, keep[st[i]:st[i + 1]])
+        one, _ = m.llm.generate_packed(x1, l1, new, use_eos=False)
+        assert _agreeing_prefix(one[0], ids[i]) >= 1
+    hc, lc = _oracle_cfgs(m.harch, m.larch)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    i = 1
+    xi = keep[st[i]:st[i + 1]]
+    res = m.llm(inputs_embeds=xi[None].clone(), output_hidden_states=True)
+    with torch.no_grad():
+        ref = lo.llama_forward(m.llm_sd_host, lc, xi[None].float().cpu(), output_hidden_states=True, last_logits_only=True)
+    errs = [rel_err(res.hidden_states[k].float().cpu(), ref["hidden_states"][k]) for k in range(m.larch.num_hidden_layers + 1)]
+    assert max(errs) < FULL_TOL, errs
+    assert rel_err(res.logits[:, -1].cpu(), ref["logits"][:, -1]) < FULL_TOL
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# long-form (BASELINE configs[4])
+# ------------------------------------------------------------------------------------------------------------------------
+def _hubert_arch(c):
+    return weights.HubertArch(c.conv_dim, c.conv_kernel, c.conv_stride, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                              c.intermediate_size, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, c.layer_norm_eps)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, BF16_TOL)])
+def test_longform_60s_120s_hubert_large_width_vs_oracle(dtype, tol):
+    """One 60 s and one 120 s utterance (T = 2 999 / 5 999 frames: attention never materialises T x T) in one ragged batch."""
+    c = WIDE_HUBERT
+    conf = cfgm.from_dict(dict(model=dict(audio_encoder=dict(base="hubert", type="synthetic", downsample_method="pool", downsample_factor=4,
+                                                             pooling=dict(kernel_size=8, stride=4)),
+                                          llm_embedding_channels=3072, llm_type=utils.LLAMA_ID)))
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=dtype, arch=_hubert_arch(c))
+    sd = ri.hubert_encoder_state_dict(c, 3072, seed=21)
+    enc.load_state_dict(sd).eval().to(DEV)
+    waves = [ri.synthetic_waveform(n, seed=500 + i) for i, n in enumerate((960000, 1920000))]
+    out, P, last_hidden, T = enc.encode_packed([w.to(DEV) for w in waves], want_last_hidden=True)
+    assert T == [2999, 5999]
+    sdq = sd if dtype == torch.float32 else _bf16_round_encoder_sd(sd)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    t0 = p0 = 0
+    for w, tt, pp in zip(waves, T, P):
+        taps = {}
+        with torch.no_grad():
+            ref = ho.audio_encoder_forward(sdq, c, w[None], taps=taps)[0]
+        assert ref.shape[0] == pp
+        assert rel_err(last_hidden[t0:t0 + tt].float().cpu(), taps["last_hidden_state"][0]) < tol
+        assert rel_err(out[p0:p0 + pp].float().cpu(), ref) < tol
+        t0 += tt
+        p0 += pp
+
+
+def test_longform_prompt_llama32_width_fp32_ids_and_bf16_hidden():
+    """A 1 560-token prompt (120 s of audio embeddings + text prompt) through Llama-3.2-3B width x 2 layers: causal D=128 GQA
+    prefill over ~1.5 k keys, decode against a 1.5 k-token cache, llama3 RoPE scaling far from position 0."""
+    c = WIDE_LLAMA
+    arch = weights.LlamaArch(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.intermediate_size,
+                             c.vocab_size, c.rms_norm_eps, c.rope_theta, c.rope_scaling, c.tie_word_embeddings, tuple(c.eos_token_ids), c.pad_token_id)
+    sd = ri.llama_state_dict(c, seed=43)
+    S, new = 1560, 8
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, S, c.hidden_size, generator=g) * 0.02
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref_ids, margins = lo.greedy_generate(sd, c, x, new, use_eos=False, return_margins=True)
+        ref = lo.llama_forward(sd, c, x, output_hidden_states=True, last_logits_only=True)
+    llm = llama_mod.AudioLlamaForCausalLM(arch, dict(sd), torch_dtype=torch.float32, device=DEV, max_ctx=1600)
+    llm.generation_config.eos_token_id = None
+    out = llm(inputs_embeds=x.to(DEV), output_hidden_states=True)
+    assert rel_err(torch.stack(out.hidden_states).cpu(), torch.stack(ref["hidden_states"])) < 1e-4
+    ids = llm.generate(inputs_embeds=x.to(DEV), max_new_tokens=new).cpu()
+    for k in range(new):            # bit-exact greedy ids on margin-qualified steps (all of them, unless a near tie)
+        if float(margins[0, k]) > 1e-4:
+            assert int(ids[0, k]) == int(ref_ids[0, k]), (k, ids, ref_ids)
+        else:
+            break
+    del llm
+    sdq = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    with torch.no_grad():
+        refq = lo.llama_forward(sdq, c, x.to(torch.bfloat16).float(), output_hidden_states=True, last_logits_only=True)
+    llm = llama_mod.AudioLlamaForCausalLM(arch, dict(sd), torch_dtype=torch.bfloat16, device=DEV, max_ctx=1600)
+    outq = llm(inputs_embeds=x.to(DEV), output_hidden_states=True)
+    assert rel_err(torch.stack(outq.hidden_states).float().cpu(), torch.stack(refq["hidden_states"])) < BF16_TOL

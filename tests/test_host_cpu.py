@@ -172,17 +172,32 @@ def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # every rank holds the same named buffers; rank r's "micro-step gradients" are (r+1) * base
+    # every rank holds the same named buffers as views of ONE flat arena laid out in backward order (p4 is final first);
+    # rank r's "micro-step gradients" are (r+1) * base
     g = torch.Generator().manual_seed(0)
-    base = {f"p{i}": torch.randn(n, generator=g) for i, n in enumerate((1000, 7, 333, 4096, 1))}
-    grads = {k: v * (rank + 1) for k, v in base.items()}
-    red = distm.BucketedAllReduce(grads, min_bucket_bytes=4 * 1200)
-    red.ready(["p4", "p3"])      # "late layers first", like the backward pass
-    red.ready(["p2"])
-    red.ready(["p1", "p0"])
-    buckets = red.finish()
-    ok = all(torch.allclose(grads[k], base[k] * sum(range(1, world + 1))) for k in base)
-    q.put((rank, ok, buckets))
+    sizes = dict(p4=(1,), p3=(64, 64), p2=(333,), p1=(7,), p0=(10, 100))
+    arena = distm.GradArena(list(sizes.items()), "cpu")
+    base = {k: torch.randn(v.shape, generator=g) for k, v in arena.views.items()}
+    ok = True
+    log = []
+    for step in range(2):        # two optimizer steps: the reducer's state must reset between them
+        for k, v in arena.views.items():
+            v.copy_(base[k] * (rank + 1) * (step + 1))
+        red = distm.BucketedAllReduce(arena, min_bucket_bytes=4 * 1200) if step == 0 else red
+        red.ready(["p3"])            # not a prefix yet (p4 missing): nothing may be sent
+        ok = ok and red._sent == 0
+        red.ready(["p4"])            # prefix p4..p3 = 64 + 4096 elements >= the bucket size: first bucket goes out
+        ok = ok and red._sent == arena.span["p2"][0]
+        red.ready(["p2"])
+        red.ready(["p1", "p0"])
+        buckets = red.finish()
+        log.append((buckets, list(red.last_buckets)))
+        tot = sum(range(1, world + 1)) * (step + 1)
+        ok = ok and all(torch.allclose(arena.views[k], base[k] * tot) for k in base)
+        # the buckets tile the arena exactly once, in order, and the padding between views was reduced too (stays zero)
+        spans = red.last_buckets
+        ok = ok and spans[0][0] == 0 and spans[-1][1] == arena.flat.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    q.put((rank, ok, log[0][0]))
     dist.destroy_process_group()
 
 
@@ -304,3 +319,102 @@ def test_ctypes_prototypes_have_the_header_arity_and_scalar_widths():
             else:
                 ctype = next(t for t in width if re.search(rf"\b{t}\b", prm))
                 assert C.sizeof(at) == width[ctype] and (at is C.c_float) == (ctype == "float"), (name, prm, at)
+
+
+def test_epoch_windows_are_dealt_disjointly_and_cover_the_epoch_at_any_world_size():
+    """every accumulation window (incl. the partial tail, which the reference also steps on, ref:trainer.py:377) is
+    dealt round-robin; ranks' shares are disjoint, cover the shuffle, and full windows give every rank accum / world samples."""
+    from types import SimpleNamespace
+    trainer_mod = pkg("trainer")
+    for n_rows, accum in [(64, 16), (70, 16), (17, 16), (5, 16)]:
+        shares = {}
+        for world in (1, 2, 4, 8):
+            per_rank = []
+            for rank in range(world):
+                stub = SimpleNamespace(config=SimpleNamespace(seed_everything=1234), train_dataset=list(range(n_rows)), grad_accum_interval=accum,
+                                       rank=rank, world=world)
+                stub._epoch_windows = lambda e, s=stub: trainer_mod.Trainer._epoch_windows(s, e)
+                wins = stub._epoch_windows(3)
+                assert sorted(i for w in wins for i in w) == list(range(n_rows)) and all(len(w) == accum for w in wins[:-1])
+                assert len(wins[-1]) == (n_rows % accum or accum)
+                mine = trainer_mod.Trainer._epoch_indices(stub, 3)
+                per_rank.append(mine)
+                for w in wins:
+                    if len(w) == accum:
+                        assert len(w[rank::world]) == accum // world
+            flat = [i for m in per_rank for i in m]
+            assert sorted(flat) == list(range(n_rows)) and len(set(flat)) == n_rows
+            shares[world] = per_rank
+        assert shares[1][0] == [i for w in stub._epoch_windows(3) for i in w]
+    c = trainer_mod.Trainer._crossed
+    assert c(0, 16, 16) and c(15, 17, 16) and not c(16, 31, 16) and c(16, 32, 16) and c(0, 16, 10) and c(16, 32, 30) and not c(0, 16, 0)
+
+
+def test_reference_param_order_matches_hf_parameters_and_weight_norm_renaming():
+    """The optimizer state inside a reference checkpoint is indexed by `audio_encoder.parameters()` order (ref:trainer.py:98-105):
+    weights.reference_param_order must reproduce it (checked against the installed transformers' modules), and checkpoint keys
+    under the other weight-norm spelling are renamed, not dropped."""
+    W = pkg("weights")
+    try:
+        from transformers import HubertConfig, HubertModel, WhisperConfig
+        from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    except Exception:
+        pytest.skip("transformers modules unavailable")
+
+    class AE(torch.nn.Module):       # ref:model/audio_encoder.py:17-54: encoder, pooling_layer, embed_projection
+        def __init__(self, enc, h):
+            super().__init__()
+            self.encoder, self.pooling_layer, self.embed_projection = enc, torch.nn.AvgPool1d(8, 4), torch.nn.Linear(h, 32)
+
+    hub = HubertModel(HubertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, conv_dim=(64,) * 7,
+                                   num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, feat_extract_norm="layer", do_stable_layer_norm=True,
+                                   conv_bias=True))
+    whi = WhisperEncoder(WhisperConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, max_source_positions=100))
+    for enc in (hub, whi):
+        names = [n for n, _ in AE(enc, 128).named_parameters()]
+        assert W.reference_param_order(sorted(names)) == names
+    like = {"encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original0": 0, "encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original1": 0,
+            "encoder.encoder.pos_conv_embed.conv.bias": 0}
+    legacy = {"encoder.encoder.pos_conv_embed.conv.weight_g": 1, "encoder.encoder.pos_conv_embed.conv.weight_v": 2, "encoder.encoder.pos_conv_embed.conv.bias": 3}
+    ren = W.rename_weight_norm_keys(legacy, like)
+    assert ren == {"encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original0": 1,
+                   "encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original1": 2, "encoder.encoder.pos_conv_embed.conv.bias": 3}
+    assert W.rename_weight_norm_keys(ren, legacy) == legacy and W.rename_weight_norm_keys(legacy, legacy) == legacy
+
+
+def test_grad_arena_views_are_aligned_slices_of_one_allocation():
+    arena = distm.GradArena([("a", (3, 5)), ("b", (64,)), ("c", (1,)), ("d", (7, 11, 2))], "cpu")
+    assert arena.order == ["a", "b", "c", "d"] and arena.flat.numel() == 64 + 64 + 64 + 192
+    for name, v in arena.views.items():
+        off, n, shape = arena.span[name]
+        assert off % arena.ALIGN == 0 and tuple(v.shape) == shape and v.data_ptr() == arena.flat.data_ptr() + 4 * off
+    arena.views["d"].fill_(2.0)
+    assert float(arena.flat.sum()) == 2.0 * 154 and arena.end_offset(3) == arena.flat.numel() and arena.end_offset(0) == 64
+
+
+def test_tokenizer_fixtures_through_autotokenizer_reproduce_recorded_ids():
+    """SURVEY §8 f1 on the CPU: the reference's tokenizer construction (ref:inference.py:32-37: AutoTokenizer.from_pretrained(
+    llm_type, use_fast=False, padding_side="left"); pad_token = eos_token) over the two committed tokenizer fixtures — a byte-level
+    BPE shaped like Llama-3's and a SentencePiece model shaped like MiniChat's — yields the recorded ids for the reference's
+    template strings (ref:utils.py:6-10) and prompts; Llama-3's prefix is 9 ids and its suffix 6 (BOS first in both)."""
+    import json
+    from transformers import AutoTokenizer
+    utils = pkg("utils")
+    root = os.path.join(REPO, "tests", "golden", "tokenizers")
+    rec = json.load(open(os.path.join(root, "tokenizer_ids.json")))
+    for family, name in (("llama3", "Llama-3.2-3B-Instruct"), ("minichat", "MiniChat-2-3B")):
+        path = os.path.join(root, name)
+        tok = AutoTokenizer.from_pretrained(path, use_fast=False, padding_side="left")
+        tok.pad_token = tok.eos_token
+        r = rec[family]
+        assert (len(tok), tok.bos_token_id, tok.eos_token_id, tok.pad_token_id) == (r["vocab_size"], r["bos_token_id"], r["eos_token_id"], r["pad_token_id"])
+        prefix, suffix = utils.prompt_template(path)            # a local directory is matched by its basename
+        assert (prefix, suffix) == (r["strings"]["prefix"], r["strings"]["suffix"])
+        assert r["strings"]["text_prompt"] == f"{prefix} hello world{suffix} "      # ref:inference.py:78
+        for key, text in r["strings"].items():
+            ids = tok(text, return_tensors="pt").input_ids
+            assert ids.shape[0] == 1 and ids[0].tolist() == r["ids"][key], (family, key)
+            assert int(ids[0, 0]) == tok.bos_token_id
+        dec = tok.batch_decode([r["ids"]["plain"] + [tok.eos_token_id]], skip_special_tokens=True, clean_up_tokenization_spaces=True)[0]
+        assert dec == r["decoded_plain_skip_special"] == r["strings"]["plain"]
+    assert len(rec["llama3"]["ids"]["prefix"]) == 9 and len(rec["llama3"]["ids"]["suffix"]) == 6

@@ -213,7 +213,7 @@ def ref_attention(qh, kh, vh, causal, scale, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("seqlens", [[499], [64], [1, 63, 65, 200], [130, 17]])
+@pytest.mark.parametrize("seqlens", [[499], [64], [1, 63, 65, 200], [130, 17], [2999], [5999, 1499]])   # 60 s / 120 s / 30 s utterances (configs[4])
 def test_attention_noncausal_d64_varlen(dt, seqlens):
     nh, D = 4, 64
     ntok = sum(seqlens)
@@ -228,7 +228,7 @@ def test_attention_noncausal_d64_varlen(dt, seqlens):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("seqlens", [[137], [5, 64, 129], [300]])
+@pytest.mark.parametrize("seqlens", [[137], [5, 64, 129], [300], [1800, 777]])   # 1800 ~ the prompt of a 120 s utterance + text prompt
 @pytest.mark.parametrize("nh,nkv", [(6, 2), (2, 2)])
 def test_attention_causal_gqa_d128(dt, seqlens, nh, nkv):
     D = 128

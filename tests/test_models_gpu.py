@@ -4,10 +4,12 @@ classes) against the golden fixtures generated from the reference and against th
 fp32 mode: hidden states <= 1e-4 relative L2 vs the reference fixtures, greedy ids IDENTICAL.
 bf16 mode: weights rounded to bf16 on both sides; hidden states <= 3e-2 relative L2 (stated tolerance).
 """
+import os
+
 import pytest
 import torch
 
-from conftest import golden, pkg, rel_err, t
+from conftest import GOLDEN, golden, pkg, rel_err, t
 from oracle import hubert_oracle as ho
 from oracle import kd_oracle as ko
 from oracle import llama_oracle as lo
@@ -133,6 +135,16 @@ def test_llama_tiny_fp32_forward_and_generate(name, cfg):
     out = llm(inputs_embeds=x, output_hidden_states=True)
     assert rel_err(out.logits.cpu(), t(g["logits"])) < F32_TOL
     assert rel_err(torch.stack(out.hidden_states).cpu(), t(g["hidden_states"])) < F32_TOL
+    # response-only next-token loss of list-labels (ref:model/audio_llama.py:72-101) against the reference's own value
+    labels = [t(g["labels"]).to(DEV)]
+    loss = llm(inputs_embeds=x, labels=labels, attention_mask=torch.ones(1, int(g["S"]), dtype=torch.long, device=DEV)).loss
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    # batch mean over two samples with different label lengths equals the oracle's restatement of the same rule
+    x2 = torch.cat([x, x.flip(1)], 0)
+    lab2 = [labels[0], labels[0][:4]]
+    out2 = llm(inputs_embeds=x2, labels=lab2)
+    ref2 = lo.response_only_loss(out2.logits.cpu(), [l.cpu() for l in lab2])
+    assert abs(float(out2.loss) - float(ref2)) < 1e-4 * max(1.0, abs(float(ref2)))
     llm.generation_config.eos_token_id = None
     assert torch.equal(llm.generate(inputs_embeds=x, max_new_tokens=32).cpu(), t(g["ids_noeos"]))
     llm.generation_config.eos_token_id = list(cfg.eos_token_ids)
@@ -303,3 +315,121 @@ def test_whisper_path_logmel_and_encoder_vs_reference_fixture(dtype, tol):
         enc(feats[:, :, :-2])
     # the trainer-side crop (ref:trainer.py:280-291)
     assert utils.compute_num_audio_embeds(20000) <= out.shape[1]
+
+
+def test_whisper_generate_audio_response_matches_reference_trainer_path():
+    """BASELINE configs[3] end to end through LLMSpeechTextInference with `base: whisper`: log-mel -> encoder -> crop to
+    compute_num_audio_embeds -> prompt -> greedy decode; ids identical (fp32) to the fixture generated with the reference's
+    AudioEncoder + HF feature extractor + AudioLlamaForCausalLM in the trainer's order of operations."""
+    from oracle.golden_cfgs import TINY_WHISPER as WC
+    g = golden("whisper_pipeline_tiny")
+    cfg = TINY_LLAMA
+    conf = cfgm.from_dict(dict(audio=dict(sampling_rate=16000),
+                               model=dict(audio_encoder=dict(base="whisper", type="synthetic", downsample_method="pool", downsample_factor=4,
+                                                             pooling=dict(kernel_size=8, stride=4)),
+                                          llm_embedding_channels=cfg.hidden_size, llm_type=utils.LLAMA_ID)))
+    arch = weights.WhisperArch(WC.d_model, WC.encoder_layers, WC.encoder_attention_heads, WC.encoder_ffn_dim, WC.num_mel_bins, WC.max_source_positions)
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=torch.float32, arch=arch)
+    enc.load_state_dict(ri.whisper_encoder_state_dict(WC, cfg.hidden_size, seed=int(g["enc_seed"]))).eval().to(DEV)
+    llm, _ = make_llama(cfg, int(g["llm_seed"]), torch.float32)
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: t(g["prefix_ids"]), utils.LLAMA_PROMPT_SUFFIX: t(g["suffix_ids"]), "EXTRA": t(g["text_prompt_ids"])})
+    inf = inf_mod.LLMSpeechTextInference(conf, None, DEV, tokenizer=tok, llm=llm, audio_encoder=enc, dtype=torch.float32)
+    for i, (n, seed) in enumerate(zip(g["n_samples"], g["wave_seeds"])):
+        wave = ri.synthetic_waveform(int(n), seed=int(seed)).numpy()
+        assert inf._whisper_audio_embeds(wave).shape[1] == int(g[f"num_audio_embeds_{i}"]) == utils.compute_num_audio_embeds(int(n))
+        inf.generate_audio_response(wave, max_new_tokens=32)
+        assert torch.equal(inf.last_generate_ids.cpu(), t(g[f"ids_audio_{i}"])), i
+        inf.generate_audio_response(wave, additional_text_prompt="EXTRA", max_new_tokens=32)
+        assert torch.equal(inf.last_generate_ids.cpu(), t(g[f"ids_text_audio_{i}"])), i
+
+
+def _write_hf_llama_dir(path, cfg, sd, bos, eos, pad=None):
+    """config.json + model.safetensors in the HF layout AudioLlamaForCausalLM.from_pretrained reads (ref:inference.py:47-52)."""
+    import json
+    from safetensors.torch import save_file
+    hf = dict(architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+              num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+              intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+              rope_scaling=(dict(cfg.rope_scaling, rope_type="llama3") if cfg.rope_scaling else None), tie_word_embeddings=cfg.tie_word_embeddings,
+              bos_token_id=bos, eos_token_id=eos, pad_token_id=pad, torch_dtype="float32")
+    with open(path / "config.json", "w") as f:
+        json.dump(hf, f)
+    keys = sorted(sd)
+    half = len(keys) // 2                      # two shards, like a hub checkpoint
+    save_file({k: sd[k].contiguous() for k in keys[:half]}, str(path / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[half:]}, str(path / "model-00002-of-00002.safetensors"))
+
+
+@pytest.mark.parametrize("family", ["llama3", "minichat"])
+def test_reference_constructor_path_real_tokenizer_safetensors_and_local_hubert(tmp_path, family):
+    """SURVEY §8 f1 + f2: `LLMSpeechTextInference(config, checkpoint_path, device)` with NOTHING injected — AutoTokenizer from a
+    local directory (a byte-level BPE shaped like Llama-3's / a SentencePiece model shaped like MiniChat's, tests/golden/tokenizers),
+    AudioLlamaForCausalLM.from_pretrained over sharded safetensors, the HuBERT architecture from a local config.json, the flat
+    encoder checkpoint under the released spelling (weight_g / weight_v) via torch.load.  generate_audio_response (with and
+    without additional_text_prompt) and generate_text_response must produce the oracle's greedy ids for the ids this tokenizer
+    yields, and the text it decodes from them (skip_special_tokens)."""
+    import json
+    import shutil
+    rec = json.load(open(os.path.join(GOLDEN, "tokenizers", "tokenizer_ids.json")))[family]
+    name = "Llama-3.2-3B-Instruct" if family == "llama3" else "MiniChat-2-3B"
+    llm_dir = tmp_path / name
+    shutil.copytree(os.path.join(GOLDEN, "tokenizers", name), llm_dir)
+    base = TINY_LLAMA if family == "llama3" else TINY_MHA
+    import dataclasses
+    cfg = dataclasses.replace(base, vocab_size=512, eos_token_ids=(rec["eos_token_id"],), pad_token_id=None)
+    sd = ri.llama_state_dict(cfg, seed=77)
+    _write_hf_llama_dir(llm_dir, cfg, sd, rec["bos_token_id"], rec["eos_token_id"])
+    hub_dir = tmp_path / "hubert-tiny"
+    hub_dir.mkdir()
+    hc = TINY_HUBERT
+    json.dump(dict(model_type="hubert", conv_dim=list(hc.conv_dim), conv_kernel=list(hc.conv_kernel), conv_stride=list(hc.conv_stride),
+                   hidden_size=hc.hidden_size, num_hidden_layers=hc.num_hidden_layers, num_attention_heads=hc.num_attention_heads,
+                   intermediate_size=hc.intermediate_size, num_conv_pos_embeddings=hc.num_conv_pos_embeddings,
+                   num_conv_pos_embedding_groups=hc.num_conv_pos_embedding_groups, layer_norm_eps=hc.layer_norm_eps, feat_extract_norm="layer",
+                   do_stable_layer_norm=True), open(hub_dir / "config.json", "w"))
+    enc_sd = ri.hubert_encoder_state_dict(hc, cfg.hidden_size, seed=78, weight_norm_keys="legacy")
+    ckpt = tmp_path / "audio_encoder.pt"
+    torch.save(enc_sd, ckpt)                                          # flat state-dict, what ref:inference.py:24-26 loads
+    conf = cfgm.from_dict(dict(audio=dict(sampling_rate=16000),
+                               model=dict(audio_encoder=dict(base="hubert", type=str(hub_dir), downsample_method="pool", downsample_factor=4,
+                                                             pooling=dict(kernel_size=8, stride=4)),
+                                          llm_embedding_channels=cfg.hidden_size, llm_type=str(llm_dir))))
+    inf = inf_mod.LLMSpeechTextInference(conf, str(ckpt), torch.device(DEV), dtype=torch.float32)
+    tok = inf.llm_tokenizer
+    assert tok.pad_token == tok.eos_token and tok.padding_side == "left"
+    # the four template strings tokenise to the recorded ids (f1), through the object the inference class built itself
+    for key in ("prefix", "suffix", "text_prompt", "additional_text_prompt"):
+        assert tok(rec["strings"][key], return_tensors="pt").input_ids[0].tolist() == rec["ids"][key], key
+    if family == "llama3":
+        assert len(rec["ids"]["prefix"]) == 9 and len(rec["ids"]["suffix"]) == 6      # BOS included: 9 + P + 5 prompt rows
+    prefix_ids, suffix_ids = t(rec["ids"]["prefix"])[None], t(rec["ids"]["suffix"])[None]
+    extra_ids = t(rec["ids"]["additional_text_prompt"])[None]
+    wave = ri.synthetic_waveform(24000, seed=5)
+    ref_audio = ho.audio_encoder_forward(enc_sd, hc, wave[None])
+    for extra_text, extra in (("", None), (rec["strings"]["additional_text_prompt"], extra_ids)):
+        text = inf.generate_audio_response(wave.numpy(), additional_text_prompt=extra_text, max_new_tokens=24)
+        ref = ko.generate_audio_response_ids(sd, cfg, ref_audio, prefix_ids, suffix_ids, extra, max_new_tokens=24)
+        assert torch.equal(inf.last_generate_ids.cpu(), ref)
+        assert text == tok.batch_decode(ref, skip_special_tokens=True, clean_up_tokenization_spaces=True)[0]
+    # generate_text_response: f"{prefix} {input_text}{suffix} " (ref:inference.py:78, spaces kept)
+    text = inf.generate_text_response("hello world", max_new_tokens=16)
+    prompt_ids = t(rec["ids"]["text_prompt"])[None]
+    ref = lo.greedy_generate(sd, cfg, sd["model.embed_tokens.weight"][prompt_ids], 16, use_eos=True)
+    assert torch.equal(inf.last_generate_ids.cpu(), ref)
+    assert text == tok.batch_decode(ref, skip_special_tokens=True, clean_up_tokenization_spaces=True)[0]
+    # f2: the safetensors loader on its own — logits of a forward pass equal the oracle on the same state dict
+    llm2 = llama_mod.AudioLlamaForCausalLM.from_pretrained(str(llm_dir), use_cache=True, torch_dtype=torch.float32).eval().to(DEV)
+    x = torch.randn(1, 11, cfg.hidden_size, generator=torch.Generator().manual_seed(3)) * 0.05
+    assert rel_err(llm2(inputs_embeds=x.to(DEV)).logits.cpu(), lo.llama_forward(sd, cfg, x)["logits"]) < F32_TOL
+
+
+def test_utils_soft_cross_entropy_drop_in():
+    """ref:utils.py:167-178 through the package's `utils` mirror (and the root `utils` import path)."""
+    import utils as root_utils
+    gen = torch.Generator().manual_seed(9)
+    s, tch = torch.randn(1, 7, 1000, generator=gen) * 3, torch.randn(1, 7, 1000, generator=gen) * 3
+    ref = ko.soft_cross_entropy(s, tch)
+    out = root_utils.soft_cross_entropy(s.to(DEV), tch.to(DEV))
+    assert out.dim() == 0 and abs(float(out) - float(ref)) < 1e-5 * abs(float(ref))
+    per = utils.soft_cross_entropy(s.to(DEV), tch.to(DEV), reduction="none")
+    assert per.shape == (1, 7) and abs(float(per.mean()) - float(ref)) < 1e-5 * abs(float(ref))

@@ -268,7 +268,18 @@ def test_trainer_loop_validate_checkpoint_roundtrip(tmp_path):
     assert tr.step == 8 and not torch.equal(w0, tr.kd.master["embed_projection.weight"])
     ck_path = tmp_path / "ckpt" / "t" / "epoch_0_step_8.pt"
     ck = torch.load(ck_path, map_location="cpu", weights_only=False)
-    assert set(ck) == {"audio_encoder", "optimizer", "lr_scheduler", "epoch", "step"} and ck["step"] == 8
+    assert set(ck) >= {"audio_encoder", "optimizer", "lr_scheduler", "epoch", "step"} and ck["step"] == 8
+    # the optimizer state is written in the reference's layout (ref:trainer.py:98-105): group 0 = every encoder parameter in
+    # audio_encoder.parameters() order, group 1 = the frozen LLM's parameters (no state)
+    groups = ck["optimizer"]["param_groups"]
+    n_enc = len(ck["audio_encoder"])
+    assert len(groups) == 2 and groups[0]["params"] == list(range(n_enc))
+    assert groups[1]["params"] == list(range(n_enc, n_enc + 2 + 9 * TINY_LLAMA.num_hidden_layers))
+    names = pkg("weights").reference_param_order(ck["audio_encoder"].keys())
+    i_proj = names.index("embed_projection.weight")
+    assert ck["optimizer"]["state"][i_proj]["exp_avg"].shape == ck["audio_encoder"]["embed_projection.weight"].shape
+    assert all(i < n_enc for i in ck["optimizer"]["state"])
+    assert names.index("encoder.masked_spec_embed") not in ck["optimizer"]["state"] or tr.kd.reg is not None
     assert torch.equal(ck["audio_encoder"]["embed_projection.weight"], tr.kd.master["embed_projection.weight"].cpu())
     lines = [l for l in open(tmp_path / "logs" / "t" / "metrics.jsonl")]
     assert any("validation/audio_perplexity" in l for l in lines) and any("train/ntp_loss" in l for l in lines)
@@ -283,6 +294,16 @@ def test_trainer_loop_validate_checkpoint_roundtrip(tmp_path):
     tr2 = trainer_mod.Trainer(args2, conf, DEV, tokenizer=tok, llm=llm, audio_encoder=enc3, train_dataset=train_ds, val_dataset=val_ds,
                               dtype=torch.float32)
     assert tr2.step == 8 and tr2.start_epoch == 0 and torch.equal(tr2.kd.master["embed_projection.weight"], tr.kd.master["embed_projection.weight"])
+    assert tr2.kd.micro_batches == tr.kd.micro_batches
+    st, st2 = tr.optimizer.state[tr.kd._param["embed_projection.weight"]], tr2.optimizer.state[tr2.kd._param["embed_projection.weight"]]
+    assert torch.equal(st["exp_avg_sq"], st2["exp_avg_sq"]) and float(st["step"]) == float(st2["step"]) == 2
+    # a checkpoint under the OTHER weight-norm spelling (torch < 2.1 wrote weight_g / weight_v: the released checkpoint) resumes too
+    enc4, _ = make_encoder(TINY_HUBERT, TINY_LLAMA.hidden_size, 51, torch.float32, weight_norm_keys="legacy")
+    tr3 = trainer_mod.Trainer(SimpleNamespace(run_name="t3", checkpoint_path=str(ck_path), gpu_idx=0), conf, DEV, tokenizer=tok, llm=llm,
+                              audio_encoder=enc4, train_dataset=train_ds, val_dataset=val_ds, dtype=torch.float32)
+    g_key = "encoder.encoder.pos_conv_embed.conv.weight_g"
+    assert g_key in tr3.kd.master and torch.equal(tr3.kd.master[g_key].cpu(), ck["audio_encoder"]["encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original0"])
+    assert rel_err(tr3.audio_encoder(wave).cpu(), tr.audio_encoder(wave).cpu()) < 1e-6
 
 
 def test_trainer_loop_whisper_base(tmp_path):
@@ -326,3 +347,47 @@ def test_trainer_loop_whisper_base(tmp_path):
     ck = torch.load(tmp_path / "ckpt" / "w" / "epoch_0_step_4.pt", map_location="cpu", weights_only=False)
     assert torch.equal(ck["audio_encoder"]["encoder.conv2.weight"], tr.kd.master["encoder.conv2.weight"].cpu())
     assert any("validation/audio_perplexity" in l for l in open(tmp_path / "logs" / "w" / "metrics.jsonl"))
+
+
+def test_validate_perplexities_match_reference_fixture(tmp_path):
+    """Trainer.validate (ref:trainer.py:400-514) on a 5-sample validation set — audio-prompt and text-prompt
+    perplexities exp(mean(nll)) equal the values the reference's own classes produced (tests/golden/validation_tiny.npz, fp32),
+    and the per-sample losses equal the reference's."""
+    from types import SimpleNamespace
+    from test_models_gpu import StubTokenizer
+    trainer_mod = pkg("trainer")
+    g, v = golden("pipeline_tiny"), golden("validation_tiny")
+    gen = torch.Generator().manual_seed(int(v["gen_seed"]))
+    V = TINY_LLAMA.vocab_size
+    val_ds = []
+    for i, n in enumerate(v["n_samples"]):
+        text_ids = torch.randint(1, V, (6 - i % 2,), generator=gen)
+        resp_ids = torch.randint(1, V, (7 + i % 3,), generator=gen)
+        bos = torch.zeros(1, dtype=torch.long)
+        val_ds.append({"audio": {"array": ri.synthetic_waveform(int(n), seed=int(n))}, "text": f"utt{n}", "text_input_ids": torch.cat([bos, text_ids]),
+                       "response_input_ids": torch.cat([bos, resp_ids])[None], "pool_ranges_4": []})
+    conf = cfgm.from_dict(dict(seed_everything=1234, audio=dict(sampling_rate=16000),
+                               model=dict(audio_encoder=dict(base="hubert", type="synthetic", downsample_method="pool", downsample_factor=4,
+                                                             pooling=dict(kernel_size=8, stride=4)),
+                                          llm_embedding_channels=TINY_LLAMA.hidden_size, llm_type=utils.LLAMA_ID),
+                               train=dict(optimizer=dict(lr=5e-5, beta1=0.9, beta2=0.999), batch_size=1, grad_accum_interval=4, epochs=1,
+                                          use_ld_loss=True, use_fd_loss=True, ntp_loss_weight=0.5, ld_loss_weight=0.5, fd_loss_weight=1.0,
+                                          fd_loss_connector_layers=[0, 1, 3]),
+                               log=dict(checkpoint_dir=str(tmp_path / "ckpt"), log_dir=str(tmp_path / "logs"), log_interval=4,
+                                        validation_interval=1000, num_generate_samples=2)))
+    enc, _ = make_encoder(TINY_HUBERT, TINY_LLAMA.hidden_size, int(v["enc_seed"]), torch.float32)
+    llm, _ = make_llama(TINY_LLAMA, int(v["llm_seed"]), torch.float32)
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: t(g["prefix_ids"]), utils.LLAMA_PROMPT_SUFFIX: t(g["suffix_ids"])})
+    tr = trainer_mod.Trainer(SimpleNamespace(run_name="v", checkpoint_path=None, gpu_idx=0), conf, DEV, tokenizer=tok, llm=llm, audio_encoder=enc,
+                             train_dataset=val_ds, val_dataset=val_ds, dtype=torch.float32)
+    out = tr.validate(0)
+    assert abs(out["validation/audio_perplexity"] - float(v["audio_perplexity"])) < 1e-4 * float(v["audio_perplexity"])
+    assert abs(out["validation/text_perplexity"] - float(v["text_perplexity"])) < 1e-4 * float(v["text_perplexity"])
+    emb = llm.model.embed_tokens
+    for i in range(len(val_ds)):
+        audio_embeds, text_ids, resp, _ = tr._val_sample(i)
+        pre, suf = emb(tr.prefix_ids.to(DEV)), emb(tr.suffix_ids.to(DEV))[:, 1:]
+        a_seq = torch.cat([pre, audio_embeds, suf, emb(resp[None])[:, 1:]], dim=1)
+        assert abs(float(llm(inputs_embeds=a_seq, labels=[resp]).loss) - float(v["audio_nll"][i])) < 1e-4 * float(v["audio_nll"][i]), i
+    line = [l for l in open(tmp_path / "logs" / "v" / "metrics.jsonl")][-1]
+    assert "validation/audio_perplexity" in line and "audio_response" in line

@@ -22,10 +22,16 @@ if __name__ == '__main__':
     parser.add_argument('-p', '--checkpoint_path', type=str, default=None, help="path of checkpoint to resume from")
     args = parser.parse_args()
     import torch
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    import datetime
+    distributed = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if distributed:
         args.gpu_idx = int(os.environ["LOCAL_RANK"])
-        torch.cuda.set_device(args.gpu_idx)
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{args.gpu_idx}"))
+    # libspeechllm launches on the current HIP device / stream: make -g N current before anything is allocated
+    torch.cuda.set_device(args.gpu_idx)
+    if distributed:
+        # validation (sharded over the ranks) ends at a barrier behind rank 0's sample generations + checkpoint write:
+        # give collectives a generous watchdog
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{args.gpu_idx}"), timeout=datetime.timedelta(hours=2))
     device = torch.device(f"cuda:{args.gpu_idx}")
     config = importlib.import_module("llm-speech-summarization_amd.config").load_config(args.config)
     dtype = torch.float32 if str(config.get("runtime", {}).get("dtype", "bf16")) == "fp32" else torch.bfloat16
