@@ -161,6 +161,22 @@ int sl_posconv_stage(const void* x, void* xg, int64_t T, int32_t H, int32_t grou
 int sl_avgpool_rows(const void* x, void* y, int64_t T, int32_t H, int32_t kernel, int32_t stride,
                     const int32_t* ranges, int64_t P, int32_t dtype, sl_stream stream);
 
+/* Whole-ragged-batch forms of the three front-end / head stages (one launch for every utterance of a packed batch; the
+ * encoder runtime and the KD tape use these: a single 10 s clip is only ~1 300 waves of conv0 work).
+ *   sl_hubert_conv0_batch: utterance u has samples [sample_offsets[u], sample_offsets[u+1]) of `waves` and writes rows
+ *     [row_offsets[u], row_offsets[u+1]) of out (both int64 device arrays of n_utt + 1 entries); max_L = longest output.
+ *   sl_posconv_stage_batch: frames cu[u] .. cu[u] + klen[u] of x; utterance u's staged (groups, T_u + k, H/groups) block
+ *     starts (cu[u] + u k) * H elements into xg.
+ *   sl_avgpool_batch: rec = int64 (n_utt, 4) device records {pooled rows P_u, element offset of the utterance's rows in y, -, -};
+ *     frames cu[u] .. of x (ref:model/audio_encoder.py:59-63). */
+int sl_hubert_conv0_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev, int32_t n_utt,
+                          int64_t max_L, const float* w, const float* bias, const float* gamma, const float* beta, void* out, int32_t C,
+                          int32_t k, int32_t stride, float eps, int32_t dtype, sl_stream stream);
+int sl_posconv_stage_batch(const void* x, void* xg, const int32_t* cu, const int32_t* klen, int32_t n_utt, int64_t max_T, int32_t H,
+                           int32_t groups, int32_t k, int32_t dtype, sl_stream stream);
+int sl_avgpool_batch(const void* x, void* y, const int32_t* cu, const int32_t* klen, const int64_t* rec, int32_t n_utt, int64_t max_P,
+                     int32_t H, int32_t kernel, int32_t stride, int32_t dtype, sl_stream stream);
+
 /* Embedding row gather (hf:...llama.py:380-381; ref:utils.py:63-64). ids int32 on device. */
 int sl_embed_gather(const void* table, const int32_t* ids, void* out, int64_t n, int32_t cols,
                     int32_t dtype, sl_stream stream);
@@ -187,8 +203,42 @@ typedef struct {
    * The softmax normaliser is the undropped sum. */
   float dropout_p;
   uint64_t dropout_seed;
+  /* training: when non-NULL receives the log-sum-exp of every (query row, head) of the packed batch — float
+   * [n_tok_q][n_heads], natural log of sum_j exp(scale * q.k_j) over the visible keys (undropped) — which sl_attn_bwd
+   * recomputes the probabilities from. */
+  float* lse;
 } sl_attn_args;
 int sl_attn_fwd(const sl_attn_args* a, sl_stream stream);
+
+/* Flash-style attention BACKWARD for the same packed layouts (the KD step's data gradients through the frozen Llama,
+ * data + parameter gradients through the HuBERT / Whisper encoder; autograd of hf:...hubert.py:234-259 /
+ * hf:...llama.py:191-213 in the reference, ref:trainer.py:373-374).  Given q, k, v, the forward output `out`, its
+ * gradient `d_out` and the forward's `lse`, writes dq (q's layout: rows cu_q[s]+t), dk and dv (k / v's layout: rows
+ * cu_k[s]+t, n_kv_heads heads — the query heads of a GQA group are summed inside the kernel).  The S x S probabilities are
+ * recomputed per tile and never stored; no atomics (results are bitwise reproducible).  `delta` is a float
+ * [n_tok_q][n_heads] workspace (rowsum(d_out * out), filled by the call).  dropout_p / dropout_seed must equal the forward's.
+ * Strides in elements; dq rows / heads must start on 4-element boundaries. */
+typedef struct {
+  const void* q; int64_t q_row_stride, q_head_stride;
+  const void* k; int64_t k_row_stride, k_head_stride;
+  const void* v; int64_t v_row_stride, v_head_stride;
+  const void* out; int64_t o_row_stride, o_head_stride;
+  const void* d_out; int64_t do_row_stride, do_head_stride;
+  void* dq; int64_t dq_row_stride, dq_head_stride;
+  void* dk; int64_t dk_row_stride, dk_head_stride;
+  void* dv; int64_t dv_row_stride, dv_head_stride;
+  const float* lse;
+  float* delta;
+  const int32_t* cu_q;   /* (nseq+1) device */
+  const int32_t* cu_k;   /* (nseq)   device */
+  const int32_t* klen;   /* (nseq)   device */
+  int64_t n_tok_q;       /* rows of q / out / d_out / dq (= cu_q[nseq]) */
+  int32_t nseq, max_qlen, max_klen, n_heads, n_kv_heads, head_dim, causal, dtype;
+  float scale;
+  float dropout_p;
+  uint64_t dropout_seed;
+} sl_attn_bwd_args;
+int sl_attn_bwd(const sl_attn_bwd_args* a, sl_stream stream);
 
 /* Backward-side companion of sl_attn_args.dropout_p for the explicit-probability backward: for every score matrix
  * z = seq * n_kv + kv_head of a packed batch ((n_mat, smax, ld) buffers, dims[z] valid rows / columns, query head
@@ -292,6 +342,18 @@ int sl_soft_ce_loss(const float* student, const float* teacher, int64_t rows, in
                     void* dstudent, int32_t accumulate, int32_t dtype, sl_stream stream);
 int sl_mse_loss(const void* a, const void* b, int64_t n, float coef, float* loss, void* da, int32_t accumulate,
                 int32_t dtype, sl_stream stream);
+/* The KD step's losses for a whole accumulation window in single launches (ref:trainer.py:325-370; what the per-utterance
+ * forms above do one utterance and one term at a time):
+ *   sl_kd_logit_losses: row r of the packed tail logits (student / teacher: float (rows, V)) carries
+ *     labels[r] (int32, < 0: no next-token term), row_coef[r] = {ce loss, ce grad, soft-ce loss, soft-ce grad} weights and
+ *     row_slot[r] = its utterance; losses (n_slots, loss_ld) float: [slot][0] += ce, [slot][1] += soft-ce;
+ *     dstudent (rows, V) of `dtype` is OVERWRITTEN with the summed gradient.  teacher may be NULL (no soft-ce).
+ *   sl_kd_mse_rows: feature-distillation MSE of one hidden-state tap: row_coef[r] = {loss weight on sum_h d^2, gradient
+ *     weight on d}; losses[slot][loss_col] += ...; da (rows, H) overwritten with the gradient (may be NULL). */
+int sl_kd_logit_losses(const float* student, const float* teacher, const int32_t* labels, const float* row_coef, const int32_t* row_slot,
+                       int64_t rows, int32_t V, float* losses, int32_t loss_ld, void* dstudent, int32_t dtype, sl_stream stream);
+int sl_kd_mse_rows(const void* a, const void* b, const float* row_coef, const int32_t* row_slot, int64_t rows, int32_t H, float* losses,
+                   int32_t loss_ld, int32_t loss_col, void* da, int32_t dtype, sl_stream stream);
 /* HuBERT front-end backward: AvgPool1d, strided-conv data gradient (col2im of the dgrad GEMM output),
  * fused conv0 (recomputes conv+LN, accumulates fp32 grads of w (C,k), bias, gamma, beta). */
 int sl_avgpool_bwd(const void* dy, void* dx, int64_t T, int32_t H, int32_t kernel, int32_t stride, int64_t P, int32_t dtype,

@@ -54,6 +54,21 @@ class AttnArgs(C.Structure):
                 ("cu_q", c_vp), ("cu_k", c_vp), ("klen", c_vp),
                 ("nseq", c_i32), ("max_qlen", c_i32), ("n_heads", c_i32), ("n_kv_heads", c_i32),
                 ("head_dim", c_i32), ("causal", c_i32), ("dtype", c_i32), ("reserved", c_i32),
+                ("scale", c_f32), ("dropout_p", c_f32), ("dropout_seed", C.c_uint64), ("lse", c_vp)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", c_vp), ("q_row_stride", c_i64), ("q_head_stride", c_i64),
+                ("k", c_vp), ("k_row_stride", c_i64), ("k_head_stride", c_i64),
+                ("v", c_vp), ("v_row_stride", c_i64), ("v_head_stride", c_i64),
+                ("out", c_vp), ("o_row_stride", c_i64), ("o_head_stride", c_i64),
+                ("d_out", c_vp), ("do_row_stride", c_i64), ("do_head_stride", c_i64),
+                ("dq", c_vp), ("dq_row_stride", c_i64), ("dq_head_stride", c_i64),
+                ("dk", c_vp), ("dk_row_stride", c_i64), ("dk_head_stride", c_i64),
+                ("dv", c_vp), ("dv_row_stride", c_i64), ("dv_head_stride", c_i64),
+                ("lse", c_vp), ("delta", c_vp), ("cu_q", c_vp), ("cu_k", c_vp), ("klen", c_vp), ("n_tok_q", c_i64),
+                ("nseq", c_i32), ("max_qlen", c_i32), ("max_klen", c_i32), ("n_heads", c_i32), ("n_kv_heads", c_i32),
+                ("head_dim", c_i32), ("causal", c_i32), ("dtype", c_i32),
                 ("scale", c_f32), ("dropout_p", c_f32), ("dropout_seed", C.c_uint64)]
 
 
@@ -125,6 +140,8 @@ _PROTOS = {
     "sl_ce_loss": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sl_soft_ce_loss": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "sl_mse_loss": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "sl_kd_logit_losses": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "sl_kd_mse_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "sl_avgpool_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "sl_col2im": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_hubert_conv0_bwd_batch": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp,
@@ -136,8 +153,12 @@ _PROTOS = {
     "sl_hubert_conv0": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sl_posconv_stage": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_avgpool_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp]),
+    "sl_hubert_conv0_batch": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "sl_posconv_stage_batch": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sl_avgpool_batch": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_embed_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "sl_attn_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
+    "sl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),
     "sl_rope_kv_append": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_attn_decode": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sl_greedy_select": (c_i32, [c_vp, c_i32, c_i32, C.POINTER(c_i32), c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -14,7 +14,7 @@ void sl_set_error(const char* fmt, ...) {
 
 extern "C" const char* sl_last_error(void) { return g_err; }
 
-extern "C" int sl_version(void) { return 1; }
+extern "C" int sl_version(void) { return 2; }
 
 extern "C" int sl_device_arch(char* buf, int n) {
   SL_CHECK_ARG(buf != nullptr && n > 0, "sl_device_arch: bad buffer");

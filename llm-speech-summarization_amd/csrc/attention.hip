@@ -18,6 +18,7 @@ struct AttnP {
   uint32_t drop_thr;     // training mode: keep iff u24(hash) >= drop_thr (0 = no dropout); see sl_attn_args.dropout_p
   float drop_scale;
   uint64_t drop_seed;
+  float* lse;            // training mode: log-sum-exp per (query row, head), natural log (NULL = not wanted)
 };
 
 // swizzled byte offset of 16-byte chunk `ch` of row `row`; rows hold `cpr` chunks (8, 16 or 32)
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     T* orow = ob + (int64_t)(q0 + qi) * p.o_rs;
 #pragma unroll
     for (int n = 0; n < NF_O; ++n) orow[n * 16 + r] = from_f32<T>(o[n][i] * inv);
+    if (p.lse && r == 0) p.lse[((int64_t)q0 + qi) * p.n_heads + head] = l_run[i] > 0.f ? m_run[i] + logf(l_run[i]) : -INFINITY;
   }
 }
 
@@ -422,6 +424,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
     const int qi = qw0 + t * 16 + r;
     if (qi >= qlen) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (p.lse && q == 0)   // m_run is in the log2 domain (scores scaled by scale * log2 e)
+      p.lse[((int64_t)q0 + qi) * p.n_heads + head] = l > 0.f ? (m_run[t] + log2f(l)) * 0.6931471805599453f : -INFINITY;
     T* orow = ob + (int64_t)(q0 + qi) * p.o_rs + 4 * q;
 #pragma unroll
     for (int n = 0; n < NF_O; ++n)
@@ -439,6 +443,7 @@ static int launch_attn(const sl_attn_args* a, hipStream_t st) {
   p.cu_q = a->cu_q; p.cu_k = a->cu_k; p.klen = a->klen;
   p.n_heads = a->n_heads; p.n_kv = a->n_kv_heads; p.scale = a->scale;
   p.drop_thr = 0; p.drop_scale = 1.f; p.drop_seed = a->dropout_seed;
+  p.lse = a->lse;
   if (a->dropout_p > 0.f) {
     p.drop_thr = (uint32_t)((double)a->dropout_p * 16777216.0);
     p.drop_scale = 1.0f / (1.0f - a->dropout_p);

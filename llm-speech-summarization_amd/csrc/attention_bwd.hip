@@ -1,0 +1,436 @@
+// attention_bwd.hip — flash-style attention BACKWARD on MFMA for packed variable-length sequences (KD step):
+// the S x S probabilities are recomputed tile by tile from q, k and the forward's log-sum-exp, never stored.
+//   HuBERT / Whisper: head_dim 64, bidirectional, optional dropout of the probabilities (hf:models/hubert/modeling_hubert.py:234-259)
+//   Llama (frozen, data gradients only): head_dim 128, causal, GQA (hf:models/llama/modeling_llama.py:191-213)
+// With S = scale q k^T, P = softmax(S), Pd = dropout(P), O = Pd v and delta_i = sum_d dO_id O_id:
+//   dV = Pd^T dO,   dPd = dO v^T,   dS = P o (mask/(1-p) o dPd - delta),   dQ = scale dS k,   dK = scale dS^T q.
+// Two kernels, no atomics (bitwise reproducible):
+//   * attn_bwd_dkdv_kernel — one block per (sequence, kv head, 64 keys); a wave keeps 16 keys' K / V fragments and their dK / dV
+//     accumulators in registers and sweeps the query tiles of every query head of its GQA group.  S and dP are computed with
+//     the QUERY on the accumulator row and the key on the lane (S = Q K^T), so that P and dS, packed, are directly the A
+//     operands of dV += Pd^T dO and dK += dS^T Q (fp32: the accumulator as it stands; bf16: two 16-query fragments interleaved,
+//     contraction slot 8a+i <-> query 4a+i of the even fragment, 8a+4+i <-> the odd one, and the transposed Q / dO images are
+//     stored with their columns in that order).
+//   * attn_bwd_dq_kernel — one block per (sequence, head, 64 queries); a wave keeps 16 queries' q / dO fragments, lse and delta
+//     and sweeps the key tiles: S^T = K Q^T puts the key on the accumulator row, dS^T packed is the B operand of
+//     dQ^T += K^T dS^T (K^T image with permuted columns, as above), the epilogue stores 4 consecutive dims per lane.
+// Both run on the dtype-generic 16x16 MFMA step (bf16 16x16x32 / exact-fp32 16x16x4), so the fp32 parity mode and the bf16
+// mode share the code; tiles are staged through XOR-swizzled LDS.
+#include "common.h"
+
+struct AttnBwdP {
+  const void* q; int64_t q_rs, q_hs;
+  const void* k; int64_t k_rs, k_hs;
+  const void* v; int64_t v_rs, v_hs;
+  const void* o; int64_t o_rs, o_hs;
+  const void* dout; int64_t do_rs, do_hs;
+  void* dq; int64_t dq_rs, dq_hs;
+  void* dk; int64_t dk_rs, dk_hs;
+  void* dv; int64_t dv_rs, dv_hs;
+  const float* lse;
+  float* delta;
+  const int32_t* cu_q; const int32_t* cu_k; const int32_t* klen;
+  int64_t n_tok_q;
+  int n_heads, n_kv;
+  float scale;
+  uint32_t drop_thr;
+  float drop_scale;
+  uint64_t drop_seed;
+};
+
+namespace {
+
+// swizzled byte offset of 16-byte chunk `ch` of row `row`; rows hold CPR chunks (power of two)
+template <int CPR>
+__device__ __forceinline__ int swz(int row, int ch) {
+  constexpr int MASK = (CPR < 16 ? CPR : 16) - 1;
+  return row * (CPR * 16) + ((ch ^ (row & MASK)) << 4);
+}
+
+// column of tile row `row` inside a transposed image: bf16 interleaves the two 16-row fragments of a 32-row group so that
+// the 8 contraction slots a lane supplies (8a .. 8a+7) are rows {4a..4a+3} of the even fragment then of the odd one
+template <typename T>
+__device__ __forceinline__ int tpos(int row) {
+  if constexpr (sizeof(T) == 2) return (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
+  else return row;
+}
+
+template <typename T> __device__ __forceinline__ float exp_scaled(float x) {   // exp(x)
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+  else return expf(x);
+}
+
+// pack accumulator fragments into the A / B operand of one k-step over the tile's rows
+template <typename T, int NFR>
+__device__ __forceinline__ uint4 pack_step(const f32x4 (&x)[NFR], int ks) {
+  if constexpr (sizeof(T) == 2) {
+    return make_uint4(pack2_bf16(x[2 * ks][0], x[2 * ks][1]), pack2_bf16(x[2 * ks][2], x[2 * ks][3]),
+                      pack2_bf16(x[2 * ks + 1][0], x[2 * ks + 1][1]), pack2_bf16(x[2 * ks + 1][2], x[2 * ks + 1][3]));
+  } else {
+    return make_uint4(__builtin_bit_cast(uint32_t, x[ks][0]), __builtin_bit_cast(uint32_t, x[ks][1]),
+                      __builtin_bit_cast(uint32_t, x[ks][2]), __builtin_bit_cast(uint32_t, x[ks][3]));
+  }
+}
+
+// delta[t][h] = sum_d dO[t][h][d] * O[t][h][d]
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(AttnBwdP p) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int LPP = D / VEC;          // lanes per (token, head) pair
+  const int64_t pair = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPP;
+  const int sub = threadIdx.x % LPP;
+  const int64_t n_pairs = p.n_tok_q * p.n_heads;
+  float acc = 0.f;
+  if (pair < n_pairs) {
+    const int64_t t = pair / p.n_heads;
+    const int h = (int)(pair % p.n_heads);
+    const uint4 uo = *(const uint4*)((const T*)p.o + t * p.o_rs + (int64_t)h * p.o_hs + sub * VEC);
+    const uint4 ud = *(const uint4*)((const T*)p.dout + t * p.do_rs + (int64_t)h * p.do_hs + sub * VEC);
+    float fo[VEC], fd[VEC];
+    Vec16<T>::unpack(uo, fo);
+    Vec16<T>::unpack(ud, fd);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc += fo[j] * fd[j];
+  }
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (pair < n_pairs && sub == 0) p.delta[pair] = acc;
+}
+
+template <typename T, int D, bool CAUSAL, int TQ>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int KSTEP = MMA<T>::KSTEP;
+  constexpr int KS_D = D / KSTEP;       // k-steps across the head dim (S, dP)
+  constexpr int KS_Q = TQ / KSTEP;      // k-steps across the queries of a tile (dV, dK)
+  constexpr int NQF = TQ / 16;          // 16-query fragments per tile
+  constexpr int NF = D / 16;            // 16-wide fragments of the head dim
+  constexpr int CPR = D * SZ / 16;      // chunks per row of the row-major tiles
+  constexpr int CPT = TQ * SZ / 16;     // chunks per row of the transposed images
+  constexpr int TILE_B = TQ * D * SZ;
+  static_assert(TQ % KSTEP == 0 && CPT == 4 * KS_Q, "tile shape");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B + 2 * TQ * 4];
+  unsigned char* Qs = smem;
+  unsigned char* dOs = smem + TILE_B;
+  unsigned char* QT = smem + 2 * TILE_B;
+  unsigned char* dOT = smem + 3 * TILE_B;
+  float* lse_s = (float*)(smem + 4 * TILE_B);
+  float* dl_s = lse_s + TQ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, qd = lane >> 4;
+  const int seq = blockIdx.z, kvh = blockIdx.y;
+  const int rep = p.n_heads / p.n_kv;
+  const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
+  const int klen = p.klen[seq];
+  const int key0 = blockIdx.x * 64;
+  if (key0 >= klen) return;
+  const int shift = klen - qlen;        // causal: key j visible to query i iff j <= i + shift
+  const int64_t krow0 = p.cu_k[seq];
+
+  // this wave's 16 keys: K and V fragments (B operands of S = Q K^T and dP = dO V^T)
+  const int kj = key0 + wave * 16 + r;
+  uint4 kf[KS_D], vf[KS_D];
+  {
+    const int kc = kj < klen ? kj : klen - 1;
+    const T* kp = (const T*)p.k + (krow0 + kc) * p.k_rs + (int64_t)kvh * p.k_hs + qd * VEC;
+    const T* vp = (const T*)p.v + (krow0 + kc) * p.v_rs + (int64_t)kvh * p.v_hs + qd * VEC;
+#pragma unroll
+    for (int s = 0; s < KS_D; ++s) { kf[s] = *(const uint4*)(kp + s * KSTEP); vf[s] = *(const uint4*)(vp + s * KSTEP); }
+  }
+  f32x4 dk[NF], dv[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) { dk[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  int qt_first = 0;
+  if (CAUSAL) { const int i0 = key0 - shift; qt_first = i0 > 0 ? i0 / TQ : 0; }   // first query that sees a key of this block
+  const int n_qt = (qlen + TQ - 1) / TQ;
+
+  for (int h = 0; h < rep; ++h) {
+    const int head = kvh * rep + h;
+    const T* qb = (const T*)p.q + (int64_t)head * p.q_hs;
+    const T* dob = (const T*)p.dout + (int64_t)head * p.do_hs;
+    for (int qt = qt_first; qt < n_qt; ++qt) {
+      const int qt0 = qt * TQ;
+      __syncthreads();   // the previous tile's LDS reads are done
+      // stage Q and dO: row-major (A operands of S / dP) and transposed with permuted columns (B operands of dK / dV)
+      for (int c = tid; c < TQ * CPR; c += 256) {
+        const int row = c / CPR, ch = c % CPR;
+        int qi = qt0 + row; qi = qi < qlen ? qi : qlen - 1;
+        const uint4 uq = *(const uint4*)(qb + (int64_t)(q0 + qi) * p.q_rs + ch * VEC);
+        const uint4 ud = *(const uint4*)(dob + (int64_t)(q0 + qi) * p.do_rs + ch * VEC);
+        *(uint4*)(Qs + swz<CPR>(row, ch)) = uq;
+        *(uint4*)(dOs + swz<CPR>(row, ch)) = ud;
+        T eq[VEC], ed[VEC];
+        *(uint4*)eq = uq;
+        *(uint4*)ed = ud;
+        const int pos = tpos<T>(row);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const int d = ch * VEC + j;
+          const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
+          *(T*)(QT + off) = eq[j];
+          *(T*)(dOT + off) = ed[j];
+        }
+      }
+      if (tid < TQ) {
+        const int qi = qt0 + tid;
+        const bool ok = qi < qlen;
+        const int64_t idx = ((int64_t)q0 + (ok ? qi : qlen - 1)) * p.n_heads + head;
+        lse_s[tid] = p.lse[idx];
+        dl_s[tid] = p.delta[idx];
+      }
+      __syncthreads();
+
+      // S = Q K^T and dP = dO V^T for TQ queries x this wave's 16 keys: lane (key r, a = qd) holds queries n*16 + 4a + i
+      f32x4 s[NQF], dp[NQF];
+#pragma unroll
+      for (int n = 0; n < NQF; ++n) {
+        s[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS_D; ++ks) {
+          const uint4 aq = *(const uint4*)(Qs + swz<CPR>(n * 16 + r, ks * 4 + qd));
+          const uint4 ad = *(const uint4*)(dOs + swz<CPR>(n * 16 + r, ks * 4 + qd));
+          MMA<T>::step(s[n], aq, kf[ks]);
+          MMA<T>::step(dp[n], ad, vf[ks]);
+        }
+      }
+      // probabilities (recomputed from the forward's lse), dropout mask, dS
+#pragma unroll
+      for (int n = 0; n < NQF; ++n) {
+        const f32x4 ls = *(const f32x4*)(lse_s + n * 16 + 4 * qd);
+        const f32x4 dl = *(const f32x4*)(dl_s + n * 16 + 4 * qd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int qi = qt0 + n * 16 + 4 * qd + i;
+          bool ok = kj < klen && qi < qlen;
+          if (CAUSAL) ok = ok && (kj <= qi + shift);
+          float pv = ok ? exp_scaled<T>(s[n][i] * p.scale - ls[i]) : 0.f;
+          float dpv = dp[n][i];
+          float pd = pv;
+          if (p.drop_thr) {
+            const bool keep = dropout_keep(((((int64_t)q0 + qi) * p.n_heads + head) << 16) | (int64_t)kj, p.drop_seed, p.drop_thr);
+            pd = keep ? pv * p.drop_scale : 0.f;
+            dpv = keep ? dpv * p.drop_scale : 0.f;
+          }
+          s[n][i] = pd;                                    // Pd  -> dV += Pd^T dO
+          dp[n][i] = pv * (dpv - dl[i]) * p.scale;         // dS (scale folded) -> dK += dS^T Q
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS_Q; ++ks) {
+        const uint4 apd = pack_step<T, NQF>(s, ks);
+        const uint4 ads = pack_step<T, NQF>(dp, ks);
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          const uint4 bd = *(const uint4*)(dOT + swz<CPT>(n * 16 + r, ks * 4 + qd));
+          const uint4 bq = *(const uint4*)(QT + swz<CPT>(n * 16 + r, ks * 4 + qd));
+          MMA<T>::step(dv[n], apd, bd);
+          MMA<T>::step(dk[n], ads, bq);
+        }
+      }
+    }
+  }
+  // epilogue: lane (dim col r, a = qd) holds keys 4a + i of this wave, dim n*16 + r
+  T* dkb = (T*)p.dk + (int64_t)kvh * p.dk_hs;
+  T* dvb = (T*)p.dv + (int64_t)kvh * p.dv_hs;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kk = key0 + wave * 16 + 4 * qd + i;
+    if (kk >= klen) continue;
+    T* dkr = dkb + (krow0 + kk) * p.dk_rs;
+    T* dvr = dvb + (krow0 + kk) * p.dv_rs;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      dkr[n * 16 + r] = from_f32<T>(dk[n][i]);
+      dvr[n * 16 + r] = from_f32<T>(dv[n][i]);
+    }
+  }
+}
+
+template <typename T, int D, bool CAUSAL, int TK>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int KSTEP = MMA<T>::KSTEP;
+  constexpr int KS_D = D / KSTEP;
+  constexpr int KS_K = TK / KSTEP;      // k-steps across the keys of a tile (dQ)
+  constexpr int NKF = TK / 16;
+  constexpr int NF = D / 16;
+  constexpr int CPR = D * SZ / 16;
+  constexpr int CPT = TK * SZ / 16;
+  constexpr int TILE_B = TK * D * SZ;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * TILE_B];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + TILE_B;
+  unsigned char* KT = smem + 2 * TILE_B;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, qd = lane >> 4;
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int kvh = head / (p.n_heads / p.n_kv);
+  const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
+  const int klen = p.klen[seq];
+  const int qt0 = blockIdx.x * 64;
+  if (qt0 >= qlen) return;
+  const int shift = klen - qlen;
+  const int64_t krow0 = p.cu_k[seq];
+  const T* kb = (const T*)p.k + krow0 * p.k_rs + (int64_t)kvh * p.k_hs;
+  const T* vb = (const T*)p.v + krow0 * p.v_rs + (int64_t)kvh * p.v_hs;
+
+  // this wave's 16 queries: q and dO fragments (B operands of S^T = K Q^T and dP^T = V dO^T), lse and delta of query r
+  const int qi = qt0 + wave * 16 + r;
+  const int qc = qi < qlen ? qi : qlen - 1;
+  uint4 qf[KS_D], dof[KS_D];
+  {
+    const T* qp = (const T*)p.q + (int64_t)(q0 + qc) * p.q_rs + (int64_t)head * p.q_hs + qd * VEC;
+    const T* dp_ = (const T*)p.dout + (int64_t)(q0 + qc) * p.do_rs + (int64_t)head * p.do_hs + qd * VEC;
+#pragma unroll
+    for (int s = 0; s < KS_D; ++s) { qf[s] = *(const uint4*)(qp + s * KSTEP); dof[s] = *(const uint4*)(dp_ + s * KSTEP); }
+  }
+  const int64_t lidx = ((int64_t)q0 + qc) * p.n_heads + head;
+  const float lse_q = p.lse[lidx], dl_q = p.delta[lidx];
+  f32x4 dq[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int n_kt = (klen + TK - 1) / TK;
+  if (CAUSAL) {
+    const int last = qt0 + 63 + shift;   // largest key index any query of this block sees
+    const int lim = last < 0 ? 0 : last / TK + 1;
+    n_kt = lim < n_kt ? lim : n_kt;
+  }
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int key0 = kt * TK;
+    __syncthreads();
+    for (int c = tid; c < TK * CPR; c += 256) {
+      const int row = c / CPR, ch = c % CPR;
+      int kr = key0 + row; kr = kr < klen ? kr : klen - 1;
+      const uint4 uk = *(const uint4*)(kb + (int64_t)kr * p.k_rs + ch * VEC);
+      const uint4 uv = *(const uint4*)(vb + (int64_t)kr * p.v_rs + ch * VEC);
+      *(uint4*)(Ks + swz<CPR>(row, ch)) = uk;
+      *(uint4*)(Vs + swz<CPR>(row, ch)) = uv;
+      T ek[VEC];
+      *(uint4*)ek = uk;
+      const int pos = tpos<T>(row);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int d = ch * VEC + j;
+        *(T*)(KT + swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ) = ek[j];
+      }
+    }
+    __syncthreads();
+
+    // S^T = K Q^T, dP^T = V dO^T: lane (query r, a = qd) holds keys n*16 + 4a + i
+    f32x4 s[NKF], dp[NKF];
+#pragma unroll
+    for (int n = 0; n < NKF; ++n) {
+      s[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dp[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS_D; ++ks) {
+        const uint4 ak = *(const uint4*)(Ks + swz<CPR>(n * 16 + r, ks * 4 + qd));
+        const uint4 av = *(const uint4*)(Vs + swz<CPR>(n * 16 + r, ks * 4 + qd));
+        MMA<T>::step(s[n], ak, qf[ks]);
+        MMA<T>::step(dp[n], av, dof[ks]);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NKF; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kj = key0 + n * 16 + 4 * qd + i;
+        bool ok = kj < klen && qi < qlen;
+        if (CAUSAL) ok = ok && (kj <= qi + shift);
+        const float pv = ok ? exp_scaled<T>(s[n][i] * p.scale - lse_q) : 0.f;
+        float dpv = dp[n][i];
+        if (p.drop_thr) {
+          const bool keep = dropout_keep(((((int64_t)q0 + qc) * p.n_heads + head) << 16) | (int64_t)kj, p.drop_seed, p.drop_thr);
+          dpv = keep ? dpv * p.drop_scale : 0.f;
+        }
+        dp[n][i] = pv * (dpv - dl_q) * p.scale;
+      }
+    // dQ^T += K^T dS^T
+#pragma unroll
+    for (int ks = 0; ks < KS_K; ++ks) {
+      const uint4 bds = pack_step<T, NKF>(dp, ks);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const uint4 ak = *(const uint4*)(KT + swz<CPT>(n * 16 + r, ks * 4 + qd));
+        MMA<T>::step(dq[n], ak, bds);
+      }
+    }
+  }
+  // epilogue: lane (query r, a = qd) holds dims n*16 + 4a + i
+  if (qi < qlen) {
+    T* dqr = (T*)p.dq + (int64_t)(q0 + qi) * p.dq_rs + (int64_t)head * p.dq_hs + 4 * qd;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      if constexpr (sizeof(T) == 2) {
+        *(uint2*)(dqr + n * 16) = make_uint2(pack2_bf16(dq[n][0], dq[n][1]), pack2_bf16(dq[n][2], dq[n][3]));
+      } else {
+        *(f32x4*)(dqr + n * 16) = dq[n];
+      }
+    }
+  }
+}
+
+template <typename T, int D, bool CAUSAL>
+int launch_attn_bwd(const sl_attn_bwd_args* a, const AttnBwdP& p, hipStream_t st) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int LPP = D / VEC;
+  const int64_t pairs = a->n_tok_q * a->n_heads;
+  hipLaunchKernelGGL((attn_bwd_delta_kernel<T, D>), dim3((unsigned)((pairs * LPP + 255) / 256)), dim3(256), 0, st, p);
+  SL_CHECK_LAUNCH("attn_bwd_delta");
+  // tile sizes keep every kernel inside 64 KiB of static LDS
+  constexpr int TQ = sizeof(T) == 2 ? (D == 64 ? 64 : 32) : (D == 64 ? 32 : 16);
+  constexpr int TK = sizeof(T) == 2 ? 64 : 32;
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, CAUSAL, TQ>), dim3((a->max_klen + 63) / 64, a->n_kv_heads, a->nseq), dim3(256), 0, st, p);
+  SL_CHECK_LAUNCH("attn_bwd_dkdv");
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, CAUSAL, TK>), dim3((a->max_qlen + 63) / 64, a->n_heads, a->nseq), dim3(256), 0, st, p);
+  SL_CHECK_LAUNCH("attn_bwd_dq");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sl_attn_bwd(const sl_attn_bwd_args* a, sl_stream stream) {
+  SL_CHECK_ARG(a && a->q && a->k && a->v && a->out && a->d_out && a->dq && a->dk && a->dv && a->lse && a->delta && a->cu_q && a->cu_k && a->klen,
+               "sl_attn_bwd: null pointer");
+  SL_CHECK_ARG(a->nseq > 0 && a->max_qlen > 0 && a->max_klen > 0 && a->n_tok_q > 0 && a->n_heads > 0 && a->n_kv_heads > 0 &&
+                   a->n_heads % a->n_kv_heads == 0, "sl_attn_bwd: bad shape");
+  SL_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "sl_attn_bwd: dropout_p=%f outside [0, 1)", (double)a->dropout_p);
+  const int vec = a->dtype == SL_F32 ? 4 : 8;
+  const int64_t strides[] = {a->q_row_stride, a->q_head_stride, a->k_row_stride, a->k_head_stride, a->v_row_stride, a->v_head_stride,
+                             a->o_row_stride, a->o_head_stride, a->do_row_stride, a->do_head_stride};
+  for (int64_t s : strides) SL_CHECK_ARG(s % vec == 0, "sl_attn_bwd: input strides must keep 16-byte alignment");
+  SL_CHECK_ARG(a->dq_row_stride % 4 == 0 && a->dq_head_stride % 4 == 0 && ((uintptr_t)a->dq & 15) == 0,
+               "sl_attn_bwd: dq rows / heads must start on 4-element boundaries of a 16-byte aligned buffer");
+  AttnBwdP p;
+  p.q = a->q; p.q_rs = a->q_row_stride; p.q_hs = a->q_head_stride;
+  p.k = a->k; p.k_rs = a->k_row_stride; p.k_hs = a->k_head_stride;
+  p.v = a->v; p.v_rs = a->v_row_stride; p.v_hs = a->v_head_stride;
+  p.o = a->out; p.o_rs = a->o_row_stride; p.o_hs = a->o_head_stride;
+  p.dout = a->d_out; p.do_rs = a->do_row_stride; p.do_hs = a->do_head_stride;
+  p.dq = a->dq; p.dq_rs = a->dq_row_stride; p.dq_hs = a->dq_head_stride;
+  p.dk = a->dk; p.dk_rs = a->dk_row_stride; p.dk_hs = a->dk_head_stride;
+  p.dv = a->dv; p.dv_rs = a->dv_row_stride; p.dv_hs = a->dv_head_stride;
+  p.lse = a->lse; p.delta = a->delta;
+  p.cu_q = a->cu_q; p.cu_k = a->cu_k; p.klen = a->klen;
+  p.n_tok_q = a->n_tok_q;
+  p.n_heads = a->n_heads; p.n_kv = a->n_kv_heads; p.scale = a->scale;
+  p.drop_thr = 0; p.drop_scale = 1.f; p.drop_seed = a->dropout_seed;
+  if (a->dropout_p > 0.f) {
+    p.drop_thr = (uint32_t)((double)a->dropout_p * 16777216.0);
+    p.drop_scale = 1.0f / (1.0f - a->dropout_p);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  SL_DISPATCH_DTYPE(a->dtype, T, {
+    if (a->head_dim == 64) return a->causal ? launch_attn_bwd<T, 64, true>(a, p, st) : launch_attn_bwd<T, 64, false>(a, p, st);
+    if (a->head_dim == 128) return a->causal ? launch_attn_bwd<T, 128, true>(a, p, st) : launch_attn_bwd<T, 128, false>(a, p, st);
+    sl_set_error("sl_attn_bwd: head_dim %d not built (64, 128)", a->head_dim);
+    return SL_ERR_UNSUPPORTED;
+  });
+}

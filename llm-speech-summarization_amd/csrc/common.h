@@ -197,12 +197,3 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
   } while (0)
 
 static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; }
-
-// conv.hip: whole-batch forms of sl_posconv_stage / sl_avgpool_rows used by the encoder runtime (one launch per ragged batch)
-int sl_posconv_stage_batch(const void* x, void* xg, const int32_t* cu, const int32_t* klen, int32_t n_utt, int64_t max_T, int32_t H,
-                           int32_t groups, int32_t k, int32_t dtype, sl_stream stream);
-int sl_avgpool_batch(const void* x, void* y, const int32_t* cu, const int32_t* klen, const int64_t* rec, int32_t n_utt, int64_t max_P, int32_t H,
-                     int32_t kernel, int32_t stride, int32_t dtype, sl_stream stream);
-int sl_hubert_conv0_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev, int32_t n_utt, int64_t max_L,
-                          const float* w, const float* bias, const float* gamma, const float* beta, void* out, int32_t C, int32_t k,
-                          int32_t stride, float eps, int32_t dtype, sl_stream stream);

@@ -104,7 +104,7 @@ static int launch_conv0_batch(const float* waves, const int64_t* soff, const int
   return 0;
 }
 
-int sl_hubert_conv0_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev, int32_t n_utt, int64_t max_L,
+extern "C" int sl_hubert_conv0_batch(const float* waves, const int64_t* sample_offsets_dev, const int64_t* row_offsets_dev, int32_t n_utt, int64_t max_L,
                           const float* w, const float* bias, const float* gamma, const float* beta, void* out, int32_t C, int32_t k,
                           int32_t stride, float eps, int32_t dtype, sl_stream stream) {
   SL_CHECK_ARG(waves && sample_offsets_dev && row_offsets_dev && w && bias && gamma && beta && out && n_utt > 0, "sl_hubert_conv0_batch: bad arguments");
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void posconv_stage_batch_kernel(const T* __res
   }
 }
 
-int sl_posconv_stage_batch(const void* x, void* xg, const int32_t* cu, const int32_t* klen, int32_t n_utt, int64_t max_T, int32_t H,
+extern "C" int sl_posconv_stage_batch(const void* x, void* xg, const int32_t* cu, const int32_t* klen, int32_t n_utt, int64_t max_T, int32_t H,
                            int32_t groups, int32_t k, int32_t dtype, sl_stream stream) {
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(x && xg && cu && klen && n_utt > 0 && groups > 0 && H % groups == 0 && (H / groups) % vec == 0, "sl_posconv_stage_batch: bad arguments");
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void avgpool_batch_kernel(const T* __restrict_
   }
 }
 
-int sl_avgpool_batch(const void* x, void* y, const int32_t* cu, const int32_t* klen, const int64_t* rec, int32_t n_utt, int64_t max_P, int32_t H,
+extern "C" int sl_avgpool_batch(const void* x, void* y, const int32_t* cu, const int32_t* klen, const int64_t* rec, int32_t n_utt, int64_t max_P, int32_t H,
                      int32_t kernel, int32_t stride, int32_t dtype, sl_stream stream) {
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(x && y && cu && klen && rec && n_utt > 0 && H % vec == 0 && kernel > 0 && stride > 0, "sl_avgpool_batch: bad arguments");

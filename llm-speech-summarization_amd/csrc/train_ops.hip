@@ -484,6 +484,130 @@ __global__ __launch_bounds__(1024) void logit_loss_kernel(const float* __restric
   }
 }
 
+// All logit losses of one accumulation window in ONE launch (KD step, ref:trainer.py:325-354): a block per row of the packed
+// student / teacher tail logits.  labels[row] >= 0: next-token CE term; teacher != NULL and coef[row][2..3] != 0: soft-CE term.
+//   losses[slot[row]][0] += c0 * (lse(s) - s[label]);   losses[slot[row]][1] += c2 * (lse(s) - sum softmax(t) s)
+//   ds[row] = c1 * (softmax(s) - onehot(label)) + c3 * (softmax(s) - softmax(t))       (written once, no read-modify-write)
+// Same arithmetic as logit_loss_kernel; rows are read as 16-byte vectors, the maxima of s and t in one pass.
+template <typename T>
+__global__ __launch_bounds__(1024) void kd_logit_losses_kernel(const float* __restrict__ s, const float* __restrict__ t, const int32_t* __restrict__ labels,
+                                                               const float* __restrict__ coef, const int32_t* __restrict__ slot, int V,
+                                                               float* __restrict__ losses, int loss_ld, T* __restrict__ ds) {
+  __shared__ float sh[16];
+  const int64_t row = blockIdx.x;
+  const float* sr = s + row * V;
+  const float c0 = coef[row * 4], c1 = coef[row * 4 + 1], c2 = coef[row * 4 + 2], c3 = coef[row * 4 + 3];
+  const bool soft = t != nullptr && (c2 != 0.f || c3 != 0.f);
+  const float* tr = soft ? t + row * V : nullptr;
+  const int lab = labels[row];
+  if (V & 3) {   // rows are not 16-byte aligned: scalar form (same arithmetic)
+    const float* tr1 = tr;
+    float ms = -INFINITY, mt = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += 1024) { ms = fmaxf(ms, sr[i]); if (soft) mt = fmaxf(mt, tr1[i]); }
+    ms = block_reduce(ms, true, sh);
+    if (soft) mt = block_reduce(mt, true, sh);
+    float ls = 0.f, lt = 0.f, cross = 0.f;
+    for (int i = threadIdx.x; i < V; i += 1024) {
+      ls += __expf(sr[i] - ms);
+      if (soft) { const float e = __expf(tr1[i] - mt); lt += e; cross += e * sr[i]; }
+    }
+    ls = block_reduce(ls, false, sh);
+    if (soft) { lt = block_reduce(lt, false, sh); cross = block_reduce(cross, false, sh); }
+    const float lse = ms + logf(ls);
+    if (threadIdx.x == 0) {
+      float* lrow = losses + (int64_t)slot[row] * loss_ld;
+      if (lab >= 0 && c0 != 0.f) atomicAdd(lrow, c0 * (lse - sr[lab]));
+      if (soft && c2 != 0.f) atomicAdd(lrow + 1, c2 * (lse - cross / lt));
+    }
+    if (!ds) return;
+    T* dr = ds + row * V;
+    const float inv_s = 1.0f / ls, inv_t = soft ? 1.0f / lt : 0.f;
+    const float cce = lab >= 0 ? c1 : 0.f;
+    const float cs = cce + (soft ? c3 : 0.f);
+    for (int i = threadIdx.x; i < V; i += 1024) {
+      float g = cs * (__expf(sr[i] - ms) * inv_s);
+      if (soft) g -= c3 * (__expf(tr1[i] - mt) * inv_t);
+      if (i == lab) g -= cce;
+      dr[i] = from_f32<T>(g);
+    }
+    return;
+  }
+  const int n4 = V >> 2;
+  const f32x4* s4 = (const f32x4*)sr;
+  const f32x4* t4 = (const f32x4*)tr;
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const f32x4 a = s4[i];
+    ms = fmaxf(fmaxf(ms, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+    if (soft) { const f32x4 b = t4[i]; mt = fmaxf(fmaxf(mt, fmaxf(b[0], b[1])), fmaxf(b[2], b[3])); }
+  }
+  ms = block_reduce(ms, true, sh);
+  if (soft) mt = block_reduce(mt, true, sh);
+  float ls = 0.f, lt = 0.f, cross = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const f32x4 a = s4[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ls += __expf(a[j] - ms);
+    if (soft) {
+      const f32x4 b = t4[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float e = __expf(b[j] - mt); lt += e; cross += e * a[j]; }
+    }
+  }
+  ls = block_reduce(ls, false, sh);
+  if (soft) { lt = block_reduce(lt, false, sh); cross = block_reduce(cross, false, sh); }
+  const float lse = ms + logf(ls);
+  if (threadIdx.x == 0) {
+    float* lrow = losses + (int64_t)slot[row] * loss_ld;
+    if (lab >= 0 && c0 != 0.f) atomicAdd(lrow, c0 * (lse - sr[lab]));
+    if (soft && c2 != 0.f) atomicAdd(lrow + 1, c2 * (lse - cross / lt));
+  }
+  if (!ds) return;
+  T* dr = ds + row * V;
+  const float inv_s = 1.0f / ls, inv_t = soft ? 1.0f / lt : 0.f;
+  const float cce = lab >= 0 ? c1 : 0.f;
+  const float cs = cce + (soft ? c3 : 0.f);          // weight of softmax(s)
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const f32x4 a = s4[i];
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = cs * (__expf(a[j] - ms) * inv_s);
+    if (soft) {
+      const f32x4 b = t4[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] -= c3 * (__expf(b[j] - mt) * inv_t);
+    }
+    if (lab >= 0 && (lab >> 2) == i) g[lab & 3] -= cce;
+    if constexpr (sizeof(T) == 2) *(uint2*)(dr + 4 * i) = make_uint2(pack2_bf16(g[0], g[1]), pack2_bf16(g[2], g[3]));
+    else *(f32x4*)(dr + 4 * i) = f32x4{g[0], g[1], g[2], g[3]};
+  }
+}
+
+// Feature-distillation MSE of one tap for every utterance of the window in ONE launch (ref:trainer.py:358-370): a wave per row
+// of the packed tail hidden states; losses[slot[row]][2] += c0 * sum_h d^2;  da[row] = c1 * d   (c0 = 1 / (n_u H),
+// c1 = 2 w / (n_u H acc) supplied per row by the host).
+template <typename T>
+__global__ __launch_bounds__(256) void kd_mse_rows_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ coef,
+                                                          const int32_t* __restrict__ slot, int64_t rows, int H, float* __restrict__ losses, int loss_ld,
+                                                          int loss_col, T* __restrict__ da) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float c0 = coef[row * 2], c1 = coef[row * 2 + 1];
+  float acc = 0.f;
+  for (int ch = lane; ch < H / VEC; ch += 64) {
+    float fa[VEC], fb[VEC];
+    Vec16<T>::unpack(*(const uint4*)(a + row * H + ch * VEC), fa);
+    Vec16<T>::unpack(*(const uint4*)(b + row * H + ch * VEC), fb);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { fa[j] -= fb[j]; acc += fa[j] * fa[j]; fa[j] *= c1; }
+    if (da) *(uint4*)(da + row * H + ch * VEC) = Vec16<T>::pack(fa);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) atomicAdd(losses + (int64_t)slot[row] * loss_ld + loss_col, c0 * acc);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, float coef, float* __restrict__ loss,
                                                   T* __restrict__ da, int accumulate) {
@@ -900,6 +1024,33 @@ extern "C" int sl_soft_ce_loss(const float* student, const float* teacher, int64
                        loss, (T*)dstudent, accumulate);
   });
   SL_CHECK_LAUNCH("soft_ce_loss");
+  return 0;
+}
+
+extern "C" int sl_kd_logit_losses(const float* student, const float* teacher, const int32_t* labels, const float* row_coef, const int32_t* row_slot,
+                                  int64_t rows, int32_t V, float* losses, int32_t loss_ld, void* dstudent, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(student && labels && row_coef && row_slot && losses && rows >= 0 && V > 0 && loss_ld >= 2, "sl_kd_logit_losses: bad arguments");
+  SL_CHECK_ARG(((uintptr_t)student & 15) == 0 && ((uintptr_t)teacher & 15) == 0 && ((uintptr_t)dstudent & 15) == 0, "sl_kd_logit_losses: 16-byte aligned buffers");
+  if (rows == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((kd_logit_losses_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, student, teacher, labels, row_coef, row_slot, V,
+                       losses, loss_ld, (T*)dstudent);
+  });
+  SL_CHECK_LAUNCH("kd_logit_losses");
+  return 0;
+}
+
+extern "C" int sl_kd_mse_rows(const void* a, const void* b, const float* row_coef, const int32_t* row_slot, int64_t rows, int32_t H, float* losses,
+                              int32_t loss_ld, int32_t loss_col, void* da, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(a && b && row_coef && row_slot && losses && rows >= 0 && H > 0 && loss_col >= 0 && loss_col < loss_ld, "sl_kd_mse_rows: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(H % vec == 0, "sl_kd_mse_rows: H must be a multiple of %d", vec);
+  if (rows == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((kd_mse_rows_kernel<T>), dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, row_coef, row_slot,
+                       rows, H, losses, loss_ld, loss_col, (T*)da);
+  });
+  SL_CHECK_LAUNCH("kd_mse_rows");
   return 0;
 }
 

@@ -86,6 +86,46 @@ def avgpool_rows(x: torch.Tensor, kernel: int = 8, stride: int = 4, ranges: Opti
     return y
 
 
+def hubert_conv0_batch(flat_waves: torch.Tensor, sample_offsets: Sequence[int], row_offsets: Sequence[int], w, bias, gamma, beta, dtype: torch.dtype,
+                       k: int = 10, stride: int = 5, eps: float = 1e-5) -> torch.Tensor:
+    """conv0 + LayerNorm + GELU of every utterance of a ragged batch in one launch -> packed (sum L_u, C) rows."""
+    dev = flat_waves.device
+    n_utt = len(sample_offsets) - 1
+    desc = torch.tensor([list(sample_offsets), list(row_offsets)], dtype=torch.int64, device=dev)
+    out = torch.empty((row_offsets[-1], w.shape[0]), device=dev, dtype=dtype)
+    max_L = max(row_offsets[u + 1] - row_offsets[u] for u in range(n_utt))
+    L.check(L.lib().sl_hubert_conv0_batch(L.ptr(flat_waves), desc[0].data_ptr(), desc[1].data_ptr(), n_utt, max_L, L.ptr(w), L.ptr(bias), L.ptr(gamma),
+                                          L.ptr(beta), L.ptr(out), w.shape[0], k, stride, eps, L.dtype_code(dtype), L.stream_ptr()), "sl_hubert_conv0_batch")
+    return out
+
+
+def posconv_stage_batch(x: torch.Tensor, seqlens: Sequence[int], groups: int, k: int) -> torch.Tensor:
+    """sl_posconv_stage for every utterance of a packed batch in one launch; utterance u's (groups, T_u + k, H/groups) block
+    starts (cu[u] + u k) * H elements into the flat result."""
+    cu, klen = seq_descriptors(seqlens, x.device)
+    H = x.shape[1]
+    xg = torch.empty((x.shape[0] + len(seqlens) * k) * H, device=x.device, dtype=x.dtype)
+    L.check(L.lib().sl_posconv_stage_batch(L.ptr(x), L.ptr(xg), cu.data_ptr(), klen.data_ptr(), len(seqlens), max(int(n) for n in seqlens), H, groups, k,
+                                           L.dtype_code(x.dtype), L.stream_ptr()), "sl_posconv_stage_batch")
+    return xg
+
+
+def avgpool_batch(x: torch.Tensor, seqlens: Sequence[int], kernel: int, stride: int):
+    """AvgPool1d over time of every utterance of a packed batch in one launch -> (packed pooled rows, P list)."""
+    cu, klen = seq_descriptors(seqlens, x.device)
+    H = x.shape[1]
+    P = [(int(t) - kernel) // stride + 1 for t in seqlens]
+    rec, row = [], 0
+    for p_ in P:
+        rec.append([p_, row * H, 0, 0])
+        row += p_
+    rec_t = torch.tensor(rec, dtype=torch.int64, device=x.device)
+    y = torch.empty((row, H), device=x.device, dtype=x.dtype)
+    L.check(L.lib().sl_avgpool_batch(L.ptr(x), L.ptr(y), cu.data_ptr(), klen.data_ptr(), rec_t.data_ptr(), len(seqlens), max(P), H, kernel, stride,
+                                     L.dtype_code(x.dtype), L.stream_ptr()), "sl_avgpool_batch")
+    return y, P
+
+
 def embed_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     ids32 = ids.to(device=table.device, dtype=torch.int32).contiguous().view(-1)
     out = torch.empty((ids32.numel(), table.shape[1]), device=table.device, dtype=table.dtype)
@@ -108,13 +148,32 @@ def attn_fwd(q, k, v, out, cu_q, cu_k, klen, *, q_strides, k_strides, v_strides,
     return out
 
 
+_SEQ_DESC = {}
+
+
+def seq_descriptors(seqlens: Sequence[int], device):
+    """(cu_seqlens int32 (n+1), lens int32 (n)) device tensors of a packed batch, cached per length tuple (the KD step calls
+    attention forward + backward for every layer with the same lengths)."""
+    key = (tuple(int(n) for n in seqlens), str(device))
+    d = _SEQ_DESC.get(key)
+    if d is None:
+        if len(_SEQ_DESC) > 64:
+            _SEQ_DESC.clear()
+        cu = [0]
+        for n in key[0]:
+            cu.append(cu[-1] + n)
+        d = (torch.tensor(cu, dtype=torch.int32, device=device), torch.tensor(list(key[0]), dtype=torch.int32, device=device))
+        _SEQ_DESC[key] = d
+    return d
+
+
 def attn_packed_qkv(qkv: torch.Tensor, seqlens: Sequence[int], n_heads: int, n_kv_heads: int, head_dim: int, causal: bool,
-                    scale: float, dropout_p: float = 0.0, dropout_seed: int = 0) -> torch.Tensor:
+                    scale: float, dropout_p: float = 0.0, dropout_seed: int = 0, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention over a packed fused (tokens, (nh+2nkv)*D) activation (the HuBERT layout).  dropout_p > 0: training-mode
-    dropout of the attention probabilities (mask index ((token * nh + head) << 16) | key, see sl_attn_args)."""
+    dropout of the attention probabilities (mask index ((token * nh + head) << 16) | key, see sl_attn_args).
+    lse: optional fp32 (tokens, n_heads) buffer that receives the log-sum-exp (what attn_packed_qkv_bwd needs)."""
     dev = qkv.device
-    cu = torch.tensor([0] + list(torch.tensor(seqlens).cumsum(0).tolist()), dtype=torch.int32, device=dev)
-    klen = torch.tensor(list(seqlens), dtype=torch.int32, device=dev)
+    cu, klen = seq_descriptors(seqlens, dev)
     ntok = qkv.shape[0]
     rs = qkv.stride(0)
     out = torch.empty((ntok, n_heads * head_dim), device=dev, dtype=qkv.dtype)
@@ -130,8 +189,39 @@ def attn_packed_qkv(qkv: torch.Tensor, seqlens: Sequence[int], n_heads: int, n_k
     a.nseq, a.max_qlen, a.n_heads, a.n_kv_heads = len(seqlens), max(seqlens), n_heads, n_kv_heads
     a.head_dim, a.causal, a.dtype, a.scale = head_dim, int(causal), L.dtype_code(qkv.dtype), scale
     a.dropout_p, a.dropout_seed = float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+    a.lse = L.ptr(lse)
     L.check(L.lib().sl_attn_fwd(C.byref(a), L.stream_ptr()), "sl_attn_fwd")
     return out
+
+
+def attn_packed_qkv_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.Tensor, lse: torch.Tensor, d_qkv: torch.Tensor, seqlens: Sequence[int],
+                        n_heads: int, n_kv_heads: int, head_dim: int, causal: bool, scale: float, dropout_p: float = 0.0,
+                        dropout_seed: int = 0) -> torch.Tensor:
+    """Flash-style backward of attn_packed_qkv (sl_attn_bwd): d_qkv (same fused layout as qkv) <- [dQ | dK | dV]."""
+    dev = qkv.device
+    cu, klen = seq_descriptors(seqlens, dev)
+    ntok, rs, D = qkv.shape[0], qkv.stride(0), head_dim
+    esz = qkv.element_size()
+    koff, voff = n_heads * D, (n_heads + n_kv_heads) * D
+    delta = torch.empty((ntok, n_heads), device=dev, dtype=torch.float32)
+    a = L.AttnBwdArgs()
+    a.q, a.q_row_stride, a.q_head_stride = qkv.data_ptr(), rs, D
+    a.k, a.k_row_stride, a.k_head_stride = qkv.data_ptr() + koff * esz, rs, D
+    a.v, a.v_row_stride, a.v_head_stride = qkv.data_ptr() + voff * esz, rs, D
+    a.out, a.o_row_stride, a.o_head_stride = out.data_ptr(), out.stride(0), D
+    a.d_out, a.do_row_stride, a.do_head_stride = d_out.data_ptr(), d_out.stride(0), D
+    drs = d_qkv.stride(0)
+    a.dq, a.dq_row_stride, a.dq_head_stride = d_qkv.data_ptr(), drs, D
+    a.dk, a.dk_row_stride, a.dk_head_stride = d_qkv.data_ptr() + koff * esz, drs, D
+    a.dv, a.dv_row_stride, a.dv_head_stride = d_qkv.data_ptr() + voff * esz, drs, D
+    a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
+    a.cu_q, a.cu_k, a.klen = cu.data_ptr(), cu.data_ptr(), klen.data_ptr()
+    a.n_tok_q, a.nseq = ntok, len(seqlens)
+    a.max_qlen = a.max_klen = max(int(n) for n in seqlens)
+    a.n_heads, a.n_kv_heads, a.head_dim, a.causal, a.dtype = n_heads, n_kv_heads, D, int(causal), L.dtype_code(qkv.dtype)
+    a.scale, a.dropout_p, a.dropout_seed = scale, float(dropout_p), int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+    L.check(L.lib().sl_attn_bwd(C.byref(a), L.stream_ptr()), "sl_attn_bwd")
+    return d_qkv
 
 
 def attn_dropout_bwd(P: torch.Tensor, Pd: torch.Tensor, dP: torch.Tensor, n_mat: int, smax: int, dims: torch.Tensor, ld: int, cu_q: torch.Tensor,
@@ -452,3 +542,15 @@ def hubert_conv0_bwd(wave, w, bias, gamma, beta, dy, dw, dbias, dgamma, dbeta, k
     L.check(L.lib().sl_hubert_conv0_bwd(L.ptr(wave), wave.numel(), L.ptr(w), L.ptr(bias), L.ptr(gamma), L.ptr(beta), L.ptr(dy), w.shape[0], k,
                                         stride, eps, L.ptr(dw), L.ptr(dbias), L.ptr(dgamma), L.ptr(dbeta), L.dtype_code(dy.dtype),
                                         L.stream_ptr()), "sl_hubert_conv0_bwd")
+
+
+def kd_logit_losses(student, teacher, labels, row_coef, row_slot, losses, dstudent, dtype):
+    """All next-token / soft cross-entropy terms of a window in one launch (sl_kd_logit_losses)."""
+    L.check(L.lib().sl_kd_logit_losses(L.ptr(student), L.ptr(teacher), L.ptr(labels), L.ptr(row_coef), L.ptr(row_slot), student.shape[0], student.shape[1],
+                                       L.ptr(losses), losses.stride(0), L.ptr(dstudent), L.dtype_code(dtype), L.stream_ptr()), "sl_kd_logit_losses")
+
+
+def kd_mse_rows(a, b, row_coef, row_slot, losses, loss_col, da=None):
+    """Feature-distillation MSE of one tap over every utterance's tail rows in one launch (sl_kd_mse_rows)."""
+    L.check(L.lib().sl_kd_mse_rows(L.ptr(a), L.ptr(b), L.ptr(row_coef), L.ptr(row_slot), a.shape[0], a.shape[1], L.ptr(losses), losses.stride(0), loss_col,
+                                   L.ptr(da), L.dtype_code(a.dtype), L.stream_ptr()), "sl_kd_mse_rows")

@@ -16,7 +16,7 @@ feature-projection / hidden / activation dropout, LayerDrop and SpecAugment time
 them on (`KDTrainer(..., regularizers=...)`).  Masks come from a counter-based hash (sl_dropout), so forward and backward
 agree without stored masks and the test oracle can rebuild them; SpecAugment spans follow HF's `_compute_mask_indices`
 on numpy's global RNG.  Attention-probability dropout is applied inside the attention kernels (the mask index is a
-function of (token, head, key), so the explicit-probability backward rebuilds it).  Deterministic KD-step parity
+function of (token, head, key), so the flash-style backward, which recomputes the probabilities tile by tile, rebuilds it).  Deterministic KD-step parity
 (golden fixtures) is defined with the regularisers off.
 """
 from __future__ import annotations
@@ -119,125 +119,6 @@ def _rup(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
-# ------------------------------------------------------------------------------------------------
-# attention backward from explicit probabilities (recomputed), all products on sl_gemm_ex
-# ------------------------------------------------------------------------------------------------
-def attention_backward(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: torch.Tensor, nh: int, nkv: int, D: int, causal: bool, scale: float) -> None:
-    """One sequence.  qkv: (S, qkv_w) row view [q heads | k heads | v heads]; d_att: (S, nh*D) row view;
-    d_qkv: (S, qkv_w) row view that receives [dQ | dK | dV]."""
-    dt = qkv.dtype
-    S, qkv_w = qkv.shape[0], qkv.stride(0)
-    rep = nh // nkv
-    ld = _rup(S, _vec(dt))
-    dev = qkv.device
-    Sb = torch.empty((nkv, S, ld), device=dev, dtype=torch.float32)
-    dPb = torch.empty((nkv, S, ld), device=dev, dtype=torch.float32)
-    koff, voff = nh * D, (nh + nkv) * D
-    # K rows zero-padded to ld so that dQ = dS . K can reduce over a whole number of 16-byte chunks
-    kpad = torch.zeros((ld, nkv * D), device=dev, dtype=dt)
-    kpad[:S] = qkv[:, koff:voff]
-    ldo = d_att.stride(0)
-    for r in range(rep):
-        # scores of q heads kvh*rep + r against kv head kvh
-        ops.gemm_ex(qkv, qkv, M=S, N=S, K=D, lda=qkv_w, ldw=qkv_w, out=Sb, ldc=ld, out_f32=True, batch=nkv, strideA=rep * D, strideW=D,
-                    strideC=S * ld, a_off=r * D, w_off=koff, dtype=dt)
-        P = ops.softmax_rows(Sb, nkv, S, S, ld, scale, causal, dt)
-        ops.gemm_ex(d_att, qkv, M=S, N=S, K=D, lda=ldo, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nkv, strideA=rep * D, strideW=D,
-                    strideC=S * ld, a_off=r * D, w_off=voff, dtype=dt)
-        dS = ops.softmax_bwd(P, dPb, S, scale)
-        # dQ_h = dS . K
-        ops.gemm_ex(dS, kpad, M=S, N=D, K=ld, lda=ld, ldw=nkv * D, out=d_qkv, ldc=qkv_w, trans_w=True, batch=nkv, strideA=S * ld, strideW=D,
-                    strideC=rep * D, c_off=r * D, dtype=dt)
-        acc = r > 0  # GQA: the rep query heads of a group add into the same dK / dV
-        # dK = dS^T . Q_h
-        ops.gemm_ex(dS, qkv, M=S, N=D, K=S, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nkv, strideA=S * ld,
-                    strideW=rep * D, strideC=D, w_off=r * D, c_off=koff, residual=(d_qkv if acc else None), ldr=qkv_w, strideR=D,
-                    r_off=koff, dtype=dt)
-        # dV = P^T . dO_h
-        ops.gemm_ex(P, d_att, M=S, N=D, K=S, lda=ld, ldw=ldo, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nkv, strideA=S * ld,
-                    strideW=rep * D, strideC=D, w_off=r * D, c_off=voff, residual=(d_qkv if acc else None), ldr=qkv_w, strideR=D,
-                    r_off=voff, dtype=dt)
-
-
-_ATT_PLANS: Dict[tuple, dict] = {}
-
-
-def _attention_plan(seqlens, qkv_w: int, ldo: int, nh: int, nkv: int, D: int, vec: int, device) -> dict:
-    """Group records ({M, a_off, c_off, r_off, w_off, N, K, 0}, sl_gemm_ex groups_ext) of the five products of the attention
-    backward for every (sequence, kv head) of a packed batch, one set per query head of a GQA group."""
-    key = (tuple(int(n) for n in seqlens), qkv_w, ldo, nh, nkv, D, vec, str(device))
-    plan = _ATT_PLANS.get(key)
-    if plan is not None:
-        return plan
-    rep = nh // nkv
-    offs = _offsets(seqlens)
-    smax = max(int(n) for n in seqlens)
-    ld = _rup(smax, max(vec, 8))
-    koff, voff = nh * D, (nh + nkv) * D
-    mat = smax * ld                       # pitch of one (sequence, head) score matrix
-    recs = {k: [] for k in ("s", "dp", "dq", "dk", "dv")}
-    for r in range(rep):
-        for k in recs:
-            recs[k].append([])
-        for si, S in enumerate(int(n) for n in seqlens):
-            o = offs[si]
-            for h in range(nkv):
-                z = si * nkv + h
-                qh = (h * rep + r) * D
-                recs["s"][r].append([S, o * qkv_w + qh, z * mat, 0, o * qkv_w + koff + h * D, S, D, 0])
-                recs["dp"][r].append([S, o * ldo + qh, z * mat, 0, o * qkv_w + voff + h * D, S, D, 0])
-                recs["dq"][r].append([S, z * mat, o * qkv_w + qh, 0, si * ld * nkv * D + h * D, D, ld, 0])
-                kc = o * qkv_w + koff + h * D
-                recs["dk"][r].append([S, z * mat, kc, kc, o * qkv_w + qh, D, S, 0])
-                vc = o * qkv_w + voff + h * D
-                recs["dv"][r].append([S, z * mat, vc, vc, o * ldo + qh, D, S, 0])
-    plan = {k: [torch.tensor(v[r], dtype=torch.int64, device=device) for r in range(rep)] for k, v in recs.items()}
-    plan.update(smax=smax, ld=ld, nmat=len(seqlens) * nkv, offs=offs,
-                dims=torch.tensor([int(n) for n in seqlens for _ in range(nkv)], dtype=torch.int32, device=device))
-    _ATT_PLANS[key] = plan
-    return plan
-
-
-def attention_backward_packed(qkv: torch.Tensor, d_att: torch.Tensor, d_qkv: torch.Tensor, seqlens, nh: int, nkv: int, D: int, causal: bool,
-                              scale: float, dropout_p: float = 0.0, dropout_seed: int = 0) -> None:
-    """attention_backward for every sequence of a packed batch at once: each of the five products is ONE grouped launch over
-    all (sequence, kv head) pairs (the per-sequence form spent 27 % of the KD step in 29-42 us launch-bound GEMMs)."""
-    dt = qkv.dtype
-    dev = qkv.device
-    qkv_w, ldo = qkv.stride(0), d_att.stride(0)
-    rep = nh // nkv
-    pl = _attention_plan(seqlens, qkv_w, ldo, nh, nkv, D, _vec(dt), dev)
-    smax, ld, nmat, offs = pl["smax"], pl["ld"], pl["nmat"], pl["offs"]
-    koff, voff = nh * D, (nh + nkv) * D
-    Sb = torch.empty((nmat, smax, ld), device=dev, dtype=torch.float32)
-    dPb = torch.empty((nmat, smax, ld), device=dev, dtype=torch.float32)
-    P = torch.zeros((nmat, smax, ld), device=dev, dtype=dt)
-    dS = torch.zeros((nmat, smax, ld), device=dev, dtype=dt)
-    drop = dropout_p > 0
-    Pd = torch.zeros((nmat, smax, ld), device=dev, dtype=dt) if drop else P    # dropped probabilities (what multiplied V in the forward)
-    cu = torch.tensor(offs, dtype=torch.int32, device=dev) if drop else None
-    kpad = torch.zeros((len(seqlens), ld, nkv * D), device=dev, dtype=dt)   # K rows zero-padded: dQ = dS . K reduces over ld
-    for si, S in enumerate(seqlens):
-        kpad[si, :S] = qkv[offs[si]:offs[si] + S, koff:voff]
-    for r in range(rep):
-        kslab = 2 if D % (64 if dt != torch.float32 else 32) == 0 else True     # K = head_dim for these two: whole slabs -> LDS-DMA kernel
-        ops.gemm_ex(qkv, qkv, M=smax, N=smax, K=D, lda=qkv_w, ldw=qkv_w, out=Sb, ldc=ld, out_f32=True, batch=nmat, dtype=dt,
-                    groups=pl["s"][r], groups_ext=kslab)
-        ops.softmax_rows_var(Sb, P, nmat, smax, pl["dims"], ld, scale, causal, dt)
-        ops.gemm_ex(d_att, qkv, M=smax, N=smax, K=D, lda=ldo, ldw=qkv_w, out=dPb, ldc=ld, out_f32=True, batch=nmat, dtype=dt,
-                    groups=pl["dp"][r], groups_ext=kslab)
-        if drop:   # d probabilities = mask / (1-p) * d(dropped probabilities); dV below sees the dropped probabilities
-            ops.attn_dropout_bwd(P, Pd, dPb, nmat, smax, pl["dims"], ld, cu, nh, nkv, r, dropout_p, dropout_seed)
-        ops.softmax_bwd_var(P, dPb, dS, nmat, smax, pl["dims"], ld, scale)
-        ops.gemm_ex(dS, kpad, M=smax, N=D, K=ld, lda=ld, ldw=nkv * D, out=d_qkv, ldc=qkv_w, trans_w=True, batch=nmat, dtype=dt,
-                    groups=pl["dq"][r], groups_ext=True)
-        acc = r > 0   # GQA: the rep query heads of a group add into the same dK / dV
-        ops.gemm_ex(dS, qkv, M=smax, N=D, K=smax, lda=ld, ldw=qkv_w, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nmat, dtype=dt,
-                    residual=(d_qkv if acc else None), ldr=qkv_w, groups=pl["dk"][r], groups_ext=True)
-        ops.gemm_ex(Pd, d_att, M=smax, N=D, K=smax, lda=ld, ldw=ldo, out=d_qkv, ldc=qkv_w, trans_a=True, trans_w=True, batch=nmat, dtype=dt,
-                    residual=(d_qkv if acc else None), ldr=qkv_w, groups=pl["dv"][r], groups_ext=True)
-
-
 def _offsets(lens: Sequence[int]) -> List[int]:
     o = [0]
     for n in lens:
@@ -276,14 +157,15 @@ class LlamaTape:
             h1 = ops.rmsnorm(x, lw["norm1"], a.rms_norm_eps)
             qkv = ops.gemm(h1, lw["wqkv"])
             ops.rope_inplace(qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D)
-            att = ops.attn_packed_qkv(qkv, list(seqlens), nh, nkv, D, True, scale)
+            lse = torch.empty((x.shape[0], nh), device=x.device, dtype=torch.float32) if save else None
+            att = ops.attn_packed_qkv(qkv, list(seqlens), nh, nkv, D, True, scale, lse=lse)
             x2 = ops.gemm(att, lw["wo"], residual=x)
             h2 = ops.rmsnorm(x2, lw["norm2"], a.rms_norm_eps)
             gu = ops.gemm(h2, lw["wgu"])                      # interleaved gate/up pre-activations (N, 2F)
             mid = ops.silu_mul(gu)
             x3 = ops.gemm(mid, lw["wdown"], residual=x2)
             if save:
-                tape.append((x, qkv, x2, gu))
+                tape.append((x, qkv, x2, gu, att, lse))
             x = x3
         xn = ops.rmsnorm(x, w.final_norm, a.rms_norm_eps)
         hidden.append(xn)
@@ -308,7 +190,7 @@ class LlamaTape:
         dx.index_copy_(0, tail_rows, ops.rmsnorm_bwd(x_final.index_select(0, tail_rows), w.final_norm, d_xn, a.rms_norm_eps))
         for li in reversed(range(a.num_hidden_layers)):
             lw = w.layer_t[li]
-            x, qkv, x2, gu = tape["layers"][li]
+            x, qkv, x2, gu, att, lse = tape["layers"][li]
             d_mid = ops.dgrad(dx, lw["wdown"], wt=self._t(li, "wdown"))
             d_gu = ops.silu_mul_bwd(gu, d_mid)
             d_h2 = ops.dgrad(d_gu, lw["wgu"], wt=self._t(li, "wgu"))
@@ -316,7 +198,7 @@ class LlamaTape:
             ops.axpby(dx, dx2)                                  # dx2 += dx (residual join)
             d_att = ops.dgrad(dx2, lw["wo"], wt=self._t(li, "wo"))
             d_qkv = torch.empty_like(qkv)
-            attention_backward_packed(qkv, d_att, d_qkv, seqlens, nh, nkv, D, True, D ** -0.5)
+            ops.attn_packed_qkv_bwd(qkv, att, d_att, lse, d_qkv, seqlens, nh, nkv, D, True, D ** -0.5)   # flash-style: no S x S buffers
             ops.rope_inplace(d_qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D, inverse=True)
             d_h1 = ops.dgrad(d_qkv, lw["wqkv"], wt=self._t(li, "wqkv"))
             dxin = ops.rmsnorm_bwd(x, lw["norm1"], d_h1, a.rms_norm_eps)
@@ -402,9 +284,10 @@ class EncoderTape:
                 Ls[i][u] = n
         offs = [_offsets(Ls[i]) for i in range(nc)]
         tape = dict(waves=waves, Ls=Ls, offs=offs)
-        x = torch.empty((offs[0][B], a.conv_dim[0]), device=dev, dtype=dt)
-        for u, wv in enumerate(waves):
-            x[offs[0][u]:offs[0][u + 1]] = ops.hubert_conv0(wv, t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], dt)
+        flat = torch.cat(waves) if B > 1 else waves[0]
+        tape["flat_waves"], tape["soff"] = flat, _offsets([wv.numel() for wv in waves])
+        x = ops.hubert_conv0_batch(flat, tape["soff"], offs[0], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], dt,
+                                   k=a.conv_kernel[0], stride=a.conv_stride[0])      # one launch for the ragged batch
         acts, pres = [x], [None]
         for i in range(1, nc):
             Cin, Cout, k, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
@@ -438,9 +321,7 @@ class EncoderTape:
         G, k = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
         Hg = H // G
         xg_off = _offsets([(T[u] + k) * H for u in range(B)])
-        xg = torch.empty(xg_off[B], device=dev, dtype=dt)
-        for u in range(B):
-            xg[xg_off[u]:xg_off[u + 1]] = ops.posconv_stage(x0[toff[u]:toff[u + 1]], G, k).reshape(-1)
+        xg = ops.posconv_stage_batch(x0, T, G, k)                                   # one launch; utterance u at xg_off[u]
         pos_grp = torch.tensor([[T[u], xg_off[u] + g * (T[u] + k) * Hg, toff[u] * H + g * Hg, toff[u] * H + g * Hg] for u in range(B) for g in range(G)],
                                dtype=torch.int64, device=dev)
         pre_pos = torch.empty_like(x0)
@@ -473,7 +354,9 @@ class EncoderTape:
             ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], eps)
             qkv = ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"])
             p_att = reg.attention_dropout if reg is not None else 0.0
-            att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att, dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
+            lse = torch.empty((NT, nh), device=dev, dtype=torch.float32)
+            att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att, dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0,
+                                      lse=lse)
             if reg is not None and reg.hidden_dropout > 0:                 # h = residual + dropout(attention(layer_norm(h)))
                 x_mid = ops.dropout(ops.gemm(att, lt["wo"], bias=lt["bo"]), reg.hidden_dropout, _site_seed(base, "attn_out", li), residual=x)
             else:
@@ -488,7 +371,7 @@ class EncoderTape:
                 x_out = ops.dropout(ops.gemm(mid, lt["w2"], bias=lt["b2"]), reg.hidden_dropout, _site_seed(base, "ffn_out", li), residual=x_mid)
             else:
                 x_out = ops.gemm(mid, lt["w2"], bias=lt["b2"], residual=x_mid)
-            layers.append(dict(x=x, ln1=ln1, qkv=qkv, att=att, x_mid=x_mid, ln2=ln2, pre1=pre1, mid=mid))
+            layers.append(dict(x=x, ln1=ln1, qkv=qkv, att=att, lse=lse, x_mid=x_mid, ln2=ln2, pre1=pre1, mid=mid))
             x = x_out
         return x, layers
 
@@ -498,11 +381,8 @@ class EncoderTape:
         t, dt, dev = W.t, enc.dtype, enc.device
         B, H = len(T), self.hidden
         lnf = ops.layernorm(x, t["final_ln_g"], t["final_ln_b"], self.ln_eps)
-        P = [(T[u] - enc.pool_kernel) // enc.pool_stride + 1 for u in range(B)]
+        pooled, P = ops.avgpool_batch(lnf, T, enc.pool_kernel, enc.pool_stride)      # one launch for the ragged batch
         poff = _offsets(P)
-        pooled = torch.empty((poff[B], H), device=dev, dtype=dt)
-        for u in range(B):
-            pooled[poff[u]:poff[u + 1]] = ops.avgpool_rows(lnf[toff[u]:toff[u + 1]], enc.pool_kernel, enc.pool_stride)
         out = ops.gemm(pooled, t["proj_w"], bias=t["proj_b"])
         return out, dict(pooled=pooled, P=P, poff=poff)
 
@@ -620,8 +500,8 @@ class EncoderTape:
             d_att = ops.dgrad(d_o1, lt["wo"], wt=ops.transpose_pad(lt["wo"], lt["wo"].shape[0], lt["wo"].shape[1]))
             d_qkv = torch.empty_like(c["qkv"])
             p_att = reg.attention_dropout if reg is not None else 0.0
-            attention_backward_packed(c["qkv"], d_att, d_qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att,
-                                      dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
+            ops.attn_packed_qkv_bwd(c["qkv"], c["att"], d_att, c["lse"], d_qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att,
+                                    dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
             ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
             d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=ops.transpose_pad(lt["wqkv"], lt["wqkv"].shape[0], lt["wqkv"].shape[1]))
             dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, eps, g[p + "ln1_g"], g[p + "ln1_b"])
@@ -904,15 +784,24 @@ class KDTrainer:
         logits_a = self.llm_tape.logits(hidden_a[-1].index_select(0, tail))           # (sum n, V) fp32
         V = logits_a.shape[1]
         losses = torch.zeros((B, 3), device=dev, dtype=torch.float32)
-        scratch = torch.zeros(1, device=dev, dtype=torch.float32)
-        d_logits = torch.zeros((toffs[B], V), device=dev, dtype=dt)
+        d_logits = torch.empty((toffs[B], V), device=dev, dtype=dt)
         inv_acc = 1.0 / self.accum                                                    # ref:trainer.py:373
+        # per-row descriptors of the window's loss launches: label (the last row of an utterance predicts nothing:
+        # logits[-n:-1] vs labels[1:], ref:model/audio_llama.py:84-89), weights of the loss values / gradients, utterance slot
+        lab_rows, coef_rows, slot_rows, mse_rows = [], [], [], []
+        H_llm = a_seq.shape[1]
         for u in range(B):
-            n, r0 = ns[u], toffs[u]
-            labels = response_ids[u][1:].to(torch.int32).contiguous()                 # logits[-n:-1] predict labels[1:]
-            ops.ce_loss(logits_a[r0:r0 + n - 1], labels, 1.0 / (n - 1), losses[u, 0:1], None, dtype=dt)
-            ops.ce_loss(logits_a[r0:r0 + n - 1], labels, self.ntp_w * inv_acc / (n - 1), scratch, d_logits[r0:r0 + n - 1], accumulate=True, dtype=dt)
+            n = ns[u]
+            lab_rows.append(torch.cat([response_ids[u][1:].to(torch.int32), torch.full((1,), -1, dtype=torch.int32, device=dev)]))
+            ld_on = 1.0 if self.use_ld else 0.0
+            coef_rows += [[1.0 / (n - 1), self.ntp_w * inv_acc / (n - 1), ld_on / n, ld_on * self.ld_w * inv_acc / n]] * n
+            slot_rows += [u] * n
+            mse_rows += [[1.0 / (n * H_llm), 2.0 * self.fd_w * inv_acc / (n * H_llm)]] * n
+        labels = torch.cat(lab_rows).contiguous()
+        row_coef = torch.tensor(coef_rows, dtype=torch.float32, device=dev)
+        row_slot = torch.tensor(slot_rows, dtype=torch.int32, device=dev)
         d_hidden: Dict[int, torch.Tensor] = {}
+        logits_t = None
         if self.use_ld or self.use_fd:
             t_parts, t_lens = [], []
             for u in range(B):
@@ -925,21 +814,17 @@ class KDTrainer:
             ttail = torch.cat([torch.arange(tto[u + 1] - ns[u], tto[u + 1]) for u in range(B)]).to(dev)
             if self.use_ld:
                 logits_t = self.llm_tape.logits(hidden_t[-1].index_select(0, ttail))
-                for u in range(B):
-                    n, r0 = ns[u], toffs[u]
-                    ops.soft_ce_loss(logits_a[r0:r0 + n], logits_t[r0:r0 + n], 1.0 / n, losses[u, 1:2], None, dtype=dt)
-                    ops.soft_ce_loss(logits_a[r0:r0 + n], logits_t[r0:r0 + n], self.ld_w * inv_acc / n, scratch, d_logits[r0:r0 + n], accumulate=True, dtype=dt)
             if self.use_fd:
-                for l in self.taps:
+                mse_coef = torch.tensor(mse_rows, dtype=torch.float32, device=dev)
+                for l in self.taps:                                                   # one launch per tap for the whole window
                     ha, ht = hidden_a[l].index_select(0, tail), hidden_t[l].index_select(0, ttail)
                     dtail = torch.empty_like(ha)
-                    for u in range(B):
-                        r0, r1 = toffs[u], toffs[u + 1]
-                        ops.mse_loss(ha[r0:r1], ht[r0:r1], 1.0, losses[u, 2:3], None)
-                        ops.mse_loss(ha[r0:r1], ht[r0:r1], self.fd_w * inv_acc, scratch, dtail[r0:r1])
+                    ops.kd_mse_rows(ha, ht, mse_coef, row_slot, losses, 2, dtail)
                     d = torch.zeros_like(hidden_a[l])
                     d.index_copy_(0, tail, dtail)
                     d_hidden[l] = d
+        # next-token CE + soft CE of every utterance: one launch, the gradient written once
+        ops.kd_logit_losses(logits_a, logits_t, labels, row_coef, row_slot, losses, d_logits, dt)
         d_seq = self.llm_tape.backward(ltape, tail, d_logits, d_hidden)
         d_audio = torch.cat([d_seq[aoff[u] + n_pre: aoff[u] + n_pre + (poff[u + 1] - poff[u])] for u in range(B)], 0).contiguous()
         self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self.reducer.ready if early_buckets else None)

@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_declared_in_header():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/speechllm.h but not exported"
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
-    assert L.lib().sl_version() == 1
+    assert L.lib().sl_version() == 2
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -280,7 +280,7 @@ def test_ctypes_struct_mirrors_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     L = pkg("_lib")
-    pairs = [("sl_gemm_args", L.GemmArgs), ("sl_gemm_fused", L.GemmFused), ("sl_gemm_ex_args", L.GemmEx), ("sl_attn_args", L.AttnArgs),
+    pairs = [("sl_gemm_args", L.GemmArgs), ("sl_gemm_fused", L.GemmFused), ("sl_gemm_ex_args", L.GemmEx), ("sl_attn_args", L.AttnArgs), ("sl_attn_bwd_args", L.AttnBwdArgs),
              ("sl_hubert_layer", L.HubertLayer), ("sl_hubert_model", L.HubertModel), ("sl_llama_layer", L.LlamaLayer),
              ("sl_llama_model", L.LlamaModel), ("sl_kv_cache", L.KVCache)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "speechllm.h")}"', 'int main(void) {']

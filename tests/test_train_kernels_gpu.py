@@ -187,29 +187,8 @@ def test_conv0_backward(dt, Cc, n):
         assert rel_err(got.cpu(), ref) < 5e-4
 
 
-@pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("nh,nkv,D,causal", [(6, 2, 128, True), (4, 4, 64, False)])
-def test_attention_backward_packed_ragged(dt, nh, nkv, D, causal):
-    """One grouped launch per product over all (sequence, kv head) pairs of a ragged packed batch (sl_gemm_ex groups_ext,
-    sl_softmax_*_var) against the per-sequence form and against autograd through an fp32 softmax attention."""
-    training = pkg("training")
-    seqlens = [37, 5, 130, 64]
-    N = sum(seqlens)
-    qkv_w = (nh + 2 * nkv) * D
-    qkv = rnd(N, qkv_w, seed=71, std=0.5)
-    d_att = rnd(N, nh * D, seed=72)
-    scale = D ** -0.5
-    qd, dd = qkv.to(DEV, dt), d_att.to(DEV, dt)
-    d_packed = torch.full_like(qd, float("nan"))
-    training.attention_backward_packed(qd, dd, d_packed, seqlens, nh, nkv, D, causal, scale)
-    d_seq = torch.empty_like(qd)
-    o = 0
-    for S in seqlens:
-        training.attention_backward(qd[o:o + S], dd[o:o + S], d_seq[o:o + S], nh, nkv, D, causal, scale)
-        o += S
-    assert bool(torch.isfinite(d_packed.float()).all())
-    assert rel_err(d_packed.float().cpu(), d_seq.float().cpu()) < (1e-5 if dt == torch.float32 else 2e-2)
-    # autograd reference (fp32 math on the values the kernels see)
+def _attn_autograd(qkv, d_att, seqlens, nh, nkv, D, causal, scale, dt, keep=None, p_drop=0.0):
+    """fp32 softmax attention + autograd on the values the kernels see; keep: (N, nh, 65536) bool dropout mask or None."""
     x = q(qkv, dt).clone().requires_grad_(True)
     outs, o = [], 0
     rep = nh // nkv
@@ -220,10 +199,68 @@ def test_attention_backward_packed_ragged(dt, nh, nkv, D, causal):
         sc = qh @ kh.transpose(1, 2) * scale
         if causal:
             sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
-        outs.append((torch.softmax(sc, -1) @ vh).transpose(0, 1).reshape(S, nh * D))
+        pr = torch.softmax(sc, -1)
+        if keep is not None:
+            pr = pr * keep[o:o + S, :, :S].transpose(0, 1).float() / (1.0 - p_drop)
+        outs.append((pr @ vh).transpose(0, 1).reshape(S, nh * D))
         o += S
-    torch.cat(outs).backward(q(d_att, dt))
-    assert rel_err(d_packed.float().cpu(), x.grad) < (2e-5 if dt == torch.float32 else 3e-2)
+    out = torch.cat(outs)
+    out.backward(q(d_att, dt))
+    return out.detach(), x.grad
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("seqlens", [[37, 5, 130, 64], [499, 1, 200], [16], [333]])
+@pytest.mark.parametrize("nh,nkv,D,causal", [(6, 2, 128, True), (4, 4, 64, False), (4, 4, 64, True), (4, 2, 128, False), (3, 1, 128, True)])
+def test_flash_attention_backward_ragged_vs_autograd(dt, seqlens, nh, nkv, D, causal):
+    """sl_attn_bwd (probabilities recomputed per tile from the forward's log-sum-exp; dK / dV of a GQA group summed in-kernel)
+    on a ragged packed batch against autograd through an fp32 softmax attention."""
+    N = sum(seqlens)
+    qkv = rnd(N, (nh + 2 * nkv) * D, seed=71, std=0.5)
+    d_att = rnd(N, nh * D, seed=72)
+    scale = D ** -0.5
+    qd, dd = qkv.to(DEV, dt), d_att.to(DEV, dt)
+    lse = torch.full((N, nh), float("nan"), device=DEV)
+    out = ops.attn_packed_qkv(qd, seqlens, nh, nkv, D, causal, scale, lse=lse)
+    d_qkv = torch.full_like(qd, float("nan"))
+    ops.attn_packed_qkv_bwd(qd, out, dd, lse, d_qkv, seqlens, nh, nkv, D, causal, scale)
+    assert bool(torch.isfinite(d_qkv.float()).all()) and bool(torch.isfinite(lse).all())
+    ref_out, ref_grad = _attn_autograd(qkv, d_att, seqlens, nh, nkv, D, causal, scale, dt)
+    assert rel_err(out.float().cpu(), ref_out) < TOL[dt]
+    # lse against the definition
+    x = q(qkv, dt)
+    S0 = seqlens[0]
+    sc = (x[:S0, :D] @ x[:S0, nh * D:nh * D + D].T) * scale
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(S0, S0, dtype=torch.bool), 1), float("-inf"))
+    assert float((lse[:S0, 0].cpu() - torch.logsumexp(sc, -1)).abs().max()) < (1e-4 if dt == torch.float32 else 2e-2)
+    tol = 2e-5 if dt == torch.float32 else 3e-2
+    for lo_, hi_ in ((0, nh * D), (nh * D, (nh + nkv) * D), ((nh + nkv) * D, (nh + 2 * nkv) * D)):     # dQ, dK, dV separately
+        assert rel_err(d_qkv[:, lo_:hi_].float().cpu(), ref_grad[:, lo_:hi_]) < tol, (lo_, hi_)
+    # bitwise reproducible (no atomics)
+    d2 = torch.empty_like(qd)
+    ops.attn_packed_qkv_bwd(qd, out, dd, lse, d2, seqlens, nh, nkv, D, causal, scale)
+    assert torch.equal(d2, d_qkv)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_flash_attention_backward_with_probability_dropout(dt):
+    """Training-mode attention dropout (hf HubertAttention): forward and backward rebuild the same counter-based mask; against
+    autograd with the mask restated on the host."""
+    nh, D, p_drop, seed = 4, 64, 0.25, 0x0123_4567_89AB_CDEF
+    seqlens = [70, 133]
+    N = sum(seqlens)
+    qkv = rnd(N, 3 * nh * D, seed=73, std=0.5)
+    d_att = rnd(N, nh * D, seed=74)
+    qd, dd = qkv.to(DEV, dt), d_att.to(DEV, dt)
+    lse = torch.empty((N, nh), device=DEV)
+    out = ops.attn_packed_qkv(qd, seqlens, nh, nh, D, False, D ** -0.5, dropout_p=p_drop, dropout_seed=seed, lse=lse)
+    d_qkv = torch.empty_like(qd)
+    ops.attn_packed_qkv_bwd(qd, out, dd, lse, d_qkv, seqlens, nh, nh, D, False, D ** -0.5, dropout_p=p_drop, dropout_seed=seed)
+    keep = ops.dropout_keep_mask((N * nh) << 16, p_drop, seed).view(N, nh, 1 << 16)
+    ref_out, ref_grad = _attn_autograd(qkv, d_att, seqlens, nh, nh, D, False, D ** -0.5, dt, keep=keep, p_drop=p_drop)
+    assert rel_err(out.float().cpu(), ref_out) < TOL[dt]
+    assert rel_err(d_qkv.float().cpu(), ref_grad) < (2e-5 if dt == torch.float32 else 3e-2)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -256,3 +293,59 @@ def test_transpose_pad(dt, rows, cols, ld_out):
     assert y.shape == (cols, ld_out)
     assert torch.equal(y[:, :rows], x[:rows, :cols].t())
     assert not bool(y[:, rows:].any())
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("V", [1000, 777])        # 16-byte vector path / scalar path (rows not 16-byte aligned)
+def test_kd_window_losses_one_launch_equal_torch(dt, V):
+    """sl_kd_logit_losses / sl_kd_mse_rows: every utterance's next-token CE, soft CE and feature MSE terms of an accumulation
+    window in single launches, against torch (ref:model/audio_llama.py:72-101, ref:utils.py:167-178, ref:trainer.py:358-370)."""
+    ns = [5, 9, 2]
+    rows = sum(ns)
+    s, tch = rnd(rows, V, seed=81, std=2.0), rnd(rows, V, seed=82, std=2.0)
+    gen = torch.Generator().manual_seed(83)
+    resp = [torch.randint(0, V, (n,), generator=gen) for n in ns]
+    w_ntp, w_ld, w_fd, acc = 0.5, 0.25, 1.0, 16.0
+    sr = s.clone().requires_grad_()
+    o, ce, soft = 0, [], []
+    for n, r in zip(ns, resp):
+        ce.append(F.cross_entropy(sr[o:o + n - 1], r[1:]))
+        soft.append((-(F.softmax(tch[o:o + n], -1) * F.log_softmax(sr[o:o + n], -1)).sum(-1)).mean())
+        o += n
+    (sum(w_ntp * c + w_ld * so for c, so in zip(ce, soft)) / acc).backward()
+    labels = torch.cat([torch.cat([r[1:], torch.tensor([-1])]) for r in resp]).to(DEV, torch.int32)
+    coef = torch.tensor([[1 / (n - 1), w_ntp / acc / (n - 1), 1 / n, w_ld / acc / n] for n in ns for _ in range(n)], device=DEV)
+    slot = torch.tensor([u for u, n in enumerate(ns) for _ in range(n)], dtype=torch.int32, device=DEV)
+    losses = torch.zeros(len(ns), 3, device=DEV)
+    ds = torch.full((rows, V), float("nan"), device=DEV, dtype=dt)
+    ops.kd_logit_losses(s.to(DEV), tch.to(DEV), labels, coef, slot, losses, ds, dt)
+    for u in range(len(ns)):
+        assert abs(float(losses[u, 0]) - float(ce[u])) < 1e-4 * float(ce[u]) and abs(float(losses[u, 1]) - float(soft[u])) < 1e-4 * float(soft[u])
+    assert rel_err(ds.float().cpu(), sr.grad) < (1e-5 if dt == torch.float32 else 1e-2)
+    # without a teacher: CE only
+    losses2 = torch.zeros(len(ns), 3, device=DEV)
+    ds2 = torch.empty((rows, V), device=DEV, dtype=dt)
+    ops.kd_logit_losses(s.to(DEV), None, labels, coef, slot, losses2, ds2, dt)
+    sr2 = s.clone().requires_grad_()
+    o = 0
+    tot = 0
+    for n, r in zip(ns, resp):
+        tot = tot + w_ntp / acc * F.cross_entropy(sr2[o:o + n - 1], r[1:])
+        o += n
+    tot.backward()
+    assert rel_err(ds2.float().cpu(), sr2.grad) < (1e-5 if dt == torch.float32 else 1e-2) and float(losses2[:, 1].abs().max()) == 0
+    # feature MSE of one tap
+    H = 256
+    a, b = rnd(rows, H, seed=84), rnd(rows, H, seed=85)
+    ar = q(a, dt).requires_grad_()
+    o, mses = 0, []
+    for n in ns:
+        mses.append(F.mse_loss(ar[o:o + n], q(b, dt)[o:o + n]))
+        o += n
+    (sum(mses) * w_fd / acc).backward()
+    mcoef = torch.tensor([[1 / (n * H), 2 * w_fd / acc / (n * H)] for n in ns for _ in range(n)], device=DEV)
+    da = torch.empty(rows, H, device=DEV, dtype=dt)
+    ops.kd_mse_rows(a.to(DEV, dt), b.to(DEV, dt), mcoef, slot, losses, 2, da)
+    for u in range(len(ns)):
+        assert abs(float(losses[u, 2]) - float(mses[u])) < 1e-5 * float(mses[u])
+    assert rel_err(da.float().cpu(), ar.grad) < TOL[dt]
