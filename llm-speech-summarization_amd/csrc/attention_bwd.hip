@@ -55,6 +55,15 @@ __device__ __forceinline__ int tpos(int row) {
   else return row;
 }
 
+// element j of a 16-byte chunk (no pointer punning: a uint4 store read back through float* is undefined under TBAA and
+// miscompiled the fp32 instantiation)
+template <typename T>
+__device__ __forceinline__ T chunk_elem(const uint4& u, int j) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+  if constexpr (sizeof(T) == 2) return T{(uint16_t)(w[j >> 1] >> (16 * (j & 1)))};
+  else return __builtin_bit_cast(float, w[j]);
+}
+
 template <typename T> __device__ __forceinline__ float exp_scaled(float x) {   // exp(x)
   if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
   else return expf(x);
@@ -67,8 +76,10 @@ __device__ __forceinline__ uint4 pack_step(const f32x4 (&x)[NFR], int ks) {
     return make_uint4(pack2_bf16(x[2 * ks][0], x[2 * ks][1]), pack2_bf16(x[2 * ks][2], x[2 * ks][3]),
                       pack2_bf16(x[2 * ks + 1][0], x[2 * ks + 1][1]), pack2_bf16(x[2 * ks + 1][2], x[2 * ks + 1][3]));
   } else {
-    return make_uint4(__builtin_bit_cast(uint32_t, x[ks][0]), __builtin_bit_cast(uint32_t, x[ks][1]),
-                      __builtin_bit_cast(uint32_t, x[ks][2]), __builtin_bit_cast(uint32_t, x[ks][3]));
+    // copy the elements to scalars first: hipcc (ROCm 7.2) miscompiles __builtin_bit_cast applied directly to an ext_vector
+    // ELEMENT (x[ks][i]) — every cast reads element 0 (verified in isolation on the .s)
+    const float f0 = x[ks][0], f1 = x[ks][1], f2 = x[ks][2], f3 = x[ks][3];
+    return make_uint4(__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3));
   }
 }
 
@@ -162,16 +173,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         const uint4 ud = *(const uint4*)(dob + (int64_t)(q0 + qi) * p.do_rs + ch * VEC);
         *(uint4*)(Qs + swz<CPR>(row, ch)) = uq;
         *(uint4*)(dOs + swz<CPR>(row, ch)) = ud;
-        T eq[VEC], ed[VEC];
-        *(uint4*)eq = uq;
-        *(uint4*)ed = ud;
         const int pos = tpos<T>(row);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const int d = ch * VEC + j;
           const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
-          *(T*)(QT + off) = eq[j];
-          *(T*)(dOT + off) = ed[j];
+          *(T*)(QT + off) = chunk_elem<T>(uq, j);
+          *(T*)(dOT + off) = chunk_elem<T>(ud, j);
         }
       }
       if (tid < TQ) {
@@ -312,13 +320,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
       const uint4 uv = *(const uint4*)(vb + (int64_t)kr * p.v_rs + ch * VEC);
       *(uint4*)(Ks + swz<CPR>(row, ch)) = uk;
       *(uint4*)(Vs + swz<CPR>(row, ch)) = uv;
-      T ek[VEC];
-      *(uint4*)ek = uk;
       const int pos = tpos<T>(row);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const int d = ch * VEC + j;
-        *(T*)(KT + swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ) = ek[j];
+        *(T*)(KT + swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ) = chunk_elem<T>(uk, j);
       }
     }
     __syncthreads();
