@@ -481,6 +481,76 @@ int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, 
                        int32_t* n_steps_host, float* timings_ms_host /* [prefill, decode] or NULL */,
                        void* workspace, size_t workspace_bytes, sl_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * KD step, layer stacks (C++ host runtime of the training tape: one call issues the launches of a whole stack of layers
+ * over a packed ragged batch; ref:trainer.py:270-384 runs the same arithmetic through autograd, one utterance at a time).
+ * Saved activations, hidden states and fp32 gradient accumulators are caller-owned; temporaries come from `workspace`.
+ *
+ * Encoder (HuBERT stable-LN layer hf:models/hubert/modeling_hubert.py:504-547; Whisper hf:models/whisper/modeling_whisper.py:
+ * 360-414; head_dim 64, bidirectional): train()-mode regularisers as sl_dropout / sl_attn_args.dropout_p, LayerDrop via `skip`.
+ *   seeds: HOST array (n_layers, 4) = {attention-probability, attention-output, activation, ffn-output} dropout seeds.
+ *   fwd: layer l reads its input (x_in or the previous layer's x_out), fills saved[l] (and records the input pointer in
+ *        saved[l].x); *x_out = the stack's output.  bwd: layers layer_end-1 .. layer_begin; dx holds d(output of layer
+ *        layer_end-1) on entry and d(input of layer layer_begin) on return; parameter gradients ACCUMULATE into grads[l]
+ *        (kernel layouts: wqkv (3H, H), w1 (F, H), w2 (H, F), ...).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype, hidden, n_heads, ffn, n_layers, nseq, max_len, reserved;
+  int64_t n_tok;
+  float ln_eps, p_hidden, p_act, p_attn;
+  const int32_t* cu;       /* (nseq+1) device: first packed row of each sequence */
+  const int32_t* klen;     /* (nseq) device */
+  const uint8_t* skip;     /* (n_layers) HOST: 1 = LayerDrop skips the layer */
+  const uint64_t* seeds;   /* (n_layers, 4) HOST */
+} sl_enc_stack_cfg;
+typedef struct {
+  const void* x;                                            /* layer input, recorded by the forward */
+  void *ln1, *qkv, *att, *x_mid, *ln2, *pre1, *mid, *x_out; /* (n_tok, H | 3H | H | H | H | F | F | H) */
+  float* lse;                                               /* (n_tok, n_heads) */
+} sl_enc_layer_saved;
+typedef struct {
+  float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+} sl_enc_layer_grads;
+size_t sl_encoder_stack_train_workspace_bytes(const sl_enc_stack_cfg* c);
+int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const sl_enc_stack_cfg* c, const void* x_in, sl_enc_layer_saved* saved,
+                               const void** x_out, void* workspace, size_t workspace_bytes, sl_stream stream);
+int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const sl_enc_stack_cfg* c, const sl_enc_layer_saved* saved,
+                               const sl_enc_layer_grads* grads, int32_t layer_begin, int32_t layer_end, void* dx, void* workspace,
+                               size_t workspace_bytes, sl_stream stream);
+
+/* Frozen Llama decoder (hf:models/llama/modeling_llama.py:284-324; head_dim 128, causal GQA) over packed sequences:
+ *   hidden: HOST array of n_layers + 1 device buffers (n_tok, H): hidden[0] = input embeddings (caller-filled),
+ *           hidden[l + 1] = output of layer l (written by fwd) — these are HF's `hidden_states` taps before the final norm.
+ *   fwd:    saved == NULL keeps nothing else (teacher pass, torch.no_grad in ref:trainer.py:337-344); otherwise saved[l]
+ *           receives what the data-gradient backward needs.
+ *   bwd:    dx = d(hidden[n_layers]) on entry, d(hidden[0]) on return; d_tap (HOST array of n_layers pointers or NULL):
+ *           d_tap[l] != NULL is added to the gradient of hidden[l] (feature-distillation terms, ref:trainer.py:358-370).
+ *   pos: (n_tok) device position ids; layers[l].*_t: transposed copies (in, out) of the frozen weights for the dgrad GEMMs. */
+typedef struct {
+  int32_t dtype, hidden, n_heads, n_kv_heads, head_dim, ffn, n_layers, nseq, max_len, reserved;
+  int64_t n_tok;
+  float rms_eps;
+  const int32_t* cu;
+  const int32_t* klen;
+  const int32_t* pos;
+  const float* rope_cos;
+  const float* rope_sin;
+} sl_llama_stack_cfg;
+typedef struct {
+  const void *norm1, *wqkv, *wo, *norm2, *wgu, *wdown;   /* nn.Linear layouts; gate/up interleaved in 16-row blocks */
+  const void *wqkv_t, *wo_t, *wgu_t, *wdown_t;           /* (in, out) copies; only the backward reads them */
+} sl_llama_train_layer;
+typedef struct {
+  void *qkv, *x2, *gu, *att;   /* (n_tok, (nh+2nkv)D | H | 2F | nh D) */
+  float* lse;                  /* (n_tok, n_heads) */
+} sl_llama_layer_saved;
+size_t sl_llama_stack_train_workspace_bytes(const sl_llama_stack_cfg* c);
+int sl_llama_stack_train_fwd(const sl_llama_train_layer* layers, const sl_llama_stack_cfg* c, void* const* hidden,
+                             const sl_llama_layer_saved* saved, void* workspace, size_t workspace_bytes, sl_stream stream);
+int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, const sl_llama_stack_cfg* c, void* const* hidden,
+                             const sl_llama_layer_saved* saved, void* const* d_tap, void* dx, void* workspace, size_t workspace_bytes,
+                             sl_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,34 @@ class LlamaModel(C.Structure):
                 ("lm_head_dec", c_vp), ("dec_fused_norm", c_i32), ("reserved", c_i32)]
 
 
+class EncStackCfg(C.Structure):
+    _fields_ = [("dtype", c_i32), ("hidden", c_i32), ("n_heads", c_i32), ("ffn", c_i32), ("n_layers", c_i32), ("nseq", c_i32), ("max_len", c_i32),
+                ("reserved", c_i32), ("n_tok", c_i64), ("ln_eps", c_f32), ("p_hidden", c_f32), ("p_act", c_f32), ("p_attn", c_f32),
+                ("cu", c_vp), ("klen", c_vp), ("skip", c_vp), ("seeds", c_vp)]
+
+
+class EncLayerSaved(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("x", "ln1", "qkv", "att", "x_mid", "ln2", "pre1", "mid", "x_out", "lse")]
+
+
+class EncLayerGrads(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
+class LlamaStackCfg(C.Structure):
+    _fields_ = [("dtype", c_i32), ("hidden", c_i32), ("n_heads", c_i32), ("n_kv_heads", c_i32), ("head_dim", c_i32), ("ffn", c_i32),
+                ("n_layers", c_i32), ("nseq", c_i32), ("max_len", c_i32), ("reserved", c_i32), ("n_tok", c_i64), ("rms_eps", c_f32),
+                ("cu", c_vp), ("klen", c_vp), ("pos", c_vp), ("rope_cos", c_vp), ("rope_sin", c_vp)]
+
+
+class LlamaTrainLayer(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("norm1", "wqkv", "wo", "norm2", "wgu", "wdown", "wqkv_t", "wo_t", "wgu_t", "wdown_t")]
+
+
+class LlamaLayerSaved(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("qkv", "x2", "gu", "att", "lse")]
+
+
 class KVCache(C.Structure):
     _fields_ = [("k_cache", c_vp), ("v_cache", c_vp), ("slots", c_i32), ("max_ctx", c_i32)]
 
@@ -163,6 +191,14 @@ _PROTOS = {
     "sl_attn_decode": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sl_greedy_select": (c_i32, [c_vp, c_i32, c_i32, C.POINTER(c_i32), c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_i32, c_vp]),
+    "sl_encoder_stack_train_workspace_bytes": (c_sz, [C.POINTER(EncStackCfg)]),
+    "sl_encoder_stack_train_fwd": (c_i32, [C.POINTER(HubertLayer), C.POINTER(EncStackCfg), c_vp, C.POINTER(EncLayerSaved), C.POINTER(c_vp), c_vp, c_sz, c_vp]),
+    "sl_encoder_stack_train_bwd": (c_i32, [C.POINTER(HubertLayer), C.POINTER(EncStackCfg), C.POINTER(EncLayerSaved), C.POINTER(EncLayerGrads), c_i32, c_i32,
+                                           c_vp, c_vp, c_sz, c_vp]),
+    "sl_llama_stack_train_workspace_bytes": (c_sz, [C.POINTER(LlamaStackCfg)]),
+    "sl_llama_stack_train_fwd": (c_i32, [C.POINTER(LlamaTrainLayer), C.POINTER(LlamaStackCfg), C.POINTER(c_vp), C.POINTER(LlamaLayerSaved), c_vp, c_sz, c_vp]),
+    "sl_llama_stack_train_bwd": (c_i32, [C.POINTER(LlamaTrainLayer), C.POINTER(LlamaStackCfg), C.POINTER(c_vp), C.POINTER(LlamaLayerSaved), C.POINTER(c_vp),
+                                         c_vp, c_vp, c_sz, c_vp]),
     "sl_hubert_workspace_bytes": (c_sz, [C.POINTER(HubertModel), C.POINTER(c_i64), c_i32]),
     "sl_hubert_num_frames": (c_i32, [C.POINTER(HubertModel), c_i64]),
     "sl_hubert_forward": (c_i32, [C.POINTER(HubertModel), c_vp, C.POINTER(c_i64), c_i32, c_vp, c_i64, C.POINTER(c_i64), c_vp,

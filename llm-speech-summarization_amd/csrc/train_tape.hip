@@ -1,0 +1,353 @@
+// train_tape.hip — C++ host runtime of the KD step's layer stacks (ref:trainer.py:270-384): the forward-with-tape and the
+// backward of the encoder's pre-LN transformer layers (HuBERT / Whisper, data + parameter gradients) and of the frozen
+// Llama decoder (data gradients only) over a PACKED ragged batch, as plain launch sequences over the library's own kernels.
+// The Python tape (training.py) used to issue these ~3 500 launches per accumulation window one ctypes call at a time and was
+// host-bound (150 ms of kernels in 236 ms of wall time); here one call covers a whole stack.  Saved activations and
+// gradient accumulators are caller-owned buffers handed in as plain structs; temporaries come from one workspace.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct Carver {
+  unsigned char* base;
+  size_t off = 0, cap;
+  Carver(void* b, size_t c) : base((unsigned char*)b), cap(c) {}
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+inline int64_t rup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+
+// C = act(A W^T + bias) + residual   (ops.gemm)
+int gemm(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* res, int64_t ldr,
+         int64_t M, int N, int K, int act, void* aux_out, hipStream_t st) {
+  sl_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.residual = res; a.ldr = ldr;
+  a.M = (int)M; a.N = N; a.K = K; a.batch = 1; a.dtype = dt; a.act = act;
+  if (!aux_out) return sl_gemm(&a, (sl_stream)st);
+  sl_gemm_ex_args ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.aux_out = aux_out; ex.w_mod = 1;
+  return sl_gemm_ex(&a, &ex, (sl_stream)st);
+}
+
+// scratch for the K-contiguous operand copies of the backward products
+struct BwdScratch {
+  void* yt;   // dY^T  (N_out_max, Mp)
+  void* xt;   // X^T   (K_in_max, Mp)
+  void* wt;   // W^T   (K_in_max, ld(N_out_max))
+};
+
+// dX (M, K_in) = dY (M, N_out) . W (N_out, K_in), through a transposed copy of W so that the product is K-contiguous
+// (ops.dgrad with wt = ops.transpose_pad(W)); wt_cached != NULL: the copy already exists (frozen weights)
+int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_in, const void* wt_cached, void* dX, int64_t ldx, int64_t M,
+          const BwdScratch& s, hipStream_t st) {
+  const int vec = dt == SL_F32 ? 4 : 8;
+  const int64_t ldw = rup(n_out, vec);
+  const void* wt = wt_cached;
+  if (!wt) {
+    SL_TRY(sl_transpose_pad(W, k_in, s.wt, ldw, n_out, k_in, n_out, dt, (sl_stream)st));
+    wt = s.wt;
+  }
+  return gemm(dt, dY, ldy, wt, wt_cached ? n_out : ldw, dX, ldx, nullptr, nullptr, 0, M, k_in, n_out, SL_ACT_NONE, nullptr, st);
+}
+
+// dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in)       (ops.wgrad_acc, plain Linear)
+int wgrad_acc(int dt, const void* dY, int64_t ldy, int n_out, const void* X, int64_t ldx, int k_in, float* dW, int64_t M, const BwdScratch& s,
+              hipStream_t st) {
+  sl_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  sl_gemm_ex_args ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.w_mod = 1; ex.residual_f32 = 1;
+  a.C = dW; a.ldc = k_in; a.residual = dW; a.ldr = k_in; a.M = n_out; a.N = k_in; a.batch = 1; a.dtype = dt; a.out_f32 = 1;
+  if (M >= 256) {
+    // contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to whole K slabs): LDS-DMA tiled kernels
+    const int64_t Mp = rup(M, 64);
+    SL_TRY(sl_transpose_pad(dY, ldy, s.yt, Mp, (int)M, n_out, (int)Mp, dt, (sl_stream)st));
+    SL_TRY(sl_transpose_pad(X, ldx, s.xt, Mp, (int)M, k_in, (int)Mp, dt, (sl_stream)st));
+    a.A = s.yt; a.lda = Mp; a.W = s.xt; a.ldw = Mp; a.K = (int)Mp;
+    return sl_gemm_ex(&a, &ex, (sl_stream)st);
+  }
+  ex.trans_a = 1; ex.trans_w = 1;
+  a.A = dY; a.lda = ldy; a.W = X; a.ldw = ldx; a.K = (int)M;
+  return sl_gemm_ex(&a, &ex, (sl_stream)st);
+}
+
+int attn_fwd(int dt, const void* qkv, int64_t qkv_w, void* out, float* lse, const int32_t* cu, const int32_t* klen, int nseq, int max_len, int nh,
+             int nkv, int D, int causal, float scale, float p_drop, uint64_t seed, hipStream_t st) {
+  const size_t sz = sl_dtype_size(dt);
+  sl_attn_args a;
+  memset(&a, 0, sizeof(a));
+  a.q = qkv; a.q_row_stride = qkv_w; a.q_head_stride = D;
+  a.k = (const unsigned char*)qkv + (size_t)nh * D * sz; a.k_row_stride = qkv_w; a.k_head_stride = D;
+  a.v = (const unsigned char*)qkv + (size_t)(nh + nkv) * D * sz; a.v_row_stride = qkv_w; a.v_head_stride = D;
+  a.out = out; a.o_row_stride = (int64_t)nh * D; a.o_head_stride = D;
+  a.cu_q = cu; a.cu_k = cu; a.klen = klen;
+  a.nseq = nseq; a.max_qlen = max_len; a.n_heads = nh; a.n_kv_heads = nkv; a.head_dim = D; a.causal = causal; a.dtype = dt;
+  a.scale = scale; a.dropout_p = p_drop; a.dropout_seed = seed; a.lse = lse;
+  return sl_attn_fwd(&a, (sl_stream)st);
+}
+
+int attn_bwd(int dt, const void* qkv, int64_t qkv_w, const void* out, const void* d_out, const float* lse, float* delta, void* d_qkv,
+             const int32_t* cu, const int32_t* klen, int nseq, int max_len, int64_t n_tok, int nh, int nkv, int D, int causal, float scale,
+             float p_drop, uint64_t seed, hipStream_t st) {
+  const size_t sz = sl_dtype_size(dt);
+  sl_attn_bwd_args a;
+  memset(&a, 0, sizeof(a));
+  const size_t koff = (size_t)nh * D * sz, voff = (size_t)(nh + nkv) * D * sz;
+  a.q = qkv; a.q_row_stride = qkv_w; a.q_head_stride = D;
+  a.k = (const unsigned char*)qkv + koff; a.k_row_stride = qkv_w; a.k_head_stride = D;
+  a.v = (const unsigned char*)qkv + voff; a.v_row_stride = qkv_w; a.v_head_stride = D;
+  a.out = out; a.o_row_stride = (int64_t)nh * D; a.o_head_stride = D;
+  a.d_out = d_out; a.do_row_stride = (int64_t)nh * D; a.do_head_stride = D;
+  a.dq = d_qkv; a.dq_row_stride = qkv_w; a.dq_head_stride = D;
+  a.dk = (unsigned char*)d_qkv + koff; a.dk_row_stride = qkv_w; a.dk_head_stride = D;
+  a.dv = (unsigned char*)d_qkv + voff; a.dv_row_stride = qkv_w; a.dv_head_stride = D;
+  a.lse = lse; a.delta = delta; a.cu_q = cu; a.cu_k = cu; a.klen = klen; a.n_tok_q = n_tok;
+  a.nseq = nseq; a.max_qlen = max_len; a.max_klen = max_len; a.n_heads = nh; a.n_kv_heads = nkv; a.head_dim = D; a.causal = causal; a.dtype = dt;
+  a.scale = scale; a.dropout_p = p_drop; a.dropout_seed = seed;
+  return sl_attn_bwd(&a, (sl_stream)st);
+}
+
+}  // namespace
+
+// ================================================================================================
+// encoder stack (hf:models/hubert/modeling_hubert.py:504-547 stable-LN layer; hf:models/whisper/modeling_whisper.py:360-414)
+// ================================================================================================
+struct EncWs {
+  void *tmp_h, *d_mid, *d_pre1, *d_h1, *d_h2, *d_att, *d_qkv;
+  float* delta;
+  BwdScratch s;
+};
+
+static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs& w) {
+  const size_t sz = sl_dtype_size(c->dtype);
+  const int64_t n = c->n_tok, H = c->hidden, F = c->ffn;
+  const int64_t Mp = rup(n, 64);
+  const int64_t big = F > 3 * H ? F : 3 * H;
+  Carver cv(base, cap);
+  w.tmp_h = cv.take(n * H * sz);
+  w.d_mid = cv.take(n * F * sz);
+  w.d_pre1 = cv.take(n * F * sz);
+  w.d_h1 = cv.take(n * H * sz);
+  w.d_h2 = cv.take(n * H * sz);
+  w.d_att = cv.take(n * H * sz);
+  w.d_qkv = cv.take(n * 3 * H * sz);
+  w.delta = (float*)cv.take(n * c->n_heads * sizeof(float));
+  w.s.yt = cv.take(big * Mp * sz);
+  w.s.xt = cv.take(big * Mp * sz);
+  w.s.wt = cv.take(big * (big + 8) * sz);
+  return cv.off + 256;
+}
+
+extern "C" size_t sl_encoder_stack_train_workspace_bytes(const sl_enc_stack_cfg* c) {
+  EncWs w;
+  return enc_carve(c, nullptr, 0, w);
+}
+
+extern "C" int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const sl_enc_stack_cfg* c, const void* x_in, sl_enc_layer_saved* saved,
+                                          const void** x_out, void* workspace, size_t workspace_bytes, sl_stream stream) {
+  SL_CHECK_ARG(layers && c && x_in && saved && x_out && workspace && c->cu && c->klen && c->seeds && c->skip, "sl_encoder_stack_train_fwd: null pointer");
+  SL_CHECK_ARG(c->hidden % c->n_heads == 0 && c->hidden / c->n_heads == 64, "sl_encoder_stack_train_fwd: head_dim must be 64");
+  EncWs w;
+  SL_CHECK_ARG(enc_carve(c, workspace, workspace_bytes, w) <= workspace_bytes, "sl_encoder_stack_train_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
+  const int64_t n = c->n_tok;
+  const void* x = x_in;
+  for (int l = 0; l < c->n_layers; ++l) {
+    sl_enc_layer_saved& sv = saved[l];
+    sv.x = x;
+    if (c->skip[l]) continue;              // LayerDrop: identity in both directions
+    const sl_hubert_layer& L = layers[l];
+    const uint64_t* sd = c->seeds + 4 * (size_t)l;
+    SL_CHECK_ARG(sv.ln1 && sv.qkv && sv.att && sv.lse && sv.x_mid && sv.ln2 && sv.pre1 && sv.mid && sv.x_out, "sl_encoder_stack_train_fwd: layer %d lacks a saved buffer", l);
+    SL_TRY(sl_layernorm(x, sv.ln1, L.ln1_g, L.ln1_b, n, H, c->ln_eps, 0, dt, stream));
+    SL_TRY(gemm(dt, sv.ln1, H, L.wqkv, H, sv.qkv, 3 * H, L.bqkv, nullptr, 0, n, 3 * H, H, SL_ACT_NONE, nullptr, st));
+    SL_TRY(attn_fwd(dt, sv.qkv, 3 * H, sv.att, sv.lse, c->cu, c->klen, c->nseq, c->max_len, nh, nh, 64, 0, 0.125f, c->p_attn, sd[0], st));
+    if (c->p_hidden > 0.f) {               // h = residual + dropout(attention(layer_norm(h)))
+      SL_TRY(gemm(dt, sv.att, H, L.wo, H, w.tmp_h, H, L.bo, nullptr, 0, n, H, H, SL_ACT_NONE, nullptr, st));
+      SL_TRY(sl_dropout(w.tmp_h, x, sv.x_mid, n * H, c->p_hidden, sd[1], dt, stream));
+    } else {
+      SL_TRY(gemm(dt, sv.att, H, L.wo, H, sv.x_mid, H, L.bo, x, H, n, H, H, SL_ACT_NONE, nullptr, st));
+    }
+    SL_TRY(sl_layernorm(sv.x_mid, sv.ln2, L.ln2_g, L.ln2_b, n, H, c->ln_eps, 0, dt, stream));
+    SL_TRY(gemm(dt, sv.ln2, H, L.w1, H, sv.mid, F, L.b1, nullptr, 0, n, F, H, SL_ACT_GELU, sv.pre1, st));
+    if (c->p_act > 0.f) SL_TRY(sl_dropout(sv.mid, nullptr, sv.mid, n * F, c->p_act, sd[2], dt, stream));
+    if (c->p_hidden > 0.f) {               // h = h + output_dropout(output_dense(...))
+      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, w.tmp_h, H, L.b2, nullptr, 0, n, H, F, SL_ACT_NONE, nullptr, st));
+      SL_TRY(sl_dropout(w.tmp_h, sv.x_mid, sv.x_out, n * H, c->p_hidden, sd[3], dt, stream));
+    } else {
+      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, sv.x_out, H, L.b2, sv.x_mid, H, n, H, F, SL_ACT_NONE, nullptr, st));
+    }
+    x = sv.x_out;
+  }
+  *x_out = x;
+  return 0;
+}
+
+extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const sl_enc_stack_cfg* c, const sl_enc_layer_saved* saved,
+                                          const sl_enc_layer_grads* grads, int32_t layer_begin, int32_t layer_end, void* dx, void* workspace,
+                                          size_t workspace_bytes, sl_stream stream) {
+  SL_CHECK_ARG(layers && c && saved && grads && dx && workspace && c->cu && c->klen && c->seeds && c->skip, "sl_encoder_stack_train_bwd: null pointer");
+  SL_CHECK_ARG(0 <= layer_begin && layer_begin <= layer_end && layer_end <= c->n_layers, "sl_encoder_stack_train_bwd: bad layer range");
+  EncWs w;
+  SL_CHECK_ARG(enc_carve(c, workspace, workspace_bytes, w) <= workspace_bytes, "sl_encoder_stack_train_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
+  const int64_t n = c->n_tok;
+  const size_t sz = sl_dtype_size(dt);
+  for (int l = layer_end - 1; l >= layer_begin; --l) {
+    if (c->skip[l]) continue;
+    const sl_hubert_layer& L = layers[l];
+    const sl_enc_layer_saved& sv = saved[l];
+    const sl_enc_layer_grads& g = grads[l];
+    const uint64_t* sd = c->seeds + 4 * (size_t)l;
+    // ---- feed-forward half: x_out = x_mid + drop(w2 . drop_act(gelu(w1 . ln2(x_mid) + b1)) + b2)
+    const void* d_o2 = dx;
+    if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(dx, nullptr, w.tmp_h, n * H, c->p_hidden, sd[3], dt, stream)); d_o2 = w.tmp_h; }
+    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, st));
+    SL_TRY(sl_colsum(d_o2, H, g.b2, n, H, dt, stream));
+    SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_mid, F, n, w.s, st));
+    if (c->p_act > 0.f) SL_TRY(sl_dropout(w.d_mid, nullptr, w.d_mid, n * F, c->p_act, sd[2], dt, stream));
+    SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, w.d_pre1, n * F, dt, stream));
+    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, st));
+    SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, stream));
+    SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st));
+    SL_TRY(sl_layernorm_bwd(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, 0, dt, stream));   // d_h2 = d x_mid (LN path)
+    SL_TRY(sl_axpby(dx, w.d_h2, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
+    // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
+    const void* d_o1 = w.d_h2;
+    if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(w.d_h2, nullptr, w.tmp_h, n * H, c->p_hidden, sd[1], dt, stream)); d_o1 = w.tmp_h; }
+    SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, st));
+    SL_TRY(sl_colsum(d_o1, H, g.bo, n, H, dt, stream));
+    SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, nullptr, w.d_att, H, n, w.s, st));
+    SL_TRY(attn_bwd(dt, sv.qkv, 3 * H, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nh, 64, 0, 0.125f,
+                    c->p_attn, sd[0], st));
+    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, st));
+    SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, stream));
+    SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st));
+    SL_TRY(sl_layernorm_bwd(sv.x, L.ln1_g, L.ln1_b, w.d_h1, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, 0, dt, stream));            // dx = d x (LN path)
+    SL_TRY(sl_axpby(w.d_h2, dx, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
+    (void)sz;
+  }
+  return 0;
+}
+
+// ================================================================================================
+// frozen Llama decoder over packed sequences (hf:models/llama/modeling_llama.py:284-324): forward with a tape and the
+// data-gradient backward (its weights have requires_grad = False, ref:trainer.py:63-64)
+// ================================================================================================
+struct LlamaTrainWs {
+  void *h, *mid, *qkv, *x2, *gu, *att, *d_mid, *d_gu, *d_h, *dx2, *d_att, *d_qkv;
+  float *lse, *delta;
+  BwdScratch s;
+};
+
+static size_t llama_train_carve(const sl_llama_stack_cfg* c, void* base, size_t cap, LlamaTrainWs& w) {
+  const size_t sz = sl_dtype_size(c->dtype);
+  const int64_t n = c->n_tok, H = c->hidden, F = c->ffn;
+  const int64_t qkv_w = (int64_t)(c->n_heads + 2 * c->n_kv_heads) * c->head_dim, att_w = (int64_t)c->n_heads * c->head_dim;
+  Carver cv(base, cap);
+  w.h = cv.take(n * H * sz);
+  w.mid = cv.take(n * F * sz);
+  w.qkv = cv.take(n * qkv_w * sz);
+  w.x2 = cv.take(n * H * sz);
+  w.gu = cv.take(n * 2 * F * sz);
+  w.att = cv.take(n * att_w * sz);
+  w.d_mid = cv.take(n * F * sz);
+  w.d_gu = cv.take(n * 2 * F * sz);
+  w.d_h = cv.take(n * H * sz);
+  w.dx2 = cv.take(n * H * sz);
+  w.d_att = cv.take(n * att_w * sz);
+  w.d_qkv = cv.take(n * qkv_w * sz);
+  w.lse = (float*)cv.take(n * c->n_heads * sizeof(float));
+  w.delta = (float*)cv.take(n * c->n_heads * sizeof(float));
+  w.s.yt = w.s.xt = w.s.wt = nullptr;    // data gradients only, on cached transposed weights
+  return cv.off + 256;
+}
+
+extern "C" size_t sl_llama_stack_train_workspace_bytes(const sl_llama_stack_cfg* c) {
+  LlamaTrainWs w;
+  return llama_train_carve(c, nullptr, 0, w);
+}
+
+extern "C" int sl_llama_stack_train_fwd(const sl_llama_train_layer* layers, const sl_llama_stack_cfg* c, void* const* hidden,
+                                        const sl_llama_layer_saved* saved, void* workspace, size_t workspace_bytes, sl_stream stream) {
+  SL_CHECK_ARG(layers && c && hidden && workspace && c->cu && c->klen && c->pos && c->rope_cos && c->rope_sin, "sl_llama_stack_train_fwd: null pointer");
+  SL_CHECK_ARG(c->head_dim == 128, "sl_llama_stack_train_fwd: head_dim %d not built (128)", c->head_dim);
+  LlamaTrainWs w;
+  SL_CHECK_ARG(llama_train_carve(c, workspace, workspace_bytes, w) <= workspace_bytes, "sl_llama_stack_train_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads, nkv = c->n_kv_heads, D = c->head_dim;
+  const int qkv_w = (nh + 2 * nkv) * D, att_w = nh * D;
+  const int64_t n = c->n_tok;
+  const float scale = 1.0f / sqrtf((float)D);
+  for (int l = 0; l < c->n_layers; ++l) {
+    const sl_llama_train_layer& L = layers[l];
+    const void* x = hidden[l];
+    void* x_next = hidden[l + 1];
+    SL_CHECK_ARG(x && x_next, "sl_llama_stack_train_fwd: hidden[%d] / hidden[%d] missing", l, l + 1);
+    // saved == NULL: teacher pass, nothing is kept but the hidden states themselves
+    void* qkv = saved ? saved[l].qkv : w.qkv;
+    void* x2 = saved ? saved[l].x2 : w.x2;
+    void* gu = saved ? saved[l].gu : w.gu;
+    void* att = saved ? saved[l].att : w.att;
+    float* lse = saved ? saved[l].lse : nullptr;
+    SL_CHECK_ARG(qkv && x2 && gu && att && (!saved || lse), "sl_llama_stack_train_fwd: layer %d lacks a saved buffer", l);
+    SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, c->rms_eps, dt, stream));
+    SL_TRY(gemm(dt, w.h, H, L.wqkv, H, qkv, qkv_w, nullptr, nullptr, 0, n, qkv_w, H, SL_ACT_NONE, nullptr, st));
+    SL_TRY(sl_rope_inplace(qkv, c->pos, c->rope_cos, c->rope_sin, n, nh + 2 * nkv, nh + nkv, D, 0, dt, stream));
+    SL_TRY(attn_fwd(dt, qkv, qkv_w, att, lse, c->cu, c->klen, c->nseq, c->max_len, nh, nkv, D, 1, scale, 0.f, 0, st));
+    SL_TRY(gemm(dt, att, att_w, L.wo, att_w, x2, H, nullptr, x, H, n, H, att_w, SL_ACT_NONE, nullptr, st));
+    SL_TRY(sl_rmsnorm(x2, w.h, L.norm2, n, H, c->rms_eps, dt, stream));
+    SL_TRY(gemm(dt, w.h, H, L.wgu, H, gu, 2 * F, nullptr, nullptr, 0, n, 2 * F, H, SL_ACT_NONE, nullptr, st));   // interleaved gate/up pre-activations
+    SL_TRY(sl_silu_mul(gu, w.mid, n, F, dt, stream));
+    SL_TRY(gemm(dt, w.mid, F, L.wdown, F, x_next, H, nullptr, x2, H, n, H, F, SL_ACT_NONE, nullptr, st));
+  }
+  return 0;
+}
+
+extern "C" int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, const sl_llama_stack_cfg* c, void* const* hidden,
+                                        const sl_llama_layer_saved* saved, void* const* d_tap, void* dx, void* workspace, size_t workspace_bytes,
+                                        sl_stream stream) {
+  SL_CHECK_ARG(layers && c && hidden && saved && dx && workspace && c->cu && c->klen && c->pos && c->rope_cos && c->rope_sin,
+               "sl_llama_stack_train_bwd: null pointer");
+  SL_CHECK_ARG(c->head_dim == 128, "sl_llama_stack_train_bwd: head_dim %d not built (128)", c->head_dim);
+  LlamaTrainWs w;
+  SL_CHECK_ARG(llama_train_carve(c, workspace, workspace_bytes, w) <= workspace_bytes, "sl_llama_stack_train_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads, nkv = c->n_kv_heads, D = c->head_dim;
+  const int qkv_w = (nh + 2 * nkv) * D, att_w = nh * D;
+  const int64_t n = c->n_tok;
+  const float scale = 1.0f / sqrtf((float)D);
+  for (int l = c->n_layers - 1; l >= 0; --l) {
+    const sl_llama_train_layer& L = layers[l];
+    const sl_llama_layer_saved& sv = saved[l];
+    SL_CHECK_ARG(L.wqkv_t && L.wo_t && L.wgu_t && L.wdown_t, "sl_llama_stack_train_bwd: layer %d lacks the transposed weights", l);
+    // x3 = x2 + wdown . (silu(gate) * up),   [gate | up] = wgu . rmsnorm(x2)
+    SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_mid, F, n, w.s, st));
+    SL_TRY(sl_silu_mul_bwd(sv.gu, w.d_mid, w.d_gu, n, F, dt, stream));
+    SL_TRY(dgrad(dt, w.d_gu, 2 * F, L.wgu, 2 * F, H, L.wgu_t, w.d_h, H, n, w.s, st));
+    SL_TRY(sl_rmsnorm_bwd(sv.x2, L.norm2, w.d_h, w.dx2, n, H, c->rms_eps, dt, stream));
+    SL_TRY(sl_axpby(dx, w.dx2, 1.f, 1.f, n * H, dt, stream));                       // residual join
+    // x2 = x + wo . attn(rope(wqkv . rmsnorm(x)))
+    SL_TRY(dgrad(dt, w.dx2, H, L.wo, H, att_w, L.wo_t, w.d_att, att_w, n, w.s, st));
+    SL_TRY(attn_bwd(dt, sv.qkv, qkv_w, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nkv, D, 1, scale, 0.f, 0,
+                    st));
+    SL_TRY(sl_rope_inplace(w.d_qkv, c->pos, c->rope_cos, c->rope_sin, n, nh + 2 * nkv, nh + nkv, D, 1, dt, stream));
+    SL_TRY(dgrad(dt, w.d_qkv, qkv_w, L.wqkv, qkv_w, H, L.wqkv_t, w.d_h, H, n, w.s, st));
+    SL_TRY(sl_rmsnorm_bwd(hidden[l], L.norm1, w.d_h, dx, n, H, c->rms_eps, dt, stream));
+    SL_TRY(sl_axpby(w.dx2, dx, 1.f, 1.f, n * H, dt, stream));
+    if (d_tap && d_tap[l]) SL_TRY(sl_axpby(d_tap[l], dx, 1.f, 1.f, n * H, dt, stream));     // feature-distillation gradient of hidden_states[l]
+  }
+  return 0;
+}

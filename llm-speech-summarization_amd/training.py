@@ -21,6 +21,7 @@ function of (token, head, key), so the flash-style backward, which recomputes th
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -130,11 +131,22 @@ def _offsets(lens: Sequence[int]) -> List[int]:
 # frozen LLM: forward with a tape, data-gradient backward — over a PACKED batch of sequences
 # ------------------------------------------------------------------------------------------------
 class LlamaTape:
+    """Frozen LLM over a packed batch: forward with a tape and data-gradient backward.  The per-layer launch sequences live in
+    the library's C++ runtime (sl_llama_stack_train_fwd / _bwd, csrc/train_tape.hip); this class owns the buffers."""
+
     def __init__(self, llm: AudioLlamaForCausalLM):
         self.llm = llm
         self.w = llm._dev()
         self.a = llm.arch
         self._wt: Dict[tuple, torch.Tensor] = {}   # frozen weights stored transposed for the data-gradient GEMMs (+1 copy)
+        n = self.a.num_hidden_layers
+        self._layers = (L.LlamaTrainLayer * n)()
+        for li in range(n):
+            lw = self.w.layer_t[li]
+            lay = self._layers[li]
+            lay.norm1, lay.wqkv, lay.wo, lay.norm2, lay.wgu, lay.wdown = (lw[k].data_ptr() for k in ("norm1", "wqkv", "wo", "norm2", "wgu", "wdown"))
+        self._have_t = False
+        self._ws: Optional[torch.Tensor] = None
 
     def _t(self, li: int, name: str) -> torch.Tensor:
         key = (li, name)
@@ -142,34 +154,49 @@ class LlamaTape:
             self._wt[key] = self.w.layer_t[li][name].t().contiguous()
         return self._wt[key]
 
+    def _cfg(self, n_tok: int, seqlens: Sequence[int], pos: torch.Tensor, dt: torch.dtype):
+        a, w = self.a, self.w
+        cu, klen = ops.seq_descriptors(seqlens, pos.device)
+        c = L.LlamaStackCfg()
+        c.dtype, c.hidden, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn = L.dtype_code(dt), a.hidden_size, a.num_attention_heads, a.num_key_value_heads, a.head_dim, a.intermediate_size
+        c.n_layers, c.nseq, c.max_len, c.n_tok, c.rms_eps = a.num_hidden_layers, len(seqlens), max(int(n) for n in seqlens), n_tok, a.rms_norm_eps
+        c.cu, c.klen, c.pos, c.rope_cos, c.rope_sin = cu.data_ptr(), klen.data_ptr(), pos.data_ptr(), w.rope_cos.data_ptr(), w.rope_sin.data_ptr()
+        return c, (cu, klen)
+
+    def _workspace(self, cfg, device) -> torch.Tensor:
+        need = int(L.lib().sl_llama_stack_train_workspace_bytes(C.byref(cfg)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
     def forward(self, x: torch.Tensor, seqlens: Sequence[int], save: bool = True):
         """x: (sum S_i, H) packed embeddings.  Returns (hidden_states: L+1 packed tensors [hidden_states[l] = input of
         layer l, last = post-norm], tape).  With save=False nothing is kept for backward (teacher pass)."""
         a, w = self.a, self.w
-        dt = x.dtype
-        nh, nkv, D = a.num_attention_heads, a.num_key_value_heads, a.head_dim
-        pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in seqlens]).to(x.device)
-        tape, hidden = [], []
-        scale = D ** -0.5
-        for li in range(a.num_hidden_layers):
-            lw = w.layer_t[li]
-            hidden.append(x)
-            h1 = ops.rmsnorm(x, lw["norm1"], a.rms_norm_eps)
-            qkv = ops.gemm(h1, lw["wqkv"])
-            ops.rope_inplace(qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D)
-            lse = torch.empty((x.shape[0], nh), device=x.device, dtype=torch.float32) if save else None
-            att = ops.attn_packed_qkv(qkv, list(seqlens), nh, nkv, D, True, scale, lse=lse)
-            x2 = ops.gemm(att, lw["wo"], residual=x)
-            h2 = ops.rmsnorm(x2, lw["norm2"], a.rms_norm_eps)
-            gu = ops.gemm(h2, lw["wgu"])                      # interleaved gate/up pre-activations (N, 2F)
-            mid = ops.silu_mul(gu)
-            x3 = ops.gemm(mid, lw["wdown"], residual=x2)
-            if save:
-                tape.append((x, qkv, x2, gu, att, lse))
-            x = x3
-        xn = ops.rmsnorm(x, w.final_norm, a.rms_norm_eps)
-        hidden.append(xn)
-        return hidden, dict(layers=tape, x_final=x, seqlens=list(seqlens), pos=pos)
+        dt, dev, n = x.dtype, x.device, x.shape[0]
+        nh, nkv, D, H, F_ = a.num_attention_heads, a.num_key_value_heads, a.head_dim, a.hidden_size, a.intermediate_size
+        nl = a.num_hidden_layers
+        pos = torch.cat([torch.arange(s_, dtype=torch.int32) for s_ in seqlens]).to(dev)
+        cfg, keep = self._cfg(n, seqlens, pos, dt)
+        states = torch.empty((nl, n, H), device=dev, dtype=dt)                 # outputs of the layers = hidden[1..L]
+        hidden = [x] + [states[l] for l in range(nl)]
+        hptr = (L.c_vp * (nl + 1))(*[h.data_ptr() for h in hidden])
+        saved, bufs = None, None
+        if save:
+            qkv_w, att_w = (nh + 2 * nkv) * D, nh * D
+            row = qkv_w + H + 2 * F_ + att_w
+            bufs = (torch.empty((nl, n * row), device=dev, dtype=dt), torch.empty((nl, n, nh), device=dev, dtype=torch.float32))
+            esz = bufs[0].element_size()
+            saved = (L.LlamaLayerSaved * nl)()
+            for l in range(nl):
+                base = bufs[0][l].data_ptr()
+                sv = saved[l]
+                sv.qkv, sv.x2, sv.gu, sv.att = base, base + n * qkv_w * esz, base + n * (qkv_w + H) * esz, base + n * (qkv_w + H + 2 * F_) * esz
+                sv.lse = bufs[1][l].data_ptr()
+        ws = self._workspace(cfg, dev)
+        L.check(L.lib().sl_llama_stack_train_fwd(self._layers, C.byref(cfg), hptr, saved, ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_llama_stack_train_fwd")
+        xn = ops.rmsnorm(hidden[nl], w.final_norm, a.rms_norm_eps)
+        return hidden[:nl] + [xn], dict(saved=saved, bufs=bufs, hidden=hidden, hptr=hptr, cfg=cfg, keep=keep, x_final=hidden[nl], seqlens=list(seqlens), pos=pos)
 
     def logits(self, xn_rows: torch.Tensor) -> torch.Tensor:
         return ops.gemm(xn_rows, self.w.lm_head, out_f32=True)
@@ -178,34 +205,23 @@ class LlamaTape:
         """tail_rows: int64 indices (packed) of the rows whose logits carry loss; d_logits_tail: (len(tail_rows), V)
         gradient (dtype T); d_hidden[l]: (N, H) gradient of hidden_states[l].  Returns d(input embeddings) (N, H)."""
         a, w = self.a, self.w
-        seqlens, pos = tape["seqlens"], tape["pos"]
-        offs = _offsets(seqlens)
-        nh, nkv, D = a.num_attention_heads, a.num_key_value_heads, a.head_dim
-        qkv_w = (nh + 2 * nkv) * D
+        nl = a.num_hidden_layers
+        if not self._have_t:                                   # (in, out) copies of the frozen weights, built once
+            for li in range(nl):
+                lay = self._layers[li]
+                lay.wqkv_t, lay.wo_t, lay.wgu_t, lay.wdown_t = (self._t(li, k).data_ptr() for k in ("wqkv", "wo", "wgu", "wdown"))
+            self._have_t = True
         x_final = tape["x_final"]
         dx = torch.zeros_like(x_final)
         d_xn = ops.dgrad(d_logits_tail, w.lm_head)  # (n_tail, H)
-        if a.num_hidden_layers in d_hidden:
-            d_xn += d_hidden[a.num_hidden_layers].index_select(0, tail_rows)
+        if nl in d_hidden:
+            d_xn += d_hidden[nl].index_select(0, tail_rows)
         dx.index_copy_(0, tail_rows, ops.rmsnorm_bwd(x_final.index_select(0, tail_rows), w.final_norm, d_xn, a.rms_norm_eps))
-        for li in reversed(range(a.num_hidden_layers)):
-            lw = w.layer_t[li]
-            x, qkv, x2, gu, att, lse = tape["layers"][li]
-            d_mid = ops.dgrad(dx, lw["wdown"], wt=self._t(li, "wdown"))
-            d_gu = ops.silu_mul_bwd(gu, d_mid)
-            d_h2 = ops.dgrad(d_gu, lw["wgu"], wt=self._t(li, "wgu"))
-            dx2 = ops.rmsnorm_bwd(x2, lw["norm2"], d_h2, a.rms_norm_eps)
-            ops.axpby(dx, dx2)                                  # dx2 += dx (residual join)
-            d_att = ops.dgrad(dx2, lw["wo"], wt=self._t(li, "wo"))
-            d_qkv = torch.empty_like(qkv)
-            ops.attn_packed_qkv_bwd(qkv, att, d_att, lse, d_qkv, seqlens, nh, nkv, D, True, D ** -0.5)   # flash-style: no S x S buffers
-            ops.rope_inplace(d_qkv, pos, w.rope_cos, w.rope_sin, nh + 2 * nkv, nh + nkv, D, inverse=True)
-            d_h1 = ops.dgrad(d_qkv, lw["wqkv"], wt=self._t(li, "wqkv"))
-            dxin = ops.rmsnorm_bwd(x, lw["norm1"], d_h1, a.rms_norm_eps)
-            ops.axpby(dx2, dxin)
-            if li in d_hidden:
-                ops.axpby(d_hidden[li], dxin)
-            dx = dxin
+        d_tap = (L.c_vp * nl)(*[(d_hidden[l].data_ptr() if l in d_hidden else None) for l in range(nl)])
+        cfg = tape["cfg"]
+        ws = self._workspace(cfg, dx.device)
+        L.check(L.lib().sl_llama_stack_train_bwd(self._layers, C.byref(cfg), tape["hptr"], tape["saved"], d_tap, dx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 L.stream_ptr()), "sl_llama_stack_train_bwd")
         return dx
 
 
@@ -337,43 +353,57 @@ class EncoderTape:
         return out, tape
 
     # -- the pre-LN transformer layers shared by the HuBERT and Whisper encoders (hf:...hubert.py:504-547 stable-LN layer,
-    #    hf:models/whisper/modeling_whisper.py:360-414), on the packed frames of the batch
+    #    hf:models/whisper/modeling_whisper.py:360-414), on the packed frames of the batch: ONE call into the library's C++ tape
+    #    runtime (sl_encoder_stack_train_fwd, csrc/train_tape.hip) issues the launches of all layers
     def _stack_forward(self, x: torch.Tensor, T: Sequence[int], reg: Optional[TrainRegularizers], base: Optional[int]):
         W, enc = self.W, self.enc
         dt, dev = enc.dtype, enc.device
         H, nh, F_, eps = self.hidden, self.n_heads, self.ffn, self.ln_eps
-        NT = x.shape[0]
-        layers = []
-        for li in range(len(W.layer_t)):
-            lt = W.layer_t[li]
+        NT, nl = x.shape[0], len(W.layer_t)
+        skip = (C.c_uint8 * nl)()
+        seeds = (C.c_uint64 * (4 * nl))()
+        for li in range(nl):
             if reg is not None and reg.layerdrop > 0:                      # hf: skip the layer when a uniform draw < layerdrop
                 u01 = (_site_seed(base, "layerdrop", li) >> 11) * (1.0 / 9007199254740992.0)
-                if u01 < reg.layerdrop:
-                    layers.append(None)
-                    continue
-            ln1 = ops.layernorm(x, lt["ln1_g"], lt["ln1_b"], eps)
-            qkv = ops.gemm(ln1, lt["wqkv"], bias=lt["bqkv"])
-            p_att = reg.attention_dropout if reg is not None else 0.0
-            lse = torch.empty((NT, nh), device=dev, dtype=torch.float32)
-            att = ops.attn_packed_qkv(qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att, dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0,
-                                      lse=lse)
-            if reg is not None and reg.hidden_dropout > 0:                 # h = residual + dropout(attention(layer_norm(h)))
-                x_mid = ops.dropout(ops.gemm(att, lt["wo"], bias=lt["bo"]), reg.hidden_dropout, _site_seed(base, "attn_out", li), residual=x)
-            else:
-                x_mid = ops.gemm(att, lt["wo"], bias=lt["bo"], residual=x)
-            ln2 = ops.layernorm(x_mid, lt["ln2_g"], lt["ln2_b"], eps)
-            pre1 = torch.empty((NT, F_), device=dev, dtype=dt)
-            mid = torch.empty_like(pre1)
-            ops.gemm_ex(ln2, lt["w1"], M=NT, N=F_, K=H, lda=H, ldw=H, out=mid, bias=lt["b1"], act=L.ACT_GELU, aux_out=pre1, dtype=dt)
-            if reg is not None and reg.activation_dropout > 0:             # intermediate_dropout(act(dense(h)))
-                ops.dropout(mid, reg.activation_dropout, _site_seed(base, "act", li), out=mid)
-            if reg is not None and reg.hidden_dropout > 0:                 # h = h + output_dropout(output_dense(...))
-                x_out = ops.dropout(ops.gemm(mid, lt["w2"], bias=lt["b2"]), reg.hidden_dropout, _site_seed(base, "ffn_out", li), residual=x_mid)
-            else:
-                x_out = ops.gemm(mid, lt["w2"], bias=lt["b2"], residual=x_mid)
-            layers.append(dict(x=x, ln1=ln1, qkv=qkv, att=att, lse=lse, x_mid=x_mid, ln2=ln2, pre1=pre1, mid=mid))
-            x = x_out
-        return x, layers
+                skip[li] = 1 if u01 < reg.layerdrop else 0
+            if reg is not None:
+                for j, site in enumerate(("attn_prob", "attn_out", "act", "ffn_out")):
+                    seeds[4 * li + j] = _site_seed(base, site, li)
+        cu, klen = ops.seq_descriptors(T, dev)
+        cfg = L.EncStackCfg()
+        cfg.dtype, cfg.hidden, cfg.n_heads, cfg.ffn, cfg.n_layers, cfg.nseq, cfg.max_len, cfg.n_tok = L.dtype_code(dt), H, nh, F_, nl, len(T), max(int(t_) for t_ in T), NT
+        cfg.ln_eps = eps
+        cfg.p_hidden = reg.hidden_dropout if reg is not None else 0.0
+        cfg.p_act = reg.activation_dropout if reg is not None else 0.0
+        cfg.p_attn = reg.attention_dropout if reg is not None else 0.0
+        cfg.cu, cfg.klen = cu.data_ptr(), klen.data_ptr()
+        cfg.skip, cfg.seeds = C.cast(skip, C.c_void_p).value, C.cast(seeds, C.c_void_p).value
+        live = [li for li in range(nl) if not skip[li]]
+        row = 8 * H + 2 * F_                                               # ln1, qkv (3H), att, x_mid, ln2, x_out + pre1, mid
+        bufs = torch.empty((max(1, len(live)), NT * row), device=dev, dtype=dt)
+        lses = torch.empty((max(1, len(live)), NT, nh), device=dev, dtype=torch.float32)
+        esz = bufs.element_size()
+        saved = (L.EncLayerSaved * nl)()
+        for j, li in enumerate(live):
+            p0, sv = bufs[j].data_ptr(), saved[li]
+            o = 0
+            for name, width in (("ln1", H), ("qkv", 3 * H), ("att", H), ("x_mid", H), ("ln2", H), ("pre1", F_), ("mid", F_), ("x_out", H)):
+                setattr(sv, name, p0 + o * NT * esz)
+                o += width
+            sv.lse = lses[j].data_ptr()
+        need = int(L.lib().sl_encoder_stack_train_workspace_bytes(C.byref(cfg)))
+        if getattr(self, "_ws", None) is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        x_out = C.c_void_p(0)
+        L.check(L.lib().sl_encoder_stack_train_fwd(W._layers, C.byref(cfg), x.data_ptr(), saved, C.byref(x_out), self._ws.data_ptr(), self._ws.numel(),
+                                                   L.stream_ptr()), "sl_encoder_stack_train_fwd")
+        if live:                                                           # the last live layer's x_out, as a tensor view
+            off = 7 * H + 2 * F_                                           # x_out is the last block of the layer's buffer
+            out = bufs[len(live) - 1][off * NT:(off + H) * NT].view(NT, H)
+            assert out.data_ptr() == x_out.value
+        else:
+            out = x
+        return out, dict(cfg=cfg, saved=saved, keep=(skip, seeds, cu, klen, bufs, lses, x), skip=[bool(v) for v in skip])
 
     # -- final LayerNorm, AvgPool1d over time, projection (ref:model/audio_encoder.py:56-63,87)
     def _head_forward(self, x: torch.Tensor, T: Sequence[int], toff: Sequence[int]):
@@ -473,41 +503,24 @@ class EncoderTape:
         done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
         return dx
 
-    def _stack_backward(self, tape, dx: torch.Tensor, g: Dict[str, torch.Tensor], done) -> torch.Tensor:
+    def _stack_backward(self, tape, dx: torch.Tensor, g: Dict[str, torch.Tensor], done, chunk: int = 4) -> torch.Tensor:
+        """Backward of the layer stack in the C++ tape runtime (sl_encoder_stack_train_bwd), `chunk` layers per call so that
+        `done` can hand finished gradient buffers to the data-parallel reducer while the rest still runs.  dx is updated in place."""
         W = self.W
-        T, nh, eps = tape["T"], self.n_heads, self.ln_eps
-        reg, base = tape.get("reg"), tape.get("base")
-        p_h = reg.hidden_dropout if reg is not None else 0.0
-        p_act = reg.activation_dropout if reg is not None else 0.0
-        for li in reversed(range(len(W.layer_t))):
-            lt, c = W.layer_t[li], tape["layers"][li]
-            p = f"l{li}."
-            if c is None:                                                    # LayerDrop: identity in both directions
-                done([p + n for n in lt])
-                continue
-            d_o2 = ops.dropout(dx, p_h, _site_seed(base, "ffn_out", li)) if p_h > 0 else dx
-            ops.wgrad_acc(d_o2, c["mid"], g[p + "w2"]); ops.colsum_acc(d_o2, g[p + "b2"])
-            d_mid = ops.dgrad(d_o2, lt["w2"], wt=ops.transpose_pad(lt["w2"], lt["w2"].shape[0], lt["w2"].shape[1]))   # weights move every optimizer step: transposed on the fly
-            if p_act > 0:
-                ops.dropout(d_mid, p_act, _site_seed(base, "act", li), out=d_mid)
-            d_pre1 = ops.gelu_bwd(d_mid, c["pre1"])
-            ops.wgrad_acc(d_pre1, c["ln2"], g[p + "w1"]); ops.colsum_acc(d_pre1, g[p + "b1"])
-            d_ln2 = ops.dgrad(d_pre1, lt["w1"], wt=ops.transpose_pad(lt["w1"], lt["w1"].shape[0], lt["w1"].shape[1]))
-            dx_mid = ops.layernorm_bwd(c["x_mid"], lt["ln2_g"], lt["ln2_b"], d_ln2, eps, g[p + "ln2_g"], g[p + "ln2_b"])
-            ops.axpby(dx, dx_mid)
-            d_o1 = ops.dropout(dx_mid, p_h, _site_seed(base, "attn_out", li)) if p_h > 0 else dx_mid
-            ops.wgrad_acc(d_o1, c["att"], g[p + "wo"]); ops.colsum_acc(d_o1, g[p + "bo"])
-            d_att = ops.dgrad(d_o1, lt["wo"], wt=ops.transpose_pad(lt["wo"], lt["wo"].shape[0], lt["wo"].shape[1]))
-            d_qkv = torch.empty_like(c["qkv"])
-            p_att = reg.attention_dropout if reg is not None else 0.0
-            ops.attn_packed_qkv_bwd(c["qkv"], c["att"], d_att, c["lse"], d_qkv, T, nh, nh, 64, False, 0.125, dropout_p=p_att,
-                                    dropout_seed=_site_seed(base, "attn_prob", li) if p_att > 0 else 0)
-            ops.wgrad_acc(d_qkv, c["ln1"], g[p + "wqkv"]); ops.colsum_acc(d_qkv, g[p + "bqkv"])
-            d_ln1 = ops.dgrad(d_qkv, lt["wqkv"], wt=ops.transpose_pad(lt["wqkv"], lt["wqkv"].shape[0], lt["wqkv"].shape[1]))
-            dxin = ops.layernorm_bwd(c["x"], lt["ln1_g"], lt["ln1_b"], d_ln1, eps, g[p + "ln1_g"], g[p + "ln1_b"])
-            ops.axpby(dx_mid, dxin)
-            dx = dxin
-            done([p + n for n in lt])
+        st = tape["layers"]
+        nl = len(W.layer_t)
+        grads = (L.EncLayerGrads * nl)()
+        for li in range(nl):
+            for name, _ in L.EncLayerGrads._fields_:
+                setattr(grads[li], name, g[f"l{li}.{name}"].data_ptr())
+        dx = dx.contiguous()
+        ws = self._ws
+        for hi in range(nl, 0, -chunk):
+            lo = max(0, hi - chunk)
+            L.check(L.lib().sl_encoder_stack_train_bwd(W._layers, C.byref(st["cfg"]), st["saved"], grads, lo, hi, dx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                       L.stream_ptr()), "sl_encoder_stack_train_bwd")
+            for li in reversed(range(lo, hi)):
+                done([f"l{li}.{n}" for n in W.layer_t[li]])
         return dx
 
 
