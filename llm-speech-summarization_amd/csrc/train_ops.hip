@@ -361,6 +361,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   atomicAdd(out + col, s);
 }
 
+// 16-byte form: a thread owns VEC adjacent columns (a wave reads 1 KiB of a row per instruction)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t rows, int cols,
+                                                         int rows_per_block) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int ch = blockIdx.y * 256 + threadIdx.x;
+  if (ch * VEC >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block) < rows ? (r0 + rows_per_block) : rows;
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    float f[VEC];
+    Vec16<T>::unpack(*(const uint4*)(x + r * ld + ch * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] += f[j];
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) atomicAdd(out + ch * VEC + j, s[j]);
+}
+
 // ----------------------------------------------------------------------------------------------
 // explicit softmax (attention backward recomputes P): rows of fp32 scores -> P (T); and its backward
 // ----------------------------------------------------------------------------------------------
@@ -920,7 +942,10 @@ extern "C" int sl_layernorm_bwd(const void* x, const void* gamma, const void* be
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_layernorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
   if (rows == 0) return 0;
-  const int rpb = 64;
+  // rows per block: enough blocks to fill 256 CUs several times over (64 rows per block left a 7 984-row encoder LayerNorm on
+  // 125 blocks: 115 us for 48 MB), few enough that the per-block column atomics (2 x cols per block) stay a small fraction
+  int rpb = (int)ceil_div64(rows, 1024);
+  rpb = rpb < 4 ? 4 : (rpb > 64 ? 64 : rpb);
   SL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((norm_bwd_kernel<T, false>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
                        (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb);
@@ -947,6 +972,17 @@ extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void
 extern "C" int sl_colsum(const void* x, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t dtype, sl_stream stream) {
   SL_CHECK_ARG(x && out && rows >= 0 && cols > 0, "sl_colsum: bad arguments");
   if (rows == 0) return 0;
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  if (cols % vec == 0 && ld % vec == 0 && ((uintptr_t)x & 15) == 0) {
+    int rpb = (int)ceil_div64(rows, 1024);
+    rpb = rpb < 8 ? 8 : (rpb > 128 ? 128 : rpb);
+    SL_DISPATCH_DTYPE(dtype, T, {
+      hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3((unsigned)ceil_div64(rows, rpb), (cols / vec + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)x, ld, out, rows, cols, rpb);
+    });
+    SL_CHECK_LAUNCH("colsum");
+    return 0;
+  }
   const int rpb = 128;
   SL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((colsum_kernel<T>), dim3((unsigned)ceil_div64(rows, rpb), (cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, out,
