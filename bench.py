@@ -7,8 +7,9 @@ ref:inference.py:95-137), random-init weights of the true shapes, inputs residen
     python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
 
 Prints ONE JSON line (rank 0).  value = generated tokens/s of the whole job (all ranks, all pipeline
-stages inside the timed region); audio_sec_per_s = throughput of the encoder stage run on its own on the same
-batch (HIP events); stage_ms = per-batch wall times inside the timed steps (stages of different batches overlap).  roofline = the decode kernel with the largest share of the step (split attention over the KV cache at
+stages inside the timed region); audio_sec_per_s_encoder_alone = throughput of the encoder stage run on its own on the same
+batch (HIP events), audio_sec_per_s_in_pipeline = audio seconds per second of the timed steps; latency_b1 = the reference's
+one-utterance-per-call pattern against the batch-1 HBM ceiling; stage_ms = per-batch wall times inside the timed steps (stages of different batches overlap).  roofline = the decode kernel with the largest share of the step (split attention over the KV cache at
 the default batch of 512, the gate/up weight-streaming GEMM below ~128) against the HBM peak; roofline_other = the other.
 cpu_baseline = the CPU oracle (oracle/*.py, a port of the reference's HF path) on a bounded sample.
 Two batches are in flight per GPU by default (`--pipelines`): host threads with their own HIP stream / KV cache pull
@@ -65,8 +66,9 @@ def gpu_llama_state_dict(arch, seed, device):
 
 
 def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tokens, full_new_tokens):
-    """The CPU oracle on ONE 10 s utterance: encode + prefill + `new_tokens` decode steps, fp32, all host
-    cores; projected to the metric's unit for `full_new_tokens` tokens per utterance."""
+    """The CPU oracle on ONE 10 s utterance: encode + prefill + `new_tokens` decode steps, fp32, `cores` host threads; one
+    warm-up pass, then the MEDIAN of 3 timed passes per stage; projected to the metric's unit for
+    `full_new_tokens` tokens per utterance."""
     from oracle import hubert_oracle as ho, llama_oracle as lo
     # torch's CPU GEMMs stop scaling (and collapse when oversubscribed across sockets) well before the
     # 256 hardware threads of the GPU node: use up to 32 threads and report that number
@@ -79,27 +81,33 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
                      larch.head_dim, larch.intermediate_size, larch.vocab_size, larch.rms_norm_eps, larch.rope_theta,
                      larch.rope_scaling, larch.tie_word_embeddings, tuple(larch.eos_token_ids), larch.pad_token_id)
     llm_sd = {k: v.float().cpu() for k, v in llm_sd_gpu.items()}  # same tensors as the GPU run (bf16 values in fp32)
+    emb = llm_sd["model.embed_tokens.weight"]
+    enc_t, pre_t, tok_t = [], [], []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        audio = ho.audio_encoder_forward(enc_sd, hc, wave[None].cpu())
-        t1 = time.perf_counter()
-        emb = llm_sd["model.embed_tokens.weight"]
-        prompt = torch.cat([emb[prefix], audio, emb[suffix][:, 1:]], dim=1)
-        out = lo.llama_forward(llm_sd, lc, prompt, last_logits_only=True)
-        t2 = time.perf_counter()
-        past = out["past"]
-        for _ in range(new_tokens):
-            nxt = out["logits"][:, -1].argmax(-1)
-            out = lo.llama_forward(llm_sd, lc, emb[nxt][:, None, :], past=past, last_logits_only=True)
+        for rep in range(4):                      # pass 0 = warm-up (page-in, thread pool, allocator)
+            t0 = time.perf_counter()
+            audio = ho.audio_encoder_forward(enc_sd, hc, wave[None].cpu())
+            t1 = time.perf_counter()
+            prompt = torch.cat([emb[prefix], audio, emb[suffix][:, 1:]], dim=1)
+            out = lo.llama_forward(llm_sd, lc, prompt, last_logits_only=True)
+            t2 = time.perf_counter()
             past = out["past"]
-        t3 = time.perf_counter()
-    enc_s, pre_s, tok_s = t1 - t0, t2 - t1, (t3 - t2) / new_tokens
+            for _ in range(new_tokens):
+                nxt = out["logits"][:, -1].argmax(-1)
+                out = lo.llama_forward(llm_sd, lc, emb[nxt][:, None, :], past=past, last_logits_only=True)
+                past = out["past"]
+            t3 = time.perf_counter()
+            if rep > 0:
+                enc_t.append(t1 - t0); pre_t.append(t2 - t1); tok_t.append((t3 - t2) / new_tokens)
+    med = lambda v: sorted(v)[len(v) // 2]
+    enc_s, pre_s, tok_s = med(enc_t), med(pre_t), med(tok_t)
     e2e = full_new_tokens / (enc_s + pre_s + full_new_tokens * tok_s)
     return {"value": round(e2e, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "audio_sec_per_s": round(wave.numel() / 16000.0 / enc_s, 2), "decode_tokens_per_s": round(1.0 / tok_s, 3),
-            "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s: encoder {enc_s:.2f} s, prefill S={prompt.shape[1]} {pre_s:.2f} s, "
-                       f"{new_tokens} decode steps {tok_s * 1e3:.0f} ms/token, fp32 oracle; value projected to "
-                       f"{full_new_tokens} tokens per utterance at batch 1")}
+            "audio_sec_per_s": round(wave.numel() / 16000.0 / enc_s, 2), "prefill_tokens_per_s": round(prompt.shape[1] / pre_s, 1),
+            "decode_tokens_per_s": round(1.0 / tok_s, 3),
+            "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s, median of 3 passes after 1 warm-up on {cores} threads: encoder {enc_s:.2f} s, "
+                       f"prefill S={prompt.shape[1]} {pre_s:.2f} s, {new_tokens} decode steps at {tok_s * 1e3:.0f} ms/token, fp32 oracle; value "
+                       f"projected to {full_new_tokens} tokens per utterance at batch 1")}
 
 
 def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist):
@@ -140,12 +148,41 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_ = float(tt.item())
     n_params = sum(p.numel() for p in tr.params)
+    # algorithmic FLOPs of one micro-step: 3 x encoder forward (fwd + dgrad + wgrad) + 2 x LLM prefill with
+    # all-position logits over the audio sequence (student fwd + dgrad) + 1 x over the text sequence (teacher)
+    a_ = larch
+    body = a_.num_hidden_layers * ((a_.num_attention_heads + 2 * a_.num_key_value_heads) * a_.head_dim * a_.hidden_size + a_.num_attention_heads * a_.head_dim * a_.hidden_size
+                                   + 3 * a_.intermediate_size * a_.hidden_size)
+    emb_w = a_.vocab_size * a_.hidden_size
+
+    def prefill_full(S_):
+        return 2.0 * body * S_ + 2.0 * emb_w * S_ + a_.num_hidden_layers * 2.0 * a_.num_attention_heads * a_.head_dim * S_ * S_
+
+    h_ = mod("weights").KNOWN_HUBERT["facebook/hubert-large-ls960-ft"]
+    Ls, n_ = [], 160000
+    for k_, s_ in zip(h_.conv_kernel, h_.conv_stride):
+        n_ = (n_ - k_) // s_ + 1
+        Ls.append(n_)
+    T_ = Ls[-1]
+    P_ = (T_ - 8) // 4 + 1
+    conv = 2.0 * (h_.conv_dim[0] * h_.conv_kernel[0] * Ls[0] + sum(h_.conv_dim[i - 1] * h_.conv_dim[i] * h_.conv_kernel[i] * Ls[i] for i in range(1, len(Ls))))
+    Hh = h_.hidden_size
+    enc_fwd = (conv + 2.0 * h_.conv_dim[-1] * Hh * T_ + 2.0 * Hh * (Hh // h_.num_conv_pos_embedding_groups) * h_.num_conv_pos_embeddings * T_
+               + h_.num_hidden_layers * (4 * 2.0 * Hh * Hh + 2 * 2.0 * Hh * h_.intermediate_size) * T_ + h_.num_hidden_layers * 4.0 * T_ * T_ * Hh
+               + 2.0 * Hh * a_.hidden_size * P_)
+    S_a = prefix.shape[1] + P_ + suffix.shape[1] - 1 + resp_ids.shape[0] - 1
+    S_t = prefix.shape[1] + text_ids.shape[0] + suffix.shape[1] - 1 + resp_ids.shape[0] - 1
+    flops = 3.0 * enc_fwd + 2.0 * prefill_full(S_a) + prefill_full(S_t)
+    ach = flops * n_micro / dt_ / 1e12
     return {"samples_per_s": round(n_micro * world / dt_, 3), "ms_per_micro_step": round(dt_ / n_micro * 1e3, 2),
+            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                         "algorithmic_flops_per_sample": round(flops), "seq_audio": S_a, "seq_text": S_t,
+                         "formula": "3 enc_fwd + 2 prefill_full(S_audio) + prefill_full(S_text), SURVEY.md §8d; per rank"},
             "optimizer_steps": args.kd_optimizer_steps, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
             "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
             "losses": {k: round(v, 4) for k, v in losses.items()}, "dtype": "bf16 compute, fp32 master/grads",
             "encoder_mode": "eval (regularisers off)" if reg is None else "train(): dropout 0.1 (feature projection, hidden, activation, attention probabilities), LayerDrop 0.1, SpecAugment 0.05 x 10",
-            "note": "one packed micro-batch per accumulation window per rank; python-driven op tape"}
+            "note": "one packed micro-batch per accumulation window per rank; layer stacks issued by the library's C++ tape runtime"}
 
 
 DEVCLEAN_MIX_SEC = (2, 4, 6, 8, 10, 12, 15, 20, 25, 32)  # dev-clean is ~1.3-33 s, mean ~7 s; cycled
@@ -241,17 +278,26 @@ def longform_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, ct
                          "decode": round(llm.last_timings_ms[1], 2)}}
 
 
-def whisper_leg(args, mod, larch, dev, rank):
-    """BASELINE configs[3]: the alternate encoder — Whisper-medium shape, log-mel front end + encoder + pool + projector on
-    30 s windows (ref:trainer.py:168-199,280-291), random init; windows/s and audio-s/s of the encoder stage."""
-    cfgm, weights, enc_mod, ri = mod("config"), mod("weights"), mod("audio_encoder"), mod("random_init")
+def whisper_leg(args, mod, larch, llm, prefix, suffix, dev, rank):
+    """BASELINE configs[3] end to end: Whisper-medium shape, 32 windows of 30 s: log-mel front end -> encoder -> pool -> projector
+    -> crop to compute_num_audio_embeds (ref:trainer.py:168-199,280-291) -> [prefix | audio | suffix[1:]] -> prefill -> greedy
+    decode through the same Llama-3.2-3B weights as the headline; random init."""
+    cfgm, weights, enc_mod, ri, utils = mod("config"), mod("weights"), mod("audio_encoder"), mod("random_init"), mod("utils")
     conf = cfgm.load_config(os.path.join(REPO, "config", "llama3_whisper.yaml"))
     warch = weights.KNOWN_WHISPER["openai/whisper-medium"]
     enc = enc_mod.AudioEncoder(conf, dev, dtype=torch.bfloat16, arch=warch)
     enc.load_state_dict(ri.whisper_encoder_state_dict(warch, larch.hidden_size, seed=3)).eval().to(dev)
-    B = 32
-    waves = [ri.synthetic_waveform(30 * 16000, seed=555 + rank * 100 + i).to(dev) for i in range(B)]
+    B, new = 32, args.max_new_tokens
+    n_samples = 30 * 16000
+    waves = [ri.synthetic_waveform(n_samples, seed=555 + rank * 100 + i).to(dev) for i in range(B)]
+    keep = utils.compute_num_audio_embeds(n_samples)
+    emb = llm.model.embed_tokens
+    pre_e, suf_e = emb(prefix.to(dev))[0], emb(suffix.to(dev))[0, 1:]
+    n_pre = pre_e.shape[0]
+    S = n_pre + keep + suf_e.shape[0]
+    llm.max_ctx, llm._kv = ((S + new + 63) // 64) * 64, None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    x = torch.empty((B, S, larch.hidden_size), device=dev, dtype=torch.bfloat16)
 
     def step():
         ev[0].record()
@@ -259,16 +305,47 @@ def whisper_leg(args, mod, larch, dev, rank):
         ev[1].record()
         out = enc(feats)
         ev[2].record()
-        return out
+        x[:, :n_pre] = pre_e
+        x[:, n_pre:n_pre + keep] = out[:, :keep]
+        x[:, n_pre + keep:] = suf_e
+        return out, llm.generate_packed(x.view(B * S, -1), [S] * B, new, use_eos=False)
 
     step()
-    out = step()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, (ids, n_cols) = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert n_cols == new
     mel_ms, enc_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
     flops = B * 1.14e12   # ~1.14 TFLOP per 30 s window
-    return {"model": "whisper-medium encoder shape (24 x 1024, 80 mel)", "windows": B, "window_sec": 30, "out_shape": list(out.shape),
-            "logmel_ms": round(mel_ms, 2), "encoder_ms": round(enc_ms, 2), "windows_per_s": round(B / ((mel_ms + enc_ms) * 1e-3), 1),
-            "audio_sec_per_s": round(B * 30 / ((mel_ms + enc_ms) * 1e-3), 1), "encoder_TFLOPs": round(flops / (enc_ms * 1e-3) / 1e12, 1)}
+    return {"model": "whisper-medium encoder shape (24 x 1024, 80 mel) -> Llama-3.2-3B", "windows": B, "window_sec": 30, "out_shape": list(out.shape),
+            "audio_embeds_kept": keep, "prompt_tokens": S, "tokens_per_s": round(B * new / el, 1), "ms_per_step": round(el * 1e3, 2),
+            "logmel_ms": round(mel_ms, 2), "encoder_ms": round(enc_ms, 2), "prefill_ms": round(llm.last_timings_ms[0], 2),
+            "decode_ms": round(llm.last_timings_ms[1], 2), "windows_per_s_encoder": round(B / ((mel_ms + enc_ms) * 1e-3), 1),
+            "audio_sec_per_s_encoder": round(B * 30 / ((mel_ms + enc_ms) * 1e-3), 1), "encoder_TFLOPs": round(flops / (enc_ms * 1e-3) / 1e12, 1)}
+
+
+def latency_leg(args, llm, x1, S, new, larch, wts):
+    """The reference's own call pattern (ref:inference.py:95-137): ONE utterance per generate call.  Decode at batch 1 is
+    HBM-bound: every step streams all weights (+ the sequence's KV rows), ceiling = 8 TB/s / bytes per token."""
+    llm.generate_packed(x1.clone(), [S], new, use_eos=False)          # graph capture / allocator warm-up
+    dec, pre, wall = [], [], []
+    for _ in range(3):
+        xin = x1.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids, n_cols = llm.generate_packed(xin, [S], new, use_eos=False)
+        wall.append(time.perf_counter() - t0)
+        pre.append(llm.last_timings_ms[0]); dec.append(llm.last_timings_ms[1])
+    med = lambda v: sorted(v)[len(v) // 2]
+    step_ms = med(dec) / max(1, new - 1)
+    bytes_tok = wts.weight_bytes_per_token() + (S + new / 2) * 2 * larch.num_key_value_heads * larch.head_dim * 2 * larch.num_hidden_layers
+    ceiling = HBM_PEAK_GBS * 1e9 / bytes_tok
+    return {"batch": 1, "prompt_tokens": S, "new_tokens": new, "decode_tokens_per_s": round(1e3 / step_ms, 1), "ms_per_token": round(step_ms, 4),
+            "prefill_ms": round(med(pre), 3), "generate_call_ms": round(med(wall) * 1e3, 2), "end_to_end_tokens_per_s": round(new / med(wall), 1),
+            "hbm_bytes_per_token": int(bytes_tok), "hbm_ceiling_tokens_per_s": round(ceiling, 1), "frac_of_hbm_ceiling": round(1e3 / step_ms / ceiling, 4),
+            "note": "median of 3 generate calls after 1 warm-up; decode graph replayed per token"}
 
 
 def main():
@@ -281,8 +358,8 @@ def main():
     ap.add_argument("--max-new-tokens", type=int, default=256)
     ap.add_argument("--pipelines", type=int, default=2, help="batches in flight per GPU (host threads x HIP streams; 1 = strictly sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (≈0.45 s each)")
-    ap.add_argument("--kd-optimizer-steps", type=int, default=2, help="optimizer steps of the KD training leg (0 = skip)")
+    ap.add_argument("--cpu-decode-steps", type=int, default=8, help="decode steps per pass of the bounded CPU-oracle sample (4 passes, ≈0.45 s per step)")
+    ap.add_argument("--kd-optimizer-steps", type=int, default=3, help="optimizer steps of the KD training leg (0 = skip)")
     ap.add_argument("--kd-eval-mode", action="store_true", help="KD leg with the encoder's training-mode regularisers off")
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
@@ -323,7 +400,7 @@ def main():
     B, new = args.batch, args.max_new_tokens
     n_samples = int(args.audio_sec * 16000)
     prefix = ri.synthetic_ids(9, larch.vocab_size, seed=7, bos=larch.bos_token_id or 0)
-    suffix = ri.synthetic_ids(5, larch.vocab_size, seed=8, bos=larch.bos_token_id or 0)
+    suffix = ri.synthetic_ids(6, larch.vocab_size, seed=8, bos=larch.bos_token_id or 0)   # BOS + 5: the Llama-3 template tokenises to 9 / 6 ids (tests/golden/tokenizers)
     T = harch.num_frames(n_samples)
     P = (T - 8) // 4 + 1
     S = prefix.shape[1] + P + suffix.shape[1] - 1
@@ -428,6 +505,15 @@ def main():
             pipes[0].ev[1].record()
             pipes[0].ev[1].synchronize()
             enc_alone_ms.append(pipes[0].ev[0].elapsed_time(pipes[0].ev[1]))
+    # one whole step alone on the GPU (no second batch in flight): un-shared stage times, the decode step the roofline
+    # fractions of DESIGN.md are quoted on
+    seq_stage = None
+    if rank == 0:
+        n_e, n_p, n_d = len(enc_ms), len(prefill_ms), len(decode_ms)
+        pipes[0].step(True)
+        torch.cuda.synchronize()
+        seq_stage = {"encode": round(enc_ms.pop(n_e), 3), "prefill": round(prefill_ms.pop(n_p), 3), "decode": round(decode_ms[n_d], 3),
+                     "decode_per_step": round(decode_ms.pop(n_d) / max(1, new - 1), 4)}
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -519,17 +605,25 @@ def main():
     mean = lambda v: sum(v) / max(1, len(v))
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md), where measured for this batch
     streaming = B > 32
-    pmc = {}
-    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_decode_kernels.json")
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f).get(str(B), {})
+    # `traffic` cannot be measured inside this process (PMC counters need rocprofv3 around it): it is READ from the committed
+    # counter summary of the same two launches (tools/probe_decode_kernels.py under separate --pmc passes), and says so
+    pmc, pmc_src = {}, None
+    for name in ("r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):
+        pmc_path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f).get(str(B), {})
+            if pmc:
+                pmc_src = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/probe_decode_kernels.py {B} (FETCH_SIZE x2 per the gfx950 correction); " \
+                          "not measured in this run"
+                break
 
     def roof(name, key):
         alg, ms = probes[key]
         ach = alg / (ms * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": pmc.get(key), "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2)}
+                "traffic": pmc.get(key), "traffic_source": pmc_src if pmc.get(key) is not None else None, "algorithmic_bytes_per_launch": alg,
+                "avg_launch_us": round(ms * 1e3, 2)}
 
     r_gemm = roof(("gemm_stream_kernel" if streaming else "gemm_skinny_kernel") + "<bf16, SILU_MUL> (gate/up projection, decode)", "gemm")
     # the same launch against the matrix-core roof: above ~256 rows the projection is nearer to it than to the HBM one
@@ -543,25 +637,42 @@ def main():
     dec_step_ms = mean(decode_ms) / max(1, new - 1)
     step_bytes = wts.weight_bytes_per_token() + B * (S + new / 2) * 2 * larch.num_key_value_heads * larch.head_dim * 2 * larch.num_hidden_layers
     result = {
-        "metric": "generated tokens/s (audio-sec/s encoded alongside), HuBERT-large -> Llama-3.2-3B generate_audio_response",
+        "metric": "generated tokens/s of end-to-end generate_audio_response steps (encode + prefill + 256-token greedy decode), HuBERT-large -> Llama-3.2-3B; "
+                  "audio-sec/s reported beside it, encoder stage alone and in the pipeline",
         "value": round(tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: HuBERT-large + Llama-3.2-3B bf16 inference, batch of synthetic 16 kHz utterances",
                    "utterances_per_gpu": B, "audio_sec": args.audio_sec, "prompt_tokens": S, "max_new_tokens": new,
                    "parallelism": f"replicas x{world} (sharded by utterance, no collective)", "batches_in_flight_per_gpu": n_pipe},
-        "audio_sec_per_s": round(B * args.audio_sec * world / (min(enc_alone_ms) * 1e-3), 1),
+        "audio_sec_per_s_encoder_alone": round(B * args.audio_sec * world / (min(enc_alone_ms) * 1e-3), 1),
+        "audio_sec_per_s_in_pipeline": round(B * args.audio_sec * args.steps * world / elapsed, 1),
+        "audio_sec_note": "encoder_alone = the encoder stage (conv stack + 24 layers + pool + projector) run on its own on one batch, HIP events; "
+                          "in_pipeline = audio seconds consumed per second of the timed end-to-end steps (encode + prefill + 256-token decode)",
         "encoder_alone_ms": round(min(enc_alone_ms), 3),
+        "encoder_mfma": {"achieved": round(B * args.audio_sec * 38.46e9 / (min(enc_alone_ms) * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(B * args.audio_sec * 38.46e9 / (min(enc_alone_ms) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                         "note": "38.46 GFLOP per audio-second at 10 s clips (SURVEY.md §8d)"},
         "stage_ms": {"encode": round(mean(enc_ms), 3), "prefill": round(mean(prefill_ms), 3), "decode": round(mean(decode_ms), 3),
                      "decode_per_step": round(dec_step_ms, 4)},
         "stage_note": f"per-batch wall times; {n_pipe} batch(es) share the GPU, so stages of different batches overlap",
+        "stage_ms_one_batch_alone": seq_stage,
         "decode_step_hbm": {"algorithmic_GB": round(step_bytes / 1e9, 3), "concurrent_batches": n_pipe,
                             "achieved_GBps": round(n_pipe * step_bytes / (dec_step_ms * 1e-3) / 1e9, 1),
-                            "frac_of_peak": round(n_pipe * step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                            "frac_of_peak": round(n_pipe * step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "one_batch_alone_frac_of_peak": (round(step_bytes / (seq_stage["decode_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if seq_stage else None)},
         "roofline": dominant, "roofline_other": other,
     }
     if kd is not None:
         result["kd_step"] = kd
+    try:      # the reference's own call pattern: one utterance per generate call
+        x1 = torch.empty((S, larch.hidden_size), device=dev, dtype=torch.bfloat16)
+        x1[:n_pre] = pre_e
+        x1[n_pre + P:] = suf_e
+        enc.encode_packed([waves[0]], out=x1, out_row_offsets=[n_pre])
+        result["latency_b1"] = latency_leg(args, llm, x1, S, new, larch, wts)
+    except Exception as e:
+        result["latency_b1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_length_mix:
         try:
             result["devclean_length_mix"] = mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx)
@@ -573,9 +684,9 @@ def main():
         except Exception as e:
             result["longform_text_prompt"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         try:
-            result["whisper_encoder"] = whisper_leg(args, mod, larch, dev, rank)
+            result["whisper_pipeline"] = whisper_leg(args, mod, larch, llm, prefix, suffix, dev, rank)
         except Exception as e:
-            result["whisper_encoder"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            result["whisper_pipeline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_cpu_baseline:
         del llm, wts
         result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)

@@ -35,7 +35,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 BF16_TOL = 3e-2    # 2-layer fixtures (tests/test_models_gpu.py)
 FULL_TOL = 6e-2    # full depth: bf16 rounding of 24 / 28 residual layers accumulates (measured 1.5-3.5e-2)
-N_PRE, N_SUF = 9, 5
+N_PRE, N_SUF = 9, 6      # Llama-3 template: 9 prefix ids, 6 suffix ids incl. BOS (tests/golden/tokenizers) -> 10 s of audio = 137 rows
 
 
 def _oracle_cfgs(harch, larch):
@@ -193,7 +193,7 @@ def test_configs1_full_depth_one_utterance_vs_oracle(llama3):
     assert e_h < FULL_TOL and e_o < FULL_TOL, (e_h, e_o)
     # LLM: the prompt assembled from the GPU's embeddings, all 29 taps + last-row logits
     x, lens, _ = m.prompts([wave.to(DEV)])
-    assert lens[0] == 136
+    assert lens[0] == 137
     res = m.llm(inputs_embeds=x[None].clone(), output_hidden_states=True)
     with torch.no_grad():
         ref = lo.llama_forward(m.llm_sd_host, lc, x[None].float().cpu(), output_hidden_states=True, last_logits_only=True)
