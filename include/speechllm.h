@@ -11,8 +11,14 @@
  * Conventions
  *   - extern "C", plain pointers and sizes only; no C++ / torch types cross this boundary.
  *   - Every device buffer (weights, activations, KV cache, workspace) is allocated and owned by the
- *     caller.  The library never allocates or frees device memory and never synchronises, except
- *     sl_greedy_generate (documented there).  All launches are asynchronous on `stream`.
+ *     caller.  The library never allocates or frees device memory.  Per-op entry points (sl_gemm*, sl_attn_*,
+ *     norms, losses, the KD tape stacks ...) only enqueue launches on `stream` and never synchronise.
+ *     The whole-model entry points that take HOST descriptor arrays synchronise as follows:
+ *       sl_hubert_forward, sl_whisper_forward, sl_llama_prefill — ONE hipStreamSynchronize(stream) after uploading the
+ *         batch descriptors (row offsets / group records built from the host arrays), before the first compute launch;
+ *       sl_greedy_generate — that of its prefill, one every `check_every` steps when EOS is enabled, and ONE at the end
+ *         behind the asynchronous copy of the ids to the host (the call returns host results).
+ *     Nothing synchronises the device or touches the null stream.
  *   - Return value: 0 on success, a negative sl_status otherwise; sl_last_error() gives the text.
  *   - dtype: SL_F32 (exact-fp32 MFMA, the parity mode) or SL_BF16 (bf16 storage, fp32 accumulate).
  *   - Layouts: activations row-major (tokens, channels); Linear weights in nn.Linear layout
@@ -43,6 +49,9 @@ enum sl_w_layout { SL_W_ROWMAJOR = 0, SL_W_PACKED = 1 };
 const char* sl_last_error(void);       /* thread-local, never NULL */
 int sl_version(void);                  /* ABI version, bumps on any signature change */
 int sl_device_arch(char* buf, int n);  /* gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-" */
+/* Tuning switches (SL_* environment variables, documented in csrc/common.h) are read once, at first use; tools that change
+ * them inside one process call this to re-read them.  Not needed in normal operation. */
+int sl_tuning_reload(void);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM  C[b] = act(A[b] . W[b]^T + bias[b]) + residual[b]        (TN: both operands K-contiguous)

@@ -1,5 +1,9 @@
 // api.hip — error reporting and library identity for libspeechllm.
 #include <stdarg.h>
+#include <stdlib.h>
+
+#include <atomic>
+#include <mutex>
 
 #include "common.h"
 
@@ -23,5 +27,65 @@ extern "C" int sl_device_arch(char* buf, int n) {
   hipDeviceProp_t prop;
   SL_HIP(hipGetDeviceProperties(&prop, dev));
   snprintf(buf, (size_t)n, "%s", prop.gcnArchName);
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// tuning switches (common.h SlEnv)
+// ----------------------------------------------------------------------------------------------
+static SlEnv g_env;
+static std::atomic<bool> g_env_loaded{false};
+static std::mutex g_env_mu;
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+
+static void env_load() {
+  SlEnv e;
+  e.stream_min_m = env_int("SL_STREAM_MIN_M", 32);
+  if (e.stream_min_m < 16) e.stream_min_m = 32;
+  e.disable_t256 = getenv("SL_DISABLE_T256") != nullptr;
+  e.t256_min_tiles = env_int("SL_T256_MIN_TILES", 512);
+  e.t256_min_k = env_int("SL_T256_MIN_K", 1024);
+  const char* g = getenv("SL_DISABLE_GLDS");
+  e.disable_glds = (g && g[0] == '1') ? 1 : ((g && g[0] == '2') ? 2 : 0);
+  e.direct_epilogue = env_int("SL_DIRECT_EPILOGUE", 0);
+  e.gemm_gm = env_int("SL_GEMM_GM", 8);
+  e.attn_full_min = env_int("SL_ATTN_FULL_MIN", 32);
+  e.attn_force_split = getenv("SL_ATTN_FORCE_SPLIT") != nullptr;
+  e.attn_generic = env_int("SL_ATTN_GENERIC", 0);
+  e.attn_qt = env_int("SL_ATTN_QT", 0);
+  e.norm_single_row = env_int("SL_NORM_SINGLE_ROW", 0);
+  e.stream_splits = e.stream_nwv = e.stream_mt = 0;
+  const char* sc = getenv("SL_STREAM_CFG");
+  if (sc && sc[0]) {
+    int sp = 0, nwv = 0, mt = 0;
+    const int n = sscanf(sc, "%d,%d,%d", &sp, &nwv, &mt);
+    if (n >= 2) {
+      if (sp >= 1 && sp <= 64) e.stream_splits = sp;
+      if (nwv == 2 || nwv == 4) e.stream_nwv = nwv;
+    }
+    if (n == 3 && (mt == 8 || mt == 16)) e.stream_mt = mt;
+  }
+  g_env = e;
+}
+
+const SlEnv& sl_env() {
+  if (!g_env_loaded.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    if (!g_env_loaded.load(std::memory_order_relaxed)) {
+      env_load();
+      g_env_loaded.store(true, std::memory_order_release);
+    }
+  }
+  return g_env;
+}
+
+extern "C" int sl_tuning_reload(void) {
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  env_load();
+  g_env_loaded.store(true, std::memory_order_release);
   return 0;
 }

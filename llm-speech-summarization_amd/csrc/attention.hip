@@ -450,7 +450,7 @@ static int launch_attn(const sl_attn_args* a, hipStream_t st) {
   }
   if constexpr (sizeof(T) == 2) {
     // bf16: transposed-score kernel (8-byte output vectors need 4-element strides / an 8-byte aligned base)
-    static const int generic = getenv("SL_ATTN_GENERIC") ? atoi(getenv("SL_ATTN_GENERIC")) : 0;
+    const int generic = sl_env().attn_generic;
     if (!generic && a->o_row_stride % 4 == 0 && a->o_head_stride % 4 == 0 && ((uintptr_t)a->out & 7) == 0) {
       if (p.drop_thr) {   // training mode (HuBERT's attention dropout): one variant (32 queries per wave) with the mask applied to
                           // the packed probabilities; other shapes take the generic kernel, which applies the same mask
@@ -461,7 +461,7 @@ static int launch_attn(const sl_attn_args* a, hipStream_t st) {
           return 0;
         }
       } else {
-        static const int qt_env = getenv("SL_ATTN_QT") ? atoi(getenv("SL_ATTN_QT")) : 0;   // tuning switch
+        const int qt_env = sl_env().attn_qt;   // tuning switch
         if constexpr (D == 64) {
           // 64 queries per wave where the sequences are long enough to fill such blocks: K / V fragments read once per 4 query tiles
           if (qt_env ? qt_env == 4 : a->max_qlen > 192) {

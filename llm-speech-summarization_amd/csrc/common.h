@@ -197,3 +197,24 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
   } while (0)
 
 static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; }
+
+// ----------------------------------------------------------------------------------------------
+// tuning switches: environment variables read ONCE (first use) into this table, never on a dispatch path;
+// sl_tuning_reload() (api.hip, exported for tools/tune_*.py) re-reads them for in-process A/B runs
+// ----------------------------------------------------------------------------------------------
+struct SlEnv {
+  int stream_min_m;        // SL_STREAM_MIN_M      (default 32)
+  int disable_t256;        // SL_DISABLE_T256
+  int t256_min_tiles;      // SL_T256_MIN_TILES    (default 512)
+  int t256_min_k;          // SL_T256_MIN_K        (default 1024)
+  int disable_glds;        // SL_DISABLE_GLDS      0 / 1 / 2
+  int direct_epilogue;     // SL_DIRECT_EPILOGUE
+  int gemm_gm;             // SL_GEMM_GM           (default 8)
+  int attn_full_min;       // SL_ATTN_FULL_MIN     (default 32)
+  int attn_force_split;    // SL_ATTN_FORCE_SPLIT
+  int attn_generic;        // SL_ATTN_GENERIC
+  int attn_qt;             // SL_ATTN_QT
+  int norm_single_row;     // SL_NORM_SINGLE_ROW
+  int stream_splits, stream_nwv, stream_mt;   // SL_STREAM_CFG "splits,nwv[,mt]" (0 = not set)
+};
+const SlEnv& sl_env();

@@ -15,11 +15,7 @@
 static int g_disable_glds = 0;  // tuning switch (SL_DISABLE_GLDS=1): A/B the two staging paths in one process
 
 // packed-weight GEMMs with more rows than this run the streaming kernel; SL_STREAM_MIN_M overrides (tuning)
-static int stream_min_m() {
-  const char* e = getenv("SL_STREAM_MIN_M");
-  if (e && e[0]) { const int v = atoi(e); if (v >= 16) return v; }
-  return 32;
-}
+static int stream_min_m() { return sl_env().stream_min_m; }
 
 // ----------------------------------------------------------------------------------------------
 // tiled kernel
@@ -855,11 +851,10 @@ template <typename T, int ACT>
 static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
   constexpr int BK_ = TROWB / (int)sizeof(T);
   // large products: 256^2 tiles once they alone give every CU >= 2 tiles (ragged batches: sized by the largest group)
-  if (!p.ta && !p.tw && p.K % BK_ == 0 && !p.grp_ext && g_disable_glds == 0 && !getenv("SL_DISABLE_T256")) {
+  if (!p.ta && !p.tw && p.K % BK_ == 0 && !p.grp_ext && g_disable_glds == 0 && !sl_env().disable_t256) {
     const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
-    const char* te = getenv("SL_T256_MIN_TILES");   // tuning switch
-    const int64_t min_tiles = (te && te[0]) ? atoi(te) : 512;
-    static const int min_k = getenv("SL_T256_MIN_K") ? atoi(getenv("SL_T256_MIN_K")) : 1024;
+    const int64_t min_tiles = sl_env().t256_min_tiles;   // tuning switches
+    const int min_k = sl_env().t256_min_k;
     // rows padded to 256 vs to 128: short (grouped) products such as the 123-row projector would half-fill the big tile
     const int64_t m128 = (int64_t)((p.M + TBM - 1) / TBM) * TBM, m256 = (int64_t)((p.M + XBM - 1) / XBM) * XBM;
     if (t256 >= min_tiles && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
@@ -961,10 +956,7 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
 
 int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st) {
   SL_CHECK_ARG(a != nullptr, "sl_gemm: null args");
-  {
-    const char* e = getenv("SL_DISABLE_GLDS");
-    g_disable_glds = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0);   // 1: register staging, 2: glds with compiler-visible LDS reads
-  }
+  g_disable_glds = sl_env().disable_glds;   // 1: register staging, 2: glds with compiler-visible LDS reads
   SL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0, "sl_gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   SL_CHECK_ARG(a->dtype == SL_F32 || a->dtype == SL_BF16, "sl_gemm: bad dtype %d", a->dtype);
   const int vec = a->dtype == SL_F32 ? 4 : 8;
@@ -989,9 +981,9 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
-  static const int direct_epi = getenv("SL_DIRECT_EPILOGUE") ? atoi(getenv("SL_DIRECT_EPILOGUE")) : 0;
+  const int direct_epi = sl_env().direct_epilogue;
   p.direct_epi = direct_epi;
-  static const int gm_env = getenv("SL_GEMM_GM") ? atoi(getenv("SL_GEMM_GM")) : 8;
+  const int gm_env = sl_env().gemm_gm;
   p.gm = gm_env;
   if (ex) {
     p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;

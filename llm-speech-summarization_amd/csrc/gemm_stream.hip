@@ -373,17 +373,9 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
   const int nfrag = (N + 15) / 16;
   const int nst = K / (2 * kstep);
   c.d = 4;
-  int sp_env = 0, nwv_env = 0;
-  const char* e = getenv("SL_STREAM_CFG");  // tuning override "splits,nwv[,mt]" (tools/tune_stream.py)
-  if (e && e[0]) {
-    int sp = 0, nwv = 0, mt = 0;
-    const int n = sscanf(e, "%d,%d,%d", &sp, &nwv, &mt);
-    if (n >= 2) {
-      if (sp >= 1 && sp <= 64) sp_env = sp;
-      if (nwv == 2 || nwv == 4) nwv_env = nwv;
-    }
-    if (n == 3 && (mt == 8 || mt == 16) && M > 64) c.mt = mt;
-  }
+  // tuning override "splits,nwv[,mt]" (tools/tune_stream.py), read once into sl_env()
+  const int sp_env = sl_env().stream_splits, nwv_env = sl_env().stream_nwv;
+  if (sl_env().stream_mt && M > 64) c.mt = sl_env().stream_mt;
   const int mblocks = (M + c.mt * 16 - 1) / (c.mt * 16);
   c.nwv = ((nfrag + 7) / 8 * mblocks >= 512 || M > 128) && c.mt <= 8 ? 4 : 2;   // 4 compute + 2 loader waves of 256-row blocks spill
   if (nwv_env && c.mt <= 8) c.nwv = nwv_env;

@@ -729,9 +729,8 @@ template <typename T, int REP>
 static int launch_attn_decode_split(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, float* part,
                                     const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    const char* fm = getenv("SL_ATTN_FULL_MIN");   // tuning switch: (sequence, kv head) pairs from which the single-pass form runs
-    const int64_t full_min = (fm && fm[0]) ? atoi(fm) : 32;   // measured faster than split + merge from B = 4 up (9.1 vs 11.4 us), 97 vs 127 us at B = 512
-    if ((int64_t)B * nkv >= full_min && !getenv("SL_ATTN_FORCE_SPLIT")) {
+    const int64_t full_min = sl_env().attn_full_min;   // tuning switch: (sequence, kv head) pairs from which the single-pass form runs; measured faster than split + merge from B = 4 up (9.1 vs 11.4 us), 97 vs 127 us at B = 512
+    if ((int64_t)B * nkv >= full_min && !sl_env().attn_force_split) {
       hipLaunchKernelGGL((attn_decode_full_kernel<REP, false>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
                          (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale);
       SL_CHECK_LAUNCH("attn_decode_full");

@@ -170,7 +170,7 @@ static int launch_norm(const void* x, void* y, const void* g, const void* b, int
   constexpr int VEC = Vec16<T>::VEC;
   SL_CHECK_ARG(cols % VEC == 0 && cols <= 64 * NORM_MAXF, "norm: cols=%d must be a multiple of %d and <= %d", cols, VEC, 64 * NORM_MAXF);
   if (rows == 0) return 0;
-  static const int single = getenv("SL_NORM_SINGLE_ROW") ? atoi(getenv("SL_NORM_SINGLE_ROW")) : 0;   // A/B switch
+  const int single = sl_env().norm_single_row;   // A/B switch
   if (!single && rows >= 4096) {
     if (cols == 64 * VEC) return launch_norm_multi<T, RMS, 1, 8>(x, y, g, b, rows, eps, gelu, st);
     if (cols == 128 * VEC) return launch_norm_multi<T, RMS, 2, 4>(x, y, g, b, rows, eps, gelu, st);

@@ -605,6 +605,36 @@ extern "C" int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* 
   return decode_step(m, kv, next_ids_dev, ctx_len_dev, B, logits, x, w, st);
 }
 
+// ---- instantiated decode graphs, cached per thread (see sl_greedy_generate)
+struct DecodeGraphKey {
+  const void *model, *layers, *w0, *lm, *embed, *kc, *vc, *ws;
+  size_t ws_bytes;
+  int B, max_new, use_eos, n_eos, pad, max_ctx, slots, dtype, n_layers, vocab, fused;
+  int eos[8];
+};
+struct DecodeGraphEntry { DecodeGraphKey key; hipGraph_t graph; hipGraphExec_t exec; uint64_t stamp; };
+static thread_local std::vector<DecodeGraphEntry> g_graphs;
+static thread_local uint64_t g_graph_clock = 0;
+constexpr size_t SL_GRAPH_CACHE = 8;
+
+static hipGraphExec_t decode_graph_lookup(const DecodeGraphKey& k) {
+  for (auto& e : g_graphs)
+    if (memcmp(&e.key, &k, sizeof(k)) == 0) { e.stamp = ++g_graph_clock; return e.exec; }
+  return nullptr;
+}
+
+static void decode_graph_store(const DecodeGraphKey& k, hipGraph_t g, hipGraphExec_t x) {
+  if (g_graphs.size() >= SL_GRAPH_CACHE) {   // evict the least recently used
+    size_t lru = 0;
+    for (size_t i = 1; i < g_graphs.size(); ++i)
+      if (g_graphs[i].stamp < g_graphs[lru].stamp) lru = i;
+    (void)hipGraphExecDestroy(g_graphs[lru].exec);
+    (void)hipGraphDestroy(g_graphs[lru].graph);
+    g_graphs.erase(g_graphs.begin() + lru);
+  }
+  g_graphs.push_back(DecodeGraphEntry{k, g, x, ++g_graph_clock});
+}
+
 extern "C" size_t sl_generate_workspace_bytes(const sl_llama_model* m, int64_t n_tok, int32_t nseq, int32_t max_new_tokens) {
   LlamaWs w;
   size_t a = llama_carve(m, n_tok > nseq ? n_tok : nseq, nseq, nullptr, 0, w);
@@ -667,21 +697,35 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
   std::vector<int32_t> unf_host(B, 1);
   bool all_done = false;
   if (max_new_tokens > 1) {
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    // Capture on a private stream (the caller's may be the legacy null stream, which cannot capture);
-    // capturing records the launches without running them, the graph is then replayed on `st`.
-    static thread_local hipStream_t cap = nullptr;
-    if (!cap) SL_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-    SL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, cap);
-    if (rc == 0)
-      rc = sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
-                                 out_ids, max_new_tokens, cap);
-    hipError_t ce = hipStreamEndCapture(cap, &graph);
-    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess) { sl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce)); return SL_ERR_LAUNCH; }
-    SL_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    // The decode step is captured ONCE per (model, cache, workspace, batch, limits) and the instantiated graph is kept in a
+    // small per-thread cache: a second sl_greedy_generate call with the same buffers (the usual case: a serving loop reusing
+    // its KV cache and workspace) replays it without re-capturing.  Every pointer the captured launches were recorded with
+    // is part of the key, so a changed buffer can never replay a stale graph.
+    DecodeGraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.model = m; key.layers = m->layers; key.w0 = m->n_layers > 0 ? m->layers[0].wqkv_dec : nullptr; key.lm = m->lm_head_dec ? m->lm_head_dec : m->lm_head;
+    key.embed = m->embed; key.kc = kv->k_cache; key.vc = kv->v_cache; key.ws = workspace; key.ws_bytes = workspace_bytes;
+    key.B = B; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
+    key.slots = kv->slots; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm;
+    for (int i = 0; i < n_eos && i < 8; ++i) key.eos[i] = eos_ids_host[i];
+    hipGraphExec_t exec = decode_graph_lookup(key);
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      // Capture on a private stream (the caller's may be the legacy null stream, which cannot capture);
+      // capturing records the launches without running them, the graph is then replayed on `st`.
+      static thread_local hipStream_t cap = nullptr;
+      if (!cap) SL_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+      SL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+      int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, cap);
+      if (rc == 0)
+        rc = sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
+                                   out_ids, max_new_tokens, cap);
+      hipError_t ce = hipStreamEndCapture(cap, &graph);
+      if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      if (ce != hipSuccess) { sl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce)); return SL_ERR_LAUNCH; }
+      SL_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      decode_graph_store(key, graph, exec);
+    }
     if (check_every <= 0) check_every = 16;
     while (steps_done < max_new_tokens) {
       SL_HIP(hipGraphLaunch(exec, st));
@@ -695,18 +739,15 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
       }
     }
     SL_HIP(hipEventRecord(ev[2], st));
-    SL_HIP(hipStreamSynchronize(st));
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
   } else {
     SL_HIP(hipEventRecord(ev[2], st));
-    SL_HIP(hipStreamSynchronize(st));
   }
-  // results
+  // results: queued behind the last step on the caller's stream, ONE synchronisation for the whole call
   std::vector<int32_t> fin(B);
-  SL_HIP(hipMemcpy(unf_host.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost));
-  SL_HIP(hipMemcpy(fin.data(), finish_len, B * sizeof(int32_t), hipMemcpyDeviceToHost));
-  SL_HIP(hipMemcpy(out_ids_host, out_ids, (size_t)B * max_new_tokens * sizeof(int32_t), hipMemcpyDeviceToHost));
+  SL_HIP(hipMemcpyAsync(unf_host.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  SL_HIP(hipMemcpyAsync(fin.data(), finish_len, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  SL_HIP(hipMemcpyAsync(out_ids_host, out_ids, (size_t)B * max_new_tokens * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  SL_HIP(hipStreamSynchronize(st));
   int n_cols = steps_done;
   if (use_eos) {
     all_done = true;

@@ -420,3 +420,35 @@ def test_tokenizer_fixtures_through_autotokenizer_reproduce_recorded_ids():
         dec = tok.batch_decode([r["ids"]["plain"] + [tok.eos_token_id]], skip_special_tokens=True, clean_up_tokenization_spaces=True)[0]
         assert dec == r["decoded_plain_skip_special"] == r["strings"]["plain"]
     assert len(rec["llama3"]["ids"]["prefix"]) == 9 and len(rec["llama3"]["ids"]["suffix"]) == 6
+
+
+def test_host_side_asan_ubsan_build_passes_the_argument_check_driver():
+    """SURVEY.md §5 (sanitizers: absent in the reference): `make asan` builds the library with host-side AddressSanitizer +
+    UndefinedBehaviorSanitizer (device code un-instrumented: GPU ASan needs xnack+) and csrc/argcheck_main.cpp drives the
+    argument validation, shape / workspace arithmetic and tuning-switch parser of every entry-point family without a GPU; the
+    sanitizers must stay silent and every bad call must come back as an error code with a message."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None or shutil.which("make") is None:
+        pytest.skip("no hipcc / make")
+    csrc = os.path.join(REPO, "llm-speech-summarization_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "asan"], check=True, capture_output=True, timeout=900)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.path.join(csrc, "build_asan", "argcheck")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "argcheck ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_integration_md_binding_stub_structs_match_the_library():
+    """INTEGRATION.md §B is a self-contained ctypes binding a maintainer of the reference would paste next to ref:inference.py:
+    its struct definitions must be the layouts _lib.py (and, through the gcc test above, include/speechllm.h) uses."""
+    import ctypes as C
+    src = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blk = src[src.index("vp, i32, f32 = C.c_void_p"):src.index("def hubert_forward")]
+    ns = {"C": C}
+    exec(blk, ns)
+    for name in ("HubertLayer", "HubertModel", "LlamaLayer", "LlamaModel", "KVCache"):
+        a, b = ns[name], getattr(L, name)
+        assert C.sizeof(a) == C.sizeof(b), name
+        assert [(f[0], getattr(a, f[0]).offset) for f in a._fields_] == [(f[0], getattr(b, f[0]).offset) for f in b._fields_], name
+    assert "speechllm_structs" not in src

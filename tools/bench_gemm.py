@@ -13,6 +13,7 @@ for M, N, K in shapes:
     res = []
     for flag in ("1", "2", "0"):
         os.environ["SL_DISABLE_GLDS"] = flag
+        L.lib().sl_tuning_reload()   # the library reads its tuning switches once; re-read after changing them
         for _ in range(3):
             ops.gemm(A, W, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -13,6 +13,7 @@ shapes = [("qkv", 5120, 3072), ("o", 3072, 3072), ("gateup", 16384, 3072), ("dow
 Ms = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [128]
 cfgs = sys.argv[2].split(";") if len(sys.argv) > 2 else ["default"]
 os.environ["SL_STREAM_MIN_M"] = os.environ.get("SL_STREAM_MIN_M", "16")
+L.lib().sl_tuning_reload()   # the library reads its tuning switches once; re-read after changing them
 for name, N, K in shapes:
     nb = 2 if name == "lm_head" else NBUF
     Wr = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(nb)]
@@ -30,8 +31,10 @@ for name, N, K in shapes:
             cfg = cfg[:-4] if fuse else cfg
             if cfg == "default":
                 os.environ.pop("SL_STREAM_CFG", None)
+                L.lib().sl_tuning_reload()   # the library reads its tuning switches once; re-read after changing them
             else:
                 os.environ["SL_STREAM_CFG"] = cfg
+                L.lib().sl_tuning_reload()   # the library reads its tuning switches once; re-read after changing them
             out = ops.gemm_decode(A, Ws[0], N, act=act, fuse_rms=fuse)
             rr = ref
             if fuse:
