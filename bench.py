@@ -137,8 +137,12 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     losses = None
+    window_ms, t_prev = [], t0
     for _ in range(args.kd_optimizer_steps):
-        losses = tr.micro_batch(waves, texts, resps)[-1]
+        losses = tr.micro_batch(waves, texts, resps)[-1]      # reading the losses back ends the window on the host
+        t_now = time.perf_counter()
+        window_ms.append(round((t_now - t_prev) * 1e3, 1))
+        t_prev = t_now
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -178,7 +182,7 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                          "algorithmic_flops_per_sample": round(flops), "seq_audio": S_a, "seq_text": S_t,
                          "formula": "3 enc_fwd + 2 prefill_full(S_audio) + prefill_full(S_text), SURVEY.md §8d; per rank"},
-            "optimizer_steps": args.kd_optimizer_steps, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
+            "optimizer_steps": args.kd_optimizer_steps, "window_ms": window_ms, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
             "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
             "losses": {k: round(v, 4) for k, v in losses.items()}, "dtype": "bf16 compute, fp32 master/grads",
             "encoder_mode": "eval (regularisers off)" if reg is None else "train(): dropout 0.1 (feature projection, hidden, activation, attention probabilities), LayerDrop 0.1, SpecAugment 0.05 x 10",
