@@ -124,13 +124,10 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     B = tr.local_accum                       # one accumulation window = one packed micro-batch per rank
     n_micro = B * args.kd_optimizer_steps
     waves, texts, resps = [wave] * B, [text_ids] * B, [resp_ids] * B
-    saved = tr.optimizer_step
-    tr.optimizer_step = lambda: None         # warm-up window: allocator + kernels, no update
+    # warm-up: ONE complete window including its optimizer step (first-use costs: allocator growth, transposed copies of the
+    # frozen LLM weights, AdamW's exp_avg / exp_avg_sq allocation, RCCL communicator set-up), untimed; the timed windows below
+    # each contain everything a step does (forward, backward, all-reduce, AdamW, in-place refresh of the kernel weights)
     tr.micro_batch(waves, texts, resps)
-    tr.optimizer_step = saved
-    if tr.reducer is not None:
-        tr.reducer.finish()                  # the warm-up window's buckets (also warms RCCL up); then discard the sums
-    tr.enc_tape.arena.zero_()
     tr.micro = 0
     if dist is not None:
         dist.barrier()
