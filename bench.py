@@ -359,6 +359,7 @@ def main():
     ap.add_argument("--max-new-tokens", type=int, default=256)
     ap.add_argument("--pipelines", type=int, default=2, help="batches in flight per GPU (host threads x HIP streams; 1 = strictly sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pack-decode", action="store_true", help="experiment: decode on the row-major weights (tiled MFMA GEMMs, unfused norms / RoPE)")
     ap.add_argument("--cpu-decode-steps", type=int, default=8, help="decode steps per pass of the bounded CPU-oracle sample (4 passes, ≈0.45 s per step)")
     ap.add_argument("--kd-optimizer-steps", type=int, default=3, help="optimizer steps of the KD training leg (0 = skip)")
     ap.add_argument("--kd-eval-mode", action="store_true", help="KD leg with the encoder's training-mode regularisers off")
@@ -412,7 +413,7 @@ def main():
     long_ctx = ((S_long + new + 63) // 64) * 64
     rope_ctx = mix_ctx if args.no_extra_legs else max(mix_ctx, long_ctx)
     keep_sd = dict(llm_sd) if (rank == 0 and not args.no_cpu_baseline) else None
-    llm = llama_mod.AudioLlamaForCausalLM(larch, llm_sd, torch_dtype=torch.bfloat16, device=dev, max_ctx=rope_ctx, max_batch=B)
+    llm = llama_mod.AudioLlamaForCausalLM(larch, llm_sd, torch_dtype=torch.bfloat16, device=dev, max_ctx=rope_ctx, max_batch=B, pack_decode=not args.no_pack_decode)
     del llm_sd
     wts = llm._dev()          # rope tables / split-attention workspace sized for the longest leg
     llm.max_ctx = max_ctx     # the headline's KV cache (and split-attention grid) is sized for its own context

@@ -490,6 +490,23 @@ int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, 
                        int32_t* n_steps_host, float* timings_ms_host /* [prefill, decode] or NULL */,
                        void* workspace, size_t workspace_bytes, sl_stream stream);
 
+/* Sampled generation (hf:generation/utils.py:2911-2923 with do_sample = True — what the hub's generation_config.json of
+ * Llama-3.2-3B-Instruct asks for when a caller does not force greedy): HF's logits warpers in HF's order —
+ * temperature (scores / T), top-k (keep scores >= the k-th largest; 0 = off; HF's default is 50), top-p over the
+ * top-k-filtered distribution (drop a token iff the mass ranked above it is >= top_p; 1.0 = off) — then one draw per row from
+ * the renormalised survivors by inverse CDF in index order at u = hash(seed, row, step): reproducible for a given seed (HF's
+ * own stream is torch.multinomial on the global CUDA generator, which no other implementation can reproduce).
+ * sl_sample_select is sl_greedy_select with the draw in place of the argmax (choice_ws: B int32 scratch);
+ * sl_sample_generate is sl_greedy_generate with it (same workspace size, same synchronisation points). */
+int sl_sample_select(const float* logits, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p, uint64_t seed,
+                     const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t* unfinished, int32_t* ctx_len,
+                     int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, int32_t* choice_ws,
+                     sl_stream stream);
+int sl_sample_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                       int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
+                       int32_t check_every, float temperature, int32_t top_k, float top_p, uint64_t seed, int32_t* out_ids_host,
+                       int32_t* n_steps_host, float* timings_ms_host, void* workspace, size_t workspace_bytes, sl_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * KD step, layer stacks (C++ host runtime of the training tape: one call issues the launches of a whole stack of layers
  * over a packed ragged batch; ref:trainer.py:270-384 runs the same arithmetic through autograd, one utterance at a time).

@@ -213,6 +213,10 @@ _PROTOS = {
                                  c_vp, c_sz, c_vp]),
     "sl_llama_decode_step": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "sl_generate_workspace_bytes": (c_sz, [C.POINTER(LlamaModel), c_i64, c_i32, c_i32]),
+    "sl_sample_select": (c_i32, [c_vp, c_i32, c_i32, c_f32, c_i32, c_f32, C.c_uint64, C.POINTER(c_i32), c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                 c_i32, c_vp, c_vp]),
+    "sl_sample_generate": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, C.POINTER(c_i32), c_i32, c_i32, C.POINTER(c_i32), c_i32, c_i32, c_i32,
+                                   c_i32, c_f32, c_i32, c_f32, C.c_uint64, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_f32), c_vp, c_sz, c_vp]),
     "sl_greedy_generate": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, C.POINTER(c_i32), c_i32, c_i32,
                                    C.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, C.POINTER(c_i32), C.POINTER(c_i32),
                                    C.POINTER(c_f32), c_vp, c_sz, c_vp]),

@@ -53,8 +53,12 @@ class AudioLlamaForCausalLM:
         self.config = SimpleNamespace(vocab_size=arch.vocab_size, hidden_size=arch.hidden_size,
                                       num_hidden_layers=arch.num_hidden_layers, eos_token_id=list(arch.eos_token_ids),
                                       pad_token_id=arch.pad_token_id, use_return_dict=True)
+        # Greedy by default: BASELINE.json's north_star specifies greedy decode (the reference never passes
+        # do_sample, so a hub generation_config.json decides; from_pretrained keeps that file's sampling parameters here and its
+        # do_sample flag under `hub_do_sample`, but sampling is only used when a caller sets do_sample=True).
         self.generation_config = SimpleNamespace(eos_token_id=list(arch.eos_token_ids), pad_token_id=arch.pad_token_id,
-                                                 do_sample=False)
+                                                 do_sample=False, temperature=1.0, top_k=50, top_p=1.0, hub_do_sample=None)
+        self.sample_seed = 0
         self._sd = state_dict
         self.device = torch.device("cpu")
         self.max_ctx, self.max_batch, self.pack_decode = max_ctx, max_batch, pack_decode
@@ -84,7 +88,20 @@ class AudioLlamaForCausalLM:
                 sd.update(load_file(os.path.join(name_or_path, fn)))
         if not sd:
             raise L.SpeechLLMError(f"no *.safetensors files under {name_or_path}")
-        return cls(arch, sd, torch_dtype=torch_dtype, **kw)
+        obj = cls(arch, sd, torch_dtype=torch_dtype, **kw)
+        gc_path = os.path.join(name_or_path, "generation_config.json")
+        if os.path.exists(gc_path):
+            with open(gc_path) as f:
+                gc = json.load(f)
+            g = obj.generation_config
+            g.temperature, g.top_k, g.top_p = float(gc.get("temperature", 1.0)), int(gc.get("top_k", 50)), float(gc.get("top_p", 1.0))
+            g.hub_do_sample = bool(gc.get("do_sample", False))
+            if gc.get("eos_token_id") is not None:
+                e = gc["eos_token_id"]
+                g.eos_token_id = list(e) if isinstance(e, (list, tuple)) else [e]
+            if gc.get("pad_token_id") is not None:
+                g.pad_token_id = gc["pad_token_id"]
+        return obj
 
     def eval(self):
         return self
@@ -187,7 +204,8 @@ class AudioLlamaForCausalLM:
 
     # -- generation -----------------------------------------------------------------------------
     def generate(self, input_ids=None, inputs_embeds=None, max_new_tokens: int = 256, attention_mask=None, use_eos: bool = True,
-                 **unused) -> torch.Tensor:
+                 do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None, seed: Optional[int] = None, **unused) -> torch.Tensor:
         w = self._dev()
         a = self.arch
         if inputs_embeds is None:
@@ -196,10 +214,18 @@ class AudioLlamaForCausalLM:
             inputs_embeds = self.model.embed_tokens(input_ids)
         x, lens = self._pack(inputs_embeds.to(self.dtype) if torch.is_tensor(inputs_embeds) else [e.to(self.dtype) for e in inputs_embeds],
                              attention_mask)
-        ids, n_cols = self.generate_packed(x, lens, max_new_tokens, use_eos=use_eos)
+        g = self.generation_config
+        sample = None
+        if (g.do_sample if do_sample is None else do_sample):
+            # hf:generation/utils.py logits warpers: temperature, top-k (HF default 50), top-p, then one draw per row
+            if seed is None:
+                seed, self.sample_seed = self.sample_seed, self.sample_seed + 1
+            sample = dict(temperature=float(g.temperature if temperature is None else temperature), top_k=int(g.top_k if top_k is None else top_k),
+                          top_p=float(g.top_p if top_p is None else top_p), seed=int(seed))
+        ids, n_cols = self.generate_packed(x, lens, max_new_tokens, use_eos=use_eos, sample=sample)
         return ids[:, :n_cols].to(torch.int64)
 
-    def generate_packed(self, x: torch.Tensor, lens: Sequence[int], max_new_tokens: int, use_eos: bool = True):
+    def generate_packed(self, x: torch.Tensor, lens: Sequence[int], max_new_tokens: int, use_eos: bool = True, sample: Optional[dict] = None):
         """x: packed prompt embeddings (sum S_i, h) on the GPU (overwritten).  Returns (int32 (B, max_new) host tensor, n_cols)."""
         w = self._dev()
         a = self.arch
@@ -221,9 +247,14 @@ class AudioLlamaForCausalLM:
         n_steps = C.c_int32(0)
         timings = (C.c_float * 2)()
         ws = self._workspace(lib.sl_generate_workspace_bytes(C.byref(w.struct), x.shape[0], B, max_new_tokens))
-        L.check(lib.sl_greedy_generate(C.byref(w.struct), C.byref(kv), x.data_ptr(), cu_c, B, max_new_tokens, eos_c, len(eos), pad,
-                                       int(use_eos), 16, out, C.byref(n_steps), timings, ws.data_ptr(), ws.numel(), L.stream_ptr()),
-                "sl_greedy_generate")
+        if sample is None:
+            L.check(lib.sl_greedy_generate(C.byref(w.struct), C.byref(kv), x.data_ptr(), cu_c, B, max_new_tokens, eos_c, len(eos), pad,
+                                           int(use_eos), 16, out, C.byref(n_steps), timings, ws.data_ptr(), ws.numel(), L.stream_ptr()),
+                    "sl_greedy_generate")
+        else:
+            L.check(lib.sl_sample_generate(C.byref(w.struct), C.byref(kv), x.data_ptr(), cu_c, B, max_new_tokens, eos_c, len(eos), pad,
+                                           int(use_eos), 16, sample["temperature"], sample["top_k"], sample["top_p"], sample["seed"] & 0xFFFFFFFFFFFFFFFF,
+                                           out, C.byref(n_steps), timings, ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_sample_generate")
         self.last_timings_ms = (timings[0], timings[1])
         ids = torch.frombuffer(out, dtype=torch.int32).clone().view(B, max_new_tokens)
         return ids, int(n_steps.value)

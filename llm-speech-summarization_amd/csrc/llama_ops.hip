@@ -243,13 +243,32 @@ struct EosList { int ids[8]; int n; };
 __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __restrict__ logits, int V, EosList eos, int pad_id, int use_eos,
                                                              int advance_ctx, int32_t* __restrict__ unfinished, int32_t* __restrict__ ctx_len,
                                                              int32_t* __restrict__ gen_count, int32_t* __restrict__ finish_len,
-                                                             int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new) {
+                                                             int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new,
+                                                             const int32_t* __restrict__ forced) {
   __shared__ float smax[16];
   __shared__ int sidx[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + (int64_t)b * V;
   float best = -INFINITY;
   int bi = 0x7fffffff;
+  if (forced) {   // sampling mode: the token was drawn by sample_rows_kernel; only the bookkeeping below runs
+    if (tid == 0) {
+      int tok = forced[b];
+      const int unf = unfinished[b];
+      if (use_eos) tok = unf ? tok : pad_id;
+      const int n = gen_count[b];
+      if (n < max_new) out_ids[(int64_t)b * max_new + n] = tok;
+      gen_count[b] = n + 1;
+      next_ids[b] = tok;
+      if (use_eos && unf) {
+        bool is_eos = false;
+        for (int e = 0; e < eos.n; ++e) is_eos |= (tok == eos.ids[e]);
+        if (is_eos) { unfinished[b] = 0; finish_len[b] = n + 1; }
+      }
+      if (advance_ctx) ctx_len[b] += 1;
+    }
+    return;
+  }
   auto upd = [&](float v, int i) {
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }   // NaN never wins, like a strict '>' scan
   };
@@ -311,9 +330,173 @@ int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32
   e.n = n_eos;
   for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
   hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, st, logits, V, e, pad_id, use_eos, advance_ctx, unfinished, ctx_len,
-                     gen_count, finish_len, next_ids, out_ids, max_new);
+                     gen_count, finish_len, next_ids, out_ids, max_new, (const int32_t*)nullptr);
   SL_CHECK_LAUNCH("greedy_select");
   return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// sampled selection (hf:generation/utils.py:2911-2923 with do_sample: logits processors then multinomial):
+//   TemperatureLogitsWarper (scores / T), TopKLogitsWarper (keep scores >= the k-th largest), TopPLogitsWarper (on the
+//   top-k-filtered distribution: drop token i iff the probability mass of the tokens ranked ABOVE it is >= top_p; at least
+//   one token survives), then one draw from the renormalised survivors.  One block per row; thresholds by 4-pass radix
+//   selection over the order-preserving 32-bit image of the logits (by count for top-k, by probability mass for top-p), so no
+//   sort and no O(V) scratch; the draw is the inverse CDF in INDEX order at u = hash(seed, row, step) — reproducible, and the
+//   test restates it on the host.  Tokens of equal logit share their fate (all kept or all dropped).
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ord_key(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restrict__ logits, int V, float inv_temp, int top_k, float top_p, uint64_t seed,
+                                                           const int32_t* __restrict__ gen_count, int32_t* __restrict__ choice) {
+  __shared__ float redf[16];
+  __shared__ int hcnt[256];
+  __shared__ float hmass[256];
+  __shared__ uint32_t s_prefix;
+  __shared__ float s_above;
+  __shared__ float part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (int64_t)b * V;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) redf[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += redf[w];
+    return t;
+  };
+  // row maximum (numerical stability of the exponentials)
+  float m = -INFINITY;
+  for (int i = tid; i < V; i += 1024) m = fmaxf(m, row[i]);
+  m = wave_max(m);
+  if (lane == 0) redf[wave] = m;
+  __syncthreads();
+  m = redf[0];
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, redf[w]);
+  __syncthreads();
+  auto prob = [&](float x) { return __expf((x - m) * inv_temp); };
+
+  // radix selection: MODE 0 = by count (k-th largest key), MODE 1 = by mass (first key, from the top, at which the mass of
+  // the strictly larger keys is still < limit).  `floor_key`: only keys >= floor_key take part.  Returns the selected key.
+  auto radix_select = [&](int mode, float limit, uint32_t floor_key) -> uint32_t {
+    uint32_t prefix = 0;
+    float above = 0.f;     // count / mass of keys larger than every key matching the current prefix
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = tid; i < 256; i += 1024) { hcnt[i] = 0; hmass[i] = 0.f; }
+      __syncthreads();
+      for (int i = tid; i < V; i += 1024) {
+        const float x = row[i];
+        const uint32_t k = ord_key(x);
+        if (k < floor_key || (k & hi_mask) != prefix) continue;
+        const int bin = (k >> shift) & 255;
+        if (mode == 0) atomicAdd(&hcnt[bin], 1);
+        else atomicAdd(&hmass[bin], prob(x));
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float run = above;
+        int sel = -1;
+        for (int bin = 255; bin >= 0; --bin) {
+          const float w = mode == 0 ? (float)hcnt[bin] : hmass[bin];
+          if (mode == 0 ? (hcnt[bin] > 0 && run + w >= limit) : (hmass[bin] > 0.f && run + w >= limit)) { sel = bin; break; }
+          run += w;
+        }
+        if (sel < 0) {           // the limit is never reached (rounding / k >= candidates): take the smallest populated bin
+          run = above;
+          for (int bin = 255; bin >= 0; --bin) {
+            const bool pop = mode == 0 ? hcnt[bin] > 0 : hmass[bin] > 0.f;
+            if (pop) { sel = bin; }
+          }
+          run = above;
+          for (int bin = 255; bin > sel; --bin) run += mode == 0 ? (float)hcnt[bin] : hmass[bin];
+          if (sel < 0) sel = 0;
+        }
+        s_prefix = prefix | ((uint32_t)sel << shift);
+        s_above = run;
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      above = s_above;
+      __syncthreads();
+    }
+    return prefix;
+  };
+
+  uint32_t keep_key = 0;                               // survivors: ord_key(logit) >= keep_key
+  if (top_k > 0 && top_k < V) keep_key = radix_select(0, (float)top_k, 0u);
+  if (top_p < 1.0f) {
+    float z1 = 0.f;
+    for (int i = tid; i < V; i += 1024) { const float x = row[i]; if (ord_key(x) >= keep_key) z1 += prob(x); }
+    z1 = block_sum(z1);
+    const uint32_t kp = radix_select(1, top_p * z1, keep_key);
+    keep_key = kp > keep_key ? kp : keep_key;
+  }
+  // inverse CDF in index order: thread t owns the contiguous slice [t * C, (t + 1) * C)
+  const int Cn = (V + 1023) / 1024;
+  const int i0 = tid * Cn, i1 = (i0 + Cn) < V ? (i0 + Cn) : V;
+  float loc = 0.f;
+  for (int i = i0; i < i1; ++i) { const float x = row[i]; if (ord_key(x) >= keep_key) loc += prob(x); }
+  part[tid] = loc;
+  __syncthreads();
+  if (tid == 0) {
+    float z = 0.f;
+    for (int t = 0; t < 1024; ++t) z += part[t];
+    const uint32_t step = (uint32_t)gen_count[b];
+    const uint32_t h = lowbias32(step ^ lowbias32((uint32_t)b ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    const float target = u * z;
+    float run = 0.f;
+    int t = 0;
+    for (; t < 1023; ++t) { if (run + part[t] > target) break; run += part[t]; }
+    // walk the slice; the LAST surviving index seen is the fallback when rounding leaves target >= the total
+    int pick = -1, last = -1;
+    const int j0 = t * Cn, j1 = (j0 + Cn) < V ? (j0 + Cn) : V;
+    for (int i = j0; i < j1; ++i) {
+      const float x = row[i];
+      if (ord_key(x) < keep_key) continue;
+      last = i;
+      run += prob(x);
+      if (run > target) { pick = i; break; }
+    }
+    if (pick < 0) pick = last;
+    if (pick < 0) {   // empty slice (cannot happen with z > 0): fall back to the global argmax bookkeeping index 0
+      for (int i = 0; i < V; ++i) if (ord_key(row[i]) >= keep_key) { pick = i; break; }
+    }
+    choice[b] = pick < 0 ? 0 : pick;
+  }
+}
+
+int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p, uint64_t seed,
+                          const int32_t* eos_ids, int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished,
+                          int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new,
+                          int32_t* choice_ws, hipStream_t st) {
+  SL_CHECK_ARG(logits && unfinished && ctx_len && gen_count && finish_len && next_ids && out_ids && choice_ws && B > 0 && V > 0,
+               "sl_sample_select: bad arguments");
+  SL_CHECK_ARG(temperature > 0.f && top_p > 0.f && top_p <= 1.0f && top_k >= 0, "sl_sample_select: need temperature > 0, 0 < top_p <= 1, top_k >= 0 (got %f, %f, %d)",
+               (double)temperature, (double)top_p, top_k);
+  SL_CHECK_ARG(n_eos >= 0 && n_eos <= 8, "sl_sample_select: at most 8 eos ids");
+  EosList e;
+  e.n = n_eos;
+  for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(B), dim3(1024), 0, st, logits, V, 1.0f / temperature, top_k, top_p, seed, gen_count, choice_ws);
+  SL_CHECK_LAUNCH("sample_rows");
+  hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(64), 0, st, logits, V, e, pad_id, use_eos, advance_ctx, unfinished, ctx_len, gen_count, finish_len,
+                     next_ids, out_ids, max_new, (const int32_t*)choice_ws);
+  SL_CHECK_LAUNCH("sample_commit");
+  return 0;
+}
+
+extern "C" int sl_sample_select(const float* logits, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p, uint64_t seed,
+                                const int32_t* eos_ids, int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t* unfinished, int32_t* ctx_len,
+                                int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, int32_t* choice_ws,
+                                sl_stream stream) {
+  return sl_sample_select_impl(logits, B, V, temperature, top_k, top_p, seed, eos_ids, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len,
+                               next_ids, out_ids, max_new, choice_ws, (hipStream_t)stream);
 }
 
 extern "C" int sl_greedy_select(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,

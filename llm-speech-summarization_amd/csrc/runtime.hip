@@ -11,6 +11,10 @@ int sl_attn_decode_impl(const void* q, int64_t q_stride, const void* k_cache, co
 int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
                           int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
                           int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st);
+int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p, uint64_t seed,
+                          const int32_t* eos_ids, int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished,
+                          int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new,
+                          int32_t* choice_ws, hipStream_t st);
 
 int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
                               const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
@@ -611,6 +615,9 @@ struct DecodeGraphKey {
   size_t ws_bytes;
   int B, max_new, use_eos, n_eos, pad, max_ctx, slots, dtype, n_layers, vocab, fused;
   int eos[8];
+  int sample, top_k;
+  float temperature, top_p;
+  uint64_t seed;
 };
 struct DecodeGraphEntry { DecodeGraphKey key; hipGraph_t graph; hipGraphExec_t exec; uint64_t stamp; };
 static thread_local std::vector<DecodeGraphEntry> g_graphs;
@@ -640,14 +647,16 @@ extern "C" size_t sl_generate_workspace_bytes(const sl_llama_model* m, int64_t n
   size_t a = llama_carve(m, n_tok > nseq ? n_tok : nseq, nseq, nullptr, 0, w);
   a += (size_t)nseq * m->hidden * sl_dtype_size(m->dtype) + 256;    // decode x
   a += (size_t)nseq * m->vocab * sizeof(float) + 256;               // logits
-  a += ((size_t)nseq * (5 + max_new_tokens)) * sizeof(int32_t) + 8 * 256;
+  a += ((size_t)nseq * (6 + max_new_tokens)) * sizeof(int32_t) + 9 * 256;
   return a;
 }
 
-extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
-                                  int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
-                                  int32_t check_every, int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host,
-                                  void* workspace, size_t workspace_bytes, sl_stream stream) {
+struct SampleOpts { float temperature; int top_k; float top_p; uint64_t seed; };
+
+static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                         int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
+                         int32_t check_every, const SampleOpts* smp, int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host,
+                         void* workspace, size_t workspace_bytes, sl_stream stream) {
   SL_TRY(llama_check(m, kv));
   SL_CHECK_ARG(x && cu_seqlens_host && out_ids_host && n_steps_host && workspace && nseq > 0 && nseq <= SL_MAX_DECODE_BATCH && max_new_tokens > 0,
                "sl_greedy_generate: bad arguments (nseq<=%d)", SL_MAX_DECODE_BATCH);
@@ -670,6 +679,7 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
   int32_t* finish_len = (int32_t*)c.take(B * sizeof(int32_t));
   int32_t* next_ids = (int32_t*)c.take(B * sizeof(int32_t));
   int32_t* out_ids = (int32_t*)c.take((size_t)B * max_new_tokens * sizeof(int32_t));
+  int32_t* choice = (int32_t*)c.take(B * sizeof(int32_t));      // sampling mode: the drawn token of every row
   c.take(0);
   void* scratch = bptr(workspace) + c.off;
   const size_t scratch_bytes = workspace_bytes - c.off;
@@ -684,8 +694,14 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
   for (auto& e : ev) SL_HIP(hipEventCreate(&e));
   SL_HIP(hipEventRecord(ev[0], st));
   SL_TRY(sl_llama_prefill(m, kv, x, cu_seqlens_host, nseq, logits, ctx_len, nullptr, scratch, scratch_bytes, stream));
-  SL_TRY(sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 0, unfinished, ctx_len, gen_count, finish_len, next_ids,
-                               out_ids, max_new_tokens, st));
+  auto select = [&](int advance_ctx, hipStream_t s_) -> int {
+    if (smp)
+      return sl_sample_select_impl(logits, B, m->vocab, smp->temperature, smp->top_k, smp->top_p, smp->seed, eos_ids_host, n_eos, pad_id, use_eos, advance_ctx,
+                                   unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, max_new_tokens, choice, s_);
+    return sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, advance_ctx, unfinished, ctx_len, gen_count, finish_len, next_ids,
+                                 out_ids, max_new_tokens, s_);
+  };
+  SL_TRY(select(0, st));
   SL_HIP(hipEventRecord(ev[1], st));
 
   // decode: one captured step, replayed.  Scratch layout for M = B rows.
@@ -708,6 +724,7 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
     key.B = B; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
     key.slots = kv->slots; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm;
     for (int i = 0; i < n_eos && i < 8; ++i) key.eos[i] = eos_ids_host[i];
+    if (smp) { key.sample = 1; key.temperature = smp->temperature; key.top_k = smp->top_k; key.top_p = smp->top_p; key.seed = smp->seed; }
     hipGraphExec_t exec = decode_graph_lookup(key);
     if (!exec) {
       hipGraph_t graph = nullptr;
@@ -717,9 +734,7 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
       if (!cap) SL_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
       SL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
       int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, cap);
-      if (rc == 0)
-        rc = sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
-                                   out_ids, max_new_tokens, cap);
+      if (rc == 0) rc = select(1, cap);
       hipError_t ce = hipStreamEndCapture(cap, &graph);
       if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       if (ce != hipSuccess) { sl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce)); return SL_ERR_LAUNCH; }
@@ -762,4 +777,22 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return 0;
+}
+
+extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                                  int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
+                                  int32_t check_every, int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host,
+                                  void* workspace, size_t workspace_bytes, sl_stream stream) {
+  return generate_impl(m, kv, x, cu_seqlens_host, nseq, max_new_tokens, eos_ids_host, n_eos, pad_id, use_eos, check_every, nullptr, out_ids_host,
+                       n_steps_host, timings_ms_host, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sl_sample_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                                  int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
+                                  int32_t check_every, float temperature, int32_t top_k, float top_p, uint64_t seed, int32_t* out_ids_host,
+                                  int32_t* n_steps_host, float* timings_ms_host, void* workspace, size_t workspace_bytes, sl_stream stream) {
+  SL_CHECK_ARG(temperature > 0.f && top_p > 0.f && top_p <= 1.0f && top_k >= 0, "sl_sample_generate: need temperature > 0, 0 < top_p <= 1, top_k >= 0");
+  SampleOpts o{temperature, top_k, top_p, seed};
+  return generate_impl(m, kv, x, cu_seqlens_host, nseq, max_new_tokens, eos_ids_host, n_eos, pad_id, use_eos, check_every, &o, out_ids_host, n_steps_host,
+                       timings_ms_host, workspace, workspace_bytes, stream);
 }

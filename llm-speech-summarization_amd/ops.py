@@ -554,3 +554,29 @@ def kd_mse_rows(a, b, row_coef, row_slot, losses, loss_col, da=None):
     """Feature-distillation MSE of one tap over every utterance's tail rows in one launch (sl_kd_mse_rows)."""
     L.check(L.lib().sl_kd_mse_rows(L.ptr(a), L.ptr(b), L.ptr(row_coef), L.ptr(row_slot), a.shape[0], a.shape[1], L.ptr(losses), losses.stride(0), loss_col,
                                    L.ptr(da), L.dtype_code(a.dtype), L.stream_ptr()), "sl_kd_mse_rows")
+
+
+def sample_select(logits, temperature, top_k, top_p, seed, eos_ids, pad_id, use_eos, unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids) -> None:
+    """sl_sample_select: HF's temperature / top-k / top-p warpers + one reproducible draw per row, then greedy_select's bookkeeping."""
+    B, V = logits.shape
+    eos = (C.c_int32 * max(1, len(eos_ids)))(*eos_ids)
+    choice = torch.empty(B, dtype=torch.int32, device=logits.device)
+    L.check(L.lib().sl_sample_select(L.ptr(logits), B, V, float(temperature), int(top_k), float(top_p), int(seed) & 0xFFFFFFFFFFFFFFFF, eos, len(eos_ids), pad_id,
+                                     int(use_eos), L.ptr(unfinished), L.ptr(ctx_len), L.ptr(gen_count), L.ptr(finish_len), L.ptr(next_ids), L.ptr(out_ids),
+                                     out_ids.shape[1], L.ptr(choice), L.stream_ptr()), "sl_sample_select")
+
+
+def sample_uniform(seed: int, row: int, step: int) -> float:
+    """Host restatement of the uniform sl_sample_select draws for (seed, row, step) — the tests rebuild the inverse-CDF pick with it."""
+    m32 = 0xFFFFFFFF
+
+    def lowbias32(v):
+        v &= m32
+        v ^= v >> 16; v = (v * 0x7feb352d) & m32
+        v ^= v >> 15; v = (v * 0x846ca68b) & m32
+        v ^= v >> 16
+        return v
+
+    seed &= 0xFFFFFFFFFFFFFFFF
+    h = lowbias32((step & m32) ^ lowbias32((row & m32) ^ (seed & m32)) ^ (seed >> 32))
+    return (h >> 8) / 16777216.0

@@ -509,3 +509,59 @@ def test_attn_decode_split_large_batch(dt, nh, nkv):
         n = lens[s]
         ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
         assert rel_err(out[s], ref[0]) < TOL[dt]
+
+
+@pytest.mark.parametrize("V,temperature,top_k,top_p", [(1000, 0.6, 50, 0.9), (128256, 0.6, 50, 0.9), (1000, 1.0, 0, 0.75), (1000, 1.3, 7, 1.0), (777, 0.8, 1, 0.5)])
+def test_sample_select_follows_hf_logits_warpers(V, temperature, top_k, top_p):
+    """Sampled selection: the survivor set must be the one HF's own TemperatureLogitsWarper ->
+    TopKLogitsWarper -> TopPLogitsWarper leave (the installed transformers' classes are the oracle), the drawn token is the
+    inverse-CDF pick over that set at the kernel's uniform (restated on the host), finished rows emit pad, top_k = 1 is greedy."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    B, seed, n_draws = 6, 0xABCDEF0123, 40
+    logits = rnd(B, V, seed=51, std=2.5)
+    scores = TemperatureLogitsWarper(temperature)(None, logits.clone())
+    if top_k > 0:
+        scores = TopKLogitsWarper(top_k=top_k)(None, scores)
+    if top_p < 1.0:
+        scores = TopPLogitsWarper(top_p=top_p)(None, scores)
+    allowed = torch.isfinite(scores)
+    probs = torch.softmax(scores.double(), -1)
+    dl = logits.to(dev())
+    unfinished = torch.tensor([1, 1, 0, 1, 1, 1], dtype=torch.int32, device=dev())
+    ctx = torch.full((B,), 10, dtype=torch.int32, device=dev())
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev())
+    fin = torch.zeros(B, dtype=torch.int32, device=dev())
+    nxt = torch.zeros(B, dtype=torch.int32, device=dev())
+    out = torch.full((B, n_draws), -1, dtype=torch.int32, device=dev())
+    for _ in range(n_draws):
+        ops.sample_select(dl, temperature, top_k, top_p, seed, [3], 5, True, unfinished, ctx, cnt, fin, nxt, out)
+    out = out.cpu()
+    assert int(cnt[0]) == n_draws and int(ctx[0]) == 10 + n_draws
+    exact = total = 0
+    for b in range(B):
+        if b == 2:
+            assert bool((out[b] == 5).all())                       # finished row: pad
+            continue
+        for step in range(n_draws):
+            tok = int(out[b, step])
+            assert bool(allowed[b, tok]), (b, step, tok)           # never outside HF's survivor set
+            if tok == 3:                                           # an EOS draw finishes the row: pad from there on
+                assert bool((out[b, step + 1:] == 5).all())
+                break
+            cdf = torch.cumsum(probs[b], 0)
+            ref = int(torch.searchsorted(cdf, torch.tensor(ops.sample_uniform(seed, b, step), dtype=torch.float64), right=True))
+            total += 1
+            exact += int(ref == tok)
+    assert exact >= 0.97 * total, (exact, total)                   # fp32 vs fp64 CDF: a draw that lands on a boundary may move by one survivor
+    if top_k == 1:
+        assert bool((out[0] == int(logits[0].argmax())).all()) or 3 in out[0].tolist()
+    # the survivor sets themselves: every surviving token is drawn at some seed when the set is small
+    if int(allowed[0].sum()) <= 8:
+        seen = set()
+        cnt.zero_(); unfinished.fill_(1)
+        out2 = torch.zeros((B, 1), dtype=torch.int32, device=dev())
+        for sd in range(400):
+            cnt.zero_()
+            ops.sample_select(dl, temperature, top_k, top_p, sd, [], 5, False, unfinished, ctx, cnt, fin, nxt, out2)
+            seen.add(int(out2[0, 0]))
+        assert seen == set(torch.nonzero(allowed[0]).flatten().tolist())

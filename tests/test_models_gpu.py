@@ -433,3 +433,23 @@ def test_utils_soft_cross_entropy_drop_in():
     assert out.dim() == 0 and abs(float(out) - float(ref)) < 1e-5 * abs(float(ref))
     per = utils.soft_cross_entropy(s.to(DEV), tch.to(DEV), reduction="none")
     assert per.shape == (1, 7) and abs(float(per.mean()) - float(ref)) < 1e-5 * abs(float(ref))
+
+
+def test_sampled_generation_is_reproducible_and_greedy_stays_default():
+    """generate(do_sample=True, ...) runs sl_sample_generate (one captured decode graph with the sampling kernels); same seed
+    -> same ids, another seed -> other ids, top_k=1 == greedy; without do_sample the reference fixture's greedy ids come out."""
+    g = golden("llama_tiny_gqa")
+    cfg = TINY_LLAMA
+    llm, _ = make_llama(cfg, int(g["weight_seed"]), torch.float32)
+    gen = torch.Generator().manual_seed(int(g["embeds_seed"]))
+    x = (torch.randn(1, int(g["S"]), cfg.hidden_size, generator=gen) * 0.05).to(DEV)
+    llm.generation_config.eos_token_id = None
+    greedy = llm.generate(inputs_embeds=x, max_new_tokens=32).cpu()
+    assert torch.equal(greedy, t(g["ids_noeos"]))
+    a = llm.generate(inputs_embeds=x, max_new_tokens=32, do_sample=True, temperature=0.9, top_k=50, top_p=0.95, seed=11).cpu()
+    b = llm.generate(inputs_embeds=x, max_new_tokens=32, do_sample=True, temperature=0.9, top_k=50, top_p=0.95, seed=11).cpu()
+    c = llm.generate(inputs_embeds=x, max_new_tokens=32, do_sample=True, temperature=0.9, top_k=50, top_p=0.95, seed=12).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, greedy)
+    k1 = llm.generate(inputs_embeds=x, max_new_tokens=32, do_sample=True, temperature=0.7, top_k=1, top_p=1.0, seed=5).cpu()
+    assert torch.equal(k1, greedy)
+    assert torch.equal(llm.generate(inputs_embeds=x, max_new_tokens=32).cpu(), greedy)      # the cached greedy graph is still the greedy one
