@@ -59,6 +59,8 @@ static void env_load() {
   e.attn_qt = env_int("SL_ATTN_QT", 0);
   e.norm_single_row = env_int("SL_NORM_SINGLE_ROW", 0);
   e.stream_splits = e.stream_nwv = e.stream_mt = 0;
+  e.stream_nl = env_int("SL_STREAM_NL", 0);
+  e.stream_wide = env_int("SL_STREAM_WIDE", 1);
   const char* sc = getenv("SL_STREAM_CFG");
   if (sc && sc[0]) {
     int sp = 0, nwv = 0, mt = 0;

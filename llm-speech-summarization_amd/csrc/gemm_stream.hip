@@ -119,15 +119,14 @@ __device__ __forceinline__ void stream_finish(const GemmP& p, const SkinnyX& sx,
   }
 }
 
-template <typename T, int MT, int ACT, int RF, int NWV, int D>
-__global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_kernel(GemmP p, SkinnyX sx, StreamX s) {
+template <typename T, int MT, int ACT, int RF, int NWV, int D, int NL, bool FUSE>
+__global__ __launch_bounds__(64 * (NWV + NL)) void gemm_stream_kernel(GemmP p, SkinnyX sx, StreamX s) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int KSTEP = MMA<T>::KSTEP;
   constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
   static_assert(!PAIRS || RF % 2 == 0, "pair epilogues need an even number of fragments");
-  static_assert(MT <= 16, "two loader waves stage at most 256 rows");
-  constexpr int NL = MT > 8 ? 2 : 1;          // loader waves: each stages up to 128 rows
-  constexpr int MTL = MT / NL;                // row tiles per loader
+  static_assert(MT % NL == 0 && MT / NL <= 8, "a loader wave stages at most 128 rows");
+  constexpr int MTL = MT / NL;                // row tiles per loader wave (NL of them: one wave's LDS-DMA stream tops out at ~25 GB/s)
   constexpr int SLAB = MT * 16 * TROWB;       // bytes of one x slab
   constexpr int NXL = 2 * MTL;                // 16-byte x chunks per loader lane per stage
   constexpr int NSLOT = 3;                    // LDS slabs: one being read, two being filled
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
   const int g_lo = sp * s.sps;
   const int g_hi = min(nks >> 1, g_lo + s.sps);
   const int per = g_hi - g_lo;
-  const int n_it = (per + D - 1) / D * D;     // whole ring turns: the extra iterations re-read the last stage, no MFMAs
+  const int n_it = per;                       // stages (= barriers) of this block; the ring's last partial turn is peeled
   const int g_last = g_hi - 1;
 
   f32x4 acc[RF][MT];
@@ -161,7 +160,8 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int f = 0; f < RF; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool fuse = sx.fuse_rms != 0 && sx.rstd_in == nullptr;   // statistics taken here unless the producer of A supplied them
+  constexpr bool fuse = FUSE;   // RMSNorm statistics taken here (sx.fuse_rms without sx.rstd_in: the producer of A did not supply them);
+                                // compile-time so that the main loop stays one basic block for the issue-order directives
 
   if (wave >= NWV) {
     // ---- x loader.  Its vmcnt queue holds only x loads: a wave that also streamed weights would, waiting for an
@@ -170,12 +170,12 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
     // The slabs go global -> LDS by LDS-DMA (no staging VGPRs, no ds_write pass: a single wave moving 16 KiB per stage
     // through registers was the critical path at ~0.5 us per stage); three LDS slots keep two stages of DMA in flight.
     const T* A = (const T*)p.A;
-    const int lw = wave - NWV;                        // loader index: rows [128 lw, 128 lw + 128) of the block
+    const int lw = wave - NWV;                        // loader index: rows [16 MTL lw, 16 MTL (lw + 1)) of the block
     const int ch = (lane & 7) ^ ((lane >> 3) & 7);   // LDS chunk c = lane + 64 i: row (lane >> 3) + 8 i, logical chunk ch
     const T* gx[NXL];
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      int xr_ = m0 + lw * 128 + (lane >> 3) + 8 * i; xr_ = xr_ < p.M ? xr_ : p.M - 1;
+      int xr_ = m0 + lw * (MTL * 16) + (lane >> 3) + 8 * i; xr_ = xr_ < p.M ? xr_ : p.M - 1;
       gx[i] = A + (int64_t)xr_ * p.lda + ch * VEC;
     }
     unsigned char* lbase = smem + lw * (MTL * 16 * TROWB);
@@ -218,52 +218,81 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
         for (int f = 0; f < RF; ++f) wr[d][s2][f] = ld_nt16(wp[f] + (int64_t)(stg * 2 + s2) * (64 * VEC));
     }
     __syncthreads();
-    for (int it0 = 0; it0 < n_it; it0 += D) {
+    // One wave per SIMD: nothing else hides the LDS latency, so the activation fragments of the NEXT k-step are requested
+    // before the MFMAs of the current one (two register sets).  The stage's barrier sits between its two k-steps: by then this
+    // wave's reads of the slab are complete (so the loader may refill it one barrier later) and the next slab has landed, whose
+    // first fragments are requested right behind the barrier, under the second k-step's MFMAs.  (Requesting each k-step's
+    // fragments just ahead of its own MFMAs left the matrix core idle for the LDS round trip twice per stage: 0.31 of the
+    // kernel's cycles in MFMAs at 512 rows, PMC in profiles/.)
+    uint4 fx[2][MT], fsx[2][NSS];
+    auto rd_x = [&](int it, int s2, int set) {
+      const unsigned char* sl_ = smem + (it % NSLOT) * SLAB;
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const int it = it0 + d;
-        if (g_lo + it < g_hi) {
-          const unsigned char* sl_ = smem + (it % NSLOT) * SLAB;
-          // the MT activation fragments of a k-step are requested together, ahead of its MFMAs (left alone, the
-          // scheduler pairs each ds_read with its two MFMAs and exposes the LDS latency 2*MT times per stage)
+      for (int t = 0; t < MT; ++t) fx[set][t] = *(const uint4*)(sl_ + lds_off(t * 16 + r, s2 * 4 + q));
+      // fused-RMSNorm statistics on the matrix core: diag(X_t X_t^T) = the row sums of squares of row tile t.  Wave w owns
+      // tiles w, w + NWV, ...; it re-reads them from LDS at a wave-dependent address (selecting among the fx registers
+      // instead needs per-wave branches, which made the compiler shuttle the accumulators between AGPRs and VGPRs: +40 %)
+      if constexpr (FUSE) {
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            uint4 fx[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) fx[t] = *(const uint4*)(sl_ + lds_off(t * 16 + r, s2 * 4 + q));
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-              for (int f = 0; f < RF; ++f) MMA<T>::step(acc[f][t], wr[d][s2][f], fx[t]);
-            if constexpr (sizeof(T) == 2) {
-              __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);       // DS reads
-              __builtin_amdgcn_sched_group_barrier(0x008, MT * RF, 0);  // MFMAs
-            }
-            // fused-RMSNorm statistics on the matrix core: diag(X_t X_t^T) = the row sums of squares of row tile t.
-            // Wave w owns tiles w, w + NWV, ...; it re-reads them from LDS at a wave-dependent address (selecting
-            // among the fx registers instead needs per-wave branches, which made the compiler shuttle the
-            // accumulators between AGPRs and VGPRs around every group: +40 % kernel time)
-            if (fuse) {
-#pragma unroll
-              for (int j = 0; j < NSS; ++j) {
-                const int t = (j * NWV + wn) < MT ? (j * NWV + wn) : MT - 1;
-                const uint4 fs = *(const uint4*)(sl_ + lds_off(t * 16 + r, s2 * 4 + q));
-                MMA<T>::step(ssacc[j], fs, fs);
-              }
-            }
-          }
+        for (int j = 0; j < NSS; ++j) {
+          const int t = (j * NWV + wn) < MT ? (j * NWV + wn) : MT - 1;
+          fsx[set][j] = *(const uint4*)(sl_ + lds_off(t * 16 + r, s2 * 4 + q));
         }
-        {
-          int stg = g_lo + it + D; stg = stg < g_last ? stg : g_last;
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int f = 0; f < RF; ++f) wr[d][s2][f] = ld_nt16(wp[f] + (int64_t)(stg * 2 + s2) * (64 * VEC));
-        }
-        __syncthreads();
       }
+    };
+    auto mma_x = [&](int d, int s2, int set) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int f = 0; f < RF; ++f) MMA<T>::step(acc[f][t], wr[d][s2][f], fx[set][t]);
+      if constexpr (FUSE) {
+#pragma unroll
+        for (int j = 0; j < NSS; ++j) MMA<T>::step(ssacc[j], fsx[set][j], fsx[set][j]);
+      }
+    };
+    // issue order inside a k-step: RF MFMAs, one fragment read, RF MFMAs, ... — the four waves' ds_read_b128 bursts no longer
+    // collide on the LDS port with the matrix core idle behind them (in-order issue: 8 reads x 4 waves queued ~130 cycles)
+    auto order = [&]() {
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, RF, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (FUSE) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NSS, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, NSS, 0);
+        }
+      }
+    };
+    auto stage = [&](const int d, const int it) {
+      __builtin_amdgcn_sched_barrier(0);
+      rd_x(it, 1, 1);
+      mma_x(d, 0, 0);
+      order();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done with slab `it`
+      __builtin_amdgcn_s_barrier();
+      rd_x(it + 1, 0, 0);
+      mma_x(d, 1, 1);
+      order();
+      __builtin_amdgcn_sched_barrier(0);
+      int stg = g_lo + it + D; stg = stg < g_last ? stg : g_last;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int f = 0; f < RF; ++f) wr[d][s2][f] = ld_nt16(wp[f] + (int64_t)(stg * 2 + s2) * (64 * VEC));
+    };
+    rd_x(0, 0, 0);
+    const int n_full = n_it / D * D;
+    for (int it0 = 0; it0 < n_full; it0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) stage(d, it0 + d);
     }
-    if (fuse) {   // lane (c = r, q) holds D[4q + i][c]: the diagonal element of row r sits in lane q == r >> 2, i = r & 3
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (n_full + d < n_it) stage(d, n_full + d);
+    if constexpr (FUSE) {   // lane (c = r, q) holds D[4q + i][c]: the diagonal element of row r sits in lane q == r >> 2, i = r & 3
 #pragma unroll
       for (int j = 0; j < NSS; ++j) {
         const int t = j * NWV + wn;
@@ -281,6 +310,133 @@ __global__ __launch_bounds__(64 * (NWV + (MT > 8 ? 2 : 1))) void gemm_stream_ker
     if (fuse) ssum[t] = ssl[t * 16 + r];
   }
   stream_finish<T, MT, ACT, RF>(p, sx, s, acc, ssum, fuse, m0, sp, fi0, nfrag, nb == 0 && wn == 0, q, r);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Wide form for >= 385 rows: 256 x rows x 128 weight rows per block, 8 compute waves (4 x 2: 64 rows x 4 fragments each) and
+// 4 loader waves; x AND the packed weight fragments go global -> LDS by LDS-DMA (a fragment k-step is 1 KiB in MFMA operand
+// order, so its LDS image is read back lane-contiguous, conflict-free), three 48 KiB slots.
+// Why (tools/ko_gateup.py knock-outs with in-kernel cycle stamps, profiles/r02_ko_gateup.txt): at 512 rows the 128 x 128
+// block's main loop is bound by what a CU can pull from L2, ~31 B/clk (~17 TB/s chip-wide, the rate of reads of lines that
+// every workgroup shares): 32 KiB per stage take ~1030 cycles with every CU streaming, whatever the loader-wave count, ring
+// depth or memory level behind L2, against 528 cycles of MFMAs.  The 256 x 128 block moves 24 KiB per such stage of MFMAs;
+// one block per CU (gate/up at 512 rows = 256 blocks) also pays the prologue / epilogue once instead of twice.
+// ----------------------------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(768) void gemm_stream_wide_kernel(GemmP p, SkinnyX sx, StreamX s) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int KSTEP = MMA<T>::KSTEP;
+  constexpr int CW = 8;                       // compute waves; waves 8..11 are the four loaders
+  constexpr int MTW = 4, RFW = 4;             // row tiles and weight fragments per compute wave
+  constexpr int BM = 256, BF = 8;             // block: x rows, weight fragments
+  constexpr int SLAB_X = BM * TROWB, SLAB_W = BF * 2 * 1024, SLOT = SLAB_X + SLAB_W;
+  constexpr int NSLOT = 3;
+  constexpr int NDMA = 12;                    // LDS-DMA instructions per loader wave per stage: 8 of x (64 rows), 4 of W (2 fragments)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int mblocks = (p.M + BM - 1) / BM;
+  const int nfrag = (p.N + 15) >> 4;
+  const int xj = blockIdx.x >> 3, nb = (xj / mblocks) * 8 + (blockIdx.x & 7);   // row blocks of one n-block share an XCD (its L2)
+  if (nb * BF >= nfrag) return;
+  const int m0 = (xj % mblocks) * BM;
+  const int sp = blockIdx.z;
+  const int nks = p.K / KSTEP;
+  const int g_lo = sp * s.sps;
+  const int g_hi = min(nks >> 1, g_lo + s.sps);
+  const int n_it = g_hi - g_lo;
+  const int g_last = g_hi - 1;
+
+  if (wave >= CW) {
+    const int lw = wave - CW;
+    const T* A = (const T*)p.A;
+    const T* W = (const T*)p.W;
+    const int ch = (lane & 7) ^ ((lane >> 3) & 7);
+    const T* gx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int xr_ = m0 + lw * 64 + (lane >> 3) + 8 * i; xr_ = xr_ < p.M ? xr_ : p.M - 1;
+      gx[i] = A + (int64_t)xr_ * p.lda + ch * VEC;
+    }
+    const T* gw[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      int fi = nb * BF + lw * 2 + f; fi = fi < nfrag ? fi : nfrag - 1;
+      gw[f] = W + (int64_t)fi * nks * (64 * VEC) + lane * VEC;
+    }
+    unsigned char* xbase = smem + lw * (64 * TROWB);
+    unsigned char* wbase = smem + SLAB_X + lw * (2 * 2 * 1024);
+    auto dma = [&](int it) {
+      int stg = g_lo + it; stg = stg < g_last ? stg : g_last;
+      const int so = (it % NSLOT) * SLOT;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gx[i] + (int64_t)stg * (2 * KSTEP)), (lds_ptr_t)(xbase + so + i * 1024), 16, 0, 0);
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(gw[f] + (int64_t)(stg * 2 + s2) * (64 * VEC)), (lds_ptr_t)(wbase + so + (f * 2 + s2) * 1024), 16, 0, 0);
+    };
+    dma(0);
+    dma(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < n_it; ++it) {
+      dma(it + 2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // stage it+1 has landed
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4 acc[RFW][MTW];
+#pragma unroll
+  for (int t = 0; t < MTW; ++t)
+#pragma unroll
+    for (int f = 0; f < RFW; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 fx[2][MTW], fw[2][RFW];
+  auto rd = [&](int it, int s2, int set) {
+    const unsigned char* sl_ = smem + (it % NSLOT) * SLOT;
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) fx[set][t] = *(const uint4*)(sl_ + lds_off(wm * 64 + t * 16 + r, s2 * 4 + q));
+#pragma unroll
+    for (int f = 0; f < RFW; ++f) fw[set][f] = *(const uint4*)(sl_ + SLAB_X + ((wn * RFW + f) * 2 + s2) * 1024 + lane * 16);
+  };
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int t = 0; t < MTW; ++t)
+#pragma unroll
+      for (int f = 0; f < RFW; ++f) MMA<T>::step(acc[f][t], fw[set][f], fx[set][t]);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int i = 0; i < MTW + RFW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  };
+  __builtin_amdgcn_s_barrier();   // slab 0 has landed
+  rd(0, 0, 0);
+  for (int it = 0; it < n_it; ++it) {
+    __builtin_amdgcn_sched_barrier(0);
+    rd(it, 1, 1);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done with slab `it`
+    __builtin_amdgcn_s_barrier();
+    rd(it + 1, 0, 0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float ssum[MTW];
+#pragma unroll
+  for (int t = 0; t < MTW; ++t) ssum[t] = 0.f;
+  stream_finish<T, MTW, ACT, RFW>(p, sx, s, acc, ssum, false, m0 + wm * 64, sp, nb * BF + wn * RFW, nfrag, false, q, r);
 }
 
 // sums the K-split partials and applies the epilogue: one thread per (row, fragment or fragment pair, 4-column group).
@@ -358,7 +514,7 @@ __global__ __launch_bounds__(ROWSTAT ? 1024 : 256) void gemm_stream_reduce_kerne
 // ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
-struct StreamCfg { int mt, splits, nwv, d; };
+struct StreamCfg { int mt, splits, nwv, d, nl; };
 
 // Measured on MI355X (tools/tune_stream.py, bf16, M = 64..256): one CU pulls at most ~23 GB/s from HBM (plus the x
 // slabs it re-reads from L2 through the same miss queue) whatever the prefetch depth, so the only lever is how many
@@ -373,6 +529,7 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
   const int nfrag = (N + 15) / 16;
   const int nst = K / (2 * kstep);
   c.d = 4;
+  c.nl = sl_env().stream_nl ? sl_env().stream_nl : 1;
   // tuning override "splits,nwv[,mt]" (tools/tune_stream.py), read once into sl_env()
   const int sp_env = sl_env().stream_splits, nwv_env = sl_env().stream_nwv;
   if (sl_env().stream_mt && M > 64) c.mt = sl_env().stream_mt;
@@ -404,12 +561,15 @@ size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype) {
   return splits * ((size_t)M * np + (size_t)M) * sizeof(float) + 256;
 }
 
-template <typename T, int MT, int ACT, int RF, int NWV, int D>
+template <typename T, int MT, int ACT, int RF, int NWV, int D, int NL>
 static int launch_stream_cfg(GemmP& p, const SkinnyX& sx, const StreamX& s, hipStream_t st) {
   const int nfrag = (p.N + 15) / 16;
   const int nblocks = (nfrag + NWV * RF - 1) / (NWV * RF), mblocks = (p.M + MT * 16 - 1) / (MT * 16);
   dim3 grid((nblocks + 7) / 8 * 8 * mblocks, 1, s.splits);
-  hipLaunchKernelGGL((gemm_stream_kernel<T, MT, ACT, RF, NWV, D>), grid, dim3(64 * (NWV + (MT > 8 ? 2 : 1))), 0, st, p, sx, s);
+  if (sx.fuse_rms != 0 && sx.rstd_in == nullptr)
+    hipLaunchKernelGGL((gemm_stream_kernel<T, MT, ACT, RF, NWV, D, NL, true>), grid, dim3(64 * (NWV + NL)), 0, st, p, sx, s);
+  else
+    hipLaunchKernelGGL((gemm_stream_kernel<T, MT, ACT, RF, NWV, D, NL, false>), grid, dim3(64 * (NWV + NL)), 0, st, p, sx, s);
   SL_CHECK_LAUNCH("gemm_stream");
   if (s.splits > 1) {
     constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
@@ -431,13 +591,18 @@ static int launch_stream_cfg(GemmP& p, const SkinnyX& sx, const StreamX& s, hipS
 template <typename T, int MT, int ACT>
 static int launch_stream_mt(GemmP& p, const SkinnyX& sx, const StreamX& s, const StreamCfg& c, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
-    return launch_stream_cfg<T, MT, ACT, 2, 4, 2>(p, sx, s, st);   // fp32 parity mode: one structure
+    return launch_stream_cfg<T, MT, ACT, 2, (MT > 8 ? 2 : 4), 2, (MT > 8 ? 2 : 1)>(p, sx, s, st);   // fp32 parity mode: one structure
   } else {
     if constexpr (MT > 8) {
-      return launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st);   // 256-row blocks: 4 compute + 2 loader waves would spill
+      return launch_stream_cfg<T, MT, ACT, 2, 2, 4, 2>(p, sx, s, st);   // 256-row blocks: 4 compute + 2 loader waves would spill
+    } else if constexpr (MT == 8) {
+      if (c.nwv == 2) return launch_stream_cfg<T, MT, ACT, 2, 2, 4, 1>(p, sx, s, st);
+      if (c.nl == 4) return launch_stream_cfg<T, MT, ACT, 2, 4, 4, 4>(p, sx, s, st);
+      if (c.nl == 2) return launch_stream_cfg<T, MT, ACT, 2, 4, 4, 2>(p, sx, s, st);
+      return launch_stream_cfg<T, MT, ACT, 2, 4, 4, 1>(p, sx, s, st);
     } else {
-      if (c.nwv == 2) return launch_stream_cfg<T, MT, ACT, 2, 2, 4>(p, sx, s, st);
-      return launch_stream_cfg<T, MT, ACT, 2, 4, 4>(p, sx, s, st);
+      if (c.nwv == 2) return launch_stream_cfg<T, MT, ACT, 2, 2, 4, 1>(p, sx, s, st);
+      return launch_stream_cfg<T, MT, ACT, 2, 4, 4, 1>(p, sx, s, st);
     }
   }
 }
@@ -463,6 +628,33 @@ static int stream_typed(GemmP& p, const SkinnyX& sx, int act, const StreamX& s, 
   return SL_ERR_UNSUPPORTED;
 }
 
+// the 256 x 128 form: bf16, > 384 rows, unsplit, row scales (if any) supplied by the producer, enough blocks to cover the CUs
+static bool stream_wide_ok(const GemmP& p, const SkinnyX& sx, int act, const StreamX& s) {
+  if (sl_env().stream_wide == 0) return false;
+  if (p.M <= 384 || s.splits != 1 || (sx.fuse_rms != 0 && sx.rstd_in == nullptr) || sx.rstd_out != nullptr) return false;
+  if (act != SL_ACT_NONE && act != SL_ACT_SILU_MUL) return false;
+  const int nfrag = (p.N + 15) / 16, mblocks = (p.M + 255) / 256;
+  return sl_env().stream_wide == 2 || mblocks * ((nfrag + 7) / 8) >= 200;
+}
+
+static int launch_stream_wide(GemmP& p, const SkinnyX& sx, int act, const StreamX& s, hipStream_t st) {
+  const int nfrag = (p.N + 15) / 16, mblocks = (p.M + 255) / 256, nblocks = (nfrag + 7) / 8;
+  constexpr int LDS_BYTES = 3 * (256 * TROWB + 8 * 2 * 1024);
+  dim3 grid((nblocks + 7) / 8 * 8 * mblocks, 1, 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SL_HIP(hipFuncSetAttribute((const void*)gemm_stream_wide_kernel<bf16_t, SL_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    SL_HIP(hipFuncSetAttribute((const void*)gemm_stream_wide_kernel<bf16_t, SL_ACT_SILU_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  if (act == SL_ACT_SILU_MUL)
+    hipLaunchKernelGGL((gemm_stream_wide_kernel<bf16_t, SL_ACT_SILU_MUL>), grid, dim3(768), LDS_BYTES, st, p, sx, s);
+  else
+    hipLaunchKernelGGL((gemm_stream_wide_kernel<bf16_t, SL_ACT_NONE>), grid, dim3(768), LDS_BYTES, st, p, sx, s);
+  SL_CHECK_LAUNCH("gemm_stream_wide");
+  return 0;
+}
+
 int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void* split_ws, size_t split_ws_bytes, hipStream_t st) {
   const int kstep = dtype == SL_F32 ? 16 : 32;
   SL_CHECK_ARG(p.K % (2 * kstep) == 0, "sl_gemm: streaming path needs K %% %d == 0 (K=%d)", 2 * kstep, p.K);
@@ -484,5 +676,6 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
   s.part = (float*)split_ws;
   s.part_ss = s.part ? s.part + (size_t)s.splits * p.M * s.np : nullptr;
   if (dtype == SL_F32) return stream_typed<float>(p, sx, act, s, c, st);
+  if (stream_wide_ok(p, sx, act, s)) return launch_stream_wide(p, sx, act, s, st);
   return stream_typed<bf16_t>(p, sx, act, s, c, st);
 }

@@ -421,6 +421,41 @@ def test_gemm_packed_many_rows_wide_matrix(M):
     assert rel_err(out2.float().cpu(), xf @ q(W, dt).T + q(R, dt)) < TOL[dt]
 
 
+@pytest.mark.parametrize("M", [385, 512, 700])
+@pytest.mark.parametrize("H", [512, 448])
+def test_gemm_packed_wide_block_form(M, H, monkeypatch):
+    """The 256 x 128 streaming block (gemm_stream_wide_kernel: x and packed weight fragments through LDS-DMA, 8 compute + 4
+    loader waves) on shapes the default rule would leave to the 128 x 128 form: ragged last row block, a fragment count that is
+    not a multiple of 8, an odd number of 128-byte K stages (H = 448), SILU pairs with handed-over row scales, bias-free
+    residual epilogue, fp32 output.  Same tolerance as the other bf16 GEMM tests; equal to the 128 x 128 form within rounding."""
+    dt = torch.bfloat16
+    Fd = 4608
+    x = rnd(M, H, seed=61)
+    g, u = rnd(Fd, H, seed=62, std=H ** -0.5), rnd(Fd, H, seed=63, std=H ** -0.5)
+    xd, xf = x.to(dev(), dt), q(x, dt)
+    rstd = torch.rsqrt(xf.pow(2).mean(-1) + 1e-5)
+    wgu = ops.pack_weight(weights.interleave_gate_up(g, u).to(dev(), dt))
+    W = rnd(8200, H, seed=64, std=H ** -0.5)
+    Wp = ops.pack_weight(W.to(dev(), dt))
+    R = rnd(M, 8200, seed=65)
+    outs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("SL_STREAM_WIDE", mode)
+        L.lib().sl_tuning_reload()
+        a = ops.gemm_decode(xd, wgu, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, rstd_in=rstd.to(dev()), split_k=False)
+        b = ops.gemm_decode(xd, Wp, 8200, residual=R.to(dev(), dt), split_k=False)
+        c = ops.gemm_decode(xd, Wp, 8200, out_f32=True, split_k=False)
+        outs[mode] = (a.float().cpu(), b.float().cpu(), c.cpu())
+    monkeypatch.delenv("SL_STREAM_WIDE")
+    L.lib().sl_tuning_reload()
+    ref_a = F.silu((xf * rstd[:, None]) @ q(g, dt).T) * ((xf * rstd[:, None]) @ q(u, dt).T)
+    ref_b = xf @ q(W, dt).T + q(R, dt)
+    for mode in ("0", "2"):
+        assert rel_err(outs[mode][0], ref_a) < TOL[dt] and rel_err(outs[mode][1], ref_b) < TOL[dt]
+        assert rel_err(outs[mode][2], xf @ q(W, dt).T) < 2e-5
+    assert rel_err(outs["2"][2], outs["0"][2]) < 1e-6      # same k order per output element in both forms
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [40, 128])
 def test_gemm_packed_rstd_handoff(dt, M):

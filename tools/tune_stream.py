@@ -8,18 +8,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("llm-speech-summarization_amd.ops")
 L = importlib.import_module("llm-speech-summarization_amd._lib")
 dev = "cuda:0"
-NBUF = 6
+NBUF = int(os.environ.get("TUNE_NBUF", "6"))
 shapes = [("qkv", 5120, 3072), ("o", 3072, 3072), ("gateup", 16384, 3072), ("down", 3072, 8192), ("lm_head", 128256, 3072)]
 Ms = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [128]
 cfgs = sys.argv[2].split(";") if len(sys.argv) > 2 else ["default"]
+PAD = int(os.environ.get("TUNE_LDA_PAD", "0"))
 os.environ["SL_STREAM_MIN_M"] = os.environ.get("SL_STREAM_MIN_M", "16")
 L.lib().sl_tuning_reload()   # the library reads its tuning switches once; re-read after changing them
 for name, N, K in shapes:
-    nb = 2 if name == "lm_head" else NBUF
+    nb = min(2, NBUF) if name == "lm_head" else NBUF
     Wr = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(nb)]
     Ws = [ops.pack_weight(w) for w in Wr]
     for M in Ms:
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        if PAD:   # padded row stride: spreads the rows of one k-stage over the L2 channels
+            big = torch.zeros(M, K + PAD, device=dev, dtype=torch.bfloat16)
+            big[:, :K] = A
+            A = big[:, :K]
         act = L.ACT_SILU_MUL if name == "gateup" else L.ACT_NONE
         ref = A.float() @ Wr[0].float().T
         if name == "gateup":   # rows interleaved in 16-row gate/up blocks
