@@ -514,14 +514,14 @@ __global__ __launch_bounds__(ROWSTAT ? 1024 : 256) void gemm_stream_reduce_kerne
 // ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
-struct StreamCfg { int mt, splits, nwv, d, nl; };
+struct StreamCfg { int mt, splits, nwv, d, nl; int wide, wsplits; };   // wide: the 256 x 128 form applies (its own K-split count)
 
 // Measured on MI355X (tools/tune_stream.py, bf16, M = 64..256): one CU pulls at most ~23 GB/s from HBM (plus the x
 // slabs it re-reads from L2 through the same miss queue) whatever the prefetch depth, so the only lever is how many
 // CUs stream.  Wide matrices (>= 512 blocks of 128 weight rows: lm_head) use 4 compute waves x 32 rows; the layer
 // projections use 2 compute waves x 32 rows (64-row blocks) and split K until ~200 blocks exist — beyond that the
 // fp32 partials (written, then re-read by the reduce kernel) cost more than the extra CUs bring.
-static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
+static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws, int dtype) {
   StreamCfg c;
   // above 128 rows: 128-row blocks x 4 compute waves (128 weight rows): the row blocks of an n-block re-read its weights
   // from L2, and each CU stages half the activation bytes of a 256-row block (measured at M = 256: gate/up 38 vs 50 us)
@@ -547,18 +547,56 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws) {
   }
   if (sp_env && (have_ws || sp_env == 1)) splits = sp_env < nst ? sp_env : nst;
   c.splits = splits;
+  // the 256 x 128 form (bf16, > 384 rows): unsplit when its blocks cover the CUs, else K split towards ~240 blocks of >= 6 stages
+  c.wide = 0; c.wsplits = 1;
+  if (dtype == SL_BF16 && M > 384 && sl_env().stream_wide != 0) {
+    const int wbase = ((M + 255) / 256) * ((nfrag + 7) / 8);
+    if (wbase >= 200 || sl_env().stream_wide == 2) {
+      c.wide = 1;
+    }
+    if (wbase < 200 && have_ws) {
+      int ws_ = 240 / wbase;
+      const int max_ws = nst / 6 > 0 ? nst / 6 : 1;
+      if (ws_ > max_ws) ws_ = max_ws;
+      if (ws_ > 8) ws_ = 8;
+      if (sl_env().stream_wsplits) ws_ = sl_env().stream_wsplits < nst ? sl_env().stream_wsplits : nst;
+      if (ws_ > 1) { c.wide = 1; c.wsplits = ws_; }
+    }
+  }
   return c;
 }
 
 int sl_gemm_stream_splits(int M, int N, int K, int dtype) {
-  return stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true).splits;
+  const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
+  return c.wide ? c.wsplits : c.splits;
 }
 
 size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype) {
   const size_t np = (size_t)((N + 15) / 16) * 16;
-  const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true);
-  size_t splits = c.splits > 1 ? (size_t)c.splits : 0;
+  const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
+  const int most = c.wide && c.wsplits > c.splits ? c.wsplits : c.splits;   // either form may run (the wide one not when the kernel takes the RMSNorm statistics itself)
+  size_t splits = most > 1 ? (size_t)most : 0;
   return splits * ((size_t)M * np + (size_t)M) * sizeof(float) + 256;
+}
+
+// second pass of a K-split launch: sums the partial records and applies the epilogue
+template <typename T, int ACT>
+static int launch_stream_reduce(GemmP& p, const SkinnyX& sx, const StreamX& s, hipStream_t st) {
+  if (s.splits <= 1) return 0;
+  constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
+  const int nfrag = (p.N + 15) / 16;
+  const int64_t nunits = PAIRS ? (nfrag + 1) / 2 : nfrag;
+  const int64_t threads = (int64_t)p.M * nunits * 4;
+  if constexpr (ACT == SL_ACT_NONE) {
+    if (sx.rstd_out) {   // checked by the caller: 4 * fragments <= 1024
+      hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT, true>), dim3(p.M), dim3((unsigned)((nunits * 4 + 63) / 64 * 64)), 0, st, p, sx, s);
+      SL_CHECK_LAUNCH("gemm_stream_reduce(rowstat)");
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, sx, s);
+  SL_CHECK_LAUNCH("gemm_stream_reduce");
+  return 0;
 }
 
 template <typename T, int MT, int ACT, int RF, int NWV, int D, int NL>
@@ -571,21 +609,7 @@ static int launch_stream_cfg(GemmP& p, const SkinnyX& sx, const StreamX& s, hipS
   else
     hipLaunchKernelGGL((gemm_stream_kernel<T, MT, ACT, RF, NWV, D, NL, false>), grid, dim3(64 * (NWV + NL)), 0, st, p, sx, s);
   SL_CHECK_LAUNCH("gemm_stream");
-  if (s.splits > 1) {
-    constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
-    const int64_t nunits = PAIRS ? (nfrag + 1) / 2 : nfrag;
-    const int64_t threads = (int64_t)p.M * nunits * 4;
-    if constexpr (ACT == SL_ACT_NONE) {
-      if (sx.rstd_out) {   // checked by the caller: 4 * fragments <= 1024
-        hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT, true>), dim3(p.M), dim3((unsigned)((nunits * 4 + 63) / 64 * 64)), 0, st, p, sx, s);
-        SL_CHECK_LAUNCH("gemm_stream_reduce(rowstat)");
-        return 0;
-      }
-    }
-    hipLaunchKernelGGL((gemm_stream_reduce_kernel<T, ACT, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, sx, s);
-    SL_CHECK_LAUNCH("gemm_stream_reduce");
-  }
-  return 0;
+  return launch_stream_reduce<T, ACT>(p, sx, s, st);
 }
 
 template <typename T, int MT, int ACT>
@@ -628,38 +652,44 @@ static int stream_typed(GemmP& p, const SkinnyX& sx, int act, const StreamX& s, 
   return SL_ERR_UNSUPPORTED;
 }
 
-// the 256 x 128 form: bf16, > 384 rows, unsplit, row scales (if any) supplied by the producer, enough blocks to cover the CUs
-static bool stream_wide_ok(const GemmP& p, const SkinnyX& sx, int act, const StreamX& s) {
-  if (sl_env().stream_wide == 0) return false;
-  if (p.M <= 384 || s.splits != 1 || (sx.fuse_rms != 0 && sx.rstd_in == nullptr) || sx.rstd_out != nullptr) return false;
-  if (act != SL_ACT_NONE && act != SL_ACT_SILU_MUL) return false;
-  const int nfrag = (p.N + 15) / 16, mblocks = (p.M + 255) / 256;
-  return sl_env().stream_wide == 2 || mblocks * ((nfrag + 7) / 8) >= 200;
+// the 256 x 128 form applies to this call: the shape qualifies (stream_cfg) and the kernel does not have to take the RMSNorm
+// statistics itself (row scales, if any, come from the producer)
+static bool stream_wide_ok(const SkinnyX& sx, int act, const StreamCfg& c, bool have_ws) {
+  if (!c.wide || (sx.fuse_rms != 0 && sx.rstd_in == nullptr)) return false;
+  if (act != SL_ACT_NONE && act != SL_ACT_SILU_MUL && act != SL_ACT_ROPE_KV) return false;
+  return c.wsplits == 1 || have_ws;
+}
+
+template <int ACT>
+static int launch_stream_wide_act(GemmP& p, const SkinnyX& sx, const StreamX& s, hipStream_t st) {
+  const int nfrag = (p.N + 15) / 16, mblocks = (p.M + 255) / 256, nblocks = (nfrag + 7) / 8;
+  constexpr int LDS_BYTES = 3 * (256 * TROWB + 8 * 2 * 1024);
+  dim3 grid((nblocks + 7) / 8 * 8 * mblocks, 1, s.splits);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SL_HIP(hipFuncSetAttribute((const void*)gemm_stream_wide_kernel<bf16_t, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_stream_wide_kernel<bf16_t, ACT>), grid, dim3(768), LDS_BYTES, st, p, sx, s);
+  SL_CHECK_LAUNCH("gemm_stream_wide");
+  return launch_stream_reduce<bf16_t, ACT>(p, sx, s, st);
 }
 
 static int launch_stream_wide(GemmP& p, const SkinnyX& sx, int act, const StreamX& s, hipStream_t st) {
-  const int nfrag = (p.N + 15) / 16, mblocks = (p.M + 255) / 256, nblocks = (nfrag + 7) / 8;
-  constexpr int LDS_BYTES = 3 * (256 * TROWB + 8 * 2 * 1024);
-  dim3 grid((nblocks + 7) / 8 * 8 * mblocks, 1, 1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SL_HIP(hipFuncSetAttribute((const void*)gemm_stream_wide_kernel<bf16_t, SL_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    SL_HIP(hipFuncSetAttribute((const void*)gemm_stream_wide_kernel<bf16_t, SL_ACT_SILU_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+  switch (act) {
+    case SL_ACT_SILU_MUL: return launch_stream_wide_act<SL_ACT_SILU_MUL>(p, sx, s, st);
+    case SL_ACT_ROPE_KV: return launch_stream_wide_act<SL_ACT_ROPE_KV>(p, sx, s, st);
+    default: return launch_stream_wide_act<SL_ACT_NONE>(p, sx, s, st);
   }
-  if (act == SL_ACT_SILU_MUL)
-    hipLaunchKernelGGL((gemm_stream_wide_kernel<bf16_t, SL_ACT_SILU_MUL>), grid, dim3(768), LDS_BYTES, st, p, sx, s);
-  else
-    hipLaunchKernelGGL((gemm_stream_wide_kernel<bf16_t, SL_ACT_NONE>), grid, dim3(768), LDS_BYTES, st, p, sx, s);
-  SL_CHECK_LAUNCH("gemm_stream_wide");
-  return 0;
 }
 
 int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void* split_ws, size_t split_ws_bytes, hipStream_t st) {
   const int kstep = dtype == SL_F32 ? 16 : 32;
   SL_CHECK_ARG(p.K % (2 * kstep) == 0, "sl_gemm: streaming path needs K %% %d == 0 (K=%d)", 2 * kstep, p.K);
-  StreamCfg c = stream_cfg(p.M, p.N, p.K, kstep, split_ws != nullptr);
+  StreamCfg c = stream_cfg(p.M, p.N, p.K, kstep, split_ws != nullptr, dtype);
   StreamX s;
+  const bool wide = stream_wide_ok(sx, act, c, split_ws != nullptr);
+  if (wide) c.splits = c.wsplits;
 
   s.np = (p.N + 15) / 16 * 16;
   const size_t per_split = ((size_t)p.M * s.np + (size_t)p.M) * sizeof(float);
@@ -676,6 +706,6 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
   s.part = (float*)split_ws;
   s.part_ss = s.part ? s.part + (size_t)s.splits * p.M * s.np : nullptr;
   if (dtype == SL_F32) return stream_typed<float>(p, sx, act, s, c, st);
-  if (stream_wide_ok(p, sx, act, s)) return launch_stream_wide(p, sx, act, s, st);
+  if (wide) return launch_stream_wide(p, sx, act, s, st);
   return stream_typed<bf16_t>(p, sx, act, s, c, st);
 }
