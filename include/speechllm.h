@@ -104,7 +104,10 @@ typedef struct {
   void* k_cache; void* v_cache;
   int32_t n_heads, n_kv_heads, max_ctx, reserved;
   /* optional scratch for K-split partial sums (M > 16 rows against few weight rows cannot fill 256 CUs
-   * otherwise): sl_gemm_split_workspace_bytes(M, N, K, dtype) bytes, or NULL to disable the split */
+   * otherwise): sl_gemm_split_workspace_bytes(M, N, K, dtype) bytes, or NULL to disable the split.
+   * Its first 8192 bytes are arrival counters for the optional in-kernel reduce (SL_STREAM_FIXUP=1: above 384 rows the
+   * block that finishes a tile last sums the partial records itself): zero them once when the buffer is created; every
+   * call leaves them zero again, in stream order.  One buffer per call chain — two streams must not share it. */
   void* split_ws; size_t split_ws_bytes;
   /* RMSNorm statistics handed from one GEMM to the next (streaming path only):
    *   rstd_out — with the plain epilogue and a K-split, the reduce kernel also writes, per output row,

@@ -62,6 +62,7 @@ static void env_load() {
   e.stream_nl = env_int("SL_STREAM_NL", 0);
   e.stream_wide = env_int("SL_STREAM_WIDE", 1);
   e.stream_wsplits = env_int("SL_STREAM_WSPLITS", 0);
+  e.stream_fixup = env_int("SL_STREAM_FIXUP", 0);
   const char* sc = getenv("SL_STREAM_CFG");
   if (sc && sc[0]) {
     int sp = 0, nwv = 0, mt = 0;

@@ -218,6 +218,7 @@ struct SlEnv {
   int stream_splits, stream_nwv, stream_mt;   // SL_STREAM_CFG "splits,nwv[,mt]" (0 = not set)
   int stream_wide;         // SL_STREAM_WIDE       0 = never use the 256 x 128 streaming block, 1 = default rule, 2 = whenever it applies
   int stream_wsplits;      // SL_STREAM_WSPLITS    K splits of the 256 x 128 form when its blocks do not cover the CUs (0 = rule)
+  int stream_fixup;        // SL_STREAM_FIXUP      1 = K splits of the 256 x 128 form are closed inside the kernel (default 0: reduce launch, faster)
   int stream_nl;           // SL_STREAM_NL         loader waves of the 128-row streaming GEMM blocks (0 = default)
 };
 const SlEnv& sl_env();

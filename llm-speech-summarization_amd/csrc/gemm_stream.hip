@@ -25,7 +25,27 @@ struct StreamX {
   float* part_ss;  // [splits][M] partial sums of squares (fused RMSNorm)
   int splits, sps; // K splits over blocks, 128-byte stages per split
   int np;          // row stride of `part` in floats (fragments * 16)
+  int* cnt;        // in-kernel K-split fix-up (wide form): [1024] tile arrival counters + [64] row-block counters, zero between launches
+  float* ss_part;  // [n-blocks][M] sums of squares of the stored rows per 128-column block (row statistics of the fix-up)
 };
+
+// Hand-off of partial records between workgroups inside one launch (K-split fix-up).  A release / acquire fence pair at agent
+// scope writes back and invalidates the XCD's whole L2 (measured: +80-95 us on a 30 us GEMM); instead every handed-off byte is
+// stored and loaded with sc1 (agent scope: through the non-coherent L2 to the memory side) and drained with s_waitcnt before /
+// after the arrival counter (MI355X_MICROARCH.md, Correctness boundaries, second valid form).
+__device__ __forceinline__ void st_sc1_16(float* ptr, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ld_sc1_16(f32x4& v, const float* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void vm_drain16(f32x4 (&v)[16]) {   // the 16 sc1 loads above have landed; ties the registers to the wait
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]),
+                 "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+               :
+               : "memory");
+}
 
 // final values for 4 consecutive output columns n4..n4+3 of fragment gf (pairs: gf = first fragment), row m
 template <typename T, int ACT>
@@ -89,7 +109,10 @@ __device__ __forceinline__ void stream_finish(const GemmP& p, const SkinnyX& sx,
       if (m >= p.M) continue;
 #pragma unroll
       for (int f = 0; f < RF; ++f)
-        if (fi0 + f < nfrag) *(f32x4*)(s.part + ((int64_t)sp * p.M + m) * s.np + (fi0 + f) * 16 + 4 * q) = acc[f][t];
+        if (fi0 + f < nfrag) {
+          float* dst = s.part + ((int64_t)sp * p.M + m) * s.np + (fi0 + f) * 16 + 4 * q;
+          if (s.cnt) st_sc1_16(dst, acc[f][t]); else *(f32x4*)dst = acc[f][t];   // s.cnt: another workgroup of this launch reads the record
+        }
       if (fuse && writes_ss && q == 0) s.part_ss[(int64_t)sp * p.M + m] = ssum[t];
     }
     return;
@@ -333,6 +356,8 @@ __global__ __launch_bounds__(768) void gemm_stream_wide_kernel(GemmP p, SkinnyX 
   constexpr int NSLOT = 3;
   constexpr int NDMA = 12;                    // LDS-DMA instructions per loader wave per stage: 8 of x (64 rows), 4 of W (2 fragments)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int fx_last[2];
+  __shared__ float fx_ss[4][2][64];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -341,13 +366,25 @@ __global__ __launch_bounds__(768) void gemm_stream_wide_kernel(GemmP p, SkinnyX 
   const int nfrag = (p.N + 15) >> 4;
   const int xj = blockIdx.x >> 3, nb = (xj / mblocks) * 8 + (blockIdx.x & 7);   // row blocks of one n-block share an XCD (its L2)
   if (nb * BF >= nfrag) return;
-  const int m0 = (xj % mblocks) * BM;
+  const int mblock = xj % mblocks;
+  const int m0 = mblock * BM;
   const int sp = blockIdx.z;
   const int nks = p.K / KSTEP;
   const int g_lo = sp * s.sps;
   const int g_hi = min(nks >> 1, g_lo + s.sps);
   const int n_it = g_hi - g_lo;
   const int g_last = g_hi - 1;
+  const int wm = (wave >> 1) & 3, wn = wave & 1;
+  const int mw = m0 + wm * 64, fi0 = nb * BF + wn * RFW;
+
+  f32x4 acc[RFW][MTW];
+  float ssum[MTW];
+#pragma unroll
+  for (int t = 0; t < MTW; ++t) {
+    ssum[t] = 0.f;
+#pragma unroll
+    for (int f = 0; f < RFW; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   if (wave >= CW) {
     const int lw = wave - CW;
@@ -390,53 +427,158 @@ __global__ __launch_bounds__(768) void gemm_stream_wide_kernel(GemmP p, SkinnyX 
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
+  } else {
+    uint4 fx[2][MTW], fw[2][RFW];
+    auto rd = [&](int it, int s2, int set) {
+      const unsigned char* sl_ = smem + (it % NSLOT) * SLOT;
+#pragma unroll
+      for (int t = 0; t < MTW; ++t) fx[set][t] = *(const uint4*)(sl_ + lds_off(wm * 64 + t * 16 + r, s2 * 4 + q));
+#pragma unroll
+      for (int f = 0; f < RFW; ++f) fw[set][f] = *(const uint4*)(sl_ + SLAB_X + ((wn * RFW + f) * 2 + s2) * 1024 + lane * 16);
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+      for (int t = 0; t < MTW; ++t)
+#pragma unroll
+        for (int f = 0; f < RFW; ++f) MMA<T>::step(acc[f][t], fw[set][f], fx[set][t]);
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < MTW + RFW; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+    };
+    __builtin_amdgcn_s_barrier();   // slab 0 has landed
+    rd(0, 0, 0);
+    for (int it = 0; it < n_it; ++it) {
+      __builtin_amdgcn_sched_barrier(0);
+      rd(it, 1, 1);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done with slab `it`
+      __builtin_amdgcn_s_barrier();
+      rd(it + 1, 0, 0);
+      mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stream_finish<T, MTW, ACT, RFW>(p, sx, s, acc, ssum, false, mw, sp, fi0, nfrag, false, q, r);
   }
+  if (!(s.splits > 1 && s.cnt)) return;
 
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x4 acc[RFW][MTW];
-#pragma unroll
-  for (int t = 0; t < MTW; ++t)
-#pragma unroll
-    for (int f = 0; f < RFW; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint4 fx[2][MTW], fw[2][RFW];
-  auto rd = [&](int it, int s2, int set) {
-    const unsigned char* sl_ = smem + (it % NSLOT) * SLOT;
-#pragma unroll
-    for (int t = 0; t < MTW; ++t) fx[set][t] = *(const uint4*)(sl_ + lds_off(wm * 64 + t * 16 + r, s2 * 4 + q));
-#pragma unroll
-    for (int f = 0; f < RFW; ++f) fw[set][f] = *(const uint4*)(sl_ + SLAB_X + ((wn * RFW + f) * 2 + s2) * 1024 + lane * 16);
-  };
-  auto mma = [&](int set) {
+  // ---- in-kernel fix-up of a K split, OFF by default (SL_STREAM_FIXUP=1 turns it on; all twelve waves walk the same barriers,
+  // the loaders do none of the work).  The block that arrives last at its tile's counter sums the S partial records — in split
+  // order, its own included: bit for bit the sum gemm_stream_reduce_kernel forms — and applies the epilogue.
+  // Measured at 512 rows (tools/tune_stream.py, bf16): with the separate reduce launch qkv / o / down take 31 / 26 / 40 us;
+  // closed in-kernel 49 / 47-52 / 65-69 us with sc1 hand-off, 111 / 121 / 136 us with agent-scope fences (those write back and
+  // invalidate the XCD's whole L2).  The partial records have to cross to the memory side either way, and the last block of
+  // each of 48-80 tiles then pulls S x 128 KiB through ONE CU's miss path behind an atomic round trip, where the reduce launch
+  // spreads the same bytes over every CU: on this chip the launch boundary is the cheaper synchronisation.  Kept as a tested
+  // option (tests/test_kernels_gpu.py: identical stores to the reduce pass) for shapes where the balance may differ.
+  const bool cw = wave < CW;
+  const int tile = nb * mblocks + mblock;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial-record stores (sc1) have reached the memory side
+  __builtin_amdgcn_s_barrier();
+  if (tid == 0) {
+    const int old = atomicAdd(&s.cnt[tile], 1);
+    fx_last[0] = old == s.splits - 1;
+    if (old == s.splits - 1) s.cnt[tile] = 0;   // every split has arrived: leave the counter as it was found
+  }
+  __builtin_amdgcn_s_barrier();
+  if (!fx_last[0]) return;
+  bool rowstat = false;
+  if constexpr (ACT == SL_ACT_NONE) rowstat = sx.rstd_out != nullptr;
+  if (cw) {
 #pragma unroll
     for (int t = 0; t < MTW; ++t)
 #pragma unroll
-      for (int f = 0; f < RFW; ++f) MMA<T>::step(acc[f][t], fw[set][f], fx[set][t]);
-    if constexpr (sizeof(T) == 2) {
+      for (int f = 0; f < RFW; ++f) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sp2 = 0; sp2 < s.splits; ++sp2) {
+      f32x4 v[MTW * RFW];
 #pragma unroll
-      for (int i = 0; i < MTW + RFW; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int t = 0; t < MTW; ++t) {
+        int m = mw + t * 16 + r; m = m < p.M ? m : p.M - 1;           // rows / fragments past the edge re-read the last one
+#pragma unroll
+        for (int f = 0; f < RFW; ++f) {
+          const int fi = fi0 + f < nfrag ? fi0 + f : nfrag - 1;
+          ld_sc1_16(v[t * RFW + f], s.part + ((int64_t)sp2 * p.M + m) * s.np + fi * 16 + 4 * q);
+        }
+      }
+      vm_drain16(v);
+#pragma unroll
+      for (int t = 0; t < MTW; ++t)
+#pragma unroll
+        for (int f = 0; f < RFW; ++f) acc[f][t] += v[t * RFW + f];
+    }
+    if (!rowstat) {
+      StreamX s1 = s;
+      s1.splits = 1;
+      stream_finish<T, MTW, ACT, RFW>(p, sx, s1, acc, ssum, false, mw, sp, fi0, nfrag, false, q, r);
+    }
+  }
+  if (!rowstat) return;
+  if constexpr (ACT == SL_ACT_NONE) {
+    if (cw) {
+      // plain (+bias, +residual) epilogue that keeps the stored values for the row statistics (as gemm_stream_reduce_kernel<ROWSTAT>)
+      const T* bias = (const T*)p.bias;
+#pragma unroll
+      for (int t = 0; t < MTW; ++t) {
+        const int m = mw + t * 16 + r;
+        float sq = 0.f;
+        if (m < p.M) {
+#pragma unroll
+          for (int f = 0; f < RFW; ++f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int col = (fi0 + f) * 16 + 4 * q + i;
+              if (col >= p.N) continue;
+              float v = acc[f][t][i];
+              if (bias) v += to_f32(bias[col]);
+              if (p.res) v += p.res_f32 ? ((const float*)p.res)[(int64_t)m * p.ldr + col] : to_f32(((const T*)p.res)[(int64_t)m * p.ldr + col]);
+              if (p.out_f32) {
+                ((float*)p.C)[(int64_t)m * p.ldc + col] = v;
+              } else {
+                const T o = from_f32<T>(v);
+                ((T*)p.C)[(int64_t)m * p.ldc + col] = o;
+                v = to_f32(o);
+              }
+              sq = fmaf(v, v, sq);
+            }
+          }
+        }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        if (q == 0) fx_ss[wm][wn][t * 16 + r] = sq;
       }
     }
-  };
-  __builtin_amdgcn_s_barrier();   // slab 0 has landed
-  rd(0, 0, 0);
-  for (int it = 0; it < n_it; ++it) {
-    __builtin_amdgcn_sched_barrier(0);
-    rd(it, 1, 1);
-    mma(0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done with slab `it`
+    // second level: this tile's per-row sums over its 128 columns -> ss_part; the block that completes a row block's last tile
+    // adds the n-block partials in n-block order (deterministic) and writes rstd_out for the 256 rows
+    const int nbv = (nfrag + BF - 1) / BF;
     __builtin_amdgcn_s_barrier();
-    rd(it + 1, 0, 0);
-    mma(1);
-    __builtin_amdgcn_sched_barrier(0);
+    if (tid < 256) {
+      const int m = m0 + tid;
+      if (m < p.M)
+        __hip_atomic_store(&s.ss_part[(int64_t)nb * p.M + m], fx_ss[tid >> 6][0][tid & 63] + fx_ss[tid >> 6][1][tid & 63], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) {
+      const int old = atomicAdd(&s.cnt[1024 + mblock], 1);
+      fx_last[1] = old == nbv - 1;
+      if (old == nbv - 1) s.cnt[1024 + mblock] = 0;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (!fx_last[1]) return;
+    if (tid < 256) {
+      const int m = m0 + tid;
+      if (m < p.M) {
+        float t = 0.f;
+        for (int j = 0; j < nbv; ++j) t += __hip_atomic_load(&s.ss_part[(int64_t)j * p.M + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sx.rstd_out[m] = rsqrtf(t / (float)p.N + sx.eps);
+      }
+    }
   }
-  float ssum[MTW];
-#pragma unroll
-  for (int t = 0; t < MTW; ++t) ssum[t] = 0.f;
-  stream_finish<T, MTW, ACT, RFW>(p, sx, s, acc, ssum, false, m0 + wm * 64, sp, nb * BF + wn * RFW, nfrag, false, q, r);
 }
 
 // sums the K-split partials and applies the epilogue: one thread per (row, fragment or fragment pair, 4-column group).
@@ -464,12 +606,28 @@ __global__ __launch_bounds__(ROWSTAT ? 1024 : 256) void gemm_stream_reduce_kerne
   float ssum = 0.f;
   const bool stats_here = sx.fuse_rms && !sx.rstd_in;
   if (live) {
-    for (int sp = 0; sp < s.splits; ++sp) {
-      const float* row = s.part + ((int64_t)sp * p.M + m) * s.np + gf * 16 + 4 * q;
-      a4 += *(const f32x4*)row;
-      if constexpr (PAIRS) b4 += *(const f32x4*)(row + 16);
-      if (stats_here) ssum += s.part_ss[(int64_t)sp * p.M + m];
+    // the partial records of up to 8 splits are requested together (a load-add chain per split left one 16-byte load in
+    // flight per thread); summed in split order
+    constexpr int UN = 8;
+    for (int sp0 = 0; sp0 < s.splits; sp0 += UN) {
+      f32x4 va[UN], vb[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int sp = sp0 + u < s.splits ? sp0 + u : s.splits - 1;
+        const float* row = s.part + ((int64_t)sp * p.M + m) * s.np + gf * 16 + 4 * q;
+        va[u] = *(const f32x4*)row;
+        if constexpr (PAIRS) vb[u] = *(const f32x4*)(row + 16);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (sp0 + u < s.splits) {
+          a4 += va[u];
+          if constexpr (PAIRS) b4 += vb[u];
+        }
+      }
     }
+    if (stats_here)
+      for (int sp = 0; sp < s.splits; ++sp) ssum += s.part_ss[(int64_t)sp * p.M + m];
   }
   const float rs = sx.rstd_in ? sx.rstd_in[m] : (stats_here ? rsqrtf(ssum / (float)p.K + sx.eps) : 1.0f);
   float a[4], b[4];
@@ -566,6 +724,10 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws, int dt
   return c;
 }
 
+// the K-split workspace opens with the fix-up's counters (8 KiB, zero whenever no launch is in flight: zeroed once by the owner
+// of the buffer, restored by every launch) and its row-statistics partials ([<= 32 n-blocks][M] floats); the partial records follow
+static size_t stream_ws_header(int M) { return 8192 + (((size_t)32 * M * sizeof(float) + 255) & ~(size_t)255); }
+
 int sl_gemm_stream_splits(int M, int N, int K, int dtype) {
   const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
   return c.wide ? c.wsplits : c.splits;
@@ -576,7 +738,7 @@ size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype) {
   const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
   const int most = c.wide && c.wsplits > c.splits ? c.wsplits : c.splits;   // either form may run (the wide one not when the kernel takes the RMSNorm statistics itself)
   size_t splits = most > 1 ? (size_t)most : 0;
-  return splits * ((size_t)M * np + (size_t)M) * sizeof(float) + 256;
+  return stream_ws_header(M) + splits * ((size_t)M * np + (size_t)M) * sizeof(float) + 256;
 }
 
 // second pass of a K-split launch: sums the partial records and applies the epilogue
@@ -672,6 +834,7 @@ static int launch_stream_wide_act(GemmP& p, const SkinnyX& sx, const StreamX& s,
   }
   hipLaunchKernelGGL((gemm_stream_wide_kernel<bf16_t, ACT>), grid, dim3(768), LDS_BYTES, st, p, sx, s);
   SL_CHECK_LAUNCH("gemm_stream_wide");
+  if (s.cnt) return 0;   // the kernel's last-arriving blocks did the reduce pass
   return launch_stream_reduce<bf16_t, ACT>(p, sx, s, st);
 }
 
@@ -693,6 +856,8 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
 
   s.np = (p.N + 15) / 16 * 16;
   const size_t per_split = ((size_t)p.M * s.np + (size_t)p.M) * sizeof(float);
+  const size_t hdr = stream_ws_header(p.M);
+  if (split_ws && split_ws_bytes > hdr) { split_ws_bytes -= hdr; } else { split_ws_bytes = 0; if (!split_ws) {} else c.splits = 1; }
   if (c.splits > 1 && (size_t)c.splits * per_split > split_ws_bytes) c.splits = (int)(split_ws_bytes / per_split);
   if (c.splits < 1) c.splits = 1;
   const int nst = p.K / (2 * kstep);
@@ -703,8 +868,17 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
     SL_CHECK_ARG(act == SL_ACT_NONE && (p.N + 15) / 16 * 4 <= 1024 && s.splits > 1,
                  "sl_gemm: rstd_out needs the plain epilogue, N <= 4096 and a K-split (splits=%d; see sl_gemm_split_count)", s.splits);
   }
-  s.part = (float*)split_ws;
+  s.part = split_ws ? (float*)((unsigned char*)split_ws + hdr) : nullptr;
   s.part_ss = s.part ? s.part + (size_t)s.splits * p.M * s.np : nullptr;
+  // in-kernel fix-up (wide form): the tile / row-block counters and the row-statistics partials must fit the header
+  s.cnt = nullptr; s.ss_part = nullptr;
+  if (wide && s.splits > 1 && sl_env().stream_fixup != 0) {
+    const int nbv = ((p.N + 15) / 16 + 7) / 8, mbl = (p.M + 255) / 256;
+    if (nbv * mbl <= 1024 && mbl <= 64 && (sx.rstd_out == nullptr || nbv <= 32)) {
+      s.cnt = (int*)split_ws;
+      s.ss_part = (float*)((unsigned char*)split_ws + 8192);
+    }
+  }
   if (dtype == SL_F32) return stream_typed<float>(p, sx, act, s, c, st);
   if (wide) return launch_stream_wide(p, sx, act, s, st);
   return stream_typed<bf16_t>(p, sx, act, s, c, st);

@@ -604,6 +604,7 @@ extern "C" int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* 
   SL_CHECK_ARG(off <= workspace_bytes, "sl_llama_decode_step: workspace too small");
   const size_t need = off + llama_carve(m, B, B, bptr(workspace) + off, workspace_bytes - off, w);
   SL_CHECK_ARG(need <= workspace_bytes, "sl_llama_decode_step: workspace %zu B < required %zu B", workspace_bytes, need);
+  if (w.split && w.split_bytes >= 8192) SL_HIP(hipMemsetAsync(w.split, 0, 8192, st));   // the K-split fix-up's counters start at zero
   hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
   SL_CHECK_LAUNCH("iota");
   return decode_step(m, kv, next_ids_dev, ctx_len_dev, B, logits, x, w, st);
@@ -707,6 +708,7 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
   // decode: one captured step, replayed.  Scratch layout for M = B rows.
   LlamaWs w;
   llama_carve(m, B, B, scratch, scratch_bytes, w);
+  if (w.split && w.split_bytes >= 8192) SL_HIP(hipMemsetAsync(w.split, 0, 8192, st));   // the K-split fix-up's counters start at zero (sl_gemm_fused.split_ws)
   hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
   SL_CHECK_LAUNCH("iota");
   int steps_done = 1;

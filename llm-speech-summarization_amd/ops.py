@@ -304,7 +304,7 @@ _SPLIT_WS = {}
 def _split_ws(device, nbytes: int) -> torch.Tensor:
     ws = _SPLIT_WS.get(device)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # the first 8 KiB hold the K-split fix-up's counters: zero on first use
         _SPLIT_WS[device] = ws
     return ws
 

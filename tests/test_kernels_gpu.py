@@ -457,7 +457,7 @@ def test_gemm_packed_wide_block_form(M, H, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M", [40, 128])
+@pytest.mark.parametrize("M", [40, 128, 512, 600])     # 512 / 600 rows in bf16: the 256 x 128 form with its K split
 def test_gemm_packed_rstd_handoff(dt, M):
     """K-split reduce pass emits the RMSNorm scale of the rows it stores; the next fused GEMM takes it (rstd_in)
     instead of recomputing it: same result as the in-kernel statistics."""
@@ -477,6 +477,51 @@ def test_gemm_packed_rstd_handoff(dt, M):
     y2 = ops.gemm_decode(x, wp, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, rstd_in=rstd, split_k=False)
     assert rel_err(y1.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
     assert rel_err(y2.float().cpu(), y0.float().cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("M", [385, 512, 700])
+def test_gemm_packed_wide_split_fixup_equals_reduce_pass(M, monkeypatch):
+    """K split of the 256 x 128 form: the in-kernel fix-up (last-arriving block sums the partial records and applies the
+    epilogue; a second counter per row block turns the per-tile sums of squares into rstd_out) must store exactly what the
+    separate reduce launch stores — same partial records, same summation order — and leave its counters at zero (second call
+    on the same workspace gives the same result).  Plain +residual epilogue with the row statistics, and the RoPE / KV epilogue."""
+    dt = torch.bfloat16
+    H, K1 = 512, 2048
+    a, wo, res = rnd(M, K1, seed=40), rnd(H, K1, seed=41, std=K1 ** -0.5), rnd(M, H, seed=42)
+    assert L.lib().sl_gemm_split_count(M, H, K1, L.dtype_code(dt)) > 1
+    wp = ops.pack_weight(wo.to(dev(), dt))
+    arch = weights.LlamaArch(hidden_size=1536, num_attention_heads=6, num_key_value_heads=2, head_dim=128,
+                             rope_scaling=dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192))
+    nh, nkv, D, Hq, max_ctx = 6, 2, 128, 1536, 64
+    cos, sin = [t_.to(dev()) for t_ in weights.rope_tables(arch, max_ctx)]
+    xq = rnd(M, Hq, seed=38).to(dev(), dt)
+    Wq = ops.pack_weight(rnd((nh + 2 * nkv) * D, Hq, seed=39, std=Hq ** -0.5).to(dev(), dt))
+    assert L.lib().sl_gemm_split_count(M, (nh + 2 * nkv) * D, Hq, L.dtype_code(dt)) > 1
+    pos = torch.tensor([(7 * i + 3) % max_ctx for i in range(M)], dtype=torch.int32, device=dev())
+    seq = torch.arange(M, dtype=torch.int32, device=dev())
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SL_STREAM_FIXUP", mode)
+        L.lib().sl_tuning_reload()
+        runs = []
+        for _ in range(2):
+            rstd = torch.zeros(M, device=dev(), dtype=torch.float32)
+            x = ops.gemm_decode(a.to(dev(), dt), wp, H, residual=res.to(dev(), dt), rstd_out=rstd, eps=1e-5)
+            kc = torch.zeros(M, nkv, max_ctx, D, device=dev(), dtype=dt); vc = torch.zeros_like(kc)
+            qo = ops.gemm_decode(xq, Wq, (nh + 2 * nkv) * D, act=L.ACT_ROPE_KV,
+                                 rope=dict(cos=cos, sin=sin, pos=pos, seq=seq, k_cache=kc, v_cache=vc, n_heads=nh, n_kv=nkv, max_ctx=max_ctx))
+            runs.append((x.cpu(), rstd.cpu(), qo.cpu(), kc.cpu(), vc.cpu()))
+        for u, v in zip(runs[0], runs[1]):
+            assert torch.equal(u, v)
+        got[mode] = runs[0]
+    monkeypatch.delenv("SL_STREAM_FIXUP")
+    L.lib().sl_tuning_reload()
+    for i in (0, 2, 3, 4):
+        assert torch.equal(got["0"][i], got["1"][i]), i
+    assert rel_err(got["1"][1], got["0"][1]) < 1e-6
+    xr = q(a, dt) @ q(wo, dt).T + q(res, dt)
+    assert rel_err(got["1"][0].float(), xr) < TOL[dt]
+    assert rel_err(got["1"][1], torch.rsqrt(got["1"][0].float().pow(2).mean(-1) + 1e-5)) < 1e-5
 
 
 @pytest.mark.parametrize("dt", DT)
