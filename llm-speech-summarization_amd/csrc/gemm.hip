@@ -519,6 +519,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 // Also measured slower (-4..-7 %): issuing the DMA of slab k+2 in the middle of slab k behind an extra bare barrier (1.25-1.5
 // product phases of cover instead of one).  PMC on 17408x16384x3072: MFMA busy 46 %, waves 30 % parked (vmcnt/barrier), 50 %
 // issue-stalled behind the MFMA pipe, 20 % issuing; no LDS bank conflicts.
+// A 256 x 128 tile with dedicated loader waves (8 compute + 4 loader waves, three 48 KiB slots, fragment reads interleaved with
+// the MFMAs — the structure of gemm_stream_wide_kernel on row-major operands) measured 0.93-1.09 x this kernel on the
+// encoder / prefill shapes (tools/bench_gemm_lw.py, round 2): it is bound by what a CU pulls from L2 (~31 B/clk) at 48 KiB per
+// 1024 MFMA-cycles, this tile needs 64 KiB per 2048; removed again.
 // A persistent form (one block per CU walking its tiles, the next tile's first slab requested before the current tile's
 // epilogue, which then turns 32-row groups through the other staging buffer) measured within +-2 % of this kernel at
 // K = 1024..8192: the vmcnt(0) that admits the prefetched slab also drains the epilogue's stores (one counter on gfx9).
