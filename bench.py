@@ -127,7 +127,8 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     # warm-up: ONE complete window including its optimizer step (first-use costs: allocator growth, transposed copies of the
     # frozen LLM weights, AdamW's exp_avg / exp_avg_sq allocation, RCCL communicator set-up), untimed; the timed windows below
     # each contain everything a step does (forward, backward, all-reduce, AdamW, in-place refresh of the kernel weights)
-    tr.micro_batch(waves, texts, resps)
+    for _ in range(2):   # the second window still ran 40 % long when the leg follows the inference legs (fresh allocator blocks)
+        tr.micro_batch(waves, texts, resps)
     tr.micro = 0
     if dist is not None:
         dist.barrier()
@@ -610,7 +611,7 @@ def main():
     # `traffic` cannot be measured inside this process (PMC counters need rocprofv3 around it): it is READ from the committed
     # counter summary of the same two launches (tools/probe_decode_kernels.py under separate --pmc passes), and says so
     pmc, pmc_src = {}, None
-    for name in ("r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):
+    for name in ("r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):   # newest committed PMC passes first
         pmc_path = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
@@ -627,7 +628,8 @@ def main():
                 "traffic": pmc.get(key), "traffic_source": pmc_src if pmc.get(key) is not None else None, "algorithmic_bytes_per_launch": alg,
                 "avg_launch_us": round(ms * 1e3, 2)}
 
-    r_gemm = roof(("gemm_stream_kernel" if streaming else "gemm_skinny_kernel") + "<bf16, SILU_MUL> (gate/up projection, decode)", "gemm")
+    r_gemm = roof(("gemm_stream_wide_kernel" if B > 384 else ("gemm_stream_kernel" if streaming else "gemm_skinny_kernel")) +
+                  "<bf16, SILU_MUL> (gate/up projection, decode)", "gemm")
     # the same launch against the matrix-core roof: above ~256 rows the projection is nearer to it than to the HBM one
     gemm_flops = 2.0 * B * 2 * larch.intermediate_size * larch.hidden_size
     r_gemm["mfma"] = {"achieved": round(gemm_flops / (probes["gemm"][1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
