@@ -705,14 +705,14 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws, int dt
   }
   if (sp_env && (have_ws || sp_env == 1)) splits = sp_env < nst ? sp_env : nst;
   c.splits = splits;
-  // the 256 x 128 form (bf16, > 384 rows): unsplit when its blocks cover the CUs, else K split towards ~240 blocks of >= 6 stages
+  // the 256 x 128 form (bf16, > 384 rows): unsplit when its blocks cover at least half the CUs, else K split towards ~240 blocks of >= 6 stages
   c.wide = 0; c.wsplits = 1;
   if (dtype == SL_BF16 && M > 384 && sl_env().stream_wide != 0) {
     const int wbase = ((M + 255) / 256) * ((nfrag + 7) / 8);
-    if (wbase >= 200 || sl_env().stream_wide == 2) {
+    if (wbase >= 128 || sl_env().stream_wide == 2) {   // unsplit from half the CUs up (qkv at 1024 rows: 160 blocks, 53 us; 61 us split in two)
       c.wide = 1;
     }
-    if (wbase < 200 && have_ws) {
+    if (wbase < 128 && have_ws) {
       int ws_ = 240 / wbase;
       const int max_ws = nst / 6 > 0 ? nst / 6 : 1;
       if (ws_ > max_ws) ws_ = max_ws;

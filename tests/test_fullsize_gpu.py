@@ -2,7 +2,7 @@
 configs[4] long-form), so that what bench.py times is also what the parity suite checks.
 
 * configs[1]: HuBERT-large (24 layers) -> Llama-3.2-3B (28 layers), bf16, random init of the true shapes (bench.py's weights),
-  512 sequences per step: (a) every copy of an utterance inside the batch gives bit-identical embedding rows and id rows
+  1024 (bench default) and 512 sequences per step: (a) every copy of an utterance inside the batch gives bit-identical embedding rows and id rows
   (64-bit indexing, row independence of every kernel); (b) the 3-utterance batch gives the same embeddings and the same
   first tokens; (c) one utterance against the CPU oracle on the same bf16-rounded weights: audio embeddings and all 29
   hidden-state taps within the stated tolerance (FULL_TOL: 28 layers of bf16 rounding, vs 3e-2 for the 2-layer fixtures).
@@ -70,7 +70,7 @@ class FullModels:
             g.manual_seed(99)
             sd["lm_head.weight"] = (torch.randn(self.larch.vocab_size, self.larch.hidden_size, generator=g, device=DEV) * 0.02).to(torch.bfloat16)
         self.llm_sd_host = {k: v.float().cpu() for k, v in sd.items()}        # the oracle's weights: bf16 values held in fp32
-        self.llm = llama_mod.AudioLlamaForCausalLM(self.larch, sd, torch_dtype=torch.bfloat16, device=DEV, max_ctx=448, max_batch=512)
+        self.llm = llama_mod.AudioLlamaForCausalLM(self.larch, sd, torch_dtype=torch.bfloat16, device=DEV, max_ctx=448, max_batch=1024)
         bos = self.larch.bos_token_id or 0
         self.prefix = ri.synthetic_ids(N_PRE, self.larch.vocab_size, seed=7, bos=bos)
         self.suffix = ri.synthetic_ids(N_SUF, self.larch.vocab_size, seed=8, bos=bos)
@@ -150,9 +150,10 @@ def _agreeing_prefix(a, b):
     return int(neq[0]) if neq.numel() else int(a.shape[0])
 
 
-def test_configs1_full_depth_batch512_copies_identical_and_equal_small_batch(llama3):
-    """bench.py's default step (512 sequences, HuBERT-large 24 L + Llama-3.2-3B 28 L, bf16) on copies of 3 distinct utterances."""
-    m, B, new = llama3, 512, 24
+@pytest.mark.parametrize("B", [1024, 512])     # 1024 = bench.py's default step; 512 = round 1's (K-split forms of the 256 x 128 block)
+def test_configs1_full_depth_large_batch_copies_identical_and_equal_small_batch(llama3, B):
+    """bench.py's default step (1024 sequences, HuBERT-large 24 L + Llama-3.2-3B 28 L, bf16) on copies of 3 distinct utterances."""
+    m, new = llama3, 24
     base = [ri.synthetic_waveform(n, seed=1234 + i).to(DEV) for i, n in enumerate((160000, 112000, 160000))]
     x3, lens3, st3 = m.prompts(base)
     x3 = x3.clone()
@@ -175,7 +176,7 @@ def test_configs1_full_depth_batch512_copies_identical_and_equal_small_batch(lla
         assert rel_err(lg_big[b].cpu(), lg_small[b % 3].cpu()) < 1e-2, b
     ids3, _ = m.llm.generate_packed(x3.clone(), lens3, new, use_eos=False)
     agree = [_agreeing_prefix(ids3[i], ids[i]) for i in range(3)]
-    print("tokens agreeing between the 512-sequence and the 3-sequence run before the first near-tie flip:", agree)
+    print(f"tokens agreeing between the {B}-sequence and the 3-sequence run before the first near-tie flip:", agree)
 
 
 def test_configs1_full_depth_one_utterance_vs_oracle(llama3):
