@@ -561,7 +561,24 @@ def main():
         def timed(fn, n):
             for i in range(len(wgu)):
                 fn(i)
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            try:
+                # as the decode loop launches them: from a captured graph (an eager Python loop adds 5-8 us of launch gap per
+                # kernel at these durations, which rocprofv3's per-kernel average of the real decode graph does not contain)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(n):
+                        fn(i)
+                g.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+            except Exception:
+                torch.cuda.synchronize()
             e0.record()
             for i in range(n):
                 fn(i)

@@ -857,7 +857,7 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
   s.np = (p.N + 15) / 16 * 16;
   const size_t per_split = ((size_t)p.M * s.np + (size_t)p.M) * sizeof(float);
   const size_t hdr = stream_ws_header(p.M);
-  if (split_ws && split_ws_bytes > hdr) { split_ws_bytes -= hdr; } else { split_ws_bytes = 0; if (!split_ws) {} else c.splits = 1; }
+  split_ws_bytes = (split_ws && split_ws_bytes > hdr) ? split_ws_bytes - hdr : 0;   // what is left for partial records
   if (c.splits > 1 && (size_t)c.splits * per_split > split_ws_bytes) c.splits = (int)(split_ws_bytes / per_split);
   if (c.splits < 1) c.splits = 1;
   const int nst = p.K / (2 * kstep);
