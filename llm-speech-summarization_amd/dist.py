@@ -92,12 +92,16 @@ class BucketedAllReduce:
     latency.  On CPU tensors (gloo, used by the tests) the same code runs without streams.
     """
 
-    def __init__(self, arena: GradArena, group=None, min_bucket_bytes: int = 32 << 20):
+    def __init__(self, arena: GradArena, group=None, min_bucket_bytes: int = 32 << 20, single_rank: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.arena = arena
         self.group = group
+        # single_rank: issue the collectives even in a group of one (identity sums) — how tests/test_dp_gpu.py drives the
+        # RCCL backend, its streams and events on a one-GPU box
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if single_rank and dist.is_initialized() and self.world == 1:
+            self.world = 2 ** 30    # only ever compared with 1
         self.min_bytes = min_bucket_bytes
         self._final = [False] * len(arena.order)
         self._n_final = 0          # buffers [0, _n_final) are final

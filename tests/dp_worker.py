@@ -23,9 +23,13 @@ def main():
     out_path, n_rows, accum, workdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(0)
-    if world > 1:
+    backend = os.environ.get("DP_BACKEND", "gloo")
+    if world > 1 or backend == "nccl":
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":     # RCCL, one rank (it refuses two per device): the collectives are identity sums, the call path is the real one
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     from conftest import golden, pkg, t
     from oracle.golden_cfgs import TINY_HUBERT, TINY_LLAMA
     from test_models_gpu import StubTokenizer, make_encoder, make_llama
@@ -57,6 +61,8 @@ def main():
     args = SimpleNamespace(run_name="dp", checkpoint_path=None, gpu_idx=0, no_regularizers=True)
     tr = trainer_mod.Trainer(args, conf, "cuda:0", tokenizer=tok, llm=llm, audio_encoder=enc, train_dataset=train_ds, val_dataset=val_ds,
                              dtype=torch.float32)
+    if backend == "nccl" and world == 1:
+        tr.kd.reducer = dist_mod.BucketedAllReduce(tr.kd.enc_tape.arena, single_rank=True)
     if tr.kd.reducer is not None:
         tr.kd.reducer.min_bytes = 64 << 10          # several buckets even at the tiny model's 1.3 MB of gradients
     tr.kd.keep_last_grads = True
@@ -83,7 +89,7 @@ def main():
                 "master": {k: v.cpu() for k, v in tr.kd.master.items()}, "val": val, "indices": tr._epoch_indices(0),
                 "windows": tr._epoch_windows(0), "step": tr.step, "optimizer_steps": tr.kd.optimizer_steps,
                 "lr": tr.lr_scheduler.get_last_lr()[0]}, out_path)
-    if world > 1:
+    if world > 1 or backend == "nccl":
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -22,12 +22,12 @@ GRAD_TOL = 2e-6     # fp32: the two runs sum the same per-utterance terms in a d
 MASTER_TOL = 1e-6
 
 
-def _run(world, out_dir, n_rows, accum, port):
+def _run(world, out_dir, n_rows, accum, port, backend="gloo"):
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        out = os.path.join(out_dir, f"w{world}_r{r}.pt")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", DP_BACKEND=backend)
+        out = os.path.join(out_dir, f"w{world}_r{r}_{backend}.pt")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, WORKER, out, str(n_rows), str(accum), out_dir], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
@@ -81,3 +81,28 @@ def test_two_rank_trainer_equals_single_rank(tmp_path):
     for key in ("validation/audio_perplexity", "validation/text_perplexity"):
         for r in two:
             assert abs(r["val"][key] - one["val"][key]) < 1e-5 * one["val"][key], (key, r["val"][key], one["val"][key])
+
+
+def test_rccl_backend_single_rank_runs_the_bucketed_exchange(tmp_path):
+    """The exchange on the backend a multi-GPU node uses: `nccl` = RCCL, a group of ONE rank on this one-GPU box (RCCL refuses two
+    ranks per device), with the reducer forced on.  Every bucket is an identity sum, so gradients, masters and perplexities must
+    equal the plain single-process run (to the atomics' run-to-run noise) — what this covers is RCCL communicator set-up, in-place all-reduce of arena
+    slices, the side stream / event ordering against the HIP kernels' stream, and tear-down."""
+    n_rows, accum = 17, 16
+    port = 29400 + os.getpid() % 500
+    (plain,) = _run(1, str(tmp_path), n_rows, accum, port)
+    (rccl,) = _run(1, str(tmp_path), n_rows, accum, port + 1, backend="nccl")
+    assert rccl["optimizer_steps"] == plain["optimizer_steps"] == 2
+    assert len(rccl["buckets"]) == 2 and len(rccl["buckets"][0]) >= 2       # the full window went out in several buckets
+    covered = sorted(rccl["buckets"][0])
+    assert covered[0][0] == 0 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))   # contiguous, in arena order
+    # run-to-run the per-column parameter gradients (conv0 weights, biases, LayerNorm gains) differ in their last bits:
+    # their sums use float atomics; everything else is bit-identical
+    for s in range(2):
+        for k in plain["grads"][s]:
+            if float(plain["grads"][s][k].norm()) > 1e-8:
+                assert rel_err(rccl["grads"][s][k], plain["grads"][s][k]) < GRAD_TOL, (s, k)
+    for k in plain["master"]:
+        assert rel_err(rccl["master"][k], plain["master"][k]) < MASTER_TOL, k
+    for key in ("validation/audio_perplexity", "validation/text_perplexity"):
+        assert abs(rccl["val"][key] - plain["val"][key]) < 1e-5 * plain["val"][key]
