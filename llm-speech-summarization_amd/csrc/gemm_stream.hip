@@ -18,6 +18,8 @@
 // k/v appended to the cache), and the fused RMSNorm row scale (sum of squares taken from the staged x slabs).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gemm_internal.h"
 
 struct StreamX {
@@ -827,10 +829,12 @@ static int launch_stream_wide_act(GemmP& p, const SkinnyX& sx, const StreamX& s,
   const int nfrag = (p.N + 15) / 16, mblocks = (p.M + 255) / 256, nblocks = (nfrag + 7) / 8;
   constexpr int LDS_BYTES = 3 * (256 * TROWB + 8 * 2 * 1024);
   dim3 grid((nblocks + 7) / 8 * 8 * mblocks, 1, s.splits);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};   // one bit per device: the opt-in to 144 KiB of dynamic LDS is per device
+  int devid = 0;
+  SL_HIP(hipGetDevice(&devid));
+  if (devid < 0 || devid >= 64 || !((attr_set.load(std::memory_order_relaxed) >> devid) & 1)) {
     SL_HIP(hipFuncSetAttribute((const void*)gemm_stream_wide_kernel<bf16_t, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+    if (devid >= 0 && devid < 64) attr_set.fetch_or(1ull << devid, std::memory_order_relaxed);
   }
   hipLaunchKernelGGL((gemm_stream_wide_kernel<bf16_t, ACT>), grid, dim3(768), LDS_BYTES, st, p, sx, s);
   SL_CHECK_LAUNCH("gemm_stream_wide");
