@@ -717,6 +717,12 @@ def main():
     if not args.no_cpu_baseline:
         del llm, wts
         result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)
+    try:      # memory head-room of the run, for the record (stderr; the JSON line stays the only stdout line)
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        print(f"[bench] peak torch allocation {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB, reserved {torch.cuda.max_memory_reserved(dev) / 2**30:.1f} GiB, "
+              f"device total {total_b / 2**30:.1f} GiB", file=sys.stderr, flush=True)
+    except Exception:
+        pass
     print(json.dumps(result), flush=True)
     leave()
 

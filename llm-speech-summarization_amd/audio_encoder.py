@@ -180,25 +180,42 @@ class AudioEncoder:
             offs.append(offs[-1] + n)
         flat = torch.cat([w.reshape(-1).to(device=self.device, dtype=torch.float32) for w in waves]).contiguous()
         n_utt = len(waves)
-        offs_c = (C.c_int64 * (n_utt + 1))(*offs)
         T = [self.arch.num_frames(n) for n in lens]
         pool = self.downsample_method == "pool"
         P = [((t - self.pool_kernel) // self.pool_stride + 1) if pool else 0 for t in T]
-        nbytes = lib.sl_hubert_workspace_bytes(C.byref(m), offs_c, n_utt)
-        if nbytes == 0:
-            raise L.SpeechLLMError("sl_hubert_workspace_bytes: " + lib.sl_last_error().decode())
-        ws = self._workspace(nbytes)
         last_hidden = None
         if want_last_hidden or not pool:
             last_hidden = torch.empty((sum(T), self.arch.hidden_size), device=self.device, dtype=self.dtype)
-        rows_c = None
-        if pool:
-            if out is None:
-                out = torch.empty((sum(P), self.llm_dim), device=self.device, dtype=self.dtype)
-            if out_row_offsets is not None:
-                rows_c = (C.c_int64 * n_utt)(*[int(r) for r in out_row_offsets])
-        L.check(lib.sl_hubert_forward(C.byref(m), flat.data_ptr(), offs_c, n_utt, L.ptr(out), (out.stride(0) if out is not None else 0),
-                                      rows_c, L.ptr(last_hidden), ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_hubert_forward")
+        if pool and out is None:
+            out = torch.empty((sum(P), self.llm_dim), device=self.device, dtype=self.dtype)
+        if pool and out_row_offsets is None:
+            out_row_offsets, acc_rows = [], 0
+            for p_ in P:
+                out_row_offsets.append(acc_rows)
+                acc_rows += p_
+        # Utterances are independent, so a large batch goes through the library in groups of at most `max_samples_per_call`
+        # samples (default 256 x 10 s): the conv stack's workspace grows with the audio in flight (33 KB per sample-ms: ~20 GB
+        # per 2 560 audio-seconds), and 1 024 x 10 s in one call would hold ~75 GB of it for no gain — the GEMMs of a 256-utterance
+        # group already have 128 k rows.
+        limit = int(getattr(self, "max_samples_per_call", 256 * 160000))
+        t_row = 0
+        start = 0
+        while start < n_utt:
+            end = start + 1
+            while end < n_utt and offs[end + 1] - offs[start] <= limit:
+                end += 1
+            n_c = end - start
+            offs_c = (C.c_int64 * (n_c + 1))(*[o - offs[start] for o in offs[start:end + 1]])
+            nbytes = lib.sl_hubert_workspace_bytes(C.byref(m), offs_c, n_c)
+            if nbytes == 0:
+                raise L.SpeechLLMError("sl_hubert_workspace_bytes: " + lib.sl_last_error().decode())
+            ws = self._workspace(nbytes)
+            rows_c = (C.c_int64 * n_c)(*[int(r) for r in out_row_offsets[start:end]]) if pool else None
+            lh_ptr = (last_hidden.data_ptr() + t_row * last_hidden.stride(0) * last_hidden.element_size()) if last_hidden is not None else None
+            L.check(lib.sl_hubert_forward(C.byref(m), flat.data_ptr() + offs[start] * 4, offs_c, n_c, L.ptr(out), (out.stride(0) if out is not None else 0),
+                                          rows_c, lh_ptr, ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_hubert_forward")
+            t_row += sum(T[start:end])
+            start = end
         return out, P, last_hidden, T
 
     def _downsample_host(self, hidden: torch.Tensor, ctc_pool_ranges) -> torch.Tensor:
