@@ -358,6 +358,9 @@ def _write_hf_llama_dir(path, cfg, sd, bos, eos, pad=None):
     half = len(keys) // 2                      # two shards, like a hub checkpoint
     save_file({k: sd[k].contiguous() for k in keys[:half]}, str(path / "model-00001-of-00002.safetensors"))
     save_file({k: sd[k].contiguous() for k in keys[half:]}, str(path / "model-00002-of-00002.safetensors"))
+    # what Llama-3.2-3B-Instruct ships on the hub: sampling parameters AND do_sample = true
+    with open(path / "generation_config.json", "w") as f:
+        json.dump(dict(bos_token_id=bos, do_sample=True, eos_token_id=eos, temperature=0.6, top_p=0.9), f)
 
 
 @pytest.mark.parametrize("family", ["llama3", "minichat"])
@@ -397,6 +400,10 @@ def test_reference_constructor_path_real_tokenizer_safetensors_and_local_hubert(
     inf = inf_mod.LLMSpeechTextInference(conf, str(ckpt), torch.device(DEV), dtype=torch.float32)
     tok = inf.llm_tokenizer
     assert tok.pad_token == tok.eos_token and tok.padding_side == "left"
+    # the hub's generation_config.json is read: its sampling parameters are kept, its do_sample flag is recorded but NOT acted on
+    # (BASELINE's north_star is greedy decode; generate(do_sample=True) opts in) — the greedy ids below prove it
+    gcfg = inf.llm.generation_config
+    assert gcfg.hub_do_sample is True and gcfg.do_sample is False and abs(gcfg.temperature - 0.6) < 1e-9 and abs(gcfg.top_p - 0.9) < 1e-9 and gcfg.top_k == 50
     # the four template strings tokenise to the recorded ids (f1), through the object the inference class built itself
     for key in ("prefix", "suffix", "text_prompt", "additional_text_prompt"):
         assert tok(rec["strings"][key], return_tensors="pt").input_ids[0].tolist() == rec["ids"][key], key
