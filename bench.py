@@ -176,10 +176,46 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     S_t = prefix.shape[1] + text_ids.shape[0] + suffix.shape[1] - 1 + resp_ids.shape[0] - 1
     flops = 3.0 * enc_fwd + 2.0 * prefill_full(S_a) + prefill_full(S_t)
     ach = flops * n_micro / dt_ / 1e12
+    # the same step counted with the logits the losses actually read (the last n response rows of each sequence,
+    # ref:model/audio_llama.py:84-89 / ref:trainer.py:325-340), which is what this build computes
+    n_resp = resp_ids.shape[0]
+    flops_tail = flops - (2.0 * (S_a - n_resp) + (S_t - n_resp)) * 2.0 * emb_w
+    ach_tail = flops_tail * n_micro / dt_ / 1e12
+    # ---- the per-rank regime of an 8-rank run, measured on this one GPU: windows of `--kd-local-accum` samples (M ~ 400 rows per
+    # GEMM), each closed by AdamW + the in-place weight refresh; the all-reduce itself cannot run here, its cost is estimated
+    probe = None
+    if world == 1 and args.kd_local_accum > 0 and args.kd_local_accum < tr.local_accum:
+        k_ = args.kd_local_accum
+        full = tr.local_accum
+        tr.local_accum = k_
+        for _ in range(2):
+            tr.micro_batch(waves[:k_], texts[:k_], resps[:k_])
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        n_win = max(4, args.kd_optimizer_steps * 2)
+        for _ in range(n_win):
+            tr.micro_batch(waves[:k_], texts[:k_], resps[:k_])
+        torch.cuda.synchronize()
+        win_ms = (time.perf_counter() - tp) / n_win * 1e3
+        tr.local_accum = full
+        ar_bytes = sum(p.numel() for p in tr.params) * 4
+        ranks = tr.accum // k_
+        # ring all-reduce over xGMI: 2 (N-1)/N x bytes cross each GPU's links; RCCL's measured bus bandwidth on 8 x MI300-class
+        # nodes is 250-350 GB/s for GB-sized fp32 buffers (7 links x ~153 GB/s raw, guide) -> both ends of that range
+        wire = 2.0 * (ranks - 1) / ranks * ar_bytes
+        ex_ms = [round(wire / (bw * 1e9) * 1e3, 2) for bw in (350.0, 250.0)]
+        probe = {"samples_per_window": k_, "emulates_world_size": ranks, "window_ms": round(win_ms, 2),
+                 "samples_per_s_per_rank_compute_only": round(k_ / (win_ms * 1e-3), 2),
+                 "allreduce_bytes": ar_bytes, "estimated_exchange_ms": ex_ms, "exchange_to_compute": [round(e / win_ms, 2) for e in ex_ms],
+                 "predicted_samples_per_s_at_world": [round(ranks * k_ / ((win_ms + e * f) * 1e-3), 1) for e, f in ((ex_ms[0], 0.0), (ex_ms[1], 1.0))],
+                 "note": f"one GPU running the per-rank share of a {ranks}-rank step: window of {k_} samples + AdamW + weight refresh; exchange "
+                         "estimated, not measured (bus bandwidth 350 / 250 GB/s); prediction = fully overlapped / not overlapped at all"}
     return {"samples_per_s": round(n_micro * world / dt_, 3), "ms_per_micro_step": round(dt_ / n_micro * 1e3, 2),
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                          "algorithmic_flops_per_sample": round(flops), "seq_audio": S_a, "seq_text": S_t,
-                         "formula": "3 enc_fwd + 2 prefill_full(S_audio) + prefill_full(S_text), SURVEY.md §8d; per rank"},
+                         "formula": "3 enc_fwd + 2 prefill_full(S_audio) + prefill_full(S_text), SURVEY.md §8d; per rank",
+                         "frac_tail_row_logits": round(ach_tail / MFMA_PEAK_TFLOPS, 4), "flops_per_sample_tail_row_logits": round(flops_tail)},
+            "per_rank_regime_probe": probe,
             "optimizer_steps": args.kd_optimizer_steps, "window_ms": window_ms, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
             "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
             "losses": {k: round(v, 4) for k, v in losses.items()}, "dtype": "bf16 compute, fp32 master/grads",
@@ -350,6 +386,72 @@ def latency_leg(args, llm, x1, S, new, larch, wts):
             "note": "median of 3 generate calls after 1 warm-up; decode graph replayed per token"}
 
 
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` started as ONE process (no WORLD_SIZE in the environment): this process becomes the launcher.
+    It starts N ranks as CHILD processes through `python -m torch.distributed.run` (one per GPU, RCCL over xGMI) BEFORE anything
+    here touches the GPU — the parent never initialises HIP, never execs — forwards rank 0's JSON line as its only stdout line
+    and returns the children's exit code; a line whose n_gpus is not N is an error (exit 4)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)        # anything else a rank wrote to stdout is not the result line
+    rc = proc.wait()
+    if line is None:
+        print(f"[bench] the {args.gpus}-rank launch produced no result line (exit code {rc})", file=sys.stderr, flush=True)
+        return rc or 3
+    print(line, flush=True)
+    try:
+        n = json.loads(line).get("n_gpus")
+    except ValueError:
+        n = None
+    if n != args.gpus:
+        print(f"[bench] result line reports n_gpus={n}, asked for {args.gpus}", file=sys.stderr, flush=True)
+        return rc or 4
+    return rc
+
+
+def dry_rank(args, rank, world) -> None:
+    """SL_BENCH_DRY=1: the multi-rank CONTROL FLOW of this script without a GPU (CPU tests of the launcher): gloo rendezvous, the
+    barrier + max-over-ranks timing bracket around K trivial steps, rank 0's JSON line, tear-down."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done = sum(1 for _ in range(args.steps))
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if os.environ.get("SL_BENCH_DRY_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    if rank == 0:
+        print("a stray stdout line from a rank", flush=True)
+        print(json.dumps({"metric": "dry run of the launcher (no GPU work)", "value": 0.0, "unit": "tokens/s",
+                          "n_gpus": int(os.environ.get("SL_BENCH_DRY_REPORT_GPUS", world)), "steps": done, "warmup": args.warmup,
+                          "ms_per_step": float(tt.item()) * 1e3 / max(1, done), "dry_run": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,11 +469,21 @@ def main():
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")
+    ap.add_argument("--kd-local-accum", type=int, default=2, help="single-GPU KD probe: windows of this many samples per optimizer step, the per-rank "
+                    "regime of an 8-rank run (grad_accum_interval 16 / 8); 0 = skip")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run `python bench.py --gpus N` "
+              "alone and let it start the ranks)", file=sys.stderr, flush=True)
+        sys.exit(4)
+    if os.environ.get("SL_BENCH_DRY") == "1":
+        return dry_rank(args, rank, world)
     dist = None
     if world > 1:
         import torch.distributed as dist  # RCCL: only the timing barrier / max-reduce, never on the data path

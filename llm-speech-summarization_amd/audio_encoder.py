@@ -26,13 +26,13 @@ import torch
 from . import _lib as L
 from . import ops
 from .weights import (KNOWN_HUBERT, KNOWN_WHISPER, HubertArch, HubertDeviceWeights, WhisperArch, WhisperDeviceWeights,
-                      normalize_encoder_state_dict)
+                      init_embed_projection, normalize_encoder_state_dict, pretrained_encoder_state_dict, resolve_pretrained_dir)
 
 
 def resolve_whisper_arch(type_str: str) -> WhisperArch:
-    cfg_path = os.path.join(type_str, "config.json")
-    if os.path.isdir(type_str) and os.path.exists(cfg_path):
-        with open(cfg_path) as f:
+    local = resolve_pretrained_dir(type_str)
+    if local and os.path.exists(os.path.join(local, "config.json")):
+        with open(os.path.join(local, "config.json")) as f:
             return WhisperArch.from_hf_config(json.load(f))
     if type_str in KNOWN_WHISPER:
         return KNOWN_WHISPER[type_str]
@@ -68,9 +68,9 @@ class WhisperFeatures:
 
 
 def resolve_hubert_arch(type_str: str) -> HubertArch:
-    cfg_path = os.path.join(type_str, "config.json")
-    if os.path.isdir(type_str) and os.path.exists(cfg_path):
-        with open(cfg_path) as f:
+    local = resolve_pretrained_dir(type_str)
+    if local and os.path.exists(os.path.join(local, "config.json")):
+        with open(os.path.join(local, "config.json")) as f:
             return HubertArch.from_hf_config(json.load(f))
     if type_str in KNOWN_HUBERT:
         return KNOWN_HUBERT[type_str]
@@ -78,7 +78,8 @@ def resolve_hubert_arch(type_str: str) -> HubertArch:
 
 
 class AudioEncoder:
-    def __init__(self, config, device, dtype: torch.dtype = torch.bfloat16, arch: Optional[HubertArch] = None):
+    def __init__(self, config, device, dtype: torch.dtype = torch.bfloat16, arch: Optional[HubertArch] = None,
+                 load_pretrained: bool = True):
         self.config = config
         self.device = torch.device(device)
         self.dtype = dtype
@@ -106,6 +107,27 @@ class AudioEncoder:
         self._ws: Optional[torch.Tensor] = None
         self.training = False
         self.last_encode_ms = None
+        self.pretrained_from: Optional[str] = None
+        if load_pretrained and arch is None:
+            self._cold_start()
+
+    def _cold_start(self) -> None:
+        """ref:model/audio_encoder.py:6-13,34-52: the reference's constructor leaves the module holding the PRETRAINED encoder
+        (`AutoModel.from_pretrained(type)`; `.encoder` of it for Whisper) and a freshly initialised `embed_projection`.  Same
+        here whenever the weights can be found without a network (a local HF directory, or the hub id's snapshot in the local HF
+        cache); otherwise the object stays weightless until `load_state_dict` (the inference path loads a checkpoint next
+        anyway, ref:inference.py:24-26) and `state_dict()` says what is missing."""
+        local = resolve_pretrained_dir(self.config.model.audio_encoder.type)
+        if local is None:
+            return
+        sd = pretrained_encoder_state_dict(local, self.encoder_base)
+        if sd is None:
+            return
+        in_dim = self.arch.hidden_size * (self.downsample_factor if self.downsample_method == "stack" else 1)
+        seed = getattr(self.config, "seed_everything", 0)
+        sd.update(init_embed_projection(in_dim, self.llm_dim, 0 if seed is None else int(seed)))
+        self.pretrained_from = local
+        self.load_state_dict(sd)
 
     # -- nn.Module-like surface the reference's callers use ------------------------------------
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -127,7 +149,10 @@ class AudioEncoder:
 
     def state_dict(self):
         if self._state is None:
-            raise L.SpeechLLMError("AudioEncoder has no weights yet: call load_state_dict first")
+            raise L.SpeechLLMError(
+                f"AudioEncoder has no weights yet: no pretrained checkpoint for '{self.config.model.audio_encoder.type}' was found "
+                "(model.audio_encoder.type must be a local HF directory with config.json + model.safetensors / pytorch_model.bin, or "
+                "a hub id already in the local HF cache — there is no network), and load_state_dict has not been called")
         return dict(self._state)
 
     def eval(self):

@@ -37,7 +37,8 @@ class LLMSpeechTextInference():
             checkpoint = audio_encoder_checkpoint
             if isinstance(checkpoint, str):
                 checkpoint = torch.load(checkpoint, map_location="cpu")
-            audio_encoder = AudioEncoder(self.config, self.device, dtype=dtype)
+            # load_pretrained=False: the checkpoint below overwrites every tensor the reference's constructor would have fetched
+            audio_encoder = AudioEncoder(self.config, self.device, dtype=dtype, load_pretrained=False)
             audio_encoder.load_state_dict(checkpoint)
         self.audio_encoder = audio_encoder.eval().to(self.device)
 

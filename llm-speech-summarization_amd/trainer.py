@@ -53,6 +53,9 @@ class Trainer():
             os.makedirs(self.checkpoint_save_dir, exist_ok=True)
             os.makedirs(self.log_dir, exist_ok=True)
         self.encoder_base = config.model.audio_encoder.base
+        # ref:trainer.py:44-46 + ref:model/audio_encoder.py:6-13,34-52: a run without `-p` starts from the PRETRAINED encoder named by
+        # config.model.audio_encoder.type and a freshly initialised embed_projection (drawn from config.seed_everything alone, so
+        # every rank starts from the same weights although the ranks' own RNG streams differ)
         self.audio_encoder = audio_encoder or AudioEncoder(config, self.device, dtype=dtype)
         self.llm_type = config.model.llm_type
         if tokenizer is None:
@@ -73,12 +76,42 @@ class Trainer():
         total_iters = self.num_epochs * len(self.train_dataset) // self.grad_accum_interval     # ref:trainer.py:106-110 (global steps)
         # ref:trainer.py:258 puts the encoder in train() mode: HF's dropouts, LayerDrop and SpecAugment are active during the
         # optimisation step (validate() runs the inference path, i.e. eval mode, ref:trainer.py:402)
-        reg = None if getattr(args, "no_regularizers", False) else TrainRegularizers(seed=seed)
+        reg = None if getattr(args, "no_regularizers", False) else self._regularizers(seed)
         self.kd = KDTrainer(config, self.audio_encoder.to(self.device), self.llm, self.prefix_ids, self.suffix_ids,
                             total_optimizer_steps=max(1, total_iters), regularizers=reg)
         self.optimizer, self.lr_scheduler = self.kd.optimizer, self.kd.scheduler
         if getattr(self.args, "checkpoint_path", None):
             self.load_checkpoint(self.args.checkpoint_path)
+        self._sync_masters()
+
+    def _regularizers(self, seed: int) -> TrainRegularizers:
+        """The training-mode regularisers HF's module would apply in train() mode (ref:trainer.py:258): read from the encoder's own
+        config.json when the encoder came from a local checkpoint directory, else the published values of the two encoders the
+        shipped configs name (hubert-large-ls960-ft; whisper-medium, which has every dropout at 0 and no SpecAugment)."""
+        from .weights import resolve_pretrained_dir
+        local = resolve_pretrained_dir(self.config.model.audio_encoder.type)
+        d = None
+        if local and os.path.exists(os.path.join(local, "config.json")):
+            with open(os.path.join(local, "config.json")) as f:
+                d = json.load(f)
+        if self.encoder_base == "whisper":
+            return TrainRegularizers.from_whisper_config(d or {}, seed=seed)
+        return TrainRegularizers.from_hf_config(d, seed=seed) if d is not None else TrainRegularizers(seed=seed)
+
+    def _sync_masters(self) -> None:
+        """Data parallel: every rank applies the same all-reduced gradient, so every rank must START from the same weights.  The
+        cold start and the checkpoint are rank-independent by construction; the broadcast from rank 0 makes it unconditional
+        (318 M fp32 once per run)."""
+        if self.dist is None or self.world == 1:
+            return
+        cpu_group = self.dist.get_backend() != "nccl"
+        for k in self.kd.param_names:
+            t = self.kd.master[k]
+            buf = t.cpu() if cpu_group else t
+            self.dist.broadcast(buf, src=0)
+            if cpu_group:
+                t.copy_(buf)
+        self.audio_encoder.refresh_weights(self.kd.master)
 
     # -- checkpoints (ref:trainer.py:116-132, 516-528) ---------------------------------------------
     def load_checkpoint(self, checkpoint_path):

@@ -60,6 +60,14 @@ class TrainRegularizers:
                                  d.get("attention_dropout", 0.1), d.get("layerdrop", 0.1), d.get("apply_spec_augment", True), d.get("mask_time_prob", 0.05),
                                  d.get("mask_time_length", 10), d.get("mask_time_min_masks", 2), seed)
 
+    @staticmethod
+    def from_whisper_config(d: dict, seed: int = 1234) -> "TrainRegularizers":
+        """hf:models/whisper/configuration_whisper.py names: `dropout` (after attention / FFN), `activation_dropout`,
+        `attention_dropout`, `encoder_layerdrop`; whisper-medium ships all of them at 0 and apply_spec_augment false.
+        WhisperEncoder has no feature-projection dropout, and its SpecAugment acts on the log-mel input (not built: off)."""
+        return TrainRegularizers(0.0, d.get("dropout", 0.0), d.get("activation_dropout", 0.0), d.get("attention_dropout", 0.0),
+                                 d.get("encoder_layerdrop", 0.0), False, 0.0, 10, 2, seed)
+
 
 def compute_mask_indices(shape: Tuple[int, int], mask_prob: float, mask_length: int, min_masks: int = 0) -> np.ndarray:
     """SpecAugment span mask, restating transformers 4.47 `_compute_mask_indices` (hf:models/hubert/modeling_hubert.py,
@@ -807,7 +815,11 @@ class KDTrainer:
             n = ns[u]
             lab_rows.append(torch.cat([response_ids[u][1:].to(torch.int32), torch.full((1,), -1, dtype=torch.int32, device=dev)]))
             ld_on = 1.0 if self.use_ld else 0.0
-            coef_rows += [[1.0 / (n - 1), self.ntp_w * inv_acc / (n - 1), ld_on / n, ld_on * self.ld_w * inv_acc / n]] * n
+            # a one-token response has no next-token target (its only row carries label -1): the reference's mean over zero
+            # targets is NaN (ref:model/audio_llama.py:84-91) and poisons every weight; here the term contributes nothing — the
+            # same on every rank, so a data-parallel window never stalls on it
+            inv_n1 = 1.0 / (n - 1) if n > 1 else 0.0
+            coef_rows += [[inv_n1, self.ntp_w * inv_acc * inv_n1, ld_on / n, ld_on * self.ld_w * inv_acc / n]] * n
             slot_rows += [u] * n
             mse_rows += [[1.0 / (n * H_llm), 2.0 * self.fd_w * inv_acc / (n * H_llm)]] * n
         labels = torch.cat(lab_rows).contiguous()

@@ -132,6 +132,95 @@ def normalize_encoder_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch
     return sd
 
 
+def resolve_pretrained_dir(type_str: str) -> Optional[str]:
+    """Where `AutoModel.from_pretrained(type_str)` (ref:model/audio_encoder.py:6-13) would read from without a network: the
+    path itself when it is a directory, else the newest snapshot of that hub id in the local HF cache (HF_HUB_CACHE /
+    HF_HOME / ~/.cache/huggingface/hub, `models--org--name/snapshots/<rev>/`).  None when neither exists."""
+    import os
+    if os.path.isdir(type_str):
+        return type_str
+    roots = [os.environ.get("HF_HUB_CACHE"), os.environ.get("HUGGINGFACE_HUB_CACHE"),
+             os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
+             os.path.join(os.path.expanduser("~"), ".cache", "huggingface", "hub")]
+    for root in roots:
+        if not root:
+            continue
+        snaps = os.path.join(root, "models--" + type_str.replace("/", "--"), "snapshots")
+        if os.path.isdir(snaps):
+            revs = [os.path.join(snaps, r) for r in os.listdir(snaps)]
+            revs = [r for r in revs if os.path.exists(os.path.join(r, "config.json"))]
+            if revs:
+                return max(revs, key=os.path.getmtime)
+    return None
+
+
+def read_hf_weight_files(path: str) -> Optional[Dict[str, torch.Tensor]]:
+    """Every tensor of an HF checkpoint directory: `model.safetensors`, sharded `model-0000x-of-0000y.safetensors`, or the
+    older `pytorch_model.bin` / `pytorch_model-*.bin` pickles (tensors only).  None when the directory holds no weights."""
+    import os
+    names = sorted(os.listdir(path))
+    st = [n for n in names if n.endswith(".safetensors")]
+    sd: Dict[str, torch.Tensor] = {}
+    if st:
+        from safetensors.torch import load_file
+        for n in st:
+            sd.update(load_file(os.path.join(path, n)))
+        return sd
+    bins = [n for n in names if n.startswith("pytorch_model") and n.endswith(".bin")]
+    for n in bins:
+        sd.update(torch.load(os.path.join(path, n), map_location="cpu", weights_only=True))
+    return sd or None
+
+
+def pretrained_encoder_state_dict(path: str, base: str) -> Optional[Dict[str, torch.Tensor]]:
+    """The `encoder.*` half of the reference AudioEncoder's state-dict, read from an HF checkpoint directory the way
+    ref:model/audio_encoder.py:6-13 gets it from `AutoModel.from_pretrained`:
+      hubert  -> HubertModel: keys of a bare HubertModel as they are, keys of a head model (HubertForCTC, e.g.
+                 hubert-large-ls960-ft) with their `hubert.` base-model prefix stripped and the head (`lm_head.*`) dropped;
+      whisper -> WhisperModel(...).encoder: `encoder.*` of a bare WhisperModel or `model.encoder.*` of
+                 WhisperForConditionalGeneration; the decoder and `proj_out` are dropped.
+    Tensors come back fp32 under `encoder.<HF name>` (the attribute the reference stores the module under).  `embed_projection`
+    is not part of any pretrained checkpoint: `init_embed_projection` draws it."""
+    raw = read_hf_weight_files(path)
+    if raw is None:
+        return None
+    out: Dict[str, torch.Tensor] = {}
+    if base == "hubert":
+        prefixed = any(k.startswith("hubert.") for k in raw)
+        for k, v in raw.items():
+            if prefixed:
+                if not k.startswith("hubert."):
+                    continue                                   # lm_head.* of the CTC head
+                k = k[len("hubert."):]
+            elif k.startswith(("lm_head.", "classifier.", "projector.")):
+                continue
+            out["encoder." + k] = v.float()
+        need = "encoder.feature_projection.projection.weight"
+    else:
+        for k, v in raw.items():
+            if k.startswith("model.encoder."):
+                out[k[len("model."):]] = v.float()
+            elif k.startswith("encoder."):
+                out[k] = v.float()
+        need = "encoder.conv1.weight"
+    if need not in out:
+        raise L.SpeechLLMError(f"{path}: no {base} encoder weights among {len(raw)} tensors (first keys {sorted(raw)[:3]})")
+    return out
+
+
+def init_embed_projection(in_features: int, out_features: int, seed: int) -> Dict[str, torch.Tensor]:
+    """`nn.Linear(in, out)`'s default initialisation (torch/nn/modules/linear.py reset_parameters: kaiming_uniform_(a=sqrt 5)
+    = U(-1/sqrt(in), 1/sqrt(in)) for the weight, the same bound for the bias) — what ref:model/audio_encoder.py:39-52 gets for
+    `embed_projection`.  The reference draws it from whatever state the CPU RNG is in (it seeds only the CUDA RNG,
+    ref:trainer.py:33); here the draw comes from a private generator seeded by `seed` alone, so every data-parallel rank starts
+    from the same projection whatever its own RNG streams are seeded with."""
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    bound = 1.0 / math.sqrt(in_features)
+    w = (torch.rand(out_features, in_features, generator=g, dtype=torch.float32) * 2 - 1) * bound
+    b = (torch.rand(out_features, generator=g, dtype=torch.float32) * 2 - 1) * bound
+    return {"embed_projection.weight": w, "embed_projection.bias": b}
+
+
 _WN_PAIRS = (("parametrizations.weight.original0", "weight_g"), ("parametrizations.weight.original1", "weight_v"))
 
 

@@ -30,7 +30,7 @@ from oracle.hubert_oracle import HubertCfg  # noqa: E402
 from oracle.llama_oracle import LlamaCfg  # noqa: E402
 
 from oracle.golden_cfgs import (LLAMA_ID, MINICHAT_ID, TINY_HUBERT, WIDE_HUBERT, TINY_LLAMA, TINY_MHA,  # noqa: E402
-                                WIDE_LLAMA, TINY_WHISPER)
+                                WIDE_LLAMA, TINY_WHISPER, WIDE_WHISPER)
 
 
 def import_reference():
@@ -411,11 +411,103 @@ def gen_validation(enc_mod, llama_mod, utils):
 
 
 
+@torch.no_grad()
+def gen_coldstart(enc_mod):
+    """ref:model/audio_encoder.py:6-13,34-52 as a cold start: the reference AudioEncoder is handed a checkpoint DIRECTORY and
+    nothing else, so `AutoModel.from_pretrained` has to find the encoder's tensors inside a head model's files
+    (HubertForCTC: `hubert.` prefix + `lm_head`, what facebook/hubert-large-ls960-ft ships; WhisperForConditionalGeneration:
+    `model.encoder.` + decoder + `proj_out`, what openai/whisper-medium ships) and `embed_projection` is whatever nn.Linear drew.
+    The fixture keeps the projection the reference drew, the hidden states in front of it and the final embeddings; the test
+    rebuilds the same directory from the same seeds on the GPU box."""
+    from transformers import HubertForCTC, WhisperConfig, WhisperFeatureExtractor, WhisperForConditionalGeneration
+    # HuBERT
+    c = TINY_HUBERT
+    tmp = tempfile.mkdtemp(prefix="hubert_ctc_")
+    hf_cfg = hf_hubert_config(c)
+    ctc = HubertForCTC(hf_cfg)
+    sd = ri.hubert_encoder_state_dict(c, 256, seed=81)
+    body = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    missing, unexpected = ctc.hubert.load_state_dict(body, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    ctc.save_pretrained(tmp)
+    cfg = SimpleNamespace(model=SimpleNamespace(
+        audio_encoder=SimpleNamespace(base="hubert", type=tmp, downsample_method="pool", downsample_factor=4,
+                                      pooling=SimpleNamespace(kernel_size=8, stride=4)),
+        llm_embedding_channels=256))
+    torch.manual_seed(4242)
+    m = enc_mod.AudioEncoder(cfg, torch.device("cpu")).eval()
+    got = m.state_dict()
+    for k, v in sd.items():                       # the reference really holds the checkpoint's encoder
+        if k.startswith("encoder.") and "pos_conv_embed" not in k:
+            assert torch.equal(got[k], v), k
+    wave = ri.synthetic_waveform(24000, seed=808)[None]
+    hidden = m.encoder(wave).last_hidden_state
+    save("coldstart_hubert", weight_seed=81, wave_seed=808, n_samples=24000, last_hidden_state=hidden, audio_embeds=m(wave),
+         proj_w=m.embed_projection.weight, proj_b=m.embed_projection.bias)
+    # Whisper
+    c = TINY_WHISPER
+    tmp = tempfile.mkdtemp(prefix="whisper_gen_")
+    wcfg = WhisperConfig(d_model=c.d_model, encoder_layers=c.encoder_layers, encoder_attention_heads=c.encoder_attention_heads,
+                         encoder_ffn_dim=c.encoder_ffn_dim, num_mel_bins=c.num_mel_bins, max_source_positions=c.max_source_positions,
+                         decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64, vocab_size=64, max_target_positions=16,
+                         dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, pad_token_id=0,
+                         bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+    gen = WhisperForConditionalGeneration(wcfg)
+    sd = ri.whisper_encoder_state_dict(c, 256, seed=82)
+    body = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    missing, unexpected = gen.model.encoder.load_state_dict(body, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    gen.save_pretrained(tmp)
+    WhisperFeatureExtractor(feature_size=c.num_mel_bins, sampling_rate=16000, hop_length=c.hop_length, chunk_length=2, n_fft=c.n_fft).save_pretrained(tmp)
+    cfg = SimpleNamespace(model=SimpleNamespace(
+        audio_encoder=SimpleNamespace(base="whisper", type=tmp, downsample_method="pool", downsample_factor=4,
+                                      pooling=SimpleNamespace(kernel_size=8, stride=4)),
+        llm_embedding_channels=256))
+    torch.manual_seed(4343)
+    m = enc_mod.AudioEncoder(cfg, torch.device("cpu")).eval()
+    wave = ri.synthetic_waveform(30000, seed=909).numpy()
+    feats = m.feature_extractor([wave], return_tensors="pt", sampling_rate=16000).input_features
+    save("coldstart_whisper", weight_seed=82, wave_seed=909, n_samples=30000, input_features=feats,
+         last_hidden_state=m.encoder(feats).last_hidden_state, audio_embeds=m(feats), proj_w=m.embed_projection.weight,
+         proj_b=m.embed_projection.bias)
+
+
+@torch.no_grad()
+def gen_whisper_wide(enc_mod):
+    """BASELINE configs[3] at Whisper-medium WIDTH (d_model 1024, 16 heads, FFN 4096, 80 mel bins, 1 500 positions = one 30 s
+    window, llm_dim 3072), 2 layers: HF feature extractor + reference AudioEncoder.  Kept small: the log-mel input, every 4th
+    row of the embeddings, 64 rows of the last hidden state."""
+    from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperModel
+    c = WIDE_WHISPER
+    tmp = tempfile.mkdtemp(prefix="whisper_wide_")
+    hf_cfg = WhisperConfig(d_model=c.d_model, encoder_layers=c.encoder_layers, encoder_attention_heads=c.encoder_attention_heads,
+                           encoder_ffn_dim=c.encoder_ffn_dim, num_mel_bins=c.num_mel_bins, max_source_positions=c.max_source_positions,
+                           decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64, vocab_size=64, max_target_positions=16,
+                           dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, pad_token_id=0,
+                           bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+    WhisperModel(hf_cfg).save_pretrained(tmp)
+    WhisperFeatureExtractor(feature_size=c.num_mel_bins, sampling_rate=16000, hop_length=c.hop_length, chunk_length=30, n_fft=c.n_fft).save_pretrained(tmp)
+    cfg = SimpleNamespace(model=SimpleNamespace(
+        audio_encoder=SimpleNamespace(base="whisper", type=tmp, downsample_method="pool", downsample_factor=4,
+                                      pooling=SimpleNamespace(kernel_size=8, stride=4)),
+        llm_embedding_channels=3072))
+    m = enc_mod.AudioEncoder(cfg, torch.device("cpu"))
+    m.load_state_dict(ri.whisper_encoder_state_dict(c, 3072, seed=91), strict=True)
+    m.eval()
+    n = 400000                                                  # 25 s, padded to the 30 s window by the feature extractor
+    wave = ri.synthetic_waveform(n, seed=1717).numpy()
+    feats = m.feature_extractor([wave], return_tensors="pt", sampling_rate=16000).input_features
+    hidden = m.encoder(feats).last_hidden_state
+    out = m(feats)
+    save("whisper_wide", weight_seed=91, wave_seed=1717, n_samples=n, input_features=feats, audio_embeds_every4=out[:, ::4],
+         last_hidden_rows=hidden[:, ::24], P=out.shape[1])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     enc_mod, llama_mod, utils = import_reference()
-    which = sys.argv[1:] or ["encoder", "llama", "pipeline", "whisper", "whisper_pipeline", "validation"]
+    which = sys.argv[1:] or ["encoder", "llama", "pipeline", "whisper", "whisper_pipeline", "validation", "coldstart", "whisper_wide"]
     if "encoder" in which:
         gen_encoder(enc_mod)
     if "llama" in which:
@@ -428,6 +520,10 @@ def main():
         gen_whisper_pipeline(enc_mod, llama_mod, utils)
     if "validation" in which:
         gen_validation(enc_mod, llama_mod, utils)
+    if "coldstart" in which:
+        gen_coldstart(enc_mod)
+    if "whisper_wide" in which:
+        gen_whisper_wide(enc_mod)
 
 
 if __name__ == "__main__":

@@ -28,3 +28,6 @@ WIDE_LLAMA = LlamaCfg(num_hidden_layers=2, eos_token_ids=(128001, 128008, 128009
 # tiny Whisper: 2 s chunks (200 mel frames -> 100 positions), head_dim 64
 TINY_WHISPER = WhisperCfg(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, num_mel_bins=80,
                           max_source_positions=100)
+# Whisper-medium width (d_model 1024, 16 heads, FFN 4096, 80 mel bins, 1 500 positions = one 30 s window), 2 layers
+WIDE_WHISPER = WhisperCfg(d_model=1024, encoder_layers=2, encoder_attention_heads=16, encoder_ffn_dim=4096, num_mel_bins=80,
+                          max_source_positions=1500)

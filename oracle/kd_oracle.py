@@ -64,7 +64,7 @@ def generate_audio_response_ids(sd_llm, cfg: LlamaCfg, audio_embeds, prefix_ids,
 
 
 def kd_losses(sd_llm, cfg: LlamaCfg, audio_embeds, text_ids, response_ids, prefix_ids, suffix_ids,
-              connector_layers=(0, 5, 11, 17, 23), ntp_w=0.5, ld_w=0.5, fd_w=1.0):
+              connector_layers=(0, 5, 11, 17, 23), ntp_w=0.5, ld_w=0.5, fd_w=1.0, tail_logits_only=False):
     """One KD micro-step's losses for batch size 1 (ref:trainer.py:299-370).
 
     audio_embeds (1,P,h) may carry grad; text_ids / response_ids are 1-D id tensors already stripped of
@@ -73,13 +73,14 @@ def kd_losses(sd_llm, cfg: LlamaCfg, audio_embeds, text_ids, response_ids, prefi
     a_seq = merge_prompt_response_tokens(sd_llm, prefix_ids, suffix_ids, audio_embeds, response_ids[None])
     t_seq = merge_prompt_response_tokens(sd_llm, prefix_ids, suffix_ids, embed(sd_llm, text_ids[None]),
                                          response_ids[None])
+    n = response_ids.shape[0]
+    last_n = n if tail_logits_only else None      # every loss below reads logits[-n:] only
     a = llama_forward(sd_llm, cfg, a_seq, attention_mask=torch.ones(1, a_seq.shape[1], dtype=torch.long),
-                      output_hidden_states=True)
+                      output_hidden_states=True, logits_last_n=last_n)
     ntp = response_only_loss(a["logits"], [response_ids])
     with torch.no_grad():
         t = llama_forward(sd_llm, cfg, t_seq, attention_mask=torch.ones(1, t_seq.shape[1], dtype=torch.long),
-                          output_hidden_states=True)
-    n = response_ids.shape[0]
+                          output_hidden_states=True, logits_last_n=last_n)
     ld = soft_cross_entropy(a["logits"][:, -n:, :], t["logits"][:, -n:, :])
     fd = 0.0
     for li in connector_layers:

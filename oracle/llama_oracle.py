@@ -100,8 +100,11 @@ def llama_forward(
     past: Optional[List[Tuple[torch.Tensor, torch.Tensor]]] = None,
     output_hidden_states: bool = False,
     last_logits_only: bool = False,
+    logits_last_n: Optional[int] = None,
 ):
     """LlamaModel.forward + lm_head.
+    `logits_last_n`: lm_head on the last n positions only (the rows ref:model/audio_llama.py:84-89 / ref:trainer.py:325-340
+    read; the other rows of HF's all-position logits never reach a loss) — keeps a 128 256-way vocabulary affordable on CPU.
 
     inputs_embeds (B,S,h); attention_mask (B, past+S) 0/1 with LEFT padding or None.
     Position ids are arange(S)+past_len irrespective of padding (hf:...llama.py:386-389).
@@ -163,7 +166,8 @@ def llama_forward(
     if output_hidden_states:
         hiddens.append(x)
     head = sd["lm_head.weight"] if "lm_head.weight" in sd else sd["model.embed_tokens.weight"]
-    logits = F.linear(x[:, -1:] if last_logits_only else x, head.float())
+    rows = x[:, -1:] if last_logits_only else (x[:, -int(logits_last_n):] if logits_last_n else x)
+    logits = F.linear(rows, head.float())
     return dict(logits=logits, hidden_states=tuple(hiddens), past=new_past, last_hidden=x)
 
 

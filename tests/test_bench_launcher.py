@@ -1,0 +1,55 @@
+"""CPU: `python bench.py --gpus N` run as ONE process starts N ranks itself (child processes under torch.distributed.run), forwards
+rank 0's JSON line as its only stdout line and hands back the children's exit code.  SL_BENCH_DRY=1 keeps the ranks off the GPU:
+gloo rendezvous + the barrier / max-over-ranks timing bracket, nothing else."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import REPO
+
+BENCH = os.path.join(REPO, "bench.py")
+
+
+def run(extra_env, *argv):
+    env = dict(os.environ, SL_BENCH_DRY="1", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, BENCH, *argv], capture_output=True, text=True, env=env, timeout=300, cwd="/tmp")
+
+
+def test_gpus_2_launches_two_ranks_and_forwards_one_line():
+    r = run({}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1                                   # the ranks' stray stdout went to stderr
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert "a stray stdout line from a rank" in r.stderr
+
+
+def test_wrong_n_gpus_in_the_line_is_an_error():
+    r = run({"SL_BENCH_DRY_REPORT_GPUS": "1"}, "--gpus", "2", "--steps", "2")
+    assert r.returncode == 4 and "n_gpus=1" in r.stderr
+
+
+def test_a_failing_rank_fails_the_launch():
+    r = run({"SL_BENCH_DRY_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "2")
+    assert r.returncode != 0
+
+
+def test_world_size_mismatch_is_refused_before_any_gpu_work():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1"], capture_output=True, text=True, env=env, timeout=120, cwd="/tmp")
+    assert r.returncode == 4 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_launched_by_torchrun_directly_as_the_driver_does():
+    """The driver's own form: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ..."""
+    env = dict(os.environ, SL_BENCH_DRY="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0"], capture_output=True, text=True,
+                       env=env, timeout=300, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2

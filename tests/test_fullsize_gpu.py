@@ -305,3 +305,78 @@ def test_longform_prompt_llama32_width_fp32_ids_and_bf16_hidden():
     llm = llama_mod.AudioLlamaForCausalLM(arch, dict(sd), torch_dtype=torch.bfloat16, device=DEV, max_ctx=1600)
     outq = llm(inputs_embeds=x.to(DEV), output_hidden_states=True)
     assert rel_err(torch.stack(outq.hidden_states).float().cpu(), torch.stack(refq["hidden_states"])) < BF16_TOL
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# round 3: the timed shapes under the oracle
+# ------------------------------------------------------------------------------------------------------------------------
+def test_configs1_full_depth_fp32_generate_audio_response_ids_vs_oracle(llama3):
+    """north_star's literal target: `generate_audio_response` (ref:inference.py:95-137) on HuBERT-large 24 L -> Llama-3.2-3B 28 L in
+    the fp32 parity mode, one 10 s utterance, 16 greedy tokens — ids identical to the CPU oracle's on every margin-qualified
+    step (a step qualifies while the oracle's top-2 logit gap exceeds 100 x the measured logit disagreement)."""
+    from test_models_gpu import StubTokenizer
+    inf_mod = pkg("inference")
+    m, new = llama3, 16
+    hc, lc = _oracle_cfgs(m.harch, m.larch)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    conf = cfgm.load_config(os.path.join(REPO, "config", "llama3_hubert.yaml"))
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=torch.float32, arch=m.harch)
+    enc.load_state_dict(m.enc_sd).eval().to(DEV)
+    llm = llama_mod.AudioLlamaForCausalLM(m.larch, dict(m.llm_sd_host), torch_dtype=torch.float32, device=DEV, max_ctx=256, max_batch=1)
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: m.prefix, utils.LLAMA_PROMPT_SUFFIX: m.suffix})
+    inf = inf_mod.LLMSpeechTextInference(conf, None, DEV, tokenizer=tok, llm=llm, audio_encoder=enc, dtype=torch.float32)
+    wave = ri.synthetic_waveform(160000, seed=1234)
+    text = inf.generate_audio_response(wave.numpy(), max_new_tokens=new)
+    ids = inf.last_generate_ids.cpu()
+    assert ids.shape[0] == 1 and text == " ".join(str(int(i)) for i in ids[0])
+    with torch.no_grad():
+        ref_audio = ho.audio_encoder_forward(m.enc_sd, hc, wave[None])
+        emb = m.llm_sd_host["model.embed_tokens.weight"]
+        prompt = torch.cat([emb[m.prefix[0]], ref_audio[0], emb[m.suffix[0, 1:]]])[None]
+        assert prompt.shape[1] == 137
+        ref_ids, margins = lo.greedy_generate(m.llm_sd_host, lc, prompt, new, use_eos=True, return_margins=True)
+        ref_last = lo.llama_forward(m.llm_sd_host, lc, prompt, last_logits_only=True)["logits"][0, -1]
+    # how far the two fp32 pipelines are apart at the first new position (24 + 28 layers, different summation orders)
+    audio = enc(wave[None].to(DEV))
+    e_audio = rel_err(audio.float().cpu(), ref_audio)
+    x = torch.cat([emb[m.prefix[0]].to(DEV), audio[0], emb[m.suffix[0, 1:]].to(DEV)])[None]
+    got_last = llm(inputs_embeds=x).logits[0, -1].cpu()
+    gap = float((got_last - ref_last).abs().max())
+    print(f"fp32 full depth: audio embeddings rel err {e_audio:.2e}, max |logit difference| {gap:.2e}, oracle margins {margins[0].tolist()}")
+    assert e_audio < 1e-4 and rel_err(got_last, ref_last) < 1e-4
+    qualified = 0
+    for k in range(ref_ids.shape[1]):
+        if float(margins[0, k]) <= 100 * gap:
+            break                              # a near tie: from here on the two runs may legitimately follow different tokens
+        assert int(ids[0, k]) == int(ref_ids[0, k]), (k, ids.tolist(), ref_ids.tolist())
+        qualified += 1
+    print("margin-qualified steps with identical ids:", qualified, "of", ref_ids.shape[1])
+    assert qualified >= 8
+
+
+@pytest.mark.parametrize("B", [1024, 512])
+def test_configs1_decode_step_logits_large_batch_vs_small_batch_and_oracle(llama3, B):
+    """The decode step bench.py times (28 layers at Llama-3.2-3B width, bf16): B rows through the 256 x 128 streaming family
+    (K = 3 072 / 8 192, N = 5 120 / 16 384 unsplit and 2-split forms, tiled lm_head, single-pass attention) against the SAME
+    sequences three at a time (skinny family, split attention) — asserted, not printed — and one sequence against the oracle."""
+    from test_models_gpu import _decode_step_logits
+    m = llama3
+    base = [ri.synthetic_waveform(n, seed=1234 + i).to(DEV) for i, n in enumerate((160000, 112000, 160000))]
+    x3, lens3, st3 = m.prompts(base)
+    prompts = [x3[st3[i]:st3[i + 1]].clone() for i in range(3)]
+    nxt = [101, 20202, 99999]
+    small = _decode_step_logits(m.llm, prompts, nxt)
+    big = _decode_step_logits(m.llm, [prompts[b % 3] for b in range(B)], [nxt[b % 3] for b in range(B)])
+    worst = max(rel_err(big[b], small[b % 3]) for b in range(B))
+    print(f"B={B}: worst relative L2 distance of a row's decode-step logits from the 3-sequence run: {worst:.2e}")
+    assert worst < 1e-2
+    for b in range(3, B):                      # and copies of a sequence are bit-identical rows
+        assert torch.equal(big[b], big[b % 3]), b
+    if B == 1024:
+        hc, lc = _oracle_cfgs(m.harch, m.larch)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        with torch.no_grad():
+            emb = m.llm_sd_host["model.embed_tokens.weight"]
+            seq = torch.cat([prompts[1].float().cpu(), emb[nxt[1]][None]])[None]
+            ref = lo.llama_forward(m.llm_sd_host, lc, seq, last_logits_only=True)["logits"][0, -1]
+        assert rel_err(big[1], ref) < FULL_TOL and rel_err(small[1], ref) < FULL_TOL

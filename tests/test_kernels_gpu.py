@@ -645,3 +645,47 @@ def test_sample_select_follows_hf_logits_warpers(V, temperature, top_k, top_p):
             ops.sample_select(dl, temperature, top_k, top_p, sd, [], 5, False, unfinished, ctx, cnt, fin, nxt, out2)
             seen.add(int(out2[0, 0]))
         assert seen == set(torch.nonzero(allowed[0]).flatten().tolist())
+
+
+@pytest.mark.parametrize("M", [512, 1024])
+def test_gemm_packed_at_the_benchmarked_decode_shapes(M):
+    """The five Linears of a Llama-3.2-3B decode step at bench.py's row counts, bf16, each as the decode graph launches it
+    (gemm_stream_wide_kernel unsplit / K-split + reduce by the library's own rule): qkv-shaped N = 5 120 with in-kernel RMS
+    statistics, o (K = 3 072, residual, row scale out), gate/up N = 16 384 with SiLU-mul and the handed-in scale, down (K = 8 192,
+    residual), and an lm_head slice in fp32 — against an fp32 reference, and against the skinny family on 16-row slices."""
+    dt = torch.bfloat16
+    H, Fd, NQ = 3072, 8192, 5120
+    x = rnd(M, H, seed=71)
+    xd, xf = x.to(dev(), dt), q(x, dt)
+    rstd = torch.rsqrt(xf.pow(2).mean(-1) + 1e-5)
+    # qkv-shaped: fused RMSNorm (gain folded into W on the host, as weights.build_decode_weights does)
+    wq = rnd(NQ, H, seed=72, std=H ** -0.5)
+    wqp = ops.pack_weight(wq.to(dev(), dt))
+    out = ops.gemm_decode(xd, wqp, NQ, fuse_rms=True, eps=1e-5)
+    ref = (xf * rstd[:, None]) @ q(wq, dt).T
+    assert rel_err(out.float().cpu(), ref) < TOL[dt]
+    sk = torch.cat([ops.gemm_decode(xd[r:r + 16], wqp, NQ, fuse_rms=True, eps=1e-5) for r in (0, M // 2, M - 16)])
+    assert rel_err(torch.cat([out[r:r + 16] for r in (0, M // 2, M - 16)]).float().cpu(), sk.float().cpu()) < 6e-3   # one bf16 rounding of the outputs apart
+    # o: K = 3072 -> N = 3072 with residual, emitting the next RMSNorm's row scale
+    wo, res = rnd(H, H, seed=73, std=H ** -0.5), rnd(M, H, seed=74)
+    r_out = torch.empty(M, device=dev(), dtype=torch.float32)
+    o = ops.gemm_decode(xd, ops.pack_weight(wo.to(dev(), dt)), H, residual=res.to(dev(), dt), rstd_out=r_out, eps=1e-5)
+    o_ref = xf @ q(wo, dt).T + q(res, dt)
+    assert rel_err(o.float().cpu(), o_ref) < TOL[dt]
+    if L.lib().sl_gemm_split_count(M, H, H, L.dtype_code(dt)) > 1:          # the scale rides on the reduce pass
+        assert rel_err(r_out.cpu(), torch.rsqrt(o.float().cpu().pow(2).mean(-1) + 1e-5)) < 2e-3
+    # gate/up: N = 16 384 interleaved pairs, SiLU-mul epilogue, handed-in scale
+    g, u = rnd(Fd, H, seed=75, std=H ** -0.5), rnd(Fd, H, seed=76, std=H ** -0.5)
+    wgu = ops.pack_weight(weights.interleave_gate_up(g, u).to(dev(), dt))
+    a = ops.gemm_decode(xd, wgu, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, rstd_in=rstd.to(dev()))
+    a_ref = F.silu((xf * rstd[:, None]) @ q(g, dt).T) * ((xf * rstd[:, None]) @ q(u, dt).T)
+    assert rel_err(a.float().cpu(), a_ref) < TOL[dt]
+    # down: K = 8192 -> N = 3072 with residual
+    y = rnd(M, Fd, seed=77)
+    wd = rnd(H, Fd, seed=78, std=Fd ** -0.5)
+    d = ops.gemm_decode(y.to(dev(), dt), ops.pack_weight(wd.to(dev(), dt)), H, residual=res.to(dev(), dt))
+    assert rel_err(d.float().cpu(), q(y, dt) @ q(wd, dt).T + q(res, dt)) < TOL[dt]
+    # lm_head slice: fp32 logits of 20 000 vocabulary rows
+    wl = rnd(20000, H, seed=79, std=H ** -0.5)
+    lg = ops.gemm_decode(xd, ops.pack_weight(wl.to(dev(), dt)), 20000, fuse_rms=True, eps=1e-5, out_f32=True)
+    assert rel_err(lg.cpu(), (xf * rstd[:, None]) @ q(wl, dt).T) < 2e-3

@@ -391,3 +391,59 @@ def test_validate_perplexities_match_reference_fixture(tmp_path):
         assert abs(float(llm(inputs_embeds=a_seq, labels=[resp]).loss) - float(v["audio_nll"][i])) < 1e-4 * float(v["audio_nll"][i]), i
     line = [l for l in open(tmp_path / "logs" / "v" / "metrics.jsonl")][-1]
     assert "validation/audio_perplexity" in line and "audio_response" in line
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_kd_window_at_benchmark_width_vs_oracle_autograd(dtype):
+    """BASELINE configs[2] at the width bench.py's KD leg runs (ref:trainer.py:270-384): HuBERT-large width x 2 layers + Llama-3.2-3B
+    width x 2 layers with the full 128 256-way vocabulary, ONE accumulation window of 16 utterances (5-10 s, ragged) as a packed
+    micro-batch — the 128^2 / 256^2 GEMMs at M ~ 3 000 rows, the transposed-operand gradient products, the C++ tape, the
+    128 256-way loss kernel.  Losses and EVERY encoder parameter gradient against autograd through the CPU oracle, one utterance
+    at a time as the reference loops.  fp32: losses <= 1e-5 relative, gradients <= 2e-3 of each parameter's norm (measured ~1e-5);
+    bf16 (same bf16-rounded weights on both sides): losses <= 2e-2, gradients <= 0.12 per parameter and <= 5e-2 over all."""
+    import os
+    from oracle.golden_cfgs import WIDE_HUBERT, WIDE_LLAMA
+    HC, LC = WIDE_HUBERT, WIDE_LLAMA
+    enc, enc_sd = make_encoder(HC, LC.hidden_size, 91, dtype)
+    llm, llm_sd = make_llama(LC, 92, dtype, max_ctx=512)
+    prefix, suffix = ri.synthetic_ids(9, LC.vocab_size, seed=7, bos=128000), ri.synthetic_ids(6, LC.vocab_size, seed=8, bos=128000)
+    taps = (0, 1, 2)
+    tr = training.KDTrainer(kd_config(taps=taps, accum=16), enc, llm, prefix, suffix)
+    tr.optimizer_step = lambda: None
+    gen = torch.Generator().manual_seed(314)
+    B = 16
+    waves = [ri.synthetic_waveform(80000 + 5000 * u, seed=700 + u) for u in range(B)]        # 5.0 ... 9.7 s
+    texts = [torch.randint(1, LC.vocab_size, (30 + u % 11,), generator=gen) for u in range(B)]
+    resps = [torch.randint(1, LC.vocab_size, (48 + (5 * u) % 17,), generator=gen) for u in range(B)]
+    losses = tr.micro_batch([w.to(DEV) for w in waves], texts, resps)
+    grads = training.kernel_grads_to_state_dict(tr.enc, tr.grads, tr.master)
+    torch.cuda.synchronize()
+    # oracle: the reference's loop, batch size 1, loss / grad_accum_interval, gradients accumulate
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    rnd_ = (lambda v: v) if dtype == torch.float32 else (lambda v: v.to(torch.bfloat16).float())
+    sd = {k: (v.clone() if "conv_layers.0." in k else rnd_(v.clone())).requires_grad_(k != "encoder.masked_spec_embed") for k, v in enc_sd.items()}
+    lsd = {k: rnd_(v) for k, v in llm_sd.items()}
+    ref_losses = []
+    for u in range(B):
+        audio = ho.audio_encoder_forward(sd, HC, waves[u][None])
+        r = ko.kd_losses(lsd, LC, audio, texts[u], resps[u], prefix, suffix, connector_layers=taps, tail_logits_only=True)
+        (r["total"] / 16).backward()
+        ref_losses.append({k: float(v) for k, v in r.items()})
+    l_tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for u in range(B):
+        for k, rk in (("ntp_loss", "ntp"), ("ld_loss", "ld"), ("fd_loss", "fd"), ("total", "total")):
+            assert abs(losses[u][k] - ref_losses[u][rk]) <= l_tol * max(1.0, abs(ref_losses[u][rk])), (u, k, losses[u][k], ref_losses[u][rk])
+    total = float(torch.stack([sd[k].grad.norm() for k in tr.trainable]).norm())
+    per_tol = 2e-3 if dtype == torch.float32 else 0.12
+    worst, sq = (None, 0.0), 0.0
+    for k in tr.trainable:
+        ref = sd[k].grad
+        err = float((grads[k].cpu().reshape(ref.shape).double() - ref.double()).norm())
+        sq += err * err
+        scale = float(ref.norm()) + 1e-5 * total      # k_proj.bias: exactly-zero true gradient (softmax shift invariance)
+        if err / scale > worst[1]:
+            worst = (k, err / scale)
+        assert err < per_tol * scale, (k, err, float(ref.norm()))
+    overall = sq ** 0.5 / total
+    print(f"{dtype}: worst per-parameter gradient error {worst[1]:.2e} ({worst[0]}), all parameters together {overall:.2e}")
+    assert overall < (1e-4 if dtype == torch.float32 else 5e-2)
