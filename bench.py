@@ -65,15 +65,36 @@ def gpu_llama_state_dict(arch, seed, device):
     return sd
 
 
+def physical_cores() -> int:
+    """Physical cores of the host (lscpu's cores x sockets; SMT siblings not counted)."""
+    try:
+        seen = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tokens, full_new_tokens):
-    """The CPU oracle on ONE 10 s utterance: encode + prefill + `new_tokens` decode steps, fp32, `cores` host threads; one
-    warm-up pass, then the MEDIAN of 3 timed passes per stage; projected to the metric's unit for
-    `full_new_tokens` tokens per utterance."""
+    """The CPU oracle on ONE 10 s utterance: encode + prefill + `new_tokens` decode steps, fp32.  Thread count:
+    the node's physical cores are tried first, then halvings of it (torch's CPU GEMMs stop scaling across sockets; round 1
+    measured a collapse when oversubscribed) — two decode steps each — and the fastest setting is the one used and reported.
+    One warm-up pass; encoder and prefill = median of 3; decode = median per-step time over `new_tokens` steps; projected to the
+    metric's unit for `full_new_tokens` tokens per utterance."""
     from oracle import hubert_oracle as ho, llama_oracle as lo
-    # torch's CPU GEMMs stop scaling (and collapse when oversubscribed across sockets) well before the
-    # 256 hardware threads of the GPU node: use up to 32 threads and report that number
-    cores = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
+    phys = physical_cores()
     hc = ho.HubertCfg(harch.conv_dim, harch.conv_kernel, harch.conv_stride, harch.hidden_size, harch.num_hidden_layers,
                       harch.num_attention_heads, harch.intermediate_size, harch.num_conv_pos_embeddings,
                       harch.num_conv_pos_embedding_groups, harch.layer_norm_eps)
@@ -82,31 +103,52 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
                      larch.rope_scaling, larch.tie_word_embeddings, tuple(larch.eos_token_ids), larch.pad_token_id)
     llm_sd = {k: v.float().cpu() for k, v in llm_sd_gpu.items()}  # same tensors as the GPU run (bf16 values in fp32)
     emb = llm_sd["model.embed_tokens.weight"]
-    enc_t, pre_t, tok_t = [], [], []
+    med = lambda v: sorted(v)[len(v) // 2]
+
+    def decode(out, n):
+        past, ts = out["past"], []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            nxt = out["logits"][:, -1].argmax(-1)
+            out = lo.llama_forward(llm_sd, lc, emb[nxt][:, None, :], past=past, last_logits_only=True)
+            past = out["past"]
+            ts.append(time.perf_counter() - t0)
+        return ts
+
     with torch.no_grad():
-        for rep in range(4):                      # pass 0 = warm-up (page-in, thread pool, allocator)
+        torch.set_num_threads(min(32, phys))
+        audio = ho.audio_encoder_forward(enc_sd, hc, wave[None].cpu())                 # warm-up pass: page-in, thread pool, allocator
+        prompt = torch.cat([emb[prefix], audio, emb[suffix][:, 1:]], dim=1)
+        out = lo.llama_forward(llm_sd, lc, prompt, last_logits_only=True)
+        decode(out, 2)
+        tried = {}
+        n = phys
+        while n >= 16:
+            torch.set_num_threads(n)
+            decode(out, 1)
+            tried[n] = round(min(decode(out, 2)) * 1e3, 1)
+            n //= 2
+        cores = min(tried, key=tried.get) if tried else min(32, phys)
+        torch.set_num_threads(cores)
+        enc_t, pre_t = [], []
+        for _ in range(3):
             t0 = time.perf_counter()
             audio = ho.audio_encoder_forward(enc_sd, hc, wave[None].cpu())
             t1 = time.perf_counter()
             prompt = torch.cat([emb[prefix], audio, emb[suffix][:, 1:]], dim=1)
             out = lo.llama_forward(llm_sd, lc, prompt, last_logits_only=True)
             t2 = time.perf_counter()
-            past = out["past"]
-            for _ in range(new_tokens):
-                nxt = out["logits"][:, -1].argmax(-1)
-                out = lo.llama_forward(llm_sd, lc, emb[nxt][:, None, :], past=past, last_logits_only=True)
-                past = out["past"]
-            t3 = time.perf_counter()
-            if rep > 0:
-                enc_t.append(t1 - t0); pre_t.append(t2 - t1); tok_t.append((t3 - t2) / new_tokens)
-    med = lambda v: sorted(v)[len(v) // 2]
-    enc_s, pre_s, tok_s = med(enc_t), med(pre_t), med(tok_t)
+            enc_t.append(t1 - t0); pre_t.append(t2 - t1)
+        tok_s = med(decode(out, new_tokens))
+    enc_s, pre_s = med(enc_t), med(pre_t)
     e2e = full_new_tokens / (enc_s + pre_s + full_new_tokens * tok_s)
-    return {"value": round(e2e, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+    return {"value": round(e2e, 3), "unit": "tokens/s", "cores": cores, "kind": "port", "physical_cores": phys,
+            "decode_ms_per_token_by_threads": tried,
             "audio_sec_per_s": round(wave.numel() / 16000.0 / enc_s, 2), "prefill_tokens_per_s": round(prompt.shape[1] / pre_s, 1),
             "decode_tokens_per_s": round(1.0 / tok_s, 3),
-            "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s, median of 3 passes after 1 warm-up on {cores} threads: encoder {enc_s:.2f} s, "
-                       f"prefill S={prompt.shape[1]} {pre_s:.2f} s, {new_tokens} decode steps at {tok_s * 1e3:.0f} ms/token, fp32 oracle; value "
+            "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s on {cores} threads (fastest of {sorted(tried)} on a host with {phys} physical cores), "
+                       f"after 1 warm-up pass: encoder {enc_s:.2f} s and prefill S={prompt.shape[1]} {pre_s:.2f} s (medians of 3), "
+                       f"{new_tokens} decode steps at {tok_s * 1e3:.0f} ms/token (median), fp32 oracle; value "
                        f"projected to {full_new_tokens} tokens per utterance at batch 1")}
 
 
@@ -463,7 +505,7 @@ def main():
     ap.add_argument("--pipelines", type=int, default=2, help="batches in flight per GPU (host threads x HIP streams; 1 = strictly sequential steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pack-decode", action="store_true", help="experiment: decode on the row-major weights (tiled MFMA GEMMs, unfused norms / RoPE)")
-    ap.add_argument("--cpu-decode-steps", type=int, default=8, help="decode steps per pass of the bounded CPU-oracle sample (4 passes, ≈0.45 s per step)")
+    ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (SURVEY.md §8d: 32; ≈0.3-0.6 s per step)")
     ap.add_argument("--kd-optimizer-steps", type=int, default=3, help="optimizer steps of the KD training leg (0 = skip)")
     ap.add_argument("--kd-eval-mode", action="store_true", help="KD leg with the encoder's training-mode regularisers off")
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
@@ -802,6 +844,16 @@ def main():
                             "one_batch_alone_frac_of_peak": (round(step_bytes / (seq_stage["decode_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if seq_stage else None)},
         "roofline": dominant, "roofline_other": other,
     }
+    if seq_stage:
+        a_ = larch
+        body = a_.num_hidden_layers * ((a_.num_attention_heads + 2 * a_.num_key_value_heads) * a_.head_dim * a_.hidden_size
+                                       + a_.num_attention_heads * a_.head_dim * a_.hidden_size + 3 * a_.intermediate_size * a_.hidden_size)
+        # per sequence: every Linear on S rows, causal attention (half of the S x S products), lm_head on the last row only
+        pf = 2.0 * body * S + a_.num_hidden_layers * 2.0 * a_.num_attention_heads * a_.head_dim * S * S + 2.0 * a_.vocab_size * a_.hidden_size
+        ach = B * pf / (seq_stage["prefill"] * 1e-3) / 1e12
+        result["prefill_mfma"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                                  "algorithmic_flops_per_sequence": round(pf), "ms": seq_stage["prefill"],
+                                  "note": f"prefill of {B} x {S} prompt rows, one batch alone on the GPU (stage_ms_one_batch_alone.prefill)"}
     if kd is not None:
         result["kd_step"] = kd
     try:      # the reference's own call pattern: one utterance per generate call

@@ -485,7 +485,14 @@ int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const i
  * prefill + up to max_new_tokens decode steps replayed from one captured hipGraph.  out_ids_host
  * (nseq, max_new_tokens) int32 receives new tokens only; *n_steps_host the number of columns
  * produced (all rows finished => early stop, checked every `check_every` steps).  This call
- * synchronises `stream` (it returns host data). */
+ * synchronises `stream` (it returns host data).
+ * LIMIT: nseq <= SL_MAX_DECODE_BATCH (1024) sequences per call — the row count the weight-streaming decode GEMMs and the
+ * single-pass attention grid are built for; a larger batch is rejected with SL_ERR_ARG (split it: sequences are independent).
+ * The captured decode graph is cached per calling thread, keyed by every buffer, limit, the device and a hash of the model's
+ * and every layer's fields; sl_decode_graph_cache_clear() destroys the calling thread's cached graphs (returns how many) —
+ * call it after re-laying-out weights in place behind unchanged struct contents, or before unloading the library. */
+#define SL_MAX_DECODE_BATCH 1024
+int sl_decode_graph_cache_clear(void);
 size_t sl_generate_workspace_bytes(const sl_llama_model* m, int64_t n_tok, int32_t nseq, int32_t max_new_tokens);
 int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host,
                        int32_t nseq, int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos,

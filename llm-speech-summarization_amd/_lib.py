@@ -143,6 +143,7 @@ _PROTOS = {
     "sl_version": (c_i32, []),
     "sl_device_arch": (c_i32, [C.c_char_p, c_i32]),
     "sl_tuning_reload": (c_i32, []),
+    "sl_decode_graph_cache_clear": (c_i32, []),
     "sl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "sl_pack_weight": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "sl_gemm_fused_decode": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmFused), c_vp]),

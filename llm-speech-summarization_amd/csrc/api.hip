@@ -33,8 +33,10 @@ extern "C" int sl_device_arch(char* buf, int n) {
 // ----------------------------------------------------------------------------------------------
 // tuning switches (common.h SlEnv)
 // ----------------------------------------------------------------------------------------------
-static SlEnv g_env;
-static std::atomic<bool> g_env_loaded{false};
+// Readers take an immutable snapshot through one atomic pointer; a reload publishes a NEW snapshot and never touches a
+// published one (the old snapshots stay allocated: a handful of 80-byte tables per process), so a dispatching thread can never
+// see a half-written table.
+static std::atomic<const SlEnv*> g_env{nullptr};
 static std::mutex g_env_mu;
 
 static int env_int(const char* name, int dflt) {
@@ -42,8 +44,8 @@ static int env_int(const char* name, int dflt) {
   return (e && e[0]) ? atoi(e) : dflt;
 }
 
-static void env_load() {
-  SlEnv e;
+static const SlEnv* env_load() {
+  SlEnv& e = *new SlEnv();
   e.stream_min_m = env_int("SL_STREAM_MIN_M", 32);
   if (e.stream_min_m < 16) e.stream_min_m = 32;
   e.disable_t256 = getenv("SL_DISABLE_T256") != nullptr;
@@ -73,23 +75,24 @@ static void env_load() {
     }
     if (n == 3 && (mt == 8 || mt == 16)) e.stream_mt = mt;
   }
-  g_env = e;
+  return &e;
 }
 
 const SlEnv& sl_env() {
-  if (!g_env_loaded.load(std::memory_order_acquire)) {
+  const SlEnv* e = g_env.load(std::memory_order_acquire);
+  if (!e) {
     std::lock_guard<std::mutex> lk(g_env_mu);
-    if (!g_env_loaded.load(std::memory_order_relaxed)) {
-      env_load();
-      g_env_loaded.store(true, std::memory_order_release);
+    e = g_env.load(std::memory_order_relaxed);
+    if (!e) {
+      e = env_load();
+      g_env.store(e, std::memory_order_release);
     }
   }
-  return g_env;
+  return *e;
 }
 
 extern "C" int sl_tuning_reload(void) {
   std::lock_guard<std::mutex> lk(g_env_mu);
-  env_load();
-  g_env_loaded.store(true, std::memory_order_release);
+  g_env.store(env_load(), std::memory_order_release);
   return 0;
 }

@@ -353,7 +353,8 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restri
                                                            const int32_t* __restrict__ gen_count, int32_t* __restrict__ choice) {
   __shared__ float redf[16];
   __shared__ int hcnt[256];
-  __shared__ float hmass[256];
+  __shared__ unsigned long long hmass_fx[256];   // probability mass per bin in 2^-40 fixed point: integer adds commute, so the
+                                                 // bin totals (and the threshold compare below) are the same on every run
   __shared__ uint32_t s_prefix;
   __shared__ float s_above;
   __shared__ float part[1024];
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restri
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
       const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-      for (int i = tid; i < 256; i += 1024) { hcnt[i] = 0; hmass[i] = 0.f; }
+      for (int i = tid; i < 256; i += 1024) { hcnt[i] = 0; hmass_fx[i] = 0ull; }
       __syncthreads();
       for (int i = tid; i < V; i += 1024) {
         const float x = row[i];
@@ -395,25 +396,25 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restri
         if (k < floor_key || (k & hi_mask) != prefix) continue;
         const int bin = (k >> shift) & 255;
         if (mode == 0) atomicAdd(&hcnt[bin], 1);
-        else atomicAdd(&hmass[bin], prob(x));
+        else atomicAdd(&hmass_fx[bin], (unsigned long long)(prob(x) * 1099511627776.0f));   // prob <= 1: < 2^57 over a 128 k row
       }
       __syncthreads();
       if (tid == 0) {
         float run = above;
         int sel = -1;
         for (int bin = 255; bin >= 0; --bin) {
-          const float w = mode == 0 ? (float)hcnt[bin] : hmass[bin];
-          if (mode == 0 ? (hcnt[bin] > 0 && run + w >= limit) : (hmass[bin] > 0.f && run + w >= limit)) { sel = bin; break; }
+          const float w = mode == 0 ? (float)hcnt[bin] : (float)hmass_fx[bin] * (1.0f / 1099511627776.0f);
+          if (mode == 0 ? (hcnt[bin] > 0 && run + w >= limit) : (hmass_fx[bin] > 0ull && run + w >= limit)) { sel = bin; break; }
           run += w;
         }
         if (sel < 0) {           // the limit is never reached (rounding / k >= candidates): take the smallest populated bin
           run = above;
           for (int bin = 255; bin >= 0; --bin) {
-            const bool pop = mode == 0 ? hcnt[bin] > 0 : hmass[bin] > 0.f;
+            const bool pop = mode == 0 ? hcnt[bin] > 0 : hmass_fx[bin] > 0ull;
             if (pop) { sel = bin; }
           }
           run = above;
-          for (int bin = 255; bin > sel; --bin) run += mode == 0 ? (float)hcnt[bin] : hmass[bin];
+          for (int bin = 255; bin > sel; --bin) run += mode == 0 ? (float)hcnt[bin] : (float)hmass_fx[bin] * (1.0f / 1099511627776.0f);
           if (sel < 0) sel = 0;
         }
         s_prefix = prefix | ((uint32_t)sel << shift);

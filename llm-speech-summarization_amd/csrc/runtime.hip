@@ -378,7 +378,7 @@ extern "C" int sl_whisper_forward(const sl_hubert_model* m, const void* mel, int
 // ================================================================================================
 // Llama
 // ================================================================================================
-constexpr int SL_MAX_DECODE_BATCH = 1024;   // rows of one decode step (M of the weight-streaming GEMMs)
+// SL_MAX_DECODE_BATCH (speechllm.h): rows of one decode step (M of the weight-streaming GEMMs)
 
 struct LlamaWs {
   void *h, *qkv, *att, *mid, *last, *part, *split;
@@ -614,6 +614,8 @@ extern "C" int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* 
 struct DecodeGraphKey {
   const void *model, *layers, *w0, *lm, *embed, *kc, *vc, *ws;
   size_t ws_bytes;
+  uint64_t content;        // FNV-1a over the model struct and every layer struct: all weight / norm / rope pointers and dimensions
+  int device;
   int B, max_new, use_eos, n_eos, pad, max_ctx, slots, dtype, n_layers, vocab, fused;
   int eos[8];
   int sample, top_k;
@@ -624,6 +626,29 @@ struct DecodeGraphEntry { DecodeGraphKey key; hipGraph_t graph; hipGraphExec_t e
 static thread_local std::vector<DecodeGraphEntry> g_graphs;
 static thread_local uint64_t g_graph_clock = 0;
 constexpr size_t SL_GRAPH_CACHE = 8;
+constexpr int SL_MAX_DEVICES = 64;
+
+static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+// Everything a captured decode step bakes in that the caller could change behind the same host addresses: the model struct's
+// fields (dimensions, eps, embed / norm / rope / lm_head pointers) and EVERY layer's pointers.  A caller that rebuilds its
+// weights and gets the same struct addresses back from malloc therefore misses the cache instead of replaying stale pointers.
+static uint64_t model_content_hash(const sl_llama_model* m) {
+  uint64_t h = fnv1a(1469598103934665603ull, m, sizeof(*m));
+  if (m->layers && m->n_layers > 0) h = fnv1a(h, m->layers, sizeof(m->layers[0]) * (size_t)m->n_layers);
+  return h;
+}
+
+extern "C" int sl_decode_graph_cache_clear(void) {
+  for (auto& e : g_graphs) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
+  const int n = (int)g_graphs.size();
+  g_graphs.clear();
+  return n;
+}
 
 static hipGraphExec_t decode_graph_lookup(const DecodeGraphKey& k) {
   for (auto& e : g_graphs)
@@ -725,6 +750,8 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
     key.embed = m->embed; key.kc = kv->k_cache; key.vc = kv->v_cache; key.ws = workspace; key.ws_bytes = workspace_bytes;
     key.B = B; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
     key.slots = kv->slots; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm;
+    key.content = model_content_hash(m);
+    SL_HIP(hipGetDevice(&key.device));
     for (int i = 0; i < n_eos && i < 8; ++i) key.eos[i] = eos_ids_host[i];
     if (smp) { key.sample = 1; key.temperature = smp->temperature; key.top_k = smp->top_k; key.top_p = smp->top_p; key.seed = smp->seed; }
     hipGraphExec_t exec = decode_graph_lookup(key);
@@ -732,7 +759,9 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
       hipGraph_t graph = nullptr;
       // Capture on a private stream (the caller's may be the legacy null stream, which cannot capture);
       // capturing records the launches without running them, the graph is then replayed on `st`.
-      static thread_local hipStream_t cap = nullptr;
+      static thread_local hipStream_t cap_by_dev[SL_MAX_DEVICES] = {};    // a stream belongs to the device that was current when it was made
+      SL_CHECK_ARG(key.device >= 0 && key.device < SL_MAX_DEVICES, "sl_greedy_generate: device index %d", key.device);
+      hipStream_t& cap = cap_by_dev[key.device];
       if (!cap) SL_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
       SL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
       int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, cap);

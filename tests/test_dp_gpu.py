@@ -73,6 +73,11 @@ def test_two_rank_trainer_equals_single_rank(tmp_path):
     # both ranks hold bit-identical gradients and weights (same all-reduced sums, same AdamW)
     for k in one["master"]:
         assert torch.equal(two[0]["master"][k], two[1]["master"][k]), k
+        if k.endswith("k_proj.bias"):
+            # exactly-zero true gradient (softmax is shift invariant): what reaches AdamW is summation-order noise, which Adam's
+            # m / sqrt(v) normalises to +-lr per step whatever its size — the two runs may drift apart by 2 steps x lr per element
+            assert float((two[0]["master"][k] - one["master"][k]).abs().max()) <= 2 * 5e-5 * 1.001, k
+            continue
         assert rel_err(two[0]["master"][k], one["master"][k]) < MASTER_TOL, k
     for s in range(2):
         for k in two[0]["grads"][s]:

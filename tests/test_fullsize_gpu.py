@@ -367,16 +367,21 @@ def test_configs1_decode_step_logits_large_batch_vs_small_batch_and_oracle(llama
     nxt = [101, 20202, 99999]
     small = _decode_step_logits(m.llm, prompts, nxt)
     big = _decode_step_logits(m.llm, [prompts[b % 3] for b in range(B)], [nxt[b % 3] for b in range(B)])
-    worst = max(rel_err(big[b], small[b % 3]) for b in range(B))
-    print(f"B={B}: worst relative L2 distance of a row's decode-step logits from the 3-sequence run: {worst:.2e}")
-    assert worst < 1e-2
-    for b in range(3, B):                      # and copies of a sequence are bit-identical rows
+    for b in range(3, B):                      # copies of a sequence are bit-identical rows
         assert torch.equal(big[b], big[b % 3]), b
-    if B == 1024:
-        hc, lc = _oracle_cfgs(m.harch, m.larch)
-        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    # Both families against the fp32 oracle on the same bf16 weights.  Two correct bf16 pipelines with different rounding points
+    # (fp32 K-split partials, folded gains, score tiles) sit a similar distance from the exact result and up to the sum of the
+    # two apart: 28 layers x ~4 bf16 roundings of 2^-9 each ~ 2e-2.  What a wrong kernel cannot do is stay as close to the
+    # oracle as the other family does.
+    hc, lc = _oracle_cfgs(m.harch, m.larch)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    emb = m.llm_sd_host["model.embed_tokens.weight"]
+    for i in range(3):
         with torch.no_grad():
-            emb = m.llm_sd_host["model.embed_tokens.weight"]
-            seq = torch.cat([prompts[1].float().cpu(), emb[nxt[1]][None]])[None]
+            seq = torch.cat([prompts[i].float().cpu(), emb[nxt[i]][None]])[None]
             ref = lo.llama_forward(m.llm_sd_host, lc, seq, last_logits_only=True)["logits"][0, -1]
-        assert rel_err(big[1], ref) < FULL_TOL and rel_err(small[1], ref) < FULL_TOL
+        e_big, e_small, apart = rel_err(big[i], ref), rel_err(small[i], ref), rel_err(big[i], small[i])
+        print(f"B={B} sequence {i}: large-batch family vs oracle {e_big:.2e}, small-batch family vs oracle {e_small:.2e}, families apart {apart:.2e}")
+        assert e_big < FULL_TOL and e_small < FULL_TOL
+        assert e_big < 1.5 * e_small + 5e-3
+        assert apart < 3e-2

@@ -26,6 +26,19 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def tuning(monkeypatch):
+    """Set an SL_* tuning switch and re-read the library's table; the table is restored in the finalizer, so a failing assert
+    between the two reloads cannot leave a switch latched for the rest of the process."""
+    def set_(name, value):
+        monkeypatch.setenv(name, value)
+        L.lib().sl_tuning_reload()
+
+    yield set_
+    monkeypatch.undo()
+    L.lib().sl_tuning_reload()
+
+
 def rnd(*shape, seed=0, std=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * std
@@ -423,7 +436,7 @@ def test_gemm_packed_many_rows_wide_matrix(M):
 
 @pytest.mark.parametrize("M", [385, 512, 700])
 @pytest.mark.parametrize("H", [512, 448])
-def test_gemm_packed_wide_block_form(M, H, monkeypatch):
+def test_gemm_packed_wide_block_form(M, H, tuning):
     """The 256 x 128 streaming block (gemm_stream_wide_kernel: x and packed weight fragments through LDS-DMA, 8 compute + 4
     loader waves) on shapes the default rule would leave to the 128 x 128 form: ragged last row block, a fragment count that is
     not a multiple of 8, an odd number of 128-byte K stages (H = 448), SILU pairs with handed-over row scales, bias-free
@@ -440,14 +453,11 @@ def test_gemm_packed_wide_block_form(M, H, monkeypatch):
     R = rnd(M, 8200, seed=65)
     outs = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("SL_STREAM_WIDE", mode)
-        L.lib().sl_tuning_reload()
+        tuning("SL_STREAM_WIDE", mode)
         a = ops.gemm_decode(xd, wgu, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5, rstd_in=rstd.to(dev()), split_k=False)
         b = ops.gemm_decode(xd, Wp, 8200, residual=R.to(dev(), dt), split_k=False)
         c = ops.gemm_decode(xd, Wp, 8200, out_f32=True, split_k=False)
         outs[mode] = (a.float().cpu(), b.float().cpu(), c.cpu())
-    monkeypatch.delenv("SL_STREAM_WIDE")
-    L.lib().sl_tuning_reload()
     ref_a = F.silu((xf * rstd[:, None]) @ q(g, dt).T) * ((xf * rstd[:, None]) @ q(u, dt).T)
     ref_b = xf @ q(W, dt).T + q(R, dt)
     for mode in ("0", "2"):
@@ -480,7 +490,7 @@ def test_gemm_packed_rstd_handoff(dt, M):
 
 
 @pytest.mark.parametrize("M", [385, 512, 700])
-def test_gemm_packed_wide_split_fixup_equals_reduce_pass(M, monkeypatch):
+def test_gemm_packed_wide_split_fixup_equals_reduce_pass(M, tuning):
     """K split of the 256 x 128 form: the in-kernel fix-up (last-arriving block sums the partial records and applies the
     epilogue; a second counter per row block turns the per-tile sums of squares into rstd_out) must store exactly what the
     separate reduce launch stores — same partial records, same summation order — and leave its counters at zero (second call
@@ -501,8 +511,7 @@ def test_gemm_packed_wide_split_fixup_equals_reduce_pass(M, monkeypatch):
     seq = torch.arange(M, dtype=torch.int32, device=dev())
     got = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SL_STREAM_FIXUP", mode)
-        L.lib().sl_tuning_reload()
+        tuning("SL_STREAM_FIXUP", mode)
         runs = []
         for _ in range(2):
             rstd = torch.zeros(M, device=dev(), dtype=torch.float32)
@@ -514,8 +523,6 @@ def test_gemm_packed_wide_split_fixup_equals_reduce_pass(M, monkeypatch):
         for u, v in zip(runs[0], runs[1]):
             assert torch.equal(u, v)
         got[mode] = runs[0]
-    monkeypatch.delenv("SL_STREAM_FIXUP")
-    L.lib().sl_tuning_reload()
     for i in (0, 2, 3, 4):
         assert torch.equal(got["0"][i], got["1"][i]), i
     assert rel_err(got["1"][1], got["0"][1]) < 1e-6
