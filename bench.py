@@ -163,6 +163,8 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g)
     resp_ids = torch.randint(1, larch.vocab_size, (64,), generator=g)
     wave = ri.synthetic_waveform(160000, seed=4321 + rank).to(dev)
+    if args.kd_window > 0:                   # profiling aid: the main leg itself in the per-rank regime of a larger world size
+        tr.local_accum = min(args.kd_window, tr.local_accum)
     B = tr.local_accum                       # one accumulation window = one packed micro-batch per rank
     n_micro = B * args.kd_optimizer_steps
     waves, texts, resps = [wave] * B, [text_ids] * B, [resp_ids] * B
@@ -511,6 +513,7 @@ def main():
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")
+    ap.add_argument("--kd-window", type=int, default=0, help="profiling aid: samples per optimizer step per rank in the main KD leg (0 = grad_accum_interval / world)")
     ap.add_argument("--kd-local-accum", type=int, default=2, help="single-GPU KD probe: windows of this many samples per optimizer step, the per-rank "
                     "regime of an 8-rank run (grad_accum_interval 16 / 8); 0 = skip")
     args = ap.parse_args()

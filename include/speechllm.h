@@ -303,6 +303,27 @@ int sl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dt
 /* y = a*x + b*y (gradient accumulation at residual joins). */
 int sl_axpby(const void* x, void* y, float a, float b, int64_t n, int32_t dtype, sl_stream stream);
 
+/* torch.optim.AdamW.step() for every trainable tensor of the encoder in ONE launch (ref:trainer.py:97-105 builds the optimizer,
+ * :380-383 steps it; arithmetic of torch/optim/adamw.py _multi_tensor_adamw, amsgrad off, maximize off: decay, lerp of exp_avg,
+ * exp_avg_sq, bias corrections formed in double on the host, addcdiv), and — where `dst` is set — the kernel-layout copy of the
+ * updated weight in the compute dtype written in the same pass (what AudioEncoder.refresh_weights would otherwise re-derive).
+ * tensors_dev: device array of n_tensors records; first_block_dev: device array of n_tensors int64, first_block[t] = sum over
+ * u < t of sl_adamw_blocks(n_u); total_blocks = that sum over all tensors.  p / g / m / v are fp32, caller-owned; `step` is the
+ * 1-based count of this update (state['step'] after the increment).  Launches on `stream`, never synchronises. */
+typedef struct sl_adamw_tensor {
+  float* p;            /* fp32 master weight, updated in place */
+  const float* g;      /* fp32 gradient */
+  float* m;            /* exp_avg */
+  float* v;            /* exp_avg_sq */
+  void* dst;           /* NULL, or where the compute-dtype copy of p goes (same element order) */
+  int64_t n;           /* elements */
+  int32_t dst_dtype;   /* SL_F32 / SL_BF16 */
+  int32_t reserved;
+} sl_adamw_tensor;
+size_t sl_adamw_blocks(int64_t n);
+int sl_adamw_step(const sl_adamw_tensor* tensors_dev, const int64_t* first_block_dev, int32_t n_tensors, int64_t total_blocks, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int64_t step, sl_stream stream);
+
 /* y (cols, ld_out) = x (rows, cols)^T with columns rows..ld_out-1 zero-filled (row strides ldx / ldy in elements): the
  * K-contiguous operand copies of the backward products (torch's autograd transposes implicitly inside its GEMM calls,
  * hf training under ref:trainer.py:374-378 loss.backward()). */

@@ -134,6 +134,10 @@ class LlamaLayerSaved(C.Structure):
     _fields_ = [(n, c_vp) for n in ("qkv", "x2", "gu", "att", "lse")]
 
 
+class AdamWTensor(C.Structure):
+    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("dst", c_vp), ("n", c_i64), ("dst_dtype", c_i32), ("reserved", c_i32)]
+
+
 class KVCache(C.Structure):
     _fields_ = [("k_cache", c_vp), ("v_cache", c_vp), ("slots", c_i32), ("max_ctx", c_i32)]
 
@@ -154,6 +158,8 @@ _PROTOS = {
     "sl_gemm_ex": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmEx), c_vp]),
     "sl_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "sl_axpby": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_i64, c_i32, c_vp]),
+    "sl_adamw_blocks": (C.c_size_t, [c_i64]),
+    "sl_adamw_step": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp]),
     "sl_attn_dropout_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_f32, C.c_uint64, c_i32, c_vp]),
     "sl_transpose_pad": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, C.c_uint64, c_i32, c_vp]),

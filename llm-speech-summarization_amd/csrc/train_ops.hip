@@ -1196,3 +1196,93 @@ extern "C" int sl_hubert_conv0_bwd(const float* wave, int64_t n_samples, const f
     }
   });
 }
+
+
+// ----------------------------------------------------------------------------------------------
+// AdamW over every trainable tensor in ONE launch (torch.optim.AdamW's arithmetic, ref:trainer.py:97-105,380-383), with the
+// compute-dtype copy of the updated weight written in the same pass.  torch's foreach path is ~10 passes over the 1.27 GB of
+// fp32 masters per optimizer step plus a cast / copy per tensor to refresh the kernels' weights; here a parameter element is read
+// (p, g, m, v) and written (p, m, v, bf16 copy) exactly once: 30 B per parameter.
+// Block b works on tensor t = the last one with first_block[t] <= b (binary search over the prefix table), elements
+// [ (b - first_block[t]) * ADAMW_CHUNK, ... ).
+// ----------------------------------------------------------------------------------------------
+constexpr int ADAMW_CHUNK = 4096;   // elements per block: 256 threads x 4 floats x 4 rounds
+
+template <bool DST_BF16>
+__device__ __forceinline__ void adamw_store_dst(void* dst, int64_t i, const float (&o)[4], int n_valid) {
+  if constexpr (DST_BF16) {
+    bf16_t* d = (bf16_t*)dst + i;
+    if (n_valid == 4 && ((uintptr_t)d & 7) == 0) {
+      *(uint2*)d = uint2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+    } else {
+      for (int e = 0; e < n_valid; ++e) d[e] = from_f32<bf16_t>(o[e]);
+    }
+  } else {
+    float* d = (float*)dst + i;
+    for (int e = 0; e < n_valid; ++e) d[e] = o[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const sl_adamw_tensor* __restrict__ tensors, const int64_t* __restrict__ first_block,
+                                                          int n_tensors, float decay, float beta1, float beta2, float eps, float step_size,
+                                                          float bias_c2_sqrt) {
+  int lo = 0, hi = n_tensors - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {                      // last t with first_block[t] <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (first_block[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const sl_adamw_tensor t = tensors[lo];
+  const int64_t base = (b - first_block[lo]) * ADAMW_CHUNK;
+  const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+  const bool al = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0;
+#pragma unroll
+  for (int r = 0; r < ADAMW_CHUNK / 1024; ++r) {
+    const int64_t i = base + r * 1024 + threadIdx.x * 4;
+    if (i >= t.n) break;
+    const int nv = (t.n - i) >= 4 ? 4 : (int)(t.n - i);
+    float p[4], g[4], m[4], v[4];
+    if (nv == 4 && al) {
+      const float4 P = *(const float4*)(t.p + i), G = *(const float4*)(t.g + i), M = *(const float4*)(t.m + i), V = *(const float4*)(t.v + i);
+      p[0] = P.x; p[1] = P.y; p[2] = P.z; p[3] = P.w; g[0] = G.x; g[1] = G.y; g[2] = G.z; g[3] = G.w;
+      m[0] = M.x; m[1] = M.y; m[2] = M.z; m[3] = M.w; v[0] = V.x; v[1] = V.y; v[2] = V.z; v[3] = V.w;
+    } else {
+      for (int e = 0; e < nv; ++e) { p[e] = t.p[i + e]; g[e] = t.g[i + e]; m[e] = t.m[i + e]; v[e] = t.v[i + e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e >= nv) break;
+      p[e] = p[e] * decay;                                   // param.mul_(1 - lr * weight_decay)
+      m[e] = m[e] + w1 * (g[e] - m[e]);                      // exp_avg.lerp_(grad, 1 - beta1)
+      v[e] = v[e] * beta2 + (w2 * g[e]) * g[e];              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+      const float denom = sqrtf(v[e]) / bias_c2_sqrt + eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+      p[e] = p[e] - step_size * (m[e] / denom);              // param.addcdiv_(exp_avg, denom, value = -step_size)
+    }
+    if (nv == 4 && al) {
+      *(float4*)(t.p + i) = float4{p[0], p[1], p[2], p[3]};
+      *(float4*)(t.m + i) = float4{m[0], m[1], m[2], m[3]};
+      *(float4*)(t.v + i) = float4{v[0], v[1], v[2], v[3]};
+    } else {
+      for (int e = 0; e < nv; ++e) { t.p[i + e] = p[e]; t.m[i + e] = m[e]; t.v[i + e] = v[e]; }
+    }
+    if (t.dst) {
+      if (t.dst_dtype == SL_BF16) adamw_store_dst<true>(t.dst, i, p, nv); else adamw_store_dst<false>(t.dst, i, p, nv);
+    }
+  }
+}
+
+extern "C" size_t sl_adamw_blocks(int64_t n) { return n <= 0 ? 0 : (size_t)((n + ADAMW_CHUNK - 1) / ADAMW_CHUNK); }
+
+extern "C" int sl_adamw_step(const sl_adamw_tensor* tensors_dev, const int64_t* first_block_dev, int32_t n_tensors, int64_t total_blocks, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t step, sl_stream stream) {
+  SL_CHECK_ARG(tensors_dev && first_block_dev && n_tensors > 0 && total_blocks > 0 && total_blocks < (int64_t)1 << 31 && step >= 1,
+               "sl_adamw_step: bad arguments (n_tensors=%d total_blocks=%lld step=%lld)", n_tensors, (long long)total_blocks, (long long)step);
+  SL_CHECK_ARG(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && weight_decay >= 0.f, "sl_adamw_step: bad hyper-parameters");
+  // the scalars torch.optim.adamw._multi_tensor_adamw forms on the host, in double, before they meet fp32 tensors
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2), decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, tensors_dev, first_block_dev, n_tensors, decay,
+                     beta1, beta2, eps, step_size, bc2_sqrt);
+  SL_CHECK_LAUNCH("adamw_multi");
+  return 0;
+}

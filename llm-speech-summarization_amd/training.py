@@ -209,9 +209,13 @@ class LlamaTape:
     def logits(self, xn_rows: torch.Tensor) -> torch.Tensor:
         return ops.gemm(xn_rows, self.w.lm_head, out_f32=True)
 
-    def backward(self, tape, tail_rows: torch.Tensor, d_logits_tail: torch.Tensor, d_hidden: Dict[int, torch.Tensor]) -> torch.Tensor:
+    def backward(self, tape, tail_rows: torch.Tensor, d_logits_tail: torch.Tensor, d_hidden: Dict[int, torch.Tensor],
+                 n_seq: Optional[int] = None) -> torch.Tensor:
         """tail_rows: int64 indices (packed) of the rows whose logits carry loss; d_logits_tail: (len(tail_rows), V)
-        gradient (dtype T); d_hidden[l]: (N, H) gradient of hidden_states[l].  Returns d(input embeddings) (N, H)."""
+        gradient (dtype T); d_hidden[l]: (N, H) gradient of hidden_states[l].  Returns d(input embeddings) (N, H).
+        n_seq: differentiate only the FIRST n_seq sequences of the forward's packed batch (N = their rows): the KD window runs
+        the student and the no-grad teacher sequences through one forward pass, student first; rows are packed sequence by
+        sequence, so the student's share of every saved buffer is its leading rows and the teacher rows are simply not visited."""
         a, w = self.a, self.w
         nl = a.num_hidden_layers
         if not self._have_t:                                   # (in, out) copies of the frozen weights, built once
@@ -219,14 +223,20 @@ class LlamaTape:
                 lay = self._layers[li]
                 lay.wqkv_t, lay.wo_t, lay.wgu_t, lay.wdown_t = (self._t(li, k).data_ptr() for k in ("wqkv", "wo", "wgu", "wdown"))
             self._have_t = True
+        cfg = tape["cfg"]
         x_final = tape["x_final"]
+        if n_seq is not None and n_seq < len(tape["seqlens"]):
+            lens = tape["seqlens"][:n_seq]
+            n_rows = int(sum(lens))
+            cfg = L.LlamaStackCfg.from_buffer_copy(cfg)           # same descriptors (cu / klen / pos are prefixes too), fewer sequences
+            cfg.nseq, cfg.n_tok, cfg.max_len = n_seq, n_rows, max(int(n) for n in lens)
+            x_final = x_final[:n_rows]
         dx = torch.zeros_like(x_final)
         d_xn = ops.dgrad(d_logits_tail, w.lm_head)  # (n_tail, H)
         if nl in d_hidden:
             d_xn += d_hidden[nl].index_select(0, tail_rows)
         dx.index_copy_(0, tail_rows, ops.rmsnorm_bwd(x_final.index_select(0, tail_rows), w.final_norm, d_xn, a.rms_norm_eps))
         d_tap = (L.c_vp * nl)(*[(d_hidden[l].data_ptr() if l in d_hidden else None) for l in range(nl)])
-        cfg = tape["cfg"]
         ws = self._workspace(cfg, dx.device)
         L.check(L.lib().sl_llama_stack_train_bwd(self._layers, C.byref(cfg), tape["hptr"], tape["saved"], d_tap, dx.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  L.stream_ptr()), "sl_llama_stack_train_bwd")
@@ -705,6 +715,87 @@ def whisper_grads_to_state_dict(enc: AudioEncoder, g: Dict[str, torch.Tensor], m
 
 
 # ------------------------------------------------------------------------------------------------
+# optimizer step on the device: AdamW + the kernels' weight copies in one launch
+# ------------------------------------------------------------------------------------------------
+def direct_refresh_map(enc: AudioEncoder, to_state_dict, grads: Dict[str, torch.Tensor], master: Dict[str, torch.Tensor]):
+    """Which state-dict parameters sit in the kernels' weight tensors in the SAME element order (so that the optimizer kernel can
+    write their compute-dtype copy itself), found by probing rather than by a hand-kept table: every kernel-layout role is filled
+    with its own element indices and sent through the gradient re-layout `to_state_dict` (the exact inverse of the weight
+    re-layout); a parameter whose image is a run of consecutive indices of one role is a contiguous slice of that role's device
+    tensor.  Returns ({state-dict key: (role, element offset)}, {roles that hold anything else})."""
+    dev = enc.device
+    roles = list(grads)
+    fake = {k: (torch.arange(grads[k].numel(), dtype=torch.float64, device=dev) + float(i << 40)).view(grads[k].shape) for i, k in enumerate(roles)}
+    image = to_state_dict(enc, fake, master)
+    direct, covered = {}, {}
+    for key, t in image.items():
+        if key not in master or t.dtype != torch.float64:
+            continue
+        o = t.reshape(-1)
+        first = int(o[0].item())
+        rid, off = first >> 40, first & ((1 << 40) - 1)
+        if 0 <= rid < len(roles) and o.numel() == master[key].numel() and off + o.numel() <= grads[roles[rid]].numel() and \
+                bool(torch.equal(o, torch.arange(o.numel(), dtype=torch.float64, device=dev) + float(first))):
+            direct[key] = (roles[rid], off)
+            covered[roles[rid]] = covered.get(roles[rid], 0) + o.numel()
+    indirect = {k for k in roles if covered.get(k, 0) != grads[k].numel()}
+    return direct, indirect
+
+
+class FusedAdamW:
+    """torch.optim.AdamW.step() as ONE HIP launch (sl_adamw_step) over the optimizer's own state tensors — the state dict stays
+    torch's, so checkpoints keep the reference's layout (ref:trainer.py:97-105, 516-528) — writing, in the same pass, the
+    compute-dtype kernel copy of every weight that is laid out like its parameter."""
+
+    def __init__(self, optimizer: torch.optim.AdamW, named_params: Sequence[Tuple[str, torch.nn.Parameter]], dst_of: Dict[str, Tuple[torch.Tensor, int]]):
+        self.opt, self.named, self.dst_of = optimizer, list(named_params), dst_of
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or len(optimizer.param_groups) != 1:
+            raise L.SpeechLLMError("FusedAdamW covers plain AdamW (one param group, amsgrad / maximize off)")
+        lib = L.lib()
+        self._blocks = [int(lib.sl_adamw_blocks(p.numel())) for _, p in self.named]
+
+    def step(self) -> None:
+        g = self.opt.param_groups[0]
+        lib = L.lib()
+        live = [(k, p, nb) for (k, p), nb in zip(self.named, self._blocks) if p.grad is not None]
+        if not live:
+            return
+        dev = live[0][1].device
+        table = (L.AdamWTensor * len(live))()
+        first = np.zeros(len(live), dtype=np.int64)
+        steps, total, t_now = [], 0, None
+        for i, (k, p, nb) in enumerate(live):
+            st = self.opt.state[p]
+            if len(st) == 0:                     # torch creates the state on a parameter's first step
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            t_i = int(st["step"]) + 1
+            if t_now is None:
+                t_now = t_i
+            elif t_i != t_now:
+                raise L.SpeechLLMError("FusedAdamW: parameters disagree on the step count")
+            grad = p.grad
+            if not (grad.is_contiguous() and grad.dtype == torch.float32 and p.dtype == torch.float32 and p.is_contiguous()):
+                raise L.SpeechLLMError(f"FusedAdamW: parameter {k} / its gradient must be contiguous fp32")
+            rec = table[i]
+            rec.p, rec.g, rec.m, rec.v, rec.n = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            d = self.dst_of.get(k)
+            if d is not None:
+                rec.dst, rec.dst_dtype = d[0].data_ptr() + d[1] * d[0].element_size(), L.dtype_code(d[0].dtype)
+            first[i] = total
+            total += nb
+            steps.append(st["step"])
+        t_dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+        f_dev = torch.from_numpy(first).to(dev)
+        L.check(lib.sl_adamw_step(t_dev.data_ptr(), f_dev.data_ptr(), len(live), total, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                  float(g["eps"]), float(g["weight_decay"]), t_now, L.stream_ptr()), "sl_adamw_step")
+        torch._foreach_add_(steps, 1.0)
+        self._keep = (t_dev, f_dev)             # alive until the launch has consumed them
+
+
+# ------------------------------------------------------------------------------------------------
 # the KD step
 # ------------------------------------------------------------------------------------------------
 class KDTrainer:
@@ -759,6 +850,34 @@ class KDTrainer:
         self.keep_last_grads = False
         from .dist import BucketedAllReduce
         self.reducer = BucketedAllReduce(self.enc_tape.arena, group=process_group) if self.world > 1 else None
+        # AdamW + the refresh of the kernels' weight copies as one launch (sl_adamw_step); `use_fused_adamw = False` falls back
+        # to torch.optim's foreach step + a full re-derivation of the device weights (what the equivalence test compares with)
+        self.merge_teacher_pass = True             # teacher + student sequences through one ragged LLM forward (False: two passes)
+        self.use_fused_adamw = True
+        self._fused: Optional[FusedAdamW] = None
+        self._fused_indirect = None
+
+    def _fused_optimizer(self) -> Optional["FusedAdamW"]:
+        if self._fused is None:
+            W = self.enc.weights
+            direct, indirect = direct_refresh_map(self.enc, self.to_state_dict, self.grads, self.master)
+            handled = set(W.indirect_roles())
+            # roles without a device tensor (masked_spec_embed) have nothing to refresh; roles the weight class declares constant
+            # (Whisper: the frozen position table, the k slot of the fused qkv bias — k_proj has no bias) never change
+            const = set(W.constant_roles())
+            need = {r for r in indirect if W.role_tensor(r) is not None and r not in const}
+            if not need <= handled:
+                self.use_fused_adamw = False            # a layout this shortcut does not know: keep the general path
+                return None
+            dst_of = {}
+            for key, (role, off) in direct.items():
+                t = W.role_tensor(role)
+                if t is not None:
+                    dst_of[key] = (t, off)
+            self._fused = FusedAdamW(self.optimizer, [(k, self._param[k]) for k in self.param_names], dst_of)
+            self._fused_indirect = sorted(need)
+            self.enc._state = self.master               # state_dict() reads the masters themselves (updated in place)
+        return self._fused
 
     # -- micro-steps ----------------------------------------------------------------------------
     def micro_step(self, wave: torch.Tensor, text_ids: torch.Tensor, response_ids: torch.Tensor) -> Dict[str, float]:
@@ -798,7 +917,27 @@ class KDTrainer:
             a_lens.append(n_pre + (poff[u + 1] - poff[u]) + suf.shape[0] + resp[u].shape[0])
         a_seq = torch.cat(a_parts, 0).contiguous()
         aoff = _offsets(a_lens)
-        hidden_a, ltape = self.llm_tape.forward(a_seq, a_lens)
+        # The teacher (text prompt, no gradient) and the student (audio prompt) run through the SAME frozen weights: when the
+        # teacher is needed at all, both go through ONE ragged forward pass, student sequences first (M ~ 5 000 rows per GEMM
+        # instead of 3 200 + 1 900; ref:trainer.py:299-323 runs them as two calls).  The backward visits the student rows only.
+        need_teacher = self.use_ld or self.use_fd
+        merged = need_teacher and self.merge_teacher_pass
+        t_seq = t_lens = None
+        if need_teacher:
+            t_parts, t_lens = [], []
+            for u in range(B):
+                te = emb(text_ids[u].to(dev)[None])[0]
+                t_parts += [pre, te, suf, resp[u]]
+                t_lens.append(n_pre + te.shape[0] + suf.shape[0] + resp[u].shape[0])
+            t_seq = torch.cat(t_parts, 0).contiguous()
+        n_a = a_seq.shape[0]
+        if merged:
+            hidden_all, ltape = self.llm_tape.forward(torch.cat([a_seq, t_seq], 0), a_lens + t_lens)
+            hidden_a = [h[:n_a] for h in hidden_all]
+            hidden_t = [h[n_a:] for h in hidden_all]
+        else:
+            hidden_a, ltape = self.llm_tape.forward(a_seq, a_lens)
+            hidden_t = self.llm_tape.forward(t_seq, t_lens, save=False)[0] if need_teacher else None   # teacher pass: same kernels, nothing kept
         # rows whose logits / hidden states the losses read: the last n_u rows of every sequence
         tail = torch.cat([torch.arange(aoff[u + 1] - ns[u], aoff[u + 1]) for u in range(B)]).to(dev)
         toffs = _offsets(ns)
@@ -827,15 +966,8 @@ class KDTrainer:
         row_slot = torch.tensor(slot_rows, dtype=torch.int32, device=dev)
         d_hidden: Dict[int, torch.Tensor] = {}
         logits_t = None
-        if self.use_ld or self.use_fd:
-            t_parts, t_lens = [], []
-            for u in range(B):
-                te = emb(text_ids[u].to(dev)[None])[0]
-                t_parts += [pre, te, suf, resp[u]]
-                t_lens.append(n_pre + te.shape[0] + suf.shape[0] + resp[u].shape[0])
-            t_seq = torch.cat(t_parts, 0).contiguous()
+        if need_teacher:
             tto = _offsets(t_lens)
-            hidden_t, _ = self.llm_tape.forward(t_seq, t_lens, save=False)            # teacher pass: same kernels, nothing kept
             ttail = torch.cat([torch.arange(tto[u + 1] - ns[u], tto[u + 1]) for u in range(B)]).to(dev)
             if self.use_ld:
                 logits_t = self.llm_tape.logits(hidden_t[-1].index_select(0, ttail))
@@ -850,7 +982,7 @@ class KDTrainer:
                     d_hidden[l] = d
         # next-token CE + soft CE of every utterance: one launch, the gradient written once
         ops.kd_logit_losses(logits_a, logits_t, labels, row_coef, row_slot, losses, d_logits, dt)
-        d_seq = self.llm_tape.backward(ltape, tail, d_logits, d_hidden)
+        d_seq = self.llm_tape.backward(ltape, tail, d_logits, d_hidden, n_seq=B if merged else None)
         d_audio = torch.cat([d_seq[aoff[u] + n_pre: aoff[u] + n_pre + (poff[u + 1] - poff[u])] for u in range(B)], 0).contiguous()
         self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self.reducer.ready if early_buckets else None)
         self.micro += B
@@ -877,11 +1009,18 @@ class KDTrainer:
             p.grad = sd_grads[k].reshape(p.shape)  # views of the arena wherever kernel and state-dict layouts coincide
         if self.keep_last_grads:                   # tests / debugging only: a 1.27 GB clone per step otherwise
             self.last_grads = {k: p.grad.clone() for k, p in zip(self.trainable, self.params)}
-        self.optimizer.step()
+        fused = self._fused_optimizer() if self.use_fused_adamw else None
+        if fused is not None:
+            fused.step()                           # p, m, v and the kernels' copy of p: one pass over 30 B per parameter
+        else:
+            self.optimizer.step()
         self.scheduler.step()
         self.optimizer.zero_grad(set_to_none=True)
         self.enc_tape.arena.zero_()
-        self.enc.refresh_weights(self.master)      # compute-dtype kernel weights follow the fp32 master, in place
+        if fused is not None:
+            self.enc.weights.refresh_indirect(self.master)      # the few re-laid-out tensors (conv taps, folded weight norm)
+        else:
+            self.enc.refresh_weights(self.master)  # compute-dtype kernel weights follow the fp32 master, in place
         self.optimizer_steps += 1
         self.micro = 0
 

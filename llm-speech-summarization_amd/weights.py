@@ -407,6 +407,33 @@ class HubertDeviceWeights:
     def n_params(self) -> int:
         return sum(t.numel() for t in self._keep)
 
+    # -- what the fused optimizer step (training.FusedAdamW) needs: the device tensor of a kernel-layout role, and the roles
+    #    whose device tensor is NOT a plain cast of state-dict parameters (re-derived by refresh_indirect) --------------------
+    def role_tensor(self, role: str) -> Optional[torch.Tensor]:
+        if role in self.t:
+            return self.t[role]
+        if role.startswith("l") and "." in role and role[1:role.index(".")].isdigit():
+            return self.layer_t[int(role[1:role.index(".")])].get(role[role.index(".") + 1:])
+        return None
+
+    def indirect_roles(self) -> List[str]:
+        return [f"conv{i}_w" for i in range(1, len(self.arch.conv_dim))] + ["pos_w"]
+
+    def constant_roles(self) -> List[str]:
+        return []
+
+    def refresh_indirect(self, sd: Dict[str, torch.Tensor]) -> None:
+        """In-place refresh of the tensors `indirect_roles` names, same expressions as _populate."""
+        arch = self.arch
+        H, G, kpos = arch.hidden_size, arch.num_conv_pos_embedding_groups, arch.num_conv_pos_embeddings
+        p = "encoder.feature_extractor.conv_layers."
+        for i in range(1, len(arch.conv_dim)):
+            w = sd[p + f"{i}.conv.weight"]
+            dst = self.t[f"conv{i}_w"]
+            dst.copy_(w.permute(0, 2, 1).reshape(dst.shape))
+        wpos = fold_pos_conv_weight(sd, "encoder.encoder.pos_conv_embed.conv.")
+        self.t["pos_w"].copy_(wpos.permute(0, 2, 1).reshape(self.t["pos_w"].shape))
+
 
 # ------------------------------------------------------------------------------------------------
 # Llama
@@ -679,3 +706,17 @@ class WhisperDeviceWeights:
         mel[:, :nb] = slaney_mel_filters(nb, arch.num_mel_bins, arch.sampling_rate).T
         self.mel_w = dev(mel, torch.float32)
         self.dft_basis = dev(windowed_dft_basis(arch.n_fft), torch.float32)
+
+    role_tensor = HubertDeviceWeights.role_tensor
+
+    def indirect_roles(self) -> List[str]:
+        return ["conv1_w", "conv2_w"]
+
+    def constant_roles(self) -> List[str]:
+        return ["pos"] + [f"l{li}.bqkv" for li in range(self.arch.encoder_layers)]      # bqkv: q / v slots are direct, the k slot stays zero
+
+    def refresh_indirect(self, sd: Dict[str, torch.Tensor]) -> None:
+        for name in ("conv1", "conv2"):
+            w = sd[f"encoder.{name}.weight"]
+            dst = self.t[f"{name}_w"]
+            dst.copy_(w.permute(0, 2, 1).reshape(dst.shape))

@@ -349,3 +349,50 @@ def test_kd_window_losses_one_launch_equal_torch(dt, V):
     for u in range(len(ns)):
         assert abs(float(losses[u, 2]) - float(mses[u])) < 1e-5 * float(mses[u])
     assert rel_err(da.float().cpu(), ar.grad) < TOL[dt]
+
+
+def test_fused_adamw_equals_torch_optim_adamw():
+    """sl_adamw_step against torch.optim.AdamW itself (the reference's optimizer, ref:trainer.py:97-105: default eps 1e-8 and
+    weight_decay 1e-2) over three steps on tensors of awkward sizes (tails, unaligned views), with the compute-dtype copy written
+    by the same launch: bf16 copy == RNE cast of the updated master, fp32 copy == the master."""
+    training = pkg("training")
+    sizes = [(512, 1024), (3,), (4097,), (1, 1, 10), (777,), (8192 + 5,)]
+    gen = torch.Generator().manual_seed(3)
+    ref_p = [torch.nn.Parameter((torch.randn(*s, generator=gen) * 0.05).to(DEV)) for s in sizes]
+    base = torch.zeros(20000, device=DEV)
+    views = [base[1:1 + 3], base[101:101 + 777]]                 # fp32 tensors that do not start on a 16-byte boundary
+    my_p = []
+    for i, p in enumerate(ref_p):
+        if p.numel() == 3:
+            views[0].copy_(p.detach()); my_p.append(torch.nn.Parameter(views[0]))
+        elif p.numel() == 777:
+            views[1].copy_(p.detach()); my_p.append(torch.nn.Parameter(views[1]))
+        else:
+            my_p.append(torch.nn.Parameter(p.detach().clone()))
+    ref_opt = torch.optim.AdamW(ref_p, lr=5e-5, betas=(0.9, 0.999))
+    my_opt = torch.optim.AdamW(my_p, lr=5e-5, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.PolynomialLR(my_opt, total_iters=10, power=1.0)
+    ref_sched = torch.optim.lr_scheduler.PolynomialLR(ref_opt, total_iters=10, power=1.0)
+    dst_bf16 = torch.zeros(512 * 1024 + 64, device=DEV, dtype=torch.bfloat16)
+    dst_f32 = torch.zeros(4097, device=DEV, dtype=torch.float32)
+    dst_odd = torch.zeros(8192 + 5 + 3, device=DEV, dtype=torch.bfloat16)
+    fused = training.FusedAdamW(my_opt, [(f"p{i}", p) for i, p in enumerate(my_p)],
+                                {"p0": (dst_bf16, 64), "p2": (dst_f32, 0), "p5": (dst_odd, 3)})     # p5's copy starts 6 bytes into the buffer
+    for step in range(3):
+        for rp, mp in zip(ref_p, my_p):
+            g = torch.randn(rp.shape, generator=gen).to(DEV) * (10.0 ** (step - 2))
+            rp.grad, mp.grad = g.clone(), g.clone()
+        ref_opt.step(); ref_sched.step()
+        fused.step(); sched.step()
+        torch.cuda.synchronize()
+        for i, (rp, mp) in enumerate(zip(ref_p, my_p)):
+            assert rel_err(mp.detach().cpu(), rp.detach().cpu()) < 1e-6, (step, i)
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert rel_err(my_opt.state[mp][key].cpu(), ref_opt.state[rp][key].cpu()) < 1e-6, (step, i, key)
+            assert float(my_opt.state[mp]["step"]) == float(ref_opt.state[rp]["step"]) == step + 1
+        assert torch.equal(dst_bf16[64:], my_p[0].detach().reshape(-1).to(torch.bfloat16))
+        assert torch.equal(dst_f32, my_p[2].detach().reshape(-1))
+        assert torch.equal(dst_odd[3:], my_p[5].detach().reshape(-1).to(torch.bfloat16))
+        assert float(dst_bf16[:64].abs().max()) == 0 and float(dst_odd[:3].abs().max()) == 0
+    # the state is torch's own: the reference optimizer loads it
+    ref_opt.load_state_dict(my_opt.state_dict())

@@ -199,6 +199,72 @@ def test_optimizer_step_updates_master_and_kernel_weights():
     assert float((before[k] - tr.master[k]).abs().max()) <= 5e-5 * (1 + 0.01 * float(before[k].abs().max())) + 1e-7
 
 
+@pytest.mark.parametrize("base_kind,dtype", [("hubert", torch.float32), ("hubert", torch.bfloat16), ("whisper", torch.bfloat16)])
+def test_fused_optimizer_step_equals_torch_adamw_plus_full_refresh(base_kind, dtype):
+    """KDTrainer.optimizer_step with the one-launch AdamW + in-pass weight refresh (default) against the general path
+    (torch.optim.AdamW's foreach step + re-deriving every device tensor from the masters): same masters, same optimizer state,
+    and device weights BIT-identical to a full refresh — over three optimizer steps, HuBERT and Whisper parameter sets."""
+    g = golden("pipeline_tiny")
+
+    def make(fused):
+        if base_kind == "hubert":
+            tr, _, _, wave = build(g, dtype, accum=1)
+            waves = [wave]
+        else:
+            from oracle.golden_cfgs import TINY_WHISPER as WC
+            weights, enc_mod = pkg("weights"), pkg("audio_encoder")
+            conf = cfgm.from_dict(dict(model=dict(audio_encoder=dict(base="whisper", type="synthetic", downsample_method="pool", downsample_factor=4,
+                                                                     pooling=dict(kernel_size=8, stride=4)), llm_embedding_channels=TINY_LLAMA.hidden_size)))
+            arch = weights.WhisperArch(WC.d_model, WC.encoder_layers, WC.encoder_attention_heads, WC.encoder_ffn_dim, WC.num_mel_bins, WC.max_source_positions)
+            enc = enc_mod.AudioEncoder(conf, DEV, dtype=dtype, arch=arch)
+            enc.load_state_dict(ri.whisper_encoder_state_dict(WC, TINY_LLAMA.hidden_size, seed=3)).eval().to(DEV)
+            llm, _ = make_llama(TINY_LLAMA, int(g["llm_seed"]), dtype)
+            tr = training.KDTrainer(kd_config(taps=(0, 1, 3), accum=1), enc, llm, t(g["prefix_ids"]), t(g["suffix_ids"]))
+            waves = [ri.synthetic_waveform(24000, seed=5)]
+        tr.use_fused_adamw = fused
+        return tr, waves
+
+    (a, waves), (b, _) = make(True), make(False)
+    for step in range(3):
+        for tr in (a, b):
+            tr.micro_batch(waves, [t(g["text_ids"])], [t(g["response_ids"])])
+        assert a._fused is not None and b._fused is None and a.optimizer_steps == b.optimizer_steps == step + 1
+        for k in a.param_names:
+            assert rel_err(a.master[k].cpu(), b.master[k].cpu()) < (2e-6 if dtype == torch.float32 else 1e-4), (step, k)
+        # device weights after the fused step == what a full refresh derives from the same masters, bit for bit
+        snap = [w.clone() for w in a.enc.weights._keep]
+        a.enc.weights.refresh(a.master)
+        for i, (x, y) in enumerate(zip(snap, a.enc.weights._keep)):
+            assert torch.equal(x, y), (step, i, tuple(x.shape))
+    sa, sb = a.optimizer_state_dict(), b.optimizer_state_dict()
+    assert sa["param_groups"][0]["params"] == sb["param_groups"][0]["params"] and set(sa["state"]) == set(sb["state"])
+    b.load_optimizer_state_dict(sa)                      # the state the fused step keeps is torch's own layout
+
+
+def test_merged_teacher_student_pass_equals_two_passes_fp32():
+    """The window's teacher (text) and student (audio) sequences through ONE ragged LLM forward, backward over the student rows
+    only (default) == the reference's two calls (ref:trainer.py:299-323): same losses, same encoder gradients."""
+    g = golden("pipeline_tiny")
+    outs = []
+    for merged in (True, False):
+        tr, _, _, wave = build(g, torch.float32, taps=(0, 1, 3), accum=4)
+        tr.merge_teacher_pass = merged
+        tr.optimizer_step = lambda: None
+        waves = [wave, wave[:20000], wave[3000:30000]]
+        texts = [t(g["text_ids"]), t(g["text_ids"])[:5], t(g["text_ids"])[2:]]
+        resps = [t(g["response_ids"]), t(g["response_ids"])[:4], t(g["response_ids"])[1:]]
+        losses = tr.micro_batch(waves, texts, resps)
+        grads = {k: v.clone() for k, v in training.kernel_grads_to_state_dict(tr.enc, tr.grads, tr.master).items()}
+        outs.append((losses, grads, tr.trainable))
+    (la, ga, names), (lb, gb, _) = outs
+    for u in range(3):
+        for k in la[u]:
+            assert abs(la[u][k] - lb[u][k]) < 1e-5 * max(1.0, abs(lb[u][k])), (u, k)
+    total = float(torch.stack([gb[k].norm() for k in names]).norm())
+    for k in names:
+        assert float((ga[k] - gb[k]).norm()) < 2e-5 * float(gb[k].norm()) + 1e-6 * total, k
+
+
 def test_kd_micro_step_bf16_runs_and_tracks_fp32():
     g = golden("pipeline_tiny")
     tr, _, _, wave = build(g, torch.bfloat16)
