@@ -309,7 +309,9 @@ int sl_axpby(const void* x, void* y, float a, float b, int64_t n, int32_t dtype,
  * updated weight in the compute dtype written in the same pass (what AudioEncoder.refresh_weights would otherwise re-derive).
  * tensors_dev: device array of n_tensors records; first_block_dev: device array of n_tensors int64, first_block[t] = sum over
  * u < t of sl_adamw_blocks(n_u); total_blocks = that sum over all tensors.  p / g / m / v are fp32, caller-owned; `step` is the
- * 1-based count of this update (state['step'] after the increment).  Launches on `stream`, never synchronises. */
+ * 1-based count of this update (state['step'] after the increment).  The hyper-parameters are doubles because torch forms
+ * 1 - beta, the bias corrections and lr / bias_correction1 from python floats before rounding them to fp32 once (1 - 0.999 in
+ * fp32 is off by 1.3e-5).  Launches on `stream`, never synchronises. */
 typedef struct sl_adamw_tensor {
   float* p;            /* fp32 master weight, updated in place */
   const float* g;      /* fp32 gradient */
@@ -321,8 +323,8 @@ typedef struct sl_adamw_tensor {
   int32_t reserved;
 } sl_adamw_tensor;
 size_t sl_adamw_blocks(int64_t n);
-int sl_adamw_step(const sl_adamw_tensor* tensors_dev, const int64_t* first_block_dev, int32_t n_tensors, int64_t total_blocks, float lr,
-                  float beta1, float beta2, float eps, float weight_decay, int64_t step, sl_stream stream);
+int sl_adamw_step(const sl_adamw_tensor* tensors_dev, const int64_t* first_block_dev, int32_t n_tensors, int64_t total_blocks, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int64_t step, sl_stream stream);
 
 /* y (cols, ld_out) = x (rows, cols)^T with columns rows..ld_out-1 zero-filled (row strides ldx / ldy in elements): the
  * K-contiguous operand copies of the backward products (torch's autograd transposes implicitly inside its GEMM calls,

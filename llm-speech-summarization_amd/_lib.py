@@ -159,7 +159,7 @@ _PROTOS = {
     "sl_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "sl_axpby": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_i64, c_i32, c_vp]),
     "sl_adamw_blocks": (C.c_size_t, [c_i64]),
-    "sl_adamw_step": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp]),
+    "sl_adamw_step": (c_i32, [c_vp, c_vp, c_i32, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_vp]),
     "sl_attn_dropout_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_f32, C.c_uint64, c_i32, c_vp]),
     "sl_transpose_pad": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, C.c_uint64, c_i32, c_vp]),

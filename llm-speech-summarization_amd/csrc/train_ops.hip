@@ -1224,7 +1224,7 @@ __device__ __forceinline__ void adamw_store_dst(void* dst, int64_t i, const floa
 }
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const sl_adamw_tensor* __restrict__ tensors, const int64_t* __restrict__ first_block,
-                                                          int n_tensors, float decay, float beta1, float beta2, float eps, float step_size,
+                                                          int n_tensors, float decay, float w1, float beta2, float w2, float eps, float step_size,
                                                           float bias_c2_sqrt) {
   int lo = 0, hi = n_tensors - 1;
   const int64_t b = blockIdx.x;
@@ -1234,7 +1234,6 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const sl_adamw_tensor*
   }
   const sl_adamw_tensor t = tensors[lo];
   const int64_t base = (b - first_block[lo]) * ADAMW_CHUNK;
-  const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
   const bool al = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0;
 #pragma unroll
   for (int r = 0; r < ADAMW_CHUNK / 1024; ++r) {
@@ -1273,16 +1272,17 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const sl_adamw_tensor*
 
 extern "C" size_t sl_adamw_blocks(int64_t n) { return n <= 0 ? 0 : (size_t)((n + ADAMW_CHUNK - 1) / ADAMW_CHUNK); }
 
-extern "C" int sl_adamw_step(const sl_adamw_tensor* tensors_dev, const int64_t* first_block_dev, int32_t n_tensors, int64_t total_blocks, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int64_t step, sl_stream stream) {
+extern "C" int sl_adamw_step(const sl_adamw_tensor* tensors_dev, const int64_t* first_block_dev, int32_t n_tensors, int64_t total_blocks, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int64_t step, sl_stream stream) {
   SL_CHECK_ARG(tensors_dev && first_block_dev && n_tensors > 0 && total_blocks > 0 && total_blocks < (int64_t)1 << 31 && step >= 1,
                "sl_adamw_step: bad arguments (n_tensors=%d total_blocks=%lld step=%lld)", n_tensors, (long long)total_blocks, (long long)step);
-  SL_CHECK_ARG(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && weight_decay >= 0.f, "sl_adamw_step: bad hyper-parameters");
-  // the scalars torch.optim.adamw._multi_tensor_adamw forms on the host, in double, before they meet fp32 tensors
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2), decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  SL_CHECK_ARG(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && weight_decay >= 0., "sl_adamw_step: bad hyper-parameters");
+  // the scalars torch.optim.adamw._multi_tensor_adamw forms on the host, in double (python floats), before they meet fp32 tensors:
+  // 1 - beta, the bias corrections, lr / bias_correction1, 1 - lr * weight_decay — each rounded to fp32 once, as torch's scalar ops do
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2), decay = (float)(1.0 - lr * weight_decay);
   hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, tensors_dev, first_block_dev, n_tensors, decay,
-                     beta1, beta2, eps, step_size, bc2_sqrt);
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt);
   SL_CHECK_LAUNCH("adamw_multi");
   return 0;
 }

@@ -793,6 +793,7 @@ class FusedAdamW:
                                   float(g["eps"]), float(g["weight_decay"]), t_now, L.stream_ptr()), "sl_adamw_step")
         torch._foreach_add_(steps, 1.0)
         self._keep = (t_dev, f_dev)             # alive until the launch has consumed them
+        self.opt._opt_called = True             # what lr_scheduler's order check looks at (it wraps optimizer.step to set it)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -310,7 +310,7 @@ def test_ctypes_prototypes_have_the_header_arity_and_scalar_widths():
     hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
     decls = dict(re.findall(r"\b(?:int|size_t|int32_t|const char\s*\*)\s+(sl_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S))
     assert set(decls) == set(L._PROTOS), set(decls) ^ set(L._PROTOS)
-    width = {"int32_t": 4, "int": 4, "int64_t": 8, "uint64_t": 8, "size_t": 8, "float": 4}
+    width = {"int32_t": 4, "int": 4, "int64_t": 8, "uint64_t": 8, "size_t": 8, "float": 4, "double": 8}
     for name, (_, argtypes) in L._PROTOS.items():
         params = [p_.strip() for p_ in decls[name].split(",")] if decls[name].strip() not in ("", "void") else []
         assert len(params) == len(argtypes), (name, len(params), len(argtypes))
@@ -320,7 +320,7 @@ def test_ctypes_prototypes_have_the_header_arity_and_scalar_widths():
                 assert at in (C.c_void_p, C.c_char_p) or hasattr(at, "contents") or issubclass(at, C._Pointer), (name, prm, at)
             else:
                 ctype = next(t for t in width if re.search(rf"\b{t}\b", prm))
-                assert C.sizeof(at) == width[ctype] and (at is C.c_float) == (ctype == "float"), (name, prm, at)
+                assert C.sizeof(at) == width[ctype] and (at is C.c_float) == (ctype == "float") and (at is C.c_double) == (ctype == "double"), (name, prm, at)
 
 
 def test_epoch_windows_are_dealt_disjointly_and_cover_the_epoch_at_any_world_size():

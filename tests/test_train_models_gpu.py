@@ -230,6 +230,11 @@ def test_fused_optimizer_step_equals_torch_adamw_plus_full_refresh(base_kind, dt
             tr.micro_batch(waves, [t(g["text_ids"])], [t(g["response_ids"])])
         assert a._fused is not None and b._fused is None and a.optimizer_steps == b.optimizer_steps == step + 1
         for k in a.param_names:
+            if k.endswith("k_proj.bias"):
+                # exactly-zero true gradient (softmax shift invariance): AdamW normalises the summation noise to +-lr per step,
+                # and the noise (fp32 atomics) is not reproducible run to run — bounded drift instead of agreement
+                assert float((a.master[k] - b.master[k]).abs().max()) <= 2 * (step + 1) * 5e-5 * 1.001, (step, k)
+                continue
             assert rel_err(a.master[k].cpu(), b.master[k].cpu()) < (2e-6 if dtype == torch.float32 else 1e-4), (step, k)
         # device weights after the fused step == what a full refresh derives from the same masters, bit for bit
         snap = [w.clone() for w in a.enc.weights._keep]
