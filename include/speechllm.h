@@ -142,6 +142,13 @@ typedef struct {
    * groups_ext == 2: as 1, and the caller vouches that every group's K is a multiple of 64 bf16 / 32 f32 elements
    * (whole 128-byte slabs), which admits the LDS-DMA tiled kernel. */
   int32_t groups_ext, reserved;
+  /* Fused row-wise top-1 in place of the store (greedy decode: lm_head + argmax, hf:generation/utils.py:2911-2925 over the logits
+   * of ref:model/audio_llama.py:67): when both are set, C is NOT written; instead, for every row m and every group g of 64
+   * output columns, amax_val[g * M + m] = max over columns [64 g, 64 g + 64) of (A.W^T + bias)[m][.] and amax_idx[g * M + m] =
+   * its column (the lowest one on a tie; -inf / 0x7fffffff when every value is NaN).  ceil(N / 64) * M entries each.
+   * Plain epilogue only (act NONE, no residual), one un-grouped row-major product, M > 64.  sl_greedy_select_partial finishes
+   * the argmax over the groups: together they give bit for bit the token sl_gemm(out_f32) + sl_greedy_select give. */
+  float* amax_val; int32_t* amax_idx;
 } sl_gemm_ex_args;
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);
 
@@ -293,6 +300,11 @@ int sl_attn_decode_split(const void* q, int64_t q_stride, const void* k_cache, c
 int sl_greedy_select(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids_host, int32_t n_eos,
                      int32_t pad_id, int32_t use_eos, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
                      int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream);
+/* sl_greedy_select over the per-group partial maxima of a fused lm_head (sl_gemm_ex_args.amax_val / amax_idx, n_groups =
+ * ceil(V / 64), layout [group][B]): same token, same EOS / pad / finished-row bookkeeping, 1/64 of the bytes. */
+int sl_greedy_select_partial(const float* amax_val, const int32_t* amax_idx, int32_t n_groups, int32_t B, const int32_t* eos_ids_host,
+                             int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len,
+                             int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Knowledge-distillation step (ref:trainer.py:270-374): backward and loss kernels.  GEMM-shaped

@@ -43,7 +43,7 @@ class GemmFused(C.Structure):
 
 class GemmEx(C.Structure):
     _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("w_mod", c_i32), ("aux_out", c_vp), ("groups", c_vp),
-                ("groups_ext", c_i32), ("reserved", c_i32)]
+                ("groups_ext", c_i32), ("reserved", c_i32), ("amax_val", c_vp), ("amax_idx", c_vp)]
 
 
 class AttnArgs(C.Structure):
@@ -197,6 +197,7 @@ _PROTOS = {
     "sl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),
     "sl_rope_kv_append": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_attn_decode": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
+    "sl_greedy_select_partial": (c_i32, [c_vp, c_vp, c_i32, c_i32, C.POINTER(c_i32), c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "sl_greedy_select": (c_i32, [c_vp, c_i32, c_i32, C.POINTER(c_i32), c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_i32, c_vp]),
     "sl_encoder_stack_train_workspace_bytes": (c_sz, [C.POINTER(EncStackCfg)]),

@@ -22,8 +22,59 @@ static int stream_min_m() { return sl_env().stream_min_m; }
 // ----------------------------------------------------------------------------------------------
 // shared epilogue of the tiled kernels: +bias, [aux store], act, +residual, store.  The wave owns MT x NT 16x16 fragments
 // whose first row / column in the output are row_base / col_base (lane (r, q) holds rows 4q..4q+3 of column r of each).
+// Fused row-wise top-1 in place of the store (greedy decode: lm_head + argmax, hf:generation/utils.py:2911-2925 `torch.argmax(
+// next_token_scores)` over ref:model/audio_llama.py:67's logits).  The wave holds MT*16 rows x 64 columns; lane (r, q) has rows
+// 4q..4q+3 of column r of each 16-column fragment.  Per row: the best of the lane's four fragments (ascending columns, strict
+// '>' so the lowest column wins a tie), then across the 16 lanes of the row group with (value, column) compared the way
+// greedy_select_kernel does — the first maximum wins, NaN never wins.  One (value, column) pair per row and 64-column group
+// goes out at [group][row]: 64 contiguous bytes per 16 rows, 1/64 of the logits the select pass would otherwise re-read.
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void tile_argmax(const GemmP& p, f32x4 (&acc)[MT][NT], int row_base, int col_base, int q, int r, int wz) {
+  static_assert(NT == 4, "one 64-column group per wave");
+  if (col_base >= p.N) return;
+  const T* bias = p.bias ? (const T*)p.bias + (int64_t)wz * p.sBias : nullptr;
+  const int64_t g = col_base >> 6;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float bv[4];
+    int bi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bv[i] = -INFINITY; bi[i] = 0x7fffffff; }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = col_base + n * 16 + r;
+      if (col >= p.N) continue;
+      const float b = bias ? to_f32(bias[col]) : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = acc[m][n][i] + b;
+        if (v > bv[i]) { bv[i] = v; bi[i] = col; }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ov = __shfl_xor(bv[i], o, 64);
+        const int oi = __shfl_xor(bi[i], o, 64);
+        if (ov > bv[i] || (ov == bv[i] && oi < bi[i])) { bv[i] = ov; bi[i] = oi; }
+      }
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row_base + m * 16 + 4 * q + i;
+        if (row < p.M) { p.amax_val[g * p.M + row] = bv[i]; p.amax_idx[g * p.M + row] = bi[i]; }
+      }
+    }
+  }
+}
+
 template <typename T, int ACT, int MT, int NT>
 __device__ __forceinline__ void tile_epilogue_g(const GemmP& p, f32x4 (&acc)[MT][NT], int row_base, int col_base, int q, int r, int z, int wz) {
+  if constexpr (ACT == SL_ACT_NONE && NT == 4) {
+    if (p.amax_val) { tile_argmax<T, MT, NT>(p, acc, row_base, col_base, q, r, wz); return; }
+  }
   const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
   void* Cb = p.out_f32 ? (void*)((float*)p.C + co) : (void*)((T*)p.C + co);
   const T* bias = p.bias ? (const T*)p.bias + (int64_t)wz * p.sBias : nullptr;
@@ -115,6 +166,7 @@ __device__ __forceinline__ void st4(bf16_t* ptr, const float (&f)[4]) { *(uint2*
 template <typename T, int ACT, int MT>
 __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int z, int wz, float* wsm) {
   static_assert(MT % 4 == 0 && ACT != SL_ACT_SILU_MUL, "64-row passes; the gate/up pairing keeps the direct epilogue");
+  if (p.amax_val) return false;     // fused top-1: nothing is stored, the accumulator layout is what the reduction wants
   const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
   const uintptr_t ca = p.out_f32 ? 15 : (4 * sizeof(T) - 1), ra = p.res_f32 ? 15 : (4 * sizeof(T) - 1);
   if ((p.N & 3) || (p.ldc & 3) || (co & 3) || ((uintptr_t)p.C & ca) || (p.aux && ((uintptr_t)p.aux & (4 * sizeof(T) - 1))) ||
@@ -985,6 +1037,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
+  p.amax_val = nullptr; p.amax_idx = nullptr;
   const int direct_epi = sl_env().direct_epilogue;
   p.direct_epi = direct_epi;
   const int gm_env = sl_env().gemm_gm;
@@ -997,7 +1050,15 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     SL_CHECK_ARG(!(p.ta || p.tw || p.aux) || a->act != SL_ACT_SILU_MUL, "sl_gemm_ex: transposed operands / aux_out are not combined with SILU_MUL");
     SL_CHECK_ARG(!p.res_f32 || a->out_f32, "sl_gemm_ex: residual_f32 needs out_f32");
     SL_CHECK_ARG(!(p.ta || p.tw) || a->w_layout == SL_W_ROWMAJOR, "sl_gemm_ex: transposed operands need row-major storage");
+    if (ex->amax_val || ex->amax_idx) {
+      SL_CHECK_ARG(ex->amax_val && ex->amax_idx && a->act == SL_ACT_NONE && a->batch == 1 && !ex->groups && !ex->trans_a && !ex->trans_w && !ex->aux_out &&
+                       !a->residual && a->M > 64 && a->w_layout == SL_W_ROWMAJOR,
+                   "sl_gemm_ex: amax_val / amax_idx (fused row-wise top-1) need both pointers, the plain epilogue without residual, one "
+                   "un-grouped row-major product and M > 64 (M=%d act=%d batch=%d)", a->M, a->act, a->batch);
+      p.amax_val = ex->amax_val; p.amax_idx = ex->amax_idx;
+    }
   }
+  SL_CHECK_ARG(p.amax_val || a->C, "sl_gemm: null C");
   SkinnyX sx;
   memset(&sx, 0, sizeof(sx));
   if (fx) {

@@ -20,6 +20,8 @@ struct GemmP {
   int grp_kslab;       // groups_ext == 2: every group's K is a whole number of 128-byte slabs (LDS-DMA kernel allowed)
   int gm;              // 256-tile kernel: tile rows per XCD patch (SL_GEMM_GM, default 8)
   int direct_epi;      // tiled kernels: skip the LDS-staged row epilogue (SL_DIRECT_EPILOGUE=1, for A/B measurements)
+  float* amax_val;     // fused row-wise top-1 (sl_gemm_ex_args.amax_*): per 64-column group g and row m the largest value of
+  int* amax_idx;       // columns [64 g, 64 g + 64) at [g][m] and its column index; C is then not written at all
 };
 
 // resolve the per-batch descriptor: returns false when this block's tile lies outside batch z's rows

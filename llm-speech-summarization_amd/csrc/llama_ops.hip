@@ -335,6 +335,71 @@ int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32
   return 0;
 }
 
+// greedy selection over the [group][B] partial maxima a fused lm_head left (gemm.hip tile_argmax): block = 64 rows x 16 group
+// stripes, every wave-level load is 64 consecutive rows of one group (256 contiguous bytes); the stripes meet in LDS in stripe
+// order and the bookkeeping of greedy_select_kernel follows.  Compare rule everywhere: larger value, then lower column.
+__global__ __launch_bounds__(1024) void greedy_select_partial_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int n_groups, int B,
+                                                                     EosList eos, int pad_id, int use_eos, int advance_ctx,
+                                                                     int32_t* __restrict__ unfinished, int32_t* __restrict__ ctx_len,
+                                                                     int32_t* __restrict__ gen_count, int32_t* __restrict__ finish_len,
+                                                                     int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new) {
+  __shared__ float sv[16][64];
+  __shared__ int si[16][64];
+  const int lr = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lr;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (b < B) {
+    for (int g = stripe; g < n_groups; g += 16) {
+      const float v = pv[(int64_t)g * B + b];
+      const int i = pi[(int64_t)g * B + b];
+      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+  }
+  sv[stripe][lr] = best;
+  si[stripe][lr] = bi;
+  __syncthreads();
+  if (stripe != 0 || b >= B) return;
+  for (int s2 = 1; s2 < 16; ++s2)
+    if (sv[s2][lr] > best || (sv[s2][lr] == best && si[s2][lr] < bi)) { best = sv[s2][lr]; bi = si[s2][lr]; }
+  if (bi == 0x7fffffff) bi = 0;
+  int tok = bi;
+  const int unf = unfinished[b];
+  if (use_eos) tok = unf ? tok : pad_id;   // hf:generation/utils.py:2928-2929
+  const int n = gen_count[b];
+  if (n < max_new) out_ids[(int64_t)b * max_new + n] = tok;
+  gen_count[b] = n + 1;
+  next_ids[b] = tok;
+  if (use_eos && unf) {
+    bool is_eos = false;
+    for (int e = 0; e < eos.n; ++e) is_eos |= (tok == eos.ids[e]);
+    if (is_eos) { unfinished[b] = 0; finish_len[b] = n + 1; }
+  }
+  if (advance_ctx) ctx_len[b] += 1;
+}
+
+int sl_greedy_select_partial_impl(const float* amax_val, const int32_t* amax_idx, int32_t n_groups, int32_t B, const int32_t* eos_ids, int32_t n_eos,
+                                  int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
+                                  int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st) {
+  SL_CHECK_ARG(amax_val && amax_idx && unfinished && ctx_len && gen_count && finish_len && next_ids && out_ids && B > 0 && n_groups > 0,
+               "sl_greedy_select_partial: bad arguments");
+  SL_CHECK_ARG(n_eos >= 0 && n_eos <= 8, "sl_greedy_select_partial: at most 8 eos ids");
+  EosList e;
+  e.n = n_eos;
+  for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
+  hipLaunchKernelGGL(greedy_select_partial_kernel, dim3((B + 63) / 64), dim3(1024), 0, st, amax_val, amax_idx, n_groups, B, e, pad_id, use_eos, advance_ctx,
+                     unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, max_new);
+  SL_CHECK_LAUNCH("greedy_select_partial");
+  return 0;
+}
+
+extern "C" int sl_greedy_select_partial(const float* amax_val, const int32_t* amax_idx, int32_t n_groups, int32_t B, const int32_t* eos_ids, int32_t n_eos,
+                                        int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
+                                        int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream) {
+  return sl_greedy_select_partial_impl(amax_val, amax_idx, n_groups, B, eos_ids, n_eos, pad_id, use_eos, advance_ctx, unfinished, ctx_len, gen_count,
+                                       finish_len, next_ids, out_ids, max_new, (hipStream_t)stream);
+}
+
 // ----------------------------------------------------------------------------------------------
 // sampled selection (hf:generation/utils.py:2911-2923 with do_sample: logits processors then multinomial):
 //   TemperatureLogitsWarper (scores / T), TopKLogitsWarper (keep scores >= the k-th largest), TopPLogitsWarper (on the

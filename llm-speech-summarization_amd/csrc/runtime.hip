@@ -11,6 +11,9 @@ int sl_attn_decode_impl(const void* q, int64_t q_stride, const void* k_cache, co
 int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
                           int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
                           int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st);
+int sl_greedy_select_partial_impl(const float* amax_val, const int32_t* amax_idx, int32_t n_groups, int32_t B, const int32_t* eos_ids, int32_t n_eos,
+                                  int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
+                                  int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st);
 int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p, uint64_t seed,
                           const int32_t* eos_ids, int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished,
                           int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new,
@@ -557,8 +560,17 @@ extern "C" int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, 
 }
 
 // decode-step state carved from the tail of the workspace by sl_greedy_generate, or supplied by the caller
+// rows from which the lm_head of a greedy decode step leaves per-64-column partial maxima instead of fp32 logits (the tiled
+// kernels' fused top-1): the logits round trip is B x vocab x 8 bytes per step, 1 GB at 1 024 rows
+constexpr int SL_FUSED_ARGMAX_MIN_B = 256;
+
+// = the steps whose lm_head runs on the tiled kernels (below: packed weights stream through dec_gemm up to 255 rows)
+static bool decode_fuses_argmax(const sl_llama_model* m, int B) { return B > 64 && !(m->lm_head_dec && B < SL_FUSED_ARGMAX_MIN_B); }
+
+// fused_top1: the caller will run sl_greedy_select_partial_impl over `logits` reinterpreted as [n_groups][B] floats followed by
+// [n_groups][B] int32 (n_groups = ceil(vocab / 64)) — only honoured where decode_fuses_argmax() says so
 static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids, const int32_t* ctx_len, int B, float* logits,
-                       void* x, LlamaWs& w, hipStream_t st) {
+                       void* x, LlamaWs& w, hipStream_t st, bool fused_top1 = false) {
   const int dt = m->dtype, H = m->hidden;
   SL_TRY(sl_embed_gather(m->embed, next_ids, x, B, H, dt, (sl_stream)st));
   // hand RMSNorm scales along the chain when every o / down projection has a reduce pass to compute them in
@@ -572,7 +584,7 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
     SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st, chain, (chain && l > 0) ? w.rstd_b : nullptr));
   // lm_head: above ~256 rows the 128-tile MFMA kernel on the row-major matrix beats the streaming kernel on the packed one
   // (M=512: 439 vs 632 us; the 263 MB of fp32 logits dominate either way)
-  if (m->lm_head_dec && B < 256) {
+  if (m->lm_head_dec && B < SL_FUSED_ARGMAX_MIN_B) {
     sl_gemm_fused fx;
     memset(&fx, 0, sizeof(fx));
     fx.fuse_rms = m->dec_fused_norm; fx.rms_eps = m->rms_eps;
@@ -582,6 +594,19 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
                     (chain && m->n_layers > 0) ? w.rstd_b : nullptr);
   }
   SL_TRY(sl_rmsnorm(x, w.last, m->final_norm, B, H, m->rms_eps, dt, (sl_stream)st));
+  if (fused_top1 && decode_fuses_argmax(m, B)) {
+    const int64_t ng = (m->vocab + 63) / 64;
+    sl_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = w.last; a.lda = H; a.W = m->lm_head; a.ldw = H; a.C = nullptr; a.ldc = m->vocab;
+    a.M = B; a.N = m->vocab; a.K = H; a.batch = 1; a.dtype = dt; a.act = SL_ACT_NONE; a.out_f32 = 1; a.w_layout = SL_W_ROWMAJOR;
+    sl_gemm_ex_args ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.w_mod = 1;
+    ex.amax_val = logits;
+    ex.amax_idx = (int32_t*)(logits + ng * B);
+    return sl_gemm_impl(&a, nullptr, &ex, st);
+  }
   SL_TRY(gemm(dt, w.last, H, m->lm_head, H, logits, m->vocab, nullptr, nullptr, 0, B, m->vocab, H, SL_ACT_NONE, 1, st));
   return 0;
 }
@@ -764,8 +789,18 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
       hipStream_t& cap = cap_by_dev[key.device];
       if (!cap) SL_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
       SL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-      int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, cap);
-      if (rc == 0) rc = select(1, cap);
+      // greedy + a batch the tiled lm_head serves: the lm_head leaves per-group maxima, the select pass reads 1/64 of the bytes
+      const bool top1 = !smp && decode_fuses_argmax(m, B);
+      int rc = decode_step(m, kv, next_ids, ctx_len, B, logits, xdec, w, cap, top1);
+      if (rc == 0) {
+        if (top1) {
+          const int ng = (m->vocab + 63) / 64;
+          rc = sl_greedy_select_partial_impl(logits, (const int32_t*)(logits + (int64_t)ng * B), ng, B, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished,
+                                             ctx_len, gen_count, finish_len, next_ids, out_ids, max_new_tokens, cap);
+        } else {
+          rc = select(1, cap);
+        }
+      }
       hipError_t ce = hipStreamEndCapture(cap, &graph);
       if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       if (ce != hipSuccess) { sl_set_error("hipStreamEndCapture: %s", hipGetErrorString(ce)); return SL_ERR_LAUNCH; }

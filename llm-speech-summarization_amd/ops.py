@@ -252,6 +252,34 @@ def greedy_select(logits, eos_ids, pad_id, use_eos, unfinished, ctx_len, gen_cou
                                      L.stream_ptr()), "sl_greedy_select")
 
 
+def gemm_top1(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """Row-wise top-1 of A W^T (+ bias) without storing the product (sl_gemm_ex_args.amax_*): returns (val, idx), each
+    (ceil(N / 64), M): the largest value of every 64-column group and its column."""
+    L.require_gpu(A, "A"); L.require_gpu(W, "W")
+    M, K = A.shape
+    N = W.shape[0]
+    ng = (N + 63) // 64
+    val = torch.empty((ng, M), device=A.device, dtype=torch.float32)
+    idx = torch.empty((ng, M), device=A.device, dtype=torch.int32)
+    a = L.GemmArgs()
+    a.A, a.lda, a.W, a.ldw, a.C, a.ldc = L.ptr(A), A.stride(0), L.ptr(W), W.stride(0), None, N
+    a.bias = L.ptr(bias)
+    a.M, a.N, a.K, a.batch = M, N, K, 1
+    a.dtype, a.act, a.out_f32 = L.dtype_code(A.dtype), L.ACT_NONE, 1
+    ex = L.GemmEx()
+    ex.w_mod, ex.amax_val, ex.amax_idx = 1, L.ptr(val), L.ptr(idx)
+    L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(ex), L.stream_ptr()), "sl_gemm_ex")
+    return val, idx
+
+
+def greedy_select_partial(val, idx, eos_ids, pad_id, use_eos, unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, advance_ctx=True) -> None:
+    ng, B = val.shape
+    eos = (C.c_int32 * max(1, len(eos_ids)))(*eos_ids)
+    L.check(L.lib().sl_greedy_select_partial(L.ptr(val), L.ptr(idx), ng, B, eos, len(eos_ids), pad_id, int(use_eos), int(advance_ctx), L.ptr(unfinished),
+                                             L.ptr(ctx_len), L.ptr(gen_count), L.ptr(finish_len), L.ptr(next_ids), L.ptr(out_ids), out_ids.shape[1],
+                                             L.stream_ptr()), "sl_greedy_select_partial")
+
+
 def pack_weight(W: torch.Tensor) -> torch.Tensor:
     """(N,K) row-major -> fragment-packed buffer for the decode kernel (sl_pack_weight)."""
     L.require_gpu(W, "W")

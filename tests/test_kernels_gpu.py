@@ -378,6 +378,57 @@ def test_greedy_select_semantics():
     assert out[0, 0] == 777 and out[1, 1] == 10 and out[2, 2] == 7 and out[3, 3] == 99
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(260, 1000, 256), (300, 5000, 512), (1024, 20000, 3072), (513, 4097 * 4, 1024), (70, 130, 64)])
+def test_fused_lm_head_top1_equals_logits_then_argmax(dt, M, N, K):
+    """lm_head + argmax without the logits round trip: the tiled kernels' fused top-1 leaves one (value, column)
+    per row and 64-column group; sl_greedy_select_partial finishes.  Against the SAME kernel's fp32 logits + sl_greedy_select the
+    tokens are identical bit for bit (same accumulators), ties and planted duplicates included, on both tile sizes (128^2: the
+    small products; 256^2: K >= 1024 with >= 512 tiles), ragged last row tile and column group."""
+    A, W = rnd(M, K, seed=91), rnd(N, K, seed=92, std=K ** -0.5)
+    W[N - 1] = W[3]                                    # duplicate weight rows: exact ties between columns 3 and N - 1 in every row
+    if N > 200:
+        W[130] = W[3]
+    Ad, Wd = A.to(dev(), dt), W.to(dev(), dt)
+    bias = rnd(N, seed=93).to(dev(), dt)
+    bias[N - 1] = bias[3]
+    if N > 200:
+        bias[130] = bias[3]
+    for b in (None, bias):
+        logits = ops.gemm(Ad, Wd, bias=b, out_f32=True)
+        val, idx = ops.gemm_top1(Ad, Wd, bias=b)
+        ng = (N + 63) // 64
+        assert val.shape == (ng, M)
+        # every partial is the group's maximum at its lowest column
+        pad = torch.full((M, ng * 64 - N), float("-inf"), device=dev())
+        grp = torch.cat([logits, pad], 1).view(M, ng, 64)
+        gmax, garg = grp.max(dim=2)
+        assert torch.equal(val.T.contiguous(), gmax)
+        first = (grp == gmax[:, :, None]).float().argmax(dim=2) + torch.arange(ng, device=dev())[None, :] * 64
+        assert torch.equal(idx.T.long().contiguous(), first)
+        # ... and the two select passes agree on token and bookkeeping
+        state = []
+        for fused in (False, True):
+            unfinished = torch.ones(M, dtype=torch.int32, device=dev()); unfinished[M // 2] = 0
+            ctx = torch.arange(M, dtype=torch.int32, device=dev())
+            gen = torch.zeros(M, dtype=torch.int32, device=dev())
+            fin = torch.zeros(M, dtype=torch.int32, device=dev())
+            nxt = torch.zeros(M, dtype=torch.int32, device=dev())
+            out = torch.full((M, 3), -1, dtype=torch.int32, device=dev())
+            eos = [int(logits[0].argmax()), 3]
+            if fused:
+                ops.greedy_select_partial(val, idx, eos, 7, True, unfinished, ctx, gen, fin, nxt, out)
+            else:
+                ops.greedy_select(logits, eos, 7, True, unfinished, ctx, gen, fin, nxt, out)
+            state.append([x.cpu() for x in (unfinished, ctx, gen, fin, nxt, out)])
+        for x, y in zip(*state):
+            assert torch.equal(x, y)
+        ref = logits.argmax(dim=1).cpu()          # torch returns the first maximum too
+        ref[M // 2] = 7
+        assert torch.equal(state[1][4].long(), ref)
+        assert int(state[1][0][0]) == 0            # row 0 emitted an EOS id
+
+
 # ---- decode-path kernels: packed weights, fused RMSNorm, fused RoPE + KV append, flash-decoding ----------
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [1, 16, 17, 40, 64, 100, 128, 200, 256])   # <= 32 rows: skinny kernel, above: gemm_stream.hip
