@@ -335,32 +335,45 @@ int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32
   return 0;
 }
 
-// greedy selection over the [group][B] partial maxima a fused lm_head left (gemm.hip tile_argmax): block = 64 rows x 16 group
-// stripes, every wave-level load is 64 consecutive rows of one group (256 contiguous bytes); the stripes meet in LDS in stripe
-// order and the bookkeeping of greedy_select_kernel follows.  Compare rule everywhere: larger value, then lower column.
+// greedy selection over the [group][B] partial maxima a fused lm_head left (gemm.hip tile_argmax): block = 32 rows x 32 group
+// stripes (a wave = two stripes of 32 consecutive rows: two 128-byte segments per load), eight groups' values and columns in
+// flight per thread — the scan is latency-bound (2 004 groups of 8 bytes per row at vocab 128 256), not bandwidth-bound; the
+// stripes meet in LDS in stripe order and the bookkeeping of greedy_select_kernel follows.  Compare rule everywhere: larger
+// value, then lower column.
 __global__ __launch_bounds__(1024) void greedy_select_partial_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int n_groups, int B,
                                                                      EosList eos, int pad_id, int use_eos, int advance_ctx,
                                                                      int32_t* __restrict__ unfinished, int32_t* __restrict__ ctx_len,
                                                                      int32_t* __restrict__ gen_count, int32_t* __restrict__ finish_len,
                                                                      int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new) {
-  __shared__ float sv[16][64];
-  __shared__ int si[16][64];
-  const int lr = threadIdx.x & 63, stripe = threadIdx.x >> 6;
-  const int b = blockIdx.x * 64 + lr;
+  constexpr int ROWS = 32, STRIPES = 32, U = 8;
+  __shared__ float sv[STRIPES][ROWS];
+  __shared__ int si[STRIPES][ROWS];
+  const int lr = threadIdx.x & (ROWS - 1), stripe = threadIdx.x / ROWS;
+  const int b = blockIdx.x * ROWS + lr;
+  const int bc = b < B ? b : B - 1;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  if (b < B) {
-    for (int g = stripe; g < n_groups; g += 16) {
-      const float v = pv[(int64_t)g * B + b];
-      const int i = pi[(int64_t)g * B + b];
-      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  for (int g0 = stripe; g0 < n_groups; g0 += STRIPES * U) {
+    float v[U];
+    int ix[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int g = g0 + u * STRIPES;
+      const int64_t at = (int64_t)(g < n_groups ? g : n_groups - 1) * B + bc;
+      v[u] = pv[at];
+      ix[u] = pi[at];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (g0 + u * STRIPES >= n_groups) continue;
+      if (v[u] > best || (v[u] == best && ix[u] < bi)) { best = v[u]; bi = ix[u]; }
     }
   }
   sv[stripe][lr] = best;
   si[stripe][lr] = bi;
   __syncthreads();
   if (stripe != 0 || b >= B) return;
-  for (int s2 = 1; s2 < 16; ++s2)
+  for (int s2 = 1; s2 < STRIPES; ++s2)
     if (sv[s2][lr] > best || (sv[s2][lr] == best && si[s2][lr] < bi)) { best = sv[s2][lr]; bi = si[s2][lr]; }
   if (bi == 0x7fffffff) bi = 0;
   int tok = bi;
@@ -387,7 +400,7 @@ int sl_greedy_select_partial_impl(const float* amax_val, const int32_t* amax_idx
   EosList e;
   e.n = n_eos;
   for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
-  hipLaunchKernelGGL(greedy_select_partial_kernel, dim3((B + 63) / 64), dim3(1024), 0, st, amax_val, amax_idx, n_groups, B, e, pad_id, use_eos, advance_ctx,
+  hipLaunchKernelGGL(greedy_select_partial_kernel, dim3((B + 31) / 32), dim3(1024), 0, st, amax_val, amax_idx, n_groups, B, e, pad_id, use_eos, advance_ctx,
                      unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, max_new);
   SL_CHECK_LAUNCH("greedy_select_partial");
   return 0;
@@ -618,11 +631,59 @@ typedef __attribute__((address_space(3))) void* lds_ptr3_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 constexpr int DSPLIT = 64;  // keys per block (KS = 128 for batches that fill the chip anyway: half the records to merge)
 
+// Partial records handed from the split blocks to the block that merges them INSIDE the launch (cnt != nullptr): every record
+// word is stored with sc1 (agent scope: through the XCD's non-coherent L2 to the memory side), drained with s_waitcnt before the
+// arrival counter is bumped, and re-read with sc1 loads by the block whose add came last (MI355X_MICROARCH.md, Correctness
+// boundaries; the same hand-off as gemm_stream.hip's K-split fix-up).  The merge is attn_decode_combine_kernel's arithmetic in
+// its order (splits ascending), so both forms give the same bits.
+__device__ __forceinline__ void st_rec(float* p, float v, bool sc1) {
+  if (sc1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+__device__ __forceinline__ float ld_rec_sc1(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// the last of a (sequence, kv head)'s `nsplit` blocks to arrive merges their records and writes the REP heads' outputs
+template <typename T, int REP>
+__device__ __forceinline__ void split_arrive_and_merge(float* __restrict__ part, int32_t* __restrict__ cnt, T* __restrict__ out, int b, int kvh, int nkv,
+                                                        int nsplit) {
+  constexpr int D = 128, PSTRIDE = REP * D + 2 * REP;
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached the memory side
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(&cnt[b * nkv + kvh], 1);
+    s_last = old == nsplit - 1;
+    if (old == nsplit - 1) cnt[b * nkv + kvh] = 0;     // leave the counter as it was found: zero between launches
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const float* base = part + ((int64_t)b * nkv + kvh) * nsplit * PSTRIDE;
+  for (int o = threadIdx.x; o < REP * D; o += 256) {
+    const int h = o / D, d = o % D;
+    float M = -INFINITY;
+    for (int sp2 = 0; sp2 < nsplit; ++sp2) M = fmaxf(M, ld_rec_sc1(base + (int64_t)sp2 * PSTRIDE + REP * D + h));
+    float Lsum = 0.f, acc = 0.f;
+    for (int sp2 = 0; sp2 < nsplit; ++sp2) {
+      const float* rec = base + (int64_t)sp2 * PSTRIDE;
+      const float m = ld_rec_sc1(rec + REP * D + h);
+      if (m == -INFINITY) continue;
+      const float w = __expf(m - M);
+      Lsum += w * ld_rec_sc1(rec + REP * D + REP + h);
+      acc += w * ld_rec_sc1(rec + h * D + d);
+    }
+    out[((int64_t)b * nkv * REP + kvh * REP + h) * D + d] = from_f32<T>(Lsum > 0.f ? acc / Lsum : 0.f);
+  }
+}
+
 template <typename T, int REP, int KS>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restrict__ q, int64_t q_stride, const T* __restrict__ kc,
                                                                 const T* __restrict__ vc, float* __restrict__ part,
                                                                 const int32_t* __restrict__ ctx_len, int ctx_add, int nkv, int max_ctx,
-                                                                float scale) {
+                                                                float scale, int32_t* __restrict__ cnt, T* __restrict__ out) {
   constexpr int D = 128;
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int EPL = D / 16, CPLN = EPL / VEC;
@@ -642,8 +703,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   const int n_keys = ctx_len[b] + ctx_add;
   const int k0 = sp * KS;
   float* rec = part + (((int64_t)b * nkv + kvh) * nsplit + sp) * PSTRIDE;
+  const bool fuse = cnt != nullptr;      // merge inside this launch (no combine kernel)
   if (k0 >= n_keys) {  // empty split: neutral record
-    if (tid < REP) { rec[REP * D + tid] = -INFINITY; rec[REP * D + REP + tid] = 0.f; }
+    if (tid < REP) { st_rec(rec + REP * D + tid, -INFINITY, fuse); st_rec(rec + REP * D + REP + tid, 0.f, fuse); }
+    if (fuse) split_arrive_and_merge<T, REP>(part, cnt, out, b, kvh, nkv, nsplit);
     return;
   }
   const int nk = (n_keys - k0) < KS ? (n_keys - k0) : KS;
@@ -739,7 +802,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
       l += p;
     }
     l = wave_sum(l);
-    if (lane == 0) { rec[REP * D + h] = m; rec[REP * D + REP + h] = l; }
+    if (lane == 0) { st_rec(rec + REP * D + h, m, fuse); st_rec(rec + REP * D + REP + h, l, fuse); }
   }
   if constexpr (MFMA_QK) {
     // phase 3 on the matrix core: O[head][dim] = P . V with V consumed column-wise by ds_read_b64_tr_b16 (a 16-lane group
@@ -769,9 +832,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
       }
       if (q4 == 0) {
 #pragma unroll
-        for (int h = 0; h < REP; ++h) rec[h * D + df * 16 + r] = oacc[h];
+        for (int h = 0; h < REP; ++h) st_rec(rec + h * D + df * 16 + r, oacc[h], fuse);
       }
     }
+    if (fuse) split_arrive_and_merge<T, REP>(part, cnt, out, b, kvh, nkv, nsplit);
     return;
   }
   __syncthreads();
@@ -806,8 +870,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
     float s = 0.f;
 #pragma unroll
     for (int kg = 0; kg < 16; ++kg) s += red[kg][h][d];
-    rec[h * D + d] = s;
+    st_rec(rec + h * D + d, s, fuse);
   }
+  if (fuse) split_arrive_and_merge<T, REP>(part, cnt, out, b, kvh, nkv, nsplit);
 }
 
 // Single-pass form (bf16, B * n_kv >= 32): one block per (sequence, kv head)
@@ -969,14 +1034,25 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
   out[((int64_t)b * nh + head) * D + d] = from_f32<T>(L > 0.f ? o / L : 0.f);
 }
 
-size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx) {
+// workspace = the partial records, then (256-byte aligned) one arrival counter per (sequence, kv head) for the in-launch merge
+static size_t attn_split_records_bytes(int B, int n_heads, int n_kv, int max_ctx) {
   const int rep = n_heads / n_kv, nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;   // sized for the finer split
-  return (size_t)B * n_kv * nsplit * (rep * 128 + 2 * rep) * sizeof(float);
+  return ((size_t)B * n_kv * nsplit * (rep * 128 + 2 * rep) * sizeof(float) + 255) & ~(size_t)255;
+}
+size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx) {
+  return attn_split_records_bytes(B, n_heads, n_kv, max_ctx) + (((size_t)B * n_kv * sizeof(int32_t) + 255) & ~(size_t)255);
+}
+// The counters must be zero when a launch starts; every launch leaves them zero.  The owner of the workspace zeroes them once
+// (the decode runtime: at the start of a generate / decode-step call, outside the captured graph).
+int sl_attn_decode_split_zero_counters(void* workspace, int B, int n_heads, int n_kv, int max_ctx, hipStream_t st) {
+  SL_HIP(hipMemsetAsync((unsigned char*)workspace + attn_split_records_bytes(B, n_heads, n_kv, max_ctx), 0, (size_t)B * n_kv * sizeof(int32_t), st));
+  return 0;
 }
 
 template <typename T, int REP>
 static int launch_attn_decode_split(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, float* part,
-                                    const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st) {
+                                    const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st,
+                                    int32_t* cnt) {
   if constexpr (sizeof(T) == 2) {
     const int64_t full_min = sl_env().attn_full_min;   // tuning switch: (sequence, kv head) pairs from which the single-pass form runs; measured faster than split + merge from B = 4 up (9.1 vs 11.4 us), 97 vs 127 us at B = 512
     if ((int64_t)B * nkv >= full_min && !sl_env().attn_force_split) {
@@ -990,32 +1066,42 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
   if ((int64_t)B * nkv >= 512) {
     nsplit = (max_ctx + 127) / 128;
     hipLaunchKernelGGL((attn_decode_split_kernel<T, REP, 128>), dim3(nkv, B, nsplit), dim3(256), 0, st, (const T*)q, q_stride, (const T*)kc,
-                       (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale);
+                       (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale, cnt, (T*)out);
   } else {
     nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;
     hipLaunchKernelGGL((attn_decode_split_kernel<T, REP, DSPLIT>), dim3(nkv, B, nsplit), dim3(256), 0, st, (const T*)q, q_stride, (const T*)kc,
-                       (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale);
+                       (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale, cnt, (T*)out);
   }
   SL_CHECK_LAUNCH("attn_decode_split");
+  if (cnt) return 0;   // the last block of every (sequence, kv head) merged its records
   hipLaunchKernelGGL((attn_decode_combine_kernel<T>), dim3(nh, B), dim3(128), 0, st, part, (T*)out, nh, nkv, nsplit);
   SL_CHECK_LAUNCH("attn_decode_combine");
   return 0;
 }
 
+// counters: 0 = separate combine launch; 1 = merge inside the split launch, the caller has zeroed the counters
+// (sl_attn_decode_split_zero_counters) on this stream; 2 = the same, zeroing them here first (one memset per call)
 int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
                               const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
-                              float scale, int32_t dtype, hipStream_t st) {
+                              float scale, int32_t dtype, hipStream_t st, int counters) {
   SL_CHECK_ARG(q && k_cache && v_cache && out && workspace && ctx_len && B > 0, "sl_attn_decode_split: bad arguments");
   SL_CHECK_ARG(D == 128, "sl_attn_decode_split: head_dim %d not built (128)", D);
   SL_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "sl_attn_decode_split: n_heads %% n_kv != 0");
   float* part = (float*)workspace;
   const int rep = n_heads / n_kv;
+  // Measured (bench.py latency_b1, Llama-3.2-3B, batch 1, ctx 137-393: 7 splits x 8 kv heads): merged in-launch 1.778 ms per token
+  // against 1.640 ms with the separate combine launch (+4.9 us per layer): the arrival counter round trip plus the sc1 re-reads
+  // behind it cost more than a launch boundary inside the captured graph (~1.2 us) plus the 4.9 us combine kernel.  Same finding
+  // as gemm_stream.hip's K-split fix-up; kept as a tested option, off by default.
+  if (!sl_env().attn_split_merge) counters = 0;
+  int32_t* cnt = counters ? (int32_t*)((unsigned char*)workspace + attn_split_records_bytes(B, n_heads, n_kv, max_ctx)) : nullptr;
+  if (counters == 2) SL_TRY(sl_attn_decode_split_zero_counters(workspace, B, n_heads, n_kv, max_ctx, st));
   SL_DISPATCH_DTYPE(dtype, T, {
     switch (rep) {
-      case 1: return launch_attn_decode_split<T, 1>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
-      case 2: return launch_attn_decode_split<T, 2>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
-      case 3: return launch_attn_decode_split<T, 3>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
-      case 4: return launch_attn_decode_split<T, 4>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st);
+      case 1: return launch_attn_decode_split<T, 1>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
+      case 2: return launch_attn_decode_split<T, 2>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
+      case 3: return launch_attn_decode_split<T, 3>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
+      case 4: return launch_attn_decode_split<T, 4>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
       default: sl_set_error("sl_attn_decode_split: n_heads/n_kv=%d not built (1..4)", rep); return SL_ERR_UNSUPPORTED;
     }
   });
@@ -1029,5 +1115,5 @@ extern "C" int sl_attn_decode_split(const void* q, int64_t q_stride, const void*
                                     const int32_t* ctx_len, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx, float scale,
                                     int32_t dtype, sl_stream stream) {
   return sl_attn_decode_split_impl(q, q_stride, k_cache, v_cache, out, workspace, ctx_len, 0, B, n_heads, n_kv, D, max_ctx, scale, dtype,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, 2);
 }

@@ -19,9 +19,10 @@ int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float tempe
                           int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new,
                           int32_t* choice_ws, hipStream_t st);
 
+int sl_attn_decode_split_zero_counters(void* workspace, int B, int n_heads, int n_kv, int max_ctx, hipStream_t st);
 int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
                               const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
-                              float scale, int32_t dtype, hipStream_t st);
+                              float scale, int32_t dtype, hipStream_t st, int counters);
 size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx);
 int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st);
 
@@ -476,7 +477,7 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
     const void* a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
     SL_TRY(dec_gemm(m, w, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st, rstd_qkv));
-    SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
+    SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1));
     SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st, nullptr,
                     rstd_chain ? w.rstd_a : nullptr));
     sl_gemm_fused fn;
@@ -495,7 +496,7 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
   SL_TRY(sl_rope_kv_append(w.qkv, kc, vc, w.tok_seq, decode ? ctx_len_dev : w.tok_pos, m->rope_cos, m->rope_sin, n, nh, nkv, D, kv->max_ctx,
                            dt, (sl_stream)st));
   if (decode) {
-    SL_TRY(sl_attn_decode_split_impl(w.qkv, qkv_w, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st));
+    SL_TRY(sl_attn_decode_split_impl(w.qkv, qkv_w, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1));
   } else {
     sl_attn_args a;
     memset(&a, 0, sizeof(a));
@@ -630,6 +631,7 @@ extern "C" int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* 
   const size_t need = off + llama_carve(m, B, B, bptr(workspace) + off, workspace_bytes - off, w);
   SL_CHECK_ARG(need <= workspace_bytes, "sl_llama_decode_step: workspace %zu B < required %zu B", workspace_bytes, need);
   if (w.split && w.split_bytes >= 8192) SL_HIP(hipMemsetAsync(w.split, 0, 8192, st));   // the K-split fix-up's counters start at zero
+  SL_TRY(sl_attn_decode_split_zero_counters(w.part, B, m->n_heads, m->n_kv_heads, kv->max_ctx, st));   // ... and the split attention's arrival counters
   hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
   SL_CHECK_LAUNCH("iota");
   return decode_step(m, kv, next_ids_dev, ctx_len_dev, B, logits, x, w, st);
@@ -759,6 +761,7 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
   LlamaWs w;
   llama_carve(m, B, B, scratch, scratch_bytes, w);
   if (w.split && w.split_bytes >= 8192) SL_HIP(hipMemsetAsync(w.split, 0, 8192, st));   // the K-split fix-up's counters start at zero (sl_gemm_fused.split_ws)
+  SL_TRY(sl_attn_decode_split_zero_counters(w.part, B, m->n_heads, m->n_kv_heads, kv->max_ctx, st));   // split attention merges its records in-launch: arrival counters start at zero
   hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
   SL_CHECK_LAUNCH("iota");
   int steps_done = 1;
