@@ -913,7 +913,17 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
     const int min_k = sl_env().t256_min_k;
     // rows padded to 256 vs to 128: short (grouped) products such as the 123-row projector would half-fill the big tile
     const int64_t m128 = (int64_t)((p.M + TBM - 1) / TBM) * TBM, m256 = (int64_t)((p.M + XBM - 1) / XBM) * XBM;
-    if (t256 >= min_tiles && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
+    // Mid-size products (KD windows: M = 2-8 k rows): neither tile count fills the chip evenly, so the choice is made on whole
+    // rounds of tiles — 256 slots of one 256^2 tile per CU against 512 slots of 128^2 tiles (two blocks per CU, each at ~0.85 of
+    // the big tile's rate per flop): 5072 x 3072 is 240 big tiles = one round (1.09 PF/s; 960 small ones = two rounds, 0.99),
+    // 3200 x 5120 is 260 big tiles = two rounds, the second almost empty (0.63 PF/s; small tiles 0.98).  tools/sweep_t256.py.
+    bool by_rounds = false;
+    if (t256 < min_tiles && !p.grp && batch == 1) {
+      const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+      const int64_t r256 = (t256 + 255) / 256, r128 = (t128 + 511) / 512;
+      by_rounds = (double)r256 * (XBM * XBN) * 0.85 < (double)r128 * 2.0 * (TBM * TBN);
+    }
+    if ((t256 >= min_tiles || by_rounds) && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
       hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
