@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspeechllm.so")
+# SL_LIB_PATH: developer switch for A/B runs of two builds of the library (tools/); the product loads the in-tree build
+LIB_PATH = os.environ.get("SL_LIB_PATH") or os.path.join(_HERE, "libspeechllm.so")
 
 SL_F32, SL_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU_MUL, ACT_ROPE_KV = 0, 1, 2, 3

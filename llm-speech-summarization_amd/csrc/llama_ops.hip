@@ -629,6 +629,19 @@ extern "C" int sl_pack_weight(const void* src, int64_t ld_src, void* dst, int32_
 // ----------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr3_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+// K / V cache rows are read exactly once per decode step (one block per sequence and kv head): non-temporal loads keep them from
+// displacing what other kernels re-read in L2 / the Infinity Cache and land sooner (MI355X_MICROARCH.md, nt-weights).  Measured
+// (tools/time_decode_attn.py, bf16, 8 kv heads, profiles/r03_l_attn_nt.txt): 1 024 sequences x 264 keys 194.1 -> 178.3 us
+// (5.77 -> 6.28 TB/s = 0.785 of the 8 TB/s peak, the rate a plain copy reaches on this chip), x 393 keys 286.5 -> 260.8 us, 512
+// sequences 102.3 -> 92.1 us, 64 sequences 17.3 -> 16.1 us.
+#ifndef SL_KV_NT
+#define SL_KV_NT 1
+#endif
+#if SL_KV_NT
+#define SL_KV_LOAD(ptr) __builtin_nontemporal_load((const u32x4_t*)(ptr))
+#else
+#define SL_KV_LOAD(ptr) (*(const u32x4_t*)(ptr))
+#endif
 constexpr int DSPLIT = 64;  // keys per block (KS = 128 for batches that fill the chip anyway: half the records to merge)
 
 // Partial records handed from the split blocks to the block that merges them INSIDE the launch (cnt != nullptr): every record
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
     int key = ps * 16 + wave * 4 + grp;
     key = key < nk ? key : nk - 1;
 #pragma unroll
-    for (int c = 0; c < CPLN; ++c) kraw[ps][c] = *(const u32x4_t*)(kbase + (int64_t)key * D + gl * EPL + c * VEC);
+    for (int c = 0; c < CPLN; ++c) kraw[ps][c] = SL_KV_LOAD(kbase + (int64_t)key * D + gl * EPL + c * VEC);
   }
   // V rows for phase 3 are requested now: their HBM latency hides behind the score / softmax phases
   const int kg = tid >> 4, dc = tid & 15;
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
     int key = kg + 16 * ps;
     key = key < nk ? key : nk - 1;
 #pragma unroll
-    for (int c = 0; c < CPLN; ++c) vraw[ps][c] = *(const u32x4_t*)(vbase + (int64_t)key * D + dc * EPL + c * VEC);
+    for (int c = 0; c < CPLN; ++c) vraw[ps][c] = SL_KV_LOAD(vbase + (int64_t)key * D + dc * EPL + c * VEC);
   }
   if constexpr (MFMA_QK) {
     // S[head][key] = Q . K^T on the matrix core: A = the REP query heads of this kv head (rows REP..15 zero), B = 16 keys
@@ -916,14 +929,14 @@ __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __r
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int key = k0 + ps * 16 + wave * 4 + grp; key = key < n_keys ? key : n_keys - 1;
-      kraw[buf][ps] = *(const u32x4_t*)(kbase + (int64_t)key * D + gl * 8);
+      kraw[buf][ps] = SL_KV_LOAD(kbase + (int64_t)key * D + gl * 8);
     }
   };
   auto fetch_v = [&](int buf, int k0) {
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int key = k0 + kg + 16 * ps; key = key < n_keys ? key : n_keys - 1;
-      vraw[buf][ps] = *(const u32x4_t*)(vbase + (int64_t)key * D + dc * 8);
+      vraw[buf][ps] = SL_KV_LOAD(vbase + (int64_t)key * D + dc * 8);
     }
   };
   auto fetch = [&](int buf, int k0) { fetch_k(buf, k0); fetch_v(buf, k0); };
