@@ -168,6 +168,8 @@ _PROTOS = {
     "sl_silu_mul_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "sl_rope_inplace": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32, c_vp]),
+    "sl_layernorm_bwd_ws_bytes": (c_sz, [c_i64, c_i32]),
+    "sl_layernorm_bwd_ws": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "sl_rmsnorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),
     "sl_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "sl_softmax_rows": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_f32, c_i32, c_i32, c_vp]),

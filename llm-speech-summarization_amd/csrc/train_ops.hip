@@ -3,6 +3,8 @@
 // gradients (ref:model/audio_llama.py:72-101, ref:utils.py:167-178, ref:trainer.py:358-370), and the
 // HuBERT front-end backward (pool, strided-conv col2im, fused conv0).  All HBM-bound row kernels:
 // 16-byte accesses, fp32 math, one wave per row where a row reduction is needed.
+#include <stdlib.h>
+
 #include "common.h"
 
 constexpr int TR_MAXF = 64;  // floats per lane for row kernels (rows up to 4096 elements)
@@ -241,13 +243,20 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(T* __restrict__ x, co
 // LayerNorm backward (optionally through a fused GELU): dx, and fp32 dgamma/dbeta accumulated with one
 // atomic per column per block.  RMSNorm backward: dx only (the LLM is frozen).
 // ----------------------------------------------------------------------------------------------
-template <typename T, bool RMS>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ b,
-                                                       const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, int64_t rows, int cols, float eps, int gelu, int rows_per_block) {
+// MAXF = floats a lane holds of one row (64 * MAXF >= cols), NW = waves per block.  The general form (MAXF = TR_MAXF = 64, 4 waves)
+// keeps four MAXF-float arrays per lane live — 256 VGPRs, one wave per SIMD — and, because the column atomics of all blocks
+// land on the same 2 x cols addresses, runs on ~one block per CU: a 7 984 x 1 024 encoder LayerNorm took 127 us for 48 MB of
+// traffic (latency-bound: ~1 wave per SIMD, 8 rows one after the other).  Rows of <= 1 024 elements (every HuBERT / Whisper
+// LayerNorm: 512 conv channels, hidden 1 024) take MAXF = 16 and 16 waves per block: the same ~250 blocks, hence the same
+// number of atomics, but 16 rows in flight per CU instead of 4.
+template <typename T, bool RMS, int MAXF, int NW>
+__global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ b,
+                                                           const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int64_t rows, int cols, float eps, int gelu, int rows_per_block,
+                                                           float* __restrict__ part) {
   constexpr int VEC = Vec16<T>::VEC;
-  constexpr int MAXCH = TR_MAXF / VEC;
-  __shared__ float red[4][64 * TR_MAXF / 4 + 4];  // per-wave column partials, folded in two passes (gamma, beta)
+  constexpr int MAXCH = MAXF / VEC;
+  __shared__ float red[NW][64 * VEC + 4];  // per-wave column partials of one 64-chunk group, folded in two passes (gamma, beta)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols / VEC;
   float gg[MAXCH][VEC], bb[MAXCH][VEC], ag[MAXCH][VEC], ab[MAXCH][VEC];
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, 
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block) < rows ? (r0 + rows_per_block) : rows;
-  for (int64_t row = r0 + wave; row < r1; row += 4) {
+  for (int64_t row = r0 + wave; row < r1; row += NW) {
     float xv[MAXCH][VEC], dv[MAXCH][VEC];
     float s = 0.f;
 #pragma unroll
@@ -324,10 +333,13 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, 
     }
   }
   if (RMS || !dgamma) return;
-  // fold the four waves' column partials, then one atomic per column per block
+  // fold the waves' column partials, then one atomic per column per block — or, with a scratch buffer (`part`), one plain store
+  // per column per block into this block's record [2][cols], which norm_colreduce_kernel sums: the atomics of all blocks land on the
+  // same 2 x cols addresses and serialise at the memory side (~0.3 us per block: 79 us at 256 blocks for a 7 984 x 1 024 LayerNorm
+  // that moves 48 MB), the records do not
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    float* dst = pass == 0 ? dgamma : dbeta;
+    float* dst = part ? part + ((int64_t)blockIdx.x * 2 + pass) * cols : (pass == 0 ? dgamma : dbeta);
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
       const int ch = lane + 64 * i;
@@ -341,10 +353,44 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const int k = lane * VEC + e;
-          atomicAdd(dst + ch * VEC + e, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+          float t = red[0][k];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) t += red[w][k];
+          if (part) dst[ch * VEC + e] = t; else atomicAdd(dst + ch * VEC + e, t);
         }
       }
     }
+  }
+}
+
+// second pass of the scratch-buffer form: dgamma[c] += sum over blocks of part[b][0][c], dbeta likewise.  Block = 64 consecutive
+// entries of the [2 * cols] record x 16 stripes of blocks (a wave reads 256 contiguous bytes of one record), eight records in
+// flight per thread; the stripes meet in LDS in a fixed order, so the sum is reproducible.
+__global__ __launch_bounds__(1024) void norm_colreduce_kernel(const float* __restrict__ part, int nblocks, int cols, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;          // [0, 2 * cols): pass = i / cols
+  const int ic = i < 2 * cols ? i : 2 * cols - 1;
+  float t = 0.f;
+  for (int b0 = stripe; b0 < nblocks; b0 += 16 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 16 * u;
+      v[u] = b < nblocks ? part[(int64_t)b * 2 * cols + ic] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  red[stripe][lane] = t;
+  __syncthreads();
+  if (stripe == 0 && i < 2 * cols) {
+    float s = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) s += red[w][lane];
+    float* dst = i < cols ? dgamma + i : dbeta + (i - cols);
+    *dst += s;
   }
 }
 
@@ -951,22 +997,74 @@ extern "C" int sl_rope_inplace(void* x, const int32_t* tok_pos, const float* cos
   return 0;
 }
 
-extern "C" int sl_layernorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta,
-                                int64_t rows, int32_t cols, float eps, int32_t gelu, int32_t dtype, sl_stream stream) {
+// blocks of the scratch-buffer form: 16 rows in flight per block (16 waves), ~one block per CU (a block pays for its gain / bias
+// loads and the LDS fold of its partials whatever its share of the rows: 500 blocks of 16 rows took 47 us on 7 984 x 1 024)
+static int ln_bwd_ws_blocks(int64_t rows, int* rpb_out) {
+  int rpb = (int)ceil_div64(ceil_div64(rows, 256), 16) * 16;
+  rpb = rpb < 16 ? 16 : rpb;
+  if (rpb_out) *rpb_out = rpb;
+  return (int)ceil_div64(rows, rpb);
+}
+
+extern "C" size_t sl_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
+  if (rows <= 0 || cols <= 0 || cols > 64 * 16) return 0;     // wider rows take the general (atomics) form
+  return (size_t)ln_bwd_ws_blocks(rows, nullptr) * 2 * (size_t)cols * sizeof(float);
+}
+
+static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta, int64_t rows,
+                              int32_t cols, float eps, int32_t gelu, int32_t dtype, void* ws, size_t ws_bytes, sl_stream stream) {
   SL_CHECK_ARG(x && gamma && beta && dy && dx && rows >= 0 && cols > 0, "sl_layernorm_bwd: bad arguments");
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_layernorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
   if (rows == 0) return 0;
+  if (cols <= 64 * 16) {      // <= 1 024 elements per row: 16 floats per lane, 16 waves per block
+    if (ws && dgamma && dbeta && ws_bytes >= sl_layernorm_bwd_ws_bytes(rows, cols)) {
+      int rpb = 16;
+      const int nb = ln_bwd_ws_blocks(rows, &rpb);
+      SL_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
+                           (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws);
+      });
+      SL_CHECK_LAUNCH("layernorm_bwd");
+      hipLaunchKernelGGL(norm_colreduce_kernel, dim3((unsigned)((2 * cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nb, cols, dgamma,
+                         dbeta);
+      SL_CHECK_LAUNCH("layernorm_bwd(colreduce)");
+      return 0;
+    }
+    // no scratch: atomics, so few blocks (measured, tools/time_lnbwd.py: 7 984 x 1 024 takes 79 / 53 / 46 us at 256 / 128 / 64 blocks,
+    // 255 984 x 512 403 / 666 / 1 287 us)
+    int64_t lnb = rows / 64;
+    lnb = lnb < 64 ? 64 : (lnb > 256 ? 256 : lnb);
+    int rpb16 = (int)ceil_div64(ceil_div64(rows, lnb), 16) * 16;
+    rpb16 = rpb16 < 16 ? 16 : rpb16;
+    SL_DISPATCH_DTYPE(dtype, T, {
+      hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)ceil_div64(rows, rpb16)), dim3(1024), 0, (hipStream_t)stream, (const T*)x,
+                         (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb16, (float*)nullptr);
+    });
+    SL_CHECK_LAUNCH("layernorm_bwd");
+    return 0;
+  }
   // rows per block: 64 rows per block left a 7 984-row encoder LayerNorm on 125 blocks (115 us for 48 MB); ~1 000 blocks were
   // WORSE (254 us): the per-block column atomics all land on the same 2 x cols addresses and serialise at the memory side
   int rpb = (int)ceil_div64(ceil_div64(rows, 256), 4) * 4;   // ~one block per CU; more blocks = more atomics on the same 2 x cols addresses
   rpb = rpb < 4 ? 4 : (rpb > 64 ? 64 : rpb);
   SL_DISPATCH_DTYPE(dtype, T, {
-    hipLaunchKernelGGL((norm_bwd_kernel<T, false>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                       (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb);
+    hipLaunchKernelGGL((norm_bwd_kernel<T, false, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
+                       (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)nullptr);
   });
   SL_CHECK_LAUNCH("layernorm_bwd");
   return 0;
+}
+
+extern "C" int sl_layernorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta,
+                                int64_t rows, int32_t cols, float eps, int32_t gelu, int32_t dtype, sl_stream stream) {
+  return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, gelu, dtype, nullptr, 0, stream);
+}
+
+extern "C" int sl_layernorm_bwd_ws(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta,
+                                   int64_t rows, int32_t cols, float eps, int32_t gelu, int32_t dtype, void* workspace, size_t workspace_bytes,
+                                   sl_stream stream) {
+  return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, gelu, dtype, workspace, workspace_bytes, stream);
 }
 
 extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
@@ -977,8 +1075,8 @@ extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void
   if (rows == 0) return 0;
   const int rpb = 16;
   SL_DISPATCH_DTYPE(dtype, T, {
-    hipLaunchKernelGGL((norm_bwd_kernel<T, true>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb);
+    hipLaunchKernelGGL((norm_bwd_kernel<T, true, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr);
   });
   SL_CHECK_LAUNCH("rmsnorm_bwd");
   return 0;

@@ -125,6 +125,8 @@ int attn_bwd(int dt, const void* qkv, int64_t qkv_w, const void* out, const void
 struct EncWs {
   void *tmp_h, *d_mid, *d_pre1, *d_h1, *d_h2, *d_att, *d_qkv;
   float* delta;
+  void* ln_ws;         // per-block dgamma / dbeta records of the LayerNorm backward (sl_layernorm_bwd_ws)
+  size_t ln_ws_bytes;
   BwdScratch s;
 };
 
@@ -142,6 +144,8 @@ static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs
   w.d_att = cv.take(n * H * sz);
   w.d_qkv = cv.take(n * 3 * H * sz);
   w.delta = (float*)cv.take(n * c->n_heads * sizeof(float));
+  w.ln_ws_bytes = sl_layernorm_bwd_ws_bytes(n, (int32_t)H);
+  w.ln_ws = cv.take(w.ln_ws_bytes);
   w.s.yt = cv.take(big * Mp * sz);
   w.s.xt = cv.take(big * Mp * sz);
   w.s.wt = cv.take(big * (big + 8) * sz);
@@ -222,7 +226,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, st));
     SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, stream));
     SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st));
-    SL_TRY(sl_layernorm_bwd(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, 0, dt, stream));   // d_h2 = d x_mid (LN path)
+    SL_TRY(sl_layernorm_bwd_ws(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));   // d_h2 = d x_mid (LN path)
     SL_TRY(sl_axpby(dx, w.d_h2, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
     const void* d_o1 = w.d_h2;
@@ -235,7 +239,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, st));
     SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, stream));
     SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st));
-    SL_TRY(sl_layernorm_bwd(sv.x, L.ln1_g, L.ln1_b, w.d_h1, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, 0, dt, stream));            // dx = d x (LN path)
+    SL_TRY(sl_layernorm_bwd_ws(sv.x, L.ln1_g, L.ln1_b, w.d_h1, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));            // dx = d x (LN path)
     SL_TRY(sl_axpby(w.d_h2, dx, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
     (void)sz;
   }

@@ -475,11 +475,21 @@ def rope_inplace(x, tok_pos, cos, sin, heads, n_rot, D, inverse=False):
     return x
 
 
+_LN_WS = {}
+
+
 def layernorm_bwd(x, g, b, dy, eps, dgamma=None, dbeta=None, gelu=False):
     dx = torch.empty_like(dy)
     rows = x.numel() // x.shape[-1]
-    L.check(L.lib().sl_layernorm_bwd(L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(dy), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), rows, x.shape[-1], eps,
-                                     int(gelu), L.dtype_code(x.dtype), L.stream_ptr()), "sl_layernorm_bwd")
+    need = int(L.lib().sl_layernorm_bwd_ws_bytes(rows, x.shape[-1])) if dgamma is not None and dbeta is not None else 0
+    ws = None
+    if need:                                  # scratch for the blocks' dgamma / dbeta records (one buffer per device, grown on demand)
+        ws = _LN_WS.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _LN_WS[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().sl_layernorm_bwd_ws(L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(dy), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), rows, x.shape[-1], eps,
+                                        int(gelu), L.dtype_code(x.dtype), L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr()),
+            "sl_layernorm_bwd_ws")
     return dx
 
 

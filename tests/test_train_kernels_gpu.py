@@ -91,7 +91,7 @@ def test_gelu_silu_rope_backward(dt):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("gelu", [False, True])
-@pytest.mark.parametrize("rows,cols", [(131, 512), (70, 1024), (5, 128)])
+@pytest.mark.parametrize("rows,cols", [(131, 512), (70, 1024), (5, 128), (20000, 512), (3000, 2048)])
 def test_layernorm_backward(dt, gelu, rows, cols):
     x, g, b, dy = rnd(rows, cols, seed=13), 1 + rnd(cols, seed=14, std=0.1), rnd(cols, seed=15, std=0.1), rnd(rows, cols, seed=16)
     xr, gr, br = q(x, dt).requires_grad_(), q(g, dt).requires_grad_(), q(b, dt).requires_grad_()
@@ -102,6 +102,17 @@ def test_layernorm_backward(dt, gelu, rows, cols):
     dx = ops.layernorm_bwd(x.to(DEV, dt), g.to(DEV, dt), b.to(DEV, dt), dy.to(DEV, dt), 1e-5, dg, db, gelu=gelu)
     assert rel_err(dx.float().cpu(), xr.grad) < TOL[dt]
     assert rel_err(dg.cpu() - 1.0, gr.grad) < 3e-4 and rel_err(db.cpu(), br.grad) < 3e-4
+    # the scratch-free entry point (atomics) accumulates the same parameter gradients; the scratch form is reproducible bit for bit
+    dg2, db2 = torch.full((cols,), 1.0, device=DEV), torch.zeros(cols, device=DEV)
+    dx2 = torch.empty_like(dx)
+    xd, gd, bd, dyd = x.to(DEV, dt), g.to(DEV, dt), b.to(DEV, dt), dy.to(DEV, dt)
+    L.check(L.lib().sl_layernorm_bwd(L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(dyd), L.ptr(dx2), L.ptr(dg2), L.ptr(db2),
+                                     rows, cols, 1e-5, int(gelu), L.dtype_code(dt), L.stream_ptr()), "sl_layernorm_bwd")
+    assert torch.equal(dx2, dx) and rel_err(dg2.cpu() - 1.0, gr.grad) < 3e-4 and rel_err(db2.cpu(), br.grad) < 3e-4
+    if cols <= 1024:
+        dg3, db3 = torch.full((cols,), 1.0, device=DEV), torch.zeros(cols, device=DEV)
+        ops.layernorm_bwd(x.to(DEV, dt), g.to(DEV, dt), b.to(DEV, dt), dy.to(DEV, dt), 1e-5, dg3, db3, gelu=gelu)
+        assert torch.equal(dg3, dg) and torch.equal(db3, db)
 
 
 @pytest.mark.parametrize("dt", DT)
