@@ -129,6 +129,14 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
             tried[n] = round(min(decode(out, 2)) * 1e3, 1)
             n //= 2
         cores = min(tried, key=tried.get) if tried else min(32, phys)
+        if len(tried) > 1:          # two steps are a noisy ranking: the best two settings run six steps each, the better median wins
+            runoff = {}
+            for n in sorted(tried, key=tried.get)[:2]:
+                torch.set_num_threads(n)
+                decode(out, 1)
+                runoff[n] = med(decode(out, 6))
+            cores = min(runoff, key=runoff.get)
+            tried = {**tried, **{f"{n} (6 steps)": round(v * 1e3, 1) for n, v in runoff.items()}}
         torch.set_num_threads(cores)
         enc_t, pre_t = [], []
         for _ in range(3):
@@ -146,7 +154,7 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
             "decode_ms_per_token_by_threads": tried,
             "audio_sec_per_s": round(wave.numel() / 16000.0 / enc_s, 2), "prefill_tokens_per_s": round(prompt.shape[1] / pre_s, 1),
             "decode_tokens_per_s": round(1.0 / tok_s, 3),
-            "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s on {cores} threads (fastest of {sorted(tried)} on a host with {phys} physical cores), "
+            "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s on {cores} threads (fastest of {[k for k in tried if isinstance(k, int)]} on a host with {phys} physical cores), "
                        f"after 1 warm-up pass: encoder {enc_s:.2f} s and prefill S={prompt.shape[1]} {pre_s:.2f} s (medians of 3), "
                        f"{new_tokens} decode steps at {tok_s * 1e3:.0f} ms/token (median), fp32 oracle; value "
                        f"projected to {full_new_tokens} tokens per utterance at batch 1")}
