@@ -164,6 +164,28 @@ int main() {
   EXPECT_ARG_ERROR(sl_llama_stack_train_fwd(nullptr, &lc, nullptr, nullptr, nullptr, 0, nullptr));
   EXPECT_ARG_ERROR(sl_llama_stack_train_bwd(nullptr, &lc, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
 
+  // ---- round-3 entry points
+  EXPECT_ARG_ERROR(sl_adamw_step(nullptr, nullptr, 0, 0, 5e-5, 0.9, 0.999, 1e-8, 0.01, 1, nullptr));
+  EXPECT_ARG_ERROR(sl_adamw_step((const sl_adamw_tensor*)ws, (const int64_t*)ws, 1, 1, 5e-5, 1.5, 0.999, 1e-8, 0.01, 1, nullptr));    // beta1 >= 1
+  EXPECT_ARG_ERROR(sl_adamw_step((const sl_adamw_tensor*)ws, (const int64_t*)ws, 1, 1, 5e-5, 0.9, 0.999, 1e-8, 0.01, 0, nullptr));    // step counts from 1
+  EXPECT(sl_adamw_blocks(0) == 0 && sl_adamw_blocks(1) == 1 && sl_adamw_blocks(4096) == 1 && sl_adamw_blocks(4097) == 2, "adamw block count");
+  EXPECT(sl_layernorm_bwd_ws_bytes(7984, 1024) > 0 && sl_layernorm_bwd_ws_bytes(7984, 2048) == 0 && sl_layernorm_bwd_ws_bytes(0, 1024) == 0, "layernorm backward scratch size");
+  EXPECT_ARG_ERROR(sl_layernorm_bwd_ws(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 16, 1024, 1e-5f, 0, SL_BF16, nullptr, 0, nullptr));
+  EXPECT_ARG_ERROR(sl_greedy_select_partial(nullptr, nullptr, 2004, 1024, eos, 3, 128001, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 8, nullptr));
+  EXPECT_ARG_ERROR(sl_greedy_select_partial((const float*)ws, (const int32_t*)ws, 2004, 8, eos, 9, 128001, 1, 1, ctx, ctx, ctx, ctx, ctx, out_ids, 8, nullptr));   // > 8 eos ids
+  {
+    sl_gemm_args ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.A = ws; ga.W = ws; ga.lda = 64; ga.ldw = 64; ga.M = 32; ga.N = 128; ga.K = 64; ga.batch = 1; ga.dtype = SL_BF16; ga.out_f32 = 1;
+    sl_gemm_ex_args gx;
+    memset(&gx, 0, sizeof(gx));
+    gx.w_mod = 1; gx.amax_val = (float*)ws;                         // amax_idx missing
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.amax_idx = (int32_t*)ws;                                     // M <= 64: the fused top-1 lives in the tiled kernels
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+  }
+  EXPECT(sl_decode_graph_cache_clear() == 0, "nothing cached on this thread");
+
   if (g_fail == 0) printf("argcheck ok\n");
   return g_fail == 0 ? 0 : 1;
 }
