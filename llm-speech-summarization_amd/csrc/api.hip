@@ -57,7 +57,7 @@ static const SlEnv* env_load() {
   e.gemm_gm = env_int("SL_GEMM_GM", 8);
   e.attn_full_min = env_int("SL_ATTN_FULL_MIN", 32);
   e.attn_force_split = getenv("SL_ATTN_FORCE_SPLIT") != nullptr;
-  e.attn_split_merge = env_int("SL_ATTN_SPLIT_MERGE", 0);
+  e.attn_split_merge = env_int("SL_ATTN_SPLIT_MERGE", -1);
   e.attn_generic = env_int("SL_ATTN_GENERIC", 0);
   e.attn_qt = env_int("SL_ATTN_QT", 0);
   e.norm_single_row = env_int("SL_NORM_SINGLE_ROW", 0);

@@ -653,17 +653,15 @@ __device__ __forceinline__ void st_rec(float* p, float v, bool sc1) {
   if (sc1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
   else *p = v;
 }
-__device__ __forceinline__ float ld_rec_sc1(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
+// agent-scope relaxed load = global_load_dword ... sc1: re-reads a word another workgroup of this launch stored with sc1; the compiler
+// keeps several in flight (an asm load + wait per word serialised ~28 memory-side round trips per merge)
+__device__ __forceinline__ float ld_rec_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // the last of a (sequence, kv head)'s `nsplit` blocks to arrive merges their records and writes the REP heads' outputs
 template <typename T, int REP>
 __device__ __forceinline__ void split_arrive_and_merge(float* __restrict__ part, int32_t* __restrict__ cnt, T* __restrict__ out, int b, int kvh, int nkv,
                                                         int nsplit) {
-  constexpr int D = 128, PSTRIDE = REP * D + 2 * REP;
+  constexpr int D = 128, PSTRIDE = REP * D + 2 * REP, U = 8;
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached the memory side
   __syncthreads();
@@ -678,15 +676,34 @@ __device__ __forceinline__ void split_arrive_and_merge(float* __restrict__ part,
   for (int o = threadIdx.x; o < REP * D; o += 256) {
     const int h = o / D, d = o % D;
     float M = -INFINITY;
-    for (int sp2 = 0; sp2 < nsplit; ++sp2) M = fmaxf(M, ld_rec_sc1(base + (int64_t)sp2 * PSTRIDE + REP * D + h));
+    for (int s0 = 0; s0 < nsplit; s0 += U) {
+      float mv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int sp2 = s0 + u < nsplit ? s0 + u : nsplit - 1;
+        mv[u] = ld_rec_sc1(base + (int64_t)sp2 * PSTRIDE + REP * D + h);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) M = fmaxf(M, mv[u]);
+    }
     float Lsum = 0.f, acc = 0.f;
-    for (int sp2 = 0; sp2 < nsplit; ++sp2) {
-      const float* rec = base + (int64_t)sp2 * PSTRIDE;
-      const float m = ld_rec_sc1(rec + REP * D + h);
-      if (m == -INFINITY) continue;
-      const float w = __expf(m - M);
-      Lsum += w * ld_rec_sc1(rec + REP * D + REP + h);
-      acc += w * ld_rec_sc1(rec + h * D + d);
+    for (int s0 = 0; s0 < nsplit; s0 += U) {
+      float mv[U], lv[U], ov[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int sp2 = s0 + u < nsplit ? s0 + u : nsplit - 1;
+        const float* rec = base + (int64_t)sp2 * PSTRIDE;
+        mv[u] = ld_rec_sc1(rec + REP * D + h);
+        lv[u] = ld_rec_sc1(rec + REP * D + REP + h);
+        ov[u] = ld_rec_sc1(rec + h * D + d);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (s0 + u >= nsplit || mv[u] == -INFINITY) continue;
+        const float w = __expf(mv[u] - M);
+        Lsum += w * lv[u];
+        acc += w * ov[u];
+      }
     }
     out[((int64_t)b * nkv * REP + kvh * REP + h) * D + d] = from_f32<T>(Lsum > 0.f ? acc / Lsum : 0.f);
   }
@@ -1102,11 +1119,14 @@ int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cac
   SL_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "sl_attn_decode_split: n_heads %% n_kv != 0");
   float* part = (float*)workspace;
   const int rep = n_heads / n_kv;
-  // Measured (bench.py latency_b1, Llama-3.2-3B, batch 1, ctx 137-393: 7 splits x 8 kv heads): merged in-launch 1.778 ms per token
-  // against 1.640 ms with the separate combine launch (+4.9 us per layer): the arrival counter round trip plus the sc1 re-reads
-  // behind it cost more than a launch boundary inside the captured graph (~1.2 us) plus the 4.9 us combine kernel.  Same finding
-  // as gemm_stream.hip's K-split fix-up; kept as a tested option, off by default.
-  if (!sl_env().attn_split_merge) counters = 0;
+  // Measured (tools/time_decode_step.py, Llama-3.2-3B, 128 new tokens, 7 splits x 8 kv heads): merged in-launch 1.5725 / 1.5884 / 1.5922 ms
+  // per step at batch 1 / 2 / 3 against 1.6136 / 1.6213 / 1.6303 ms with the separate combine launch (the merge costs an arrival-counter
+  // round trip plus two batches of sc1 re-reads, ~3 us, the launch boundary + combine kernel ~4.5 us).  A first version that waited
+  // for every sc1 load on its own was SLOWER than the combine launch (1.778 vs 1.640 ms per token).  Default: merge where the split
+  // path serves small batches (B * n_kv <= 32); large fp32 batches keep the combine launch (one counter per (sequence, kv head)).
+  // SL_ATTN_SPLIT_MERGE = 0 / 1 forces it off / on.
+  const int mode = sl_env().attn_split_merge;
+  if (mode == 0 || (mode < 0 && (int64_t)B * n_kv > 32)) counters = 0;
   int32_t* cnt = counters ? (int32_t*)((unsigned char*)workspace + attn_split_records_bytes(B, n_heads, n_kv, max_ctx)) : nullptr;
   if (counters == 2) SL_TRY(sl_attn_decode_split_zero_counters(workspace, B, n_heads, n_kv, max_ctx, st));
   SL_DISPATCH_DTYPE(dtype, T, {

@@ -631,9 +631,9 @@ def test_attn_decode_split_matches_reference(dt, nh, nkv):
 
 @pytest.mark.parametrize("dt", DT)
 def test_attn_decode_split_in_launch_merge_equals_combine_launch(dt, tuning):
-    """SL_ATTN_SPLIT_MERGE=1 (off by default: measured slower, llama_ops.hip): the last block of a (sequence, kv head) to arrive merges
-    the partial records inside the split launch — sc1 hand-off, arrival counter left at zero — bit for bit what the combine launch
-    writes, call after call on the same workspace."""
+    """The last block of a (sequence, kv head) to arrive merges the partial records inside the split launch (default for small batches;
+    SL_ATTN_SPLIT_MERGE=0 / 1 forces the combine launch / the merge) — sc1 hand-off, arrival counter left at zero — bit for bit what the
+    combine launch writes, call after call on the same workspace."""
     D, max_ctx, B, nh, nkv = 128, 448, 3, 6, 2
     lens = [1, 65, 393]
     kc = rnd(B, nkv, max_ctx, D, seed=40).to(dev(), dt)
@@ -643,6 +643,7 @@ def test_attn_decode_split_in_launch_merge_equals_combine_launch(dt, tuning):
     if dt == torch.bfloat16:
         tuning("SL_ATTN_FORCE_SPLIT", "1")
     ws = torch.empty(int(L.lib().sl_attn_decode_workspace_bytes(B, nh, nkv, max_ctx)), dtype=torch.uint8, device=dev())
+    tuning("SL_ATTN_SPLIT_MERGE", "0")
     ref = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5, ws=ws).cpu()
     tuning("SL_ATTN_SPLIT_MERGE", "1")
     for _ in range(3):
