@@ -24,9 +24,8 @@ static int stream_min_m() { return sl_env().stream_min_m; }
 // whose first row / column in the output are row_base / col_base (lane (r, q) holds rows 4q..4q+3 of column r of each).
 // Fused row-wise top-1 in place of the store (greedy decode: lm_head + argmax, hf:generation/utils.py:2911-2925 `torch.argmax(
 // next_token_scores)` over ref:model/audio_llama.py:67's logits).  The wave holds MT*16 rows x 64 columns; lane (r, q) has rows
-// 4q..4q+3 of column r of each 16-column fragment.  Per row: the best of the lane's four fragments (ascending columns, strict
-// '>' so the lowest column wins a tie), then across the 16 lanes of the row group with (value, column) compared the way
-// greedy_select_kernel does — the first maximum wins, NaN never wins.  One (value, column) pair per row and 64-column group
+// 4q..4q+3 of column r of each 16-column fragment.  Per row: the best of the lane's four fragments, then across the 16 lanes of
+// the row group, always with (value, column) compared the way greedy_select_kernel does — the first maximum wins, NaN never wins.  One (value, column) pair per row and 64-column group
 // goes out at [group][row]: 64 contiguous bytes per 16 rows, 1/64 of the logits the select pass would otherwise re-read.
 template <typename T, int MT, int NT>
 __device__ __forceinline__ void tile_argmax(const GemmP& p, f32x4 (&acc)[MT][NT], int row_base, int col_base, int q, int r, int wz) {
@@ -48,7 +47,7 @@ __device__ __forceinline__ void tile_argmax(const GemmP& p, f32x4 (&acc)[MT][NT]
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float v = acc[m][n][i] + b;
-        if (v > bv[i]) { bv[i] = v; bi[i] = col; }
+        if (v > bv[i] || (v == bv[i] && col < bi[i])) { bv[i] = v; bi[i] = col; }   // greedy_select_kernel's rule, -inf columns included
       }
     }
 #pragma unroll
