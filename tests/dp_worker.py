@@ -55,7 +55,9 @@ def main():
                                           fd_loss_connector_layers=[0, 1, 3]),
                                log=dict(checkpoint_dir=os.path.join(workdir, f"ckpt_w{world}"), log_dir=os.path.join(workdir, f"logs_w{world}"),
                                         log_interval=4, validation_interval=100000, num_generate_samples=1)))
-    enc, _ = make_encoder(TINY_HUBERT, TINY_LLAMA.hidden_size, 51, torch.float32)
+    # DP_PERTURB=1: every rank but 0 starts from OTHER encoder weights — Trainer must bring all ranks to rank 0's before the first step
+    enc_seed = 51 + (rank if os.environ.get("DP_PERTURB") == "1" else 0)
+    enc, _ = make_encoder(TINY_HUBERT, TINY_LLAMA.hidden_size, enc_seed, torch.float32)
     llm, _ = make_llama(TINY_LLAMA, 52, torch.float32)
     tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: t(g["prefix_ids"]), utils.LLAMA_PROMPT_SUFFIX: t(g["suffix_ids"])})
     args = SimpleNamespace(run_name="dp", checkpoint_path=None, gpu_idx=0, no_regularizers=True)
@@ -65,6 +67,8 @@ def main():
         tr.kd.reducer = dist_mod.BucketedAllReduce(tr.kd.enc_tape.arena, single_rank=True)
     if tr.kd.reducer is not None:
         tr.kd.reducer.min_bytes = 64 << 10          # several buckets even at the tiny model's 1.3 MB of gradients
+    master0 = {k: v.cpu().clone() for k, v in tr.kd.master.items()}
+    dev_w0 = [w.cpu().clone() for w in tr.audio_encoder.weights._keep]
     tr.kd.keep_last_grads = True
     steps, buckets = [], []
     inner = tr.kd.optimizer_step
@@ -86,7 +90,7 @@ def main():
     tr.validate = recording_validate
     tr.train()
     torch.save({"rank": rank, "world": world, "grads": steps, "buckets": buckets,
-                "master": {k: v.cpu() for k, v in tr.kd.master.items()}, "val": val, "indices": tr._epoch_indices(0),
+                "master": {k: v.cpu() for k, v in tr.kd.master.items()}, "master0": master0, "dev_w0": dev_w0, "val": val, "indices": tr._epoch_indices(0),
                 "windows": tr._epoch_windows(0), "step": tr.step, "optimizer_steps": tr.kd.optimizer_steps,
                 "lr": tr.lr_scheduler.get_last_lr()[0]}, out_path)
     if world > 1 or backend == "nccl":
