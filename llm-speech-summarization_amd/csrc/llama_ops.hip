@@ -1085,7 +1085,13 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
                                     int32_t* cnt) {
   if constexpr (sizeof(T) == 2) {
     const int64_t full_min = sl_env().attn_full_min;   // tuning switch: (sequence, kv head) pairs from which the single-pass form runs; measured faster than split + merge from B = 4 up (9.1 vs 11.4 us), 97 vs 127 us at B = 512
-    if ((int64_t)B * nkv >= full_min && !sl_env().attn_force_split) {
+    // ... except long caches at batches that leave the chip under-filled: a block of the single-pass form walks its whole context in
+    // 128-key chunks one after the other (16 sequences x 8 kv heads = 128 blocks, up to 14 chunks each at 1 800 keys), the split
+    // form spreads the same keys over (sequence, kv head, 64 keys) blocks: long-form leg of bench.py (16 utterances of 30-120 s,
+    // contexts up to 1 782) decode 680 -> 627 ms; at contexts of a few hundred keys the single pass stays ahead (1.88 vs 1.94 ms
+    // per step at 16 sequences, 709 vs 743 ms for the Whisper leg's 32 sequences)
+    const bool long_thin = max_ctx >= 1024 && (int64_t)B * nkv < 768;
+    if ((int64_t)B * nkv >= full_min && !long_thin && !sl_env().attn_force_split) {
       hipLaunchKernelGGL((attn_decode_full_kernel<REP, false>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
                          (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale);
       SL_CHECK_LAUNCH("attn_decode_full");
