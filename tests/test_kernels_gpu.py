@@ -652,6 +652,25 @@ def test_attn_decode_split_in_launch_merge_equals_combine_launch(dt, tuning):
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_attn_decode_long_cache_mid_batch(dt):
+    """16 sequences against a 2 048-position cache (the long-form leg of bench.py): the dispatcher leaves the single-pass kernel for the
+    split form (B x kv heads < 768, cache >= 1 024 positions); contexts from 1 to 1 900 keys against the reference and the per-sequence kernel."""
+    D, max_ctx, B, nh, nkv = 128, 2048, 16, 24, 8
+    lens = [1, 63, 64, 65, 500, 1023, 1024, 1025, 1500, 1900, 137, 393, 777, 1234, 1782, 2000]
+    kc = rnd(B, nkv, max_ctx, D, seed=46).to(dev(), dt)
+    vc = rnd(B, nkv, max_ctx, D, seed=47).to(dev(), dt)
+    qd = rnd(B, nh * D, seed=48).to(dev(), dt)
+    ctx = torch.tensor(lens, dtype=torch.int32, device=dev())
+    out = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    out1 = ops.attn_decode(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    assert rel_err(out, out1) < TOL[dt]
+    for s in (0, 3, 7, 9, 14, 15):
+        n = lens[s]
+        ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
+        assert rel_err(out[s], ref[0]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("nh,nkv", [(6, 2), (2, 2)])
 def test_attn_decode_split_large_batch(dt, nh, nkv):
     """Decode batches in the hundreds: split + merge against the per-sequence single-pass kernel and the reference."""
