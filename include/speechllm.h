@@ -149,8 +149,26 @@ typedef struct {
    * Plain epilogue only (act NONE, no residual), one un-grouped row-major product, M > 64.  sl_greedy_select_partial finishes
    * the argmax over the groups: together they give bit for bit the token sl_gemm(out_f32) + sl_greedy_select give. */
   float* amax_val; int32_t* amax_idx;
+  /* LayerNorm folded into the Linears around it (hf:models/hubert/modeling_hubert.py:515-517,612 stable-LN layer: x -> LN -> Linear;
+   * bf16, plain row-major un-grouped products with M > 64, N % 64 == 0 — sl_gemm_ln_fold_ok()):
+   *   producer side, stats_out: besides storing C, write for every row m and 64-column segment s the pair {sum, sum of squares} of
+   *     the values AS STORED (after bias / act / residual, rounded to the output type) at stats_out[(m * (N / 64) + s) * 2];
+   *     sl_layernorm_stats_finalize turns the N / 64 pairs of a row into {mean, rstd};
+   *   consumer side, ln_mr / ln_u / ln_c: A holds the un-normalised rows x; W is the Linear's weight with the LayerNorm gain
+   *     multiplied into its columns, ln_u[n] = sum_k W[n][k] (of the stored, rounded W), ln_c[n] = sum_k W0[n][k] beta[k] + bias[n];
+   *     with {mean, rstd} = ln_mr[2 m], ln_mr[2 m + 1]:  out[m][n] = rstd * ((x W^T)[m][n] - mean * ln_u[n]) + ln_c[n], then act /
+   *     residual as usual (bias must be NULL: it is inside ln_c).  Equals Linear(LayerNorm(x)) without the LayerNorm pass over x. */
+  const float* ln_mr; const float* ln_u; const float* ln_c; float* stats_out;
 } sl_gemm_ex_args;
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);
+/* 1 when sl_gemm_ex takes ln_* / stats_out for a plain (M, N, K) product of this dtype, else 0 */
+int32_t sl_gemm_ln_fold_ok(int32_t M, int32_t N, int32_t K, int32_t dtype);
+/* {mean, rstd} per row from the per-segment {sum, sum of squares} a stats_out GEMM left ([rows][segs][2] floats, cols = 64 * segs
+ * elements per row): mr[2 m] = mean, mr[2 m + 1] = rsqrt(max(E[x^2] - mean^2, 0) + eps); segments summed in order. */
+int sl_layernorm_stats_finalize(const float* stats, int32_t segs, int64_t rows, int32_t cols, float eps, float* mr, sl_stream stream);
+/* The same pair straight from the rows of x (rows, cols) — two-pass mean / variance, one wave per row — for a row set no GEMM
+ * has just produced (the first layer's input). */
+int sl_layernorm_stats(const void* x, int64_t rows, int32_t cols, float eps, float* mr, int32_t dtype, sl_stream stream);
 
 /* LayerNorm over the last dim, optional fused GELU (conv layers: hf:...hubert.py:144-150;
  * encoder LNs hf:...hubert.py:515,517,612; feature projection :226).  In-place allowed. */
@@ -434,6 +452,15 @@ typedef struct {
   const void *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
 } sl_hubert_layer;
 
+/* Optional per-layer copies for the inference path's LayerNorm fold (bf16; sl_gemm_ex_args.ln_*): the two LayerNorms of a stable-LN
+ * layer (hf:models/hubert/modeling_hubert.py:515-517) disappear into the q|k|v and FFN1 Linears —
+ *   wqkv_f = wqkv with ln1's gain multiplied into its columns, uqkv[n] = sum_k wqkv_f[n][k], cqkv[n] = (wqkv . ln1_b)[n] + bqkv[n];
+ *   w1_f / u1 / c1 likewise from ln2, w1, b1.  The row statistics come out of the out_proj / FFN2 epilogues (stats_out). */
+typedef struct {
+  const void* wqkv_f; const float* uqkv; const float* cqkv;
+  const void* w1_f; const float* u1; const float* c1;
+} sl_hubert_fold;
+
 typedef struct {
   int32_t dtype, n_conv, hidden, n_layers, n_heads, ffn, pos_k, pos_groups;
   int32_t conv_dim[8], conv_kernel[8], conv_stride[8];
@@ -446,6 +473,7 @@ typedef struct {
   const sl_hubert_layer* layers;      /* host array, n_layers entries */
   const void *final_ln_g, *final_ln_b;
   const void *proj_w, *proj_b;        /* embed_projection (llm_dim, hidden) */
+  const sl_hubert_fold* fold;         /* NULL, or host array of n_layers entries: LayerNorms folded into the Linears (bf16 inference) */
 } sl_hubert_model;
 
 /* AudioEncoder.forward with the `pool` downsample for a batch of utterances

@@ -44,7 +44,8 @@ class GemmFused(C.Structure):
 
 class GemmEx(C.Structure):
     _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("w_mod", c_i32), ("aux_out", c_vp), ("groups", c_vp),
-                ("groups_ext", c_i32), ("reserved", c_i32), ("amax_val", c_vp), ("amax_idx", c_vp)]
+                ("groups_ext", c_i32), ("reserved", c_i32), ("amax_val", c_vp), ("amax_idx", c_vp),
+                ("ln_mr", c_vp), ("ln_u", c_vp), ("ln_c", c_vp), ("stats_out", c_vp)]
 
 
 class AttnArgs(C.Structure):
@@ -78,6 +79,10 @@ class HubertLayer(C.Structure):
                                     "w1", "b1", "w2", "b2")]
 
 
+class HubertFold(C.Structure):
+    _fields_ = [(n, c_vp) for n in ("wqkv_f", "uqkv", "cqkv", "w1_f", "u1", "c1")]
+
+
 class HubertModel(C.Structure):
     _fields_ = [("dtype", c_i32), ("n_conv", c_i32), ("hidden", c_i32), ("n_layers", c_i32),
                 ("n_heads", c_i32), ("ffn", c_i32), ("pos_k", c_i32), ("pos_groups", c_i32),
@@ -90,7 +95,8 @@ class HubertModel(C.Structure):
                 ("pos_w", c_vp), ("pos_b", c_vp),
                 ("layers", C.POINTER(HubertLayer)),
                 ("final_ln_g", c_vp), ("final_ln_b", c_vp),
-                ("proj_w", c_vp), ("proj_b", c_vp)]
+                ("proj_w", c_vp), ("proj_b", c_vp),
+                ("fold", C.POINTER(HubertFold))]
 
 
 class LlamaLayer(C.Structure):
@@ -157,6 +163,9 @@ _PROTOS = {
     "sl_attn_decode_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "sl_attn_decode_split": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "sl_gemm_ex": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmEx), c_vp]),
+    "sl_gemm_ln_fold_ok": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    "sl_layernorm_stats_finalize": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp]),
+    "sl_layernorm_stats": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_vp, c_i32, c_vp]),
     "sl_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "sl_axpby": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_i64, c_i32, c_vp]),
     "sl_adamw_blocks": (C.c_size_t, [c_i64]),

@@ -198,6 +198,9 @@ class AudioEncoder:
         if self.weights is None:
             raise L.SpeechLLMError("AudioEncoder weights are not on the GPU: call load_state_dict(...).to('cuda')")
         lib = L.lib()
+        if getattr(self.weights, "fold_stale", False):       # a fused optimizer step moved the layer weights since the folded copies were made
+            from .weights import build_layernorm_fold
+            build_layernorm_fold(self.weights)
         m = self.weights.struct
         lens = [int(w.numel()) for w in waves]
         offs = [0]
@@ -303,6 +306,9 @@ class AudioEncoder:
             raise ValueError(f"Whisper expects the mel input features to be of length {a.n_frames}, but found {tuple(input_features.shape)}. "
                              f"Make sure to pad the input mel features to {a.n_frames}.")
         B = input_features.shape[0]
+        if getattr(self.weights, "fold_stale", False):
+            from .weights import build_layernorm_fold
+            build_layernorm_fold(self.weights)
         mel = input_features.to(self.device).transpose(1, 2).to(self.dtype).contiguous()       # channel-last rows for the implicit-GEMM convs
         m = self.weights.struct
         ws = self._workspace(lib.sl_whisper_workspace_bytes(C.byref(m), B))

@@ -216,6 +216,8 @@ struct SlEnv {
   int attn_generic;        // SL_ATTN_GENERIC
   int attn_qt;             // SL_ATTN_QT
   int norm_single_row;     // SL_NORM_SINGLE_ROW
+  int no_ln_fold;          // SL_NO_LN_FOLD        1 = the encoder runs its LayerNorm kernels even when folded weights are supplied (A/B)
+  int no_swap_epilogue;    // SL_NO_SWAP_EPILOGUE  1 = the 256-tile GEMM keeps the LDS-turned rows epilogue where the swapped-operand form applies (A/B)
   int stream_splits, stream_nwv, stream_mt;   // SL_STREAM_CFG "splits,nwv[,mt]" (0 = not set)
   int stream_wide;         // SL_STREAM_WIDE       0 = never use the 256 x 128 streaming block, 1 = default rule, 2 = whenever it applies
   int stream_wsplits;      // SL_STREAM_WSPLITS    K splits of the 256 x 128 form when its blocks do not cover the CUs (0 = rule)

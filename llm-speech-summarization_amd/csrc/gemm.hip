@@ -155,6 +155,16 @@ __device__ __forceinline__ void unpack4(const uint2& u, float (&f)[4]) {
 __device__ __forceinline__ void st4(float* ptr, const float (&f)[4]) { *(f32x4*)ptr = f32x4{f[0], f[1], f[2], f[3]}; }
 __device__ __forceinline__ void st4(bf16_t* ptr, const float (&f)[4]) { *(uint2*)ptr = make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])); }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), left in every lane: four rotate-and-add steps on the VALU's DPP path
+// (row_ror 8, 4, 2, 1), no LDS crossbar traffic — the order of the additions is fixed, so the result is reproducible.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
 // Row-contiguous epilogue: the MFMA accumulator layout gives a lane ONE column of four rows, so the direct epilogue
 // above moves 2-byte elements (a wave-level access = 4 rows x 32 B; the residual read alone doubled the time of the
 // K = 1024 encoder products).  Here each wave turns its 64 x 64 sub-tile through its own 16 KiB of the (now idle)
@@ -162,15 +172,19 @@ __device__ __forceinline__ void st4(bf16_t* ptr, const float (&f)[4]) { *(uint2*
 // different banks, read back as rows — and 16 lanes then cover 128 contiguous bytes of one output row: bias, residual,
 // pre-activation copy and result all move as 8/16-byte vectors.  Returns false (nothing done) when the operands do
 // not allow 4-element vectors; the caller falls back to the direct epilogue.
-template <typename T, int ACT, int MT>
-__device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int z, int wz, float* wsm) {
-  static_assert(MT % 4 == 0 && ACT != SL_ACT_SILU_MUL, "64-row passes; the gate/up pairing keeps the direct epilogue");
-  if (p.amax_val) return false;     // fused top-1: nothing is stored, the accumulator layout is what the reduction wants
-  const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
-  const uintptr_t ca = p.out_f32 ? 15 : (4 * sizeof(T) - 1), ra = p.res_f32 ? 15 : (4 * sizeof(T) - 1);
-  if ((p.N & 3) || (p.ldc & 3) || (co & 3) || ((uintptr_t)p.C & ca) || (p.aux && ((uintptr_t)p.aux & (4 * sizeof(T) - 1))) ||
-      (p.res && ((p.ldr & 3) || (ro & 3) || ((uintptr_t)p.res & ra))))
-    return false;
+// The features of a launch are uniform, but tested per row pass they leave ~10 scalar branches in each pass and the compiler
+// cannot move the LDS read of pass t+1 over them (one block per CU: the epilogue is an exposed tail of every tile).  F fixes
+// them at compile time for the forms the encoder / prefill / KD launches use; EPI_GENERIC keeps every test at run time.
+enum : int { EPI_GENERIC = 1, EPI_RES = 2, EPI_LN = 4, EPI_STATS = 8 };
+
+template <typename T, int ACT, int MT, int F>
+__device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int wz, float* wsm,
+                                                        const float2* mr_lds, int64_t co, int64_t ro) {
+  constexpr bool G = (F & EPI_GENERIC) != 0, BF = sizeof(T) == 2;      // the LayerNorm fold is a bf16 form (sl_gemm_impl checks)
+  const bool f_aux = G && p.aux != nullptr, f_out32 = G && p.out_f32, f_res32 = G && p.res && p.res_f32;
+  const bool f_rest = G ? (p.res && !p.res_f32) : (F & EPI_RES) != 0;
+  const bool f_ln = BF && (G ? p.ln_mr != nullptr : (F & EPI_LN) != 0);
+  const bool f_stats = BF && (G ? p.stats_out != nullptr : (F & EPI_STATS) != 0);
   const int q = lane >> 4, r = lane & 15;
   const int c4 = r * 4;                       // read phase: lane = (row within a 4-row pass, 4-column group)
   const int col = col_base + c4;
@@ -182,20 +196,39 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
     for (int j = 0; j < 4; ++j) b4[j] = to_f32(bias[j]);
   }
+  // LayerNorm fold, consumer side: the four columns' ln_u / ln_c stay in registers, {mean, rstd} come per row pass
+  float u4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (f_ln && col_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u4[j] = p.ln_u[col + j]; b4[j] = p.ln_c[col + j]; }
+  }
+  const int segs = (p.N + 63) >> 6, seg = col_base >> 6;
   using RawT = typename std::conditional<sizeof(T) == 2, uint2, f32x4>::type;   // four residual elements of type T as loaded
-  const bool res_t = p.res && !p.res_f32;
 #pragma unroll
   for (int mg = 0; mg < MT; mg += 4) {
     // residual in the output's type (the encoder / prefill form): all 16 row passes of this 64-row group are requested
     // before the tile is turned through LDS, on clamped addresses, so one memory latency is exposed per group (issued
     // pass by pass under the bounds test they cost ~45 % on the K = 1024 products)
     RawT raw[16];
-    if (res_t) {
+    if (f_rest) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         int64_t row = row_base + mg * 16 + t * 4 + q;
         row = row < p.M ? row : p.M - 1;
         raw[t] = *(const RawT*)((const T*)p.res + ro + row * p.ldr + colc);
+      }
+    }
+    // LayerNorm fold, consumer side: {mean, rstd} of the group's 16 row passes, requested up front for the same reason (a load
+    // issued between the stores of two passes waits for those stores: vmcnt retires in order) — unless the 256-row tile kernel
+    // staged its rows' pairs in LDS under the main loop (mr_lds, indexed by the row within the wave's tile)
+    float2 keep = make_float2(0.f, 0.f);
+    float2 mr[16];
+    if (f_ln && !mr_lds) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        int64_t row = row_base + mg * 16 + t * 4 + q;
+        row = row < p.M ? row : p.M - 1;
+        mr[t] = ((const float2*)p.ln_mr)[row];
       }
     }
 #pragma unroll
@@ -208,7 +241,7 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
     for (int t0 = 0; t0 < 16; t0 += 4) {
       float rv[4][4];
-      if (p.res_f32 && p.res) {   // fp32 accumulation targets (weight gradients): four passes at a time
+      if (f_res32) {   // fp32 accumulation targets (weight gradients): four passes at a time
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           int64_t row = row_base + mg * 16 + (t0 + u) * 4 + q;
@@ -221,30 +254,214 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
         const int t = t0 + u, lr = t * 4 + q;
         const int64_t row = row_base + mg * 16 + lr;
         const f32x4 a = *(const f32x4*)&wsm[lr * 64 + (c4 ^ ((t & 3) << 4))];
-        float v[4] = {a[0] + b4[0], a[1] + b4[1], a[2] + b4[2], a[3] + b4[3]};
+        float v[4];
+        if (f_ln) {   // rstd a + (c - rstd mean u): two packed fp32 FMAs per pair of columns
+          const float2 mrt = mr_lds ? mr_lds[mg * 16 + lr] : mr[t];
+          const float nk = -mrt.y * mrt.x;
+          const f32x2_t k2 = {nk, nk}, r2 = {mrt.y, mrt.y};
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            const f32x2_t t2 = __builtin_elementwise_fma(k2, f32x2_t{u4[j], u4[j + 1]}, f32x2_t{b4[j], b4[j + 1]});
+            const f32x2_t v2 = __builtin_elementwise_fma(r2, f32x2_t{a[j], a[j + 1]}, t2);
+            v[j] = v2[0]; v[j + 1] = v2[1];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = a[j] + b4[j];
+        }
+        float s1 = 0.f, s2 = 0.f;   // LayerNorm fold, producer side: statistics of the values as stored
         if (row < p.M && col_ok) {
-          if (p.aux) st4((T*)p.aux + co + row * p.ldc + col, v);
+          if (f_aux) st4((T*)p.aux + co + row * p.ldc + col, v);
           if constexpr (ACT == SL_ACT_GELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = gelu_act<T>(v[j]);
           }
-          if (res_t) {
+          if (f_rest) {
             float rr[4];
             unpack4(raw[t], rr);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += rr[j];
-          } else if (p.res) {
+          } else if (f_res32) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += rv[u][j];
           }
-          if (p.out_f32) st4((float*)p.C + co + row * p.ldc + col, v);
+          if (f_out32) st4((float*)p.C + co + row * p.ldc + col, v);
           else st4((T*)p.C + co + row * p.ldc + col, v);
+          if (f_stats) {
+            f32x2_t f01 = {v[0], v[1]}, f23 = {v[2], v[3]};
+            if (!f_out32) {               // the values as stored: the same v_cvt_pk_bf16_f32 st4 issued, its halves shifted back up
+              const uint32_t lo = pack2_bf16(v[0], v[1]), hi = pack2_bf16(v[2], v[3]);
+              f01 = f32x2_t{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u)};
+              f23 = f32x2_t{__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+            }
+            const f32x2_t a2 = f01 + f23, q2 = __builtin_elementwise_fma(f23, f23, f01 * f01);
+            s1 = a2[0] + a2[1];
+            s2 = q2[0] + q2[1];
+          }
+        }
+        if (f_stats) {             // the 16 lanes of a row pass cover the wave's 64 columns: fixed-order sum
+          s1 = row16_sum(s1); s2 = row16_sum(s2);
+          if (r == t) keep = make_float2(s1, s2);     // every lane of the row has the sums; lane r holds on to pass r's
         }
       }
     }
+    if (f_stats) {                   // one store per 64-row group: lane (q, r) has row 4 r + q of it
+      const int64_t row = row_base + mg * 16 + r * 4 + q;
+      if (row < p.M && col_base < p.N) ((float2*)p.stats_out)[row * segs + seg] = keep;
+    }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <typename T, int ACT, int MT>
+__device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int z, int wz, float* wsm,
+                                                   const float2* mr_lds = nullptr) {
+  static_assert(MT % 4 == 0 && ACT != SL_ACT_SILU_MUL, "64-row passes; the gate/up pairing keeps the direct epilogue");
+  if (p.amax_val) return false;     // fused top-1: nothing is stored, the accumulator layout is what the reduction wants
+  const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
+  const uintptr_t ca = p.out_f32 ? 15 : (4 * sizeof(T) - 1), ra = p.res_f32 ? 15 : (4 * sizeof(T) - 1);
+  if ((p.N & 3) || (p.ldc & 3) || (co & 3) || ((uintptr_t)p.C & ca) || (p.aux && ((uintptr_t)p.aux & (4 * sizeof(T) - 1))) ||
+      (p.res && ((p.ldr & 3) || (ro & 3) || ((uintptr_t)p.res & ra))))
+    return false;
+  if constexpr (sizeof(T) == 2) {
+    if (!p.aux && !p.out_f32 && !(p.res && p.res_f32)) {
+      const bool res = p.res != nullptr, ln = p.ln_mr != nullptr, st = p.stats_out != nullptr;
+      if (!ln && !st) {
+        if (res) tile_epilogue_rows_impl<T, ACT, MT, EPI_RES>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro);
+        else tile_epilogue_rows_impl<T, ACT, MT, 0>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro);
+        return true;
+      }
+      if (ln && !res && !st) { tile_epilogue_rows_impl<T, ACT, MT, EPI_LN>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro); return true; }
+      if (st && res && !ln) { tile_epilogue_rows_impl<T, ACT, MT, EPI_RES | EPI_STATS>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro); return true; }
+    }
+  }
+  tile_epilogue_rows_impl<T, ACT, MT, EPI_GENERIC>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro);
   return true;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Register epilogue of the swapped-operand 256-tile kernel (bf16).  With the MFMA operands exchanged (D = W_frag . A_frag^T)
+// a lane holds four consecutive COLUMNS of one output row; the kernel reads W fragment n of lane r from tile row
+// 32 (n >> 1) + 8 (r >> 2) + 4 (n & 1) + (r & 3), which makes lane (q, r)'s sixteen values of row m*16 + r the columns
+// [8q, 8q + 8) and [32 + 8q, 32 + 8q + 8) of the wave's 64: two 16-byte stores per row, the four q's of a row filling 64
+// contiguous bytes per instruction.  Nothing is turned through LDS (the LDS turn was ~30 % of the rows epilogue: 64 ds_write_b32 +
+// 16 ds_read_b128 per 64-row group and wave, with the read latency in every pass's dependency chain), bias / LayerNorm-fold
+// vectors stay in registers per column, the residual arrives as 16-byte loads, four rows requested at a time.
+// The launch code guarantees: N, ldc, ldr, the batch strides multiples of 8, 16-byte aligned C / residual, no aux / fp32 forms.
+// ----------------------------------------------------------------------------------------------
+template <int ACT, int F>
+__device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8][4], int row_base, int col_base, int lane, int z, int wz, const float2* mr_lds) {
+  using T = bf16_t;
+  constexpr bool RES = (F & EPI_RES) != 0, LN = (F & EPI_LN) != 0, ST = (F & EPI_STATS) != 0;
+  const int64_t co = (int64_t)z * p.sC, ro = (int64_t)z * p.sR;
+  const int q = lane >> 4, r = lane & 15;
+  int colh[2];
+  bool okh[2];
+  float bc[2][8], uu[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    colh[h] = col_base + 32 * h + 8 * q;
+    okh[h] = colh[h] < p.N;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bc[h][j] = 0.f; uu[h][j] = 0.f; }
+    if (!okh[h]) { colh[h] = 0; continue; }
+    if constexpr (LN) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { uu[h][j] = p.ln_u[colh[h] + j]; bc[h][j] = p.ln_c[colh[h] + j]; }
+    } else if (p.bias) {
+      const T* bias = (const T*)p.bias + (int64_t)wz * p.sBias + colh[h];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bc[h][j] = to_f32(bias[j]);
+    }
+  }
+  float s1[8][2], s2[8][2];
+#pragma unroll
+  for (int mb = 0; mb < 8; mb += 4) {
+    uint4 raw[4][2];
+    if constexpr (RES) {
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        int64_t row = row_base + (mb + m4) * 16 + r;
+        row = row < p.M ? row : p.M - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) raw[m4][h] = *(const uint4*)((const T*)p.res + ro + row * p.ldr + colh[h]);
+      }
+    }
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+      const int m = mb + m4;
+      const int64_t row = row_base + m * 16 + r;
+      f32x2_t k2 = {0.f, 0.f}, r2 = {0.f, 0.f};
+      if constexpr (LN) {
+        const float2 mrt = mr_lds[m * 16 + r];
+        const float nk = -mrt.y * mrt.x;
+        k2 = f32x2_t{nk, nk}; r2 = f32x2_t{mrt.y, mrt.y};
+      }
+      float la[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, lq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // [h][4-column leaf]: sums, sums of squares
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const f32x2_t a2 = {acc[m][2 * h + (j >> 2)][j & 3], acc[m][2 * h + (j >> 2)][(j & 3) + 1]};
+          f32x2_t v2;
+          if constexpr (LN) v2 = __builtin_elementwise_fma(r2, a2, __builtin_elementwise_fma(k2, f32x2_t{uu[h][j], uu[h][j + 1]}, f32x2_t{bc[h][j], bc[h][j + 1]}));
+          else v2 = a2 + f32x2_t{bc[h][j], bc[h][j + 1]};
+          v[j] = v2[0]; v[j + 1] = v2[1];
+        }
+        if constexpr (ACT == SL_ACT_GELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_act<T>(v[j]);
+        }
+        if constexpr (RES) {
+          float rr[8];
+          Vec16<T>::unpack(raw[m4][h], rr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        }
+        const uint4 pk = Vec16<T>::pack(v);
+        if (row < p.M && okh[h]) {
+          *(uint4*)((T*)p.C + co + row * p.ldc + colh[h]) = pk;
+          if constexpr (ST) {             // statistics of the values as stored (the packed halves shifted back up), per 4-column leaf
+            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};   // exactly as the rows epilogue forms them: the tree below is its tree
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const f32x2_t f01 = {__builtin_bit_cast(float, w[2 * g] << 16), __builtin_bit_cast(float, w[2 * g] & 0xffff0000u)};
+              const f32x2_t f23 = {__builtin_bit_cast(float, w[2 * g + 1] << 16), __builtin_bit_cast(float, w[2 * g + 1] & 0xffff0000u)};
+              const f32x2_t a2 = f01 + f23, q2 = __builtin_elementwise_fma(f23, f23, f01 * f01);
+              la[h][g] = a2[0] + a2[1];
+              lq[h][g] = q2[0] + q2[1];
+            }
+          }
+        }
+      }
+      if constexpr (ST) {   // leaves 2q, 2q + 1 (h = 0) and 2q + 8, 2q + 9 (h = 1) of the row's 16: the first level of the 16-lane tree is in-lane
+        s1[m][0] = la[0][0] + la[1][0]; s1[m][1] = la[0][1] + la[1][1];
+        s2[m][0] = lq[0][0] + lq[1][0]; s2[m][1] = lq[0][1] + lq[1][1];
+      }
+    }
+  }
+  if constexpr (ST) {
+    // The rows epilogue sums a row's sixteen 4-column leaves l_0..l_15 as S_i = l_i + l_(i+8), E_i = S_i + S_(i+4), T_i = E_i + E_(i+2),
+    // T_0 + T_1 (row16_sum); a batch and its single utterances may take different tile kernels and must get the same bits, so this
+    // is that tree: lane q holds S_2q and S_2q+1, partners are q ^ 2 (lane ^ 32) and then q ^ 1 (lane ^ 16).  Lane (q, r) stores
+    // the rows of m = q and m = q + 4 (two store instructions for the wave's 128 rows).
+    const int segs = (p.N + 63) >> 6, seg = col_base >> 6;
+    float2 k0 = make_float2(0.f, 0.f), k1 = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float a0 = s1[m][0], a1 = s1[m][1], b0 = s2[m][0], b1 = s2[m][1];
+      a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
+      a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
+      const float a = a0 + a1, b = b0 + b1;
+      if ((m & 3) == q) { if (m < 4) k0 = make_float2(a, b); else k1 = make_float2(a, b); }
+    }
+    if (col_base < p.N) {
+      const int64_t row0 = row_base + q * 16 + r, row1 = row0 + 64;
+      if (row0 < p.M) ((float2*)p.stats_out)[row0 * segs + seg] = k0;
+      if (row1 < p.M) ((float2*)p.stats_out)[row1 * segs + seg] = k1;
+    }
+  }
 }
 
 template <typename T, int ACT>
@@ -580,11 +797,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 // ----------------------------------------------------------------------------------------------
 constexpr int XBM = 256, XBN = 256;
 
-template <typename T, int ACT>
+template <typename T, int ACT, bool SW = false>
 __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
+  static_assert(!SW || (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL), "the swapped-operand form is the bf16 store epilogue");
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int BK = TROWB / (int)sizeof(T);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][XBM * TROWB];   // [buf][A|W], 32 KiB each
+  __shared__ float2 mr_s[XBM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
@@ -619,10 +838,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 512 * i, row = c >> 3, ch = (c & 7) ^ (row & 7);
+    // SW: the W fragments are read at rows 8 (r >> 2) + (r & 3) + {0, 4, 32, 36}; the image is swizzled by those rows' (r & 3) and
+    // bit 0 of (r >> 2), which keeps each 16-lane group of a ds_read_b128 on 16 different 16-byte slots of the 256-byte bank row
+    const int chw = SW ? (c & 7) ^ ((row & 3) | (((row >> 3) & 1) << 2)) : ch;
     int ar = bm * XBM + row; ar = ar < p.M ? ar : p.M - 1;
     int wr = bn * XBN + row; wr = wr < p.N ? wr : p.N - 1;
     ga[i] = A + (int64_t)ar * p.lda + ch * VEC;
-    gw[i] = W + (int64_t)wr * p.ldw + ch * VEC;
+    gw[i] = W + (int64_t)wr * p.ldw + chw * VEC;
   }
   const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;  // this wave's 1 KiB piece inside an 8 KiB group
 
@@ -643,40 +865,66 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
   };
 
   issue(0, 0);
+  if (sizeof(T) == 2 && p.ln_mr && tid < XBM) {   // LayerNorm fold: this tile's {mean, rstd} pairs wait in LDS for the epilogue
+    int row = bm * XBM + tid;
+    row = row < p.M ? row : p.M - 1;
+    mr_s[tid] = ((const float2*)p.ln_mr)[row];
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
     const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(&smem[buf][0][0]);
-    const uint32_t ra = sb + (uint32_t)((wm * 128 + r) * TROWB), rb = sb + (uint32_t)(XBM * TROWB + (wn * 64 + r) * TROWB);
+    const uint32_t ra = sb + (uint32_t)((wm * 128 + r) * TROWB);
+    const uint32_t rb = sb + (uint32_t)(XBM * TROWB + (wn * 64 + (SW ? 8 * (r >> 2) + (r & 3) : r)) * TROWB);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const uint32_t xs = (uint32_t)(((s * 4 + q) ^ (r & 7)) << 4);
+      const uint32_t xw = SW ? (uint32_t)(((s * 4 + q) ^ ((r & 3) | (((r >> 2) & 1) << 2))) << 4) : xs;
       u32x4_t a[8], b[4];
       SL_LDS_RD(a[0], ra + xs, 0); SL_LDS_RD(a[1], ra + xs, 2048); SL_LDS_RD(a[2], ra + xs, 4096); SL_LDS_RD(a[3], ra + xs, 6144);
-      SL_LDS_RD(b[0], rb + xs, 0); SL_LDS_RD(b[1], rb + xs, 2048); SL_LDS_RD(b[2], rb + xs, 4096); SL_LDS_RD(b[3], rb + xs, 6144);
+      if constexpr (SW) { SL_LDS_RD(b[0], rb + xw, 0); SL_LDS_RD(b[1], rb + xw, 512); SL_LDS_RD(b[2], rb + xw, 4096); SL_LDS_RD(b[3], rb + xw, 4608); }
+      else { SL_LDS_RD(b[0], rb + xw, 0); SL_LDS_RD(b[1], rb + xw, 2048); SL_LDS_RD(b[2], rb + xw, 4096); SL_LDS_RD(b[3], rb + xw, 6144); }
       SL_LDS_RD(a[4], ra + xs, 8192); SL_LDS_RD(a[5], ra + xs, 10240); SL_LDS_RD(a[6], ra + xs, 12288); SL_LDS_RD(a[7], ra + xs, 14336);
       lds_wait8<4>(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], as_uint4(a[m]), as_uint4(b[n]));
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (SW) MMA<T>::step(acc[m][n], as_uint4(b[n]), as_uint4(a[m]));
+          else MMA<T>::step(acc[m][n], as_uint4(a[m]), as_uint4(b[n]));
+        }
       __builtin_amdgcn_sched_barrier(0);
       lds_wait8<0>(a[4], a[5], a[6], a[7], b[0], b[1], b[2], b[3]);
 #pragma unroll
       for (int m = 4; m < 8; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) MMA<T>::step(acc[m][n], as_uint4(a[m]), as_uint4(b[n]));
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (SW) MMA<T>::step(acc[m][n], as_uint4(b[n]), as_uint4(a[m]));
+          else MMA<T>::step(acc[m][n], as_uint4(a[m]), as_uint4(b[n]));
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if constexpr (ACT != SL_ACT_SILU_MUL) {
-    if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)&smem[0][0][0] + wave * 4096)) return;
+  if constexpr (SW) {
+    const int rb0 = bm * XBM + wm * 128, cb0 = bn * XBN + wn * 64;
+    const float2* mrl = mr_s + wm * 128;
+    const bool res = p.res != nullptr, ln = p.ln_mr != nullptr, st = p.stats_out != nullptr;    // launch_tiled admits these four forms only
+    if (ln) tile_epilogue_sw<ACT, EPI_LN>(p, acc, rb0, cb0, lane, z, wz, mrl);
+    else if (st) tile_epilogue_sw<ACT, EPI_RES | EPI_STATS>(p, acc, rb0, cb0, lane, z, wz, mrl);
+    else if (res) tile_epilogue_sw<ACT, EPI_RES>(p, acc, rb0, cb0, lane, z, wz, mrl);
+    else tile_epilogue_sw<ACT, 0>(p, acc, rb0, cb0, lane, z, wz, mrl);
+    return;
+  } else {
+    if constexpr (ACT != SL_ACT_SILU_MUL) {
+      if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)&smem[0][0][0] + wave * 4096,
+                                                        sizeof(T) == 2 && p.ln_mr ? mr_s + wm * 128 : nullptr)) return;
+    }
+    tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, q, r, z, wz);
   }
-  tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, q, r, z, wz);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -925,6 +1173,18 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
     if ((t256 >= min_tiles || by_rounds) && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
+      if constexpr (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL) {
+        // swapped-operand form (register epilogue, 16-byte stores): plain bf16 stores on 8-element aligned rows, one of the forms
+        // {bias}, {bias, residual}, {LayerNorm fold}, {bias, residual, row statistics}
+        const bool al = !(p.N & 7) && !(p.ldc & 7) && !(p.sC & 7) && !((uintptr_t)p.C & 15) &&
+                        (!p.res || (!(p.ldr & 7) && !(p.sR & 7) && !((uintptr_t)p.res & 15)));
+        const bool form = !p.ln_mr ? (!p.stats_out || p.res) : (!p.res && !p.stats_out);
+        if (al && form && !p.grp && !p.aux && !p.out_f32 && !p.res_f32 && !p.amax_val && !p.direct_epi && !sl_env().no_swap_epilogue) {
+          hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT, true>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+          SL_CHECK_LAUNCH("gemm_tiled256 (swapped operands)");
+          return 0;
+        }
+      }
       hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
       SL_CHECK_LAUNCH("gemm_tiled256");
       return 0;
@@ -1019,6 +1279,13 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
   return SL_ERR_ARG;
 }
 
+// true when a plain (M, N, K) product of this dtype is served by one of the LDS-DMA tiled kernels, whose rows epilogue carries the
+// LayerNorm fold (ln_* / stats_out)
+bool sl_gemm_rows_epilogue_ok(int M, int N, int K, int dtype) {
+  if (dtype != SL_BF16 || M <= 64 || (N & 63) || sl_env().disable_glds != 0 || sl_env().direct_epilogue != 0) return false;
+  return K % (TROWB / 2) == 0;
+}
+
 int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st) {
   SL_CHECK_ARG(a != nullptr, "sl_gemm: null args");
   g_disable_glds = sl_env().disable_glds;   // 1: register staging, 2: glds with compiler-visible LDS reads
@@ -1046,7 +1313,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
-  p.amax_val = nullptr; p.amax_idx = nullptr;
+  p.amax_val = nullptr; p.amax_idx = nullptr; p.ln_mr = nullptr; p.ln_u = nullptr; p.ln_c = nullptr; p.stats_out = nullptr;
   const int direct_epi = sl_env().direct_epilogue;
   p.direct_epi = direct_epi;
   const int gm_env = sl_env().gemm_gm;
@@ -1059,6 +1326,16 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     SL_CHECK_ARG(!(p.ta || p.tw || p.aux) || a->act != SL_ACT_SILU_MUL, "sl_gemm_ex: transposed operands / aux_out are not combined with SILU_MUL");
     SL_CHECK_ARG(!p.res_f32 || a->out_f32, "sl_gemm_ex: residual_f32 needs out_f32");
     SL_CHECK_ARG(!(p.ta || p.tw) || a->w_layout == SL_W_ROWMAJOR, "sl_gemm_ex: transposed operands need row-major storage");
+    if (ex->ln_mr || ex->ln_u || ex->ln_c || ex->stats_out) {
+      // both sides of the LayerNorm fold live in the rows epilogue of the LDS-DMA tiled kernels (bf16, 4-column vectors)
+      SL_CHECK_ARG(sl_gemm_rows_epilogue_ok(a->M, a->N, a->K, a->dtype) && a->batch == 1 && !ex->groups && !ex->trans_a && !ex->trans_w && !ex->aux_out &&
+                       a->act != SL_ACT_SILU_MUL && a->w_layout == SL_W_ROWMAJOR && a->ldc % 4 == 0 && ((uintptr_t)a->C & 7) == 0 &&
+                       (!a->residual || (a->ldr % 4 == 0 && ((uintptr_t)a->residual & 7) == 0)),
+                   "sl_gemm_ex: ln_* / stats_out need a plain bf16 row-major product the LDS-DMA tiled kernels take (M=%d N=%d K=%d), 4-element aligned rows", a->M, a->N, a->K);
+      SL_CHECK_ARG((!ex->ln_mr && !ex->ln_u && !ex->ln_c) || (ex->ln_mr && ex->ln_u && ex->ln_c && !a->bias),
+                   "sl_gemm_ex: the LayerNorm fold needs ln_mr, ln_u and ln_c together (the bias is inside ln_c)");
+      p.ln_mr = ex->ln_mr; p.ln_u = ex->ln_u; p.ln_c = ex->ln_c; p.stats_out = ex->stats_out;
+    }
     if (ex->amax_val || ex->amax_idx) {
       SL_CHECK_ARG(ex->amax_val && ex->amax_idx && a->act == SL_ACT_NONE && a->batch == 1 && !ex->groups && !ex->trans_a && !ex->trans_w && !ex->aux_out &&
                        !a->residual && a->M > 64 && a->w_layout == SL_W_ROWMAJOR,
@@ -1100,6 +1377,8 @@ extern "C" size_t sl_gemm_split_workspace_bytes(int32_t M, int32_t N, int32_t K,
   if (M <= stream_min_m() || M <= 0 || N <= 0 || K <= 0) return 0;
   return sl_gemm_stream_ws_bytes(M, N, K, dtype);
 }
+
+extern "C" int32_t sl_gemm_ln_fold_ok(int32_t M, int32_t N, int32_t K, int32_t dtype) { return sl_gemm_rows_epilogue_ok(M, N, K, dtype) ? 1 : 0; }
 
 extern "C" int sl_gemm(const sl_gemm_args* a, sl_stream stream) { return sl_gemm_impl(a, nullptr, nullptr, (hipStream_t)stream); }
 

@@ -20,6 +20,11 @@ struct GemmP {
   int grp_kslab;       // groups_ext == 2: every group's K is a whole number of 128-byte slabs (LDS-DMA kernel allowed)
   int gm;              // 256-tile kernel: tile rows per XCD patch (SL_GEMM_GM, default 8)
   int direct_epi;      // tiled kernels: skip the LDS-staged row epilogue (SL_DIRECT_EPILOGUE=1, for A/B measurements)
+  // LayerNorm folded into the surrounding Linears (sl_gemm_ex_args.ln_* / stats_out; rows epilogue of the LDS-DMA tiled kernels, bf16):
+  const float* ln_mr;  // consumer: per row {mean, rstd} of the LayerNorm in front of this Linear; W carries the gain, ln_u[n] = sum_k W[n][k],
+  const float* ln_u;   //           ln_c[n] = (W0 . beta)[n] + bias[n]:  out = rstd * (A . W^T - mean * ln_u) + ln_c
+  const float* ln_c;
+  float* stats_out;    // producer: per row and 64-column segment {sum, sum of squares} of the STORED (rounded) values, [row][N / 64][2]
   float* amax_val;     // fused row-wise top-1 (sl_gemm_ex_args.amax_*): per 64-column group g and row m the largest value of
   int* amax_idx;       // columns [64 g, 64 g + 64) at [g][m] and its column index; C is then not written at all
 };

@@ -192,3 +192,72 @@ extern "C" int sl_rmsnorm(const void* x, void* y, const void* w, int64_t rows, i
   SL_CHECK_ARG(x && y && w && rows >= 0 && cols > 0, "sl_rmsnorm: bad arguments");
   SL_DISPATCH_DTYPE(dtype, T, return (launch_norm<T, true>(x, y, w, nullptr, rows, cols, eps, 0, (hipStream_t)stream)));
 }
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm folded into the Linears around it (sl_gemm_ex_args.ln_* / stats_out): the row statistics
+// ----------------------------------------------------------------------------------------------
+// {mean, rstd} of a row from the {sum, sum of squares} pairs its producer GEMM left per 64-column segment; one thread per row
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ stats, int segs, int64_t rows, int cols, float eps,
+                                                                float* __restrict__ mr) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float2* s = (const float2*)stats + row * segs;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < segs; ++i) { const float2 v = s[i]; s1 += v.x; s2 += v.y; }
+  const float mean = s1 / (float)cols;
+  float var = s2 / (float)cols - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  ((float2*)mr)[row] = make_float2(mean, rsqrtf(var + eps));
+}
+
+// the same pair from the rows themselves: one wave per row, the row in registers, two-pass variance
+template <typename T>
+__global__ __launch_bounds__(256) void ln_rowstats_kernel(const T* __restrict__ x, int64_t rows, int cols, float eps, float* __restrict__ mr) {
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int MAXCH = NORM_MAXF / VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = cols / VEC;
+  float xv[MAXCH][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      Vec16<T>::unpack(*(const uint4*)(x + row * cols + ch * VEC), xv[i]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += xv[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i)
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = xv[i][e] - mean; s2 += d * d; }
+    }
+  const float var = wave_sum(s2) / (float)cols;
+  if (lane == 0) ((float2*)mr)[row] = make_float2(mean, rsqrtf(var + eps));
+}
+
+extern "C" int sl_layernorm_stats_finalize(const float* stats, int32_t segs, int64_t rows, int32_t cols, float eps, float* mr, sl_stream stream) {
+  SL_CHECK_ARG(stats && mr && segs > 0 && rows >= 0 && cols == 64 * segs, "sl_layernorm_stats_finalize: bad arguments (segs=%d cols=%d)", segs, cols);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)ceil_div64(rows, 256)), dim3(256), 0, (hipStream_t)stream, stats, segs, rows, cols, eps, mr);
+  SL_CHECK_LAUNCH("ln_stats_finalize");
+  return 0;
+}
+
+extern "C" int sl_layernorm_stats(const void* x, int64_t rows, int32_t cols, float eps, float* mr, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(x && mr && rows >= 0 && cols > 0, "sl_layernorm_stats: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * NORM_MAXF, "sl_layernorm_stats: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * NORM_MAXF);
+  if (rows == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((ln_rowstats_kernel<T>), dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, rows, cols, eps, mr);
+  });
+  SL_CHECK_LAUNCH("ln_rowstats");
+  return 0;
+}

@@ -25,6 +25,7 @@ int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cac
                               float scale, int32_t dtype, hipStream_t st, int counters);
 size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx);
 int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st);
+bool sl_gemm_rows_epilogue_ok(int M, int N, int K, int dtype);
 
 namespace {
 
@@ -101,6 +102,8 @@ struct HubertWs {
   int64_t* desc;
   int64_t* c0desc;  // n_utt + 1 sample offsets, then n_utt + 1 row offsets of the conv0 output (batched conv0 launch)
   int64_t* pdesc;   // per utterance {pooled rows, element offset into `pooled`, element offset into `out`, 0}: AvgPool + grouped projector
+  float* ln_stats;  // LayerNorm fold: [frames][hidden / 64][2] partial {sum, sum of squares} out of the out_proj / FFN2 epilogues
+  float* ln_mr;     //                 [frames][2] {mean, rstd}
 };
 
 static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n_utt, void* base, size_t cap, HubertWs& w) {
@@ -123,6 +126,8 @@ static size_t hubert_carve(const sl_hubert_model* m, const HubertPlan& pl, int n
   w.cu = (int32_t*)c.take((n_utt + 1) * sizeof(int32_t));
   w.cuk = (int32_t*)c.take(n_utt * sizeof(int32_t));
   w.klen = (int32_t*)c.take(n_utt * sizeof(int32_t));
+  w.ln_stats = (float*)c.take((size_t)pl.total_T * (size_t)((H + 63) / 64) * 2 * sizeof(float));
+  w.ln_mr = (float*)c.take((size_t)pl.total_T * 2 * sizeof(float));
   return c.off + 256;
 }
 
@@ -147,10 +152,36 @@ static int encoder_tail(const sl_hubert_model* m, HubertWs& w, const HubertPlan&
   sl_stream stream = (sl_stream)st;
   const int dt = m->dtype, H = m->hidden, NT = (int)pl.total_T;
   const size_t sz = sl_dtype_size(dt);
+  // LayerNorm fold (bf16 inference, weights prepared by the caller: m->fold): no LayerNorm pass over the frames inside the layers.
+  // x -> [q|k|v Linear with ln1 folded in, row statistics applied in its epilogue] -> attention -> out_proj (+ bias + residual;
+  // its epilogue leaves the row statistics of the new x) -> [FFN1 with ln2 folded in, GELU] -> FFN2 (+ bias + residual, statistics
+  // again).  Two LayerNorm launches per layer (160 us each at 255 k frames, HBM-bound) become two 8 us finalize launches.
+  const bool fold = m->fold != nullptr && dt == SL_BF16 && !sl_env().no_ln_fold && H % 64 == 0 && m->ffn % 64 == 0 &&
+                    sl_gemm_rows_epilogue_ok(NT, 3 * H, H, dt) && sl_gemm_rows_epilogue_ok(NT, H, H, dt) &&
+                    sl_gemm_rows_epilogue_ok(NT, m->ffn, H, dt) && sl_gemm_rows_epilogue_ok(NT, H, m->ffn, dt);
+  auto gemm_x = [&](const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* res, int N, int K, int act,
+                    const float* ln_u, const float* ln_c, bool stats) -> int {
+    sl_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.residual = res; a.ldr = res ? ldc : 0;
+    a.M = NT; a.N = N; a.K = K; a.batch = 1; a.dtype = dt; a.act = act;
+    sl_gemm_ex_args ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.w_mod = 1;
+    if (ln_u) { ex.ln_mr = w.ln_mr; ex.ln_u = ln_u; ex.ln_c = ln_c; }
+    if (stats) ex.stats_out = w.ln_stats;
+    return sl_gemm_impl(&a, nullptr, &ex, st);
+  };
+  if (fold) SL_TRY(sl_layernorm_stats(w.x, NT, H, m->ln_eps, w.ln_mr, dt, stream));       // the first layer's input comes out of the positional conv
   for (int l = 0; l < m->n_layers; ++l) {
     const sl_hubert_layer& L = m->layers[l];
-    SL_TRY(sl_layernorm(w.x, w.ln, L.ln1_g, L.ln1_b, NT, H, m->ln_eps, 0, dt, stream));
-    SL_TRY(gemm(dt, w.ln, H, L.wqkv, H, w.qkv, 3 * H, L.bqkv, nullptr, 0, NT, 3 * H, H, SL_ACT_NONE, 0, st));
+    if (fold) {
+      const sl_hubert_fold& F = m->fold[l];
+      SL_TRY(gemm_x(w.x, H, F.wqkv_f, H, w.qkv, 3 * H, nullptr, nullptr, 3 * H, H, SL_ACT_NONE, F.uqkv, F.cqkv, false));
+    } else {
+      SL_TRY(sl_layernorm(w.x, w.ln, L.ln1_g, L.ln1_b, NT, H, m->ln_eps, 0, dt, stream));
+      SL_TRY(gemm(dt, w.ln, H, L.wqkv, H, w.qkv, 3 * H, L.bqkv, nullptr, 0, NT, 3 * H, H, SL_ACT_NONE, 0, st));
+    }
     sl_attn_args a;
     memset(&a, 0, sizeof(a));
     a.q = w.qkv; a.q_row_stride = 3 * H; a.q_head_stride = 64;
@@ -161,6 +192,16 @@ static int encoder_tail(const sl_hubert_model* m, HubertWs& w, const HubertPlan&
     a.nseq = n_utt; a.max_qlen = (int)pl.max_T; a.n_heads = m->n_heads; a.n_kv_heads = m->n_heads; a.head_dim = 64; a.causal = 0;
     a.dtype = dt; a.scale = 0.125f;
     SL_TRY(sl_attn_fwd(&a, stream));
+    if (fold) {
+      const sl_hubert_fold& F = m->fold[l];
+      SL_TRY(gemm_x(w.att, H, L.wo, H, w.x, H, L.bo, w.x, H, H, SL_ACT_NONE, nullptr, nullptr, true));
+      SL_TRY(sl_layernorm_stats_finalize(w.ln_stats, H / 64, NT, H, m->ln_eps, w.ln_mr, stream));
+      SL_TRY(gemm_x(w.x, H, F.w1_f, H, w.mid, m->ffn, nullptr, nullptr, m->ffn, H, SL_ACT_GELU, F.u1, F.c1, false));
+      const bool more = l + 1 < m->n_layers;       // the final LayerNorm keeps its own kernel (its output is the product)
+      SL_TRY(gemm_x(w.mid, m->ffn, L.w2, m->ffn, w.x, H, L.b2, w.x, H, m->ffn, SL_ACT_NONE, nullptr, nullptr, more));
+      if (more) SL_TRY(sl_layernorm_stats_finalize(w.ln_stats, H / 64, NT, H, m->ln_eps, w.ln_mr, stream));
+      continue;
+    }
     SL_TRY(gemm(dt, w.att, H, L.wo, H, w.x, H, L.bo, w.x, H, NT, H, H, SL_ACT_NONE, 0, st));
     SL_TRY(sl_layernorm(w.x, w.ln, L.ln2_g, L.ln2_b, NT, H, m->ln_eps, 0, dt, stream));
     SL_TRY(gemm(dt, w.ln, H, L.w1, H, w.mid, m->ffn, L.b1, nullptr, 0, NT, m->ffn, H, SL_ACT_GELU, 0, st));

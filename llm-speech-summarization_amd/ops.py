@@ -355,8 +355,10 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
             residual=None, ldr: int = 0, act: int = L.ACT_NONE, out_f32: bool = False, trans_a: bool = False, trans_w: bool = False,
             residual_f32: bool = False, aux_out=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0,
             strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, r_off: int = 0,
-            dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1, groups_ext: bool = False):
-    """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors."""
+            dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1, groups_ext: bool = False,
+            ln_mr=None, ln_u=None, ln_c=None, stats_out=None):
+    """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors.  ln_mr/ln_u/ln_c: the
+    LayerNorm-folded consumer epilogue; stats_out: per-64-column {sum, sum of squares} of the stored rows (speechllm.h)."""
     dt = dtype or A.dtype
     esz = 4 if dt == torch.float32 else 2
     a = L.GemmArgs()
@@ -371,8 +373,25 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     e = L.GemmEx()
     e.trans_a, e.trans_w, e.residual_f32, e.aux_out = int(trans_a), int(trans_w), int(residual_f32), L.ptr(aux_out)
     e.groups, e.w_mod, e.groups_ext = L.ptr(groups), w_mod, int(groups_ext)
+    e.ln_mr, e.ln_u, e.ln_c, e.stats_out = L.ptr(ln_mr), L.ptr(ln_u), L.ptr(ln_c), L.ptr(stats_out)
     L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(e), L.stream_ptr()), "sl_gemm_ex")
     return out
+
+
+def layernorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """(rows, 2) fp32 {mean, rstd} of every row of x (sl_layernorm_stats) — the first layer's input of the folded encoder."""
+    rows, cols = x.shape
+    mr = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    L.check(L.lib().sl_layernorm_stats(L.ptr(x), rows, cols, eps, L.ptr(mr), L.dtype_code(x.dtype), L.stream_ptr()), "sl_layernorm_stats")
+    return mr
+
+
+def layernorm_stats_finalize(stats: torch.Tensor, cols: int, eps: float) -> torch.Tensor:
+    """(rows, 2) fp32 {mean, rstd} from a producer GEMM's (rows, cols/64, 2) segment sums (sl_layernorm_stats_finalize)."""
+    rows, segs = stats.shape[0], stats.shape[1]
+    mr = torch.empty((rows, 2), device=stats.device, dtype=torch.float32)
+    L.check(L.lib().sl_layernorm_stats_finalize(L.ptr(stats), segs, rows, cols, eps, L.ptr(mr), L.stream_ptr()), "sl_layernorm_stats_finalize")
+    return mr
 
 
 def transpose_pad(x: torch.Tensor, rows: int, cols: int, ld_out: Optional[int] = None) -> torch.Tensor:

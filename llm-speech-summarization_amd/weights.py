@@ -299,6 +299,36 @@ def fold_pos_conv_weight(sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tens
     return v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
 
 
+def build_layernorm_fold(w) -> None:
+    """LayerNorm-folded copies of every layer's q|k|v and FFN1 weights for the inference path (sl_hubert_fold, bf16 only): the
+    gain goes into the weight's columns (rounded to bf16 once), u = the row sums of that rounded matrix, c = W . beta + bias in
+    fp32 — Linear(LayerNorm(x)) = rstd (x W'^T - mean u) + c, so sl_hubert_forward needs no LayerNorm pass inside the layers
+    (hf:models/hubert/modeling_hubert.py:515-517,612).  Built from the DEVICE tensors (the values the unfused kernels would
+    read); the first call allocates, later calls (weights moved: KD optimizer steps) update in place."""
+    w.fold_stale = False
+    if w.dtype != torch.bfloat16 or torch.device(w.device).type != "cuda":
+        return
+    first = not hasattr(w, "_fold_t")
+    if first:
+        w._fold_t = []
+        w._fold = (L.HubertFold * len(w.layer_t))()
+    for li, lt in enumerate(w.layer_t):
+        outs = []
+        for wk, bk, gk, bek in (("wqkv", "bqkv", "ln1_g", "ln1_b"), ("w1", "b1", "ln2_g", "ln2_b")):
+            W0 = lt[wk].float()
+            Wf = (W0 * lt[gk].float()[None, :]).to(torch.bfloat16)
+            outs += [Wf, Wf.float().sum(dim=1).contiguous(), (W0 @ lt[bek].float() + lt[bk].float()).contiguous()]
+        if first:
+            w._fold_t.append(outs)
+            f = w._fold[li]
+            f.wqkv_f, f.uqkv, f.cqkv, f.w1_f, f.u1, f.c1 = (t.data_ptr() for t in outs)
+        else:
+            for dst, src in zip(w._fold_t[li], outs):
+                dst.copy_(src)
+    if first:
+        w.struct.fold = C.cast(w._fold, C.POINTER(L.HubertFold))
+
+
 class HubertDeviceWeights:
     """Owns the device tensors and the sl_hubert_model struct that points at them."""
 
@@ -320,6 +350,7 @@ class HubertDeviceWeights:
             return t
 
         self._populate(sd, dev, by_ptr)
+        build_layernorm_fold(self)
 
     def refresh(self, sd: Dict[str, torch.Tensor]) -> None:
         """Re-derive every device tensor from `sd` IN PLACE (the optimizer step of the KD trainer: the fp32 master weights
@@ -334,6 +365,7 @@ class HubertDeviceWeights:
             return dst
 
         self._populate(sd, dev, None)
+        build_layernorm_fold(self)
 
     def _populate(self, sd, dev, by_ptr) -> None:
         arch, dtype, llm_dim = self.arch, self.dtype, self.llm_dim
@@ -433,6 +465,7 @@ class HubertDeviceWeights:
             dst.copy_(w.permute(0, 2, 1).reshape(dst.shape))
         wpos = fold_pos_conv_weight(sd, "encoder.encoder.pos_conv_embed.conv.")
         self.t["pos_w"].copy_(wpos.permute(0, 2, 1).reshape(self.t["pos_w"].shape))
+        self.fold_stale = True      # the fused optimizer step rewrote the layer weights: the LayerNorm-folded copies follow lazily
 
 
 # ------------------------------------------------------------------------------------------------
@@ -640,6 +673,7 @@ class WhisperDeviceWeights:
             return t
 
         self._populate(sd, dev, by_ptr)
+        build_layernorm_fold(self)
 
     def refresh(self, sd: Dict[str, torch.Tensor]) -> None:
         """In-place update of every device tensor from `sd` (see HubertDeviceWeights.refresh)."""
@@ -652,6 +686,7 @@ class WhisperDeviceWeights:
             return dst
 
         self._populate(sd, dev, None)
+        build_layernorm_fold(self)
 
     def _populate(self, sd, dev, by_ptr) -> None:
         arch, dtype, llm_dim = self.arch, self.dtype, self.llm_dim
@@ -720,3 +755,4 @@ class WhisperDeviceWeights:
             w = sd[f"encoder.{name}.weight"]
             dst = self.t[f"{name}_w"]
             dst.copy_(w.permute(0, 2, 1).reshape(dst.shape))
+        self.fold_stale = True

@@ -283,7 +283,7 @@ def test_ctypes_struct_mirrors_match_the_c_header(tmp_path):
     pairs = [("sl_gemm_args", L.GemmArgs), ("sl_gemm_fused", L.GemmFused), ("sl_gemm_ex_args", L.GemmEx), ("sl_attn_args", L.AttnArgs), ("sl_attn_bwd_args", L.AttnBwdArgs), ("sl_enc_stack_cfg", L.EncStackCfg), ("sl_enc_layer_saved", L.EncLayerSaved),
              ("sl_enc_layer_grads", L.EncLayerGrads), ("sl_llama_stack_cfg", L.LlamaStackCfg), ("sl_llama_train_layer", L.LlamaTrainLayer),
              ("sl_llama_layer_saved", L.LlamaLayerSaved), ("sl_adamw_tensor", L.AdamWTensor),
-             ("sl_hubert_layer", L.HubertLayer), ("sl_hubert_model", L.HubertModel), ("sl_llama_layer", L.LlamaLayer),
+             ("sl_hubert_layer", L.HubertLayer), ("sl_hubert_fold", L.HubertFold), ("sl_hubert_model", L.HubertModel), ("sl_llama_layer", L.LlamaLayer),
              ("sl_llama_model", L.LlamaModel), ("sl_kv_cache", L.KVCache)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "speechllm.h")}"', 'int main(void) {']
     for cname, cls in pairs:

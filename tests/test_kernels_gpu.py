@@ -788,3 +788,124 @@ def test_gemm_packed_at_the_benchmarked_decode_shapes(M):
     wl = rnd(20000, H, seed=79, std=H ** -0.5)
     lg = ops.gemm_decode(xd, ops.pack_weight(wl.to(dev(), dt)), 20000, fuse_rms=True, eps=1e-5, out_f32=True)
     assert rel_err(lg.cpu(), (xf * rstd[:, None]) @ q(wl, dt).T) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(499, 1024, 1024), (4100, 1024, 4096), (20000, 1280, 1280), (65, 64, 64)])
+def test_gemm_row_statistics_epilogue_equals_sums_of_the_stored_rows(M, N, K):
+    """stats_out (the producer side of the LayerNorm fold): {sum, sum of squares} of every 64-column segment of the rows the GEMM
+    stored — of the bf16-rounded values, the ones the next kernel reads — with bias and residual in; finalize then gives the
+    {mean, rstd} torch computes from the same stored rows, and sl_layernorm_stats (the first layer's input) agrees with both."""
+    dt = torch.bfloat16
+    A, W, b, R = rnd(M, K, seed=61), rnd(N, K, seed=62, std=K ** -0.5), rnd(N, seed=63), rnd(M, N, seed=64) + 0.5
+    assert L.lib().sl_gemm_ln_fold_ok(M, N, K, L.dtype_code(dt)) == 1
+    out = torch.empty((M, N), device=dev(), dtype=dt)
+    stats = torch.full((M, N // 64, 2), float("nan"), device=dev(), dtype=torch.float32)
+    Ad, Wd, bd, Rd = A.to(dev(), dt), W.to(dev(), dt), b.to(dev(), dt), R.to(dev(), dt)
+    ops.gemm_ex(Ad, Wd, M=M, N=N, K=K, lda=K, ldw=K, out=out, bias=bd, residual=Rd, ldr=N, stats_out=stats)
+    plain = ops.gemm(Ad, Wd, bias=bd, residual=Rd)
+    assert torch.equal(out, plain)                                       # the statistics ride along; the product is untouched
+    seg = out.float().view(M, N // 64, 64)
+    assert rel_err(stats[..., 0].cpu(), seg.sum(-1).cpu()) < 1e-5
+    assert rel_err(stats[..., 1].cpu(), (seg * seg).sum(-1).cpu()) < 1e-5
+    eps = 1e-5
+    mr = ops.layernorm_stats_finalize(stats, N, eps)
+    x = out.double()
+    mean, var = x.mean(-1), x.var(-1, unbiased=False)
+    want = torch.stack([mean, (var + eps).rsqrt()], dim=-1).float()
+    assert rel_err(mr.cpu(), want.cpu()) < 1e-5
+    assert rel_err(ops.layernorm_stats(out, eps).cpu(), want.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_GELU])
+@pytest.mark.parametrize("M,N,K", [(499, 3072, 1024), (4100, 4096, 1024), (20000, 3840, 1280)])
+def test_gemm_layernorm_fold_equals_layernorm_then_linear(act, M, N, K):
+    """The consumer side: Linear(LayerNorm(x)) = rstd (x W'^T - mean u) + c with W' = W o gain, u = rowsum(W'), c = W beta + bias
+    (weights.build_layernorm_fold) against fp32 LayerNorm -> Linear on the same bf16 inputs, and within the same distance of it as
+    the unfolded kernels (LayerNorm rounding its output to bf16, then the plain GEMM).  Rows carry a mean of 3 standard
+    deviations so the mean term is not a rounding-level correction."""
+    dt = torch.bfloat16
+    x = (rnd(M, K, seed=71) * (1 + rnd(M, 1, seed=72).abs()) + 3.0 * rnd(M, 1, seed=73)).to(dt)
+    g, beta = (1 + 0.3 * rnd(K, seed=74)).to(dt), (0.2 * rnd(K, seed=75)).to(dt)
+    W, b = rnd(N, K, seed=76, std=K ** -0.5).to(dt), rnd(N, seed=77).to(dt)
+    eps = 1e-5
+    ref = F.layer_norm(x.float(), (K,), g.float(), beta.float(), eps) @ W.float().T + b.float()
+    ref = F.gelu(ref) if act == L.ACT_GELU else ref
+    xd, gd, bed, Wd, bd = (t.to(dev()) for t in (x, g, beta, W, b))
+    Wf = (Wd.float() * gd.float()[None, :]).to(dt)
+    u = Wf.float().sum(1).contiguous()
+    c = (Wd.float() @ bed.float() + bd.float()).contiguous()
+    mr = ops.layernorm_stats(xd, eps)
+    out = torch.empty((M, N), device=dev(), dtype=dt)
+    ops.gemm_ex(xd, Wf, M=M, N=N, K=K, lda=K, ldw=K, out=out, act=act, ln_mr=mr, ln_u=u, ln_c=c)
+    unfolded = ops.gemm(ops.layernorm(xd, gd, bed, eps), Wd, bias=bd, act=act)
+    e_fold, e_plain = rel_err(out.float().cpu(), ref), rel_err(unfolded.float().cpu(), ref)
+    assert e_fold < TOL[dt] and e_fold < 1.5 * e_plain + 1e-3, (e_fold, e_plain)
+
+
+def test_gemm_layernorm_fold_arguments_are_checked():
+    """ln_* come together, exclude a separate bias, and need a product the LDS-DMA tiled kernels take (bf16, M > 64, N % 64 == 0)."""
+    dt = torch.bfloat16
+    M, N, K = 256, 128, 128
+    x, W = rnd(M, K, seed=81).to(dev(), dt), rnd(N, K, seed=82).to(dev(), dt)
+    mr, u, c = (torch.zeros(n, device=dev()) for n in (2 * M, N, N))
+    out = torch.empty((M, N), device=dev(), dtype=dt)
+    for kw in (dict(ln_mr=mr, ln_u=u), dict(ln_mr=mr, ln_u=u, ln_c=c, bias=W[0].contiguous())):
+        with pytest.raises(RuntimeError, match="LayerNorm fold needs"):
+            ops.gemm_ex(x, W, M=M, N=N, K=K, lda=K, ldw=K, out=out, **kw)
+    with pytest.raises(RuntimeError, match="ln_\\* / stats_out need"):
+        ops.gemm_ex(x, W, M=32, N=N, K=K, lda=K, ldw=K, out=out, ln_mr=mr, ln_u=u, ln_c=c)
+    with pytest.raises(RuntimeError, match="ln_\\* / stats_out need"):
+        ops.gemm_ex(x.float(), W.float(), M=M, N=N, K=K, lda=K, ldw=K, out=out.float(), stats_out=mr)
+    assert L.lib().sl_gemm_ln_fold_ok(32, N, K, L.dtype_code(dt)) == 0 and L.lib().sl_gemm_ln_fold_ok(M, 100, K, L.dtype_code(dt)) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(40000, 1000, 2048), (33000, 3072, 1024), (16500, 2056, 192)])
+def test_gemm_swapped_operand_epilogue_equals_lds_turned_rows_epilogue(M, N, K, tuning):
+    """The 256-tile kernel's two bf16 store paths — operands exchanged in the MFMA so a lane owns 16 columns of a row and stores
+    them from registers (default where rows are 8-element aligned), and the accumulator tile turned through LDS
+    (SL_NO_SWAP_EPILOGUE=1) — on the same launches: bias, bias + GELU, bias + residual, ragged M and N edges, a batch of two.
+    Same products in the same order; only the store pattern differs, so the outputs are bit-identical."""
+    dt = torch.bfloat16
+    A, W, b, R = rnd(M, K, seed=91), rnd(N, K, seed=92, std=K ** -0.5), rnd(N, seed=93), rnd(M, N, seed=94)
+    Ad, Wd, bd, Rd = A.to(dev(), dt), W.to(dev(), dt), b.to(dev(), dt), R.to(dev(), dt)
+
+    def run():
+        outs = [ops.gemm(Ad, Wd, bias=bd), ops.gemm(Ad, Wd, bias=bd, act=L.ACT_GELU), ops.gemm(Ad, Wd, bias=bd, residual=Rd), ops.gemm(Ad, Wd)]
+        o2 = torch.empty((2, M // 2, N), device=dev(), dtype=dt)
+        ops.gemm_ex(Ad, Wd, M=M // 2, N=N, K=K, lda=K, ldw=K, out=o2, ldc=N, bias=bd, batch=2, strideA=(M // 2) * K, strideC=(M // 2) * N)
+        return outs + [o2]
+
+    swapped = run()
+    tuning("SL_NO_SWAP_EPILOGUE", "1")
+    turned = run()
+    for s_, t_ in zip(swapped, turned):
+        assert torch.equal(s_, t_)
+    ref = F.gelu(q(A, dt) @ q(W, dt).T + q(b, dt))
+    assert rel_err(swapped[1].float().cpu(), ref) < TOL[dt]
+    assert torch.equal(swapped[4].view(-1, N)[: 2 * (M // 2)], swapped[0][: 2 * (M // 2)])
+
+
+def test_gemm_layernorm_fold_is_bit_identical_across_tile_kernels(tuning):
+    """Row statistics and the folded consumer from the 256-tile kernel's register epilogue, from its LDS-turned rows epilogue
+    and from the 128-tile kernel (what a short batch takes): one summation tree, so the same bits — a batch of utterances and
+    the utterances alone must encode identically whichever kernel their row count selects."""
+    dt = torch.bfloat16
+    M, N, K = 33000, 1024, 1024
+    A, W, b, R = rnd(M, K, seed=95), rnd(N, K, seed=96, std=K ** -0.5), rnd(N, seed=97), rnd(M, N, seed=98)
+    Ad, Wd, bd, Rd = A.to(dev(), dt), W.to(dev(), dt), b.to(dev(), dt), R.to(dev(), dt)
+    u, c = rnd(N, seed=99).to(dev()), rnd(N, seed=100).to(dev())
+
+    def run(rows):
+        out, st = torch.empty((rows, N), device=dev(), dtype=dt), torch.empty((rows, N // 64, 2), device=dev())
+        ops.gemm_ex(Ad, Wd, M=rows, N=N, K=K, lda=K, ldw=K, out=out, bias=bd, residual=Rd, ldr=N, stats_out=st)
+        mr = ops.layernorm_stats_finalize(st, N, 1e-5)
+        out2 = torch.empty((rows, N), device=dev(), dtype=dt)
+        ops.gemm_ex(out, Wd, M=rows, N=N, K=K, lda=K, ldw=K, out=out2, act=L.ACT_GELU, ln_mr=mr, ln_u=u, ln_c=c)
+        return out, st, out2
+
+    big = run(M)                       # 256-tile kernel, swapped operands
+    small = run(300)                   # 128-tile kernel, rows epilogue
+    tuning("SL_NO_SWAP_EPILOGUE", "1")
+    turned = run(M)                    # 256-tile kernel, rows epilogue
+    for x, y, z in zip(big, turned, small):
+        assert torch.equal(x, y) and torch.equal(x[:300], z)

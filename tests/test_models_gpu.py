@@ -22,6 +22,7 @@ cfgm = pkg("config")
 enc_mod = pkg("audio_encoder")
 llama_mod = pkg("audio_llama")
 weights = pkg("weights")
+L = pkg("_lib")
 inf_mod = pkg("inference")
 utils = pkg("utils")
 
@@ -124,6 +125,38 @@ def test_encoder_wide_hubert_large_width(dtype, tol):
         ref_h = taps["last_hidden_state"][0]
     assert rel_err(last_hidden.float().cpu(), ref_h) < tol
     assert rel_err(out.float().cpu(), ref_o) < tol
+
+
+def test_encoder_layernorm_fold_against_the_unfolded_layers_and_the_oracle(monkeypatch):
+    """bf16 inference folds each layer's two LayerNorms into the neighbouring GEMMs (sl_hubert_fold).  Both forms against the
+    fp32 oracle on the same bf16-rounded weights: the folded one within the bf16 bound and no further from the oracle than the
+    unfolded one by more than a rounding's worth; the two differ bit-wise (the fold is what ran); and after the weights move
+    (refresh: a KD optimizer step) the folded copies follow."""
+    enc, sd = make_encoder(WIDE_HUBERT, 3072, 31, torch.bfloat16)
+    assert enc.weights.struct.fold
+    waves = [ri.synthetic_waveform(n, seed=n) for n in (32000, 48000, 25000)]
+    keep32 = "conv_layers.0."
+    sdq = {k: (v if keep32 in k else v.to(torch.bfloat16).float()) for k, v in sd.items()}
+    ref = torch.cat([ho.audio_encoder_forward(sdq, WIDE_HUBERT, w[None])[0] for w in waves])
+    folded = enc.encode_packed(waves)[0].float().cpu()
+    monkeypatch.setenv("SL_NO_LN_FOLD", "1")
+    L.lib().sl_tuning_reload()
+    try:
+        plain = enc.encode_packed(waves)[0].float().cpu()
+    finally:
+        monkeypatch.undo()
+        L.lib().sl_tuning_reload()
+    e_f, e_p = rel_err(folded, ref), rel_err(plain, ref)
+    assert e_f < BF16_TOL and e_f < 1.5 * e_p + 2e-3, (e_f, e_p)
+    assert not torch.equal(folded, plain)
+    gen = torch.Generator().manual_seed(5)
+    sd2 = {k: (v * (1 + 0.5 * torch.randn(v.shape, generator=gen)) if k.endswith("layer_norm.weight") and ".layers." in k else v)
+           for k, v in sd.items()}
+    enc.weights.refresh(sd2)
+    sdq2 = {k: (v if keep32 in k else v.to(torch.bfloat16).float()) for k, v in sd2.items()}
+    ref2 = torch.cat([ho.audio_encoder_forward(sdq2, WIDE_HUBERT, w[None])[0] for w in waves])
+    assert rel_err(enc.encode_packed(waves)[0].float().cpu(), ref2) < BF16_TOL
+    assert rel_err(ref2, ref) > 3 * BF16_TOL      # the gains mattered: stale folded copies would have failed the line above
 
 
 @pytest.mark.parametrize("name,cfg", [("tiny_gqa", TINY_LLAMA), ("tiny_mha", TINY_MHA)])
