@@ -217,6 +217,7 @@ struct SlEnv {
   int attn_qt;             // SL_ATTN_QT
   int norm_single_row;     // SL_NORM_SINGLE_ROW
   int no_ln_fold;          // SL_NO_LN_FOLD        1 = the encoder runs its LayerNorm kernels even when folded weights are supplied (A/B)
+  int gemm_log;            // SL_GEMM_LOG          1 = every sl_gemm* call prints its shape and flags on stderr (shape census for tuning)
   int no_swap_epilogue;    // SL_NO_SWAP_EPILOGUE  1 = the 256-tile GEMM keeps the LDS-turned rows epilogue where the swapped-operand form applies (A/B)
   int stream_splits, stream_nwv, stream_mt;   // SL_STREAM_CFG "splits,nwv[,mt]" (0 = not set)
   int stream_wide;         // SL_STREAM_WIDE       0 = never use the 256 x 128 streaming block, 1 = default rule, 2 = whenever it applies

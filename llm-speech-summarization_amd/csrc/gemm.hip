@@ -421,7 +421,7 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
         }
         const uint4 pk = Vec16<T>::pack(v);
         if (row < p.M && okh[h]) {
-          *(uint4*)((T*)p.C + co + row * p.ldc + colh[h]) = pk;
+          *(uint4*)((T*)p.C + co + row * p.ldc + colh[h]) = pk;       // (non-temporal stores: 0.89 x at N = K = 1024 without residual, 1.00-1.04 x on every encoder shape)
           if constexpr (ST) {             // statistics of the values as stored (the packed halves shifted back up), per 4-column leaf
             const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};   // exactly as the rows epilogue forms them: the tree below is its tree
 #pragma unroll
@@ -794,6 +794,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 // A persistent form (one block per CU walking its tiles, the next tile's first slab requested before the current tile's
 // epilogue, which then turns 32-row groups through the other staging buffer) measured within +-2 % of this kernel at
 // K = 1024..8192: the vmcnt(0) that admits the prefetched slab also drains the epilogue's stores (one counter on gfx9).
+// Round 3, again with the register epilogue of the swapped-operand form (no LDS in the epilogue, the K slabs of consecutive tiles as
+// one double-buffered stream, scalar tile bases): 0.97-1.02 x on the encoder shapes (tools/time_fold_epilogue.py); removed again.
+// Where the time goes (127744 x 4096 x 1024, bias + GELU, 1180 us): product loop alone 820-845 us (1.27-1.3 PF/s), epilogue
+// arithmetic without its stores +45 us, the stores +170..290 us — 128 KiB per tile leave a CU at ~24 GB/s, and neither spreading
+// the first-round blocks of an XCD over a tile time nor a block that outlives its tile changes that.
 // ----------------------------------------------------------------------------------------------
 constexpr int XBM = 256, XBN = 256;
 
@@ -1345,6 +1350,9 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     }
   }
   SL_CHECK_ARG(p.amax_val || a->C, "sl_gemm: null C");
+  if (sl_env().gemm_log)     // SL_GEMM_LOG=1: one line per product on stderr (tools/kd_gemm_shapes.py turns a KD window's lines into a per-shape table)
+    fprintf(stderr, "SLGEMM M=%d N=%d K=%d batch=%d act=%d ta=%d tw=%d res=%d resf32=%d outf32=%d aux=%d grp=%d bias=%d packed=%d dt=%d\n", a->M, a->N, a->K, a->batch, a->act,
+            p.ta, p.tw, a->residual != nullptr, p.res_f32, a->out_f32, p.aux != nullptr, p.grp ? (p.grp_ext ? 2 : 1) : 0, a->bias != nullptr, a->w_layout == SL_W_PACKED, a->dtype);
   SkinnyX sx;
   memset(&sx, 0, sizeof(sx));
   if (fx) {
