@@ -64,6 +64,7 @@ static const SlEnv* env_load() {
   e.no_ln_fold = env_int("SL_NO_LN_FOLD", 0);
   e.no_swap_epilogue = env_int("SL_NO_SWAP_EPILOGUE", 0);
   e.gemm_log = env_int("SL_GEMM_LOG", 0);
+  e.no_wgrad_stream = env_int("SL_NO_WGRAD_STREAM", 0);
   e.stream_splits = e.stream_nwv = e.stream_mt = 0;
   e.stream_nl = env_int("SL_STREAM_NL", 0);
   e.stream_wide = env_int("SL_STREAM_WIDE", 1);

@@ -179,6 +179,8 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+constexpr int SL_MAX_DEVICES = 64;      // per-thread, per-device helper objects (capture streams, side streams) are kept in arrays of this size
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // dtype dispatch on the host
@@ -217,6 +219,7 @@ struct SlEnv {
   int attn_qt;             // SL_ATTN_QT
   int norm_single_row;     // SL_NORM_SINGLE_ROW
   int no_ln_fold;          // SL_NO_LN_FOLD        1 = the encoder runs its LayerNorm kernels even when folded weights are supplied (A/B)
+  int no_wgrad_stream;     // SL_NO_WGRAD_STREAM   1 = the encoder backward keeps its parameter-gradient products on the caller's stream (A/B)
   int gemm_log;            // SL_GEMM_LOG          1 = every sl_gemm* call prints its shape and flags on stderr (shape census for tuning)
   int no_swap_epilogue;    // SL_NO_SWAP_EPILOGUE  1 = the 256-tile GEMM keeps the LDS-turned rows epilogue where the swapped-operand form applies (A/B)
   int stream_splits, stream_nwv, stream_mt;   // SL_STREAM_CFG "splits,nwv[,mt]" (0 = not set)

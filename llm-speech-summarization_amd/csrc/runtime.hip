@@ -694,7 +694,6 @@ struct DecodeGraphEntry { DecodeGraphKey key; hipGraph_t graph; hipGraphExec_t e
 static thread_local std::vector<DecodeGraphEntry> g_graphs;
 static thread_local uint64_t g_graph_clock = 0;
 constexpr size_t SL_GRAPH_CACHE = 8;
-constexpr int SL_MAX_DEVICES = 64;
 
 static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
   const unsigned char* b = (const unsigned char*)p;

@@ -117,6 +117,60 @@ int attn_bwd(int dt, const void* qkv, int64_t qkv_w, const void* out, const void
   return sl_attn_bwd(&a, (sl_stream)st);
 }
 
+// The parameter-gradient products of a layer (dW += dY^T X, db += colsum dY) feed nothing in the backward chain; at KD window sizes
+// each of them — and each data-gradient product beside it — fills a quarter to a half of the chip (tools/kd_gemm_shapes.py: 16 to 256
+// tiles).  They go to a second stream, forked off the caller's stream where their dY is complete; the caller's stream waits for them
+// only where it is about to overwrite a buffer they read, and once at the end.  One side stream and a ring of events per thread
+// and device; SL_NO_WGRAD_STREAM=1 keeps everything on the caller's stream.
+struct SideStream {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool pending[4] = {false, false, false, false};
+  hipStream_t main_ = nullptr;
+  bool on = false;
+  int init(hipStream_t main, int64_t n_tok) {
+    main_ = main;
+    on = !sl_env().no_wgrad_stream && n_tok >= 2048;      // below ~2 k rows the products are too short for the fork / join events to pay (1 k rows: -1 %)
+    if (!on) return 0;
+    int dev = 0;
+    SL_HIP(hipGetDevice(&dev));
+    SL_CHECK_ARG(dev >= 0 && dev < SL_MAX_DEVICES, "device %d out of range", dev);
+    struct PerDev { hipStream_t s; hipEvent_t f; hipEvent_t d[4]; };
+    static thread_local PerDev per[SL_MAX_DEVICES] = {};
+    PerDev& pd = per[dev];
+    if (!pd.s) {
+      SL_HIP(hipStreamCreateWithFlags(&pd.s, hipStreamNonBlocking));
+      SL_HIP(hipEventCreateWithFlags(&pd.f, hipEventDisableTiming));
+      for (auto& e : pd.d) SL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    side = pd.s; fork = pd.f;
+    for (int i = 0; i < 4; ++i) done[i] = pd.d[i];
+    return 0;
+  }
+  // the stream the k-th parameter-gradient group of a layer runs on, ordered after everything issued on the caller's stream so far
+  int begin(hipStream_t& st) {
+    st = main_;
+    if (!on) return 0;
+    SL_HIP(hipEventRecord(fork, main_));
+    SL_HIP(hipStreamWaitEvent(side, fork, 0));
+    st = side;
+    return 0;
+  }
+  int end(int k) {
+    if (!on) return 0;
+    SL_HIP(hipEventRecord(done[k], side));
+    pending[k] = true;
+    return 0;
+  }
+  // the caller's stream may not pass this point before group k (and, the side stream being in order, every earlier one) has finished
+  int join(int k) {
+    if (!on || !pending[k]) return 0;
+    SL_HIP(hipStreamWaitEvent(main_, done[k], 0));
+    pending[k] = false;
+    return 0;
+  }
+};
+
 }  // namespace
 
 // ================================================================================================
@@ -209,6 +263,9 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
   const int64_t n = c->n_tok;
   const size_t sz = sl_dtype_size(dt);
+  SideStream ss;
+  SL_TRY(ss.init(st, n));
+  hipStream_t sw = st;           // where the current parameter-gradient group runs
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     if (c->skip[l]) continue;
     const sl_hubert_layer& L = layers[l];
@@ -217,32 +274,45 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     const uint64_t* sd = c->seeds + 4 * (size_t)l;
     // ---- feed-forward half: x_out = x_mid + drop(w2 . drop_act(gelu(w1 . ln2(x_mid) + b1)) + b2)
     const void* d_o2 = dx;
+    SL_TRY(ss.join(2));                                   // tmp_h / d_h2 were the previous layer's d_o1 (read by its wo group)
     if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(dx, nullptr, w.tmp_h, n * H, c->p_hidden, sd[3], dt, stream)); d_o2 = w.tmp_h; }
-    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, st));
-    SL_TRY(sl_colsum(d_o2, H, g.b2, n, H, dt, stream));
+    SL_TRY(ss.begin(sw));
+    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw));
+    SL_TRY(sl_colsum(d_o2, H, g.b2, n, H, dt, (sl_stream)sw));
+    SL_TRY(ss.end(0));
     SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_mid, F, n, w.s, st));
     if (c->p_act > 0.f) SL_TRY(sl_dropout(w.d_mid, nullptr, w.d_mid, n * F, c->p_act, sd[2], dt, stream));
+    SL_TRY(ss.join(1));                                   // d_pre1 was read by the previous layer's w1 group
     SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, w.d_pre1, n * F, dt, stream));
-    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, st));
-    SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, stream));
+    SL_TRY(ss.begin(sw));
+    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw));
+    SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, (sl_stream)sw));
+    SL_TRY(ss.end(1));
     SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st));
     SL_TRY(sl_layernorm_bwd_ws(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));   // d_h2 = d x_mid (LN path)
     SL_TRY(sl_axpby(dx, w.d_h2, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
     const void* d_o1 = w.d_h2;
+    SL_TRY(ss.join(0));                                   // d_o2 (tmp_h or dx) is overwritten below
     if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(w.d_h2, nullptr, w.tmp_h, n * H, c->p_hidden, sd[1], dt, stream)); d_o1 = w.tmp_h; }
-    SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, st));
-    SL_TRY(sl_colsum(d_o1, H, g.bo, n, H, dt, stream));
+    SL_TRY(ss.begin(sw));
+    SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw));
+    SL_TRY(sl_colsum(d_o1, H, g.bo, n, H, dt, (sl_stream)sw));
+    SL_TRY(ss.end(2));
     SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, nullptr, w.d_att, H, n, w.s, st));
+    SL_TRY(ss.join(3));                                   // d_qkv was read by the previous layer's wqkv group
     SL_TRY(attn_bwd(dt, sv.qkv, 3 * H, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nh, 64, 0, 0.125f,
                     c->p_attn, sd[0], st));
-    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, st));
-    SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, stream));
+    SL_TRY(ss.begin(sw));
+    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw));
+    SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, (sl_stream)sw));
+    SL_TRY(ss.end(3));
     SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st));
     SL_TRY(sl_layernorm_bwd_ws(sv.x, L.ln1_g, L.ln1_b, w.d_h1, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));            // dx = d x (LN path)
     SL_TRY(sl_axpby(w.d_h2, dx, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
     (void)sz;
   }
+  for (int k = 0; k < 4; ++k) SL_TRY(ss.join(k));          // the caller's stream owns the gradients again
   return 0;
 }
 

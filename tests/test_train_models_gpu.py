@@ -518,3 +518,53 @@ def test_kd_window_at_benchmark_width_vs_oracle_autograd(dtype):
     overall = sq ** 0.5 / total
     print(f"{dtype}: worst per-parameter gradient error {worst[1]:.2e} ({worst[0]}), all parameters together {overall:.2e}")
     assert overall < (1e-4 if dtype == torch.float32 else 5e-2)
+
+
+def test_parameter_gradient_side_stream_equals_single_stream(monkeypatch):
+    """The encoder backward forks its dW / db products onto a second stream (train_tape.hip SideStream; windows of >= 2048 frames).
+    Same kernels, same accumulation order — so every gradient must have the same bits as with SL_NO_WGRAD_STREAM=1, on repeated
+    runs (a missing join would show as a run-to-run difference: the products read buffers the main chain recycles)."""
+    from oracle.golden_cfgs import WIDE_HUBERT, WIDE_LLAMA
+    L_ = pkg("_lib")
+    HC, LC = WIDE_HUBERT, WIDE_LLAMA
+    enc, _ = make_encoder(HC, LC.hidden_size, 93, torch.bfloat16)
+    llm, _ = make_llama(LC, 94, torch.bfloat16, max_ctx=512)
+    prefix, suffix = ri.synthetic_ids(9, LC.vocab_size, seed=7, bos=128000), ri.synthetic_ids(6, LC.vocab_size, seed=8, bos=128000)
+    tr = training.KDTrainer(kd_config(taps=(0, 1, 2), accum=16), enc, llm, prefix, suffix)
+    tr.optimizer_step = lambda: None
+    gen = torch.Generator().manual_seed(271)
+    B = 16
+    waves = [ri.synthetic_waveform(90000 + 4000 * u, seed=800 + u).to(DEV) for u in range(B)]
+    texts = [torch.randint(1, LC.vocab_size, (30 + u % 7,), generator=gen) for u in range(B)]
+    resps = [torch.randint(1, LC.vocab_size, (40 + (3 * u) % 13,), generator=gen) for u in range(B)]
+
+    def window():
+        tr.enc_tape.arena.zero_()
+        tr.micro = 0                      # the optimizer step that would close the window (and reset the counter) is stubbed out
+        tr.micro_batch(waves, texts, resps)
+        torch.cuda.synchronize()
+        return tr.enc_tape.arena.flat.clone()
+
+    forked = [window() for _ in range(3)]
+    monkeypatch.setenv("SL_NO_WGRAD_STREAM", "1")
+    L_.lib().sl_tuning_reload()
+    try:
+        serial = [window() for _ in range(2)]
+    finally:
+        monkeypatch.undo()
+        L_.lib().sl_tuning_reload()
+    assert float(serial[0].abs().max()) > 0
+    # bias / conv0 gradients are column sums with atomics: their last bits move from run to run on ONE stream too; every dW is
+    # a tiled product accumulated in a fixed order — those must not move at all
+    fixed = 0
+    for name, (o, n, _shape) in tr.enc_tape.arena.span.items():
+        a, b = serial[0][o:o + n], serial[1][o:o + n]
+        if torch.equal(a, b):
+            fixed += 1
+            for f in forked:
+                assert torch.equal(f[o:o + n], a), name
+        else:
+            assert not any(name.endswith(w) for w in (".wqkv", ".wo", ".w1", ".w2")), name
+            for f in forked:
+                assert float((f[o:o + n] - a).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, name
+    assert fixed >= 4 * HC.num_hidden_layers
