@@ -209,6 +209,29 @@ class LlamaTape:
     def logits(self, xn_rows: torch.Tensor) -> torch.Tensor:
         return ops.gemm(xn_rows, self.w.lm_head, out_f32=True)
 
+    LM_HEAD_DGRAD_SPLITS = (12, 8, 6, 4, 3, 2)
+
+    def _lm_head_dgrad(self, d_logits: torch.Tensor) -> torch.Tensor:
+        """d_xn (n, H) = d_logits (n, V) . lm_head (V, H): few output tiles (n ~ 1 k rows x H) under a 128 k-long reduction.  As one
+        transposed-operand product it ran 48 tiles for 2.5 ms (KD window, profiles/r03_ep_kd_gemm_shapes.txt); here the vocabulary is
+        cut into slices (the first count of LM_HEAD_DGRAD_SPLITS that leaves whole 128-byte K slabs: 12 for V = 128 256, 0.88 ms;
+        tools/time_lm_head_dgrad.py) — one batched launch on a K-contiguous (H, V) copy of the frozen matrix, fp32 partials summed
+        in slice order."""
+        w = self.w
+        n, V = d_logits.shape
+        H = w.lm_head.shape[1]
+        vec = 4 if d_logits.dtype == torch.float32 else 8
+        S = next((s_ for s_ in self.LM_HEAD_DGRAD_SPLITS if V % (s_ * 8 * vec) == 0), 1)
+        if S <= 1 or n < 256 or not d_logits.is_contiguous():
+            return ops.dgrad(d_logits, w.lm_head)
+        if getattr(self, "_lm_head_t", None) is None:
+            self._lm_head_t = w.lm_head.t().contiguous()        # frozen (ref:trainer.py:63-64): built once
+        part = torch.empty((S, n, H), device=d_logits.device, dtype=torch.float32)
+        Ks = V // S
+        ops.gemm_ex(d_logits, self._lm_head_t, M=n, N=H, K=Ks, lda=V, ldw=V, out=part, ldc=H, out_f32=True, batch=S, strideA=Ks, strideW=Ks,
+                    strideC=n * H, dtype=d_logits.dtype)
+        return part.sum(0).to(d_logits.dtype)
+
     def backward(self, tape, tail_rows: torch.Tensor, d_logits_tail: torch.Tensor, d_hidden: Dict[int, torch.Tensor],
                  n_seq: Optional[int] = None) -> torch.Tensor:
         """tail_rows: int64 indices (packed) of the rows whose logits carry loss; d_logits_tail: (len(tail_rows), V)
@@ -232,7 +255,7 @@ class LlamaTape:
             cfg.nseq, cfg.n_tok, cfg.max_len = n_seq, n_rows, max(int(n) for n in lens)
             x_final = x_final[:n_rows]
         dx = torch.zeros_like(x_final)
-        d_xn = ops.dgrad(d_logits_tail, w.lm_head)  # (n_tail, H)
+        d_xn = self._lm_head_dgrad(d_logits_tail)   # (n_tail, H)
         if nl in d_hidden:
             d_xn += d_hidden[nl].index_select(0, tail_rows)
         dx.index_copy_(0, tail_rows, ops.rmsnorm_bwd(x_final.index_select(0, tail_rows), w.final_norm, d_xn, a.rms_norm_eps))
