@@ -822,9 +822,12 @@ def test_gemm_layernorm_fold_equals_layernorm_then_linear(act, M, N, K):
     """The consumer side: Linear(LayerNorm(x)) = rstd (x W'^T - mean u) + c with W' = W o gain, u = rowsum(W'), c = W beta + bias
     (weights.build_layernorm_fold) against fp32 LayerNorm -> Linear on the same bf16 inputs, and within the same distance of it as
     the unfolded kernels (LayerNorm rounding its output to bf16, then the plain GEMM).  Rows carry a mean of 3 standard
-    deviations so the mean term is not a rounding-level correction."""
+    deviations so the mean term is not a rounding-level correction, and half of them two outlier channels (80 x, + 40)."""
     dt = torch.bfloat16
-    x = (rnd(M, K, seed=71) * (1 + rnd(M, 1, seed=72).abs()) + 3.0 * rnd(M, 1, seed=73)).to(dt)
+    x = rnd(M, K, seed=71) * (1 + rnd(M, 1, seed=72).abs()) + 3.0 * rnd(M, 1, seed=73)
+    x[::2, 7] *= 80.0                       # every other row with the outlier channels pretrained residual streams carry:
+    x[::2, 300] += 40.0                     # the variance comes from sum(x^2) - mean^2 of the producer's fp32 sums
+    x = x.to(dt)
     g, beta = (1 + 0.3 * rnd(K, seed=74)).to(dt), (0.2 * rnd(K, seed=75)).to(dt)
     W, b = rnd(N, K, seed=76, std=K ** -0.5).to(dt), rnd(N, seed=77).to(dt)
     eps = 1e-5
