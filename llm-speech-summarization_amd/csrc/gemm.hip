@@ -175,7 +175,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // The features of a launch are uniform, but tested per row pass they leave ~10 scalar branches in each pass and the compiler
 // cannot move the LDS read of pass t+1 over them (one block per CU: the epilogue is an exposed tail of every tile).  F fixes
 // them at compile time for the forms the encoder / prefill / KD launches use; EPI_GENERIC keeps every test at run time.
-enum : int { EPI_GENERIC = 1, EPI_RES = 2, EPI_LN = 4, EPI_STATS = 8 };
+enum : int { EPI_GENERIC = 1, EPI_RES = 2, EPI_LN = 4, EPI_STATS = 8, EPI_AUX = 16 };
 
 template <typename T, int ACT, int MT, int F>
 __device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int wz, float* wsm,
@@ -352,7 +352,7 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
 template <int ACT, int F>
 __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8][4], int row_base, int col_base, int lane, int z, int wz, const float2* mr_lds) {
   using T = bf16_t;
-  constexpr bool RES = (F & EPI_RES) != 0, LN = (F & EPI_LN) != 0, ST = (F & EPI_STATS) != 0;
+  constexpr bool RES = (F & EPI_RES) != 0, LN = (F & EPI_LN) != 0, ST = (F & EPI_STATS) != 0, AUX = (F & EPI_AUX) != 0;
   const int64_t co = (int64_t)z * p.sC, ro = (int64_t)z * p.sR;
   const int q = lane >> 4, r = lane & 15;
   int colh[2];
@@ -408,6 +408,9 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
           if constexpr (LN) v2 = __builtin_elementwise_fma(r2, a2, __builtin_elementwise_fma(k2, f32x2_t{uu[h][j], uu[h][j + 1]}, f32x2_t{bc[h][j], bc[h][j + 1]}));
           else v2 = a2 + f32x2_t{bc[h][j], bc[h][j + 1]};
           v[j] = v2[0]; v[j + 1] = v2[1];
+        }
+        if constexpr (AUX) {            // the training forward keeps the pre-activation (after bias), same layout as C
+          if (row < p.M && okh[h]) *(uint4*)((T*)p.aux + co + row * p.ldc + colh[h]) = Vec16<T>::pack(v);
         }
         if constexpr (ACT == SL_ACT_GELU) {
 #pragma unroll
@@ -917,8 +920,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
   if constexpr (SW) {
     const int rb0 = bm * XBM + wm * 128, cb0 = bn * XBN + wn * 64;
     const float2* mrl = mr_s + wm * 128;
-    const bool res = p.res != nullptr, ln = p.ln_mr != nullptr, st = p.stats_out != nullptr;    // launch_tiled admits these four forms only
-    if (ln) tile_epilogue_sw<ACT, EPI_LN>(p, acc, rb0, cb0, lane, z, wz, mrl);
+    const bool res = p.res != nullptr, ln = p.ln_mr != nullptr, st = p.stats_out != nullptr;    // launch_tiled admits these five forms only
+    if (p.aux) tile_epilogue_sw<ACT, EPI_AUX>(p, acc, rb0, cb0, lane, z, wz, mrl);
+    else if (ln) tile_epilogue_sw<ACT, EPI_LN>(p, acc, rb0, cb0, lane, z, wz, mrl);
     else if (st) tile_epilogue_sw<ACT, EPI_RES | EPI_STATS>(p, acc, rb0, cb0, lane, z, wz, mrl);
     else if (res) tile_epilogue_sw<ACT, EPI_RES>(p, acc, rb0, cb0, lane, z, wz, mrl);
     else tile_epilogue_sw<ACT, 0>(p, acc, rb0, cb0, lane, z, wz, mrl);
@@ -1180,11 +1184,12 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
       p.tiles_n = (p.N + XBN - 1) / XBN;
       if constexpr (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL) {
         // swapped-operand form (register epilogue, 16-byte stores): plain bf16 stores on 8-element aligned rows, one of the forms
-        // {bias}, {bias, residual}, {LayerNorm fold}, {bias, residual, row statistics}
+        // {bias}, {bias, residual}, {LayerNorm fold}, {bias, residual, row statistics}, {bias, pre-activation copy}
         const bool al = !(p.N & 7) && !(p.ldc & 7) && !(p.sC & 7) && !((uintptr_t)p.C & 15) &&
                         (!p.res || (!(p.ldr & 7) && !(p.sR & 7) && !((uintptr_t)p.res & 15)));
-        const bool form = !p.ln_mr ? (!p.stats_out || p.res) : (!p.res && !p.stats_out);
-        if (al && form && !p.grp && !p.aux && !p.out_f32 && !p.res_f32 && !p.amax_val && !p.direct_epi && !sl_env().no_swap_epilogue) {
+        const bool form = p.aux ? (!p.ln_mr && !p.stats_out && !p.res && !((uintptr_t)p.aux & 15))        // {bias, pre-activation copy}: the training forward's FFN1
+                                : !p.ln_mr ? (!p.stats_out || p.res) : (!p.res && !p.stats_out);
+        if (al && form && !p.grp && !p.out_f32 && !p.res_f32 && !p.amax_val && !p.direct_epi && !sl_env().no_swap_epilogue) {
           hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT, true>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
           SL_CHECK_LAUNCH("gemm_tiled256 (swapped operands)");
           return 0;

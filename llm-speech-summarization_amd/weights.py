@@ -365,7 +365,7 @@ class HubertDeviceWeights:
             return dst
 
         self._populate(sd, dev, None)
-        build_layernorm_fold(self)
+        self.fold_stale = True          # the LayerNorm-folded copies follow lazily, at the next inference-mode encode
 
     def _populate(self, sd, dev, by_ptr) -> None:
         arch, dtype, llm_dim = self.arch, self.dtype, self.llm_dim
@@ -686,7 +686,7 @@ class WhisperDeviceWeights:
             return dst
 
         self._populate(sd, dev, None)
-        build_layernorm_fold(self)
+        self.fold_stale = True          # the LayerNorm-folded copies follow lazily, at the next inference-mode encode
 
     def _populate(self, sd, dev, by_ptr) -> None:
         arch, dtype, llm_dim = self.arch, self.dtype, self.llm_dim

@@ -876,7 +876,9 @@ def test_gemm_swapped_operand_epilogue_equals_lds_turned_rows_epilogue(M, N, K, 
         outs = [ops.gemm(Ad, Wd, bias=bd), ops.gemm(Ad, Wd, bias=bd, act=L.ACT_GELU), ops.gemm(Ad, Wd, bias=bd, residual=Rd), ops.gemm(Ad, Wd)]
         o2 = torch.empty((2, M // 2, N), device=dev(), dtype=dt)
         ops.gemm_ex(Ad, Wd, M=M // 2, N=N, K=K, lda=K, ldw=K, out=o2, ldc=N, bias=bd, batch=2, strideA=(M // 2) * K, strideC=(M // 2) * N)
-        return outs + [o2]
+        o3, pre = torch.empty((M, N), device=dev(), dtype=dt), torch.empty((M, N), device=dev(), dtype=dt)
+        ops.gemm_ex(Ad, Wd, M=M, N=N, K=K, lda=K, ldw=K, out=o3, bias=bd, act=L.ACT_GELU, aux_out=pre)      # the training forward's FFN1: result + pre-activation
+        return outs + [o2, o3, pre]
 
     swapped = run()
     tuning("SL_NO_SWAP_EPILOGUE", "1")
@@ -886,6 +888,7 @@ def test_gemm_swapped_operand_epilogue_equals_lds_turned_rows_epilogue(M, N, K, 
     ref = F.gelu(q(A, dt) @ q(W, dt).T + q(b, dt))
     assert rel_err(swapped[1].float().cpu(), ref) < TOL[dt]
     assert torch.equal(swapped[4].view(-1, N)[: 2 * (M // 2)], swapped[0][: 2 * (M // 2)])
+    assert torch.equal(swapped[5], swapped[1]) and torch.equal(swapped[6], swapped[0])        # GELU output / pre-activation = the bias-only product
 
 
 def test_gemm_layernorm_fold_is_bit_identical_across_tile_kernels(tuning):
