@@ -398,6 +398,7 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
         k2 = f32x2_t{nk, nk}; r2 = f32x2_t{mrt.y, mrt.y};
       }
       float la[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, lq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // [h][4-column leaf]: sums, sums of squares
+      uint4 pkh[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float v[8];
@@ -423,8 +424,8 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
           for (int j = 0; j < 8; ++j) v[j] += rr[j];
         }
         const uint4 pk = Vec16<T>::pack(v);
+        pkh[h] = pk;
         if (row < p.M && okh[h]) {
-          *(uint4*)((T*)p.C + co + row * p.ldc + colh[h]) = pk;       // (non-temporal stores: 0.89 x at N = K = 1024 without residual, 1.00-1.04 x on every encoder shape)
           if constexpr (ST) {             // statistics of the values as stored (the packed halves shifted back up), per 4-column leaf
             const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};   // exactly as the rows epilogue forms them: the tree below is its tree
 #pragma unroll
@@ -437,6 +438,29 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
             }
           }
         }
+      }
+      {
+        // Stores.  As computed, an instruction would put 64 bytes into each of 16 rows — 16 half-written 128-byte lines; a CU's store
+        // path takes ~4 clocks per line touched whatever it carries (tools/probe_store_rate.hip, one CU storing alone: a 128 KiB tile in
+        // 3.47 us that way, 1.23 us as 8 full lines per instruction, 1.84 us as the LDS-turned epilogue's 4 lines of 8-byte pieces).
+        // So lanes r and r + 8 of a DPP row trade halves first (row_ror:8): the lower eight lanes then hold the left 64 bytes of rows
+        // r and r + 8, the upper eight the right 64 bytes of rows r - 8 and r, and each of the two instructions writes eight whole lines.
+        const bool lo = r < 8;
+        const uint32_t a0[4] = {pkh[0].x, pkh[0].y, pkh[0].z, pkh[0].w}, a1[4] = {pkh[1].x, pkh[1].y, pkh[1].z, pkh[1].w};
+        uint32_t e1[4], e2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {       // component-wise selects: an indexed pick between the two vectors goes through scratch memory
+          const uint32_t send = lo ? a1[j] : a0[j];
+          const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xf, 0xf, false);
+          e1[j] = lo ? a0[j] : recv;
+          e2[j] = lo ? recv : a1[j];
+        }
+        const uint4 d1 = make_uint4(e1[0], e1[1], e1[2], e1[3]), d2 = make_uint4(e2[0], e2[1], e2[2], e2[3]);
+        const int64_t row1 = row_base + m * 16 + (r & 7), row2 = row1 + 8;
+        const int colx = lo ? colh[0] : colh[1];
+        const bool okx = lo ? okh[0] : okh[1];
+        if (row1 < p.M && okx) *(uint4*)((T*)p.C + co + row1 * p.ldc + colx) = d1;       // (non-temporal stores: 0.89 x at N = K = 1024 without residual, 1.00-1.04 x on every encoder shape)
+        if (row2 < p.M && okx) *(uint4*)((T*)p.C + co + row2 * p.ldc + colx) = d2;
       }
       if constexpr (ST) {   // leaves 2q, 2q + 1 (h = 0) and 2q + 8, 2q + 9 (h = 1) of the row's 16: the first level of the 16-lane tree is in-lane
         s1[m][0] = la[0][0] + la[1][0]; s1[m][1] = la[0][1] + la[1][1];
