@@ -823,6 +823,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 // K = 1024..8192: the vmcnt(0) that admits the prefetched slab also drains the epilogue's stores (one counter on gfx9).
 // Round 3, again with the register epilogue of the swapped-operand form (no LDS in the epilogue, the K slabs of consecutive tiles as
 // one double-buffered stream, scalar tile bases): 0.97-1.02 x on the encoder shapes (tools/time_fold_epilogue.py); removed again.
+// A second build with one epilogue form per instantiation (0-44 bytes of spills instead of 20-96): QKV 748-761 vs 770 us, out_proj
+// 300 vs 306-309, FFN1 + GELU 1 134 vs 1 131, FFN2 equal, the LayerNorm-fold forms 3 % slower — the 3-6 us per tile that in-kernel
+// stamps show between a block's last store and its successor's first product do not turn into throughput; removed again.
 // Where the time goes (127744 x 4096 x 1024, bias + GELU, 1180 us): product loop alone 820-845 us (1.27-1.3 PF/s), epilogue
 // arithmetic without its stores +45 us, the stores +170..290 us — 128 KiB per tile leave a CU at ~24 GB/s, and neither spreading
 // the first-round blocks of an XCD over a tile time nor a block that outlives its tile changes that.
