@@ -51,6 +51,7 @@ static const SlEnv* env_load() {
   e.disable_t256 = getenv("SL_DISABLE_T256") != nullptr;
   e.t256_min_tiles = env_int("SL_T256_MIN_TILES", 512);
   e.t256_min_k = env_int("SL_T256_MIN_K", 1024);
+  e.t256_phased = env_int("SL_T256_PHASED", 1);
   const char* g = getenv("SL_DISABLE_GLDS");
   e.disable_glds = (g && g[0] == '1') ? 1 : ((g && g[0] == '2') ? 2 : 0);
   e.direct_epilogue = env_int("SL_DIRECT_EPILOGUE", 0);

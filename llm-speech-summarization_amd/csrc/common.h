@@ -209,6 +209,7 @@ struct SlEnv {
   int disable_t256;        // SL_DISABLE_T256
   int t256_min_tiles;      // SL_T256_MIN_TILES    (default 512)
   int t256_min_k;          // SL_T256_MIN_K        (default 1024)
+  int t256_phased;         // SL_T256_PHASED       1 (default) = the 256-tile GEMM runs the staggered 4-phase main loop, 0 = the round-3 one-barrier-per-slab loop (A/B), 6 = phased with 6 pieces of lead
   int disable_glds;        // SL_DISABLE_GLDS      0 / 1 / 2
   int direct_epilogue;     // SL_DIRECT_EPILOGUE
   int gemm_gm;             // SL_GEMM_GM           (default 8)

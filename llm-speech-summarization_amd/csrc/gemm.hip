@@ -964,6 +964,228 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// 256 x 256 tile, staggered 4-phase main loop (round 4).  Same tile, wave grid (2 x 4 waves of 128 x 64), fragment layouts and
+// epilogues as gemm_tiled256_kernel; what changes is how a K slab of 64 bytes per row moves through the block:
+//   * the slab is cut into four 16 KiB PIECES in the order the waves need them — PA0 (A rows of the waves' upper 64 x 64 halves),
+//     PB0 (W rows of the waves' left 32 columns), PB1 (right 32 columns), PA1 (lower halves) — and a wave's 128 x 64 output into
+//     four 64 x 32 quadrants, one per PHASE: (0,0) reads PA0 + PB0 into registers, (0,1) reads PB1, (1,1) reads PA1, (1,0) reads
+//     nothing (PB0's fragments are kept).  A phase = {fragment reads, DMA of ONE piece LEAD pieces ahead, counted vmcnt, barrier,
+//     16 MFMAs, barrier}: the DMA stays in flight across barriers (never vmcnt(0) in the steady loop), eight LDS slots.
+//   * waves 4-7 (the lower 128 rows) run ONE BARRIER behind waves 0-3: while one wave of a SIMD issues its 16 MFMAs its partner
+//     issues its reads and its DMA, so the matrix pipe of a SIMD always has a wave to draw from (in the one-barrier-per-slab loop
+//     all eight waves read together and multiply together: MFMA busy 0.40-0.49).
+// Ordering (guide §5 "Read a staged buffer one phase AFTER the wait that retires it"): piece n is issued in phase n - LEAD, its
+// vmcnt wait sits in phase n - 2 in front of that phase's first barrier (both halves of the block have waited once the lagging
+// half's barrier of that phase is passed), it is first read in phase n - 1 or n, last read in phase n, and its slot is re-filled by
+// piece n + 8 in phase n + 8 - LEAD >= n + 2 — so LEAD is 5 or 6.  The lagging half's fragment reads of its last phase are still
+// in flight when the leading half leaves the loop: that half passes one more barrier before the epilogue touches LDS.
+// ----------------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ void lds_rd(u32x4_t& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void vm_wait_pieces(int n_out) {   // n_out pieces (two DMAs each per wave) may stay in flight; uniform
+  switch (n_out) {
+    case 0: vm_wait<0>(); break;
+    case 1: vm_wait<2>(); break;
+    case 2: vm_wait<4>(); break;
+    case 3: vm_wait<6>(); break;
+    default: vm_wait<8>(); break;
+  }
+}
+
+template <typename T, int ACT, bool SW = false, int LEAD = 5>
+__global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
+  static_assert(!SW || (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL), "the swapped-operand form is the bf16 store epilogue");
+  static_assert(LEAD == 5 || LEAD == 6, "see the ordering note");
+  constexpr int VEC = Vec16<T>::VEC;
+  constexpr int BK = TROWB / (int)sizeof(T);
+  constexpr int PIECE = 128 * TROWB;            // 16 KiB
+  // one LDS object (a second one beside an LDS-DMA target can cost a vmcnt(0) per k-step, guide §5 item 4a): 8 piece slots + {mean, rstd}
+  __shared__ __attribute__((aligned(16))) unsigned char smem[8 * PIECE + XBM * 8];
+  float2* mr_s = (float2*)(smem + 8 * PIECE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  int bm, bn;   // XCD patches of tiles as in gemm_tiled256_kernel
+  {
+    const int GM = p.gm;
+    const int per = GM * p.tiles_n, grp = bid / per, first = grp * GM;
+    const int gsz = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
+    const int in = bid - grp * per;
+    bm = first + in % gsz;
+    bn = in / gsz;
+  }
+  const int z = blockIdx.y;
+  int64_t a_off; int wz;
+  if (!resolve_group(p, z, bm, a_off, wz, XBM)) return;
+  const T* A = (const T*)p.A + a_off;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW + p.wx;
+  if (p.grp_ext && bn * XBN >= p.N) return;
+
+  // staging: LDS chunk c = tid + 512 i of a piece sits at (piece row c >> 3, physical chunk c & 7) and holds the logical chunk
+  // (c & 7) ^ key(piece row).  Piece rows: A pieces = [half of the block 0/1][64 rows], W pieces = [wave column 0..3][32 rows].
+  const T* gp[4][2];     // [PA0, PB0, PB1, PA1][i]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 512 * i, rho = c >> 3, pc = c & 7;
+    const int cha = pc ^ (rho & 7);
+    const int chw = SW ? pc ^ ((rho & 3) | (((rho >> 3) & 1) << 2)) : cha;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ar = bm * XBM + (rho >> 6) * 128 + h * 64 + (rho & 63); ar = ar < p.M ? ar : p.M - 1;
+      int wr = bn * XBN + (rho >> 5) * 64 + h * 32 + (rho & 31); wr = wr < p.N ? wr : p.N - 1;
+      gp[h ? 3 : 0][i] = A + (int64_t)ar * p.lda + cha * VEC;
+      gp[h ? 2 : 1][i] = W + (int64_t)wr * p.ldw + chw * VEC;
+    }
+  }
+  const int nkt = p.K / BK, NP = 4 * nkt;
+  // piece n = 4 * tile + kind goes to slot n & 7
+  auto issue = [&](int n, int kind) {
+    const int64_t k0 = (int64_t)(n >> 2) * BK;
+    unsigned char* dst = smem + (n & 7) * PIECE + wave * 1024;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gp[kind][0] + k0), (lds_ptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gp[kind][1] + k0), (lds_ptr_t)(dst + 8192), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (sizeof(T) == 2 && p.ln_mr && tid < XBM) {   // LayerNorm fold: this tile's {mean, rstd} pairs wait in LDS for the epilogue
+    int row = bm * XBM + tid;                     // (before the first DMA: the compiler drains vmcnt for this load's use)
+    row = row < p.M ? row : p.M - 1;
+    mr_s[tid] = ((const float2*)p.ln_mr)[row];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < LEAD; ++n)
+    if (n < NP) issue(n, n & 3);
+  {
+    const int last = (LEAD - 1) < (NP - 1) ? (LEAD - 1) : (NP - 1);
+    vm_wait_pieces(last - 1 > 0 ? last - 1 : 0);       // pieces 0 and 1 have landed
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();           // the lower half of the block runs one barrier behind
+
+  const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  const uint32_t ra0 = sb + (uint32_t)((wm * 64 + r) * TROWB);
+  const uint32_t rb0 = sb + (uint32_t)((wn * 32 + (SW ? 8 * (r >> 2) + (r & 3) : r)) * TROWB);
+  const uint32_t ka = (uint32_t)(r & 7), kw = SW ? (uint32_t)((r & 3) | (((r >> 2) & 1) << 2)) : ka;
+  const uint32_t xa0 = ((uint32_t)q ^ ka) << 4, xa1 = ((uint32_t)(4 + q) ^ ka) << 4;
+  const uint32_t xw0 = ((uint32_t)q ^ kw) << 4, xw1 = ((uint32_t)(4 + q) ^ kw) << 4;
+  constexpr int BN1 = SW ? 512 : 2048;               // second W fragment of a 32-column half: +4 rows (swapped form) / +16 rows
+
+  u32x4_t a[8], b0[4], b1[4];                        // a[4 s + m'], b[2 s + n']
+
+  auto rd_a = [&](uint32_t base) {                   // base = address of the piece's row (wm * 64 + r)
+    lds_rd<0>(a[0], base + xa0); lds_rd<2048>(a[1], base + xa0); lds_rd<4096>(a[2], base + xa0); lds_rd<6144>(a[3], base + xa0);
+    lds_rd<0>(a[4], base + xa1); lds_rd<2048>(a[5], base + xa1); lds_rd<4096>(a[6], base + xa1); lds_rd<6144>(a[7], base + xa1);
+  };
+  auto rd_b = [&](u32x4_t (&b)[4], uint32_t base) {
+    lds_rd<0>(b[0], base + xw0); lds_rd<BN1>(b[1], base + xw0);
+    lds_rd<0>(b[2], base + xw1); lds_rd<BN1>(b[3], base + xw1);
+  };
+  auto mma_q = [&](int mi, int nj, u32x4_t (&b)[4]) {     // quadrant (mi, nj): 16 MFMAs, both 64-byte k-steps
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          if constexpr (SW) MMA<T>::step(acc[mi * 4 + m][nj * 2 + n], as_uint4(b[2 * s + n]), as_uint4(a[4 * s + m]));
+          else MMA<T>::step(acc[mi * 4 + m][nj * 2 + n], as_uint4(a[4 * s + m]), as_uint4(b[2 * s + n]));
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // the second half of a phase's load segment: DMA of piece p + LEAD, the wait that retires piece p + 2, the barrier
+  auto stage = [&](int ph, int kind, bool steady) {
+    if (steady) {
+      issue(ph + LEAD, kind);
+      vm_wait<2 * (LEAD - 2)>();
+    } else {
+      if (ph + LEAD < NP) issue(ph + LEAD, kind);
+      const int last = (ph + LEAD) < (NP - 1) ? (ph + LEAD) : (NP - 1);
+      vm_wait_pieces(last - (ph + 2) > 0 ? last - (ph + 2) : 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  auto tile = [&](int t, bool steady) {
+    const uint32_t bo = (uint32_t)(t & 1) * (4 * PIECE);
+    const int p0 = 4 * t;
+    // phase 0: quadrant (0, 0)
+    rd_b(b0, rb0 + bo + 1 * PIECE);
+    rd_a(ra0 + bo + 0 * PIECE);
+    stage(p0 + 0, (0 + LEAD) & 3, steady);
+    lds_wait8<0>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+    lds_wait8<0>(b0[0], b0[1], b0[2], b0[3], a[0], a[1], a[2], a[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_q(0, 0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // phase 1: quadrant (0, 1)
+    rd_b(b1, rb0 + bo + 2 * PIECE);
+    stage(p0 + 1, (1 + LEAD) & 3, steady);
+    lds_wait8<0>(b1[0], b1[1], b1[2], b1[3], a[0], a[1], a[2], a[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_q(0, 1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // phase 2: quadrant (1, 1)
+    rd_a(ra0 + bo + 3 * PIECE);
+    stage(p0 + 2, (2 + LEAD) & 3, steady);
+    lds_wait8<0>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_q(1, 1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // phase 3: quadrant (1, 0), operands already in registers
+    stage(p0 + 3, (3 + LEAD) & 3, steady);
+    mma_q(1, 0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  const int nsteady = nkt - 2;
+  int t = 0;
+  for (; t < nsteady; ++t) tile(t, true);
+  for (; t < nkt; ++t) tile(t, false);
+  if (wm == 0) __builtin_amdgcn_s_barrier();           // the lagging half's last fragment reads are retired behind this one
+
+  if constexpr (SW) {
+    const int rb0_ = bm * XBM + wm * 128, cb0 = bn * XBN + wn * 64;
+    const float2* mrl = mr_s + wm * 128;
+    const bool res = p.res != nullptr, ln = p.ln_mr != nullptr, st = p.stats_out != nullptr;    // launch_tiled admits these five forms only
+    if (p.aux) tile_epilogue_sw<ACT, EPI_AUX>(p, acc, rb0_, cb0, lane, z, wz, mrl);
+    else if (ln) tile_epilogue_sw<ACT, EPI_LN>(p, acc, rb0_, cb0, lane, z, wz, mrl);
+    else if (st) tile_epilogue_sw<ACT, EPI_RES | EPI_STATS>(p, acc, rb0_, cb0, lane, z, wz, mrl);
+    else if (res) tile_epilogue_sw<ACT, EPI_RES>(p, acc, rb0_, cb0, lane, z, wz, mrl);
+    else tile_epilogue_sw<ACT, 0>(p, acc, rb0_, cb0, lane, z, wz, mrl);
+    return;
+  } else {
+    if constexpr (ACT != SL_ACT_SILU_MUL) {
+      // the LDS-turned rows epilogue uses 16 KiB per wave of the piece slots; the leading half may only start once the lagging
+      // half has left the loop too (its MFMAs read registers only, but its scratch is disjoint anyway: wave * 16 KiB)
+      if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)smem + wave * 4096,
+                                                        sizeof(T) == 2 && p.ln_mr ? mr_s + wm * 128 : nullptr)) return;
+    }
+    tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, q, r, z, wz);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // skinny kernel (M <= 16*MT): HBM-bound weight streaming for decode.
 //   block = RF 16-row weight fragments x NW waves; wave w takes 64-byte k-steps w, w+NW, ... with U steps
 //   of loads in flight; W fragments go global -> VGPR -> MFMA (A operand), the M activation rows are the
@@ -1209,6 +1431,7 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
     if ((t256 >= min_tiles || by_rounds) && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
+      const int phased = sl_env().t256_phased;   // 0: round-3 loop (A/B), 6: six pieces of DMA lead, anything else: five
       if constexpr (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL) {
         // swapped-operand form (register epilogue, 16-byte stores): plain bf16 stores on 8-element aligned rows, one of the forms
         // {bias}, {bias, residual}, {LayerNorm fold}, {bias, residual, row statistics}, {bias, pre-activation copy}
@@ -1217,12 +1440,16 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
         const bool form = p.aux ? (!p.ln_mr && !p.stats_out && !p.res && !((uintptr_t)p.aux & 15))        // {bias, pre-activation copy}: the training forward's FFN1
                                 : !p.ln_mr ? (!p.stats_out || p.res) : (!p.res && !p.stats_out);
         if (al && form && !p.grp && !p.out_f32 && !p.res_f32 && !p.amax_val && !p.direct_epi && !sl_env().no_swap_epilogue) {
-          hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT, true>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+          if (phased == 6) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 6>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+          else if (phased) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 5>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+          else hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT, true>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
           SL_CHECK_LAUNCH("gemm_tiled256 (swapped operands)");
           return 0;
         }
       }
-      hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+      if (phased == 6) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, false, 6>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+      else if (phased) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, false, 5>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
       SL_CHECK_LAUNCH("gemm_tiled256");
       return 0;
     }

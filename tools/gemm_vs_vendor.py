@@ -1,0 +1,80 @@
+"""Tiled GEMM against the vendor library (torch.nn.functional.linear = hipBLASLt) on the shapes the three legs run:
+the KD-window rows of profiles/r03_i_tile_choice_sweep.txt, the four encoder products at 127 744 rows and the prefill
+products at 140 288 rows.  Random bf16 operands, all variants interleaved in ONE process (guide §5.4 rule 24), median of the
+rounds; every variant's result is checked against the fp32 product first.
+
+    python tools/gemm_vs_vendor.py [--rounds 5] [--quick]
+
+Variants: r3 = round-3 loop (SL_T256_PHASED=0), p5 / p6 = staggered 4-phase loop with 5 / 6 pieces of DMA lead, vendor."""
+import argparse, importlib, os, statistics, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ops = importlib.import_module("llm-speech-summarization_amd.ops")
+L = importlib.import_module("llm-speech-summarization_amd._lib")
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--quick", action="store_true")
+ap.add_argument("--variants", default="r3,p5,p6,vendor")
+args = ap.parse_args()
+dev = "cuda:0"
+
+shapes = []
+for M in (7984, 3200, 5072, 1872):
+    enc = M == 7984
+    for N, K in (((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)) if enc else ((5120, 3072), (3072, 3072), (16384, 3072), (3072, 8192))):
+        shapes.append((M, N, K))
+shapes += [(3200, 3072, 1024), (3200, 4096, 1024), (3200, 1024, 4096)]
+big = [(127744, 3072, 1024), (127744, 1024, 1024), (127744, 4096, 1024), (127744, 1024, 4096), (140288, 5120, 3072), (140288, 3072, 8192),
+       (70144, 16384, 3072)]
+if args.quick:
+    shapes = [(7984, 3072, 1024), (5072, 5120, 3072), (3200, 3072, 3072)]
+    big = [(127744, 3072, 1024), (127744, 1024, 4096), (140288, 5120, 3072)]
+shapes = big + shapes
+variants = args.variants.split(",")
+
+
+def set_variant(v):
+    if v == "vendor":
+        return
+    os.environ["SL_T256_PHASED"] = {"r3": "0", "p5": "1", "p6": "6"}[v]
+    L.lib().sl_tuning_reload()
+
+
+print(f"{'shape':>26} " + "".join(f"{v:>9}" for v in variants) + "   best/vendor   (TF/s, median of %d rounds)" % args.rounds, flush=True)
+worst = 10.0
+for M, N, K in shapes:
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    Ws = [(torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16) for _ in range(3)]
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    # correctness of every variant on a row sample (the fp32 product of the whole thing is too big at 140 k rows)
+    idx = torch.randint(0, M, (512,), device=dev)
+    ref = A[idx].float() @ Ws[0].float().T
+    for v in variants:
+        if v == "vendor":
+            continue
+        set_variant(v)
+        out.zero_()
+        ops.gemm(A, Ws[0], out=out)
+        err = float((out[idx].float() - ref).norm() / ref.norm())
+        assert err < 6e-3, (M, N, K, v, err)
+    n = 6 if M * N * K > 3e11 else 16
+    times = {v: [] for v in variants}
+    for rnd in range(args.rounds + 1):
+        for v in variants:
+            set_variant(v)
+            fn = (lambda i: torch.nn.functional.linear(A, Ws[i % 3])) if v == "vendor" else (lambda i: ops.gemm(A, Ws[i % 3], out=out))
+            fn(0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n):
+                fn(i)
+            e1.record(); torch.cuda.synchronize()
+            if rnd:
+                times[v].append(e0.elapsed_time(e1) / n * 1e3)
+    tf = {v: 2.0 * M * N * K / statistics.median(times[v]) / 1e6 for v in variants}
+    ours = max(tf[v] for v in variants if v not in ("vendor", "r3")) if any(v.startswith("p") for v in variants) else tf[variants[0]]
+    ratio = ours / tf["vendor"] if "vendor" in tf else float("nan")
+    worst = min(worst, ratio)
+    print(f"{M:7d} x {N:6d} x {K:5d}  " + "".join(f"{tf[v]:9.0f}" for v in variants) + f"   {ratio:6.3f}", flush=True)
+print(f"worst best/vendor ratio: {worst:.3f}")
+os.environ.pop("SL_T256_PHASED", None)
+L.lib().sl_tuning_reload()
