@@ -52,6 +52,8 @@ static const SlEnv* env_load() {
   e.t256_min_tiles = env_int("SL_T256_MIN_TILES", 512);
   e.t256_min_k = env_int("SL_T256_MIN_K", 1024);
   e.t256_phased = env_int("SL_T256_PHASED", 1);
+  e.gemm_ko = env_int("SL_GEMM_KO", 0);
+  { const char* sp = getenv("SL_GEMM_STAMP_PTR"); e.gemm_stamp_ptr = (sp && sp[0]) ? strtoull(sp, nullptr, 16) : 0ull; }
   const char* g = getenv("SL_DISABLE_GLDS");
   e.disable_glds = (g && g[0] == '1') ? 1 : ((g && g[0] == '2') ? 2 : 0);
   e.direct_epilogue = env_int("SL_DIRECT_EPILOGUE", 0);

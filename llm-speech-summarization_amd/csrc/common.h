@@ -209,7 +209,7 @@ struct SlEnv {
   int disable_t256;        // SL_DISABLE_T256
   int t256_min_tiles;      // SL_T256_MIN_TILES    (default 512)
   int t256_min_k;          // SL_T256_MIN_K        (default 1024)
-  int t256_phased;         // SL_T256_PHASED       1 (default) = the 256-tile GEMM runs the staggered 4-phase main loop, 0 = the round-3 one-barrier-per-slab loop (A/B), 6 = phased with 6 pieces of lead
+  int t256_phased;         // SL_T256_PHASED       1 (default) = the 256-tile GEMM runs the staggered two-phase main loop, 0 = the round-3 one-barrier-per-slab loop (A/B)
   int disable_glds;        // SL_DISABLE_GLDS      0 / 1 / 2
   int direct_epilogue;     // SL_DIRECT_EPILOGUE
   int gemm_gm;             // SL_GEMM_GM           (default 8)
@@ -223,6 +223,9 @@ struct SlEnv {
   int no_wgrad_stream;     // SL_NO_WGRAD_STREAM   1 = the encoder backward keeps its parameter-gradient products on the caller's stream (A/B)
   int gemm_log;            // SL_GEMM_LOG          1 = every sl_gemm* call prints its shape and flags on stderr (shape census for tuning)
   int no_swap_epilogue;    // SL_NO_SWAP_EPILOGUE  1 = the 256-tile GEMM keeps the LDS-turned rows epilogue where the swapped-operand form applies (A/B)
+  int gemm_ko;             // SL_GEMM_KO           debug builds (-DSL_GEMM_DEBUG): knock-out bits of the phased 256-tile GEMM (1 reads, 2 DMA, 4 MFMAs)
+  unsigned long long gemm_stamp_ptr;   // SL_GEMM_STAMP_PTR  device address (hex) of a uint32 buffer: the phased 256-tile GEMM launches its instrumented build and
+                                       // leaves in-kernel cycle stamps there (tools/gemm_stamps.py); 0 = off
   int stream_splits, stream_nwv, stream_mt;   // SL_STREAM_CFG "splits,nwv[,mt]" (0 = not set)
   int stream_wide;         // SL_STREAM_WIDE       0 = never use the 256 x 128 streaming block, 1 = default rule, 2 = whenever it applies
   int stream_wsplits;      // SL_STREAM_WSPLITS    K splits of the 256 x 128 form when its blocks do not cover the CUs (0 = rule)

@@ -964,21 +964,29 @@ __global__ __launch_bounds__(512, 1) void gemm_tiled256_kernel(GemmP p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// 256 x 256 tile, staggered 4-phase main loop (round 4).  Same tile, wave grid (2 x 4 waves of 128 x 64), fragment layouts and
+// 256 x 256 tile, staggered two-phase main loop (round 4).  Same tile, wave grid (2 x 4 waves of 128 x 64), fragment layouts and
 // epilogues as gemm_tiled256_kernel; what changes is how a K slab of 64 bytes per row moves through the block:
-//   * the slab is cut into four 16 KiB PIECES in the order the waves need them — PA0 (A rows of the waves' upper 64 x 64 halves),
-//     PB0 (W rows of the waves' left 32 columns), PB1 (right 32 columns), PA1 (lower halves) — and a wave's 128 x 64 output into
-//     four 64 x 32 quadrants, one per PHASE: (0,0) reads PA0 + PB0 into registers, (0,1) reads PB1, (1,1) reads PA1, (1,0) reads
-//     nothing (PB0's fragments are kept).  A phase = {fragment reads, DMA of ONE piece LEAD pieces ahead, counted vmcnt, barrier,
-//     16 MFMAs, barrier}: the DMA stays in flight across barriers (never vmcnt(0) in the steady loop), eight LDS slots.
-//   * waves 4-7 (the lower 128 rows) run ONE BARRIER behind waves 0-3: while one wave of a SIMD issues its 16 MFMAs its partner
+//   * the slab is cut into four 16 KiB PIECES — PA0 (A rows of the waves' upper 64 x 64 halves), PB0 (W rows of the waves' left 32
+//     columns), PB1 (right 32 columns), PA1 (lower halves) — and a wave's 128 x 64 output into an upper and a lower 64 x 64 half,
+//     one per PHASE: the upper phase reads PA0 + PB0 + PB1 into registers (16 ds_read_b128), the lower one PA1 (8; W's fragments
+//     are kept).  A phase = {fragment reads, DMA of the two pieces 6 and 7 pieces ahead, counted vmcnt, lgkmcnt(0), barrier,
+//     32 MFMAs, barrier}: the DMA stays in flight across barriers (never vmcnt(0) in the steady loop), eight LDS slots.
+//   * waves 4-7 (the lower 128 rows) run ONE BARRIER behind waves 0-3: while one wave of a SIMD issues its 32 MFMAs its partner
 //     issues its reads and its DMA, so the matrix pipe of a SIMD always has a wave to draw from (in the one-barrier-per-slab loop
 //     all eight waves read together and multiply together: MFMA busy 0.40-0.49).
-// Ordering (guide §5 "Read a staged buffer one phase AFTER the wait that retires it"): piece n is issued in phase n - LEAD, its
-// vmcnt wait sits in phase n - 2 in front of that phase's first barrier (both halves of the block have waited once the lagging
-// half's barrier of that phase is passed), it is first read in phase n - 1 or n, last read in phase n, and its slot is re-filled by
-// piece n + 8 in phase n + 8 - LEAD >= n + 2 — so LEAD is 5 or 6.  The lagging half's fragment reads of its last phase are still
-// in flight when the leading half leaves the loop: that half passes one more barrier before the epilogue touches LDS.
+// Ordering (guide §5 "Read a staged buffer one phase AFTER the wait that retires it"): phase P issues pieces 2P + 6 and 2P + 7 and
+// waits until piece 2P + 4 has landed (vmcnt(6): three pieces stay in flight); both halves of the block have made that wait once
+// the lagging half's first barrier of phase P is passed, and the pieces of phase P + 1 (4t .. 4t + 2 for an upper phase 2t) are
+// read behind it.  A slot is re-filled (piece n + 8, phase (n >> 1) + 1) one phase after its last read; that is enough because every
+// wave retires its fragment reads (lgkmcnt(0)) in FRONT of the phase's first barrier.  The lagging half's MFMAs of its last phase
+// are still running when the leading half leaves the loop: that half passes one more barrier before the epilogue touches LDS.
+// What was measured on the way (profiles/r04_b_*.txt, tools/gemm_knockout.py, tools/gemm_qvar.py — MI355X, random bf16):
+//   four phases of 16 MFMAs (the first form of this loop)   1 311-1 365 TF/s on 140 288 x 5 120 x 3 072 (round-3 loop 1 212, vendor 1 396-1 440)
+//   knock-outs of that form: MFMAs + barriers alone 2 154 us, reads + DMA + barriers alone 2 010 us (= 67 GB/s per CU, the rate a CU
+//     pulls from L2 when every CU streams: a 256^2 tile needs 64 KiB per 2 048 MFMA cycles = 32 B/clk), both 3 461 us: the loop is
+//     bound by how well two equal costs overlap, and the eight barriers of a slab cost the matrix pipe ~56 cycles each
+//   reads rebalanced 8/4/8/4 (next slab's W fragments early), DMA lead 5 / 7 / 8 pieces, no s_setprio: -13 .. +3 %
+//   two phases of 32 MFMAs (half the barriers)              +3-6 %;  and without s_setprio around the clusters  +1-3 % more  <- this loop
 // ----------------------------------------------------------------------------------------------
 template <int OFF>
 __device__ __forceinline__ void lds_rd(u32x4_t& d, uint32_t addr) {
@@ -990,15 +998,16 @@ __device__ __forceinline__ void vm_wait_pieces(int n_out) {   // n_out pieces (t
     case 0: vm_wait<0>(); break;
     case 1: vm_wait<2>(); break;
     case 2: vm_wait<4>(); break;
-    case 3: vm_wait<6>(); break;
-    default: vm_wait<8>(); break;
+    default: vm_wait<6>(); break;
   }
 }
 
-template <typename T, int ACT, bool SW = false, int LEAD = 5>
+// DBG (debug builds only, -DSL_GEMM_DEBUG): 8 = cycle stamps; knock-outs 1 = no fragment reads, 2 = no DMA, 4 = no MFMAs (results are then
+// meaningless: timing experiments, tools/gemm_knockout.py)
+template <typename T, int ACT, bool SW = false, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
+  constexpr bool STAMP = (DBG & 8) != 0, KO_RD = (DBG & 1) != 0, KO_DMA = (DBG & 2) != 0, KO_MMA = (DBG & 4) != 0;
   static_assert(!SW || (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL), "the swapped-operand form is the bf16 store epilogue");
-  static_assert(LEAD == 5 || LEAD == 6, "see the ordering note");
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int BK = TROWB / (int)sizeof(T);
   constexpr int PIECE = 128 * TROWB;            // 16 KiB
@@ -1008,6 +1017,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // instrumented build: lane 0 of waves 0 and 4 drops the low word of s_memtime into the {mean, rstd} area (unused without the fold),
+  // copied out after the loop — no VMEM traffic, so the counted vmcnt waits are undisturbed
+  auto stamp = [&](int i) {
+    if constexpr (STAMP) {
+      if ((wave & 3) == 0 && lane == 0) ((uint32_t*)mr_s)[(wave >> 2) * 32 + i] = (uint32_t)__builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp(0);
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, q = lane >> 4;
   const int nt = p.tiles_m * p.tiles_n;
@@ -1049,8 +1066,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
     }
   }
   const int nkt = p.K / BK, NP = 4 * nkt;
-  // piece n = 4 * tile + kind goes to slot n & 7
+  // piece n = 4 * slab + kind goes to slot n & 7
   auto issue = [&](int n, int kind) {
+    if constexpr (KO_DMA) return;
     const int64_t k0 = (int64_t)(n >> 2) * BK;
     unsigned char* dst = smem + (n & 7) * PIECE + wave * 1024;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(gp[kind][0] + k0), (lds_ptr_t)dst, 16, 0, 0);
@@ -1070,11 +1088,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int n = 0; n < LEAD; ++n)
+  for (int n = 0; n < 6; ++n)
     if (n < NP) issue(n, n & 3);
   {
-    const int last = (LEAD - 1) < (NP - 1) ? (LEAD - 1) : (NP - 1);
-    vm_wait_pieces(last - 1 > 0 ? last - 1 : 0);       // pieces 0 and 1 have landed
+    const int last = 5 < (NP - 1) ? 5 : (NP - 1);
+    vm_wait_pieces(last - 2 > 0 ? last - 2 : 0);        // pieces 0, 1, 2 have landed
   }
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();           // the lower half of the block runs one barrier behind
@@ -1088,17 +1106,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
   constexpr int BN1 = SW ? 512 : 2048;               // second W fragment of a 32-column half: +4 rows (swapped form) / +16 rows
 
   u32x4_t a[8], b0[4], b1[4];                        // a[4 s + m'], b[2 s + n']
+  if constexpr (KO_RD) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = u32x4_t{0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(a[i])); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b0[i] = a[i]; b1[i] = a[4 + i]; asm volatile("" : "+v"(b0[i]), "+v"(b1[i])); }
+  }
 
   auto rd_a = [&](uint32_t base) {                   // base = address of the piece's row (wm * 64 + r)
+    if constexpr (KO_RD) return;
     lds_rd<0>(a[0], base + xa0); lds_rd<2048>(a[1], base + xa0); lds_rd<4096>(a[2], base + xa0); lds_rd<6144>(a[3], base + xa0);
     lds_rd<0>(a[4], base + xa1); lds_rd<2048>(a[5], base + xa1); lds_rd<4096>(a[6], base + xa1); lds_rd<6144>(a[7], base + xa1);
   };
   auto rd_b = [&](u32x4_t (&b)[4], uint32_t base) {
+    if constexpr (KO_RD) return;
     lds_rd<0>(b[0], base + xw0); lds_rd<BN1>(b[1], base + xw0);
     lds_rd<0>(b[2], base + xw1); lds_rd<BN1>(b[3], base + xw1);
   };
   auto mma_q = [&](int mi, int nj, u32x4_t (&b)[4]) {     // quadrant (mi, nj): 16 MFMAs, both 64-byte k-steps
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (KO_MMA) { asm volatile("" : "+v"(a[0]), "+v"(b[0])); return; }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1108,61 +1134,63 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
           if constexpr (SW) MMA<T>::step(acc[mi * 4 + m][nj * 2 + n], as_uint4(b[2 * s + n]), as_uint4(a[4 * s + m]));
           else MMA<T>::step(acc[mi * 4 + m][nj * 2 + n], as_uint4(a[4 * s + m]), as_uint4(b[2 * s + n]));
         }
-    __builtin_amdgcn_s_setprio(0);
   };
-  // the second half of a phase's load segment: DMA of piece p + LEAD, the wait that retires piece p + 2, the barrier
-  auto stage = [&](int ph, int kind, bool steady) {
+  // the rest of a phase's load segment: DMA of pieces 2P + 6 and 2P + 7, the wait that retires piece 2P + 4, the fragment reads
+  // retired (every fragment register tied to the wait so no MFMA moves above it), the barrier
+  auto stage = [&](int P, bool steady) {
+    const int n0 = 2 * P + 6;
     if (steady) {
-      issue(ph + LEAD, kind);
-      vm_wait<2 * (LEAD - 2)>();
+      issue(n0, n0 & 3); issue(n0 + 1, (n0 + 1) & 3);
+      vm_wait<6>();
     } else {
-      if (ph + LEAD < NP) issue(ph + LEAD, kind);
-      const int last = (ph + LEAD) < (NP - 1) ? (ph + LEAD) : (NP - 1);
-      vm_wait_pieces(last - (ph + 2) > 0 ? last - (ph + 2) : 0);
+      if (n0 < NP) issue(n0, n0 & 3);
+      if (n0 + 1 < NP) issue(n0 + 1, (n0 + 1) & 3);
+      const int last = (n0 + 1) < (NP - 1) ? (n0 + 1) : (NP - 1);
+      vm_wait_pieces(last - (2 * P + 4) > 0 ? last - (2 * P + 4) : 0);
     }
+    lds_wait8<0>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+    lds_wait8<0>(b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
+  auto close = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); };
+  // stamps (instrumented build): slabs 4 and 5, per phase {load segment start, first barrier passed, MFMAs issued} -> entries 2 .. 13
   auto tile = [&](int t, bool steady) {
     const uint32_t bo = (uint32_t)(t & 1) * (4 * PIECE);
-    const int p0 = 4 * t;
-    // phase 0: quadrant (0, 0)
+    const bool st = STAMP && (t == 4 || t == 5);
+    const int sb_ = 2 + (t - 4) * 6;
+    if (st) stamp(sb_ + 0);
     rd_b(b0, rb0 + bo + 1 * PIECE);
     rd_a(ra0 + bo + 0 * PIECE);
-    stage(p0 + 0, (0 + LEAD) & 3, steady);
-    lds_wait8<0>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
-    lds_wait8<0>(b0[0], b0[1], b0[2], b0[3], a[0], a[1], a[2], a[3]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_q(0, 0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase 1: quadrant (0, 1)
     rd_b(b1, rb0 + bo + 2 * PIECE);
-    stage(p0 + 1, (1 + LEAD) & 3, steady);
-    lds_wait8<0>(b1[0], b1[1], b1[2], b1[3], a[0], a[1], a[2], a[3]);
-    __builtin_amdgcn_sched_barrier(0);
+    stage(2 * t, steady);
+    if (st) stamp(sb_ + 1);
+    mma_q(0, 0, b0);
     mma_q(0, 1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase 2: quadrant (1, 1)
+    if (st) stamp(sb_ + 2);
+    close();
+    if (st) stamp(sb_ + 3);
     rd_a(ra0 + bo + 3 * PIECE);
-    stage(p0 + 2, (2 + LEAD) & 3, steady);
-    lds_wait8<0>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
-    __builtin_amdgcn_sched_barrier(0);
+    stage(2 * t + 1, steady);
+    if (st) stamp(sb_ + 4);
     mma_q(1, 1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase 3: quadrant (1, 0), operands already in registers
-    stage(p0 + 3, (3 + LEAD) & 3, steady);
     mma_q(1, 0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (st) stamp(sb_ + 5);
+    close();
   };
-  const int nsteady = nkt - 2;
+  const int nsteady = nkt - 2;                         // slabs whose two phases both issue: 2 (2 t + 1) + 7 <= NP - 1
   int t = 0;
+  stamp(1);
   for (; t < nsteady; ++t) tile(t, true);
   for (; t < nkt; ++t) tile(t, false);
-  if (wm == 0) __builtin_amdgcn_s_barrier();           // the lagging half's last fragment reads are retired behind this one
+  stamp(14);
+  if (wm == 0) __builtin_amdgcn_s_barrier();           // the lagging half's last MFMA segment ends behind this one
+  if constexpr (STAMP) {
+    if ((wave & 3) == 0 && lane < 32 && p.stamp) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      p.stamp[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave >> 2)) * 32 + lane] = ((const uint32_t*)mr_s)[(wave >> 2) * 32 + lane];
+    }
+  }
 
   if constexpr (SW) {
     const int rb0_ = bm * XBM + wm * 128, cb0 = bn * XBN + wn * 64;
@@ -1176,8 +1204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
     return;
   } else {
     if constexpr (ACT != SL_ACT_SILU_MUL) {
-      // the LDS-turned rows epilogue uses 16 KiB per wave of the piece slots; the leading half may only start once the lagging
-      // half has left the loop too (its MFMAs read registers only, but its scratch is disjoint anyway: wave * 16 KiB)
+      // the LDS-turned rows epilogue uses 16 KiB per wave of the piece slots (every DMA has landed: the last phases wait vmcnt(0))
       if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)smem + wave * 4096,
                                                         sizeof(T) == 2 && p.ln_mr ? mr_s + wm * 128 : nullptr)) return;
     }
@@ -1431,7 +1458,7 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
     if ((t256 >= min_tiles || by_rounds) && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
-      const int phased = sl_env().t256_phased;   // 0: round-3 loop (A/B), 6: six pieces of DMA lead, anything else: five
+      const int phased = sl_env().t256_phased;   // 0: round-3 one-barrier-per-slab loop (A/B)
       if constexpr (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL) {
         // swapped-operand form (register epilogue, 16-byte stores): plain bf16 stores on 8-element aligned rows, one of the forms
         // {bias}, {bias, residual}, {LayerNorm fold}, {bias, residual, row statistics}, {bias, pre-activation copy}
@@ -1440,15 +1467,30 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
         const bool form = p.aux ? (!p.ln_mr && !p.stats_out && !p.res && !((uintptr_t)p.aux & 15))        // {bias, pre-activation copy}: the training forward's FFN1
                                 : !p.ln_mr ? (!p.stats_out || p.res) : (!p.res && !p.stats_out);
         if (al && form && !p.grp && !p.out_f32 && !p.res_f32 && !p.amax_val && !p.direct_epi && !sl_env().no_swap_epilogue) {
-          if (phased == 6) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 6>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
-          else if (phased) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 5>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+#ifdef SL_GEMM_DEBUG
+          if constexpr (ACT == SL_ACT_NONE) {       // instrumented / knocked-out builds (tools/gemm_stamps.py, tools/gemm_knockout.py), never in the product .so
+            const int ko = sl_env().gemm_ko;
+            if (phased && !p.ln_mr && (sl_env().gemm_stamp_ptr || ko)) {
+              p.stamp = (uint32_t*)(uintptr_t)sl_env().gemm_stamp_ptr;
+              const dim3 g(p.tiles_m * p.tiles_n, batch);
+              if (p.stamp) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 8>), g, dim3(512), 0, st, p);
+              else if (ko == 1) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 1>), g, dim3(512), 0, st, p);
+              else if (ko == 2) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 2>), g, dim3(512), 0, st, p);
+              else if (ko == 3) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 3>), g, dim3(512), 0, st, p);
+              else if (ko == 4) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 4>), g, dim3(512), 0, st, p);
+              else hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true, 6>), g, dim3(512), 0, st, p);
+              SL_CHECK_LAUNCH("gemm_tiled256 (debug)");
+              return 0;
+            }
+          }
+#endif
+          if (phased) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, true>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
           else hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT, true>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
           SL_CHECK_LAUNCH("gemm_tiled256 (swapped operands)");
           return 0;
         }
       }
-      if (phased == 6) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, false, 6>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
-      else if (phased) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, false, 5>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
+      if (phased) hipLaunchKernelGGL((gemm_tiled256p_kernel<T, ACT, false>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
       else hipLaunchKernelGGL((gemm_tiled256_kernel<T, ACT>), dim3(p.tiles_m * p.tiles_n, batch), dim3(512), 0, st, p);
       SL_CHECK_LAUNCH("gemm_tiled256");
       return 0;
@@ -1577,7 +1619,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
-  p.amax_val = nullptr; p.amax_idx = nullptr; p.ln_mr = nullptr; p.ln_u = nullptr; p.ln_c = nullptr; p.stats_out = nullptr;
+  p.stamp = nullptr; p.amax_val = nullptr; p.amax_idx = nullptr; p.ln_mr = nullptr; p.ln_u = nullptr; p.ln_c = nullptr; p.stats_out = nullptr;
   const int direct_epi = sl_env().direct_epilogue;
   p.direct_epi = direct_epi;
   const int gm_env = sl_env().gemm_gm;

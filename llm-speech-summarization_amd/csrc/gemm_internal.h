@@ -27,6 +27,7 @@ struct GemmP {
   float* stats_out;    // producer: per row and 64-column segment {sum, sum of squares} of the STORED (rounded) values, [row][N / 64][2]
   float* amax_val;     // fused row-wise top-1 (sl_gemm_ex_args.amax_*): per 64-column group g and row m the largest value of
   int* amax_idx;       // columns [64 g, 64 g + 64) at [g][m] and its column index; C is then not written at all
+  uint32_t* stamp;     // instrumented build of the phased 256-tile kernel only: [block][half][32] cycle stamps (SL_GEMM_STAMP_PTR)
 };
 
 // resolve the per-batch descriptor: returns false when this block's tile lies outside batch z's rows
