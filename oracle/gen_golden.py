@@ -503,6 +503,75 @@ def gen_whisper_wide(enc_mod):
          last_hidden_rows=hidden[:, ::24], P=out.shape[1])
 
 
+def _greedy_with_margins(llm, seq, new):
+    """HF greedy generate with per-step scores: ids, top-2 logit margins of every step, and the first step's full logits row."""
+    out = llm.generate(input_ids=None, inputs_embeds=seq, max_new_tokens=new, do_sample=False, output_scores=True, return_dict_in_generate=True)
+    scores = torch.stack(out.scores, dim=1)                       # (1, steps, V): processed scores = raw logits under greedy
+    top2 = scores.topk(2, dim=-1).values
+    return out.sequences, (top2[..., 0] - top2[..., 1]), scores[0, 0]
+
+
+def gen_full_depth(enc_mod, llama_mod, utils):
+    """north_star's literal target at FULL depth, from the reference classes themselves: the reference AudioEncoder on HF
+    HubertModel at HuBERT-large size (24 layers) and the reference AudioLlamaForCausalLM at Llama-3.2-3B size (28 layers, 128 256-way
+    tied head), fp32, seeded random-init weights (`random_init`, so only seeds travel), one 10 s utterance (seed 1234) through
+    generate_audio_response's order of operations (ref:inference.py:95-137): 16 greedy ids, the top-2 margin of every step, the
+    first step's logits (strided) and a strided slice of the audio embeddings.  Second fixture: the Whisper-medium encoder at its
+    full 24 layers (HF feature extractor + reference AudioEncoder, trainer order of operations) in front of the same LLM."""
+    from oracle.llama_oracle import LLAMA32_3B
+    c = LLAMA32_3B
+    new = 16
+    llm, _ = build_ref_llama(llama_mod, c, 3)
+    prefix_ids = ri.synthetic_ids(9, c.vocab_size, seed=7, bos=128000)       # Llama-3 template lengths (tests/golden/tokenizers)
+    suffix_ids = ri.synthetic_ids(6, c.vocab_size, seed=8, bos=128000)
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: prefix_ids, utils.LLAMA_PROMPT_SUFFIX: suffix_ids})
+    with torch.no_grad():
+        enc, _ = build_ref_encoder(enc_mod, HubertCfg(), c.hidden_size, seed=0, method="pool")
+        wave = ri.synthetic_waveform(160000, seed=1234)[None]
+        audio_embeds = enc(wave, ctc_pool_ranges=None)
+        del enc
+        seq = utils.merge_prompt_tokens(inputs_embeds=audio_embeds, tokenizer=tok, embed_tokens=llm.model.embed_tokens, llm_type=LLAMA_ID,
+                                        device=torch.device("cpu"))
+        ids, margins, first = _greedy_with_margins(llm, seq, new)
+        save("full_depth_llama32", enc_seed=0, llm_seed=3, wave_seed=1234, n_samples=160000, prefix_ids=prefix_ids, suffix_ids=suffix_ids,
+             prompt_len=seq.shape[1], ids=ids, margins=margins, first_logits_every16=first[::16], first_logits_top16=first.topk(16).values,
+             first_logits_top16_idx=first.topk(16).indices, audio_embeds_rows=audio_embeds[0, ::8, ::4], audio_embeds_norm=audio_embeds.norm(),
+             P=audio_embeds.shape[1])
+        # Whisper-medium, 24 layers
+        from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperModel
+        from oracle.whisper_oracle import WhisperCfg
+        wc = WhisperCfg()
+        tmp = tempfile.mkdtemp(prefix="whisper_full_")
+        hf_cfg = WhisperConfig(d_model=wc.d_model, encoder_layers=wc.encoder_layers, encoder_attention_heads=wc.encoder_attention_heads,
+                               encoder_ffn_dim=wc.encoder_ffn_dim, num_mel_bins=wc.num_mel_bins, max_source_positions=wc.max_source_positions,
+                               decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64, vocab_size=64, max_target_positions=16,
+                               dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, pad_token_id=0,
+                               bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+        WhisperModel(hf_cfg).save_pretrained(tmp)
+        WhisperFeatureExtractor(feature_size=wc.num_mel_bins, sampling_rate=16000, hop_length=wc.hop_length, chunk_length=30, n_fft=wc.n_fft).save_pretrained(tmp)
+        cfg = SimpleNamespace(model=SimpleNamespace(
+            audio_encoder=SimpleNamespace(base="whisper", type=tmp, downsample_method="pool", downsample_factor=4,
+                                          pooling=SimpleNamespace(kernel_size=8, stride=4)),
+            llm_embedding_channels=c.hidden_size))
+        wenc = enc_mod.AudioEncoder(cfg, torch.device("cpu"))
+        wenc.load_state_dict(ri.whisper_encoder_state_dict(wc, c.hidden_size, seed=93), strict=True)
+        wenc.eval()
+        n = 240000                                                      # 15 s, padded to the 30 s window by the feature extractor
+        wv = ri.synthetic_waveform(n, seed=1718).numpy()
+        feats = wenc.feature_extractor([wv], return_tensors="pt", sampling_rate=16000).input_features
+        padded = wenc(feats)
+        keep = utils.compute_num_audio_embeds(n, sr=16000)               # ref:trainer.py:283-289
+        w_embeds = padded[:, :keep]
+        del wenc
+        seq = utils.merge_prompt_tokens(inputs_embeds=w_embeds, tokenizer=tok, embed_tokens=llm.model.embed_tokens, llm_type=LLAMA_ID,
+                                        device=torch.device("cpu"))
+        ids, margins, first = _greedy_with_margins(llm, seq, new)
+        save("whisper_medium_full", enc_seed=93, llm_seed=3, wave_seed=1718, n_samples=n, prefix_ids=prefix_ids, suffix_ids=suffix_ids,
+             prompt_len=seq.shape[1], num_audio_embeds=keep, ids=ids, margins=margins, first_logits_every16=first[::16],
+             first_logits_top16=first.topk(16).values, first_logits_top16_idx=first.topk(16).indices, audio_embeds_rows=w_embeds[0, ::8, ::4],
+             audio_embeds_norm=w_embeds.norm(), padded_P=padded.shape[1])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -524,6 +593,8 @@ def main():
         gen_coldstart(enc_mod)
     if "whisper_wide" in which:
         gen_whisper_wide(enc_mod)
+    if "full_depth" in which:        # 13 GB of fp32 LLM weights, ~10 minutes on 8 cores: only on request (`python oracle/gen_golden.py full_depth`)
+        gen_full_depth(enc_mod, llama_mod, utils)
 
 
 if __name__ == "__main__":
