@@ -159,8 +159,17 @@ typedef struct {
    *     with {mean, rstd} = ln_mr[2 m], ln_mr[2 m + 1]:  out[m][n] = rstd * ((x W^T)[m][n] - mean * ln_u[n]) + ln_c[n], then act /
    *     residual as usual (bias must be NULL: it is inside ln_c).  Equals Linear(LayerNorm(x)) without the LayerNorm pass over x. */
   const float* ln_mr; const float* ln_u; const float* ln_c; float* stats_out;
+  /* Stream-K workspace (optional).  Products whose 256 x 256 output tiles do not fill the chip evenly — the KD step's windows of a few
+   * thousand rows (ref:trainer.py:270-384 at grad_accum_interval 16), its per-rank share under data parallelism, weight gradients of a
+   * few dozen tiles under a long reduction — are cut along K as well: every CU takes an equal run of (tile, K slab) units, tiles
+   * shared by two or three CUs are summed through this workspace inside the launch (fp32, fixed order: reproducible, not bit-equal
+   * to the unsplit product).  Caller-owned, sl_gemm_streamk_workspace_bytes() bytes, 16-byte aligned, ZEROED ONCE before its first
+   * use and not shared by launches that may run concurrently (one per stream).  NULL, a shape the rule does not take, transposed /
+   * grouped operands or the ln_* / stats_out / amax_* / aux_out forms: the product runs one block per tile as without it. */
+  void* sk_ws; size_t sk_ws_bytes;
 } sl_gemm_ex_args;
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);
+size_t sl_gemm_streamk_workspace_bytes(void);
 /* 1 when sl_gemm_ex takes ln_* / stats_out for a plain (M, N, K) product of this dtype, else 0 */
 int32_t sl_gemm_ln_fold_ok(int32_t M, int32_t N, int32_t K, int32_t dtype);
 /* {mean, rstd} per row from the per-segment {sum, sum of squares} a stats_out GEMM left ([rows][segs][2] floats, cols = 64 * segs

@@ -45,7 +45,7 @@ class GemmFused(C.Structure):
 class GemmEx(C.Structure):
     _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("w_mod", c_i32), ("aux_out", c_vp), ("groups", c_vp),
                 ("groups_ext", c_i32), ("reserved", c_i32), ("amax_val", c_vp), ("amax_idx", c_vp),
-                ("ln_mr", c_vp), ("ln_u", c_vp), ("ln_c", c_vp), ("stats_out", c_vp)]
+                ("ln_mr", c_vp), ("ln_u", c_vp), ("ln_c", c_vp), ("stats_out", c_vp), ("sk_ws", c_vp), ("sk_ws_bytes", C.c_size_t)]
 
 
 class AttnArgs(C.Structure):
@@ -156,6 +156,7 @@ _PROTOS = {
     "sl_tuning_reload": (c_i32, []),
     "sl_decode_graph_cache_clear": (c_i32, []),
     "sl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "sl_gemm_streamk_workspace_bytes": (C.c_size_t, []),
     "sl_pack_weight": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "sl_gemm_fused_decode": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmFused), c_vp]),
     "sl_gemm_split_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),

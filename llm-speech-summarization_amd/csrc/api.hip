@@ -18,7 +18,7 @@ void sl_set_error(const char* fmt, ...) {
 
 extern "C" const char* sl_last_error(void) { return g_err; }
 
-extern "C" int sl_version(void) { return 3; }   // 3: sl_gemm_ex_args.amax_*, sl_greedy_select_partial, sl_adamw_step, sl_layernorm_bwd_ws, sl_decode_graph_cache_clear
+extern "C" int sl_version(void) { return 4; }   // 4: sl_gemm_ex_args.sk_ws / sk_ws_bytes, sl_gemm_streamk_workspace_bytes; 3: sl_gemm_ex_args.amax_*, sl_greedy_select_partial, sl_adamw_step, sl_layernorm_bwd_ws, sl_decode_graph_cache_clear
 
 extern "C" int sl_device_arch(char* buf, int n) {
   SL_CHECK_ARG(buf != nullptr && n > 0, "sl_device_arch: bad buffer");
@@ -52,6 +52,7 @@ static const SlEnv* env_load() {
   e.t256_min_tiles = env_int("SL_T256_MIN_TILES", 512);
   e.t256_min_k = env_int("SL_T256_MIN_K", 1024);
   e.t256_phased = env_int("SL_T256_PHASED", 1);
+  e.stream_k = env_int("SL_STREAM_K", 1);
   e.gemm_ko = env_int("SL_GEMM_KO", 0);
   { const char* sp = getenv("SL_GEMM_STAMP_PTR"); e.gemm_stamp_ptr = (sp && sp[0]) ? strtoull(sp, nullptr, 16) : 0ull; }
   const char* g = getenv("SL_DISABLE_GLDS");

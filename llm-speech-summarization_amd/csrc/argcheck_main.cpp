@@ -33,7 +33,7 @@ static void fill_hubert(sl_hubert_model* m, sl_hubert_layer* layers, int n_layer
 }
 
 int main() {
-  EXPECT(sl_version() == 3, "ABI version");
+  EXPECT(sl_version() == 4, "ABI version");
   EXPECT(sl_last_error() != nullptr, "error string never NULL");
 
   // ---- tuning switches: parser under the sanitizers, garbage included

@@ -1004,88 +1004,32 @@ __device__ __forceinline__ void vm_wait_pieces(int n_out) {   // n_out pieces (t
 
 // DBG (debug builds only, -DSL_GEMM_DEBUG): 8 = cycle stamps; knock-outs 1 = no fragment reads, 2 = no DMA, 4 = no MFMAs (results are then
 // meaningless: timing experiments, tools/gemm_knockout.py)
-template <typename T, int ACT, bool SW = false, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
+//
+// The main loop over `nkt` K slabs starting at element k_first, shared by the one-tile-per-block kernel and the stream-K kernel.
+// gp[kind][i]: this thread's two source rows of piece kind {PA0, PB0, PB1, PA1} at k = 0; all eight waves call it together and
+// leave it together (the leading half waits for the lagging one), with every DMA landed and every fragment read retired.
+template <typename T, bool SW, int DBG>
+__device__ __forceinline__ void t256_mainloop(unsigned char* smem, const T* const (&gp)[4][2], int64_t k_first, int nkt, int wave, int lane,
+                                              f32x4 (&acc)[8][4], uint32_t* stamps) {
   constexpr bool STAMP = (DBG & 8) != 0, KO_RD = (DBG & 1) != 0, KO_DMA = (DBG & 2) != 0, KO_MMA = (DBG & 4) != 0;
-  static_assert(!SW || (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL), "the swapped-operand form is the bf16 store epilogue");
-  constexpr int VEC = Vec16<T>::VEC;
   constexpr int BK = TROWB / (int)sizeof(T);
   constexpr int PIECE = 128 * TROWB;            // 16 KiB
-  // one LDS object (a second one beside an LDS-DMA target can cost a vmcnt(0) per k-step, guide §5 item 4a): 8 piece slots + {mean, rstd}
-  __shared__ __attribute__((aligned(16))) unsigned char smem[8 * PIECE + XBM * 8];
-  float2* mr_s = (float2*)(smem + 8 * PIECE);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // instrumented build: lane 0 of waves 0 and 4 drops the low word of s_memtime into the {mean, rstd} area (unused without the fold),
-  // copied out after the loop — no VMEM traffic, so the counted vmcnt waits are undisturbed
-  auto stamp = [&](int i) {
-    if constexpr (STAMP) {
-      if ((wave & 3) == 0 && lane == 0) ((uint32_t*)mr_s)[(wave >> 2) * 32 + i] = (uint32_t)__builtin_amdgcn_s_memtime();
-    }
-  };
-  stamp(0);
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, q = lane >> 4;
-  const int nt = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  }
-  int bm, bn;   // XCD patches of tiles as in gemm_tiled256_kernel
-  {
-    const int GM = p.gm;
-    const int per = GM * p.tiles_n, grp = bid / per, first = grp * GM;
-    const int gsz = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
-    const int in = bid - grp * per;
-    bm = first + in % gsz;
-    bn = in / gsz;
-  }
-  const int z = blockIdx.y;
-  int64_t a_off; int wz;
-  if (!resolve_group(p, z, bm, a_off, wz, XBM)) return;
-  const T* A = (const T*)p.A + a_off;
-  const T* W = (const T*)p.W + (int64_t)wz * p.sW + p.wx;
-  if (p.grp_ext && bn * XBN >= p.N) return;
-
-  // staging: LDS chunk c = tid + 512 i of a piece sits at (piece row c >> 3, physical chunk c & 7) and holds the logical chunk
-  // (c & 7) ^ key(piece row).  Piece rows: A pieces = [half of the block 0/1][64 rows], W pieces = [wave column 0..3][32 rows].
-  const T* gp[4][2];     // [PA0, PB0, PB1, PA1][i]
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 512 * i, rho = c >> 3, pc = c & 7;
-    const int cha = pc ^ (rho & 7);
-    const int chw = SW ? pc ^ ((rho & 3) | (((rho >> 3) & 1) << 2)) : cha;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int ar = bm * XBM + (rho >> 6) * 128 + h * 64 + (rho & 63); ar = ar < p.M ? ar : p.M - 1;
-      int wr = bn * XBN + (rho >> 5) * 64 + h * 32 + (rho & 31); wr = wr < p.N ? wr : p.N - 1;
-      gp[h ? 3 : 0][i] = A + (int64_t)ar * p.lda + cha * VEC;
-      gp[h ? 2 : 1][i] = W + (int64_t)wr * p.ldw + chw * VEC;
+  auto stamp = [&](int i) {
+    if constexpr (STAMP) {
+      if ((wave & 3) == 0 && lane == 0) stamps[(wave >> 2) * 32 + i] = (uint32_t)__builtin_amdgcn_s_memtime();
     }
-  }
-  const int nkt = p.K / BK, NP = 4 * nkt;
+  };
+  const int NP = 4 * nkt;
   // piece n = 4 * slab + kind goes to slot n & 7
   auto issue = [&](int n, int kind) {
     if constexpr (KO_DMA) return;
-    const int64_t k0 = (int64_t)(n >> 2) * BK;
+    const int64_t k0 = k_first + (int64_t)(n >> 2) * BK;
     unsigned char* dst = smem + (n & 7) * PIECE + wave * 1024;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(gp[kind][0] + k0), (lds_ptr_t)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(gp[kind][1] + k0), (lds_ptr_t)(dst + 8192), 16, 0, 0);
   };
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int m = 0; m < 8; ++m)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (sizeof(T) == 2 && p.ln_mr && tid < XBM) {   // LayerNorm fold: this tile's {mean, rstd} pairs wait in LDS for the epilogue
-    int row = bm * XBM + tid;                     // (before the first DMA: the compiler drains vmcnt for this load's use)
-    row = row < p.M ? row : p.M - 1;
-    mr_s[tid] = ((const float2*)p.ln_mr)[row];
-  }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int n = 0; n < 6; ++n)
@@ -1185,13 +1129,46 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
   for (; t < nkt; ++t) tile(t, false);
   stamp(14);
   if (wm == 0) __builtin_amdgcn_s_barrier();           // the lagging half's last MFMA segment ends behind this one
-  if constexpr (STAMP) {
-    if ((wave & 3) == 0 && lane < 32 && p.stamp) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      p.stamp[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave >> 2)) * 32 + lane] = ((const uint32_t*)mr_s)[(wave >> 2) * 32 + lane];
+}
+
+// staging pointers of tile (bm, bn): LDS chunk c = tid + 512 i of a piece sits at (piece row c >> 3, physical chunk c & 7) and holds the
+// logical chunk (c & 7) ^ key(piece row).  Piece rows: A pieces = [half of the block 0/1][64 rows], W pieces = [wave column 0..3][32 rows].
+template <typename T, bool SW>
+__device__ __forceinline__ void t256_stage_ptrs(const GemmP& p, const T* A, const T* W, int bm, int bn, int tid, const T* (&gp)[4][2]) {
+  constexpr int VEC = Vec16<T>::VEC;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 512 * i, rho = c >> 3, pc = c & 7;
+    const int cha = pc ^ (rho & 7);
+    const int chw = SW ? pc ^ ((rho & 3) | (((rho >> 3) & 1) << 2)) : cha;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ar = bm * XBM + (rho >> 6) * 128 + h * 64 + (rho & 63); ar = ar < p.M ? ar : p.M - 1;
+      int wr = bn * XBN + (rho >> 5) * 64 + h * 32 + (rho & 31); wr = wr < p.N ? wr : p.N - 1;
+      gp[h ? 3 : 0][i] = A + (int64_t)ar * p.lda + cha * VEC;
+      gp[h ? 2 : 1][i] = W + (int64_t)wr * p.ldw + chw * VEC;
     }
   }
+}
 
+// tile index (after the XCD remap) -> tile coordinates: XCD patches of GM tile rows (see gemm_tiled256_kernel)
+__device__ __forceinline__ void t256_tile_coords(const GemmP& p, int v, int& bm, int& bn) {
+  const int GM = p.gm;
+  const int per = GM * p.tiles_n, grp = v / per, first = grp * GM;
+  const int gsz = (p.tiles_m - first) < GM ? (p.tiles_m - first) : GM;
+  const int in = v - grp * per;
+  bm = first + in % gsz;
+  bn = in / gsz;
+}
+__device__ __forceinline__ int xcd_remap(int bid, int n) {      // bijective: the blocks of one XCD (bid % 8 equal) get consecutive indices
+  const int qn = n >> 3, rn = n & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+}
+
+template <typename T, int ACT, bool SW>
+__device__ __forceinline__ void t256_epilogue(const GemmP& p, f32x4 (&acc)[8][4], int bm, int bn, int wave, int lane, int z, int wz, unsigned char* smem,
+                                              float2* mr_s) {
+  const int wm = wave >> 2, wn = wave & 3;
   if constexpr (SW) {
     const int rb0_ = bm * XBM + wm * 128, cb0 = bn * XBN + wn * 64;
     const float2* mrl = mr_s + wm * 128;
@@ -1201,14 +1178,165 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
     else if (st) tile_epilogue_sw<ACT, EPI_RES | EPI_STATS>(p, acc, rb0_, cb0, lane, z, wz, mrl);
     else if (res) tile_epilogue_sw<ACT, EPI_RES>(p, acc, rb0_, cb0, lane, z, wz, mrl);
     else tile_epilogue_sw<ACT, 0>(p, acc, rb0_, cb0, lane, z, wz, mrl);
-    return;
   } else {
     if constexpr (ACT != SL_ACT_SILU_MUL) {
       // the LDS-turned rows epilogue uses 16 KiB per wave of the piece slots (every DMA has landed: the last phases wait vmcnt(0))
       if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)smem + wave * 4096,
                                                         sizeof(T) == 2 && p.ln_mr ? mr_s + wm * 128 : nullptr)) return;
     }
-    tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, q, r, z, wz);
+    tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane >> 4, lane & 15, z, wz);
+  }
+}
+
+template <typename T, int ACT, bool SW = false, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
+  constexpr bool STAMP = (DBG & 8) != 0;
+  static_assert(!SW || (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL), "the swapped-operand form is the bf16 store epilogue");
+  constexpr int BK = TROWB / (int)sizeof(T);
+  constexpr int PIECE = 128 * TROWB;            // 16 KiB
+  // one LDS object (a second one beside an LDS-DMA target can cost a vmcnt(0) per k-step, guide §5 item 4a): 8 piece slots + {mean, rstd}
+  __shared__ __attribute__((aligned(16))) unsigned char smem[8 * PIECE + XBM * 8];
+  float2* mr_s = (float2*)(smem + 8 * PIECE);   // instrumented build: the stamps of lane 0 of waves 0 and 4 live here (no fold in that build)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (STAMP) {
+    if ((wave & 3) == 0 && lane == 0) ((uint32_t*)mr_s)[(wave >> 2) * 32] = (uint32_t)__builtin_amdgcn_s_memtime();
+  }
+  int bm, bn;
+  t256_tile_coords(p, xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), bm, bn);
+  const int z = blockIdx.y;
+  int64_t a_off; int wz;
+  if (!resolve_group(p, z, bm, a_off, wz, XBM)) return;
+  const T* A = (const T*)p.A + a_off;
+  const T* W = (const T*)p.W + (int64_t)wz * p.sW + p.wx;
+  if (p.grp_ext && bn * XBN >= p.N) return;
+  const T* gp[4][2];     // [PA0, PB0, PB1, PA1][i]
+  t256_stage_ptrs<T, SW>(p, A, W, bm, bn, tid, gp);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (sizeof(T) == 2 && p.ln_mr && tid < XBM) {   // LayerNorm fold: this tile's {mean, rstd} pairs wait in LDS for the epilogue
+    int row = bm * XBM + tid;                     // (before the first DMA: the compiler drains vmcnt for this load's use)
+    row = row < p.M ? row : p.M - 1;
+    mr_s[tid] = ((const float2*)p.ln_mr)[row];
+  }
+  t256_mainloop<T, SW, DBG>(smem, gp, 0, p.K / BK, wave, lane, acc, (uint32_t*)mr_s);
+  if constexpr (STAMP) {
+    if ((wave & 3) == 0 && lane < 32 && p.stamp) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      p.stamp[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave >> 2)) * 32 + lane] = ((const uint32_t*)mr_s)[(wave >> 2) * 32 + lane];
+    }
+  }
+  t256_epilogue<T, ACT, SW>(p, acc, bm, bn, wave, lane, z, wz, smem, mr_s);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Stream-K form of the kernel above (un-grouped bf16 / fp32 products whose 256^2 tiles do not fill the chip evenly: KD windows of
+// 2-8 k rows, the per-rank KD regime of a few hundred rows, weight gradients of 16-64 tiles under K = 8 000, decode projections).
+// The tiles' K slabs form one sequence of tiles x slabs units, cut into `gridDim.x` equal contiguous ranges, one per block (one
+// block per CU); a block walks its range from the top down, tile segment by tile segment, each segment through the main loop above.
+//   * a segment that is a whole tile: the usual epilogue;
+//   * a segment that does not reach its tile's last slab (only a block's FIRST segment can be one): the accumulators go to the
+//     block's slot of the workspace as fp32 (16-byte write-through stores), every wave drains, one lane raises the block's flag;
+//   * a segment that ends its tile but does not start it (only a block's LAST segment): the tile's other segments belong to the
+//     blocks just below, which produced them first thing — the owner polls their flags (one lane, relaxed, s_sleep), takes ONE
+//     agent-scope acquire, adds the partial sums in descending block order (a fixed order: results are reproducible, though not
+//     bit-identical to the unsplit kernel), clears the flags and runs the epilogue.
+// Waiting is only ever for work that was started before the waiter's own: no cycle, and with at most one block per CU resident
+// (130 KiB of LDS) every block of a grid of <= #CUs blocks is resident or becomes resident as soon as any kernel's block retires.
+// Workspace (caller-owned, zero-initialised once): [flags: 1 KiB][gridDim.x slots of 256 KiB].  Guide §6 Guideline 16 (R1).
+// ----------------------------------------------------------------------------------------------
+constexpr size_t SK_FLAG_BYTES = 1024, SK_SLOT_BYTES = (size_t)XBM * XBN * 4;
+
+template <typename T, int ACT, bool SW>
+__global__ __launch_bounds__(512, 2) void gemm_tiled256sk_kernel(GemmP p, unsigned char* ws) {
+  static_assert(!SW || (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL), "the swapped-operand form is the bf16 store epilogue");
+  constexpr int BK = TROWB / (int)sizeof(T);
+  constexpr int PIECE = 128 * TROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[8 * PIECE + XBM * 8];
+  float2* mr_s = (float2*)(smem + 8 * PIECE);
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x, nkt = p.K / BK, nt = p.tiles_m * p.tiles_n;
+  const int vb = xcd_remap(blockIdx.x, G);                 // blocks of one XCD take consecutive ranges: their tiles share A / W slabs in its L2
+  const int64_t U = (int64_t)nt * nkt;
+  const int64_t u_lo = U * vb / G;
+  int64_t u_hi = U * (vb + 1) / G;
+  gu32* flags = (gu32*)ws;
+  float* slots = (float*)(ws + SK_FLAG_BYTES);
+  const T* A = (const T*)p.A;
+  const T* W = (const T*)p.W;
+  bool first = true;
+  while (u_hi > u_lo) {
+    const int tile = (int)((u_hi - 1) / nkt);
+    const int64_t t0 = (int64_t)tile * nkt;
+    const int s1 = (int)(u_hi - t0), s0 = (int)((u_lo > t0 ? u_lo : t0) - t0);
+    int bm, bn;
+    t256_tile_coords(p, tile, bm, bn);               // unit order = the XCD-patch tile order: the blocks of one XCD (consecutive vb) work on neighbouring tiles
+    const T* gp[4][2];
+    t256_stage_ptrs<T, SW>(p, A, W, bm, bn, tid, gp);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first) __builtin_amdgcn_s_barrier();              // the previous segment's epilogue may still be turning rows through LDS in another wave
+    first = false;
+    t256_mainloop<T, SW, 0>(smem, gp, (int64_t)s0 * BK, s1 - s0, wave, lane, acc, nullptr);
+    if (s1 < nkt) {
+      // partial sums -> this block's slot, in register order: [wave][fragment][lane] x 16 bytes, write-through (sc1)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slots + (int64_t)vb * (XBM * XBN), 0, (int)SK_SLOT_BYTES, 0x00020000);
+      const int off = (wave * 32 * 64 + lane) * 16;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[m][n]), rs, off + (m * 4 + n) * 1024, 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains, then the workgroup's barrier, then ONE flag store
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + vb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (s0 > 0) {
+        // owner: the rest of this tile sits in the slots of the blocks below, down to the one that holds the tile's first slab
+        int v_first = vb - 1;
+        while (U * v_first / G > t0) --v_first;
+        if (wave == 0) {
+          for (int v = vb - 1; v >= v_first; --v) {
+            if (lane == 0) {
+              while (__hip_atomic_load(flags + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        for (int v = vb - 1; v >= v_first; --v) {
+          const f32x4* src = (const f32x4*)(slots + (int64_t)v * (XBM * XBN)) + wave * 32 * 64 + lane;
+#pragma unroll
+          for (int m = 0; m < 8; m += 2) {       // eight fragments (32 registers) in flight at a time: all 32 at once would need 128, fewer leaves the
+            f32x4 t8[2][4];                        // read latency-bound (guide: >= 8 loads per lane outstanding on a handed-off tile)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int n = 0; n < 4; ++n) t8[h][n] = __builtin_nontemporal_load(src + ((m + h) * 4 + n) * 64);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int n = 0; n < 4; ++n) acc[m + h][n] += t8[h][n];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (tid < vb - v_first) __hip_atomic_store(flags + (vb - 1 - tid), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed: ready for the next launch
+      }
+      t256_epilogue<T, ACT, SW>(p, acc, bm, bn, wave, lane, 0, 0, smem, mr_s);
+    }
+    u_hi = t0 + s0;
   }
 }
 
@@ -1435,9 +1563,60 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmP p, SkinnyX s
 // ----------------------------------------------------------------------------------------------
 // host dispatch
 // ----------------------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------------------
+// stream-K admission (sl_gemm_ex_args.sk_ws): returns the grid size, 0 = keep one block per tile
+// ----------------------------------------------------------------------------------------------
+static int sk_cu_count() {
+  static int cus[SL_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SL_MAX_DEVICES) return 256;
+  if (!cus[dev]) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
+extern "C" size_t sl_gemm_streamk_workspace_bytes(void) { return SK_FLAG_BYTES + 256 * SK_SLOT_BYTES; }
+
+static int sk_grid(const GemmP& p, int batch, int bk, size_t ws_bytes) {
+  const int mode = sl_env().stream_k;          // SL_STREAM_K: 0 = never, 1 = rule (default), 2 = whenever the form allows
+  if (!mode || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.N < 192) return 0;
+  const int cus = sk_cu_count() < 256 ? sk_cu_count() : 256;
+  const int64_t tm = (p.M + XBM - 1) / XBM, tn = (p.N + XBN - 1) / XBN, nt = tm * tn, nkt = p.K / bk;
+  if (nkt < 8 || tm * XBM * 4 > (int64_t)p.M * 5 + 4 * XBM) return 0;      // short reductions; rows padded by more than a quarter (+ one tile)
+  int G = cus;
+  if (nt * 4 < G) G = (int)(nt * 4);                                        // a tile's slabs go to at most ~4 blocks: the owner reads the others' sums serially
+  if (nt * nkt < (int64_t)G * 4) return 0;
+  if (ws_bytes < SK_FLAG_BYTES + (size_t)G * SK_SLOT_BYTES) return 0;
+  if (mode == 2) return G;
+  // Measured (profiles/r04_f_streamk.txt): cutting K across blocks gives up what the XCD tile patches buy — neighbouring blocks no longer
+  // stream the SAME slabs, so every block pulls its 64 KiB per slab from beyond L2 (3 200 x 3 072 x 16 384: 156 tiles, all 256 CUs busy,
+  // 2.6 GB through the Infinity Cache in 310 us = its bandwidth; 0.94 x the one-block-per-tile time) — and a tile's fp32 hand-off costs
+  // 10-20 us.  It pays only where a few tiles sit under a long reduction (400 x 3 072 x 16 384: 24 tiles, 1.6 x).
+  return (nt * 8 <= cus && nkt >= 128) ? G : 0;
+}
+
 template <typename T, int ACT>
-static int launch_tiled(GemmP& p, int batch, hipStream_t st) {
+static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
   constexpr int BK_ = TROWB / (int)sizeof(T);
+  if (sk_ws) {
+    const int G = sk_grid(p, batch, BK_, sk_ws_bytes);
+    if (G) {
+      p.tiles_m = (p.M + XBM - 1) / XBM;
+      p.tiles_n = (p.N + XBN - 1) / XBN;
+      if constexpr (sizeof(T) == 2 && ACT != SL_ACT_SILU_MUL) {
+        const bool al = !(p.N & 7) && !(p.ldc & 7) && !((uintptr_t)p.C & 15) && (!p.res || (!(p.ldr & 7) && !((uintptr_t)p.res & 15)));
+        if (al && !p.out_f32 && !p.res_f32 && !p.direct_epi && !sl_env().no_swap_epilogue) {
+          hipLaunchKernelGGL((gemm_tiled256sk_kernel<T, ACT, true>), dim3(G), dim3(512), 0, st, p, (unsigned char*)sk_ws);
+          SL_CHECK_LAUNCH("gemm_tiled256sk (swapped operands)");
+          return 0;
+        }
+      }
+      hipLaunchKernelGGL((gemm_tiled256sk_kernel<T, ACT, false>), dim3(G), dim3(512), 0, st, p, (unsigned char*)sk_ws);
+      SL_CHECK_LAUNCH("gemm_tiled256sk");
+      return 0;
+    }
+  }
   // large products: 256^2 tiles once they alone give every CU >= 2 tiles (ragged batches: sized by the largest group)
   if (!p.ta && !p.tw && p.K % BK_ == 0 && !p.grp_ext && g_disable_glds == 0 && !sl_env().disable_t256) {
     const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
@@ -1568,7 +1747,7 @@ static int launch_skinny(GemmP& p, const SkinnyX& sx, int batch, bool packed, hi
 }
 
 template <typename T>
-static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStream_t st) {
+static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStream_t st, void* sk_ws, size_t sk_ws_bytes) {
   const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32 && !p.grp;  // backward features live in the tiled kernel
   const bool packed = a->w_layout == SL_W_PACKED;
   if (!skinny && (packed || a->act == SL_ACT_ROPE_KV || sx.fuse_rms)) {
@@ -1576,9 +1755,9 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
     return SL_ERR_UNSUPPORTED;
   }
   switch (a->act) {
-    case SL_ACT_NONE: return skinny ? launch_skinny<T, SL_ACT_NONE>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_NONE>(p, a->batch, st);
-    case SL_ACT_GELU: return skinny ? launch_skinny<T, SL_ACT_GELU>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_GELU>(p, a->batch, st);
-    case SL_ACT_SILU_MUL: return skinny ? launch_skinny<T, SL_ACT_SILU_MUL>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_SILU_MUL>(p, a->batch, st);
+    case SL_ACT_NONE: return skinny ? launch_skinny<T, SL_ACT_NONE>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_NONE>(p, a->batch, st, sk_ws, sk_ws_bytes);
+    case SL_ACT_GELU: return skinny ? launch_skinny<T, SL_ACT_GELU>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_GELU>(p, a->batch, st, sk_ws, sk_ws_bytes);
+    case SL_ACT_SILU_MUL: return skinny ? launch_skinny<T, SL_ACT_SILU_MUL>(p, sx, a->batch, packed, st) : launch_tiled<T, SL_ACT_SILU_MUL>(p, a->batch, st, sk_ws, sk_ws_bytes);
     case SL_ACT_ROPE_KV: return launch_skinny<T, SL_ACT_ROPE_KV>(p, sx, a->batch, packed, st);
   }
   sl_set_error("sl_gemm: unknown act %d", a->act);
@@ -1673,8 +1852,11 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     return sl_gemm_stream_launch(p, sx, a->dtype, a->act, fx ? fx->split_ws : nullptr, fx ? fx->split_ws_bytes : 0, st);
   SL_CHECK_ARG(a->w_layout != SL_W_PACKED || a->M <= 64, "sl_gemm: packed weights with M=%d > 64 need batch 1 and K %% 64 == 0", a->M);
   SL_CHECK_ARG(!sx.rstd_in && !sx.rstd_out, "sl_gemm: rstd_in / rstd_out are features of the streaming path (M > %d rows, packed weights)", stream_min_m());
-  if (a->dtype == SL_F32) return gemm_typed<float>(a, p, sx, st);
-  return gemm_typed<bf16_t>(a, p, sx, st);
+  void* sk_ws = ex ? ex->sk_ws : nullptr;
+  const size_t sk_ws_bytes = ex ? ex->sk_ws_bytes : 0;
+  SL_CHECK_ARG(!sk_ws || ((uintptr_t)sk_ws & 15) == 0, "sl_gemm_ex: sk_ws must be 16-byte aligned");
+  if (a->dtype == SL_F32) return gemm_typed<float>(a, p, sx, st, sk_ws, sk_ws_bytes);
+  return gemm_typed<bf16_t>(a, p, sx, st, sk_ws, sk_ws_bytes);
 }
 
 extern "C" int32_t sl_gemm_split_count(int32_t M, int32_t N, int32_t K, int32_t dtype) {

@@ -25,16 +25,18 @@ struct Carver {
 inline int64_t rup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
 // C = act(A W^T + bias) + residual   (ops.gemm)
+// sk_ws: optional stream-K workspace (sl_gemm_ex_args.sk_ws) for products of a few tiles under a long reduction
 int gemm(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* res, int64_t ldr,
-         int64_t M, int N, int K, int act, void* aux_out, hipStream_t st) {
+         int64_t M, int N, int K, int act, void* aux_out, hipStream_t st, void* sk_ws = nullptr) {
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.residual = res; a.ldr = ldr;
   a.M = (int)M; a.N = N; a.K = K; a.batch = 1; a.dtype = dt; a.act = act;
-  if (!aux_out) return sl_gemm(&a, (sl_stream)st);
+  if (!aux_out && !sk_ws) return sl_gemm(&a, (sl_stream)st);
   sl_gemm_ex_args ex;
   memset(&ex, 0, sizeof(ex));
   ex.aux_out = aux_out; ex.w_mod = 1;
+  if (sk_ws) { ex.sk_ws = sk_ws; ex.sk_ws_bytes = sl_gemm_streamk_workspace_bytes(); }
   return sl_gemm_ex(&a, &ex, (sl_stream)st);
 }
 
@@ -48,7 +50,7 @@ struct BwdScratch {
 // dX (M, K_in) = dY (M, N_out) . W (N_out, K_in), through a transposed copy of W so that the product is K-contiguous
 // (ops.dgrad with wt = ops.transpose_pad(W)); wt_cached != NULL: the copy already exists (frozen weights)
 int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_in, const void* wt_cached, void* dX, int64_t ldx, int64_t M,
-          const BwdScratch& s, hipStream_t st) {
+          const BwdScratch& s, hipStream_t st, void* sk_ws = nullptr) {
   const int vec = dt == SL_F32 ? 4 : 8;
   const int64_t ldw = rup(n_out, vec);
   const void* wt = wt_cached;
@@ -56,7 +58,7 @@ int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_i
     SL_TRY(sl_transpose_pad(W, k_in, s.wt, ldw, n_out, k_in, n_out, dt, (sl_stream)st));
     wt = s.wt;
   }
-  return gemm(dt, dY, ldy, wt, wt_cached ? n_out : ldw, dX, ldx, nullptr, nullptr, 0, M, k_in, n_out, SL_ACT_NONE, nullptr, st);
+  return gemm(dt, dY, ldy, wt, wt_cached ? n_out : ldw, dX, ldx, nullptr, nullptr, 0, M, k_in, n_out, SL_ACT_NONE, nullptr, st, sk_ws);
 }
 
 // dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in)       (ops.wgrad_acc, plain Linear)
@@ -323,6 +325,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
 struct LlamaTrainWs {
   void *h, *mid, *qkv, *x2, *gu, *att, *d_mid, *d_gu, *d_h, *dx2, *d_att, *d_qkv;
   float *lse, *delta;
+  void* sk;       // stream-K workspace of the data-gradient products (flags zeroed at the start of every backward call)
   BwdScratch s;
 };
 
@@ -345,6 +348,7 @@ static size_t llama_train_carve(const sl_llama_stack_cfg* c, void* base, size_t 
   w.d_qkv = cv.take(n * qkv_w * sz);
   w.lse = (float*)cv.take(n * c->n_heads * sizeof(float));
   w.delta = (float*)cv.take(n * c->n_heads * sizeof(float));
+  w.sk = cv.take(sl_gemm_streamk_workspace_bytes());
   w.s.yt = w.s.xt = w.s.wt = nullptr;    // data gradients only, on cached transposed weights
   return cv.off + 256;
 }
@@ -403,14 +407,15 @@ extern "C" int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, cons
   const int qkv_w = (nh + 2 * nkv) * D, att_w = nh * D;
   const int64_t n = c->n_tok;
   const float scale = 1.0f / sqrtf((float)D);
+  SL_HIP(hipMemsetAsync(w.sk, 0, 1024, st));        // the stream-K flags (a run of an earlier call cut short must not poison this one)
   for (int l = c->n_layers - 1; l >= 0; --l) {
     const sl_llama_train_layer& L = layers[l];
     const sl_llama_layer_saved& sv = saved[l];
     SL_CHECK_ARG(L.wqkv_t && L.wo_t && L.wgu_t && L.wdown_t, "sl_llama_stack_train_bwd: layer %d lacks the transposed weights", l);
     // x3 = x2 + wdown . (silu(gate) * up),   [gate | up] = wgu . rmsnorm(x2)
-    SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_mid, F, n, w.s, st));
+    SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_mid, F, n, w.s, st, w.sk));
     SL_TRY(sl_silu_mul_bwd(sv.gu, w.d_mid, w.d_gu, n, F, dt, stream));
-    SL_TRY(dgrad(dt, w.d_gu, 2 * F, L.wgu, 2 * F, H, L.wgu_t, w.d_h, H, n, w.s, st));
+    SL_TRY(dgrad(dt, w.d_gu, 2 * F, L.wgu, 2 * F, H, L.wgu_t, w.d_h, H, n, w.s, st, w.sk));
     SL_TRY(sl_rmsnorm_bwd(sv.x2, L.norm2, w.d_h, w.dx2, n, H, c->rms_eps, dt, stream));
     SL_TRY(sl_axpby(dx, w.dx2, 1.f, 1.f, n * H, dt, stream));                       // residual join
     // x2 = x + wo . attn(rope(wqkv . rmsnorm(x)))

@@ -356,7 +356,7 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
             residual_f32: bool = False, aux_out=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0,
             strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, r_off: int = 0,
             dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1, groups_ext: bool = False,
-            ln_mr=None, ln_u=None, ln_c=None, stats_out=None):
+            ln_mr=None, ln_u=None, ln_c=None, stats_out=None, sk_ws: Optional[torch.Tensor] = None):
     """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors.  ln_mr/ln_u/ln_c: the
     LayerNorm-folded consumer epilogue; stats_out: per-64-column {sum, sum of squares} of the stored rows (speechllm.h)."""
     dt = dtype or A.dtype
@@ -374,8 +374,15 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     e.trans_a, e.trans_w, e.residual_f32, e.aux_out = int(trans_a), int(trans_w), int(residual_f32), L.ptr(aux_out)
     e.groups, e.w_mod, e.groups_ext = L.ptr(groups), w_mod, int(groups_ext)
     e.ln_mr, e.ln_u, e.ln_c, e.stats_out = L.ptr(ln_mr), L.ptr(ln_u), L.ptr(ln_c), L.ptr(stats_out)
+    if sk_ws is not None:       # stream-K workspace (streamk_workspace): zeroed once, one per stream
+        e.sk_ws, e.sk_ws_bytes = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size()
     L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(e), L.stream_ptr()), "sl_gemm_ex")
     return out
+
+
+def streamk_workspace(device) -> torch.Tensor:
+    """A zeroed stream-K workspace (sl_gemm_ex_args.sk_ws): one per stream that launches GEMMs."""
+    return torch.zeros(int(L.lib().sl_gemm_streamk_workspace_bytes()), device=device, dtype=torch.uint8)
 
 
 def layernorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:

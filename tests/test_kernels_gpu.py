@@ -891,6 +891,42 @@ def test_gemm_swapped_operand_epilogue_equals_lds_turned_rows_epilogue(M, N, K, 
     assert torch.equal(swapped[5], swapped[1]) and torch.equal(swapped[6], swapped[0])        # GELU output / pre-activation = the bias-only product
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(400, 3072, 16384), (634, 1000, 2048), (1300, 520, 4096), (257, 256, 8192), (3200, 3072, 1024)])
+def test_gemm_stream_k_equals_the_tile_kernel_product(M, N, K, dt, tuning):
+    """Stream-K form of the 256-tile GEMM (sl_gemm_ex_args.sk_ws): every CU takes an equal run of (tile, K slab) units, tiles cut
+    between blocks are summed through the workspace inside the launch.  Forced on (SL_STREAM_K=2) over ragged M / N edges, tiles
+    split two to five ways, whole tiles inside a block's run, bf16 (register epilogue and, with an odd N, the LDS-turned one) and
+    fp32, plain / + residual / fp32 accumulation; repeated launches on one workspace (flags are cleared by their consumers).
+    Against the fp32 product, and against the one-block-per-tile result within a few fp32 ulps of re-association."""
+    if dt == torch.float32 and M * N * K > 3e10:
+        pytest.skip("fp32 MFMA at this size adds nothing")
+    A, W, R = rnd(M, K, seed=191), rnd(N, K, seed=192, std=K ** -0.5), rnd(M, N, seed=193)
+    Ad, Wd, Rd = A.to(dev(), dt), W.to(dev(), dt), R.to(dev(), dt)
+    ws = ops.streamk_workspace(dev())
+    acc0 = rnd(M, N, seed=194).to(dev())
+
+    def run(sk):
+        kw = dict(M=M, N=N, K=K, lda=K, ldw=K, sk_ws=ws if sk else None)
+        o1 = ops.gemm_ex(Ad, Wd, out=torch.empty((M, N), device=dev(), dtype=dt), **kw)
+        o2 = ops.gemm_ex(Ad, Wd, out=torch.empty((M, N), device=dev(), dtype=dt), residual=Rd, ldr=N, **kw)
+        o3 = acc0.clone()
+        ops.gemm_ex(Ad, Wd, out=o3, residual=o3, ldr=N, out_f32=True, residual_f32=True, **kw)
+        return o1, o2, o3
+
+    tile = run(False)
+    tuning("SL_STREAM_K", "2")
+    for rep in range(3):
+        sk = run(True)
+        ref = q(A, dt) @ q(W, dt).T
+        assert rel_err(sk[0].float().cpu(), ref) < TOL[dt]
+        assert rel_err(sk[1].float().cpu(), ref + q(R, dt)) < TOL[dt]
+        assert rel_err(sk[2].cpu(), ref + acc0.cpu()) < TOL[dt]
+        for a_, b_ in zip(sk, tile):
+            assert rel_err(a_.float().cpu(), b_.float().cpu()) < (5e-6 if dt == torch.float32 else 4e-3)     # re-association over up to 16 384 terms
+    assert int(ws[:1024].to(torch.int32).abs().sum()) == 0          # every raised flag was consumed and cleared
+
+
 def test_gemm_layernorm_fold_is_bit_identical_across_tile_kernels(tuning):
     """Row statistics and the folded consumer from the 256-tile kernel's register epilogue, from its LDS-turned rows epilogue
     and from the 128-tile kernel (what a short batch takes): one summation tree, so the same bits — a batch of utterances and
