@@ -166,6 +166,10 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     torch.cuda.empty_cache()     # the inference legs leave a fragmented block cache behind; the warm-up window below repopulates it
     # the reference trains with the encoder in train() mode (ref:trainer.py:258): dropouts, LayerDrop and SpecAugment on
     reg = None if args.kd_eval_mode else training.TrainRegularizers(seed=1234 + rank)   # ranks draw different masks, as seed_everything + rank does in Trainer
+    # regime under data parallelism: "weak" = train.per_rank_accum 16 (every rank keeps the single-GPU window, a step averages
+    # 16 x world samples), "strong" = the reference's grad_accum_interval 16 dealt to the ranks (16 / world samples each).  One GPU: the same run.
+    accum_ref = int(conf.train.grad_accum_interval)
+    conf.train["per_rank_accum"] = accum_ref if (args.kd_scaling == "weak" and world > 1) else 0
     tr = training.KDTrainer(conf, enc, llm, prefix, suffix, total_optimizer_steps=1000, regularizers=reg)
     g = torch.Generator().manual_seed(99 + rank)
     text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g)
@@ -256,7 +260,12 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
         # nodes is 250-350 GB/s for GB-sized fp32 buffers (7 links x ~153 GB/s raw, guide) -> both ends of that range
         wire = 2.0 * (ranks - 1) / ranks * ar_bytes
         ex_ms = [round(wire / (bw * 1e9) * 1e3, 2) for bw in (350.0, 250.0)]
-        probe = {"samples_per_window": k_, "emulates_world_size": ranks, "window_ms": round(win_ms, 2),
+        full_ms = sorted(window_ms)[len(window_ms) // 2]       # the window this GPU just ran = the per-rank window of the weak-scaling mode at any world size
+        weak = {"samples_per_window_per_rank": full, "window_ms": full_ms, "estimated_exchange_ms": ex_ms,
+                "predicted_samples_per_s_at_world": [round(ranks * full / ((full_ms + e * f) * 1e-3), 1) for e, f in ((ex_ms[0], 0.0), (ex_ms[1], 1.0))],
+                "note": f"train.per_rank_accum = {full}: every rank keeps this GPU's window of {full} samples, a step averages {full} x {ranks} samples; "
+                        "same exchange, same estimate (fully overlapped / not overlapped at all)"}
+        probe = {"samples_per_window": k_, "emulates_world_size": ranks, "window_ms": round(win_ms, 2), "weak_scaling_mode": weak,
                  "samples_per_s_per_rank_compute_only": round(k_ / (win_ms * 1e-3), 2),
                  "allreduce_bytes": ar_bytes, "estimated_exchange_ms": ex_ms, "exchange_to_compute": [round(e / win_ms, 2) for e in ex_ms],
                  "predicted_samples_per_s_at_world": [round(ranks * k_ / ((win_ms + e * f) * 1e-3), 1) for e, f in ((ex_ms[0], 0.0), (ex_ms[1], 1.0))],
@@ -268,6 +277,7 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
                          "formula": "3 enc_fwd + 2 prefill_full(S_audio) + prefill_full(S_text), SURVEY.md §8d; per rank",
                          "frac_tail_row_logits": round(ach_tail / MFMA_PEAK_TFLOPS, 4), "flops_per_sample_tail_row_logits": round(flops_tail)},
             "per_rank_regime_probe": probe,
+            "scaling_mode": ("weak: train.per_rank_accum = %d" % tr.local_accum) if conf.train["per_rank_accum"] else "strong: grad_accum_interval dealt to the ranks (reference-equivalent)",
             "optimizer_steps": args.kd_optimizer_steps, "window_ms": window_ms, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
             "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
             "losses": {k: round(v, 4) for k, v in losses.items()}, "dtype": "bf16 compute, fp32 master/grads",
@@ -522,6 +532,8 @@ def main():
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")
     ap.add_argument("--kd-window", type=int, default=0, help="profiling aid: samples per optimizer step per rank in the main KD leg (0 = grad_accum_interval / world)")
+    ap.add_argument("--kd-scaling", choices=["weak", "strong"], default="weak", help="KD leg under --gpus N > 1: weak = train.per_rank_accum 16 (16 samples per "
+                    "rank per optimizer step, the line's \"scaling\": \"weak\"), strong = the reference's grad_accum_interval 16 dealt to the ranks")
     ap.add_argument("--kd-local-accum", type=int, default=2, help="single-GPU KD probe: windows of this many samples per optimizer step, the per-rank "
                     "regime of an 8-rank run (grad_accum_interval 16 / 8); 0 = skip")
     args = ap.parse_args()
@@ -833,7 +845,7 @@ def main():
                   "audio-sec/s reported beside it, encoder stage alone and in the pipeline",
         "value": round(tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16", "data": "synthetic", "native_library": mod("_lib").LIB_PATH,
         "config": {"workload": "configs[1]: HuBERT-large + Llama-3.2-3B bf16 inference, batch of synthetic 16 kHz utterances",
                    "utterances_per_gpu": B, "audio_sec": args.audio_sec, "prompt_tokens": S, "max_new_tokens": new,
                    "parallelism": f"replicas x{world} (sharded by utterance, no collective)", "batches_in_flight_per_gpu": n_pipe},
@@ -867,6 +879,8 @@ def main():
                                   "note": f"prefill of {B} x {S} prompt rows, one batch alone on the GPU (stage_ms_one_batch_alone.prefill)"}
     if kd is not None:
         result["kd_step"] = kd
+        if isinstance(kd, dict) and kd.get("per_rank_regime_probe"):      # the 8-rank KD regimes at the top level of the line
+            result["kd_per_rank_regime_probe"] = kd["per_rank_regime_probe"]
     try:      # the reference's own call pattern: one utterance per generate call
         x1 = torch.empty((S, larch.hidden_size), device=dev, dtype=torch.bfloat16)
         x1[:n_pre] = pre_e
@@ -878,6 +892,7 @@ def main():
     if not args.no_length_mix:
         try:
             result["devclean_length_mix"] = mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx)
+            result["devclean_audio_sec_per_s"] = result["devclean_length_mix"].get("audio_sec_per_s")
         except Exception as e:
             result["devclean_length_mix"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_extra_legs:

@@ -666,6 +666,27 @@ int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, const sl_llama_
                              const sl_llama_layer_saved* saved, void* const* d_tap, void* dx, void* workspace, size_t workspace_bytes,
                              sl_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Collective (group 11): the ONE exchange of the hot path — the in-place sum of the encoder's fp32 gradient arena over the ranks
+ * of a data-parallel KD step.  The reference has none (ref:README.md:86: "only supports training on a single GPU with a batch size
+ * of 1"); its accumulation boundary ref:trainer.py:373-384 is where the sum goes.  RCCL over xGMI, one process per GPU; librccl is
+ * bound at run time (a host without it gets SL_ERR_UNSUPPORTED from these calls and everything else keeps working).
+ *   sl_comm_unique_id : rank 0 draws the 128-byte RCCL id; the caller carries it to the other ranks over whatever channel launched
+ *                       them (torchrun's store, MPI, a file) — the library opens no sockets of its own.
+ *   sl_comm_init      : collective over `world` processes, each on its own current device; the communicator belongs to that device.
+ *   sl_allreduce_sum  : in place on `count` elements (SL_F32 / SL_BF16) of caller-owned device memory, asynchronous on `stream`
+ *                       (the KD step passes a side stream behind an event on the kernels' stream); same call order on all ranks.
+ *   sl_comm_destroy   : collective; the caller has synchronised the streams it used.
+ * --------------------------------------------------------------------------------------------- */
+#define SL_COMM_ID_BYTES 128
+typedef struct sl_comm_s* sl_comm;
+int sl_comm_unique_id(void* id_out /* SL_COMM_ID_BYTES */);
+int sl_comm_init(sl_comm* comm_out, const void* unique_id /* SL_COMM_ID_BYTES */, int32_t rank, int32_t world);
+int sl_allreduce_sum(sl_comm comm, void* buf, int64_t count, int32_t dtype, sl_stream stream);
+int sl_comm_destroy(sl_comm comm);
+int32_t sl_comm_rank(sl_comm comm);    /* -1: not a communicator */
+int32_t sl_comm_world(sl_comm comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,12 +12,14 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SL_LIB_PATH: developer switch for A/B runs of two builds of the library (tools/); the product loads the in-tree build
-LIB_PATH = os.environ.get("SL_LIB_PATH") or os.path.join(_HERE, "libspeechllm.so")
+# The product loads the in-tree build.  SL_LIB_PATH (A/B runs of two builds, tools/) is honoured only together with SL_DEV=1, and
+# bench.py records the resolved path in its JSON line (`native_library`), so a foreign build can never pass for the in-tree one.
+LIB_PATH = (os.environ.get("SL_LIB_PATH") if os.environ.get("SL_DEV") == "1" else None) or os.path.join(_HERE, "libspeechllm.so")
 
 SL_F32, SL_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU_MUL, ACT_ROPE_KV = 0, 1, 2, 3
 W_ROWMAJOR, W_PACKED = 0, 1
+COMM_ID_BYTES = 128          # SL_COMM_ID_BYTES = sizeof(ncclUniqueId)
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -157,6 +159,12 @@ _PROTOS = {
     "sl_decode_graph_cache_clear": (c_i32, []),
     "sl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "sl_gemm_streamk_workspace_bytes": (C.c_size_t, []),
+    "sl_comm_unique_id": (c_i32, [c_vp]),
+    "sl_comm_init": (c_i32, [C.POINTER(c_vp), c_vp, c_i32, c_i32]),
+    "sl_allreduce_sum": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "sl_comm_destroy": (c_i32, [c_vp]),
+    "sl_comm_rank": (c_i32, [c_vp]),
+    "sl_comm_world": (c_i32, [c_vp]),
     "sl_pack_weight": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "sl_gemm_fused_decode": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmFused), c_vp]),
     "sl_gemm_split_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),

@@ -186,6 +186,15 @@ int main() {
   }
   EXPECT(sl_decode_graph_cache_clear() == 0, "nothing cached on this thread");
 
+  {   // collective group: argument checks only (no device here)
+    sl_comm c = nullptr;
+    unsigned char id[SL_COMM_ID_BYTES] = {0};
+    EXPECT(sl_comm_unique_id(nullptr) == SL_ERR_ARG, "sl_comm_unique_id(null)");
+    EXPECT(sl_comm_init(nullptr, id, 0, 1) == SL_ERR_ARG, "sl_comm_init(null out)");
+    EXPECT(sl_comm_init(&c, id, 2, 2) == SL_ERR_ARG && c == nullptr, "sl_comm_init(rank >= world)");
+    EXPECT(sl_allreduce_sum(nullptr, id, 4, SL_F32, nullptr) == SL_ERR_ARG, "sl_allreduce_sum(no communicator)");
+    EXPECT(sl_comm_destroy(nullptr) == 0 && sl_comm_rank(nullptr) == -1 && sl_comm_world(nullptr) == -1, "sl_comm_destroy(null) is a no-op");
+  }
   if (g_fail == 0) printf("argcheck ok\n");
   return g_fail == 0 ? 0 : 1;
 }

@@ -92,11 +92,19 @@ class BucketedAllReduce:
     latency.  On CPU tensors (gloo, used by the tests) the same code runs without streams.
     """
 
-    def __init__(self, arena: GradArena, group=None, min_bucket_bytes: int = 32 << 20, single_rank: bool = False):
+    def __init__(self, arena: GradArena, group=None, min_bucket_bytes: int = 32 << 20, single_rank: bool = False, backend: str = "auto"):
         import torch.distributed as dist
         self.dist = dist
         self.arena = arena
         self.group = group
+        # backend "sl": the collective is the library's own RCCL binding (sl_comm_init / sl_allreduce_sum, include/speechllm.h group 11),
+        # launched on the side stream on a slice pointer of the arena; "torch": torch.distributed's all_reduce on the same slice (gloo on
+        # CPU tensors — the tests here — or nccl).  "auto" = "sl" for device arenas in an nccl process group, unless SL_COMM_BACKEND=torch.
+        self.backend = backend
+        if backend == "auto":
+            use_sl = (arena.flat.is_cuda and dist.is_initialized() and dist.get_backend(group) == "nccl" and os.environ.get("SL_COMM_BACKEND", "sl") != "torch")
+            self.backend = "sl" if use_sl else "torch"
+        self.comm = None
         # single_rank: issue the collectives even in a group of one (identity sums) — how tests/test_dp_gpu.py drives the
         # RCCL backend, its streams and events on a one-GPU box
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -111,6 +119,44 @@ class BucketedAllReduce:
         self.stream = torch.cuda.Stream(device=arena.flat.device) if (self.cuda and self.world > 1) else None
         self.bucket_log: List[tuple] = []     # (start, end) element ranges of the buckets launched so far in this step
         self.last_buckets: List[tuple] = []   # ... of the previous optimizer step
+        if self.backend == "sl" and self.world > 1:
+            self._init_sl_comm()
+
+    def _init_sl_comm(self) -> None:
+        """One RCCL communicator per process (= per GPU) through the C ABI: rank 0 draws the unique id (sl_comm_unique_id), the
+        existing process group — torchrun's rendezvous — carries its 128 bytes to the other ranks, every rank calls sl_comm_init."""
+        import ctypes as C
+        from . import _lib as L
+        dist = self.dist
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        ident = torch.zeros(L.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * L.COMM_ID_BYTES)()
+            L.check(L.lib().sl_comm_unique_id(buf), "sl_comm_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            dev_id = ident.to(self.arena.flat.device)          # an nccl group moves device tensors
+            dist.broadcast(dev_id, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            ident = dev_id.cpu()
+        raw = (C.c_ubyte * L.COMM_ID_BYTES)(*ident.tolist())
+        handle = C.c_void_p()
+        with torch.cuda.device(self.arena.flat.device):
+            L.check(L.lib().sl_comm_init(C.byref(handle), raw, rank, world), "sl_comm_init")
+        self.comm = handle
+
+    def close(self) -> None:
+        if self.comm is not None:
+            from . import _lib as L
+            torch.cuda.synchronize(self.arena.flat.device)
+            L.check(L.lib().sl_comm_destroy(self.comm), "sl_comm_destroy")
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def ready(self, names: Sequence[str]) -> None:
         """Mark gradient buffers as final for this optimizer step; launches a bucket once the final prefix is large enough."""
@@ -130,7 +176,15 @@ class BucketedAllReduce:
         chunk = self.arena.flat[self._sent:upto]
         self.bucket_log.append((self._sent, upto))
         self._sent = upto
-        if self.cuda:
+        if self.cuda and self.comm is not None:
+            from . import _lib as L
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)                         # the bucket's gradients are complete on the kernels' stream
+            with torch.cuda.device(self.arena.flat.device):
+                L.check(L.lib().sl_allreduce_sum(self.comm, chunk.data_ptr(), chunk.numel(), L.SL_F32, self.stream.cuda_stream), "sl_allreduce_sum")
+            work = None                                        # ordered on the side stream; finish() joins the streams
+        elif self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -156,7 +210,8 @@ class BucketedAllReduce:
         if self.cuda and self.stream is not None:
             with torch.cuda.stream(self.stream):
                 for work in self._pending:
-                    work.wait()
+                    if work is not None:
+                        work.wait()
             torch.cuda.current_stream().wait_stream(self.stream)
         else:
             for work in self._pending:

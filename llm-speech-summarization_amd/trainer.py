@@ -68,7 +68,10 @@ class Trainer():
         if self.train_dataset is None:
             self.get_dataloaders()
         self.step, self.start_epoch = 0, 0
-        self.grad_accum_interval = int(config.train.grad_accum_interval)
+        # samples per optimizer step over all ranks: grad_accum_interval (reference-equivalent strong scaling) or, with the new key
+        # train.per_rank_accum = k, k x world (weak scaling: every rank keeps k samples per step) — training.effective_accum
+        from .training import effective_accum
+        self.grad_accum_interval = effective_accum(config.train, self.world)[0]
         self.num_epochs = int(config.train.epochs)
         prefix, suffix = prompt_template(self.llm_type)
         self.prefix_ids = self.tokenizer(prefix, return_tensors="pt").input_ids

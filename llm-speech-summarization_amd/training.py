@@ -822,6 +822,24 @@ class FusedAdamW:
 # ------------------------------------------------------------------------------------------------
 # the KD step
 # ------------------------------------------------------------------------------------------------
+def effective_accum(train_cfg, world: int):
+    """(samples per optimizer step over all ranks, samples per optimizer step on one rank).
+    Default (strong scaling, equal to the reference's single-GPU run): `grad_accum_interval` samples per step (ref:config/
+    llama3_hubert.yaml:34, ref:trainer.py:373-377) dealt to the ranks, grad_accum_interval / world each.
+    `train.per_rank_accum: k` (new key, weak scaling): every rank packs k samples per step, so a step averages k x world samples —
+    the per-rank GEMMs keep the row counts of the single-GPU run (k = 16: ~3 200 / 5 072 rows instead of ~400 / 634 at 8 ranks),
+    the optimizer sees a `world` times larger batch and the PolynomialLR horizon (total steps = epochs x samples / (k x world),
+    ref:trainer.py:106-110) shrinks accordingly; each loss is divided by k x world where the reference divides by
+    grad_accum_interval (ref:trainer.py:373)."""
+    k = int(getattr(train_cfg, "per_rank_accum", 0) or 0)
+    if k > 0:
+        return k * world, k
+    accum = int(train_cfg.grad_accum_interval)
+    if accum % world:
+        raise L.SpeechLLMError(f"grad_accum_interval={accum} must be a multiple of the world size {world} (or set train.per_rank_accum)")
+    return accum, accum // world
+
+
 class KDTrainer:
     """ref:trainer.py:23-398 restricted to the optimisation step: losses, backward, accumulation, AdamW + PolynomialLR,
     and (new) data parallelism: rank r runs `grad_accum_interval / world` micro-steps per optimizer step, gradients are
@@ -834,14 +852,11 @@ class KDTrainer:
         self.ntp_w, self.ld_w, self.fd_w = tr.ntp_loss_weight, tr.ld_loss_weight, tr.fd_loss_weight
         self.use_ld, self.use_fd = bool(tr.use_ld_loss), bool(tr.use_fd_loss)
         self.taps = list(tr.fd_loss_connector_layers)
-        self.accum = int(tr.grad_accum_interval)
         self.pg = process_group
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        if self.accum % self.world:
-            raise L.SpeechLLMError(f"grad_accum_interval={self.accum} must be a multiple of the world size {self.world}")
-        self.local_accum = self.accum // self.world
+        self.accum, self.local_accum = effective_accum(tr, self.world)
         dev = encoder.device
         self.prefix_ids, self.suffix_ids = prefix_ids.to(dev), suffix_ids.to(dev)
         self.is_whisper = getattr(encoder, "encoder_base", "hubert") == "whisper"

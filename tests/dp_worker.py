@@ -50,7 +50,7 @@ def main():
                                model=dict(audio_encoder=dict(base="hubert", type="synthetic", downsample_method="pool", downsample_factor=4,
                                                              pooling=dict(kernel_size=8, stride=4)),
                                           llm_embedding_channels=TINY_LLAMA.hidden_size, llm_type=utils.LLAMA_ID),
-                               train=dict(optimizer=dict(lr=5e-5, beta1=0.9, beta2=0.999), batch_size=1, grad_accum_interval=accum, epochs=1,
+                               train=dict(optimizer=dict(lr=5e-5, beta1=0.9, beta2=0.999), batch_size=1, grad_accum_interval=accum, epochs=1, **({"per_rank_accum": int(os.environ["DP_PER_RANK_ACCUM"])} if os.environ.get("DP_PER_RANK_ACCUM") else {}),
                                           use_ld_loss=True, use_fd_loss=True, ntp_loss_weight=0.5, ld_loss_weight=0.5, fd_loss_weight=1.0,
                                           fd_loss_connector_layers=[0, 1, 3]),
                                log=dict(checkpoint_dir=os.path.join(workdir, f"ckpt_w{world}"), log_dir=os.path.join(workdir, f"logs_w{world}"),

@@ -88,6 +88,31 @@ def test_two_rank_trainer_equals_single_rank(tmp_path):
             assert abs(r["val"][key] - one["val"][key]) < 1e-5 * one["val"][key], (key, r["val"][key], one["val"][key])
 
 
+def test_weak_scaling_mode_per_rank_accum(tmp_path):
+    """`train.per_rank_accum: k` (weak scaling, new key): every rank packs k samples per optimizer step, a step averages k x world
+    samples.  Two ranks x k = 8 must therefore reproduce the single-rank run at grad_accum_interval = 16 — same windows, same
+    1 / 16 loss scale, same gradients and masters — although the config's own grad_accum_interval says 4 (ignored in this mode);
+    and the single-rank run of that very config steps every 8 samples (k x 1)."""
+    n_rows = 17
+    port = 29650 + os.getpid() % 300
+    (one,) = _run(1, str(tmp_path), n_rows, 16, port)
+    two = _run(2, str(tmp_path), n_rows, 4, port + 1, extra_env={"DP_PER_RANK_ACCUM": "8"}, tag="_weak")
+    assert two[0]["windows"] == one["windows"] and [len(w) for w in one["windows"]] == [16, 1]
+    for r in two:
+        assert r["optimizer_steps"] == one["optimizer_steps"] == 2 and r["lr"] == one["lr"]
+    for s in range(2):
+        for r in two:
+            num = sum(float((r["grads"][s][k].double() - one["grads"][s][k].double()).pow(2).sum()) for k in one["grads"][s])
+            den = sum(float(one["grads"][s][k].double().pow(2).sum()) for k in one["grads"][s])
+            assert (num / den) ** 0.5 < GRAD_TOL, (s, r["rank"], (num / den) ** 0.5)
+    for k in one["master"]:
+        assert torch.equal(two[0]["master"][k], two[1]["master"][k]), k
+        if not k.endswith("k_proj.bias"):
+            assert rel_err(two[0]["master"][k], one["master"][k]) < MASTER_TOL, k
+    (solo,) = _run(1, str(tmp_path), n_rows, 4, port + 2, extra_env={"DP_PER_RANK_ACCUM": "8"}, tag="_weak_solo")
+    assert [len(w) for w in solo["windows"]] == [8, 8, 1] and solo["optimizer_steps"] == 3
+
+
 def test_ranks_that_start_from_different_weights_are_brought_to_rank0s(tmp_path):
     """Every rank applies the same all-reduced gradient, so every rank must start from the same weights: rank 1 is
     handed a differently seeded encoder; after `Trainer.__init__` its fp32 masters AND the kernels' device copies equal rank 0's bit
@@ -133,3 +158,41 @@ def test_rccl_backend_single_rank_runs_the_bucketed_exchange(tmp_path):
         assert rel_err(rccl["master"][k], plain["master"][k]) < MASTER_TOL, k
     for key in ("validation/audio_perplexity", "validation/text_perplexity"):
         assert abs(rccl["val"][key] - plain["val"][key]) < 1e-5 * plain["val"][key]
+
+
+def test_sl_comm_c_abi_one_rank_communicator_orders_against_the_compute_stream():
+    """include/speechllm.h group 11 driven directly: sl_comm_unique_id -> sl_comm_init (a communicator of one rank: RCCL refuses two
+    ranks per device) -> sl_allreduce_sum in place on slices of a device buffer, on a SIDE stream behind an event recorded on the stream
+    that produced the data -> the producer stream waits for the side stream -> sl_comm_destroy.  Identity sums: the buffer must hold
+    exactly what the producer wrote (fp32 and bf16), including a slice that the producer finishes only just before the collective."""
+    import ctypes as C
+    import importlib
+    L = importlib.import_module("llm-speech-summarization_amd._lib")
+    lib = L.lib()
+    dev = torch.device("cuda:0")
+    ident = (C.c_ubyte * L.COMM_ID_BYTES)()
+    L.check(lib.sl_comm_unique_id(ident), "sl_comm_unique_id")
+    assert any(ident)
+    comm = C.c_void_p()
+    L.check(lib.sl_comm_init(C.byref(comm), ident, 0, 1), "sl_comm_init")
+    assert lib.sl_comm_rank(comm) == 0 and lib.sl_comm_world(comm) == 1 and lib.sl_comm_rank(None) == -1
+    side = torch.cuda.Stream(device=dev)
+    for dt, code in ((torch.float32, L.SL_F32), (torch.bfloat16, L.SL_BF16)):
+        n = 8 << 20
+        buf = torch.zeros(n, device=dev, dtype=dt)
+        src = torch.randn(n, device=dev).to(dt)
+        for lo, hi in ((0, n // 3), (n // 3, n)):
+            big = torch.randn(4096, 4096, device=dev)
+            for _ in range(4):
+                big = big @ big * 1e-3                 # keeps the compute stream busy in front of the copy
+            buf[lo:hi].copy_(src[lo:hi])
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            L.check(lib.sl_allreduce_sum(comm, buf[lo:hi].data_ptr(), hi - lo, code, side.cuda_stream), "sl_allreduce_sum")
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(buf, src)
+    assert lib.sl_allreduce_sum(comm, 0, 16, L.SL_F32, side.cuda_stream) != 0 and b"bad buffer" in lib.sl_last_error()
+    assert lib.sl_allreduce_sum(None, buf.data_ptr(), 16, L.SL_F32, side.cuda_stream) != 0
+    torch.cuda.synchronize()
+    L.check(lib.sl_comm_destroy(comm), "sl_comm_destroy")

@@ -315,7 +315,7 @@ def test_ctypes_prototypes_have_the_header_arity_and_scalar_widths():
         params = [p_.strip() for p_ in decls[name].split(",")] if decls[name].strip() not in ("", "void") else []
         assert len(params) == len(argtypes), (name, len(params), len(argtypes))
         for prm, at in zip(params, argtypes):
-            is_ptr = "*" in prm or prm.split()[0] == "sl_stream"
+            is_ptr = "*" in prm or prm.split()[0] in ("sl_stream", "sl_comm")     # opaque handles are pointers
             if is_ptr:
                 assert at in (C.c_void_p, C.c_char_p) or hasattr(at, "contents") or issubclass(at, C._Pointer), (name, prm, at)
             else:
@@ -350,6 +350,29 @@ def test_epoch_windows_are_dealt_disjointly_and_cover_the_epoch_at_any_world_siz
         assert shares[1][0] == [i for w in stub._epoch_windows(3) for i in w]
     c = trainer_mod.Trainer._crossed
     assert c(0, 16, 16) and c(15, 17, 16) and not c(16, 31, 16) and c(16, 32, 16) and c(0, 16, 10) and c(16, 32, 30) and not c(0, 16, 0)
+
+
+def test_weak_scaling_key_per_rank_accum_sets_the_window_and_the_per_rank_share():
+    """`train.per_rank_accum: k` (new; weak scaling of the KD step, DESIGN §7): a step averages k x world samples, each rank packs k;
+    without the key the reference's grad_accum_interval is dealt to the ranks (strong scaling) and must divide by the world size."""
+    from types import SimpleNamespace
+    tr = pkg("training")
+    cfg = pkg("config")
+    strong = cfg.from_dict(dict(grad_accum_interval=16))
+    assert [tr.effective_accum(strong, w) for w in (1, 2, 8)] == [(16, 16), (16, 8), (16, 2)]
+    with pytest.raises(Exception):
+        tr.effective_accum(strong, 3)
+    weak = cfg.from_dict(dict(grad_accum_interval=16, per_rank_accum=16))
+    assert [tr.effective_accum(weak, w) for w in (1, 2, 3, 8)] == [(16, 16), (32, 16), (48, 16), (128, 16)]
+    assert tr.effective_accum(SimpleNamespace(grad_accum_interval=16, per_rank_accum=0), 4) == (16, 4)
+    # the Trainer's windows follow: 8 ranks x 16 = windows of 128 samples, 16 to every rank
+    trainer_mod = pkg("trainer")
+    for rank in range(8):
+        stub = SimpleNamespace(config=SimpleNamespace(seed_everything=7), train_dataset=list(range(300)), grad_accum_interval=tr.effective_accum(weak, 8)[0],
+                               rank=rank, world=8)
+        stub._epoch_windows = lambda e, s=stub: trainer_mod.Trainer._epoch_windows(s, e)
+        wins = stub._epoch_windows(0)
+        assert [len(w) for w in wins] == [128, 128, 44] and all(len(w[rank::8]) == 16 for w in wins[:2])
 
 
 def test_reference_param_order_matches_hf_parameters_and_weight_norm_renaming():
