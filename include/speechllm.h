@@ -172,6 +172,11 @@ int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream strea
 size_t sl_gemm_streamk_workspace_bytes(void);
 /* 1 when sl_gemm_ex takes ln_* / stats_out for a plain (M, N, K) product of this dtype, else 0 */
 int32_t sl_gemm_ln_fold_ok(int32_t M, int32_t N, int32_t K, int32_t dtype);
+/* The weight side of that fold for one Linear W (N, K) behind LayerNorm(gain, beta) (hf:models/hubert/modeling_hubert.py:515-517,612):
+ * Wf = W with the gain multiplied into its columns, rounded to the storage type once; u[n] = sum_k Wf[n][k] (of the rounded values);
+ * c[n] = sum_k W[n][k] beta[k] + bias[n] (bias may be NULL) — the ln_u / ln_c vectors and the weight a consumer GEMM takes. */
+int sl_layernorm_fold_build(const void* W, const void* gain, const void* beta, const void* bias, void* Wf, float* u, float* c, int32_t N,
+                            int32_t K, int32_t dtype, sl_stream stream);
 /* {mean, rstd} per row from the per-segment {sum, sum of squares} a stats_out GEMM left ([rows][segs][2] floats, cols = 64 * segs
  * elements per row): mr[2 m] = mean, mr[2 m + 1] = rsqrt(max(E[x^2] - mean^2, 0) + eps); segments summed in order. */
 int sl_layernorm_stats_finalize(const float* stats, int32_t segs, int64_t rows, int32_t cols, float eps, float* mr, sl_stream stream);
@@ -398,6 +403,13 @@ int sl_layernorm_bwd_ws(const void* x, const void* gamma, const void* beta, cons
 /* LlamaRMSNorm backward, data gradient only (the LLM is frozen, ref:trainer.py:63-64). */
 int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps,
                    int32_t dtype, sl_stream stream);
+/* Weight-norm backward of the positional conv (hf:models/hubert/modeling_hubert.py:50-68, weight_norm(dim = 2): W[h][j][t] =
+ * g[t] v[h][j][t] / ||v[:, :, t]||; ref:trainer.py:373-384 steps on g and v).  dW_khg: the tape's gradient of the folded weight in
+ * the kernel layout (H, k, Hg) fp32; v (H, Hg, k), g (k) fp32 masters; writes dg (k) and dv (H, Hg, k).  workspace:
+ * sl_weight_norm_bwd_workspace_bytes(k) bytes.  Fixed summation order (reproducible). */
+size_t sl_weight_norm_bwd_workspace_bytes(int32_t k);
+int sl_weight_norm_bwd(const float* dW_khg, const float* v, const float* g, float* dg, float* dv, float* workspace, int32_t H, int32_t Hg,
+                       int32_t k, sl_stream stream);
 /* out[c] += sum_r x[r][c]  (bias gradients), fp32 accumulate. */
 int sl_colsum(const void* x, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t dtype, sl_stream stream);
 /* Explicit softmax over rows of fp32 scores (n_mats matrices of rows x cols, row stride ld):

@@ -159,6 +159,9 @@ _PROTOS = {
     "sl_decode_graph_cache_clear": (c_i32, []),
     "sl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "sl_gemm_streamk_workspace_bytes": (C.c_size_t, []),
+    "sl_layernorm_fold_build": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "sl_weight_norm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "sl_weight_norm_bwd_workspace_bytes": (C.c_size_t, [c_i32]),
     "sl_comm_unique_id": (c_i32, [c_vp]),
     "sl_comm_init": (c_i32, [C.POINTER(c_vp), c_vp, c_i32, c_i32]),
     "sl_allreduce_sum": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),

@@ -202,10 +202,18 @@ __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __r
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const float2* s = (const float2*)stats + row * segs;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < segs; ++i) { const float2 v = s[i]; s1 += v.x; s2 += v.y; }
+  float s1 = 0.f;
+  for (int i = 0; i < segs; ++i) s1 += s[i].x;
   const float mean = s1 / (float)cols;
-  float var = s2 / (float)cols - mean * mean;
+  // segments merged the way Chan et al. merge partial variances: M2 = sum_s [ (sumsq_s - sum_s^2 / 64) + 64 (mean_s - mean)^2 ] — the
+  // one-pass E[x^2] - mean^2 over the whole row cancels catastrophically once |mean| >> std; here only a segment's own 64 values do
+  float m2 = 0.f;
+  for (int i = 0; i < segs; ++i) {
+    const float2 v = s[i];
+    const float ms = v.x * (1.0f / 64.0f), d = ms - mean;
+    m2 += (v.y - v.x * ms) + 64.0f * d * d;
+  }
+  float var = m2 / (float)cols;
   var = var > 0.f ? var : 0.f;
   ((float2*)mr)[row] = make_float2(mean, rsqrtf(var + eps));
 }
@@ -259,5 +267,46 @@ extern "C" int sl_layernorm_stats(const void* x, int64_t rows, int32_t cols, flo
     hipLaunchKernelGGL((ln_rowstats_kernel<T>), dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, rows, cols, eps, mr);
   });
   SL_CHECK_LAUNCH("ln_rowstats");
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm fold, weight side (sl_hubert_fold's tensors): for a Linear W (N, K) behind LayerNorm(gain, beta)
+//   Wf[n][k] = round_T(W[n][k] * gain[k]),   u[n] = sum_k float(Wf[n][k]),   c[n] = sum_k W[n][k] * beta[k] + bias[n]
+// One wave per output row, fp32 sums in a fixed order (lane-strided, then the wave tree).  Replaces three torch launches per tensor
+// (an element-wise product, a row reduction and a vendor GEMV) that ran after every optimizer step followed by an inference encode.
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_build_kernel(const T* __restrict__ W, const T* __restrict__ gain, const T* __restrict__ beta,
+                                                            const T* __restrict__ bias, T* __restrict__ Wf, float* __restrict__ u, float* __restrict__ c,
+                                                            int N, int K) {
+  constexpr int VEC = Vec16<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float su = 0.f, sc = 0.f;
+  for (int k = lane * VEC; k < K; k += 64 * VEC) {
+    float w[VEC], g[VEC], b[VEC], f[VEC];
+    Vec16<T>::unpack(*(const uint4*)(W + (int64_t)n * K + k), w);
+    Vec16<T>::unpack(*(const uint4*)(gain + k), g);
+    Vec16<T>::unpack(*(const uint4*)(beta + k), b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { f[e] = to_f32(from_f32<T>(w[e] * g[e])); su += f[e]; sc = fmaf(w[e], b[e], sc); }
+    *(uint4*)(Wf + (int64_t)n * K + k) = Vec16<T>::pack(f);
+  }
+  su = wave_sum(su); sc = wave_sum(sc);
+  if (lane == 0) { u[n] = su; c[n] = sc + (bias ? to_f32(bias[n]) : 0.f); }
+}
+
+extern "C" int sl_layernorm_fold_build(const void* W, const void* gain, const void* beta, const void* bias, void* Wf, float* u, float* c, int32_t N,
+                                       int32_t K, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(W && gain && beta && Wf && u && c && N > 0 && K > 0, "sl_layernorm_fold_build: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(K % vec == 0, "sl_layernorm_fold_build: K=%d must be a multiple of %d", K, vec);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((ln_fold_build_kernel<T>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)W, (const T*)gain, (const T*)beta,
+                       (const T*)bias, (T*)Wf, u, c, N, K);
+  });
+  SL_CHECK_LAUNCH("ln_fold_build");
   return 0;
 }

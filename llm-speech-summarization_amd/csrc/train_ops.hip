@@ -1384,3 +1384,73 @@ extern "C" int sl_adamw_step(const sl_adamw_tensor* tensors_dev, const int64_t* 
   SL_CHECK_LAUNCH("adamw_multi");
   return 0;
 }
+
+// ----------------------------------------------------------------------------------------------
+// Weight-norm backward of the positional conv (hf:models/hubert/modeling_hubert.py:50-68 wraps the conv in weight_norm(dim = 2):
+// W[h][j][t] = g[t] v[h][j][t] / ||v[:, :, t]||).  The tape leaves dW in the kernel layout (H, k, Hg) fp32; the optimizer wants
+//   d g[t] = <dW[:, :, t], v[:, :, t]> / ||v_t||,     d v = (g / ||v_t||) (dW - v <dW_t, v_t> / ||v_t||^2)     in v's (H, Hg, k) layout.
+// Two launches, fixed summation order: per-block partial {||v_t||^2, <dW_t, v_t>} over a run of h (the (k, Hg) slab of dW turned
+// through LDS so both tensors are read in whole lines), then every block sums the partial records in block order and finishes its
+// run.  Replaces six torch element-wise / reduction launches and a permuted copy per optimizer step.
+// ----------------------------------------------------------------------------------------------
+constexpr int WN_BLOCKS = 64;
+
+template <bool FINISH>
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dWk, const float* __restrict__ v, const float* __restrict__ g,
+                                                              float* __restrict__ dg, float* __restrict__ dv, float* __restrict__ ws, int H, int Hg, int k) {
+  extern __shared__ float wn_lds[];          // [k][Hg + 1] slab of dW, then 2 k totals
+  const int tid = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  const int h0 = (int)((int64_t)H * b / nb), h1 = (int)((int64_t)H * (b + 1) / nb);
+  const int pitch = Hg + 1;
+  float* tot = wn_lds + k * pitch;
+  if constexpr (FINISH) {
+    for (int i = tid; i < 2 * k; i += 256) {
+      float s_ = 0.f;
+      for (int bb = 0; bb < nb; ++bb) s_ += ws[(int64_t)bb * 2 * k + i];
+      tot[i] = s_;
+    }
+    __syncthreads();
+    if (b == 0)
+      for (int t = tid; t < k; t += 256) dg[t] = tot[k + t] * rsqrtf(tot[t]);
+  }
+  float n2 = 0.f, dt_ = 0.f;                  // thread t < k: tap t's sums over this block's rows
+  for (int h = h0; h < h1; ++h) {
+    __syncthreads();
+    for (int i = tid; i < k * Hg; i += 256) wn_lds[(i / Hg) * pitch + (i % Hg)] = dWk[(int64_t)h * k * Hg + i];
+    __syncthreads();
+    if constexpr (!FINISH) {
+      if (tid < k) {
+        for (int j = 0; j < Hg; ++j) {
+          const float vv = v[((int64_t)h * Hg + j) * k + tid];
+          n2 = fmaf(vv, vv, n2);
+          dt_ = fmaf(wn_lds[tid * pitch + j], vv, dt_);
+        }
+      }
+    } else {
+      for (int i = tid; i < Hg * k; i += 256) {
+        const int j = i / k, t = i % k;
+        const float inv = rsqrtf(tot[t]);
+        const float vv = v[((int64_t)h * Hg + j) * k + t];
+        dv[((int64_t)h * Hg + j) * k + t] = g[t] * inv * (wn_lds[t * pitch + j] - vv * tot[k + t] * inv * inv);
+      }
+    }
+  }
+  if constexpr (!FINISH) {
+    if (tid < k) { ws[(int64_t)b * 2 * k + tid] = n2; ws[(int64_t)b * 2 * k + k + tid] = dt_; }
+  }
+}
+
+extern "C" size_t sl_weight_norm_bwd_workspace_bytes(int32_t k) { return (size_t)WN_BLOCKS * 2 * (size_t)(k > 0 ? k : 0) * sizeof(float); }
+
+extern "C" int sl_weight_norm_bwd(const float* dW_khg, const float* v, const float* g, float* dg, float* dv, float* workspace, int32_t H, int32_t Hg,
+                                  int32_t k, sl_stream stream) {
+  SL_CHECK_ARG(dW_khg && v && g && dg && dv && workspace && H > 0 && Hg > 0 && k > 0 && k <= 256, "sl_weight_norm_bwd: bad arguments (H=%d Hg=%d k=%d)", H, Hg, k);
+  const size_t lds = ((size_t)k * (Hg + 1) + 2 * (size_t)k) * sizeof(float);
+  SL_CHECK_ARG(lds <= 64 * 1024, "sl_weight_norm_bwd: a (k, Hg) slab of %zu bytes does not fit the staging LDS", lds);
+  const int nb = H < WN_BLOCKS ? H : WN_BLOCKS;
+  hipLaunchKernelGGL((weight_norm_bwd_kernel<false>), dim3(nb), dim3(256), lds, (hipStream_t)stream, dW_khg, v, g, dg, dv, workspace, H, Hg, k);
+  SL_CHECK_LAUNCH("weight_norm_bwd (sums)");
+  hipLaunchKernelGGL((weight_norm_bwd_kernel<true>), dim3(nb), dim3(256), lds, (hipStream_t)stream, dW_khg, v, g, dg, dv, workspace, H, Hg, k);
+  SL_CHECK_LAUNCH("weight_norm_bwd (finish)");
+  return 0;
+}

@@ -584,14 +584,22 @@ def kernel_grads_to_state_dict(enc: AudioEncoder, g: Dict[str, torch.Tensor], ma
     out[p + "projection.weight"], out[p + "projection.bias"] = g["fp_w"], g["fp_b"]
     # positional conv: d folded weight (H, Hg, k) -> weight-norm backward (g = original0 (1,1,k), v = original1)
     p = "encoder.encoder.pos_conv_embed.conv."
-    dW = g["pos_w"].view(H, k, Hg).permute(0, 2, 1).contiguous()
     k0 = p + "parametrizations.weight.original0" if p + "parametrizations.weight.original0" in master else p + "weight_g"
     k1 = p + "parametrizations.weight.original1" if p + "parametrizations.weight.original1" in master else p + "weight_v"
-    gw, v = master[k0].float(), master[k1].float()
-    norm = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
-    dot = (dW * v).sum(dim=(0, 1), keepdim=True)
-    out[k0] = dot / norm
-    out[k1] = (gw / norm) * (dW - v * dot / norm.pow(2))
+    gw, v = master[k0], master[k1]
+    if g["pos_w"].is_cuda and g["pos_w"].dtype == torch.float32 and v.dtype == torch.float32 and v.is_contiguous() and k <= 256:
+        # sl_weight_norm_bwd: dW stays in the kernel layout (H, k, Hg); two HIP launches, fixed summation order
+        out[k0], out[k1] = torch.empty_like(gw), torch.empty_like(v)
+        ws = torch.empty(int(L.lib().sl_weight_norm_bwd_workspace_bytes(k)) // 4, device=v.device, dtype=torch.float32)
+        L.check(L.lib().sl_weight_norm_bwd(L.ptr(g["pos_w"]), L.ptr(v), L.ptr(gw.contiguous()), L.ptr(out[k0]), L.ptr(out[k1]), L.ptr(ws), H, Hg, k,
+                                           L.stream_ptr()), "sl_weight_norm_bwd")
+    else:                    # host tensors / probing images of direct_refresh_map (float64 index images): the defining formulas
+        dW = g["pos_w"].view(H, k, Hg).permute(0, 2, 1).contiguous()
+        gw, v = gw.to(dW.dtype), v.to(dW.dtype)
+        norm = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+        dot = (dW * v).sum(dim=(0, 1), keepdim=True)
+        out[k0] = dot / norm
+        out[k1] = (gw / norm) * (dW - v * dot / norm.pow(2))
     out[p + "bias"] = g["pos_b"]
     for li in range(a.num_hidden_layers):
         p, q = f"encoder.encoder.layers.{li}.", f"l{li}."

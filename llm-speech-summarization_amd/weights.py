@@ -313,18 +313,21 @@ def build_layernorm_fold(w) -> None:
         w._fold_t = []
         w._fold = (L.HubertFold * len(w.layer_t))()
     for li, lt in enumerate(w.layer_t):
-        outs = []
-        for wk, bk, gk, bek in (("wqkv", "bqkv", "ln1_g", "ln1_b"), ("w1", "b1", "ln2_g", "ln2_b")):
-            W0 = lt[wk].float()
-            Wf = (W0 * lt[gk].float()[None, :]).to(torch.bfloat16)
-            outs += [Wf, Wf.float().sum(dim=1).contiguous(), (W0 @ lt[bek].float() + lt[bk].float()).contiguous()]
         if first:
+            outs = []
+            for wk in ("wqkv", "w1"):
+                N_ = lt[wk].shape[0]
+                outs += [torch.empty_like(lt[wk]), torch.empty(N_, device=lt[wk].device, dtype=torch.float32), torch.empty(N_, device=lt[wk].device, dtype=torch.float32)]
             w._fold_t.append(outs)
             f = w._fold[li]
             f.wqkv_f, f.uqkv, f.cqkv, f.w1_f, f.u1, f.c1 = (t.data_ptr() for t in outs)
-        else:
-            for dst, src in zip(w._fold_t[li], outs):
-                dst.copy_(src)
+        outs = w._fold_t[li]
+        # one HIP launch per Linear (sl_layernorm_fold_build), in place into the tensors the model struct already points at
+        for j, (wk, bk, gk, bek) in enumerate((("wqkv", "bqkv", "ln1_g", "ln1_b"), ("w1", "b1", "ln2_g", "ln2_b"))):
+            Wd = lt[wk]
+            L.check(L.lib().sl_layernorm_fold_build(L.ptr(Wd), L.ptr(lt[gk]), L.ptr(lt[bek]), L.ptr(lt[bk]), L.ptr(outs[3 * j]), L.ptr(outs[3 * j + 1]),
+                                                    L.ptr(outs[3 * j + 2]), Wd.shape[0], Wd.shape[1], L.dtype_code(Wd.dtype), L.stream_ptr()),
+                    "sl_layernorm_fold_build")
     if first:
         w.struct.fold = C.cast(w._fold, C.POINTER(L.HubertFold))
 

@@ -951,3 +951,33 @@ def test_gemm_layernorm_fold_is_bit_identical_across_tile_kernels(tuning):
     turned = run(M)                    # 256-tile kernel, rows epilogue
     for x, y, z in zip(big, turned, small):
         assert torch.equal(x, y) and torch.equal(x[:300], z)
+
+
+def test_layernorm_fold_build_and_finalize_with_a_dc_offset():
+    """sl_layernorm_fold_build (the weight side of the LayerNorm fold, one HIP launch per Linear instead of torch's product + row
+    reduction + vendor GEMV) against its defining formulas; and sl_layernorm_stats_finalize on rows whose mean is 30 x their standard
+    deviation (segments merged Chan-style: the row-wide E[x^2] - mean^2 it replaces loses three digits there) against the two-pass
+    statistics of the same rows."""
+    dt = torch.bfloat16
+    N, K = 3072, 1024
+    W, g, b, bias = rnd(N, K, seed=301, std=K ** -0.5), 1.0 + rnd(K, seed=302, std=0.1), rnd(K, seed=303, std=0.1), rnd(N, seed=304)
+    Wd, gd, bd, biasd = (t.to(dev(), dt) for t in (W, g, b, bias))
+    Wf, u, c = torch.empty_like(Wd), torch.empty(N, device=dev()), torch.empty(N, device=dev())
+    L.check(L.lib().sl_layernorm_fold_build(L.ptr(Wd), L.ptr(gd), L.ptr(bd), L.ptr(biasd), L.ptr(Wf), L.ptr(u), L.ptr(c), N, K, L.dtype_code(dt), L.stream_ptr()),
+            "sl_layernorm_fold_build")
+    W0 = Wd.float()
+    ref_wf = (W0 * gd.float()[None, :]).to(dt)
+    assert torch.equal(Wf, ref_wf)
+    assert rel_err(u.cpu(), ref_wf.float().sum(dim=1).cpu()) < 1e-6
+    assert rel_err(c.cpu(), (W0 @ bd.float() + biasd.float()).cpu()) < 1e-6
+    # finalize under a DC offset: 1024-wide rows, mean 30, std 1, values as a bf16 producer stores them
+    rows, cols = 4096, 1024
+    x = (30.0 + rnd(rows, cols, seed=305)).to(dt)
+    xf = x.float()
+    segs = cols // 64
+    st = torch.stack([xf.view(rows, segs, 64).sum(-1), (xf * xf).view(rows, segs, 64).sum(-1)], dim=-1).contiguous().to(dev())
+    mr = ops.layernorm_stats_finalize(st, cols, 1e-5).cpu()
+    mean = xf.double().mean(dim=1)
+    rstd = 1.0 / torch.sqrt(xf.double().var(dim=1, unbiased=False) + 1e-5)
+    assert float((mr[:, 0].double() - mean).abs().max()) < 1e-4
+    assert float(((mr[:, 1].double() - rstd) / rstd).abs().max()) < 2e-3        # E[x^2] - mean^2 over the whole row: ~2e-2 here

@@ -407,3 +407,29 @@ def test_fused_adamw_equals_torch_optim_adamw():
         assert float(dst_bf16[:64].abs().max()) == 0 and float(dst_odd[:3].abs().max()) == 0
     # the state is torch's own: the reference optimizer loads it
     ref_opt.load_state_dict(my_opt.state_dict())
+
+
+def test_weight_norm_backward_of_the_positional_conv_vs_autograd():
+    """sl_weight_norm_bwd: d g and d v of W = g v / ||v|| (norm over all but the tap axis, hf weight_norm(dim = 2)) from the tape's
+    gradient of the folded weight in the kernel layout (H, k, Hg), against autograd through torch's own parametrisation formula;
+    HuBERT-large's shape and an odd one; bitwise reproducible."""
+    import importlib
+    L_ = importlib.import_module("llm-speech-summarization_amd._lib")
+    for H, Hg, k in ((1024, 64, 128), (48, 12, 16)):
+        gen = torch.Generator().manual_seed(H + k)
+        v = torch.randn(H, Hg, k, generator=gen, dtype=torch.float64).requires_grad_()
+        g = (1.0 + 0.1 * torch.randn(1, 1, k, generator=gen, dtype=torch.float64)).requires_grad_()
+        dW = torch.randn(H, Hg, k, generator=gen, dtype=torch.float64)
+        W = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+        W.backward(dW)
+        dWk = dW.permute(0, 2, 1).contiguous().float().cuda()            # the tape's layout (H, k, Hg)
+        vd, gd = v.detach().float().cuda(), g.detach().float().cuda()
+        ws = torch.empty(int(L_.lib().sl_weight_norm_bwd_workspace_bytes(k)) // 4, device="cuda")
+        outs = []
+        for _ in range(2):
+            dg, dv = torch.empty_like(gd), torch.empty_like(vd)
+            L_.check(L_.lib().sl_weight_norm_bwd(L_.ptr(dWk), L_.ptr(vd), L_.ptr(gd), L_.ptr(dg), L_.ptr(dv), L_.ptr(ws), H, Hg, k, L_.stream_ptr()), "sl_weight_norm_bwd")
+            outs.append((dg.cpu(), dv.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert float((outs[0][0].double() - g.grad).norm() / g.grad.norm()) < 2e-6
+        assert float((outs[0][1].double() - v.grad).norm() / v.grad.norm()) < 2e-6
