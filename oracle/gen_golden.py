@@ -572,6 +572,39 @@ def gen_full_depth(enc_mod, llama_mod, utils):
              audio_embeds_norm=w_embeds.norm(), padded_P=padded.shape[1])
 
 
+def gen_fp16_autocast(enc_mod, llama_mod, utils):
+    """The reference's own precision regime (ref:inference.py:56-57 and ref:trainer.py:252,270: torch autocast to float16 around fp32
+    modules) on the full-depth models of `full_depth_llama32` (same seeds, same utterance): the audio embeddings, the last prompt
+    row of the final hidden state and the first-step logits under `torch.autocast("cpu", dtype=torch.float16)` — the CPU autocast
+    policy of this torch build (Linear / conv / matmul / attention in fp16, normalisations and softmax statistics in fp32), the
+    nearest runnable stand-in for the CUDA policy the reference would meet on a GPU.  The bf16 HIP path is measured against it
+    (tests/test_fullsize_gpu.py): how far the build's precision regime sits from the reference's."""
+    from oracle.llama_oracle import LLAMA32_3B
+    c = LLAMA32_3B
+    z = np.load(os.path.join(OUT, "full_depth_llama32.npz"))
+    llm, _ = build_ref_llama(llama_mod, c, int(z["llm_seed"]))
+    prefix_ids, suffix_ids = torch.from_numpy(z["prefix_ids"]), torch.from_numpy(z["suffix_ids"])
+    tok = StubTokenizer({utils.LLAMA_PROMPT_PREFIX: prefix_ids, utils.LLAMA_PROMPT_SUFFIX: suffix_ids})
+    with torch.no_grad():
+        enc, _ = build_ref_encoder(enc_mod, HubertCfg(), c.hidden_size, seed=int(z["enc_seed"]), method="pool")
+        wave = ri.synthetic_waveform(int(z["n_samples"]), seed=int(z["wave_seed"]))[None]
+        with torch.autocast("cpu", dtype=torch.float16):
+            audio_embeds = enc(wave, ctc_pool_ranges=None)
+        del enc
+        audio32 = audio_embeds.float()
+        seq = utils.merge_prompt_tokens(inputs_embeds=audio32, tokenizer=tok, embed_tokens=llm.model.embed_tokens, llm_type=LLAMA_ID,
+                                        device=torch.device("cpu"))
+        with torch.autocast("cpu", dtype=torch.float16):
+            out = llm(inputs_embeds=seq, output_hidden_states=True)
+        first = out.logits[0, -1].float()
+        hid = out.hidden_states[-1][0, -1].float()
+    save("fp16_autocast_full", enc_seed=int(z["enc_seed"]), llm_seed=int(z["llm_seed"]), wave_seed=int(z["wave_seed"]), n_samples=int(z["n_samples"]),
+         audio_embeds_rows=audio32[0, ::8, ::4], audio_embeds_norm=audio32.norm(), first_logits_every16=first[::16], first_logits_top16=first.topk(16).values,
+         first_logits_top16_idx=first.topk(16).indices, last_hidden_row=hid, argmax=int(first.argmax()),
+         audio_rel_err_vs_fp32=float((audio32[0, ::8, ::4] - torch.from_numpy(z["audio_embeds_rows"])).norm() / torch.from_numpy(z["audio_embeds_rows"]).norm()),
+         logits_rel_err_vs_fp32=float((first[::16] - torch.from_numpy(z["first_logits_every16"])).norm() / torch.from_numpy(z["first_logits_every16"]).norm()))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -593,6 +626,8 @@ def main():
         gen_coldstart(enc_mod)
     if "whisper_wide" in which:
         gen_whisper_wide(enc_mod)
+    if "fp16_autocast" in which:     # needs full_depth_llama32.npz; ~5 minutes (fp16 GEMMs on the CPU)
+        gen_fp16_autocast(enc_mod, llama_mod, utils)
     if "full_depth" in which:        # 13 GB of fp32 LLM weights, ~10 minutes on 8 cores: only on request (`python oracle/gen_golden.py full_depth`)
         gen_full_depth(enc_mod, llama_mod, utils)
 

@@ -452,6 +452,42 @@ def test_whisper_medium_full_depth_fp32_ids_vs_REFERENCE_fixture():
     _check_ids_against_reference(ids, g, got_first)
 
 
+def test_bf16_path_distance_to_the_references_fp16_autocast_regime_full_depth():
+    """The reference computes under fp16 autocast (ref:inference.py:56-57, ref:trainer.py:252,270); this build's performance mode is
+    bf16 storage with fp32 accumulation (documented deviation).  How far apart the two regimes are, measured at FULL depth
+    on the fixture's utterance: tests/golden/fp16_autocast_full.npz holds the reference classes' audio embeddings and first-step
+    logits under torch.autocast(float16) (CPU policy), full_depth_llama32.npz the same in fp32.  Recorded and bounded: the bf16 HIP
+    path against both, next to the references' own fp16-vs-fp32 distance; the greedy token of the first step is the same in all."""
+    import numpy as np
+    h = np.load(os.path.join(REPO, "tests", "golden", "fp16_autocast_full.npz"))
+    g = np.load(os.path.join(REPO, "tests", "golden", "full_depth_llama32.npz"))
+    _SLOT.clear(); torch.cuda.empty_cache()
+    harch, larch = weights.KNOWN_HUBERT["facebook/hubert-large-ls960-ft"], weights.KNOWN_LLAMA[utils.LLAMA_ID]
+    conf = cfgm.load_config(os.path.join(REPO, "config", "llama3_hubert.yaml"))
+    enc = enc_mod.AudioEncoder(conf, DEV, dtype=torch.bfloat16, arch=harch)
+    enc.load_state_dict(ri.hubert_encoder_state_dict(harch, larch.hidden_size, seed=int(h["enc_seed"]))).eval().to(DEV)
+    sd = ri.llama_state_dict(larch, seed=int(h["llm_seed"]))
+    llm = llama_mod.AudioLlamaForCausalLM(larch, sd, torch_dtype=torch.bfloat16, device=DEV, max_ctx=256, max_batch=1)
+    wave = ri.synthetic_waveform(int(h["n_samples"]), seed=int(h["wave_seed"]))
+    audio = enc(wave[None].to(DEV))
+    rows = audio[0, ::8, ::4].float().cpu()
+    a16, a32 = torch.from_numpy(h["audio_embeds_rows"]), torch.from_numpy(g["audio_embeds_rows"])
+    prefix, suffix = torch.from_numpy(g["prefix_ids"]), torch.from_numpy(g["suffix_ids"])
+    emb = llm.model.embed_tokens
+    x = torch.cat([emb(prefix.to(DEV))[0], audio[0], emb(suffix.to(DEV))[0, 1:]])[None]
+    first = llm(inputs_embeds=x).logits[0, -1].float().cpu()
+    l16, l32 = torch.from_numpy(h["first_logits_every16"]), torch.from_numpy(g["first_logits_every16"])
+    d = {"audio: bf16 path vs fp16-autocast reference": rel_err(rows, a16), "audio: bf16 path vs fp32 reference": rel_err(rows, a32),
+         "audio: fp16-autocast vs fp32 reference": float(h["audio_rel_err_vs_fp32"]),
+         "first-step logits: bf16 path vs fp16-autocast reference": rel_err(first[::16], l16), "first-step logits: bf16 path vs fp32 reference": rel_err(first[::16], l32),
+         "first-step logits: fp16-autocast vs fp32 reference": float(h["logits_rel_err_vs_fp32"])}
+    for k, v in d.items():
+        print(f"{k}: {v:.3e}")
+    assert d["audio: bf16 path vs fp16-autocast reference"] < 3e-2 and d["audio: bf16 path vs fp32 reference"] < 3e-2
+    assert d["first-step logits: bf16 path vs fp16-autocast reference"] < FULL_TOL and d["first-step logits: bf16 path vs fp32 reference"] < FULL_TOL
+    assert int(first.argmax()) == int(h["argmax"]) == int(g["ids"][0, 0])      # top-2 margin 0.18 against logit differences of a few 1e-2
+
+
 @pytest.mark.parametrize("B", [1024, 512])
 def test_configs1_decode_step_logits_large_batch_vs_small_batch_and_oracle(llama3, B):
     """The decode step bench.py times (28 layers at Llama-3.2-3B width, bf16): B rows through the 256 x 128 streaming family
