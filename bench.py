@@ -9,11 +9,11 @@ ref:inference.py:95-137), random-init weights of the true shapes, inputs residen
 Prints ONE JSON line (rank 0).  value = generated tokens/s of the whole job (all ranks, all pipeline
 stages inside the timed region); audio_sec_per_s_encoder_alone = throughput of the encoder stage run on its own on the same
 batch (HIP events), audio_sec_per_s_in_pipeline = audio seconds per second of the timed steps; latency_b1 = the reference's
-one-utterance-per-call pattern against the batch-1 HBM ceiling; stage_ms = per-batch wall times inside the timed steps (stages of different batches overlap).  roofline = the decode kernel with the largest share of the step (split attention over the KV cache at
+one-utterance-per-call pattern against the batch-1 HBM ceiling; stage_ms = per-batch wall times inside the timed steps (two batches take turns on the GPU).  roofline = the decode kernel with the largest share of the step (split attention over the KV cache at
 the default batch of 1024, the gate/up weight-streaming GEMM below ~128) against the HBM peak; roofline_other = the other.
 cpu_baseline = the CPU oracle (oracle/*.py, a port of the reference's HF path) on a bounded sample.
 Two batches are in flight per GPU by default (`--pipelines`): host threads with their own HIP stream / KV cache pull
-steps from one counter, so one batch's encode + prefill (MFMA-bound) overlaps another's decode (HBM-bound).
+steps from one counter, so one batch's encode + prefill interleaves with another's decode (worth ~2 %: every kernel fills the chip on its own).
 Multi-GPU: inference shards by utterance, replicas only, no data-path collective (weak scaling).
 """
 from __future__ import annotations
@@ -811,7 +811,7 @@ def main():
     # `traffic` cannot be measured inside this process (PMC counters need rocprofv3 around it): it is READ from the committed
     # counter summary of the same two launches (tools/probe_decode_kernels.py under separate --pmc passes), and says so
     pmc, pmc_src = {}, None
-    for name in ("r03_pmc_decode_kernels.json", "r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):   # newest committed PMC passes first
+    for name in ("r04_pmc_decode_kernels.json", "r03_pmc_decode_kernels.json", "r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):   # newest committed PMC passes first
         pmc_path = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
@@ -859,7 +859,8 @@ def main():
                          "note": "38.46 GFLOP per audio-second at 10 s clips (SURVEY.md §8d)"},
         "stage_ms": {"encode": round(mean(enc_ms), 3), "prefill": round(mean(prefill_ms), 3), "decode": round(mean(decode_ms), 3),
                      "decode_per_step": round(dec_step_ms, 4)},
-        "stage_note": f"per-batch wall times; {n_pipe} batch(es) share the GPU, so stages of different batches overlap",
+        "stage_note": f"per-batch wall times; {n_pipe} batch(es) take turns on the GPU (kernels of different batches interleave; every kernel fills the chip, so this "
+                      "buys ~2 % over strictly sequential steps: compare stage_ms_one_batch_alone)",
         "stage_ms_one_batch_alone": seq_stage,
         "decode_step_hbm": {"algorithmic_GB": round(step_bytes / 1e9, 3), "concurrent_batches": n_pipe,
                             "achieved_GBps": round(n_pipe * step_bytes / (dec_step_ms * 1e-3) / 1e9, 1),
@@ -871,6 +872,17 @@ def main():
         a_ = larch
         body = a_.num_hidden_layers * ((a_.num_attention_heads + 2 * a_.num_key_value_heads) * a_.head_dim * a_.hidden_size
                                        + a_.num_attention_heads * a_.head_dim * a_.hidden_size + 3 * a_.intermediate_size * a_.hidden_size)
+        # the decode step's projection FAMILY (the five Linears of every layer + lm_head with its selection, their K-split reduce launches and
+        # the RMSNorm hand-off): what is left of a step of one batch alone once the attention launches are taken out — the larger part of the
+        # step, which `roofline` (the single dominant kernel) does not show
+        fam_ms = seq_stage["decode_per_step"] - a_.num_hidden_layers * probes["attn"][1]
+        if fam_ms > 0:
+            fam_flops = 2.0 * B * (body + a_.vocab_size * a_.hidden_size)
+            result["decode_gemm_family"] = {"bound": "mfma", "achieved": round(fam_flops / (fam_ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": round(fam_flops / (fam_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(fam_ms, 3),
+                                            "share_of_step": round(fam_ms / seq_stage["decode_per_step"], 3),
+                                            "note": f"decode step of one batch alone ({seq_stage['decode_per_step']} ms) minus {a_.num_hidden_layers} x the attention launch "
+                                                    f"({round(probes['attn'][1] * 1e3, 1)} us): qkv + o + gate/up + down of every layer, lm_head + selection, reduce launches, embedding gather"}
         # per sequence: every Linear on S rows, causal attention (half of the S x S products), lm_head on the last row only
         pf = 2.0 * body * S + a_.num_hidden_layers * 2.0 * a_.num_attention_heads * a_.head_dim * S * S + 2.0 * a_.vocab_size * a_.hidden_size
         ach = B * pf / (seq_stage["prefill"] * 1e-3) / 1e12
