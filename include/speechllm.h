@@ -114,6 +114,11 @@ typedef struct {
    *              rsqrt(mean(row^2) + rms_eps) of the values it stores (N <= 4096);
    *   rstd_in  — with fuse_rms, multiply by rstd_in[m] instead of recomputing the statistics of A's rows. */
   const float* rstd_in; float* rstd_out;
+  /* with rstd_out: the reduce pass also writes the RMS-normalised rows themselves (hf:models/llama/modeling_llama.py:60-71:
+   * weight * (x * rsqrt(mean(x^2) + eps)).to(dtype)) to norm_out (row stride N, the output's type), gain = norm_gain (N values) —
+   * for a consumer that runs on the row-major tiled kernels and therefore wants its input normalised (decode steps above ~900 rows:
+   * gate/up on the 256 x 256 tiles).  Both NULL: off. */
+  void* norm_out; const void* norm_gain;
 } sl_gemm_fused;
 size_t sl_gemm_split_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype);
 /* K splits sl_gemm_fused_decode will use for this shape when split_ws is supplied (1: no reduce pass, so no rstd_out) */

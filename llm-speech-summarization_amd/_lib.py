@@ -41,7 +41,7 @@ class GemmArgs(C.Structure):
 class GemmFused(C.Structure):
     _fields_ = [("fuse_rms", c_i32), ("rms_eps", c_f32), ("rope_cos", c_vp), ("rope_sin", c_vp), ("tok_pos", c_vp), ("tok_seq", c_vp),
                 ("k_cache", c_vp), ("v_cache", c_vp), ("n_heads", c_i32), ("n_kv_heads", c_i32), ("max_ctx", c_i32), ("reserved", c_i32),
-                ("split_ws", c_vp), ("split_ws_bytes", C.c_size_t), ("rstd_in", c_vp), ("rstd_out", c_vp)]
+                ("split_ws", c_vp), ("split_ws_bytes", C.c_size_t), ("rstd_in", c_vp), ("rstd_out", c_vp), ("norm_out", c_vp), ("norm_gain", c_vp)]
 
 
 class GemmEx(C.Structure):

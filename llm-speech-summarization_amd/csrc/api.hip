@@ -52,6 +52,7 @@ static const SlEnv* env_load() {
   e.t256_min_tiles = env_int("SL_T256_MIN_TILES", 512);
   e.t256_min_k = env_int("SL_T256_MIN_K", 1024);
   e.t256_phased = env_int("SL_T256_PHASED", 1);
+  e.decode_tiled = env_int("SL_DECODE_TILED", 1);
   e.stream_k = env_int("SL_STREAM_K", 1);
   e.gemm_ko = env_int("SL_GEMM_KO", 0);
   { const char* sp = getenv("SL_GEMM_STAMP_PTR"); e.gemm_stamp_ptr = (sp && sp[0]) ? strtoull(sp, nullptr, 16) : 0ull; }

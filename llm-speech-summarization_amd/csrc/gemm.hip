@@ -1839,7 +1839,8 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     sx.fuse_rms = fx->fuse_rms; sx.eps = fx->rms_eps;
     sx.cos = fx->rope_cos; sx.sin = fx->rope_sin; sx.pos = fx->tok_pos; sx.seq = fx->tok_seq;
     sx.kc = fx->k_cache; sx.vc = fx->v_cache; sx.nh = fx->n_heads; sx.nkv = fx->n_kv_heads; sx.max_ctx = fx->max_ctx;
-    sx.rstd_in = fx->rstd_in; sx.rstd_out = fx->rstd_out;
+    sx.rstd_in = fx->rstd_in; sx.rstd_out = fx->rstd_out; sx.norm_out = fx->norm_out; sx.norm_gain = fx->norm_gain;
+    SL_CHECK_ARG((!fx->norm_out && !fx->norm_gain) || (fx->norm_out && fx->norm_gain && fx->rstd_out && !a->out_f32), "sl_gemm: norm_out needs norm_gain, rstd_out and an output in the storage type");
   }
   if (a->act == SL_ACT_ROPE_KV) {
     SL_CHECK_ARG(fx && fx->rope_cos && fx->rope_sin && fx->tok_pos && fx->tok_seq && fx->k_cache && fx->v_cache,
@@ -1851,7 +1852,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
       a->K % (a->dtype == SL_F32 ? 32 : 64) == 0)
     return sl_gemm_stream_launch(p, sx, a->dtype, a->act, fx ? fx->split_ws : nullptr, fx ? fx->split_ws_bytes : 0, st);
   SL_CHECK_ARG(a->w_layout != SL_W_PACKED || a->M <= 64, "sl_gemm: packed weights with M=%d > 64 need batch 1 and K %% 64 == 0", a->M);
-  SL_CHECK_ARG(!sx.rstd_in && !sx.rstd_out, "sl_gemm: rstd_in / rstd_out are features of the streaming path (M > %d rows, packed weights)", stream_min_m());
+  SL_CHECK_ARG(!sx.rstd_in && !sx.rstd_out && !sx.norm_out, "sl_gemm: rstd_in / rstd_out / norm_out are features of the streaming path (M > %d rows, packed weights)", stream_min_m());
   void* sk_ws = ex ? ex->sk_ws : nullptr;
   const size_t sk_ws_bytes = ex ? ex->sk_ws_bytes : 0;
   SL_CHECK_ARG(!sk_ws || ((uintptr_t)sk_ws & 15) == 0, "sl_gemm_ex: sk_ws must be 16-byte aligned");

@@ -80,6 +80,8 @@ struct SkinnyX {
   float eps;
   const float* rstd_in;   // per-row RMSNorm scale computed by the producer of A (replaces the in-kernel statistics)
   float* rstd_out;        // K-split reduce kernel: also emit rsqrt(mean(out_row^2) + eps) of the rows it stores
+  void* norm_out;         // ... and the normalised rows themselves: gain * round(row * rstd), row stride N (sl_gemm_fused.norm_out)
+  const void* norm_gain;
 };
 
 // gemm_stream.hip: packed-weight streaming GEMM for 16 < M <= 256 (large-batch decode)

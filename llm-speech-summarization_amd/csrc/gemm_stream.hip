@@ -637,8 +637,9 @@ __global__ __launch_bounds__(ROWSTAT ? 1024 : 256) void gemm_stream_reduce_kerne
   for (int i = 0; i < 4; ++i) { a[i] = a4[i] * rs; b[i] = b4[i] * rs; }
   if constexpr (ROWSTAT) {
     // same arithmetic as stream_epilogue4's plain branch, keeping the stored values for the statistics
-    __shared__ float wsum[16];
+    __shared__ float wsum[17];
     float sq = 0.f;
+    float kept[4] = {0.f, 0.f, 0.f, 0.f};      // the values as stored, for the normalised copy (sx.norm_out)
     if (live) {
       const T* bias = (const T*)p.bias;
 #pragma unroll
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(ROWSTAT ? 1024 : 256) void gemm_stream_reduce_kerne
           ((T*)p.C)[(int64_t)m * p.ldc + col] = o;
           v = to_f32(o);
         }
+        kept[i] = v;
         sq = fmaf(v, v, sq);
       }
     }
@@ -664,7 +666,29 @@ __global__ __launch_bounds__(ROWSTAT ? 1024 : 256) void gemm_stream_reduce_kerne
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
-      sx.rstd_out[m] = rsqrtf(t / (float)p.N + sx.eps);
+      const float rstd = rsqrtf(t / (float)p.N + sx.eps);
+      sx.rstd_out[m] = rstd;
+      wsum[16] = rstd;
+    }
+    if (sx.norm_out) {
+      // the RMS-normalised row beside the row itself, in HF's rounding order: weight * (x * rstd).to(dtype) (hf:...llama.py:60-71) —
+      // what a separate sl_rmsnorm launch over these rows would write (11 us per 1 024 x 3 072 in the decode graph)
+      __syncthreads();
+      const float rstd = wsum[16];
+      if (live) {
+        const int col0 = gf * 16 + 4 * q;
+        if (col0 + 3 < p.N) {
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = to_f32(((const T*)sx.norm_gain)[col0 + i]) * to_f32(from_f32<T>(kept[i] * rstd));
+          T* dst = (T*)sx.norm_out + (int64_t)m * p.N + col0;        // 8 (bf16) / 16 (f32) bytes per lane, 64 / 128 contiguous bytes per fragment
+          if constexpr (sizeof(T) == 2) *(uint2*)dst = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+          else *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
+        } else {
+          for (int i = 0; i < 4 && col0 + i < p.N; ++i)
+            ((T*)sx.norm_out)[(int64_t)m * p.N + col0 + i] = from_f32<T>(to_f32(((const T*)sx.norm_gain)[col0 + i]) * to_f32(from_f32<T>(kept[i] * rstd)));
+        }
+      }
     }
   } else {
     if (live) stream_epilogue4<T, ACT>(p, sx, m, gf, 4 * q, a, b);

@@ -483,11 +483,12 @@ static inline size_t kv_layer_bytes(const sl_llama_model* m, const sl_kv_cache* 
 // decode GEMM on the fragment-packed weights, optionally absorbing the preceding RMSNorm / RoPE+KV-append
 static int dec_gemm(const sl_llama_model* m, const LlamaWs& w, const void* A, int64_t lda, const void* Wp, void* C, int64_t ldc, const void* res,
                     int M, int N, int K, int act, int out_f32, const sl_gemm_fused* fx_in, hipStream_t st, const float* rstd_in = nullptr,
-                    float* rstd_out = nullptr) {
+                    float* rstd_out = nullptr, void* norm_out = nullptr, const void* norm_gain = nullptr) {
   sl_gemm_fused fxl;
   if (fx_in) fxl = *fx_in; else memset(&fxl, 0, sizeof(fxl));
   fxl.split_ws = w.split; fxl.split_ws_bytes = w.split_bytes;
   fxl.rstd_in = rstd_in; fxl.rstd_out = rstd_out; fxl.rms_eps = m->rms_eps;
+  fxl.norm_out = norm_out; fxl.norm_gain = norm_gain;
   const sl_gemm_fused* fx = &fxl;
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
@@ -519,15 +520,25 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
     SL_TRY(dec_gemm(m, w, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st, rstd_qkv));
     SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1));
-    SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st, nullptr,
-                    rstd_chain ? w.rstd_a : nullptr));
-    sl_gemm_fused fn;
-    memset(&fn, 0, sizeof(fn));
-    fn.fuse_rms = m->dec_fused_norm; fn.rms_eps = m->rms_eps;
-    a_in = x;
-    if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
-    SL_TRY(dec_gemm(m, w, a_in, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st,
-                    rstd_chain ? w.rstd_a : nullptr));
+    // Above ~900 rows gate/up runs on the row-major 256 x 256 tiles (the prefill kernel): at 1 024 rows it is 4 x 64 = 256 tiles, one per
+    // CU, 78-81 us against 99 us on the 256 x 128 streaming block (tools/time_decode_tiled.py; in the graph: profiles/r04_l_*).  Its input
+    // must then be normalised: the o projection's reduce pass, which already forms each row's RMSNorm scale, writes the normalised rows
+    // beside x (sl_gemm_fused.norm_out) — a separate sl_rmsnorm launch costs 11.5 us per layer in the graph and ate the gain, and o itself
+    // stays on the streaming form (27 + 11 us against 47 us on the 128 x 128 tiles its 48 big tiles fall back to).  SL_DECODE_TILED=0: off.
+    if (n > 896 && dt == SL_BF16 && L.wgu && rstd_chain && sl_env().decode_tiled) {
+      SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st, nullptr, w.rstd_a, w.h, L.norm2));
+      SL_TRY(gemm(dt, w.h, H, L.wgu, H, w.mid, m->ffn, nullptr, nullptr, 0, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, st));
+    } else {
+      SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st, nullptr,
+                      rstd_chain ? w.rstd_a : nullptr));
+      sl_gemm_fused fn;
+      memset(&fn, 0, sizeof(fn));
+      fn.fuse_rms = m->dec_fused_norm; fn.rms_eps = m->rms_eps;
+      a_in = x;
+      if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
+      SL_TRY(dec_gemm(m, w, a_in, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st,
+                      rstd_chain ? w.rstd_a : nullptr));
+    }
     SL_TRY(dec_gemm(m, w, w.mid, m->ffn, L.wdown_dec, x, H, x, (int)n, H, m->ffn, SL_ACT_NONE, 0, nullptr, st, nullptr,
                     rstd_chain ? w.rstd_b : nullptr));
     return 0;
@@ -817,7 +828,7 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
     key.model = m; key.layers = m->layers; key.w0 = m->n_layers > 0 ? m->layers[0].wqkv_dec : nullptr; key.lm = m->lm_head_dec ? m->lm_head_dec : m->lm_head;
     key.embed = m->embed; key.kc = kv->k_cache; key.vc = kv->v_cache; key.ws = workspace; key.ws_bytes = workspace_bytes;
     key.B = B; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
-    key.slots = kv->slots; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm;
+    key.slots = kv->slots; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8);   // + the switch that shapes the captured launches
     key.content = model_content_hash(m);
     SL_HIP(hipGetDevice(&key.device));
     for (int i = 0; i < n_eos && i < 8; ++i) key.eos[i] = eos_ids_host[i];

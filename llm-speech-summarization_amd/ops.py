@@ -291,7 +291,8 @@ def pack_weight(W: torch.Tensor) -> torch.Tensor:
 
 def gemm_decode(A: torch.Tensor, Wp: torch.Tensor, N: int, *, residual=None, act: int = L.ACT_NONE, out_f32: bool = False,
                 fuse_rms: bool = False, eps: float = 1e-5, rope=None, out: Optional[torch.Tensor] = None,
-                split_k: bool = True, rstd_in: Optional[torch.Tensor] = None, rstd_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                split_k: bool = True, rstd_in: Optional[torch.Tensor] = None, rstd_out: Optional[torch.Tensor] = None,
+                norm_out: Optional[torch.Tensor] = None, norm_gain: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Decode GEMM on packed weights.  rope = dict(cos, sin, pos, seq, k_cache, v_cache, n_heads, n_kv, max_ctx) for ACT_ROPE_KV.
     split_k: hand the kernel a scratch buffer so that row counts > 64 may split K over blocks (gemm_stream.hip)."""
     M, K = A.shape
@@ -313,6 +314,7 @@ def gemm_decode(A: torch.Tensor, Wp: torch.Tensor, N: int, *, residual=None, act
     f = L.GemmFused()
     f.fuse_rms, f.rms_eps = int(fuse_rms), eps
     f.rstd_in, f.rstd_out = L.ptr(rstd_in), L.ptr(rstd_out)
+    f.norm_out, f.norm_gain = L.ptr(norm_out), L.ptr(norm_gain)     # the reduce pass also writes the RMS-normalised rows (sl_gemm_fused.norm_out)
     if rope is not None:
         f.rope_cos, f.rope_sin, f.tok_pos, f.tok_seq = L.ptr(rope["cos"]), L.ptr(rope["sin"]), L.ptr(rope["pos"]), L.ptr(rope["seq"])
         f.k_cache, f.v_cache = L.ptr(rope["k_cache"]), L.ptr(rope["v_cache"])

@@ -531,6 +531,13 @@ def test_gemm_packed_rstd_handoff(dt, M):
     assert rel_err(x.float().cpu(), xr) < TOL[dt]
     xf = x.float().cpu()
     assert rel_err(rstd.cpu(), torch.rsqrt(xf.pow(2).mean(-1) + 1e-5)) < 1e-5
+    # norm_out: the same pass also leaves the RMS-normalised rows (what sl_rmsnorm over its output would write), bit for bit
+    gain = (1.0 + rnd(H, seed=45, std=0.1)).to(dev(), dt)
+    rstd2, h = torch.empty(M, device=dev(), dtype=torch.float32), torch.empty(M, H, device=dev(), dtype=dt)
+    x2 = ops.gemm_decode(a.to(dev(), dt), ops.pack_weight(wo.to(dev(), dt)), H, residual=res.to(dev(), dt), rstd_out=rstd2, eps=1e-5, norm_out=h, norm_gain=gain)
+    assert torch.equal(x2, x) and torch.equal(rstd2, rstd)
+    assert rel_err(h.float().cpu(), ops.rmsnorm(x, gain, 1e-5).float().cpu()) < (1e-6 if dt == torch.float32 else 2e-3)
+    assert rel_err(h.float().cpu(), (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)) * gain.float().cpu()) < TOL[dt]
     g, u = rnd(Fd, H, seed=43, std=H ** -0.5), rnd(Fd, H, seed=44, std=H ** -0.5)
     wp = ops.pack_weight(weights.interleave_gate_up(g, u).to(dev(), dt))
     y0 = ops.gemm_decode(x, wp, 2 * Fd, act=L.ACT_SILU_MUL, fuse_rms=True, eps=1e-5)
