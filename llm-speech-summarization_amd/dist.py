@@ -120,7 +120,20 @@ class BucketedAllReduce:
         self.bucket_log: List[tuple] = []     # (start, end) element ranges of the buckets launched so far in this step
         self.last_buckets: List[tuple] = []   # ... of the previous optimizer step
         if self.backend == "sl" and self.world > 1:
-            self._init_sl_comm()
+            # all ranks or none: a rank whose communicator did not come up would otherwise wait in a different collective than the rest
+            ok = 1
+            try:
+                self._init_sl_comm()
+            except Exception as e:     # noqa: BLE001 — reported, then decided collectively
+                ok = 0
+                print(f"[dist] sl_comm_init failed on this rank ({e}); asking the group to fall back to torch.distributed", flush=True)
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                flag = torch.tensor([ok], device=arena.flat.device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
+            if not ok:
+                self.close()
+                self.backend = "torch"
 
     def _init_sl_comm(self) -> None:
         """One RCCL communicator per process (= per GPU) through the C ABI: rank 0 draws the unique id (sl_comm_unique_id), the
