@@ -988,3 +988,35 @@ def test_layernorm_fold_build_and_finalize_with_a_dc_offset():
     rstd = 1.0 / torch.sqrt(xf.double().var(dim=1, unbiased=False) + 1e-5)
     assert float((mr[:, 0].double() - mean).abs().max()) < 1e-4
     assert float(((mr[:, 1].double() - rstd) / rstd).abs().max()) < 2e-3        # E[x^2] - mean^2 over the whole row: ~2e-2 here
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_gemm_phased_loop_is_bit_identical_to_the_one_barrier_per_slab_loop(dt, tuning):
+    """The staggered two-phase main loop of the 256-tile GEMM (LDS-DMA in flight across barriers, wave halves one barrier apart)
+    adds every output element's products in the same order as the round-3 loop (SL_T256_PHASED=0), so the two must agree BIT FOR BIT
+    — which makes this a race screen as well: a fragment read that overtook its DMA, or a slot re-filled under a reader, shows up as a
+    differing tile.  Shapes with 1, 2, 3 and many K slabs (prologue / tail paths), ragged M and N edges, every epilogue family; each
+    launched repeatedly, back to back with other work so that blocks start under uneven load."""
+    shapes = [(40000, 1024, 64), (33000, 768, 128), (20000, 1024, 192), (66000, 512, 1024), (9000, 4096, 1024), (2500, 16384, 3072), (70000, 1000, 2048)]
+    if dt == torch.float32:
+        shapes = [(40000, 1024, 32), (20000, 768, 96), (33000, 512, 512)]
+    for M, N, K in shapes:
+        A, W, b, R = rnd(M, K, seed=M % 97), rnd(N, K, seed=N % 89, std=K ** -0.5), rnd(N, seed=5), rnd(M, N, seed=6)
+        Ad, Wd, bd, Rd = A.to(dev(), dt), W.to(dev(), dt), b.to(dev(), dt), R.to(dev(), dt)
+        noise = torch.randn(2048, 2048, device=dev())
+
+        def run():
+            outs = [ops.gemm(Ad, Wd), ops.gemm(Ad, Wd, bias=bd, residual=Rd), ops.gemm(Ad, Wd, bias=bd, act=L.ACT_GELU)]
+            if N % 32 == 0:
+                outs.append(ops.gemm(Ad, Wd, act=L.ACT_SILU_MUL))
+            outs.append(ops.gemm(Ad, Wd, out_f32=True))
+            return outs
+
+        tuning("SL_T256_PHASED", "0")
+        ref = run()
+        tuning("SL_T256_PHASED", "1")
+        for rep in range(4):
+            (noise @ noise).sum()                                   # other kernels in flight around the launches
+            for got, want in zip(run(), ref):
+                assert torch.equal(got, want), (M, N, K, rep)
+    assert rel_err(ref[0].float().cpu(), q(A, dt) @ q(W, dt).T) < TOL[dt]
