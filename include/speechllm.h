@@ -155,7 +155,8 @@ typedef struct {
    * the argmax over the groups: together they give bit for bit the token sl_gemm(out_f32) + sl_greedy_select give. */
   float* amax_val; int32_t* amax_idx;
   /* LayerNorm folded into the Linears around it (hf:models/hubert/modeling_hubert.py:515-517,612 stable-LN layer: x -> LN -> Linear;
-   * bf16, plain row-major un-grouped products with M > 64, N % 64 == 0 — sl_gemm_ln_fold_ok()):
+   * bf16, plain row-major un-grouped products with N % 64 == 0, any row count (a product carrying these fields stays on the tiled
+   * kernels even below 65 rows, so a short utterance alone gets the bits it gets inside a batch) — sl_gemm_ln_fold_ok()):
    *   producer side, stats_out: besides storing C, write for every row m and 64-column segment s the pair {sum, sum of squares} of
    *     the values AS STORED (after bias / act / residual, rounded to the output type) at stats_out[(m * (N / 64) + s) * 2];
    *     sl_layernorm_stats_finalize turns the N / 64 pairs of a row into {mean, rstd};

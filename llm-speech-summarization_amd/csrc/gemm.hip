@@ -1748,7 +1748,7 @@ static int launch_skinny(GemmP& p, const SkinnyX& sx, int batch, bool packed, hi
 
 template <typename T>
 static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStream_t st, void* sk_ws, size_t sk_ws_bytes) {
-  const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32 && !p.grp;  // backward features live in the tiled kernel
+  const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32 && !p.grp && !p.ln_mr && !p.stats_out;  // backward features and the LayerNorm fold live in the tiled kernel
   const bool packed = a->w_layout == SL_W_PACKED;
   if (!skinny && (packed || a->act == SL_ACT_ROPE_KV || sx.fuse_rms)) {
     sl_set_error("sl_gemm: packed weights / ROPE_KV / fused RMSNorm need plain operands (no transposes / groups), M=%d", a->M);
@@ -1767,7 +1767,9 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
 // true when a plain (M, N, K) product of this dtype is served by one of the LDS-DMA tiled kernels, whose rows epilogue carries the
 // LayerNorm fold (ln_* / stats_out)
 bool sl_gemm_rows_epilogue_ok(int M, int N, int K, int dtype) {
-  if (dtype != SL_BF16 || M <= 64 || (N & 63) || sl_env().disable_glds != 0 || sl_env().direct_epilogue != 0) return false;
+  // any row count: a product that carries ln_* / stats_out is kept on the tiled kernels even below 65 rows (gemm_typed), so that the fold is a
+  // property of the MODEL — a short utterance encoded alone takes the same epilogues, hence the same bits, as inside a batch
+  if (dtype != SL_BF16 || M <= 0 || (N & 63) || sl_env().disable_glds != 0 || sl_env().direct_epilogue != 0) return false;
   return K % (TROWB / 2) == 0;
 }
 

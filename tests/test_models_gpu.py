@@ -109,6 +109,19 @@ def test_encoder_ragged_batch_equals_single_utterances():
         r0 += p
 
 
+def test_encoder_short_utterance_alone_equals_inside_a_batch_bf16_fold():
+    """the LayerNorm fold is decided per MODEL, not per call — a 1 s utterance (49 frames: fewer rows than the skinny-GEMM
+    threshold) encoded alone must come out bit-identical to the same utterance inside a batch (bf16, folded layers)."""
+    enc, _ = make_encoder(TINY_HUBERT, 256, 13, torch.bfloat16)
+    waves = [ri.synthetic_waveform(n, seed=n) for n in (16000, 40000, 9000)]
+    out, P, _, _ = enc.encode_packed(waves)
+    r0 = 0
+    for w, p in zip(waves, P):
+        alone, Pa, _, _ = enc.encode_packed([w])
+        assert Pa[0] == p and torch.equal(alone, out[r0:r0 + p]), w.numel()
+        r0 += p
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 def test_encoder_wide_hubert_large_width(dtype, tol):
     g = golden("enc_wide_pool_32000")
