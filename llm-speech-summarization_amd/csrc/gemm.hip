@@ -1709,6 +1709,17 @@ static int launch_skinny_mt(GemmP& p, const SkinnyX& sx, int batch, hipStream_t 
   constexpr bool PAIRS = (ACT == SL_ACT_SILU_MUL || ACT == SL_ACT_ROPE_KV);
   const int nfrag = (p.N + 15) / 16 * batch;
   if constexpr (MT == 1) {
+    if constexpr (PACKED && sizeof(T) == 2 && !PAIRS) {
+      // N = hidden (o, down) at M <= 8: three or four 64-byte steps of loads in flight per wave, chosen so the wave's share
+      // of K divides evenly (o: 6 steps = 2 x 3, down: 16 = 4 x 4): 1.575 -> 1.49 ms per decode step at M = 1, +3 % at M = 16
+      // where the x fragments crowd the loads.  The same sweep over the qkv and gate/up structures (2x16x3, 2x8x6, 2x8x3;
+      // 4x4x6, 4x4x3, 2x8x3, 2x8x6, 4x8x3) moved nothing (profiles/r04_r_skinny_small_m.txt).  SL_SKINNY_ALT=1: old structure.
+      if (nfrag < 256 && p.M <= 8 && !(sl_env().skinny_alt & 1)) {
+        const int per_wave = p.K / 32 / 16;
+        if (per_wave % 3 == 0) return launch_skinny_cfg<T, MT, ACT, 1, 16, 3, PACKED>(p, sx, batch, st);
+        return launch_skinny_cfg<T, MT, ACT, 1, 16, 4, PACKED>(p, sx, batch, st);
+      }
+    }
     if (nfrag >= 1024) return launch_skinny_cfg<T, MT, ACT, 4, 4, 4, PACKED>(p, sx, batch, st);
     if (nfrag >= 256 || PAIRS) return launch_skinny_cfg<T, MT, ACT, 2, 8, 4, PACKED>(p, sx, batch, st);
     if constexpr (!PAIRS) return launch_skinny_cfg<T, MT, ACT, 1, 16, 2, PACKED>(p, sx, batch, st);

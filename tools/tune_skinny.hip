@@ -117,21 +117,22 @@ int main() {
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       printf("  %-34s %51.2f us  %7.1f GB/s\n", "plain nt stream read (2048 blocks)", ms * 1e3 / (5 * L), bytes / (ms * 1e-3 / (5 * L)) / 1e9);
     }
-    for (int M : {32}) {
-      run<1, 16, 2, 0, 1, 1, 2>("M32 rf1 nw16 u2", Ws, X, C, M, s.N, s.K);
-      run<2, 16, 2, 0, 1, 1, 2>("M32 rf2 nw16 u2", Ws, X, C, M, s.N, s.K);
-      run<2, 8, 4, 0, 1, 1, 2>("M32 rf2 nw8 u4 (current)", Ws, X, C, M, s.N, s.K);
-      run<4, 8, 2, 0, 1, 1, 2>("M32 rf4 nw8 u2", Ws, X, C, M, s.N, s.K);
-      run<4, 4, 4, 0, 1, 1, 2>("M32 rf4 nw4 u4 (current big)", Ws, X, C, M, s.N, s.K);
-      run<8, 4, 2, 0, 1, 1, 2>("M32 rf8 nw4 u2", Ws, X, C, M, s.N, s.K);
-      run<8, 8, 2, 0, 1, 1, 2>("M32 rf8 nw8 u2", Ws, X, C, M, s.N, s.K);
-    }
-    for (int M : {64}) {
-      run<1, 16, 2, 0, 1, 1, 4>("M64 rf1 nw16 u2", Ws, X, C, M, s.N, s.K);
-      run<2, 16, 2, 0, 1, 1, 4>("M64 rf2 nw16 u2", Ws, X, C, M, s.N, s.K);
-      run<2, 8, 2, 0, 1, 1, 4>("M64 rf2 nw8 u2 (current)", Ws, X, C, M, s.N, s.K);
-      run<4, 8, 2, 0, 1, 1, 4>("M64 rf4 nw8 u2", Ws, X, C, M, s.N, s.K);
-      run<8, 4, 1, 0, 1, 1, 4>("M64 rf8 nw4 u1", Ws, X, C, M, s.N, s.K);
+    for (int M : {1, 16}) {
+      run<1, 16, 2, 0, 1, 1, 1>("rf1 nw16 u2 (current small-N)", Ws, X, C, M, s.N, s.K);
+      run<1, 16, 3, 0, 1, 1, 1>("rf1 nw16 u3", Ws, X, C, M, s.N, s.K);
+      run<1, 16, 6, 0, 1, 1, 1>("rf1 nw16 u6", Ws, X, C, M, s.N, s.K);
+      run<1, 16, 8, 0, 1, 1, 1>("rf1 nw16 u8", Ws, X, C, M, s.N, s.K);
+      run<1, 16, 6, 1, 1, 1, 1>("rf1 nw16 u6 contiguous", Ws, X, C, M, s.N, s.K);
+      run<1, 8, 4, 0, 1, 1, 1>("rf1 nw8 u4", Ws, X, C, M, s.N, s.K);
+      run<1, 8, 6, 0, 1, 1, 1>("rf1 nw8 u6", Ws, X, C, M, s.N, s.K);
+      run<1, 8, 12, 0, 1, 1, 1>("rf1 nw8 u12", Ws, X, C, M, s.N, s.K);
+      run<2, 16, 2, 0, 1, 1, 1>("rf2 nw16 u2", Ws, X, C, M, s.N, s.K);
+      run<2, 16, 4, 0, 1, 1, 1>("rf2 nw16 u4", Ws, X, C, M, s.N, s.K);
+      run<2, 8, 4, 0, 1, 1, 1>("rf2 nw8 u4", Ws, X, C, M, s.N, s.K);
+      run<2, 8, 8, 0, 1, 1, 1>("rf2 nw8 u8", Ws, X, C, M, s.N, s.K);
+      run<4, 4, 4, 0, 1, 1, 1>("rf4 nw4 u4 (current big-N)", Ws, X, C, M, s.N, s.K);
+      run<4, 4, 8, 0, 1, 1, 1>("rf4 nw4 u8", Ws, X, C, M, s.N, s.K);
+      run<4, 8, 4, 0, 1, 1, 1>("rf4 nw8 u4", Ws, X, C, M, s.N, s.K);
     }
     for (auto w : Ws) CK(hipFree(w));
     CK(hipFree(X)); CK(hipFree(C));
