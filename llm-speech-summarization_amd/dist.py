@@ -81,6 +81,27 @@ class GradArena:
         self.flat.zero_()
 
 
+def _call_with_timeout(fn, seconds: float, what: str):
+    """Run fn() on a daemon thread; TimeoutError if it has not returned after `seconds` (the thread is left behind)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except BaseException as e:     # noqa: BLE001 — re-raised on the caller's thread
+            box["e"] = e
+
+    t = threading.Thread(target=run, daemon=True, name=what)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise TimeoutError(f"{what} did not return within {seconds:.0f} s")
+    if "e" in box:
+        raise box["e"]
+    return box.get("r")
+
+
 class BucketedAllReduce:
     """Sum-all-reduce of the gradient arena in buckets, launched as soon as a bucket is final so the exchange overlaps the
     rest of the backward pass (KD step).
@@ -154,8 +175,14 @@ class BucketedAllReduce:
             ident = dev_id.cpu()
         raw = (C.c_ubyte * L.COMM_ID_BYTES)(*ident.tolist())
         handle = C.c_void_p()
-        with torch.cuda.device(self.arena.flat.device):
-            L.check(L.lib().sl_comm_init(C.byref(handle), raw, rank, world), "sl_comm_init")
+
+        def init():
+            with torch.cuda.device(self.arena.flat.device):    # the current device is per thread
+                L.check(L.lib().sl_comm_init(C.byref(handle), raw, rank, world), "sl_comm_init")
+
+        # ncclCommInitRank is a collective: a rank that cannot reach its peers blocks inside it.  It runs on a helper thread so that
+        # this rank can give up after SL_COMM_INIT_TIMEOUT_S (default 180 s) and take part in the group's fall-back vote instead.
+        _call_with_timeout(init, float(os.environ.get("SL_COMM_INIT_TIMEOUT_S", "180")), "sl_comm_init")
         self.comm = handle
 
     def close(self) -> None:
