@@ -315,7 +315,7 @@ def mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx
         ev[0].record()
         enc.encode_packed(waves, out=x, out_row_offsets=audio_rows)
         ev[1].record()
-        return llm.generate_packed(x, lens, new, use_eos=False)
+        return llm.generate_packed(x, lens, new, use_eos=False, shared_prefix=n_pre)   # every prompt opens with the template rows
 
     step()
     torch.cuda.synchronize()
@@ -362,7 +362,7 @@ def longform_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, ct
         ev[0].record()
         enc.encode_packed(waves, out=x, out_row_offsets=[starts[b] + n_head for b in range(B)])
         ev[1].record()
-        return llm.generate_packed(x, lens, new, use_eos=False)
+        return llm.generate_packed(x, lens, new, use_eos=False, shared_prefix=n_head)   # template + the one instruction text
 
     step()
     torch.cuda.synchronize()
@@ -408,7 +408,7 @@ def whisper_leg(args, mod, larch, llm, prefix, suffix, dev, rank):
         x[:, :n_pre] = pre_e
         x[:, n_pre:n_pre + keep] = out[:, :keep]
         x[:, n_pre + keep:] = suf_e
-        return out, llm.generate_packed(x.view(B * S, -1), [S] * B, new, use_eos=False)
+        return out, llm.generate_packed(x.view(B * S, -1), [S] * B, new, use_eos=False, shared_prefix=n_pre)
 
     step()
     torch.cuda.synchronize()
@@ -629,7 +629,8 @@ def main():
                 self.ev[0].record()
                 self.enc.encode_packed(waves, out=self.x, out_row_offsets=audio_rows)
                 self.ev[1].record()
-                ids, n_cols = self.llm.generate_packed(self.x, [S] * B, new, use_eos=False)   # syncs this stream at its end
+                # shared_prefix: the n_pre template rows are the same in every prompt (what inference.generate_audio_responses passes)
+                ids, n_cols = self.llm.generate_packed(self.x, [S] * B, new, use_eos=False, shared_prefix=n_pre)   # syncs this stream at its end
                 if record:
                     enc_ms.append(self.ev[0].elapsed_time(self.ev[1]))
                     prefill_ms.append(self.llm.last_timings_ms[0])
@@ -848,6 +849,7 @@ def main():
         "dtype": "bf16", "data": "synthetic", "native_library": mod("_lib").LIB_PATH,
         "config": {"workload": "configs[1]: HuBERT-large + Llama-3.2-3B bf16 inference, batch of synthetic 16 kHz utterances",
                    "utterances_per_gpu": B, "audio_sec": args.audio_sec, "prompt_tokens": S, "max_new_tokens": new,
+                   "shared_prompt_prefix_tokens": n_pre,   # the template rows in front of every utterance: decode attention reads their K/V once per batch
                    "parallelism": f"replicas x{world} (sharded by utterance, no collective)", "batches_in_flight_per_gpu": n_pipe},
         "audio_sec_per_s_encoder_alone": round(B * args.audio_sec * world / (min(enc_alone_ms) * 1e-3), 1),
         "audio_sec_per_s_in_pipeline": round(B * args.audio_sec * args.steps * world / elapsed, 1),

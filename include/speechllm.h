@@ -557,6 +557,11 @@ typedef struct {
 typedef struct {
   void* k_cache; void* v_cache;  /* (n_layers, slots, n_kv, max_ctx, D) each */
   int32_t slots, max_ctx;
+  /* shared_prefix = P > 0 is the caller's promise that the first P prompt positions of EVERY sequence of a generate call carry the
+   * same input rows (one prompt template in front of the audio, ref:inference.py:95-113 builds it per call): prefill then leaves
+   * bit-identical K/V rows at positions [0, P) of every slot, and the batched decode attention reads those positions from slot 0
+   * (out of L2 instead of once per sequence from HBM).  0 = no promise.  P <= every prompt length (checked). */
+  int32_t shared_prefix, reserved;
 } sl_kv_cache;
 
 /* LlamaModel.forward over packed prompt embeddings + last-token logits

@@ -148,7 +148,7 @@ class AdamWTensor(C.Structure):
 
 
 class KVCache(C.Structure):
-    _fields_ = [("k_cache", c_vp), ("v_cache", c_vp), ("slots", c_i32), ("max_ctx", c_i32)]
+    _fields_ = [("k_cache", c_vp), ("v_cache", c_vp), ("slots", c_i32), ("max_ctx", c_i32), ("shared_prefix", c_i32), ("reserved", c_i32)]
 
 
 _PROTOS = {

@@ -124,7 +124,7 @@ class AudioLlamaForCausalLM:
         return self._w
 
     # -- buffers --------------------------------------------------------------------------------
-    def _kv_cache(self, slots: int):
+    def _kv_cache(self, slots: int, shared_prefix: int = 0):
         a = self.arch
         if self._kv is None or self._kv[0].shape[1] < slots:
             shape = (a.num_hidden_layers, slots, a.num_key_value_heads, self.max_ctx, a.head_dim)
@@ -134,6 +134,7 @@ class AudioLlamaForCausalLM:
         k, v = self._kv
         kv = L.KVCache()
         kv.k_cache, kv.v_cache, kv.slots, kv.max_ctx = k.data_ptr(), v.data_ptr(), k.shape[1], self.max_ctx
+        kv.shared_prefix = int(shared_prefix)
         return kv
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
@@ -225,15 +226,21 @@ class AudioLlamaForCausalLM:
         ids, n_cols = self.generate_packed(x, lens, max_new_tokens, use_eos=use_eos, sample=sample)
         return ids[:, :n_cols].to(torch.int64)
 
-    def generate_packed(self, x: torch.Tensor, lens: Sequence[int], max_new_tokens: int, use_eos: bool = True, sample: Optional[dict] = None):
-        """x: packed prompt embeddings (sum S_i, h) on the GPU (overwritten).  Returns (int32 (B, max_new) host tensor, n_cols)."""
+    def generate_packed(self, x: torch.Tensor, lens: Sequence[int], max_new_tokens: int, use_eos: bool = True, sample: Optional[dict] = None,
+                        shared_prefix: int = 0):
+        """x: packed prompt embeddings (sum S_i, h) on the GPU (overwritten).  Returns (int32 (B, max_new) host tensor, n_cols).
+        shared_prefix = P: the caller's promise that the first P rows of every sequence are the same rows (one prompt template in
+        front of the audio, ref:inference.py:95-113) — the batched decode attention then reads those P cache positions from slot 0
+        (sl_kv_cache.shared_prefix); ids and logits are bit for bit those of P = 0."""
         w = self._dev()
         a = self.arch
         lib = L.lib()
         B = len(lens)
         if max(lens) + max_new_tokens > self.max_ctx:
             raise L.SpeechLLMError(f"prompt ({max(lens)}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
-        kv = self._kv_cache(B)
+        if not 0 <= shared_prefix <= min(lens):
+            raise L.SpeechLLMError(f"shared_prefix={shared_prefix} outside [0, shortest prompt={min(lens)}]")
+        kv = self._kv_cache(B, shared_prefix)
         cu = [0]
         for n in lens:
             cu.append(cu[-1] + int(n))

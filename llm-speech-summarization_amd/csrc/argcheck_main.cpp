@@ -33,7 +33,7 @@ static void fill_hubert(sl_hubert_model* m, sl_hubert_layer* layers, int n_layer
 }
 
 int main() {
-  EXPECT(sl_version() == 4, "ABI version");
+  EXPECT(sl_version() == 5, "ABI version");
   EXPECT(sl_last_error() != nullptr, "error string never NULL");
 
   // ---- tuning switches: parser under the sanitizers, garbage included
@@ -145,6 +145,11 @@ int main() {
   int32_t eos[3] = {128001, 128008, 128009};
   EXPECT_ARG_ERROR(sl_greedy_generate(&lm, &kv, ws, cu, 1, 256, eos, 3, 128001, 1, 16, out_ids, &n_steps, nullptr, ws, sizeof(ws), nullptr));   // prompt + new > max_ctx
   EXPECT_ARG_ERROR(sl_greedy_generate(&lm, &kv, ws, cu, 4096, 8, eos, 3, 128001, 1, 16, out_ids, &n_steps, nullptr, ws, sizeof(ws), nullptr));  // batch above the limit
+  kv.shared_prefix = 200;
+  EXPECT_ARG_ERROR(sl_greedy_generate(&lm, &kv, ws, cu, 1, 8, eos, 3, 128001, 1, 16, out_ids, &n_steps, nullptr, ws, sizeof(ws), nullptr));     // shared prefix longer than the prompt
+  kv.shared_prefix = -1;
+  EXPECT_ARG_ERROR(sl_llama_prefill(&lm, &kv, ws, cu, 1, logits, ctx, nullptr, ws, sizeof(ws), nullptr));            // negative shared prefix
+  kv.shared_prefix = 0;
   lm.head_dim = 96;
   EXPECT_ARG_ERROR(sl_llama_prefill(&lm, &kv, ws, cu, 1, logits, ctx, nullptr, ws, sizeof(ws), nullptr));            // head_dim not built
   EXPECT_ARG_ERROR(sl_llama_decode_step(&lm, &kv, nullptr, nullptr, 1, logits, ws, sizeof(ws), nullptr));

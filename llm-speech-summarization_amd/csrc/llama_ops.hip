@@ -917,7 +917,7 @@ template <int REP, bool PREFETCH>
 __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __restrict__ q, int64_t q_stride, const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
                                                                const int32_t* __restrict__ ctx_len, int ctx_add, int nh, int nkv, int max_ctx,
-                                                               float scale) {
+                                                               float scale, int shared_prefix) {
   using T = bf16_t;
   constexpr int D = 128, KS = 128, NPS = KS / 16;
   constexpr int PROW = KS * 2 + 16;
@@ -932,6 +932,12 @@ __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __r
   const int n_keys = ctx_len[b] + ctx_add;
   const T* kbase = kc + ((int64_t)b * nkv + kvh) * max_ctx * D;
   const T* vbase = vc + ((int64_t)b * nkv + kvh) * max_ctx * D;
+  // positions below shared_prefix hold the same rows in every slot (the caller's promise: one prompt prefix for the whole batch);
+  // every block reads them from slot 0, so they come out of L2 instead of HBM.  Measured (tools/time_decode_step.py 1024 with
+  // SHARED_PREFIX=9, three A/B rounds on one box, profiles/r04_w_shared_prefix.txt): decode step 11.08 -> 10.82 ms; the same rows
+  // through plain (not non-temporal) loads behind a per-load branch: 11.30 ms, slower than no sharing.
+  const T* kbase0 = kc + (int64_t)kvh * max_ctx * D;
+  const T* vbase0 = vc + (int64_t)kvh * max_ctx * D;
   auto voff = [](int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); };
 
   uint4 qf[4];
@@ -946,14 +952,14 @@ __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __r
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int key = k0 + ps * 16 + wave * 4 + grp; key = key < n_keys ? key : n_keys - 1;
-      kraw[buf][ps] = SL_KV_LOAD(kbase + (int64_t)key * D + gl * 8);
+      kraw[buf][ps] = SL_KV_LOAD((key < shared_prefix ? kbase0 : kbase) + (int64_t)key * D + gl * 8);
     }
   };
   auto fetch_v = [&](int buf, int k0) {
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int key = k0 + kg + 16 * ps; key = key < n_keys ? key : n_keys - 1;
-      vraw[buf][ps] = SL_KV_LOAD(vbase + (int64_t)key * D + dc * 8);
+      vraw[buf][ps] = SL_KV_LOAD((key < shared_prefix ? vbase0 : vbase) + (int64_t)key * D + dc * 8);
     }
   };
   auto fetch = [&](int buf, int k0) { fetch_k(buf, k0); fetch_v(buf, k0); };
@@ -1082,7 +1088,7 @@ int sl_attn_decode_split_zero_counters(void* workspace, int B, int n_heads, int 
 template <typename T, int REP>
 static int launch_attn_decode_split(const void* q, int64_t q_stride, const void* kc, const void* vc, void* out, float* part,
                                     const int32_t* ctx_len, int ctx_add, int B, int nh, int nkv, int max_ctx, float scale, hipStream_t st,
-                                    int32_t* cnt) {
+                                    int32_t* cnt, int shared_prefix) {
   if constexpr (sizeof(T) == 2) {
     const int64_t full_min = sl_env().attn_full_min;   // tuning switch: (sequence, kv head) pairs from which the single-pass form runs; measured faster than split + merge from B = 4 up (9.1 vs 11.4 us), 97 vs 127 us at B = 512
     // ... except long caches at batches that leave the chip under-filled: a block of the single-pass form walks its whole context in
@@ -1093,7 +1099,7 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
     const bool long_thin = max_ctx >= 1024 && (int64_t)B * nkv < 768;
     if ((int64_t)B * nkv >= full_min && !long_thin && !sl_env().attn_force_split) {
       hipLaunchKernelGGL((attn_decode_full_kernel<REP, false>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
-                         (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale);
+                         (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale, shared_prefix);
       SL_CHECK_LAUNCH("attn_decode_full");
       return 0;
     }
@@ -1119,10 +1125,11 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
 // (sl_attn_decode_split_zero_counters) on this stream; 2 = the same, zeroing them here first (one memset per call)
 int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
                               const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
-                              float scale, int32_t dtype, hipStream_t st, int counters) {
+                              float scale, int32_t dtype, hipStream_t st, int counters, int shared_prefix) {
   SL_CHECK_ARG(q && k_cache && v_cache && out && workspace && ctx_len && B > 0, "sl_attn_decode_split: bad arguments");
   SL_CHECK_ARG(D == 128, "sl_attn_decode_split: head_dim %d not built (128)", D);
   SL_CHECK_ARG(n_kv > 0 && n_heads % n_kv == 0, "sl_attn_decode_split: n_heads %% n_kv != 0");
+  SL_CHECK_ARG(shared_prefix >= 0 && shared_prefix <= max_ctx, "sl_attn_decode_split: shared_prefix %d outside [0, max_ctx=%d]", shared_prefix, max_ctx);
   float* part = (float*)workspace;
   const int rep = n_heads / n_kv;
   // Measured (tools/time_decode_step.py, Llama-3.2-3B, 128 new tokens, 7 splits x 8 kv heads): merged in-launch 1.5725 / 1.5884 / 1.5922 ms
@@ -1137,10 +1144,10 @@ int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cac
   if (counters == 2) SL_TRY(sl_attn_decode_split_zero_counters(workspace, B, n_heads, n_kv, max_ctx, st));
   SL_DISPATCH_DTYPE(dtype, T, {
     switch (rep) {
-      case 1: return launch_attn_decode_split<T, 1>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
-      case 2: return launch_attn_decode_split<T, 2>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
-      case 3: return launch_attn_decode_split<T, 3>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
-      case 4: return launch_attn_decode_split<T, 4>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt);
+      case 1: return launch_attn_decode_split<T, 1>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt, shared_prefix);
+      case 2: return launch_attn_decode_split<T, 2>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt, shared_prefix);
+      case 3: return launch_attn_decode_split<T, 3>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt, shared_prefix);
+      case 4: return launch_attn_decode_split<T, 4>(q, q_stride, k_cache, v_cache, out, part, ctx_len, ctx_add, B, n_heads, n_kv, max_ctx, scale, st, cnt, shared_prefix);
       default: sl_set_error("sl_attn_decode_split: n_heads/n_kv=%d not built (1..4)", rep); return SL_ERR_UNSUPPORTED;
     }
   });
@@ -1154,5 +1161,5 @@ extern "C" int sl_attn_decode_split(const void* q, int64_t q_stride, const void*
                                     const int32_t* ctx_len, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx, float scale,
                                     int32_t dtype, sl_stream stream) {
   return sl_attn_decode_split_impl(q, q_stride, k_cache, v_cache, out, workspace, ctx_len, 0, B, n_heads, n_kv, D, max_ctx, scale, dtype,
-                                   (hipStream_t)stream, 2);
+                                   (hipStream_t)stream, 2, 0);
 }

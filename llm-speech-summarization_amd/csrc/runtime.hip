@@ -22,7 +22,7 @@ int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float tempe
 int sl_attn_decode_split_zero_counters(void* workspace, int B, int n_heads, int n_kv, int max_ctx, hipStream_t st);
 int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
                               const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
-                              float scale, int32_t dtype, hipStream_t st, int counters);
+                              float scale, int32_t dtype, hipStream_t st, int counters, int shared_prefix);
 size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx);
 int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st);
 bool sl_gemm_rows_epilogue_ok(int M, int N, int K, int dtype);
@@ -471,6 +471,7 @@ static int llama_check(const sl_llama_model* m, const sl_kv_cache* kv) {
   SL_CHECK_ARG(m && kv && m->layers && m->embed && m->lm_head && m->final_norm && m->rope_cos && m->rope_sin, "llama: null model field");
   SL_CHECK_ARG(m->head_dim == 128, "llama: head_dim %d not built (128)", m->head_dim);
   SL_CHECK_ARG(kv->k_cache && kv->v_cache && kv->slots > 0 && kv->max_ctx > 0, "llama: bad kv cache");
+  SL_CHECK_ARG(kv->shared_prefix >= 0 && kv->shared_prefix <= kv->max_ctx, "llama: kv cache shared_prefix %d outside [0, max_ctx=%d]", kv->shared_prefix, kv->max_ctx);
   SL_CHECK_ARG(kv->max_ctx <= m->rope_len, "llama: max_ctx %d exceeds the rope table (%d)", kv->max_ctx, m->rope_len);
   return 0;
 }
@@ -519,7 +520,7 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
     const void* a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
     SL_TRY(dec_gemm(m, w, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st, rstd_qkv));
-    SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1));
+    SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1, kv->shared_prefix));
     // Above ~900 rows gate/up runs on the row-major 256 x 256 tiles (the prefill kernel): at 1 024 rows it is 4 x 64 = 256 tiles, one per
     // CU, 78-81 us against 99 us on the 256 x 128 streaming block (tools/time_decode_tiled.py; in the graph: profiles/r04_l_*).  Its input
     // must then be normalised: the o projection's reduce pass, which already forms each row's RMSNorm scale, writes the normalised rows
@@ -548,7 +549,7 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
   SL_TRY(sl_rope_kv_append(w.qkv, kc, vc, w.tok_seq, decode ? ctx_len_dev : w.tok_pos, m->rope_cos, m->rope_sin, n, nh, nkv, D, kv->max_ctx,
                            dt, (sl_stream)st));
   if (decode) {
-    SL_TRY(sl_attn_decode_split_impl(w.qkv, qkv_w, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1));
+    SL_TRY(sl_attn_decode_split_impl(w.qkv, qkv_w, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1, kv->shared_prefix));
   } else {
     sl_attn_args a;
     memset(&a, 0, sizeof(a));
@@ -695,7 +696,7 @@ struct DecodeGraphKey {
   size_t ws_bytes;
   uint64_t content;        // FNV-1a over the model struct and every layer struct: all weight / norm / rope pointers and dimensions
   int device;
-  int B, max_new, use_eos, n_eos, pad, max_ctx, slots, dtype, n_layers, vocab, fused;
+  int B, max_new, use_eos, n_eos, pad, max_ctx, slots, shared_prefix, dtype, n_layers, vocab, fused;
   int eos[8];
   int sample, top_k;
   float temperature, top_p;
@@ -771,6 +772,9 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
     SL_CHECK_ARG(cu_seqlens_host[s + 1] - cu_seqlens_host[s] + max_new_tokens <= kv->max_ctx,
                  "sl_greedy_generate: prompt %d (%d tokens) + %d new tokens exceeds max_ctx %d", s,
                  cu_seqlens_host[s + 1] - cu_seqlens_host[s], max_new_tokens, kv->max_ctx);
+  for (int s = 0; s < nseq; ++s)
+    SL_CHECK_ARG(kv->shared_prefix <= cu_seqlens_host[s + 1] - cu_seqlens_host[s], "sl_greedy_generate: kv cache shared_prefix %d exceeds prompt %d (%d tokens)",
+                 kv->shared_prefix, s, cu_seqlens_host[s + 1] - cu_seqlens_host[s]);
   SL_CHECK_ARG(sl_generate_workspace_bytes(m, n_tok, nseq, max_new_tokens) <= workspace_bytes, "sl_greedy_generate: workspace %zu B < required %zu B",
                workspace_bytes, sl_generate_workspace_bytes(m, n_tok, nseq, max_new_tokens));
   // carve: generation state first, then the prefill/decode scratch
@@ -828,7 +832,7 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
     key.model = m; key.layers = m->layers; key.w0 = m->n_layers > 0 ? m->layers[0].wqkv_dec : nullptr; key.lm = m->lm_head_dec ? m->lm_head_dec : m->lm_head;
     key.embed = m->embed; key.kc = kv->k_cache; key.vc = kv->v_cache; key.ws = workspace; key.ws_bytes = workspace_bytes;
     key.B = B; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
-    key.slots = kv->slots; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8);   // + the switch that shapes the captured launches
+    key.slots = kv->slots; key.shared_prefix = kv->shared_prefix; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8);   // + the switch that shapes the captured launches
     key.content = model_content_hash(m);
     SL_HIP(hipGetDevice(&key.device));
     for (int i = 0; i < n_eos && i < 8; ++i) key.eos[i] = eos_ids_host[i];

@@ -144,7 +144,12 @@ class LLMSpeechTextInference():
                 x[o + pre_e.shape[0]:o + heads[i]] = txt_e[i]
             x[o + heads[i] + Ps[i]:starts[i + 1]] = suf_e
         enc.encode_packed(waves, out=x, out_row_offsets=[starts[i] + heads[i] for i in range(n)])
-        ids, n_cols = self.llm.generate_packed(x, lens, max_new_tokens, use_eos=True)
+        # every prompt opens with the same template rows (and the same instruction text when the caller gave one text for all):
+        # the batched decode attention reads those cache positions once for the batch (sl_kv_cache.shared_prefix)
+        shared = int(pre_e.shape[0])
+        if txt_e[0] is not None and all(t_ == texts[0] for t_ in texts):
+            shared += int(txt_e[0].shape[0])
+        ids, n_cols = self.llm.generate_packed(x, lens, max_new_tokens, use_eos=True, shared_prefix=shared)
         generate_ids = ids[:, :n_cols].to(torch.int64)
         self.last_generate_ids = generate_ids
         return self.llm_tokenizer.batch_decode(generate_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)

@@ -222,7 +222,7 @@ def test_llama_batched_generate_equals_single():
         assert bool((ids[b, r.shape[0]:] == cfg.pad_token_id).all())
 
 
-def _decode_step_logits(llm, prompts, next_ids):
+def _decode_step_logits(llm, prompts, next_ids, shared_prefix=0):
     """prefill + ONE decode step through the C ABI (sl_llama_prefill, sl_llama_decode_step): fp32 logits of the new position."""
     import ctypes as C
     L = pkg("_lib")
@@ -231,7 +231,7 @@ def _decode_step_logits(llm, prompts, next_ids):
     cu = [0]
     for p in prompts:
         cu.append(cu[-1] + p.shape[0])
-    kv = llm._kv_cache(B)
+    kv = llm._kv_cache(B, shared_prefix)
     ws = llm._workspace(lib.sl_generate_workspace_bytes(C.byref(w.struct), x.shape[0], B, 1))
     logits = torch.empty((B, llm.arch.vocab_size), device=DEV, dtype=torch.float32)
     ctx = torch.empty(B, device=DEV, dtype=torch.int32)
@@ -257,6 +257,33 @@ def test_llama_decode_step_large_batch_matches_small_batch(dtype, tol):
     big = _decode_step_logits(llm, [base[b % 5] for b in range(B)], [nxt[b % 5] for b in range(B)])
     for b in range(B):
         assert rel_err(big[b], small[b % 5]) < tol, b
+
+
+def test_llama_shared_prompt_prefix_is_read_from_slot_zero_with_unchanged_bits():
+    """sl_kv_cache.shared_prefix (one prompt template in front of every utterance, ref:inference.py:95-113): prefill leaves
+    bit-identical K / V rows at the prefix positions of every slot, so the single-pass decode attention may read them from slot 0 —
+    ids, the decode step's logits and the whole cache after 24 steps are bit for bit those of shared_prefix = 0."""
+    cfg = TINY_LLAMA
+    llm, _ = make_llama(cfg, 35, torch.bfloat16)
+    gen = torch.Generator().manual_seed(12)
+    P, B = 11, 40
+    pre = torch.randn(P, cfg.hidden_size, generator=gen) * 0.05
+    tails = [torch.randn(n, cfg.hidden_size, generator=gen) * 0.05 for n in (9, 140, 14, 5, 77, 30, 21, 1)]
+    prompts = [torch.cat([pre, tails[b % len(tails)] * (1.0 + 0.01 * (b // len(tails)))]) for b in range(B)]
+    lens = [int(p.shape[0]) for p in prompts]
+    x = torch.cat(prompts).to(DEV, torch.bfloat16)
+    ids0, n0 = llm.generate_packed(x.clone(), lens, 24, use_eos=False)
+    k0, v0 = llm._kv[0].clone(), llm._kv[1].clone()
+    for c in (k0, v0):                                   # (layers, slots, n_kv, max_ctx, D)
+        assert torch.equal(c[:, :B, :, :P], c[:, :1, :, :P].expand(-1, B, -1, -1, -1))
+    llm._kv[0].zero_(); llm._kv[1].zero_()
+    ids1, n1 = llm.generate_packed(x.clone(), lens, 24, use_eos=False, shared_prefix=P)
+    assert n0 == n1 and torch.equal(ids0, ids1)
+    assert torch.equal(llm._kv[0], k0) and torch.equal(llm._kv[1], v0)
+    nxt = [(7 * b + 3) % cfg.vocab_size for b in range(B)]
+    assert torch.equal(_decode_step_logits(llm, prompts, nxt, shared_prefix=P), _decode_step_logits(llm, prompts, nxt))
+    with pytest.raises(pkg("_lib").SpeechLLMError):
+        llm.generate_packed(x.clone(), lens, 4, use_eos=False, shared_prefix=min(lens) + 1)
 
 
 @pytest.mark.parametrize("B", [40, 72, 130, 260])
