@@ -55,6 +55,7 @@ static const SlEnv* env_load() {
   e.decode_tiled = env_int("SL_DECODE_TILED", 1);
   e.stream_k = env_int("SL_STREAM_K", 1);
   e.skinny_alt = env_int("SL_SKINNY_ALT", 0);
+  e.prefill_share_prefix = env_int("SL_PREFILL_SHARE_PREFIX", 1);
   e.gemm_ko = env_int("SL_GEMM_KO", 0);
   { const char* sp = getenv("SL_GEMM_STAMP_PTR"); e.gemm_stamp_ptr = (sp && sp[0]) ? strtoull(sp, nullptr, 16) : 0ull; }
   const char* g = getenv("SL_DISABLE_GLDS");

@@ -225,6 +225,7 @@ struct SlEnv {
   int gemm_log;            // SL_GEMM_LOG          1 = every sl_gemm* call prints its shape and flags on stderr (shape census for tuning)
   int no_swap_epilogue;    // SL_NO_SWAP_EPILOGUE  1 = the 256-tile GEMM keeps the LDS-turned rows epilogue where the swapped-operand form applies (A/B)
   int decode_tiled;        // SL_DECODE_TILED      1 (default) = decode steps above ~900 rows run o and gate/up on the row-major 256-tile kernels, 0 = streaming forms
+  int prefill_share_prefix; // SL_PREFILL_SHARE_PREFIX 1 (default) = prefill computes a shared prompt prefix (sl_kv_cache.shared_prefix) once per batch, 0 = per sequence (A/B)
   int skinny_alt;          // SL_SKINNY_ALT        1 = o / down at M <= 8 keep the two-steps-in-flight structure of the larger row counts (A/B)
   int stream_k;            // SL_STREAM_K          stream-K form of the 256-tile GEMM when a workspace is supplied: 0 = never, 1 = by rule (default), 2 = whenever the form allows
   int gemm_ko;             // SL_GEMM_KO           debug builds (-DSL_GEMM_DEBUG): knock-out bits of the phased 256-tile GEMM (1 reads, 2 DMA, 4 MFMAs)

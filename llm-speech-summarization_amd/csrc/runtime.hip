@@ -456,9 +456,9 @@ static size_t llama_carve(const sl_llama_model* m, int64_t n_tok, int nseq, void
   w.rstd_b = (float*)c.take((size_t)nseq * sizeof(float));
   w.tok_seq = (int32_t*)c.take(n_tok * sizeof(int32_t));
   w.tok_pos = (int32_t*)c.take(n_tok * sizeof(int32_t));
-  w.cu = (int32_t*)c.take((nseq + 1) * sizeof(int32_t));
-  w.cuk = (int32_t*)c.take(nseq * sizeof(int32_t));
-  w.klen = (int32_t*)c.take(nseq * sizeof(int32_t));
+  w.cu = (int32_t*)c.take((nseq + 2) * sizeof(int32_t));     // + 1: the shared prompt prefix is one more attention sequence in prefill
+  w.cuk = (int32_t*)c.take((nseq + 1) * sizeof(int32_t));
+  w.klen = (int32_t*)c.take((nseq + 1) * sizeof(int32_t));
   return c.off + 256;
 }
 
@@ -478,6 +478,27 @@ static int llama_check(const sl_llama_model* m, const sl_kv_cache* kv) {
 
 static inline size_t kv_layer_bytes(const sl_llama_model* m, const sl_kv_cache* kv) {
   return (size_t)kv->slots * m->n_kv_heads * kv->max_ctx * m->head_dim * sl_dtype_size(m->dtype);
+}
+
+// ---- shared prompt prefix in prefill (sl_kv_cache.shared_prefix = P): the P rows every sequence opens with are computed once ----
+// rows of the packed prompt buffer gathered by an index list (16-byte pieces; dst and src do not overlap)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int32_t* __restrict__ map,
+                                                          int64_t n_rows, int row_vec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows * row_vec) return;
+  const int64_t r = i / row_vec;
+  const int c = (int)(i - r * row_vec);
+  dst[i] = src[(int64_t)map[r] * row_vec + c];
+}
+// K / V rows [0, P) of slot 0 copied to slots 1 .. nseq-1 of one layer's cache: grid (P, n_kv, nseq - 1); lanes 0..31 move the K row,
+// 32..63 the V row, 16 bytes each (rows of 256 B in bf16, 512 B in fp32)
+__global__ __launch_bounds__(64) void kv_prefix_broadcast_kernel(uint4* __restrict__ kc, uint4* __restrict__ vc, int nkv, int max_ctx, int row_vec) {
+  const int pos = blockIdx.x, h = blockIdx.y, s = blockIdx.z + 1;
+  uint4* c = threadIdx.x < 32 ? kc : vc;
+  const int lane = threadIdx.x & 31;
+  if (lane >= row_vec) return;
+  const int64_t src = ((int64_t)h * max_ctx + pos) * row_vec + lane;
+  c[((int64_t)s * nkv * max_ctx) * row_vec + src] = c[src];
 }
 
 // one decoder layer over `n` token rows; attention chosen by `decode`
@@ -502,8 +523,11 @@ static int dec_gemm(const sl_llama_model* m, const LlamaWs& w, const void* A, in
 // rstd_chain (decode): the o / down projections run K-split, so their reduce passes emit the RMSNorm scale of the rows
 // they store and the next fused GEMM (gate/up, next layer's qkv, lm_head) takes it instead of recomputing it per block;
 // rstd_qkv = scale of x on entry (NULL: this layer's qkv takes its own statistics)
+// prefix_bcast = P > 0 (prefill with a shared prompt prefix): the P prefix rows were appended to slot 0 only and are copied to the other
+// bcast_slots - 1 slots before attention, in which the prefix is one more sequence (nseq counts it)
 static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, void* x, int64_t n, LlamaWs& w, bool decode, int nseq,
-                       int max_qlen, const int32_t* ctx_len_dev, hipStream_t st, bool rstd_chain = false, const float* rstd_qkv = nullptr) {
+                       int max_qlen, const int32_t* ctx_len_dev, hipStream_t st, bool rstd_chain = false, const float* rstd_qkv = nullptr,
+                       int prefix_bcast = 0, int bcast_slots = 0) {
   const sl_llama_layer& L = m->layers[l];
   const int dt = m->dtype, H = m->hidden, D = m->head_dim, nh = m->n_heads, nkv = m->n_kv_heads;
   const int qkv_w = (nh + 2 * nkv) * D;
@@ -551,6 +575,12 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
   if (decode) {
     SL_TRY(sl_attn_decode_split_impl(w.qkv, qkv_w, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1, kv->shared_prefix));
   } else {
+    if (prefix_bcast > 0 && bcast_slots > 1) {
+      const int row_vec = (int)(D * sl_dtype_size(dt) / 16);
+      SL_CHECK_ARG(row_vec <= 32 && (D * sl_dtype_size(dt)) % 16 == 0, "llama: shared prefix broadcast needs K / V rows of <= 512 bytes");
+      hipLaunchKernelGGL(kv_prefix_broadcast_kernel, dim3(prefix_bcast, nkv, bcast_slots - 1), dim3(64), 0, st, (uint4*)kc, (uint4*)vc, nkv, kv->max_ctx, row_vec);
+      SL_CHECK_LAUNCH("kv_prefix_broadcast");
+    }
     sl_attn_args a;
     memset(&a, 0, sizeof(a));
     a.q = w.qkv; a.q_row_stride = qkv_w; a.q_head_stride = D;
@@ -580,34 +610,79 @@ extern "C" int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, 
   LlamaWs w;
   const size_t need = llama_carve(m, n_tok, nseq, workspace, workspace_bytes, w);
   SL_CHECK_ARG(need <= workspace_bytes, "sl_llama_prefill: workspace %zu B < required %zu B", workspace_bytes, need);
-  std::vector<int32_t> tseq(n_tok), tpos(n_tok), cuk(nseq), kl(nseq);
+  std::vector<int32_t> tseq(n_tok), tpos(n_tok), cuk(nseq + 1), kl(nseq + 1), ctx(nseq), cuq(nseq + 2), last_row(nseq);
   int max_q = 0;
+  // Shared prompt prefix (sl_kv_cache.shared_prefix = P, the caller's promise that rows [0, P) of every sequence are the same rows): they
+  // are computed ONCE — the batch becomes [P prefix rows | tail of sequence 0 | tail of sequence 1 | ...], the prefix's K / V rows are
+  // appended to slot 0 and copied to the other slots in every layer, and attention sees the prefix as one more sequence while a tail's
+  // queries attend [prefix + tail] keys of their own slot (causal with klen > qlen).  Every row-wise product, RoPE at the row's own
+  // position and attention over the same keys in the same order give the bits the unshared pass gives (asserted on the cache and the
+  // logits).  Not with hidden_taps (they are per row of the caller's layout) or when a sequence is nothing but the prefix.
+  int P = (kv->shared_prefix > 0 && nseq > 1 && !hidden_taps && sl_env().prefill_share_prefix) ? kv->shared_prefix : 0;
   for (int s = 0; s < nseq; ++s) {
     const int len = cu_seqlens_host[s + 1] - cu_seqlens_host[s];
     SL_CHECK_ARG(len > 0 && len <= kv->max_ctx, "sl_llama_prefill: sequence %d length %d outside (0, max_ctx=%d]", s, len, kv->max_ctx);
-    for (int t = 0; t < len; ++t) { tseq[cu_seqlens_host[s] + t] = s; tpos[cu_seqlens_host[s] + t] = t; }
-    cuk[s] = s * m->n_kv_heads * kv->max_ctx;  // first cache row of the sequence (rows of D elements, head-major inside)
-    kl[s] = len;
-    if (len > max_q) max_q = len;
+    SL_CHECK_ARG(kv->shared_prefix <= len, "sl_llama_prefill: kv cache shared_prefix %d exceeds sequence %d (%d tokens)", kv->shared_prefix, s, len);
+    if (len <= P) P = 0;
   }
-  SL_HIP(hipMemcpyAsync(w.tok_seq, tseq.data(), n_tok * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemcpyAsync(w.tok_pos, tpos.data(), n_tok * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemcpyAsync(w.cu, cu_seqlens_host, (nseq + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemcpyAsync(w.cuk, cuk.data(), nseq * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemcpyAsync(w.klen, kl.data(), nseq * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemcpyAsync(ctx_len_dev, kl.data(), nseq * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  int64_t n_run = n_tok;       // rows the layers run over
+  int nseq_attn = nseq;
+  if (P > 0) {
+    std::vector<int32_t> map;
+    map.reserve(n_tok);
+    for (int t = 0; t < P; ++t) { map.push_back(cu_seqlens_host[0] + t); }
+    cuq[0] = 0; cuq[1] = P; cuk[0] = 0; kl[0] = P;
+    for (int t = 0; t < P; ++t) { tseq[t] = 0; tpos[t] = t; }
+    max_q = P;
+    for (int s = 0; s < nseq; ++s) {
+      const int len = cu_seqlens_host[s + 1] - cu_seqlens_host[s], tail = len - P;
+      const int r0 = (int)map.size();
+      for (int t = 0; t < tail; ++t) { map.push_back(cu_seqlens_host[s] + P + t); tseq[r0 + t] = s; tpos[r0 + t] = P + t; }
+      cuq[s + 2] = r0 + tail;
+      cuk[s + 1] = s * m->n_kv_heads * kv->max_ctx;
+      kl[s + 1] = len; ctx[s] = len;
+      last_row[s] = r0 + tail - 1;
+      if (tail > max_q) max_q = tail;
+    }
+    n_run = (int64_t)map.size();
+    nseq_attn = nseq + 1;
+    // x -> compact rows: gathered into the (still unused) FFN scratch, then copied back to the head of x
+    const int row_vec = (int)((size_t)H * sz / 16);
+    SL_CHECK_ARG(((size_t)H * sz) % 16 == 0, "sl_llama_prefill: hidden rows must be a multiple of 16 bytes");
+    SL_HIP(hipMemcpyAsync(w.tok_pos, map.data(), n_run * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n_run * row_vec + 255) / 256)), dim3(256), 0, st, (const uint4*)x, (uint4*)w.mid, w.tok_pos, n_run, row_vec);
+    SL_CHECK_LAUNCH("gather_rows");
+    SL_HIP(hipMemcpyAsync(x, w.mid, (size_t)n_run * H * sz, hipMemcpyDeviceToDevice, st));
+    SL_HIP(hipStreamSynchronize(st));      // `map` leaves scope / tok_pos is rewritten below
+  } else {
+    for (int s = 0; s < nseq; ++s) {
+      const int len = cu_seqlens_host[s + 1] - cu_seqlens_host[s];
+      for (int t = 0; t < len; ++t) { tseq[cu_seqlens_host[s] + t] = s; tpos[cu_seqlens_host[s] + t] = t; }
+      cuk[s] = s * m->n_kv_heads * kv->max_ctx;  // first cache row of the sequence (rows of D elements, head-major inside)
+      kl[s] = len; ctx[s] = len;
+      cuq[s] = cu_seqlens_host[s];
+      last_row[s] = cu_seqlens_host[s + 1] - 1;
+      if (len > max_q) max_q = len;
+    }
+    cuq[nseq] = cu_seqlens_host[nseq];
+  }
+  SL_HIP(hipMemcpyAsync(w.tok_seq, tseq.data(), n_run * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.tok_pos, tpos.data(), n_run * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.cu, cuq.data(), (nseq_attn + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.cuk, cuk.data(), nseq_attn * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(w.klen, kl.data(), nseq_attn * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(ctx_len_dev, ctx.data(), nseq * sizeof(int32_t), hipMemcpyHostToDevice, st));
   SL_HIP(hipStreamSynchronize(st));
   for (int l = 0; l < m->n_layers; ++l) {
     if (hidden_taps) SL_HIP(hipMemcpyAsync(bptr(hidden_taps) + (size_t)l * n_tok * H * sz, x, n_tok * H * sz, hipMemcpyDeviceToDevice, st));
-    SL_TRY(llama_layer(m, kv, l, x, n_tok, w, false, nseq, max_q, nullptr, st));
+    SL_TRY(llama_layer(m, kv, l, x, n_run, w, false, nseq_attn, max_q, nullptr, st, false, nullptr, P, nseq));
   }
   if (hidden_taps) {
     SL_TRY(sl_rmsnorm(x, bptr(hidden_taps) + (size_t)m->n_layers * n_tok * H * sz, m->final_norm, n_tok, H, m->rms_eps, dt, stream));
   }
   // last-token rows -> final norm -> lm_head (fp32 logits)
   for (int s = 0; s < nseq; ++s)
-    SL_HIP(hipMemcpyAsync(bptr(w.last) + (size_t)s * H * sz, bptr(x) + (size_t)(cu_seqlens_host[s + 1] - 1) * H * sz, H * sz,
-                          hipMemcpyDeviceToDevice, st));
+    SL_HIP(hipMemcpyAsync(bptr(w.last) + (size_t)s * H * sz, bptr(x) + (size_t)last_row[s] * H * sz, H * sz, hipMemcpyDeviceToDevice, st));
   SL_TRY(sl_rmsnorm(w.last, w.last, m->final_norm, nseq, H, m->rms_eps, dt, stream));
   SL_TRY(gemm(dt, w.last, H, m->lm_head, H, logits, m->vocab, nullptr, nullptr, 0, nseq, m->vocab, H, SL_ACT_NONE, 1, st));
   return 0;

@@ -259,19 +259,22 @@ def test_llama_decode_step_large_batch_matches_small_batch(dtype, tol):
         assert rel_err(big[b], small[b % 5]) < tol, b
 
 
-def test_llama_shared_prompt_prefix_is_read_from_slot_zero_with_unchanged_bits():
-    """sl_kv_cache.shared_prefix (one prompt template in front of every utterance, ref:inference.py:95-113): prefill leaves
-    bit-identical K / V rows at the prefix positions of every slot, so the single-pass decode attention may read them from slot 0 —
-    ids, the decode step's logits and the whole cache after 24 steps are bit for bit those of shared_prefix = 0."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_llama_shared_prompt_prefix_is_read_from_slot_zero_with_unchanged_bits(dtype):
+    """sl_kv_cache.shared_prefix (one prompt template in front of every utterance, ref:inference.py:95-113): an unshared prefill
+    leaves bit-identical K / V rows at the prefix positions of every slot; with the promise given, prefill computes the prefix rows
+    once (compacted batch, K / V copied to every slot, the prefix as one more attention sequence) and the single-pass decode
+    attention reads them from slot 0 — ids, the decode step's logits and the whole cache after 24 steps are bit for bit those of
+    shared_prefix = 0."""
     cfg = TINY_LLAMA
-    llm, _ = make_llama(cfg, 35, torch.bfloat16)
+    llm, _ = make_llama(cfg, 35, dtype)
     gen = torch.Generator().manual_seed(12)
     P, B = 11, 40
     pre = torch.randn(P, cfg.hidden_size, generator=gen) * 0.05
     tails = [torch.randn(n, cfg.hidden_size, generator=gen) * 0.05 for n in (9, 140, 14, 5, 77, 30, 21, 1)]
     prompts = [torch.cat([pre, tails[b % len(tails)] * (1.0 + 0.01 * (b // len(tails)))]) for b in range(B)]
     lens = [int(p.shape[0]) for p in prompts]
-    x = torch.cat(prompts).to(DEV, torch.bfloat16)
+    x = torch.cat(prompts).to(DEV, dtype)
     ids0, n0 = llm.generate_packed(x.clone(), lens, 24, use_eos=False)
     k0, v0 = llm._kv[0].clone(), llm._kv[1].clone()
     for c in (k0, v0):                                   # (layers, slots, n_kv, max_ctx, D)

@@ -14,8 +14,8 @@ for B in Bs:
     x = (torch.randn(B * S, larch.hidden_size, device=dev) * 0.02).to(torch.bfloat16)
     SP = int(os.environ.get('SHARED_PREFIX', '0'))   # timing only: the rows are random, so the promise does not hold and the ids are meaningless
     llm.generate_packed(x.clone(), [S] * B, new, use_eos=False, shared_prefix=SP)
-    ts = []
+    ts, tp = [], []
     for _ in range(3):
         llm.generate_packed(x.clone(), [S] * B, new, use_eos=False, shared_prefix=SP)
-        ts.append(llm.last_timings_ms[1] / (new - 1))
-    print(f"B={B:5d}: decode step {sorted(ts)[1]:8.4f} ms  ({B / sorted(ts)[1]:9.1f} tok/ms)", flush=True)
+        ts.append(llm.last_timings_ms[1] / (new - 1)); tp.append(llm.last_timings_ms[0])
+    print(f"B={B:5d}: decode step {sorted(ts)[1]:8.4f} ms  ({B / sorted(ts)[1]:9.1f} tok/ms)   prefill {sorted(tp)[1]:8.2f} ms", flush=True)
