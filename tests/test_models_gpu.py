@@ -287,6 +287,13 @@ def test_llama_shared_prompt_prefix_is_read_from_slot_zero_with_unchanged_bits(d
     assert torch.equal(_decode_step_logits(llm, prompts, nxt, shared_prefix=P), _decode_step_logits(llm, prompts, nxt))
     with pytest.raises(pkg("_lib").SpeechLLMError):
         llm.generate_packed(x.clone(), lens, 4, use_eos=False, shared_prefix=min(lens) + 1)
+    # a prompt that is nothing but the prefix: prefill falls back to the per-sequence pass, decode still reads slot 0
+    prompts2 = prompts[:17] + [pre.clone()]
+    lens2 = [int(p.shape[0]) for p in prompts2]
+    x2 = torch.cat(prompts2).to(DEV, dtype)
+    a, na = llm.generate_packed(x2.clone(), lens2, 8, use_eos=False)
+    b, nb = llm.generate_packed(x2.clone(), lens2, 8, use_eos=False, shared_prefix=P)
+    assert na == nb and torch.equal(a, b)
 
 
 @pytest.mark.parametrize("B", [40, 72, 130, 260])
