@@ -717,7 +717,7 @@ def main():
         out = torch.empty(B, F_, device=dev, dtype=torch.bfloat16)
         wgu = wts.dec_wgu  # the fragment-packed, RMSNorm-folded gate/up matrices the decode graph streams
         assert len(wgu) == larch.num_hidden_layers
-        # above 32 rows the o projection's reduce pass hands the RMSNorm scale down (runtime.hip decode_step): same here
+        # above 26 rows the o projection's reduce pass hands the RMSNorm scale down (runtime.hip decode_step): same here
         chain = bool(wts.struct.dec_fused_norm) and L.lib().sl_gemm_split_count(B, H, nh * D, L.dtype_code(torch.bfloat16)) > 1
         rstd = torch.rsqrt(xin.float().pow(2).mean(-1) + larch.rms_norm_eps) if chain else None
 
@@ -808,7 +808,7 @@ def main():
     tokens = B * new * args.steps * world
     mean = lambda v: sum(v) / max(1, len(v))
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md), where measured for this batch
-    streaming = B > 32
+    streaming = B > 26   # SL_STREAM_MIN_M default (csrc/api.hip)
     # `traffic` cannot be measured inside this process (PMC counters need rocprofv3 around it): it is READ from the committed
     # counter summary of the same two launches (tools/probe_decode_kernels.py under separate --pmc passes), and says so
     pmc, pmc_src = {}, None

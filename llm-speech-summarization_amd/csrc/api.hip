@@ -46,8 +46,10 @@ static int env_int(const char* name, int dflt) {
 
 static const SlEnv* env_load() {
   SlEnv& e = *new SlEnv();
-  e.stream_min_m = env_int("SL_STREAM_MIN_M", 32);
-  if (e.stream_min_m < 16) e.stream_min_m = 32;
+  // 26: the decode step at 17..32 sequences on either family (tools/time_decode_step.py, profiles/r04_zb_stream_min_m.txt): the skinny kernels win
+  // up to 26 rows (2.34 vs 2.36 ms), the 32-row streaming blocks from 27 (2.42 vs 2.38) to 32 (2.57 vs 2.40)
+  e.stream_min_m = env_int("SL_STREAM_MIN_M", 26);
+  if (e.stream_min_m < 16) e.stream_min_m = 26;
   e.disable_t256 = getenv("SL_DISABLE_T256") != nullptr;
   e.t256_min_tiles = env_int("SL_T256_MIN_TILES", 512);
   e.t256_min_k = env_int("SL_T256_MIN_K", 1024);

@@ -206,7 +206,7 @@ static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; 
 // sl_tuning_reload() (api.hip, exported for tools/tune_*.py) re-reads them for in-process A/B runs
 // ----------------------------------------------------------------------------------------------
 struct SlEnv {
-  int stream_min_m;        // SL_STREAM_MIN_M      (default 32)
+  int stream_min_m;        // SL_STREAM_MIN_M      (default 26) packed-weight products with more rows than this take the LDS-staged streaming kernels
   int disable_t256;        // SL_DISABLE_T256
   int t256_min_tiles;      // SL_T256_MIN_TILES    (default 512)
   int t256_min_k;          // SL_T256_MIN_K        (default 1024)

@@ -298,7 +298,7 @@ def test_llama_shared_prompt_prefix_is_read_from_slot_zero_with_unchanged_bits(d
 
 @pytest.mark.parametrize("B", [40, 72, 130, 260])
 def test_llama_large_batch_decode_equals_single(B):
-    """Batches above 32 rows decode through gemm_stream.hip (loader wave, K-split + reduce, RMSNorm scales handed down the
+    """Batches above 26 rows decode through gemm_stream.hip (loader wave, K-split + reduce, RMSNorm scales handed down the
     chain); every sequence must still produce exactly the ids it produces alone (fp32: bit-exact vs the oracle)."""
     cfg = TINY_LLAMA
     llm, sd = make_llama(cfg, 31, torch.float32)

@@ -1,5 +1,5 @@
 """Launch the two kernels that carry a decode step, as decode launches them, for rocprofv3 --pmc runs:
-gate/up weight-streaming GEMM (packed, RMSNorm scale handed in above 32 rows) and split attention over a KV cache.
+gate/up weight-streaming GEMM (packed, RMSNorm scale handed in above 26 rows) and split attention over a KV cache.
 
     python tools/probe_decode_kernels.py [B=256] [ctx=264]
 """
