@@ -642,6 +642,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 #else
 #define SL_KV_LOAD(ptr) (*(const u32x4_t*)(ptr))
 #endif
+// floats per partial record (REP x 128 outputs, REP maxima, REP sums), rounded up to whole 128-byte lines so that the records of
+// different (sequence, kv head, split) blocks never share a line (the in-launch merge hands them between workgroups with sc1 stores)
+constexpr int split_record_floats(int rep) { return (rep * 128 + 2 * rep + 31) / 32 * 32; }
 constexpr int DSPLIT = 64;  // keys per block (KS = 128 for batches that fill the chip anyway: half the records to merge)
 
 // Partial records handed from the split blocks to the block that merges them INSIDE the launch (cnt != nullptr): every record
@@ -661,7 +664,7 @@ __device__ __forceinline__ float ld_rec_sc1(const float* p) { return __hip_atomi
 template <typename T, int REP>
 __device__ __forceinline__ void split_arrive_and_merge(float* __restrict__ part, int32_t* __restrict__ cnt, T* __restrict__ out, int b, int kvh, int nkv,
                                                         int nsplit) {
-  constexpr int D = 128, PSTRIDE = REP * D + 2 * REP, U = 8;
+  constexpr int D = 128, PSTRIDE = split_record_floats(REP), U = 8;
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record stores have reached the memory side
   __syncthreads();
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
   constexpr int D = 128;
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int EPL = D / 16, CPLN = EPL / VEC;
-  constexpr int PSTRIDE = REP * D + 2 * REP;  // floats per partial record
+  constexpr int PSTRIDE = split_record_floats(REP);  // floats per partial record
   constexpr int NPS = KS / 16;   // passes of 16 keys
   constexpr bool MFMA_QK = sizeof(T) == 2;   // bf16: scores on the matrix core (the VALU form was ~75 % VALU-busy at B = 256)
   constexpr int KT_BYTES = MFMA_QK ? KS * D * (int)sizeof(T) : 16, RED_BYTES = 16 * REP * D * (int)sizeof(float);
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
   constexpr int D = 128;
   const int b = blockIdx.y, head = blockIdx.x, d = threadIdx.x;
   const int rep = nh / nkv, kvh = head / rep, h = head % rep;
-  const int pstride = rep * D + 2 * rep;
+  const int pstride = split_record_floats(rep);
   const float* base = part + ((int64_t)b * nkv + kvh) * nsplit * pstride;
   float M = -INFINITY;
   for (int s = 0; s < nsplit; ++s) M = fmaxf(M, base[(int64_t)s * pstride + rep * D + h]);
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 // workspace = the partial records, then (256-byte aligned) one arrival counter per (sequence, kv head) for the in-launch merge
 static size_t attn_split_records_bytes(int B, int n_heads, int n_kv, int max_ctx) {
   const int rep = n_heads / n_kv, nsplit = (max_ctx + DSPLIT - 1) / DSPLIT;   // sized for the finer split
-  return ((size_t)B * n_kv * nsplit * (rep * 128 + 2 * rep) * sizeof(float) + 255) & ~(size_t)255;
+  return ((size_t)B * n_kv * nsplit * split_record_floats(rep) * sizeof(float) + 255) & ~(size_t)255;
 }
 size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx) {
   return attn_split_records_bytes(B, n_heads, n_kv, max_ctx) + (((size_t)B * n_kv * sizeof(int32_t) + 255) & ~(size_t)255);
