@@ -180,6 +180,8 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
     B = tr.local_accum                       # one accumulation window = one packed micro-batch per rank
     n_micro = B * args.kd_optimizer_steps
     waves, texts, resps = [wave] * B, [text_ids] * B, [resp_ids] * B
+    if tr.reducer is not None:
+        tr.reducer.time_exchange = True      # HIP events around every bucket on the side stream -> kd_step.comm
     # warm-up: ONE complete window including its optimizer step (first-use costs: allocator growth, transposed copies of the
     # frozen LLM weights, AdamW's exp_avg / exp_avg_sq allocation, RCCL communicator set-up), untimed; the timed windows below
     # each contain everything a step does (forward, backward, all-reduce, AdamW, in-place refresh of the kernel weights)
@@ -206,6 +208,33 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_ = float(tt.item())
     n_params = sum(p.numel() for p in tr.params)
+    # ---- what carried the gradient exchange (the N > 1 line must verify itself).  N > 1: the step's own reducer.
+    # N = 1: the same code path through a communicator of ONE rank (identity sums; RCCL refuses two ranks per device) for two extra,
+    # untimed windows, so that the fields and the side-stream / event plumbing are exercised by every default run.
+    comm, comm_error = None, None
+    try:
+        if tr.reducer is not None:
+            comm = tr.reducer.comm_info()
+            comm["source"] = f"the timed windows' own exchange over {world} ranks"
+        else:
+            red = mod("dist").BucketedAllReduce(tr.enc_tape.arena, single_rank=True, backend="sl")
+            red.time_exchange = True
+            tr.reducer = red
+            try:
+                for _ in range(2):
+                    tr.micro_batch(waves, texts, resps)
+                torch.cuda.synchronize()
+                comm = red.comm_info()
+                comm["source"] = "one-rank communicator driven through the same reducer for two extra untimed windows (identity sums: durations are local copies, not xGMI)"
+            finally:
+                tr.reducer = None
+                red.close()
+        if comm["backend"] != comm["requested_backend"] or comm["fell_back"]:
+            comm_error = f"gradient exchange fell back from {comm['requested_backend']} to {comm['backend']}"
+        elif comm["backend"] == "sl" and comm["rccl_nranks"] != (world if world > 1 else 1):
+            comm_error = f"RCCL communicator spans {comm['rccl_nranks']} ranks, the job has {world}"
+    except Exception as e:      # noqa: BLE001 — reported in the line
+        comm_error = f"{type(e).__name__}: {e}"[:300]
     # algorithmic FLOPs of one micro-step: 3 x encoder forward (fwd + dgrad + wgrad) + 2 x LLM prefill with
     # all-position logits over the audio sequence (student fwd + dgrad) + 1 x over the text sequence (teacher)
     a_ = larch
@@ -276,7 +305,7 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
                          "algorithmic_flops_per_sample": round(flops), "seq_audio": S_a, "seq_text": S_t,
                          "formula": "3 enc_fwd + 2 prefill_full(S_audio) + prefill_full(S_text), SURVEY.md §8d; per rank",
                          "frac_tail_row_logits": round(ach_tail / MFMA_PEAK_TFLOPS, 4), "flops_per_sample_tail_row_logits": round(flops_tail)},
-            "per_rank_regime_probe": probe,
+            "per_rank_regime_probe": probe, "comm": comm, **({"error": comm_error} if comm_error else {}),
             "scaling_mode": ("weak: train.per_rank_accum = %d" % tr.local_accum) if conf.train["per_rank_accum"] else "strong: grad_accum_interval dealt to the ranks (reference-equivalent)",
             "optimizer_steps": args.kd_optimizer_steps, "window_ms": window_ms, "micro_steps_per_rank": n_micro, "grad_accum_interval": tr.accum,
             "trainable_params": n_params, "allreduce_bytes_per_optimizer_step": n_params * 4 if world > 1 else 0,
@@ -503,13 +532,33 @@ def dry_rank(args, rank, world) -> None:
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    # the self-describing fields of the real line, produced by the same code on CPU tensors over gloo: per-rank work gathered from
+    # the ranks, and the gradient exchange's comm_info() from a small arena through BucketedAllReduce
+    mine = [float(rank), float(done), float(done) * 10.0, float(done) * 256.0, float(tt.item())]
+    per_rank = [mine]
+    comm = None
+    if world > 1:
+        gathered = [torch.zeros(len(mine), dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(mine, dtype=torch.float64))
+        per_rank = [g_.tolist() for g_ in gathered]
+        dm = mod("dist")
+        arena = dm.GradArena([("b", (1000,)), ("a", (24,))], "cpu")
+        arena.flat.fill_(1.0)
+        red = dm.BucketedAllReduce(arena, min_bucket_bytes=4 * 512)
+        red.ready(["b"]); red.ready(["a"])
+        red.finish()
+        comm = red.comm_info()
+        comm["sum_ok"] = bool((arena.views["b"] == float(world)).all())
+        red.close()
     if os.environ.get("SL_BENCH_DRY_FAIL_RANK") == str(rank):
         sys.exit(7)
     if rank == 0:
         print("a stray stdout line from a rank", flush=True)
         print(json.dumps({"metric": "dry run of the launcher (no GPU work)", "value": 0.0, "unit": "tokens/s",
                           "n_gpus": int(os.environ.get("SL_BENCH_DRY_REPORT_GPUS", world)), "steps": done, "warmup": args.warmup,
-                          "ms_per_step": float(tt.item()) * 1e3 / max(1, done), "dry_run": True}), flush=True)
+                          "ms_per_step": float(tt.item()) * 1e3 / max(1, done), "dry_run": True,
+                          "per_rank": [{"rank": int(r_[0]), "utterances": int(r_[1]), "audio_sec": r_[2], "tokens": int(r_[3]), "elapsed_s": r_[4]} for r_ in per_rank],
+                          "collective_backend": (dist.get_backend() if world > 1 else None), "kd_step": {"comm": comm}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -695,7 +744,13 @@ def main():
         torch.cuda.synchronize()
         seq_stage = {"encode": round(enc_ms.pop(n_e), 3), "prefill": round(prefill_ms.pop(n_p), 3), "decode": round(decode_ms[n_d], 3),
                      "decode_per_step": round(decode_ms.pop(n_d) / max(1, new - 1), 4)}
+    # what every rank did inside the bracket (replicas: each rank its own utterances; the line must show them, not assume them)
+    mine = [float(rank), float(B * args.steps), float(B * args.steps * args.audio_sec), float(B * new * args.steps), elapsed]
+    per_rank = [mine]
     if dist is not None:
+        gathered = [torch.zeros(len(mine), device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(mine, device=dev, dtype=torch.float64))
+        per_rank = [g_.tolist() for g_ in gathered]
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -805,7 +860,8 @@ def main():
         leave()
         return
 
-    tokens = B * new * args.steps * world
+    tokens = int(sum(r_[3] for r_ in per_rank))      # == B * new * steps * world: summed from what the ranks report
+    assert tokens == B * new * args.steps * world and len(per_rank) == world
     mean = lambda v: sum(v) / max(1, len(v))
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/README.md), where measured for this batch
     streaming = B > 26   # SL_STREAM_MIN_M default (csrc/api.hip)
@@ -852,6 +908,8 @@ def main():
                    "utterances_per_gpu": B, "audio_sec": args.audio_sec, "prompt_tokens": S, "max_new_tokens": new,
                    "shared_prompt_prefix_tokens": n_pre,   # the template rows in front of every utterance: decode attention reads their K/V once per batch
                    "parallelism": f"replicas x{world} (sharded by utterance, no collective)", "batches_in_flight_per_gpu": n_pipe},
+        "per_rank": [{"rank": int(r_[0]), "utterances": int(r_[1]), "audio_sec": r_[2], "tokens": int(r_[3]), "elapsed_s": round(r_[4], 3)} for r_ in per_rank],
+        "collective_backend": (dist.get_backend() if dist is not None else None),
         "audio_sec_per_s_encoder_alone": round(B * args.audio_sec * world / (min(enc_alone_ms) * 1e-3), 1),
         "audio_sec_per_s_in_pipeline": round(B * args.audio_sec * args.steps * world / elapsed, 1),
         "audio_sec_note": "encoder_alone = the encoder stage (conv stack + 24 layers + pool + projector) run on its own on one batch, HIP events; "

@@ -47,7 +47,8 @@ enum sl_act { SL_ACT_NONE = 0, SL_ACT_GELU = 1, SL_ACT_SILU_MUL = 2, SL_ACT_ROPE
 enum sl_w_layout { SL_W_ROWMAJOR = 0, SL_W_PACKED = 1 };
 
 const char* sl_last_error(void);       /* thread-local, never NULL */
-int sl_version(void);                  /* ABI version, bumps on any signature change */
+#define SL_ABI_VERSION 6
+int sl_version(void);                  /* == SL_ABI_VERSION of the header the library was built from; bumps on any signature change */
 int sl_device_arch(char* buf, int n);  /* gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-" */
 /* Tuning switches (SL_* environment variables, documented in csrc/common.h) are read once, at first use; tools that change
  * them inside one process call this to re-read them.  Not needed in normal operation. */
@@ -700,6 +701,8 @@ int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, const sl_llama_
  *   sl_allreduce_sum  : in place on `count` elements (SL_F32 / SL_BF16) of caller-owned device memory, asynchronous on `stream`
  *                       (the KD step passes a side stream behind an event on the kernels' stream); same call order on all ranks.
  *   sl_comm_destroy   : collective; the caller has synchronised the streams it used.
+ *   sl_comm_abort     : LOCAL tear-down (ncclCommAbort): for a communicator whose peers may never have made theirs — a start-up the
+ *                       ranks voted to abandon, or one obtained after this rank had given up waiting (ABI version 6).
  * --------------------------------------------------------------------------------------------- */
 #define SL_COMM_ID_BYTES 128
 typedef struct sl_comm_s* sl_comm;
@@ -707,6 +710,7 @@ int sl_comm_unique_id(void* id_out /* SL_COMM_ID_BYTES */);
 int sl_comm_init(sl_comm* comm_out, const void* unique_id /* SL_COMM_ID_BYTES */, int32_t rank, int32_t world);
 int sl_allreduce_sum(sl_comm comm, void* buf, int64_t count, int32_t dtype, sl_stream stream);
 int sl_comm_destroy(sl_comm comm);
+int sl_comm_abort(sl_comm comm);
 int32_t sl_comm_rank(sl_comm comm);    /* -1: not a communicator */
 int32_t sl_comm_world(sl_comm comm);
 

@@ -166,6 +166,7 @@ _PROTOS = {
     "sl_comm_init": (c_i32, [C.POINTER(c_vp), c_vp, c_i32, c_i32]),
     "sl_allreduce_sum": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     "sl_comm_destroy": (c_i32, [c_vp]),
+    "sl_comm_abort": (c_i32, [c_vp]),
     "sl_comm_rank": (c_i32, [c_vp]),
     "sl_comm_world": (c_i32, [c_vp]),
     "sl_pack_weight": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),

@@ -18,7 +18,7 @@ void sl_set_error(const char* fmt, ...) {
 
 extern "C" const char* sl_last_error(void) { return g_err; }
 
-extern "C" int sl_version(void) { return 5; }   // 5: sl_kv_cache.shared_prefix; 4: sl_gemm_ex_args.sk_ws / sk_ws_bytes, sl_gemm_streamk_workspace_bytes; 3: sl_gemm_ex_args.amax_*, sl_greedy_select_partial, sl_adamw_step, sl_layernorm_bwd_ws, sl_decode_graph_cache_clear
+extern "C" int sl_version(void) { return SL_ABI_VERSION; }   // 6: sl_comm_abort, SL_MAX_DECODE_BATCH 2048, sl_gemm_fused.norm_out / norm_gain (grew that struct in round 4), sl_generate_opts (compaction); 5: sl_kv_cache.shared_prefix; 4: sl_gemm_ex_args.sk_ws / sk_ws_bytes, sl_gemm_streamk_workspace_bytes; 3: sl_gemm_ex_args.amax_*, sl_greedy_select_partial, sl_adamw_step, sl_layernorm_bwd_ws, sl_decode_graph_cache_clear
 
 extern "C" int sl_device_arch(char* buf, int n) {
   SL_CHECK_ARG(buf != nullptr && n > 0, "sl_device_arch: bad buffer");

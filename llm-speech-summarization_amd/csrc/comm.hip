@@ -19,6 +19,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: sl_comm_abort falls back to CommDestroy without it
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -37,6 +38,7 @@ const RcclApi& rccl() {
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
     a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+    a.CommAbort = (decltype(a.CommAbort))dlsym(a.handle, "ncclCommAbort");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
     a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
   });
@@ -116,6 +118,21 @@ extern "C" int sl_comm_destroy(sl_comm comm) {
   c->magic = 0;
   delete c;
   if (r != ncclSuccess) { sl_set_error("ncclCommDestroy: %s", api.GetErrorString(r)); return SL_ERR_LAUNCH; }
+  return 0;
+}
+
+// Local tear-down of a communicator whose peers may never have made theirs (a start-up that the group voted to abandon, or a
+// communicator obtained after this rank had already given up): ncclCommAbort does not wait for the other ranks.
+extern "C" int sl_comm_abort(sl_comm comm) {
+  SlComm* c = (SlComm*)comm;
+  if (!c) return 0;
+  SL_CHECK_ARG(c->magic == SL_COMM_MAGIC, "sl_comm_abort: not a communicator");
+  const RcclApi& api = rccl();
+  ncclResult_t r = ncclSuccess;
+  if (api.ok) r = api.CommAbort ? api.CommAbort(c->comm) : api.CommDestroy(c->comm);
+  c->magic = 0;
+  delete c;
+  if (r != ncclSuccess) { sl_set_error("ncclCommAbort: %s", api.GetErrorString(r)); return SL_ERR_LAUNCH; }
   return 0;
 }
 

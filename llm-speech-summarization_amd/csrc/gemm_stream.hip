@@ -892,6 +892,7 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
   s.sps = (nst + c.splits - 1) / c.splits;
   s.splits = (nst + s.sps - 1) / s.sps;   // no empty splits
   c.splits = s.splits;
+  SL_CHECK_ARG(sx.norm_out == nullptr || sx.rstd_out != nullptr, "sl_gemm: norm_out comes from the pass that forms rstd_out (pass both)");
   if (sx.rstd_out) {
     SL_CHECK_ARG(act == SL_ACT_NONE && (p.N + 15) / 16 * 4 <= 1024 && s.splits > 1,
                  "sl_gemm: rstd_out needs the plain epilogue, N <= 4096 and a K-split (splits=%d; see sl_gemm_split_count)", s.splits);
@@ -900,7 +901,8 @@ int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void*
   s.part_ss = s.part ? s.part + (size_t)s.splits * p.M * s.np : nullptr;
   // in-kernel fix-up (wide form): the tile / row-block counters and the row-statistics partials must fit the header
   s.cnt = nullptr; s.ss_part = nullptr;
-  if (wide && s.splits > 1 && sl_env().stream_fixup != 0) {
+  // (norm_out is written by the reduce launch only: a call that asks for it keeps that launch)
+  if (wide && s.splits > 1 && sl_env().stream_fixup != 0 && sx.norm_out == nullptr) {
     const int nbv = ((p.N + 15) / 16 + 7) / 8, mbl = (p.M + 255) / 256;
     if (nbv * mbl <= 1024 && mbl <= 64 && (sx.rstd_out == nullptr || nbv <= 32)) {
       s.cnt = (int*)split_ws;

@@ -238,6 +238,11 @@ class Trainer():
                     self.validate(epoch)
             self.validate(epoch)
 
+    def close(self) -> None:
+        """End of the run: every rank tears down the gradient exchange's communicator together (train.py calls it before the
+        process group goes away)."""
+        self.kd.close()
+
     # -- validation (ref:trainer.py:400-528) ---------------------------------------------------------
     def _val_sample(self, sample_idx):
         """One validation sample -> (audio_embeds (1,P,H), text ids, response ids, text)."""

@@ -1042,6 +1042,12 @@ class KDTrainer:
             self.optimizer_step()
         return out
 
+    def close(self) -> None:
+        """Tear the data-parallel reducer's communicator down (a collective over the ranks; BucketedAllReduce never does it from
+        __del__).  Idempotent; the step must not be used for exchanges afterwards."""
+        if self.reducer is not None:
+            self.reducer.close()
+
     def close_window(self) -> None:
         """Optimizer step of a window in which THIS rank held no sample (the tail of an epoch under data parallel): its
         gradients are zero, the all-reduce still has to be joined."""

@@ -67,6 +67,7 @@ def main():
         tr.kd.reducer = dist_mod.BucketedAllReduce(tr.kd.enc_tape.arena, single_rank=True)
     if tr.kd.reducer is not None:
         tr.kd.reducer.min_bytes = 64 << 10          # several buckets even at the tiny model's 1.3 MB of gradients
+        tr.kd.reducer.time_exchange = True          # what bench.py's kd_step.comm reports: asserted by the test
     master0 = {k: v.cpu().clone() for k, v in tr.kd.master.items()}
     dev_w0 = [w.cpu().clone() for w in tr.audio_encoder.weights._keep]
     tr.kd.keep_last_grads = True
@@ -89,7 +90,9 @@ def main():
 
     tr.validate = recording_validate
     tr.train()
-    torch.save({"rank": rank, "world": world, "grads": steps, "buckets": buckets,
+    comm = tr.kd.reducer.comm_info() if tr.kd.reducer is not None else None
+    tr.close()                                      # collective tear-down of the exchange, before the process group goes
+    torch.save({"rank": rank, "comm": comm, "world": world, "grads": steps, "buckets": buckets,
                 "master": {k: v.cpu() for k, v in tr.kd.master.items()}, "master0": master0, "dev_w0": dev_w0, "val": val, "indices": tr._epoch_indices(0),
                 "windows": tr._epoch_windows(0), "step": tr.step, "optimizer_steps": tr.kd.optimizer_steps,
                 "lr": tr.lr_scheduler.get_last_lr()[0]}, out_path)

@@ -26,6 +26,12 @@ def test_gpus_2_launches_two_ranks_and_forwards_one_line():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
     assert "a stray stdout line from a rank" in r.stderr
+    # the self-describing fields survive the launcher: what every rank did, and what carried the gradient exchange
+    assert [p_["rank"] for p_ in rec["per_rank"]] == [0, 1] and all(p_["utterances"] == 3 and p_["tokens"] == 3 * 256 for p_ in rec["per_rank"])
+    assert rec["collective_backend"] == "gloo"
+    c = rec["kd_step"]["comm"]
+    assert c["backend"] == "torch" and c["group_world"] == 2 and c["group_backend"] == "gloo" and not c["fell_back"] and c["sum_ok"]
+    assert c["buckets"] == 2 and sum(c["bucket_bytes"]) == 4 * (1024 + 64) and c["rccl_nranks"] is None
 
 
 def test_wrong_n_gpus_in_the_line_is_an_error():

@@ -158,6 +158,13 @@ def test_rccl_backend_single_rank_runs_the_bucketed_exchange(tmp_path):
         assert rel_err(rccl["master"][k], plain["master"][k]) < MASTER_TOL, k
     for key in ("validation/audio_perplexity", "validation/text_perplexity"):
         assert abs(rccl["val"][key] - plain["val"][key]) < 1e-5 * plain["val"][key]
+    # the self-description bench.py prints as kd_step.comm: which library carried the exchange, how many ranks RCCL
+    # saw, the bucket sequence of the last optimizer step, its duration on the side stream (HIP events) and how much of it was overlapped
+    c = rccl["comm"]
+    assert plain["comm"] is None
+    assert c["backend"] == "sl" and c["requested_backend"] == "sl" and not c["fell_back"] and c["rccl_nranks"] == 1 and c["group_backend"] == "nccl"
+    assert c["buckets"] == len(rccl["buckets"][-1]) and c["bucket_bytes"] == [4 * (b - a) for a, b in rccl["buckets"][-1]]
+    assert c["measured_exchange_ms"] > 0.0 and 0.0 <= c["exposed_ms"] <= c["measured_exchange_ms"] and 0.0 <= c["overlap_frac"] <= 1.0
 
 
 def test_sl_comm_c_abi_one_rank_communicator_orders_against_the_compute_stream():
@@ -196,3 +203,8 @@ def test_sl_comm_c_abi_one_rank_communicator_orders_against_the_compute_stream()
     assert lib.sl_allreduce_sum(None, buf.data_ptr(), 16, L.SL_F32, side.cuda_stream) != 0
     torch.cuda.synchronize()
     L.check(lib.sl_comm_destroy(comm), "sl_comm_destroy")
+    # local tear-down (ABI 6): what a rank does with a communicator the group voted to abandon
+    comm2 = C.c_void_p()
+    L.check(lib.sl_comm_init(C.byref(comm2), ident, 0, 1), "sl_comm_init")
+    L.check(lib.sl_comm_abort(comm2), "sl_comm_abort")
+    assert lib.sl_comm_abort(None) == 0

@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_declared_in_header():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/speechllm.h but not exported"
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
-    assert L.lib().sl_version() == 5
+    assert L.lib().sl_version() == 6
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -212,6 +212,99 @@ def test_bucketed_gradient_allreduce_two_ranks_over_gloo():
     res = [q.get(timeout=120) for _ in procs]
     [p.join(timeout=60) for p in procs]
     assert all(ok for _, ok, _ in res) and all(b >= 2 for _, _, b in res)
+
+
+def _negotiate_worker(rank, world, port, q, case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def make_id():
+        calls.append("id")
+        if case == "id_fails":
+            raise RuntimeError("no rccl here")
+        return bytes(range(16))
+
+    def init_rank(ident, r, w):
+        calls.append("init")
+        assert ident == bytes(range(16)) and r == rank and w == world      # every rank received rank 0's id
+        if case == "init_fails_on_1" and r == 1:
+            raise RuntimeError("cannot reach peers")
+        return f"comm{r}"
+
+    handle, ok = distm.negotiate_comm(dist, None, "cpu", make_id, init_rank, 16, log=lambda *a, **k: None)
+    # the group must still be in step: one more collective after the handshake, whatever failed
+    t_ = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t_)
+    out = {"rank": rank, "handle": handle, "ok": ok, "calls": calls, "sum": float(t_.item())}
+    if case == "reducer_falls_back":
+        # the real class on a CPU arena, `sl` asked for, rank 1's init forced to fail: all ranks end on torch.distributed and the sums are right
+        os.environ["SL_COMM_TEST_FAIL"] = "init:1"
+        arena = distm.GradArena([("a", (300,)), ("b", (17,))], "cpu")
+        arena.flat.fill_(float(rank + 1))
+        red = distm.BucketedAllReduce(arena, min_bucket_bytes=4 * 100, backend="sl")
+        red.ready(["a"])
+        red.ready(["b"])
+        n = red.finish()
+        info = red.comm_info()
+        out.update(backend=red.backend, fell_back=red.fell_back, buckets=n, info=info, value=float(arena.views["a"][0]))
+        red.close()
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["ok", "id_fails", "init_fails_on_1", "reducer_falls_back"])
+def test_comm_handshake_keeps_every_rank_in_the_same_collective(case):
+    """dist.negotiate_comm (the `sl` backend's start-up): broadcast(id + status byte) -> init on every rank -> one MIN vote, the
+    same sequence on every rank whether rank 0 cannot draw an id, one rank's init fails, or all is well (a rank that skipped a
+    collective would hang the group: the worker's extra all_reduce proves it did not).  Round-4 advisor finding."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() + hash(case)) % 1000
+    procs = [ctx.Process(target=_negotiate_worker, args=(r, 2, port, q, case)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda d: d["rank"])
+    [p.join(timeout=60) for p in procs]
+    assert [d["sum"] for d in res] == [3.0, 3.0]
+    if case == "ok":
+        assert [d["handle"] for d in res] == ["comm0", "comm1"] and all(d["ok"] for d in res)
+        assert res[0]["calls"] == ["id", "init"] and res[1]["calls"] == ["init"]
+    elif case == "id_fails":
+        assert all(d["handle"] is None and not d["ok"] for d in res)
+        assert res[0]["calls"] == ["id"] and res[1]["calls"] == []                    # nobody entered the init collective
+    elif case == "init_fails_on_1":
+        assert not any(d["ok"] for d in res)                                           # all ranks or none
+        assert res[0]["handle"] == "comm0" and res[1]["handle"] is None                # rank 0's came up: the caller aborts it
+    else:
+        for d in res:
+            assert d["backend"] == "torch" and d["fell_back"] and d["value"] == 3.0 and d["buckets"] >= 2
+            assert d["info"]["backend"] == "torch" and d["info"]["requested_backend"] == "sl" and d["info"]["rccl_nranks"] is None
+            assert d["info"]["group_world"] == 2 and sum(d["info"]["bucket_bytes"]) == 4 * (320 + 64)
+
+
+def test_call_with_timeout_hands_a_late_result_to_the_cleanup():
+    """A helper thread that returns after its caller gave up (ncclCommInitRank whose peers showed up late) must not leak what it
+    made: on_late receives it.  In time: the result is returned and on_late is not called."""
+    import threading
+    import time
+    late, gate = [], threading.Event()
+
+    def slow():
+        gate.wait(10)
+        return "comm"
+
+    with pytest.raises(TimeoutError):
+        distm._call_with_timeout(slow, 0.2, "slow", on_late=late.append)
+    gate.set()
+    for _ in range(100):
+        if late:
+            break
+        time.sleep(0.02)
+    assert late == ["comm"]
+    assert distm._call_with_timeout(lambda: 7, 5, "fast", on_late=late.append) == 7 and late == ["comm"]
+    with pytest.raises(ValueError):
+        distm._call_with_timeout(lambda: (_ for _ in ()).throw(ValueError("x")), 5, "raises")
 
 
 def test_spec_augment_spans_follow_hf_compute_mask_indices():

@@ -36,4 +36,10 @@ if __name__ == '__main__':
     config = importlib.import_module("llm-speech-summarization_amd.config").load_config(args.config)
     dtype = torch.float32 if str(config.get("runtime", {}).get("dtype", "bf16")) == "fp32" else torch.bfloat16
     Trainer = importlib.import_module("llm-speech-summarization_amd.trainer").Trainer
-    Trainer(args, config, device, dtype=dtype).train()
+    trainer = Trainer(args, config, device, dtype=dtype)
+    try:
+        trainer.train()
+    finally:
+        trainer.close()            # collective tear-down of the gradient exchange, while the process group still exists
+        if distributed:
+            torch.distributed.destroy_process_group()
