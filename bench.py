@@ -361,6 +361,44 @@ def mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx
             "ms_per_step": round(el / args.steps * 1e3, 2), "note": "per-rank figures (rank 0)"}
 
 
+def eos_leg(args, pipe, waves, audio_rows, B, S, P, new, n_pre, pre_e, suf_e, fixed_tok_s, fixed_decode_tok_s):
+    """Answers of different lengths: the headline batch with a fixed synthetic stop-length distribution — sequence b
+    stops after new/4 + (61 b mod (3 new/4 + 1)) tokens (64 .. 256 at 256 new tokens, mean 160; per-sequence budgets of sl_generate, which finish a row exactly as its
+    EOS would) — once with the batch compacted as rows finish (sl_generate_opts.compact, the default of the inference surface) and once
+    without.  USEFUL tokens = tokens up to each sequence's stop; pads are not counted."""
+    lo_ = max(1, new // 4)
+    stops = [lo_ + (61 * b) % (new - lo_ + 1) for b in range(B)]      # new = 256: 64 + (61 b mod 193)
+    useful = sum(stops)
+    res = {"stop_lengths": f"{lo_} + (61 b mod {new - lo_ + 1})", "mean_stop": round(useful / B, 1), "useful_tokens": useful}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for mode, compact in (("compacted", True), ("uncompacted", False)):
+        times, dec = [], []
+        for it in range(2):            # first pass: graph captures of the ladder's rungs
+            with torch.cuda.stream(pipe.stream):
+                xv = pipe.x.view(B, S, -1)
+                xv[:, :n_pre] = pre_e
+                xv[:, n_pre + P:] = suf_e
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pipe.enc.encode_packed(waves, out=pipe.x, out_row_offsets=audio_rows)
+                ids, n_cols = pipe.llm.generate_packed(pipe.x, [S] * B, new, use_eos=False, shared_prefix=n_pre, row_limits=stops, compact=compact)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                dec.append(pipe.llm.last_timings_ms[1])
+        st = dict(pipe.llm.last_generate_stats)
+        assert n_cols == max(stops) and tuple(ids.shape) == (B, new)
+        res[mode] = {"ms_per_step": round(times[-1] * 1e3, 2), "decode_ms": round(dec[-1], 2), "useful_tokens_per_s": round(useful / times[-1], 1),
+                     "useful_decode_tokens_per_s": round((useful - B) / (dec[-1] * 1e-3), 1), "compactions": st["compactions"], "final_rows": st["final_rows"],
+                     "row_steps": st["row_steps"], "decode_launches": st["decode_launches"], "first_pass_ms_incl_graph_captures": round(times[0] * 1e3, 2)}
+    res["fixed_length_tokens_per_s_one_batch_alone"] = round(fixed_tok_s, 1)
+    res["fixed_length_decode_tokens_per_s"] = round(fixed_decode_tok_s, 1)
+    res["compacted_over_fixed_length_decode"] = round(res["compacted"]["useful_decode_tokens_per_s"] / fixed_decode_tok_s, 4)
+    res["compacted_over_uncompacted"] = round(res["compacted"]["useful_tokens_per_s"] / res["uncompacted"]["useful_tokens_per_s"], 4)
+    res["note"] = ("one batch alone on the GPU; useful_decode = useful tokens after each sequence's first (prefill) token / decode time; the fixed-length figures are "
+                   "the same batch decoding max_new_tokens for every row (stage_ms_one_batch_alone)")
+    return res
+
+
 LONGFORM_SEC = (30, 60, 120)   # SURVEY.md §8d: long-form utterances of BASELINE configs[4]
 
 
@@ -578,6 +616,7 @@ def main():
     ap.add_argument("--kd-optimizer-steps", type=int, default=3, help="optimizer steps of the KD training leg (0 = skip)")
     ap.add_argument("--kd-eval-mode", action="store_true", help="KD leg with the encoder's training-mode regularisers off")
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
+    ap.add_argument("--no-eos-leg", action="store_true", help="skip the answers-of-different-lengths leg (per-sequence stop lengths, batch compaction)")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the long-form + text-prompt leg (configs[4]) and the Whisper encoder leg (configs[3])")
     ap.add_argument("--kd-window", type=int, default=0, help="profiling aid: samples per optimizer step per rank in the main KD leg (0 = grad_accum_interval / world)")
@@ -772,13 +811,23 @@ def main():
         out = torch.empty(B, F_, device=dev, dtype=torch.bfloat16)
         wgu = wts.dec_wgu  # the fragment-packed, RMSNorm-folded gate/up matrices the decode graph streams
         assert len(wgu) == larch.num_hidden_layers
-        # above 26 rows the o projection's reduce pass hands the RMSNorm scale down (runtime.hip decode_step): same here
-        chain = bool(wts.struct.dec_fused_norm) and L.lib().sl_gemm_split_count(B, H, nh * D, L.dtype_code(torch.bfloat16)) > 1
-        rstd = torch.rsqrt(xin.float().pow(2).mean(-1) + larch.rms_norm_eps) if chain else None
+        # the same dispatch rule as runtime.hip decode_step / llama_layer: above 26 rows the o projection's reduce pass hands the RMSNorm
+        # scale down (`chain`); from ~900 rows gate/up runs on the ROW-MAJOR weights through the 256 x 256 tile kernel on rows the
+        # producer normalised; where o / down run unsplit (~1 500 rows up) a one-read pass leaves scales / normalised rows instead
+        bf = L.dtype_code(torch.bfloat16)
+        sc_o, sc_d = L.lib().sl_gemm_split_count(B, H, nh * D, bf), L.lib().sl_gemm_split_count(B, H, F_, bf)
+        chain = bool(wts.struct.dec_fused_norm) and sc_o > 1 and sc_d > 1
+        rstd_pass = (not chain) and bool(wts.struct.dec_fused_norm) and B > 384 and sc_o == 1 and sc_d == 1
+        tiled_gu = os.environ.get("SL_DECODE_TILED", "1") != "0" and ((chain and B > 896) or rstd_pass)
+        rstd = torch.rsqrt(xin.float().pow(2).mean(-1) + larch.rms_norm_eps) if (chain or rstd_pass) else None
+        wgu_rm = [wts.layer_t[i]["wgu"] for i in range(larch.num_hidden_layers)]     # row-major, gate/up interleaved in 16-row blocks
 
         def probe_gemm(i):
-            ops.gemm_decode(xin, wgu[i % len(wgu)], 2 * F_, act=L.ACT_SILU_MUL, fuse_rms=bool(wts.struct.dec_fused_norm), eps=larch.rms_norm_eps,
-                            out=out, rstd_in=rstd)
+            if tiled_gu:
+                ops.gemm(xin, wgu_rm[i % len(wgu_rm)], act=L.ACT_SILU_MUL, out=out)
+            else:
+                ops.gemm_decode(xin, wgu[i % len(wgu)], 2 * F_, act=L.ACT_SILU_MUL, fuse_rms=bool(wts.struct.dec_fused_norm), eps=larch.rms_norm_eps,
+                                out=out, rstd_in=rstd)
 
         kc, vc = llm._kv                       # (layers, slots, n_kv, max_ctx, D): the caches the timed steps filled
         ctx_mid = S + new // 2                  # mean context of the decode phase
@@ -824,7 +873,7 @@ def main():
         attn_ms = timed(probe_attn, n_probe)     # split + merge launches together
         gemm_bytes = 2 * F_ * H * 2 + B * H * 2 + B * F_ * 2            # weights once + activations in/out
         attn_bytes = B * nkv * ctx_mid * D * 2 * 2 + 2 * B * nh * D * 2  # K and V rows once + q in / o out
-        probes = {"gemm": (gemm_bytes, gemm_ms), "attn": (attn_bytes, attn_ms)}
+        probes = {"gemm": (gemm_bytes, gemm_ms), "attn": (attn_bytes, attn_ms), "tiled_gu": tiled_gu}
 
     # ---- KD training leg (BASELINE configs[2]): one optimizer step = grad_accum_interval micro-steps shared by the ranks,
     # fp32 gradient buckets all-reduced with RCCL on a side stream while backward still runs
@@ -868,7 +917,7 @@ def main():
     # `traffic` cannot be measured inside this process (PMC counters need rocprofv3 around it): it is READ from the committed
     # counter summary of the same two launches (tools/probe_decode_kernels.py under separate --pmc passes), and says so
     pmc, pmc_src = {}, None
-    for name in ("r04_pmc_decode_kernels.json", "r03_pmc_decode_kernels.json", "r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):   # newest committed PMC passes first
+    for name in ("r05_pmc_decode_kernels.json", "r04_pmc_decode_kernels.json", "r03_pmc_decode_kernels.json", "r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):   # newest committed PMC passes first
         pmc_path = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
@@ -885,15 +934,27 @@ def main():
                 "traffic": pmc.get(key), "traffic_source": pmc_src if pmc.get(key) is not None else None, "algorithmic_bytes_per_launch": alg,
                 "avg_launch_us": round(ms * 1e3, 2)}
 
-    r_gemm = roof(("gemm_stream_wide_kernel" if B > 384 else ("gemm_stream_kernel" if streaming else "gemm_skinny_kernel")) +
-                  "<bf16, SILU_MUL> (gate/up projection, decode)", "gemm")
-    # the same launch against the matrix-core roof: above ~256 rows the projection is nearer to it than to the HBM one
+    # the gate/up launch of the decode graph at THIS batch (runtime.hip llama_layer): the row-major 256-tile kernel from ~900 rows, the
+    # 256 x 128 streaming block above 384, the 128-row streaming block above 26, the skinny kernel below
+    gu_kernel = ("gemm_tiled256p_kernel<bf16, SILU_MUL> on row-major weights" if probes["tiled_gu"] else
+                 ("gemm_stream_wide_kernel" if B > 384 else ("gemm_stream_kernel" if streaming else "gemm_skinny_kernel")) + "<bf16, SILU_MUL> on packed weights")
+    r_gemm = roof(gu_kernel + " (gate/up projection, decode)", "gemm")
     gemm_flops = 2.0 * B * 2 * larch.intermediate_size * larch.hidden_size
-    r_gemm["mfma"] = {"achieved": round(gemm_flops / (probes["gemm"][1] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": round(gemm_flops / (probes["gemm"][1] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    mf = gemm_flops / (probes["gemm"][1] * 1e-3) / 1e12
+    if B > 128:      # above ~128 rows the projection is bound by the matrix core / the L2 -> CU fetch rate, not by HBM: that roof is the entry, the HBM view rides along
+        r_gemm = {"kernel": r_gemm["kernel"], "bound": "mfma", "achieved": round(mf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TFLOPS, 4),
+                  "traffic": r_gemm["traffic"], "traffic_source": r_gemm["traffic_source"], "algorithmic_bytes_per_launch": r_gemm["algorithmic_bytes_per_launch"],
+                  "algorithmic_flops_per_launch": gemm_flops, "avg_launch_us": r_gemm["avg_launch_us"],
+                  "hbm": {"achieved": r_gemm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_gemm["frac"]}}
+    else:
+        r_gemm["mfma"] = {"achieved": round(mf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TFLOPS, 4)}
     single_pass = B * larch.num_key_value_heads >= 32
     r_attn = roof(("attn_decode_full_kernel<bf16> (single-pass" if single_pass else "attn_decode_split_kernel<bf16> + merge (split") +
                   " one-token GQA attention over the KV cache, decode)", "attn")
+    n_lay = larch.num_hidden_layers
+    for r_, key in ((r_attn, "attn"), (r_gemm, "gemm")):
+        r_["launches_per_decode_step"] = n_lay
+        r_["launches_in_timed_region"] = n_lay * (new - 1) * args.steps        # per rank; the rocprofv3 kernel stats of the same command show them
     dominant, other = (r_attn, r_gemm) if probes["attn"][1] > probes["gemm"][1] else (r_gemm, r_attn)
     dec_step_ms = mean(decode_ms) / max(1, new - 1)
     # K/V rows a step has to pull from HBM: every sequence's own rows, the n_pre shared template rows once per batch (sl_kv_cache.shared_prefix)
@@ -969,6 +1030,13 @@ def main():
         result["latency_b1"] = latency_leg(args, llm, x1, S, new, larch, wts)
     except Exception as e:
         result["latency_b1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if seq_stage and not args.no_eos_leg:
+        try:
+            one_ms = seq_stage["encode"] + seq_stage["prefill"] + seq_stage["decode"]
+            result["eos_stop_mix"] = eos_leg(args, pipes[0], waves, audio_rows, B, S, P, new, n_pre, pre_e, suf_e, B * new / (one_ms * 1e-3),
+                                             B * (new - 1) / (seq_stage["decode"] * 1e-3))
+        except Exception as e:
+            result["eos_stop_mix"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_length_mix:
         try:
             result["devclean_length_mix"] = mix_leg(args, ri, harch, larch, enc, llm, prefix, suffix, dev, rank, mix_ctx)
@@ -984,6 +1052,18 @@ def main():
             result["whisper_pipeline"] = whisper_leg(args, mod, larch, llm, prefix, suffix, dev, rank)
         except Exception as e:
             result["whisper_pipeline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the four figures BASELINE.md §4 grades, side by side (the headline `roofline` entry is the single dominant decode kernel, not the
+    # whole story): encoder / prefill / KD step against the dense bf16 MFMA peak, batch-1 decode against the HBM ceiling
+    def _frac(d, *path):
+        for k in path:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+    result["graded"] = {"encoder_mfma_frac": _frac(result, "encoder_mfma", "frac"), "prefill_mfma_frac": _frac(result, "prefill_mfma", "frac"),
+                        "kd_step_mfma_frac": _frac(result, "kd_step", "roofline", "frac"), "batch1_decode_hbm_frac": _frac(result, "latency_b1", "frac_of_hbm_ceiling"),
+                        "decode_gemm_family_mfma_frac": _frac(result, "decode_gemm_family", "frac"),
+                        "decode_attention_hbm_frac": (r_attn["frac"] if r_attn.get("bound") == "hbm" else None),
+                        "note": "BASELINE.md §4: fraction of the MFMA roofline for encoder, prefill and KD step, of the HBM roofline for batch-1 decode; "
+                                "the decode projection family and the decode attention kernel beside them"}
     if not args.no_cpu_baseline:
         del llm, wts
         result["cpu_baseline"] = cpu_baseline(enc_sd, keep_sd, harch, larch, waves[0].cpu(), prefix, suffix, args.cpu_decode_steps, new)

@@ -577,7 +577,7 @@ int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, void* x, co
                      size_t workspace_bytes, sl_stream stream);
 
 /* One KV-cached decode step for B sequences: embeds next_ids, runs all layers with M = B, writes
- * logits (B, vocab) fp32 (B <= 1024).  The new token's K/V are appended at position ctx_len[b] and
+ * logits (B, vocab) fp32 (B <= SL_MAX_DECODE_BATCH).  The new token's K/V are appended at position ctx_len[b] and
  * ctx_len[b]+1 keys are attended; ctx_len itself is advanced by sl_greedy_select.  Reads/writes only
  * device state, so the call is hipGraph-capturable.  Workspace: sl_llama_workspace_bytes(m, B, B) + B*hidden. */
 int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int32_t* next_ids_dev,
@@ -589,12 +589,13 @@ int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const i
  * (nseq, max_new_tokens) int32 receives new tokens only; *n_steps_host the number of columns
  * produced (all rows finished => early stop, checked every `check_every` steps).  This call
  * synchronises `stream` (it returns host data).
- * LIMIT: nseq <= SL_MAX_DECODE_BATCH (1024) sequences per call — the row count the weight-streaming decode GEMMs and the
- * single-pass attention grid are built for; a larger batch is rejected with SL_ERR_ARG (split it: sequences are independent).
+ * LIMIT: nseq <= SL_MAX_DECODE_BATCH (2048) sequences per call — the row count the decode GEMMs, the single-pass attention grid and
+ * the 288 GB of HBM are sized for (a KV cache of 2 048 slots x 393 positions of Llama-3.2-3B is 92 GB); a larger batch is rejected with
+ * SL_ERR_ARG (split it: sequences are independent — the Python surface does, inference.generate_audio_responses).
  * The captured decode graph is cached per calling thread, keyed by every buffer, limit, the device and a hash of the model's
  * and every layer's fields; sl_decode_graph_cache_clear() destroys the calling thread's cached graphs (returns how many) —
  * call it after re-laying-out weights in place behind unchanged struct contents, or before unloading the library. */
-#define SL_MAX_DECODE_BATCH 1024
+#define SL_MAX_DECODE_BATCH 2048
 int sl_decode_graph_cache_clear(void);
 size_t sl_generate_workspace_bytes(const sl_llama_model* m, int64_t n_tok, int32_t nseq, int32_t max_new_tokens);
 int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host,
@@ -602,6 +603,50 @@ int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, 
                        int32_t pad_id, int32_t use_eos, int32_t check_every, int32_t* out_ids_host,
                        int32_t* n_steps_host, float* timings_ms_host /* [prefill, decode] or NULL */,
                        void* workspace, size_t workspace_bytes, sl_stream stream);
+
+/* sl_generate (ABI version 6): the general form of the two calls around it — same prefill, same captured decode step, same HF
+ * semantics (hf:generation/utils.py:2928-2942: a finished row emits pad_id, generation ends at the step where the last row
+ * finished) — plus what a batch whose answers have different lengths needs:
+ *   row_limits_host : NULL, or one token budget per sequence in [1, max_new_tokens] (a per-request max_new_tokens): a row that
+ *                     has produced its budget is finished exactly like a row that emitted EOS.  Implies use_eos semantics.
+ *   compact         : 1 = at a `check_every` synchronisation, once the live rows fit the next lower rung of a fixed ladder of
+ *                     row counts (... 1024, 896, 768, 640, 512, 384, 256, 192, 128, ... 1), the batch is COMPACTED: finished
+ *                     sequences are written out, the live rows above the rung take the places of finished rows below it — their
+ *                     state, output ids and K / V cache slot move with them — and decoding continues with that many rows (one
+ *                     cached graph per rung).  Per sequence the result is what compact = 0 gives: identical ids in SL_F32 (every
+ *                     kernel family is bit-exact there); in SL_BF16 the row count selects the GEMM family, so a logit near-tie
+ *                     may resolve differently after a compaction, as it may between two batch sizes.  The K / V cache is
+ *                     re-ordered in place: after the call slot j no longer belongs to sequence j.
+ *   sample          : 0 = greedy argmax; 1 = temperature / top_k / top_p / seed as in sl_sample_generate (the draw of a
+ *                     sequence depends on (seed, the sequence's index in THIS call, step) only, compacted or not).
+ * out_ids_host (nseq, max_new_tokens) is indexed by the caller's sequence order whatever moved.  stats may be NULL. */
+typedef struct {
+  const int32_t* eos_ids_host;     /* n_eos ids (<= 8) */
+  const int32_t* row_limits_host;  /* NULL or nseq budgets */
+  uint64_t seed;
+  int32_t max_new_tokens;
+  int32_t n_eos;
+  int32_t pad_id;
+  int32_t use_eos;
+  int32_t check_every;             /* host check of the finished flags every this many steps (<= 0: 16) */
+  int32_t sample;
+  float temperature;
+  int32_t top_k;
+  float top_p;
+  int32_t compact;
+} sl_generate_opts;
+typedef struct {
+  int64_t row_steps;        /* sum over decode launches of the rows the launch ran (nseq x launches without compaction) */
+  int32_t n_steps;          /* columns of out_ids_host produced */
+  int32_t decode_launches;
+  int32_t compactions;
+  int32_t final_rows;       /* rows of the last decode launch */
+  float prefill_ms;
+  float decode_ms;
+} sl_generate_stats;
+int sl_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                const sl_generate_opts* opts, int32_t* out_ids_host, sl_generate_stats* stats, void* workspace,
+                size_t workspace_bytes, sl_stream stream);
 
 /* Sampled generation (hf:generation/utils.py:2911-2923 with do_sample = True — what the hub's generation_config.json of
  * Llama-3.2-3B-Instruct asks for when a caller does not force greedy): HF's logits warpers in HF's order —

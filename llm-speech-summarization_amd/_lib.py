@@ -20,6 +20,7 @@ SL_F32, SL_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU_MUL, ACT_ROPE_KV = 0, 1, 2, 3
 W_ROWMAJOR, W_PACKED = 0, 1
 COMM_ID_BYTES = 128          # SL_COMM_ID_BYTES = sizeof(ncclUniqueId)
+MAX_DECODE_BATCH = 2048      # SL_MAX_DECODE_BATCH: sequences per generate call / rows per decode step
 
 c_i32, c_i64, c_f32, c_vp, c_sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -151,6 +152,17 @@ class KVCache(C.Structure):
     _fields_ = [("k_cache", c_vp), ("v_cache", c_vp), ("slots", c_i32), ("max_ctx", c_i32), ("shared_prefix", c_i32), ("reserved", c_i32)]
 
 
+class GenerateOpts(C.Structure):
+    _fields_ = [("eos_ids_host", C.POINTER(c_i32)), ("row_limits_host", C.POINTER(c_i32)), ("seed", C.c_uint64), ("max_new_tokens", c_i32),
+                ("n_eos", c_i32), ("pad_id", c_i32), ("use_eos", c_i32), ("check_every", c_i32), ("sample", c_i32), ("temperature", c_f32),
+                ("top_k", c_i32), ("top_p", c_f32), ("compact", c_i32)]
+
+
+class GenerateStats(C.Structure):
+    _fields_ = [("row_steps", c_i64), ("n_steps", c_i32), ("decode_launches", c_i32), ("compactions", c_i32), ("final_rows", c_i32),
+                ("prefill_ms", c_f32), ("decode_ms", c_f32)]
+
+
 _PROTOS = {
     "sl_last_error": (C.c_char_p, []),
     "sl_version": (c_i32, []),
@@ -246,6 +258,8 @@ _PROTOS = {
                                  c_vp, c_sz, c_vp]),
     "sl_llama_decode_step": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "sl_generate_workspace_bytes": (c_sz, [C.POINTER(LlamaModel), c_i64, c_i32, c_i32]),
+    "sl_generate": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, C.POINTER(c_i32), c_i32, C.POINTER(GenerateOpts), C.POINTER(c_i32),
+                            C.POINTER(GenerateStats), c_vp, c_sz, c_vp]),
     "sl_sample_select": (c_i32, [c_vp, c_i32, c_i32, c_f32, c_i32, c_f32, C.c_uint64, C.POINTER(c_i32), c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_i32, c_vp, c_vp]),
     "sl_sample_generate": (c_i32, [C.POINTER(LlamaModel), C.POINTER(KVCache), c_vp, C.POINTER(c_i32), c_i32, c_i32, C.POINTER(c_i32), c_i32, c_i32, c_i32,

@@ -7,7 +7,7 @@ inputs_embeds=, max_new_tokens=)` -> LongTensor(B, n_new) of NEW tokens only (th
 hf:generation/utils.py:736-744), `.eval()`, `.to(device)`, `.parameters()`.
 
 RMSNorm, RoPE, GQA attention, SwiGLU, lm_head, argmax, EOS handling and the KV cache all run in
-libspeechllm (sl_llama_prefill / sl_greedy_generate); generation is greedy by construction
+libspeechllm (sl_llama_prefill / sl_generate); generation is greedy by construction
 (SURVEY.md §9 Q3).  No PyTorch fallback exists.
 """
 from __future__ import annotations
@@ -67,6 +67,7 @@ class AudioLlamaForCausalLM:
         self._ws: Optional[torch.Tensor] = None
         self.model = SimpleNamespace(embed_tokens=_EmbedTokens(self))
         self.last_timings_ms = None
+        self.last_generate_stats = None
         if device is not None:
             self.to(device)
 
@@ -227,15 +228,20 @@ class AudioLlamaForCausalLM:
         return ids[:, :n_cols].to(torch.int64)
 
     def generate_packed(self, x: torch.Tensor, lens: Sequence[int], max_new_tokens: int, use_eos: bool = True, sample: Optional[dict] = None,
-                        shared_prefix: int = 0):
+                        shared_prefix: int = 0, row_limits: Optional[Sequence[int]] = None, compact: bool = True, check_every: int = 16):
         """x: packed prompt embeddings (sum S_i, h) on the GPU (overwritten).  Returns (int32 (B, max_new) host tensor, n_cols).
         shared_prefix = P: the caller's promise that the first P rows of every sequence are the same rows (one prompt template in
         front of the audio, ref:inference.py:95-113) — the batched decode attention then reads those P cache positions from slot 0
-        (sl_kv_cache.shared_prefix); ids and logits are bit for bit those of P = 0."""
+        (sl_kv_cache.shared_prefix); ids and logits are bit for bit those of P = 0.
+        row_limits: one token budget per sequence (a per-request max_new_tokens; the row then finishes like a row that emitted EOS).
+        compact: with EOS / budgets on, the batch is compacted as its rows finish (sl_generate_opts.compact) — the decode step then
+        costs what the LIVE rows cost; per-sequence results are those of the uncompacted batch (`last_generate_stats` has the counts)."""
         w = self._dev()
         a = self.arch
         lib = L.lib()
         B = len(lens)
+        if B > L.MAX_DECODE_BATCH:
+            raise L.SpeechLLMError(f"{B} sequences in one generate call; the library takes {L.MAX_DECODE_BATCH} (split the batch: sequences are independent)")
         if max(lens) + max_new_tokens > self.max_ctx:
             raise L.SpeechLLMError(f"prompt ({max(lens)}) + max_new_tokens ({max_new_tokens}) exceeds max_ctx={self.max_ctx}")
         if not 0 <= shared_prefix <= min(lens):
@@ -251,17 +257,24 @@ class AudioLlamaForCausalLM:
         pad = gen.pad_token_id if gen.pad_token_id is not None else (eos[0] if eos else 0)
         eos_c = (C.c_int32 * max(1, len(eos)))(*eos)
         out = (C.c_int32 * (B * max_new_tokens))()
-        n_steps = C.c_int32(0)
-        timings = (C.c_float * 2)()
+        o = L.GenerateOpts()
+        o.eos_ids_host, o.n_eos, o.pad_id, o.use_eos = eos_c, (len(eos) if use_eos else 0), int(pad), int(use_eos)
+        o.max_new_tokens, o.check_every, o.compact = int(max_new_tokens), int(check_every), int(bool(compact))
+        lim_c = None
+        if row_limits is not None:
+            if len(row_limits) != B:
+                raise L.SpeechLLMError(f"row_limits has {len(row_limits)} entries for {B} sequences")
+            lim_c = (C.c_int32 * B)(*[int(v) for v in row_limits])
+            o.row_limits_host = lim_c
+        if sample is not None:
+            o.sample, o.temperature, o.top_k, o.top_p = 1, float(sample["temperature"]), int(sample["top_k"]), float(sample["top_p"])
+            o.seed = int(sample["seed"]) & 0xFFFFFFFFFFFFFFFF
+        st = L.GenerateStats()
         ws = self._workspace(lib.sl_generate_workspace_bytes(C.byref(w.struct), x.shape[0], B, max_new_tokens))
-        if sample is None:
-            L.check(lib.sl_greedy_generate(C.byref(w.struct), C.byref(kv), x.data_ptr(), cu_c, B, max_new_tokens, eos_c, len(eos), pad,
-                                           int(use_eos), 16, out, C.byref(n_steps), timings, ws.data_ptr(), ws.numel(), L.stream_ptr()),
-                    "sl_greedy_generate")
-        else:
-            L.check(lib.sl_sample_generate(C.byref(w.struct), C.byref(kv), x.data_ptr(), cu_c, B, max_new_tokens, eos_c, len(eos), pad,
-                                           int(use_eos), 16, sample["temperature"], sample["top_k"], sample["top_p"], sample["seed"] & 0xFFFFFFFFFFFFFFFF,
-                                           out, C.byref(n_steps), timings, ws.data_ptr(), ws.numel(), L.stream_ptr()), "sl_sample_generate")
-        self.last_timings_ms = (timings[0], timings[1])
+        L.check(lib.sl_generate(C.byref(w.struct), C.byref(kv), x.data_ptr(), cu_c, B, C.byref(o), out, C.byref(st), ws.data_ptr(), ws.numel(),
+                                L.stream_ptr()), "sl_generate")
+        self.last_timings_ms = (st.prefill_ms, st.decode_ms)
+        self.last_generate_stats = {"rows": B, "n_steps": int(st.n_steps), "decode_launches": int(st.decode_launches), "compactions": int(st.compactions),
+                                    "final_rows": int(st.final_rows), "row_steps": int(st.row_steps)}
         ids = torch.frombuffer(out, dtype=torch.int32).clone().view(B, max_new_tokens)
-        return ids, int(n_steps.value)
+        return ids, int(st.n_steps)

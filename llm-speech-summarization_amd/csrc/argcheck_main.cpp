@@ -33,7 +33,7 @@ static void fill_hubert(sl_hubert_model* m, sl_hubert_layer* layers, int n_layer
 }
 
 int main() {
-  EXPECT(sl_version() == 5, "ABI version");
+  EXPECT(sl_version() == SL_ABI_VERSION && SL_ABI_VERSION == 6, "ABI version");
   EXPECT(sl_last_error() != nullptr, "error string never NULL");
 
   // ---- tuning switches: parser under the sanitizers, garbage included
@@ -147,6 +147,29 @@ int main() {
   EXPECT_ARG_ERROR(sl_greedy_generate(&lm, &kv, ws, cu, 4096, 8, eos, 3, 128001, 1, 16, out_ids, &n_steps, nullptr, ws, sizeof(ws), nullptr));  // batch above the limit
   kv.shared_prefix = 200;
   EXPECT_ARG_ERROR(sl_greedy_generate(&lm, &kv, ws, cu, 1, 8, eos, 3, 128001, 1, 16, out_ids, &n_steps, nullptr, ws, sizeof(ws), nullptr));     // shared prefix longer than the prompt
+  kv.shared_prefix = 0;
+  {   // sl_generate (ABI 6): options checked before anything is launched
+    sl_generate_opts go;
+    memset(&go, 0, sizeof(go));
+    sl_generate_stats gs;
+    go.max_new_tokens = 8; go.eos_ids_host = eos; go.n_eos = 3; go.pad_id = 128001; go.use_eos = 1; go.compact = 1;
+    EXPECT_ARG_ERROR(sl_generate(&lm, &kv, ws, cu, 1, nullptr, out_ids, &gs, ws, sizeof(ws), nullptr));                 // no options
+    EXPECT_ARG_ERROR(sl_generate(&lm, &kv, ws, cu, SL_MAX_DECODE_BATCH + 1, &go, out_ids, &gs, ws, sizeof(ws), nullptr));   // batch above the limit
+    go.n_eos = 9;
+    EXPECT_ARG_ERROR(sl_generate(&lm, &kv, ws, cu, 1, &go, out_ids, &gs, ws, sizeof(ws), nullptr));                      // more than 8 eos ids
+    go.n_eos = 3;
+    int32_t lim[1] = {9};
+    go.row_limits_host = lim;
+    EXPECT_ARG_ERROR(sl_generate(&lm, &kv, ws, cu, 1, &go, out_ids, &gs, ws, sizeof(ws), nullptr));                      // budget above max_new_tokens
+    lim[0] = 0;
+    EXPECT_ARG_ERROR(sl_generate(&lm, &kv, ws, cu, 1, &go, out_ids, &gs, ws, sizeof(ws), nullptr));                      // budget below 1
+    go.row_limits_host = nullptr;
+    go.sample = 1; go.temperature = 0.f; go.top_p = 1.f;
+    EXPECT_ARG_ERROR(sl_generate(&lm, &kv, ws, cu, 1, &go, out_ids, &gs, ws, sizeof(ws), nullptr));                      // temperature 0
+    go.sample = 0;
+    EXPECT_ARG_ERROR(sl_generate(&lm, &kv, ws, cu, 1, &go, out_ids, &gs, ws, 64, nullptr));                              // workspace too small
+  }
+  EXPECT(sl_comm_abort(nullptr) == 0, "aborting no communicator is a no-op");
   kv.shared_prefix = -1;
   EXPECT_ARG_ERROR(sl_llama_prefill(&lm, &kv, ws, cu, 1, logits, ctx, nullptr, ws, sizeof(ws), nullptr));            // negative shared prefix
   kv.shared_prefix = 0;

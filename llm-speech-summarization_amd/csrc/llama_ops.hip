@@ -244,7 +244,7 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
                                                              int advance_ctx, int32_t* __restrict__ unfinished, int32_t* __restrict__ ctx_len,
                                                              int32_t* __restrict__ gen_count, int32_t* __restrict__ finish_len,
                                                              int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new,
-                                                             const int32_t* __restrict__ forced) {
+                                                             const int32_t* __restrict__ forced, const int32_t* __restrict__ row_limit) {
   __shared__ float smax[16];
   __shared__ int sidx[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,6 +263,7 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
       if (use_eos && unf) {
         bool is_eos = false;
         for (int e = 0; e < eos.n; ++e) is_eos |= (tok == eos.ids[e]);
+        if (row_limit) is_eos |= (n + 1 >= row_limit[b]);       // the row's own token budget is spent: finished like a row that emitted EOS
         if (is_eos) { unfinished[b] = 0; finish_len[b] = n + 1; }
       }
       if (advance_ctx) ctx_len[b] += 1;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
     if (use_eos && unf) {
       bool is_eos = false;
       for (int e = 0; e < eos.n; ++e) is_eos |= (tok == eos.ids[e]);
+      if (row_limit) is_eos |= (n + 1 >= row_limit[b]);
       if (is_eos) { unfinished[b] = 0; finish_len[b] = n + 1; }
     }
     if (advance_ctx) ctx_len[b] += 1;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
 
 int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
                           int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
-                          int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st) {
+                          int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st, const int32_t* row_limit) {
   SL_CHECK_ARG(logits && unfinished && ctx_len && gen_count && finish_len && next_ids && out_ids && B > 0 && V > 0,
                "sl_greedy_select: bad arguments");
   SL_CHECK_ARG(n_eos >= 0 && n_eos <= 8, "sl_greedy_select: at most 8 eos ids");
@@ -330,7 +332,7 @@ int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32
   e.n = n_eos;
   for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
   hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, st, logits, V, e, pad_id, use_eos, advance_ctx, unfinished, ctx_len,
-                     gen_count, finish_len, next_ids, out_ids, max_new, (const int32_t*)nullptr);
+                     gen_count, finish_len, next_ids, out_ids, max_new, (const int32_t*)nullptr, row_limit);
   SL_CHECK_LAUNCH("greedy_select");
   return 0;
 }
@@ -344,7 +346,8 @@ __global__ __launch_bounds__(1024) void greedy_select_partial_kernel(const float
                                                                      EosList eos, int pad_id, int use_eos, int advance_ctx,
                                                                      int32_t* __restrict__ unfinished, int32_t* __restrict__ ctx_len,
                                                                      int32_t* __restrict__ gen_count, int32_t* __restrict__ finish_len,
-                                                                     int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new) {
+                                                                     int32_t* __restrict__ next_ids, int32_t* __restrict__ out_ids, int max_new,
+                                                                     const int32_t* __restrict__ row_limit) {
   constexpr int ROWS = 32, STRIPES = 32, U = 8;
   __shared__ float sv[STRIPES][ROWS];
   __shared__ int si[STRIPES][ROWS];
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(1024) void greedy_select_partial_kernel(const float
   if (use_eos && unf) {
     bool is_eos = false;
     for (int e = 0; e < eos.n; ++e) is_eos |= (tok == eos.ids[e]);
+    if (row_limit) is_eos |= (n + 1 >= row_limit[b]);
     if (is_eos) { unfinished[b] = 0; finish_len[b] = n + 1; }
   }
   if (advance_ctx) ctx_len[b] += 1;
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(1024) void greedy_select_partial_kernel(const float
 
 int sl_greedy_select_partial_impl(const float* amax_val, const int32_t* amax_idx, int32_t n_groups, int32_t B, const int32_t* eos_ids, int32_t n_eos,
                                   int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
-                                  int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st) {
+                                  int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st, const int32_t* row_limit) {
   SL_CHECK_ARG(amax_val && amax_idx && unfinished && ctx_len && gen_count && finish_len && next_ids && out_ids && B > 0 && n_groups > 0,
                "sl_greedy_select_partial: bad arguments");
   SL_CHECK_ARG(n_eos >= 0 && n_eos <= 8, "sl_greedy_select_partial: at most 8 eos ids");
@@ -401,7 +405,7 @@ int sl_greedy_select_partial_impl(const float* amax_val, const int32_t* amax_idx
   e.n = n_eos;
   for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
   hipLaunchKernelGGL(greedy_select_partial_kernel, dim3((B + 31) / 32), dim3(1024), 0, st, amax_val, amax_idx, n_groups, B, e, pad_id, use_eos, advance_ctx,
-                     unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, max_new);
+                     unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, max_new, row_limit);
   SL_CHECK_LAUNCH("greedy_select_partial");
   return 0;
 }
@@ -410,7 +414,7 @@ extern "C" int sl_greedy_select_partial(const float* amax_val, const int32_t* am
                                         int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
                                         int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream) {
   return sl_greedy_select_partial_impl(amax_val, amax_idx, n_groups, B, eos_ids, n_eos, pad_id, use_eos, advance_ctx, unfinished, ctx_len, gen_count,
-                                       finish_len, next_ids, out_ids, max_new, (hipStream_t)stream);
+                                       finish_len, next_ids, out_ids, max_new, (hipStream_t)stream, nullptr);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -428,7 +432,8 @@ __device__ __forceinline__ uint32_t ord_key(float x) {
 }
 
 __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restrict__ logits, int V, float inv_temp, int top_k, float top_p, uint64_t seed,
-                                                           const int32_t* __restrict__ gen_count, int32_t* __restrict__ choice) {
+                                                           const int32_t* __restrict__ gen_count, int32_t* __restrict__ choice,
+                                                           const int32_t* __restrict__ row_ids) {
   __shared__ float redf[16];
   __shared__ int hcnt[256];
   __shared__ unsigned long long hmass_fx[256];   // probability mass per bin in 2^-40 fixed point: integer adds commute, so the
@@ -526,7 +531,8 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restri
     float z = 0.f;
     for (int t = 0; t < 1024; ++t) z += part[t];
     const uint32_t step = (uint32_t)gen_count[b];
-    const uint32_t h = lowbias32(step ^ lowbias32((uint32_t)b ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+    const uint32_t rid = row_ids ? (uint32_t)row_ids[b] : (uint32_t)b;    // the sequence's index in the caller's batch (rows move when a batch is compacted)
+    const uint32_t h = lowbias32(step ^ lowbias32(rid ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
     const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
     const float target = u * z;
     float run = 0.f;
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restri
 int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p, uint64_t seed,
                           const int32_t* eos_ids, int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished,
                           int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new,
-                          int32_t* choice_ws, hipStream_t st) {
+                          int32_t* choice_ws, hipStream_t st, const int32_t* row_limit, const int32_t* row_ids) {
   SL_CHECK_ARG(logits && unfinished && ctx_len && gen_count && finish_len && next_ids && out_ids && choice_ws && B > 0 && V > 0,
                "sl_sample_select: bad arguments");
   SL_CHECK_ARG(temperature > 0.f && top_p > 0.f && top_p <= 1.0f && top_k >= 0, "sl_sample_select: need temperature > 0, 0 < top_p <= 1, top_k >= 0 (got %f, %f, %d)",
@@ -562,10 +568,10 @@ int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float tempe
   EosList e;
   e.n = n_eos;
   for (int i = 0; i < 8; ++i) e.ids[i] = i < n_eos ? eos_ids[i] : -1;
-  hipLaunchKernelGGL(sample_rows_kernel, dim3(B), dim3(1024), 0, st, logits, V, 1.0f / temperature, top_k, top_p, seed, gen_count, choice_ws);
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(B), dim3(1024), 0, st, logits, V, 1.0f / temperature, top_k, top_p, seed, gen_count, choice_ws, row_ids);
   SL_CHECK_LAUNCH("sample_rows");
   hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(64), 0, st, logits, V, e, pad_id, use_eos, advance_ctx, unfinished, ctx_len, gen_count, finish_len,
-                     next_ids, out_ids, max_new, (const int32_t*)choice_ws);
+                     next_ids, out_ids, max_new, (const int32_t*)choice_ws, row_limit);
   SL_CHECK_LAUNCH("sample_commit");
   return 0;
 }
@@ -575,14 +581,14 @@ extern "C" int sl_sample_select(const float* logits, int32_t B, int32_t V, float
                                 int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, int32_t* choice_ws,
                                 sl_stream stream) {
   return sl_sample_select_impl(logits, B, V, temperature, top_k, top_p, seed, eos_ids, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len,
-                               next_ids, out_ids, max_new, choice_ws, (hipStream_t)stream);
+                               next_ids, out_ids, max_new, choice_ws, (hipStream_t)stream, nullptr, nullptr);
 }
 
 extern "C" int sl_greedy_select(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
                                 int32_t use_eos, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len,
                                 int32_t* next_ids, int32_t* out_ids, int32_t max_new, sl_stream stream) {
   return sl_greedy_select_impl(logits, B, V, eos_ids, n_eos, pad_id, use_eos, 1, unfinished, ctx_len, gen_count, finish_len, next_ids,
-                               out_ids, max_new, (hipStream_t)stream);
+                               out_ids, max_new, (hipStream_t)stream, nullptr);
 }
 
 // ----------------------------------------------------------------------------------------------

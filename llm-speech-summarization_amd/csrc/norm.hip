@@ -8,7 +8,8 @@ constexpr int NORM_MAXF = 64;  // floats per lane -> rows of up to 4096 elements
 
 template <typename T, bool RMS>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ g,
-                                                        const T* __restrict__ b, int64_t rows, int cols, float eps, int gelu) {
+                                                        const T* __restrict__ b, int64_t rows, int cols, float eps, int gelu,
+                                                        float* __restrict__ rstd_out = nullptr) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int MAXCH = NORM_MAXF / VEC;
   const int lane = threadIdx.x & 63;
@@ -48,6 +49,8 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T* __restrict__ x,
     s2 = wave_sum(s2);
     rstd = rsqrtf(s2 / (float)cols + eps);
   }
+  if (rstd_out && lane == 0) rstd_out[row] = rstd;     // the scale alone, for a consumer that folds the gain into its weights
+  if (y == nullptr) return;
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
     const int ch = lane + 64 * i;
@@ -191,6 +194,22 @@ extern "C" int sl_rmsnorm(const void* x, void* y, const void* w, int64_t rows, i
                           sl_stream stream) {
   SL_CHECK_ARG(x && y && w && rows >= 0 && cols > 0, "sl_rmsnorm: bad arguments");
   SL_DISPATCH_DTYPE(dtype, T, return (launch_norm<T, true>(x, y, w, nullptr, rows, cols, eps, 0, (hipStream_t)stream)));
+}
+
+// RMSNorm scale of every row (rstd_out, fp32) and / or the normalised rows (y with gain w; y = w = NULL: the scale only).  The
+// decode step above ~1 500 rows runs its o / down projections unsplit (no reduce pass to take the statistics in), so the scale
+// the gain-folded qkv / gate-up weights need comes from this one-read pass instead (runtime.hip llama_layer).
+int sl_rmsnorm_rstd_impl(const void* x, void* y, const void* w, float* rstd_out, int64_t rows, int32_t cols, float eps, int32_t dtype, hipStream_t st) {
+  SL_CHECK_ARG(x && rows >= 0 && cols > 0 && (y == nullptr) == (w == nullptr) && (y || rstd_out), "sl_rmsnorm_rstd: bad arguments");
+  if (rows == 0) return 0;
+  SL_DISPATCH_DTYPE(dtype, T, {
+    constexpr int VEC = Vec16<T>::VEC;
+    SL_CHECK_ARG(cols % VEC == 0 && cols <= 64 * NORM_MAXF, "norm: cols=%d must be a multiple of %d and <= %d", cols, VEC, 64 * NORM_MAXF);
+    hipLaunchKernelGGL((norm_rows_kernel<T, true>), dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, (const T*)x, (T*)y, (const T*)w, (const T*)nullptr,
+                       rows, cols, eps, 0, rstd_out);
+    SL_CHECK_LAUNCH("rmsnorm_rstd");
+    return 0;
+  });
 }
 
 // ----------------------------------------------------------------------------------------------

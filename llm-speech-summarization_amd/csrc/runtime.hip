@@ -10,20 +10,21 @@ int sl_attn_decode_impl(const void* q, int64_t q_stride, const void* k_cache, co
                         hipStream_t st);
 int sl_greedy_select_impl(const float* logits, int32_t B, int32_t V, const int32_t* eos_ids, int32_t n_eos, int32_t pad_id,
                           int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
-                          int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st);
+                          int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st, const int32_t* row_limit);
 int sl_greedy_select_partial_impl(const float* amax_val, const int32_t* amax_idx, int32_t n_groups, int32_t B, const int32_t* eos_ids, int32_t n_eos,
                                   int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished, int32_t* ctx_len, int32_t* gen_count,
-                                  int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st);
+                                  int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new, hipStream_t st, const int32_t* row_limit);
 int sl_sample_select_impl(const float* logits, int32_t B, int32_t V, float temperature, int32_t top_k, float top_p, uint64_t seed,
                           const int32_t* eos_ids, int32_t n_eos, int32_t pad_id, int32_t use_eos, int32_t advance_ctx, int32_t* unfinished,
                           int32_t* ctx_len, int32_t* gen_count, int32_t* finish_len, int32_t* next_ids, int32_t* out_ids, int32_t max_new,
-                          int32_t* choice_ws, hipStream_t st);
+                          int32_t* choice_ws, hipStream_t st, const int32_t* row_limit, const int32_t* row_ids);
 
 int sl_attn_decode_split_zero_counters(void* workspace, int B, int n_heads, int n_kv, int max_ctx, hipStream_t st);
 int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache, void* out, void* workspace,
                               const int32_t* ctx_len, int ctx_add, int32_t B, int32_t n_heads, int32_t n_kv, int32_t D, int32_t max_ctx,
                               float scale, int32_t dtype, hipStream_t st, int counters, int shared_prefix);
 size_t sl_attn_decode_split_ws(int B, int n_heads, int n_kv, int max_ctx);
+int sl_rmsnorm_rstd_impl(const void* x, void* y, const void* w, float* rstd_out, int64_t rows, int32_t cols, float eps, int32_t dtype, hipStream_t st);
 int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_ex_args* ex, hipStream_t st);
 bool sl_gemm_rows_epilogue_ok(int M, int N, int K, int dtype);
 
@@ -527,7 +528,7 @@ static int dec_gemm(const sl_llama_model* m, const LlamaWs& w, const void* A, in
 // bcast_slots - 1 slots before attention, in which the prefix is one more sequence (nseq counts it)
 static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, void* x, int64_t n, LlamaWs& w, bool decode, int nseq,
                        int max_qlen, const int32_t* ctx_len_dev, hipStream_t st, bool rstd_chain = false, const float* rstd_qkv = nullptr,
-                       int prefix_bcast = 0, int bcast_slots = 0) {
+                       int prefix_bcast = 0, int bcast_slots = 0, bool rstd_pass = false) {
   const sl_llama_layer& L = m->layers[l];
   const int dt = m->dtype, H = m->hidden, D = m->head_dim, nh = m->n_heads, nkv = m->n_kv_heads;
   const int qkv_w = (nh + 2 * nkv) * D;
@@ -543,6 +544,9 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
     fx.k_cache = kc; fx.v_cache = vc; fx.n_heads = nh; fx.n_kv_heads = nkv; fx.max_ctx = kv->max_ctx;
     const void* a_in = x;
     if (!m->dec_fused_norm) { SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, m->rms_eps, dt, (sl_stream)st)); a_in = w.h; }
+    // rstd_pass (rows whose o / down projections run unsplit: no reduce pass forms the RMSNorm scales): one read of x leaves them, so
+    // that the gain-folded products stay on the 256 x 128 streaming blocks instead of taking the statistics per block themselves
+    if (rstd_pass) { SL_TRY(sl_rmsnorm_rstd_impl(x, nullptr, nullptr, w.rstd_b, n, H, m->rms_eps, dt, st)); rstd_qkv = w.rstd_b; }
     SL_TRY(dec_gemm(m, w, a_in, H, L.wqkv_dec, w.qkv, (int64_t)nh * D, nullptr, (int)n, qkv_w, H, SL_ACT_ROPE_KV, 0, &fx, st, rstd_qkv));
     SL_TRY(sl_attn_decode_split_impl(w.qkv, (int64_t)nh * D, kc, vc, w.att, w.part, ctx_len_dev, 1, (int)n, nh, nkv, D, kv->max_ctx, scale, dt, st, 1, kv->shared_prefix));
     // Above ~900 rows gate/up runs on the row-major 256 x 256 tiles (the prefill kernel): at 1 024 rows it is 4 x 64 = 256 tiles, one per
@@ -550,7 +554,19 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
     // must then be normalised: the o projection's reduce pass, which already forms each row's RMSNorm scale, writes the normalised rows
     // beside x (sl_gemm_fused.norm_out) — a separate sl_rmsnorm launch costs 11.5 us per layer in the graph and ate the gain, and o itself
     // stays on the streaming form (27 + 11 us against 47 us on the 128 x 128 tiles its 48 big tiles fall back to).  SL_DECODE_TILED=0: off.
-    if (n > 896 && dt == SL_BF16 && L.wgu && rstd_chain && sl_env().decode_tiled) {
+    if (rstd_pass) {
+      SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st));
+      if (L.wgu && sl_env().decode_tiled) {     // gate/up on the row-major 256 x 256 tiles (2 048 rows: 512 tiles = two whole rounds of the chip)
+        SL_TRY(sl_rmsnorm(x, w.h, L.norm2, n, H, m->rms_eps, dt, (sl_stream)st));
+        SL_TRY(gemm(dt, w.h, H, L.wgu, H, w.mid, m->ffn, nullptr, nullptr, 0, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, st));
+      } else {
+        SL_TRY(sl_rmsnorm_rstd_impl(x, nullptr, nullptr, w.rstd_a, n, H, m->rms_eps, dt, st));
+        sl_gemm_fused fn;
+        memset(&fn, 0, sizeof(fn));
+        fn.fuse_rms = 1; fn.rms_eps = m->rms_eps;
+        SL_TRY(dec_gemm(m, w, x, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st, w.rstd_a));
+      }
+    } else if (n > 896 && dt == SL_BF16 && L.wgu && rstd_chain && sl_env().decode_tiled) {
       SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st, nullptr, w.rstd_a, w.h, L.norm2));
       SL_TRY(gemm(dt, w.h, H, L.wgu, H, w.mid, m->ffn, nullptr, nullptr, 0, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, st));
     } else {
@@ -709,8 +725,16 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
     const sl_llama_layer& L = m->layers[l];
     chain = L.wqkv_dec && L.wo_dec && L.wgu_dec && L.wdown_dec;
   }
+  // rows whose o / down projections run UNSPLIT on the 256 x 128 blocks (from ~1 500 rows at Llama-3.2-3B's widths: 8 x 24 = 192 blocks
+  // at 2 048): no reduce pass exists to take the RMSNorm scales in, a one-read pass in front of qkv and gate/up leaves them instead
+  bool rstd_pass = !chain && dt == SL_BF16 && m->dec_fused_norm && B > 384 && sl_gemm_split_count(B, H, m->n_heads * m->head_dim, dt) == 1 &&
+                   sl_gemm_split_count(B, H, m->ffn, dt) == 1;
+  for (int l = 0; l < m->n_layers && rstd_pass; ++l) {
+    const sl_llama_layer& L = m->layers[l];
+    rstd_pass = L.wqkv_dec && L.wo_dec && L.wgu_dec && L.wdown_dec;
+  }
   for (int l = 0; l < m->n_layers; ++l)
-    SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st, chain, (chain && l > 0) ? w.rstd_b : nullptr));
+    SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st, chain, (chain && l > 0) ? w.rstd_b : nullptr, 0, 0, rstd_pass));
   // lm_head: above ~256 rows the 128-tile MFMA kernel on the row-major matrix beats the streaming kernel on the packed one
   // (M=512: 439 vs 632 us; the 263 MB of fp32 logits dominate either way)
   if (m->lm_head_dec && B < SL_FUSED_ARGMAX_MIN_B) {
@@ -765,13 +789,13 @@ extern "C" int sl_llama_decode_step(const sl_llama_model* m, const sl_kv_cache* 
   return decode_step(m, kv, next_ids_dev, ctx_len_dev, B, logits, x, w, st);
 }
 
-// ---- instantiated decode graphs, cached per thread (see sl_greedy_generate)
+// ---- instantiated decode graphs, cached per thread (see sl_generate)
 struct DecodeGraphKey {
   const void *model, *layers, *w0, *lm, *embed, *kc, *vc, *ws;
   size_t ws_bytes;
   uint64_t content;        // FNV-1a over the model struct and every layer struct: all weight / norm / rope pointers and dimensions
   int device;
-  int B, max_new, use_eos, n_eos, pad, max_ctx, slots, shared_prefix, dtype, n_layers, vocab, fused;
+  int B, B0, max_new, use_eos, n_eos, pad, max_ctx, slots, shared_prefix, dtype, n_layers, vocab, fused, limits;
   int eos[8];
   int sample, top_k;
   float temperature, top_p;
@@ -780,7 +804,7 @@ struct DecodeGraphKey {
 struct DecodeGraphEntry { DecodeGraphKey key; hipGraph_t graph; hipGraphExec_t exec; uint64_t stamp; };
 static thread_local std::vector<DecodeGraphEntry> g_graphs;
 static thread_local uint64_t g_graph_clock = 0;
-constexpr size_t SL_GRAPH_CACHE = 8;
+constexpr size_t SL_GRAPH_CACHE = 32;      // a generation that compacts its batch walks down a ladder of row counts: one graph per rung
 
 static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
   const unsigned char* b = (const unsigned char*)p;
@@ -827,87 +851,128 @@ extern "C" size_t sl_generate_workspace_bytes(const sl_llama_model* m, int64_t n
   size_t a = llama_carve(m, n_tok > nseq ? n_tok : nseq, nseq, nullptr, 0, w);
   a += (size_t)nseq * m->hidden * sl_dtype_size(m->dtype) + 256;    // decode x
   a += (size_t)nseq * m->vocab * sizeof(float) + 256;               // logits
-  a += ((size_t)nseq * (6 + max_new_tokens)) * sizeof(int32_t) + 9 * 256;
+  a += ((size_t)nseq * (8 + max_new_tokens)) * sizeof(int32_t) + 11 * 256;
   return a;
+}
+
+// ---- compaction of a batch whose rows finish at different steps (sl_generate_opts.compact) ----
+// K / V rows [0, len) of slot `src` copied to slot `dst` in every layer: grid (pair, layer * n_kv); src >= every dst (the movers sit
+// above the rows that stay), so no block reads what another writes
+struct KvMove { int32_t src, dst, len, pad; };
+__global__ __launch_bounds__(256) void kv_move_kernel(uint4* __restrict__ kc, uint4* __restrict__ vc, const KvMove* __restrict__ mv, int nkv, int slots,
+                                                      int max_ctx, int row_vec) {
+  const KvMove m = mv[blockIdx.x];
+  const int l = blockIdx.y / nkv, h = blockIdx.y - l * nkv;
+  const int64_t lay = (int64_t)l * slots * nkv * max_ctx * row_vec;
+  const int64_t s0 = lay + ((int64_t)m.src * nkv + h) * max_ctx * row_vec, d0 = lay + ((int64_t)m.dst * nkv + h) * max_ctx * row_vec;
+  const int n = m.len * row_vec;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    kc[d0 + i] = kc[s0 + i];
+    vc[d0 + i] = vc[s0 + i];
+  }
+}
+
+// rungs of the row-count ladder a compacting generation steps down: each is a row count some kernel family runs at full blocks, and
+// each costs one captured graph (kept in the per-thread cache)
+static int compact_rung(int n_live) {
+  static const int rungs[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048};
+  for (int r : rungs)
+    if (n_live <= r) return r;
+  return n_live;
 }
 
 struct SampleOpts { float temperature; int top_k; float top_p; uint64_t seed; };
 
 static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
-                         int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
-                         int32_t check_every, const SampleOpts* smp, int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host,
-                         void* workspace, size_t workspace_bytes, sl_stream stream) {
+                         const sl_generate_opts* o, int32_t* out_ids_host, sl_generate_stats* stats, void* workspace, size_t workspace_bytes,
+                         sl_stream stream) {
   SL_TRY(llama_check(m, kv));
-  SL_CHECK_ARG(x && cu_seqlens_host && out_ids_host && n_steps_host && workspace && nseq > 0 && nseq <= SL_MAX_DECODE_BATCH && max_new_tokens > 0,
-               "sl_greedy_generate: bad arguments (nseq<=%d)", SL_MAX_DECODE_BATCH);
+  SL_CHECK_ARG(o != nullptr, "sl_generate: null options");
+  const int max_new_tokens = o->max_new_tokens, n_eos = o->n_eos, pad_id = o->pad_id;
+  const int32_t* eos_ids_host = o->eos_ids_host;
+  const int use_eos = (o->use_eos || o->row_limits_host) ? 1 : 0;       // per-row budgets finish rows the way EOS does
+  SL_CHECK_ARG(x && cu_seqlens_host && out_ids_host && workspace && nseq > 0 && nseq <= SL_MAX_DECODE_BATCH && max_new_tokens > 0,
+               "sl_generate: bad arguments (nseq<=%d)", SL_MAX_DECODE_BATCH);
+  SL_CHECK_ARG(n_eos >= 0 && n_eos <= 8 && (n_eos == 0 || eos_ids_host != nullptr), "sl_generate: 0..8 eos ids");
+  SampleOpts smp_s{o->temperature, o->top_k, o->top_p, o->seed};
+  const SampleOpts* smp = o->sample ? &smp_s : nullptr;
+  if (smp) SL_CHECK_ARG(smp->temperature > 0.f && smp->top_p > 0.f && smp->top_p <= 1.0f && smp->top_k >= 0, "sl_generate: sampling needs temperature > 0, 0 < top_p <= 1, top_k >= 0");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n_tok = cu_seqlens_host[nseq];
-  const int B = nseq;
+  const int B0 = nseq;
   for (int s = 0; s < nseq; ++s)
     SL_CHECK_ARG(cu_seqlens_host[s + 1] - cu_seqlens_host[s] + max_new_tokens <= kv->max_ctx,
-                 "sl_greedy_generate: prompt %d (%d tokens) + %d new tokens exceeds max_ctx %d", s,
+                 "sl_generate: prompt %d (%d tokens) + %d new tokens exceeds max_ctx %d", s,
                  cu_seqlens_host[s + 1] - cu_seqlens_host[s], max_new_tokens, kv->max_ctx);
   for (int s = 0; s < nseq; ++s)
-    SL_CHECK_ARG(kv->shared_prefix <= cu_seqlens_host[s + 1] - cu_seqlens_host[s], "sl_greedy_generate: kv cache shared_prefix %d exceeds prompt %d (%d tokens)",
+    SL_CHECK_ARG(kv->shared_prefix <= cu_seqlens_host[s + 1] - cu_seqlens_host[s], "sl_generate: kv cache shared_prefix %d exceeds prompt %d (%d tokens)",
                  kv->shared_prefix, s, cu_seqlens_host[s + 1] - cu_seqlens_host[s]);
-  SL_CHECK_ARG(sl_generate_workspace_bytes(m, n_tok, nseq, max_new_tokens) <= workspace_bytes, "sl_greedy_generate: workspace %zu B < required %zu B",
+  if (o->row_limits_host)
+    for (int s = 0; s < nseq; ++s)
+      SL_CHECK_ARG(o->row_limits_host[s] >= 1 && o->row_limits_host[s] <= max_new_tokens, "sl_generate: row limit %d of sequence %d outside [1, max_new_tokens=%d]",
+                   o->row_limits_host[s], s, max_new_tokens);
+  SL_CHECK_ARG(sl_generate_workspace_bytes(m, n_tok, nseq, max_new_tokens) <= workspace_bytes, "sl_generate: workspace %zu B < required %zu B",
                workspace_bytes, sl_generate_workspace_bytes(m, n_tok, nseq, max_new_tokens));
   // carve: generation state first, then the prefill/decode scratch
   Carver c(workspace, workspace_bytes);
-  float* logits = (float*)c.take((size_t)B * m->vocab * sizeof(float));
-  void* xdec = c.take((size_t)B * m->hidden * sl_dtype_size(m->dtype));
-  int32_t* unfinished = (int32_t*)c.take(B * sizeof(int32_t));
-  int32_t* ctx_len = (int32_t*)c.take(B * sizeof(int32_t));
-  int32_t* gen_count = (int32_t*)c.take(B * sizeof(int32_t));
-  int32_t* finish_len = (int32_t*)c.take(B * sizeof(int32_t));
-  int32_t* next_ids = (int32_t*)c.take(B * sizeof(int32_t));
-  int32_t* out_ids = (int32_t*)c.take((size_t)B * max_new_tokens * sizeof(int32_t));
-  int32_t* choice = (int32_t*)c.take(B * sizeof(int32_t));      // sampling mode: the drawn token of every row
+  float* logits = (float*)c.take((size_t)B0 * m->vocab * sizeof(float));
+  void* xdec = c.take((size_t)B0 * m->hidden * sl_dtype_size(m->dtype));
+  int32_t* unfinished = (int32_t*)c.take(B0 * sizeof(int32_t));
+  int32_t* ctx_len = (int32_t*)c.take(B0 * sizeof(int32_t));
+  int32_t* gen_count = (int32_t*)c.take(B0 * sizeof(int32_t));
+  int32_t* finish_len = (int32_t*)c.take(B0 * sizeof(int32_t));
+  int32_t* next_ids = (int32_t*)c.take(B0 * sizeof(int32_t));
+  int32_t* out_ids = (int32_t*)c.take((size_t)B0 * max_new_tokens * sizeof(int32_t));
+  int32_t* choice = (int32_t*)c.take(B0 * sizeof(int32_t));      // sampling mode: the drawn token of every row
+  int32_t* row_limit = (int32_t*)c.take(B0 * sizeof(int32_t));   // per-row token budgets (sl_generate_opts.row_limits_host)
+  int32_t* row_id = (int32_t*)c.take(B0 * sizeof(int32_t));      // the caller's index of the sequence a row holds (rows move when the batch is compacted)
   c.take(0);
   void* scratch = bptr(workspace) + c.off;
   const size_t scratch_bytes = workspace_bytes - c.off;
+  const int32_t* row_limit_arg = o->row_limits_host ? row_limit : nullptr;
 
-  std::vector<int32_t> ones(B, 1), zeros(B, 0);
-  SL_HIP(hipMemcpyAsync(unfinished, ones.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemcpyAsync(gen_count, zeros.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemcpyAsync(finish_len, zeros.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  SL_HIP(hipMemsetAsync(out_ids, 0, (size_t)B * max_new_tokens * sizeof(int32_t), st));
+  std::vector<int32_t> ones(B0, 1), zeros(B0, 0), orig(B0);
+  for (int b = 0; b < B0; ++b) orig[b] = b;
+  SL_HIP(hipMemcpyAsync(unfinished, ones.data(), B0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(gen_count, zeros.data(), B0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(finish_len, zeros.data(), B0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemcpyAsync(row_id, orig.data(), B0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  if (o->row_limits_host) SL_HIP(hipMemcpyAsync(row_limit, o->row_limits_host, B0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  SL_HIP(hipMemsetAsync(out_ids, 0, (size_t)B0 * max_new_tokens * sizeof(int32_t), st));
 
   hipEvent_t ev[3];
   for (auto& e : ev) SL_HIP(hipEventCreate(&e));
   SL_HIP(hipEventRecord(ev[0], st));
   SL_TRY(sl_llama_prefill(m, kv, x, cu_seqlens_host, nseq, logits, ctx_len, nullptr, scratch, scratch_bytes, stream));
-  auto select = [&](int advance_ctx, hipStream_t s_) -> int {
+  auto select = [&](int B, int advance_ctx, hipStream_t s_) -> int {
     if (smp)
       return sl_sample_select_impl(logits, B, m->vocab, smp->temperature, smp->top_k, smp->top_p, smp->seed, eos_ids_host, n_eos, pad_id, use_eos, advance_ctx,
-                                   unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, max_new_tokens, choice, s_);
+                                   unfinished, ctx_len, gen_count, finish_len, next_ids, out_ids, max_new_tokens, choice, s_, row_limit_arg, row_id);
     return sl_greedy_select_impl(logits, B, m->vocab, eos_ids_host, n_eos, pad_id, use_eos, advance_ctx, unfinished, ctx_len, gen_count, finish_len, next_ids,
-                                 out_ids, max_new_tokens, s_);
+                                 out_ids, max_new_tokens, s_, row_limit_arg);
   };
-  SL_TRY(select(0, st));
+  SL_TRY(select(B0, 0, st));
   SL_HIP(hipEventRecord(ev[1], st));
 
-  // decode: one captured step, replayed.  Scratch layout for M = B rows.
-  LlamaWs w;
-  llama_carve(m, B, B, scratch, scratch_bytes, w);
-  if (w.split && w.split_bytes >= 8192) SL_HIP(hipMemsetAsync(w.split, 0, 8192, st));   // the K-split fix-up's counters start at zero (sl_gemm_fused.split_ws)
-  SL_TRY(sl_attn_decode_split_zero_counters(w.part, B, m->n_heads, m->n_kv_heads, kv->max_ctx, st));   // split attention merges its records in-launch: arrival counters start at zero
-  hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
-  SL_CHECK_LAUNCH("iota");
-  int steps_done = 1;
-  std::vector<int32_t> unf_host(B, 1);
-  bool all_done = false;
-  if (max_new_tokens > 1) {
-    // The decode step is captured ONCE per (model, cache, workspace, batch, limits) and the instantiated graph is kept in a
-    // small per-thread cache: a second sl_greedy_generate call with the same buffers (the usual case: a serving loop reusing
-    // its KV cache and workspace) replays it without re-capturing.  Every pointer the captured launches were recorded with
-    // is part of the key, so a changed buffer can never replay a stale graph.
+  // The decode step for `B` rows: captured ONCE per (model, cache, workspace, row count, limits) and kept in a small per-thread
+  // cache — a second call with the same buffers (the usual case: a serving loop reusing its KV cache and workspace) replays it
+  // without re-capturing.  Every pointer the captured launches were recorded with is part of the key (the state arrays and the
+  // scratch layout follow from the workspace pointer, the ORIGINAL batch B0 and the row count B), so a changed buffer can never
+  // replay a stale graph.  Also resets the per-graph scratch (K-split counters, split-attention counters, the slot index list).
+  auto graph_for = [&](int B, hipGraphExec_t* exec_out) -> int {
+    LlamaWs w;
+    llama_carve(m, B, B, scratch, scratch_bytes, w);
+    if (w.split && w.split_bytes >= 8192) SL_HIP(hipMemsetAsync(w.split, 0, 8192, st));   // the K-split fix-up's counters start at zero (sl_gemm_fused.split_ws)
+    SL_TRY(sl_attn_decode_split_zero_counters(w.part, B, m->n_heads, m->n_kv_heads, kv->max_ctx, st));   // split attention merges its records in-launch: arrival counters start at zero
+    hipLaunchKernelGGL(iota_kernel, dim3((B + 255) / 256), dim3(256), 0, st, w.tok_seq, B);
+    SL_CHECK_LAUNCH("iota");
     DecodeGraphKey key;
     memset(&key, 0, sizeof(key));
     key.model = m; key.layers = m->layers; key.w0 = m->n_layers > 0 ? m->layers[0].wqkv_dec : nullptr; key.lm = m->lm_head_dec ? m->lm_head_dec : m->lm_head;
     key.embed = m->embed; key.kc = kv->k_cache; key.vc = kv->v_cache; key.ws = workspace; key.ws_bytes = workspace_bytes;
-    key.B = B; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
+    key.B = B; key.B0 = B0; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
     key.slots = kv->slots; key.shared_prefix = kv->shared_prefix; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8);   // + the switch that shapes the captured launches
+    key.limits = row_limit_arg ? 1 : 0;
     key.content = model_content_hash(m);
     SL_HIP(hipGetDevice(&key.device));
     for (int i = 0; i < n_eos && i < 8; ++i) key.eos[i] = eos_ids_host[i];
@@ -918,7 +983,7 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
       // Capture on a private stream (the caller's may be the legacy null stream, which cannot capture);
       // capturing records the launches without running them, the graph is then replayed on `st`.
       static thread_local hipStream_t cap_by_dev[SL_MAX_DEVICES] = {};    // a stream belongs to the device that was current when it was made
-      SL_CHECK_ARG(key.device >= 0 && key.device < SL_MAX_DEVICES, "sl_greedy_generate: device index %d", key.device);
+      SL_CHECK_ARG(key.device >= 0 && key.device < SL_MAX_DEVICES, "sl_generate: device index %d", key.device);
       hipStream_t& cap = cap_by_dev[key.device];
       if (!cap) SL_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
       SL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
@@ -929,9 +994,9 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
         if (top1) {
           const int ng = (m->vocab + 63) / 64;
           rc = sl_greedy_select_partial_impl(logits, (const int32_t*)(logits + (int64_t)ng * B), ng, B, eos_ids_host, n_eos, pad_id, use_eos, 1, unfinished,
-                                             ctx_len, gen_count, finish_len, next_ids, out_ids, max_new_tokens, cap);
+                                             ctx_len, gen_count, finish_len, next_ids, out_ids, max_new_tokens, cap, row_limit_arg);
         } else {
-          rc = select(1, cap);
+          rc = select(B, 1, cap);
         }
       }
       hipError_t ce = hipStreamEndCapture(cap, &graph);
@@ -940,41 +1005,133 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
       SL_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       decode_graph_store(key, graph, exec);
     }
-    if (check_every <= 0) check_every = 16;
+    *exec_out = exec;
+    return 0;
+  };
+
+  // host copies of the per-row state, filled at a check; `done[s]`: sequence s (caller's index) has been written to out_ids_host
+  std::vector<int32_t> h_unf(B0, 1), h_fin(B0, 0), h_ctx, h_cnt, h_next, h_lim, h_out;
+  std::vector<char> done(B0, 0);
+  std::vector<int32_t> fin_of(B0, 0), unf_of(B0, 1);
+  int steps_done = 1, B = B0, compactions = 0, launches = 0;
+  int64_t row_steps = 0;
+  bool all_done = false;
+  // rows [0, B) -> the caller's output rows, for the sequences not written yet (a retired sequence's row may live on as padding of
+  // the compacted batch: its pads are not written again)
+  auto retire = [&](bool only_finished) {
+    for (int r = 0; r < B; ++r) {
+      const int s = orig[r];
+      if (done[s] || (only_finished && h_unf[r] != 0)) continue;
+      memcpy(out_ids_host + (size_t)s * max_new_tokens, h_out.data() + (size_t)r * max_new_tokens, (size_t)max_new_tokens * sizeof(int32_t));
+      fin_of[s] = h_fin[r]; unf_of[s] = h_unf[r];
+      done[s] = 1;
+    }
+  };
+  if (max_new_tokens > 1) {
+    hipGraphExec_t exec = nullptr;
+    SL_TRY(graph_for(B, &exec));
+    const int check_every = o->check_every > 0 ? o->check_every : 16;
     while (steps_done < max_new_tokens) {
       SL_HIP(hipGraphLaunch(exec, st));
-      ++steps_done;
-      if (use_eos && (steps_done % check_every == 0) && steps_done < max_new_tokens) {
-        SL_HIP(hipMemcpyAsync(unf_host.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        SL_HIP(hipStreamSynchronize(st));
-        all_done = true;
-        for (int b = 0; b < B; ++b) all_done = all_done && (unf_host[b] == 0);
-        if (all_done) break;
+      ++steps_done; ++launches; row_steps += B;
+      if (!(use_eos && (steps_done % check_every == 0) && steps_done < max_new_tokens)) continue;
+      SL_HIP(hipMemcpyAsync(h_unf.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SL_HIP(hipStreamSynchronize(st));
+      int n_live = 0;
+      for (int b = 0; b < B; ++b) n_live += (h_unf[b] != 0);
+      if (n_live == 0) { all_done = true; break; }
+      const int rung = compact_rung(n_live);
+      if (!o->compact || rung >= B) continue;
+      // ---- compact: the live rows that sit at or above `rung` (the movers) take the places of finished rows below it; live rows
+      // below it and the remaining finished ones (padding of the rung) stay where they are.  Finished sequences are written to the
+      // caller's buffer first.  Everything per-row moves with the row: state arrays (through the host: a few KB), output ids, and
+      // the row's K / V slot (on the device).
+      h_ctx.resize(B); h_cnt.resize(B); h_next.resize(B); h_lim.resize(B); h_out.resize((size_t)B * max_new_tokens);
+      SL_HIP(hipMemcpyAsync(h_fin.data(), finish_len, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SL_HIP(hipMemcpyAsync(h_ctx.data(), ctx_len, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SL_HIP(hipMemcpyAsync(h_cnt.data(), gen_count, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SL_HIP(hipMemcpyAsync(h_next.data(), next_ids, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      if (row_limit_arg) SL_HIP(hipMemcpyAsync(h_lim.data(), row_limit, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SL_HIP(hipMemcpyAsync(h_out.data(), out_ids, (size_t)B * max_new_tokens * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SL_HIP(hipStreamSynchronize(st));
+      retire(true);
+      std::vector<KvMove> moves;
+      int hole = 0;
+      for (int r = rung; r < B; ++r) {
+        if (h_unf[r] == 0) continue;
+        while (h_unf[hole] != 0) ++hole;          // exists: at most `rung` rows are live
+        moves.push_back(KvMove{r, hole, h_ctx[r], 0});
+        h_unf[hole] = h_unf[r]; h_fin[hole] = h_fin[r]; h_ctx[hole] = h_ctx[r]; h_cnt[hole] = h_cnt[r]; h_next[hole] = h_next[r]; h_lim[hole] = h_lim[r];
+        memcpy(h_out.data() + (size_t)hole * max_new_tokens, h_out.data() + (size_t)r * max_new_tokens, (size_t)max_new_tokens * sizeof(int32_t));
+        orig[hole] = orig[r];
+        ++hole;
       }
+      if (!moves.empty()) {
+        const int row_vec = (int)(m->head_dim * sl_dtype_size(m->dtype) / 16);
+        KvMove* mv_dev = (KvMove*)logits;         // the logits buffer is idle between steps (>= B0 * vocab floats)
+        SL_CHECK_ARG(moves.size() * sizeof(KvMove) <= (size_t)B0 * m->vocab * sizeof(float), "sl_generate: move list does not fit");
+        SL_HIP(hipMemcpyAsync(mv_dev, moves.data(), moves.size() * sizeof(KvMove), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(kv_move_kernel, dim3((unsigned)moves.size(), m->n_layers * m->n_kv_heads), dim3(256), 0, st, (uint4*)kv->k_cache, (uint4*)kv->v_cache,
+                           mv_dev, m->n_kv_heads, kv->slots, kv->max_ctx, row_vec);
+        SL_CHECK_LAUNCH("kv_move");
+      }
+      B = rung;
+      SL_HIP(hipMemcpyAsync(unfinished, h_unf.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      SL_HIP(hipMemcpyAsync(finish_len, h_fin.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      SL_HIP(hipMemcpyAsync(ctx_len, h_ctx.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      SL_HIP(hipMemcpyAsync(gen_count, h_cnt.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      SL_HIP(hipMemcpyAsync(next_ids, h_next.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      SL_HIP(hipMemcpyAsync(row_id, orig.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      if (row_limit_arg) SL_HIP(hipMemcpyAsync(row_limit, h_lim.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      SL_HIP(hipMemcpyAsync(out_ids, h_out.data(), (size_t)B * max_new_tokens * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      SL_HIP(hipStreamSynchronize(st));           // the host vectors above are reused / the move list is overwritten by the next step's logits
+      SL_TRY(graph_for(B, &exec));
+      ++compactions;
     }
-    SL_HIP(hipEventRecord(ev[2], st));
-  } else {
-    SL_HIP(hipEventRecord(ev[2], st));
   }
-  // results: queued behind the last step on the caller's stream, ONE synchronisation for the whole call
-  std::vector<int32_t> fin(B);
-  SL_HIP(hipMemcpyAsync(unf_host.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  SL_HIP(hipMemcpyAsync(fin.data(), finish_len, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  SL_HIP(hipMemcpyAsync(out_ids_host, out_ids, (size_t)B * max_new_tokens * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  SL_HIP(hipEventRecord(ev[2], st));
+  // results: queued behind the last step on the caller's stream, ONE synchronisation for the whole call (plus one per check above)
+  h_out.resize((size_t)B * max_new_tokens);
+  SL_HIP(hipMemcpyAsync(h_unf.data(), unfinished, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  SL_HIP(hipMemcpyAsync(h_fin.data(), finish_len, B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  SL_HIP(hipMemcpyAsync(h_out.data(), out_ids, (size_t)B * max_new_tokens * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   SL_HIP(hipStreamSynchronize(st));
+  retire(false);
   int n_cols = steps_done;
   if (use_eos) {
     all_done = true;
     int mx = 0;
-    for (int b = 0; b < B; ++b) { all_done = all_done && unf_host[b] == 0; if (fin[b] > mx) mx = fin[b]; }
+    for (int s = 0; s < B0; ++s) { all_done = all_done && unf_of[s] == 0; if (fin_of[s] > mx) mx = fin_of[s]; }
     if (all_done) n_cols = mx;  // HF stops at the step where the last row emitted its EOS
+    // a sequence retired at a compaction has pads up to the step of its retirement only: pad the rest of its row, as the uncompacted
+    // batch would have (hf:generation/utils.py:2928-2929)
+    for (int s = 0; s < B0; ++s)
+      if (unf_of[s] == 0)
+        for (int t = fin_of[s]; t < max_new_tokens; ++t) out_ids_host[(size_t)s * max_new_tokens + t] = pad_id;
   }
-  *n_steps_host = n_cols;
-  if (timings_ms_host) {
-    SL_HIP(hipEventElapsedTime(&timings_ms_host[0], ev[0], ev[1]));
-    SL_HIP(hipEventElapsedTime(&timings_ms_host[1], ev[1], ev[2]));
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->n_steps = n_cols; stats->decode_launches = launches; stats->compactions = compactions; stats->final_rows = B; stats->row_steps = row_steps;
+    SL_HIP(hipEventElapsedTime(&stats->prefill_ms, ev[0], ev[1]));
+    SL_HIP(hipEventElapsedTime(&stats->decode_ms, ev[1], ev[2]));
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
+  return 0;
+}
+
+extern "C" int sl_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
+                           const sl_generate_opts* opts, int32_t* out_ids_host, sl_generate_stats* stats, void* workspace, size_t workspace_bytes,
+                           sl_stream stream) {
+  return generate_impl(m, kv, x, cu_seqlens_host, nseq, opts, out_ids_host, stats, workspace, workspace_bytes, stream);
+}
+
+static int generate_compat(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq, sl_generate_opts& o,
+                           int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host, void* workspace, size_t workspace_bytes, sl_stream stream) {
+  SL_CHECK_ARG(n_steps_host != nullptr, "sl_greedy_generate: null n_steps");
+  sl_generate_stats stt;
+  SL_TRY(generate_impl(m, kv, x, cu_seqlens_host, nseq, &o, out_ids_host, &stt, workspace, workspace_bytes, stream));
+  *n_steps_host = stt.n_steps;
+  if (timings_ms_host) { timings_ms_host[0] = stt.prefill_ms; timings_ms_host[1] = stt.decode_ms; }
   return 0;
 }
 
@@ -982,8 +1139,10 @@ extern "C" int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv
                                   int32_t max_new_tokens, const int32_t* eos_ids_host, int32_t n_eos, int32_t pad_id, int32_t use_eos,
                                   int32_t check_every, int32_t* out_ids_host, int32_t* n_steps_host, float* timings_ms_host,
                                   void* workspace, size_t workspace_bytes, sl_stream stream) {
-  return generate_impl(m, kv, x, cu_seqlens_host, nseq, max_new_tokens, eos_ids_host, n_eos, pad_id, use_eos, check_every, nullptr, out_ids_host,
-                       n_steps_host, timings_ms_host, workspace, workspace_bytes, stream);
+  sl_generate_opts o;
+  memset(&o, 0, sizeof(o));
+  o.max_new_tokens = max_new_tokens; o.eos_ids_host = eos_ids_host; o.n_eos = n_eos; o.pad_id = pad_id; o.use_eos = use_eos; o.check_every = check_every;
+  return generate_compat(m, kv, x, cu_seqlens_host, nseq, o, out_ids_host, n_steps_host, timings_ms_host, workspace, workspace_bytes, stream);
 }
 
 extern "C" int sl_sample_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, const int32_t* cu_seqlens_host, int32_t nseq,
@@ -991,7 +1150,9 @@ extern "C" int sl_sample_generate(const sl_llama_model* m, const sl_kv_cache* kv
                                   int32_t check_every, float temperature, int32_t top_k, float top_p, uint64_t seed, int32_t* out_ids_host,
                                   int32_t* n_steps_host, float* timings_ms_host, void* workspace, size_t workspace_bytes, sl_stream stream) {
   SL_CHECK_ARG(temperature > 0.f && top_p > 0.f && top_p <= 1.0f && top_k >= 0, "sl_sample_generate: need temperature > 0, 0 < top_p <= 1, top_k >= 0");
-  SampleOpts o{temperature, top_k, top_p, seed};
-  return generate_impl(m, kv, x, cu_seqlens_host, nseq, max_new_tokens, eos_ids_host, n_eos, pad_id, use_eos, check_every, &o, out_ids_host, n_steps_host,
-                       timings_ms_host, workspace, workspace_bytes, stream);
+  sl_generate_opts o;
+  memset(&o, 0, sizeof(o));
+  o.max_new_tokens = max_new_tokens; o.eos_ids_host = eos_ids_host; o.n_eos = n_eos; o.pad_id = pad_id; o.use_eos = use_eos; o.check_every = check_every;
+  o.sample = 1; o.temperature = temperature; o.top_k = top_k; o.top_p = top_p; o.seed = seed;
+  return generate_compat(m, kv, x, cu_seqlens_host, nseq, o, out_ids_host, n_steps_host, timings_ms_host, workspace, workspace_bytes, stream);
 }

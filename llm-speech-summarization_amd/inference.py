@@ -113,13 +113,35 @@ class LLMSpeechTextInference():
         """Batched form of generate_audio_response (an extension: the reference answers one utterance per call).
         Every utterance is encoded and prefilled at its own length in ONE ragged batch — the encoder writes its embeddings
         straight into the packed prompt buffer `[prefix | text[1:] | audio | suffix[1:]]` — and decoded together, so that the
-        weights are streamed once per step for the whole batch.  Results equal per-utterance calls (tests)."""
-        if self.audio_encoder.downsample_method != "pool" or self.audio_encoder.encoder_base != "hubert":
-            return [self.generate_audio_response(a, (additional_text_prompts or [""] * len(audios))[i], max_new_tokens)
-                    for i, a in enumerate(audios)]
-        from .utils import prompt_template
+        weights are streamed once per step for the whole batch; rows that stop early leave the batch (sl_generate's compaction).
+        Both encoder bases take this path (Whisper: log-mel of all windows -> one encoder pass -> each utterance's rows cropped to
+        compute_num_audio_embeds, the trainer's order of operations ref:trainer.py:168-199,278-291); more utterances than one
+        generate call takes (SL_MAX_DECODE_BATCH) are answered in consecutive chunks.  Results equal per-utterance calls (tests)."""
         n = len(audios)
         texts = list(additional_text_prompts) if additional_text_prompts is not None else [""] * n
+        if len(texts) != n:
+            raise ValueError(f"{len(texts)} text prompts for {n} utterances")
+        if self.audio_encoder.downsample_method != "pool":       # stack / ctc_pool: the one-utterance path (ctc_pool raises as the reference does)
+            return [self.generate_audio_response(a, texts[i], max_new_tokens) for i, a in enumerate(audios)]
+        out: List[str] = []
+        ids_all = []
+        for lo_ in range(0, n, L.MAX_DECODE_BATCH):
+            ids = self._generate_chunk(audios[lo_:lo_ + L.MAX_DECODE_BATCH], texts[lo_:lo_ + L.MAX_DECODE_BATCH], max_new_tokens)
+            ids_all.append(ids)
+            out += self.llm_tokenizer.batch_decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+        # one (n, widest chunk) id matrix, pad-filled like a single HF call over the whole list would leave it
+        width = max(int(i.shape[1]) for i in ids_all) if ids_all else 0
+        pad = self.llm.generation_config.pad_token_id
+        if pad is None:
+            e = self.llm.generation_config.eos_token_id
+            pad = (e[0] if isinstance(e, (list, tuple)) else e) if e else 0
+        self.last_generate_ids = torch.cat([torch.nn.functional.pad(i, (0, width - int(i.shape[1])), value=int(pad)) for i in ids_all]) if ids_all else None
+        return out
+
+    def _generate_chunk(self, audios, texts, max_new_tokens) -> torch.Tensor:
+        """One generate call's worth of utterances -> LongTensor (n, n_cols) of new tokens."""
+        from .utils import compute_num_audio_embeds, prompt_template
+        n = len(audios)
         emb = self.llm.model.embed_tokens
         prefix, suffix = prompt_template(self.llm_type)
         pre_e = emb(self.llm_tokenizer(prefix, return_tensors="pt").input_ids.to(self.device))[0]
@@ -127,7 +149,14 @@ class LLMSpeechTextInference():
         txt_e = [emb(self.llm_tokenizer(t_, return_tensors="pt").input_ids[:, 1:].to(self.device))[0] if len(t_) > 0 else None for t_ in texts]
         waves = [torch.as_tensor(a, dtype=torch.float32).reshape(-1) for a in audios]
         enc = self.audio_encoder
-        Ps = [(enc.arch.num_frames(int(w.numel())) - enc.pool_kernel) // enc.pool_stride + 1 for w in waves]
+        whisper = enc.encoder_base == "whisper"
+        if whisper:
+            sr = int(getattr(getattr(self.config, "audio", None), "sampling_rate", 16000) or 16000)
+            feats = enc.feature_extractor(waves, return_tensors="pt", sampling_rate=sr).input_features
+            padded = enc(feats)                                                  # (n, P_window, llm_dim): every 30 s window in one pass
+            Ps = [max(0, min(int(padded.shape[1]), compute_num_audio_embeds(int(w.numel()), sr=sr))) for w in waves]
+        else:
+            Ps = [(enc.arch.num_frames(int(w.numel())) - enc.pool_kernel) // enc.pool_stride + 1 for w in waves]
         lens, heads = [], []
         for i in range(n):
             n_head = pre_e.shape[0] + (txt_e[i].shape[0] if txt_e[i] is not None else 0)
@@ -142,14 +171,15 @@ class LLMSpeechTextInference():
             x[o:o + pre_e.shape[0]] = pre_e
             if txt_e[i] is not None:
                 x[o + pre_e.shape[0]:o + heads[i]] = txt_e[i]
+            if whisper:
+                x[o + heads[i]:o + heads[i] + Ps[i]] = padded[i, :Ps[i]]
             x[o + heads[i] + Ps[i]:starts[i + 1]] = suf_e
-        enc.encode_packed(waves, out=x, out_row_offsets=[starts[i] + heads[i] for i in range(n)])
+        if not whisper:
+            enc.encode_packed(waves, out=x, out_row_offsets=[starts[i] + heads[i] for i in range(n)])
         # every prompt opens with the same template rows (and the same instruction text when the caller gave one text for all):
         # the batched decode attention reads those cache positions once for the batch (sl_kv_cache.shared_prefix)
         shared = int(pre_e.shape[0])
         if txt_e[0] is not None and all(t_ == texts[0] for t_ in texts):
             shared += int(txt_e[0].shape[0])
         ids, n_cols = self.llm.generate_packed(x, lens, max_new_tokens, use_eos=True, shared_prefix=shared)
-        generate_ids = ids[:, :n_cols].to(torch.int64)
-        self.last_generate_ids = generate_ids
-        return self.llm_tokenizer.batch_decode(generate_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+        return ids[:, :n_cols].to(torch.int64)

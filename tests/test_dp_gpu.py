@@ -208,3 +208,34 @@ def test_sl_comm_c_abi_one_rank_communicator_orders_against_the_compute_stream()
     L.check(lib.sl_comm_init(C.byref(comm2), ident, 0, 1), "sl_comm_init")
     L.check(lib.sl_comm_abort(comm2), "sl_comm_abort")
     assert lib.sl_comm_abort(None) == 0
+
+
+def test_bench_line_describes_itself_small_batch(tmp_path):
+    """bench.py end to end on the GPU at a small batch: the line carries what makes an N > 1 run verifiable without interpretation
+     — per-rank work, the gradient exchange's comm block (here the one-rank communicator driven through the
+    same reducer: backend, RCCL rank count, buckets, measured exchange on the side stream), the four graded fractions side by side,
+    roofline entries that name what the decode graph launches, and the answers-of-different-lengths leg."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--batch", "48", "--steps", "2", "--warmup", "1", "--kd-optimizer-steps", "1",
+                        "--no-cpu-baseline", "--no-extra-legs", "--no-length-mix", "--max-new-tokens", "48"], capture_output=True, text=True, env=env,
+                       timeout=1500, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["per_rank"] == [{"rank": 0, "utterances": 96, "audio_sec": 960.0, "tokens": 96 * 48, "elapsed_s": rec["per_rank"][0]["elapsed_s"]}]
+    c = rec["kd_step"]["comm"]
+    assert "error" not in rec["kd_step"], rec["kd_step"].get("error")
+    assert c["backend"] == "sl" and c["rccl_nranks"] == 1 and not c["fell_back"] and c["buckets"] >= 2 and sum(c["bucket_bytes"]) >= rec["kd_step"]["trainable_params"] * 4
+    assert c["measured_exchange_ms"] > 0 and 0.0 <= c["overlap_frac"] <= 1.0
+    g = rec["graded"]
+    assert all(isinstance(g[k], float) and 0.0 < g[k] < 1.0 for k in ("encoder_mfma_frac", "prefill_mfma_frac", "kd_step_mfma_frac", "batch1_decode_hbm_frac"))
+    for key in ("roofline", "roofline_other"):
+        assert rec[key]["launches_in_timed_region"] == 28 * 47 * 2 and rec[key]["frac"] > 0
+    e = rec["eos_stop_mix"]
+    assert "error" not in e, e
+    assert e["compacted"]["compactions"] >= 1 and e["compacted"]["row_steps"] < e["uncompacted"]["row_steps"] and e["useful_tokens"] == sum(12 + (61 * b) % 37 for b in range(48))

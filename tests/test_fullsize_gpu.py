@@ -70,7 +70,7 @@ class FullModels:
             g.manual_seed(99)
             sd["lm_head.weight"] = (torch.randn(self.larch.vocab_size, self.larch.hidden_size, generator=g, device=DEV) * 0.02).to(torch.bfloat16)
         self.llm_sd_host = {k: v.float().cpu() for k, v in sd.items()}        # the oracle's weights: bf16 values held in fp32
-        self.llm = llama_mod.AudioLlamaForCausalLM(self.larch, sd, torch_dtype=torch.bfloat16, device=DEV, max_ctx=448, max_batch=1024)
+        self.llm = llama_mod.AudioLlamaForCausalLM(self.larch, sd, torch_dtype=torch.bfloat16, device=DEV, max_ctx=448, max_batch=2048)
         bos = self.larch.bos_token_id or 0
         self.prefix = ri.synthetic_ids(N_PRE, self.larch.vocab_size, seed=7, bos=bos)
         self.suffix = ri.synthetic_ids(N_SUF, self.larch.vocab_size, seed=8, bos=bos)
@@ -150,7 +150,7 @@ def _agreeing_prefix(a, b):
     return int(neq[0]) if neq.numel() else int(a.shape[0])
 
 
-@pytest.mark.parametrize("B", [1024, 512])     # 1024 = bench.py's default step; 512 = round 1's (K-split forms of the 256 x 128 block)
+@pytest.mark.parametrize("B", [2048, 1024, 512])     # 2048 = the largest step the library takes (o / down unsplit, RMSNorm scales from a one-read pass); 1024 = bench.py's default; 512 = round 1's (K-split forms of the 256 x 128 block)
 def test_configs1_full_depth_large_batch_copies_identical_and_equal_small_batch(llama3, B):
     """bench.py's default step (1024 sequences, HuBERT-large 24 L + Llama-3.2-3B 28 L, bf16) on copies of 3 distinct utterances."""
     m, new = llama3, 24
@@ -488,7 +488,7 @@ def test_bf16_path_distance_to_the_references_fp16_autocast_regime_full_depth():
     assert int(first.argmax()) == int(h["argmax"]) == int(g["ids"][0, 0])      # top-2 margin 0.18 against logit differences of a few 1e-2
 
 
-@pytest.mark.parametrize("B", [1024, 512])
+@pytest.mark.parametrize("B", [2048, 1024, 512])
 def test_configs1_decode_step_logits_large_batch_vs_small_batch_and_oracle(llama3, B):
     """The decode step bench.py times (28 layers at Llama-3.2-3B width, bf16): B rows through the 256 x 128 streaming family
     (K = 3 072 / 8 192, N = 5 120 / 16 384 unsplit and 2-split forms, tiled lm_head, single-pass attention) against the SAME
@@ -519,3 +519,35 @@ def test_configs1_decode_step_logits_large_batch_vs_small_batch_and_oracle(llama
         assert e_big < FULL_TOL and e_small < FULL_TOL
         assert e_big < 1.5 * e_small + 5e-3
         assert apart < 3e-2
+
+
+def test_configs1_decode_step_tiled_gate_up_equals_streaming_form(llama3):
+    """Round-4 advisor: from ~900 rows the decode step runs gate/up on the row-major 256-tile kernel, fed by the o projection's
+    reduce pass (norm_out), instead of the gain-folded streaming form — a different kernel family and rounding order behind one
+    switch (SL_DECODE_TILED).  Both forms at 1 000 rows on the same sequences: logits within bf16 distance of each other, and the
+    greedy token of every row whose top-2 margin exceeds that distance is the same."""
+    from test_models_gpu import _decode_step_logits
+    L = pkg("_lib")
+    m = llama3
+    base = [ri.synthetic_waveform(n, seed=1234 + i).to(DEV) for i, n in enumerate((160000, 112000, 160000))]
+    x3, lens3, st3 = m.prompts(base)
+    prompts = [x3[st3[i]:st3[i + 1]].clone() for i in range(3)]
+    nxt = [101, 20202, 99999]
+    B = 1000
+    tiled = _decode_step_logits(m.llm, [prompts[b % 3] for b in range(B)], [nxt[b % 3] for b in range(B)])
+    os.environ["SL_DECODE_TILED"] = "0"
+    try:
+        L.lib().sl_tuning_reload()
+        stream = _decode_step_logits(m.llm, [prompts[b % 3] for b in range(B)], [nxt[b % 3] for b in range(B)])
+    finally:
+        del os.environ["SL_DECODE_TILED"]
+        L.lib().sl_tuning_reload()
+    for b in range(3, B):
+        assert torch.equal(tiled[b], tiled[b % 3]) and torch.equal(stream[b], stream[b % 3]), b
+    for i in range(3):
+        d = rel_err(tiled[i], stream[i])
+        print(f"sequence {i}: tiled vs streaming gate/up form {d:.2e}")
+        assert d < 3e-2
+        top2 = tiled[i].topk(2).values
+        if float(top2[0] - top2[1]) > 4 * float((tiled[i] - stream[i]).abs().max()):
+            assert int(tiled[i].argmax()) == int(stream[i].argmax()), i

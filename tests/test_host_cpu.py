@@ -377,7 +377,8 @@ def test_ctypes_struct_mirrors_match_the_c_header(tmp_path):
              ("sl_enc_layer_grads", L.EncLayerGrads), ("sl_llama_stack_cfg", L.LlamaStackCfg), ("sl_llama_train_layer", L.LlamaTrainLayer),
              ("sl_llama_layer_saved", L.LlamaLayerSaved), ("sl_adamw_tensor", L.AdamWTensor),
              ("sl_hubert_layer", L.HubertLayer), ("sl_hubert_fold", L.HubertFold), ("sl_hubert_model", L.HubertModel), ("sl_llama_layer", L.LlamaLayer),
-             ("sl_llama_model", L.LlamaModel), ("sl_kv_cache", L.KVCache)]
+             ("sl_llama_model", L.LlamaModel), ("sl_kv_cache", L.KVCache),
+             ("sl_generate_opts", L.GenerateOpts), ("sl_generate_stats", L.GenerateStats)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "speechllm.h")}"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -23,7 +23,7 @@ def med(d, counter, sub):
 fd, wd, B, out = sys.argv[1:5]
 res = {}
 detail = {}
-for key, subs in (("gemm", ["gemm_stream_kernel", "gemm_stream_wide_kernel"]), ("attn", ["attn_decode_full_kernel", "attn_decode_split_kernel", "attn_decode_combine_kernel"])):
+for key, subs in (("gemm", ["gemm_stream_kernel", "gemm_stream_wide_kernel", "gemm_tiled256p_kernel"]), ("attn", ["attn_decode_full_kernel", "attn_decode_split_kernel", "attn_decode_combine_kernel"])):
     tot = 0.0
     for sub in subs:   # whichever of the attention forms this batch dispatched to
         fk, n = med(fd, "FETCH_SIZE", sub)
