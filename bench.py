@@ -32,6 +32,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 PKG = "llm-speech-summarization_amd"
 
+RESULT_OUT = sys.stdout     # main() replaces it with a private copy of fd 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md)
 
@@ -596,7 +597,7 @@ def dry_rank(args, rank, world) -> None:
                           "n_gpus": int(os.environ.get("SL_BENCH_DRY_REPORT_GPUS", world)), "steps": done, "warmup": args.warmup,
                           "ms_per_step": float(tt.item()) * 1e3 / max(1, done), "dry_run": True,
                           "per_rank": [{"rank": int(r_[0]), "utterances": int(r_[1]), "audio_sec": r_[2], "tokens": int(r_[3]), "elapsed_s": r_[4]} for r_ in per_rank],
-                          "collective_backend": (dist.get_backend() if world > 1 else None), "kd_step": {"comm": comm}}), flush=True)
+                          "collective_backend": (dist.get_backend() if world > 1 else None), "kd_step": {"comm": comm}}), file=RESULT_OUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -628,6 +629,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))
+    # The result line is the ONLY thing on stdout: libraries that write to file descriptor 1 themselves (RCCL prints a version banner
+    # when a communicator comes up) are pointed at stderr for the life of the process; the line goes to a private copy of the descriptor.
+    global RESULT_OUT
+    sys.stdout.flush()
+    RESULT_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1073,7 +1080,7 @@ def main():
               f"device total {total_b / 2**30:.1f} GiB", file=sys.stderr, flush=True)
     except Exception:
         pass
-    print(json.dumps(result), flush=True)
+    print(json.dumps(result), file=RESULT_OUT, flush=True)
     leave()
 
 

@@ -54,6 +54,7 @@ static const SlEnv* env_load() {
   e.t256_min_tiles = env_int("SL_T256_MIN_TILES", 512);
   e.t256_min_k = env_int("SL_T256_MIN_K", 1024);
   e.t256_phased = env_int("SL_T256_PHASED", 1);
+  e.t256_by_rounds_pad = env_int("SL_T256_BY_ROUNDS_PAD", 1);
   e.decode_tiled = env_int("SL_DECODE_TILED", 1);
   e.stream_k = env_int("SL_STREAM_K", 1);
   e.skinny_alt = env_int("SL_SKINNY_ALT", 0);

@@ -210,6 +210,7 @@ struct SlEnv {
   int disable_t256;        // SL_DISABLE_T256
   int t256_min_tiles;      // SL_T256_MIN_TILES    (default 512)
   int t256_min_k;          // SL_T256_MIN_K        (default 1024)
+  int t256_by_rounds_pad;  // SL_T256_BY_ROUNDS_PAD 1 (default) = a product chosen for the 256-tile kernel by whole rounds of tiles may pad its rows to 256 freely (634 rows -> 768), 0 = round-4 rule (<= 1/8 more rows than the 128-row padding)
   int t256_phased;         // SL_T256_PHASED       1 (default) = the 256-tile GEMM runs the staggered two-phase main loop, 0 = the round-3 one-barrier-per-slab loop (A/B)
   int disable_glds;        // SL_DISABLE_GLDS      0 / 1 / 2
   int direct_epilogue;     // SL_DIRECT_EPILOGUE

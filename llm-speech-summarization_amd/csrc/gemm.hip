@@ -1634,7 +1634,11 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
       const int64_t r256 = (t256 + 255) / 256, r128 = (t128 + 511) / 512;
       by_rounds = (double)r256 * (XBM * XBN) * 0.85 < (double)r128 * 2.0 * (TBM * TBN);
     }
-    if ((t256 >= min_tiles || by_rounds) && p.N >= 192 && p.K >= min_k && m256 <= m128 + m128 / 8) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
+    // rows padded to 256: the whole-rounds comparison above already prices the padding (it counts TILES), so a product it picks may pad
+    // freely — 634 x 16 384 x 3 072 (the per-rank KD window) is 192 big tiles = one round against 640 small ones = two; only products
+    // admitted by their tile count alone (grouped / batched: the 123-row projector) keep the 1/8 bound
+    const bool pad_ok = m256 <= m128 + m128 / 8 || (by_rounds && sl_env().t256_by_rounds_pad);
+    if ((t256 >= min_tiles || by_rounds) && p.N >= 192 && p.K >= min_k && pad_ok) {   // 1024: with the row epilogue the big tile also wins at K = 1024..1536 (+10..20 %)
       p.tiles_m = (p.M + XBM - 1) / XBM;
       p.tiles_n = (p.N + XBN - 1) / XBN;
       const int phased = sl_env().t256_phased;   // 0: round-3 one-barrier-per-slab loop (A/B)

@@ -107,7 +107,9 @@ def test_weak_scaling_mode_per_rank_accum(tmp_path):
             assert (num / den) ** 0.5 < GRAD_TOL, (s, r["rank"], (num / den) ** 0.5)
     for k in one["master"]:
         assert torch.equal(two[0]["master"][k], two[1]["master"][k]), k
-        if not k.endswith("k_proj.bias"):
+        if k.endswith("k_proj.bias"):      # zero true gradient: bounded drift (2 optimizer steps x lr per element), see the test above
+            assert float((two[0]["master"][k] - one["master"][k]).abs().max()) <= 2 * 5e-5 * 1.001, k
+        else:
             assert rel_err(two[0]["master"][k], one["master"][k]) < MASTER_TOL, k
     (solo,) = _run(1, str(tmp_path), n_rows, 4, port + 2, extra_env={"DP_PER_RANK_ACCUM": "8"}, tag="_weak_solo")
     assert [len(w) for w in solo["windows"]] == [8, 8, 1] and solo["optimizer_steps"] == 3
@@ -127,8 +129,9 @@ def test_ranks_that_start_from_different_weights_are_brought_to_rank0s(tmp_path)
         assert torch.equal(a, b)
     for k in base[0]["master"]:
         assert torch.equal(pert[0]["master"][k], pert[1]["master"][k]), k
-        if k.endswith("k_proj.bias"):
-            continue                     # zero true gradient: AdamW amplifies run-to-run summation noise (see the test above)
+        if k.endswith("k_proj.bias"):    # zero true gradient: AdamW turns run-to-run summation noise into +-lr per step — bounded, not skipped
+            assert float((pert[0]["master"][k] - base[0]["master"][k]).abs().max()) <= 2 * 5e-5 * 1.001, k
+            continue
         assert rel_err(pert[0]["master"][k], base[0]["master"][k]) < MASTER_TOL, k
 
 
@@ -204,8 +207,10 @@ def test_sl_comm_c_abi_one_rank_communicator_orders_against_the_compute_stream()
     torch.cuda.synchronize()
     L.check(lib.sl_comm_destroy(comm), "sl_comm_destroy")
     # local tear-down (ABI 6): what a rank does with a communicator the group voted to abandon
+    ident2 = (C.c_ubyte * L.COMM_ID_BYTES)()          # an id names ONE communicator: a second one needs its own
+    L.check(lib.sl_comm_unique_id(ident2), "sl_comm_unique_id")
     comm2 = C.c_void_p()
-    L.check(lib.sl_comm_init(C.byref(comm2), ident, 0, 1), "sl_comm_init")
+    L.check(lib.sl_comm_init(C.byref(comm2), ident2, 0, 1), "sl_comm_init")
     L.check(lib.sl_comm_abort(comm2), "sl_comm_abort")
     assert lib.sl_comm_abort(None) == 0
 

@@ -296,7 +296,7 @@ def test_llama_shared_prompt_prefix_is_read_from_slot_zero_with_unchanged_bits(d
     assert na == nb and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("B", [40, 72, 130, 260])
+@pytest.mark.parametrize("B", [40, 72, 130, 260, 1100, 2048])      # 2048 = SL_MAX_DECODE_BATCH
 def test_llama_large_batch_decode_equals_single(B):
     """Batches above 26 rows decode through gemm_stream.hip (loader wave, K-split + reduce, RMSNorm scales handed down the
     chain); every sequence must still produce exactly the ids it produces alone (fp32: bit-exact vs the oracle)."""
@@ -312,6 +312,9 @@ def test_llama_large_batch_decode_equals_single(B):
         r = refs[b % 5]
         assert torch.equal(ids[b, :r.shape[0]], r), b
         assert bool((ids[b, r.shape[0]:] == cfg.pad_token_id).all())
+    if B == 2048:       # one more sequence than a generate call takes: refused with the instruction to split (the inference surface chunks)
+        with pytest.raises(pkg("_lib").SpeechLLMError):
+            llm.generate(inputs_embeds=[base[b % 5].to(DEV) for b in range(B + 1)], max_new_tokens=4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -5,7 +5,8 @@ rounds; every variant's result is checked against the fp32 product first.
 
     python tools/gemm_vs_vendor.py [--rounds 5] [--quick]
 
-Variants: r3 = round-3 loop (SL_T256_PHASED=0), p = staggered two-phase loop (default), vendor."""
+Variants: r3 = round-3 loop (SL_T256_PHASED=0), p = staggered two-phase loop (default), pad0 = p with round 4's padding bound
+on the whole-rounds tile choice (SL_T256_BY_ROUNDS_PAD=0), vendor."""
 import argparse, importlib, os, statistics, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("llm-speech-summarization_amd.ops")
@@ -23,6 +24,9 @@ for M in (7984, 3200, 5072, 1872):
     for N, K in (((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)) if enc else ((5120, 3072), (3072, 3072), (16384, 3072), (3072, 8192))):
         shapes.append((M, N, K))
 shapes += [(3200, 3072, 1024), (3200, 4096, 1024), (3200, 1024, 4096)]
+# the per-rank KD window (2 samples: 634 LLM rows, 998 encoder frames) and the decode rows
+shapes += [(634, 5120, 3072), (634, 3072, 3072), (634, 16384, 3072), (634, 3072, 8192), (634, 8192, 3072), (634, 3072, 16384),
+           (998, 3072, 1024), (998, 4096, 1024), (998, 1024, 4096), (2048, 5120, 3072), (2048, 3072, 3072), (2048, 16384, 3072), (2048, 3072, 8192)]
 big = [(127744, 3072, 1024), (127744, 1024, 1024), (127744, 4096, 1024), (127744, 1024, 4096), (140288, 5120, 3072), (140288, 3072, 8192),
        (70144, 16384, 3072)]
 if args.quick:
@@ -35,7 +39,8 @@ variants = args.variants.split(",")
 def set_variant(v):
     if v == "vendor":
         return
-    os.environ["SL_T256_PHASED"] = {"r3": "0", "p": "1"}[v]
+    os.environ["SL_T256_PHASED"] = {"r3": "0", "p": "1", "pad0": "1"}[v]
+    os.environ["SL_T256_BY_ROUNDS_PAD"] = "0" if v == "pad0" else "1"      # pad0 = round 4's row-padding bound on the whole-rounds choice
     L.lib().sl_tuning_reload()
 
 
@@ -77,4 +82,5 @@ for M, N, K in shapes:
     print(f"{M:7d} x {N:6d} x {K:5d}  " + "".join(f"{tf[v]:9.0f}" for v in variants) + f"   {ratio:6.3f}", flush=True)
 print(f"worst p/vendor ratio: {worst:.3f}")
 os.environ.pop("SL_T256_PHASED", None)
+os.environ.pop("SL_T256_BY_ROUNDS_PAD", None)
 L.lib().sl_tuning_reload()
