@@ -217,6 +217,7 @@ struct SlEnv {
   int gemm_gm;             // SL_GEMM_GM           (default 8)
   int attn_full_min;       // SL_ATTN_FULL_MIN     (default 32)
   int attn_force_split;    // SL_ATTN_FORCE_SPLIT
+  int attn_decode_ks;      // SL_ATTN_DECODE_KS    keys per chunk of the single-pass decode attention: 128 (default) or 64 (a block small enough to share a CU with a 256-tile GEMM block of another stream)
   int attn_split_merge;    // SL_ATTN_SPLIT_MERGE    split attention merges its partial records inside the split launch: -1 (default) = where B * n_kv <= 32, 0 = never, 1 = always
   int attn_generic;        // SL_ATTN_GENERIC
   int attn_qt;             // SL_ATTN_QT

@@ -922,13 +922,18 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const T* __restr
 // Four blocks per CU (query fragments and a shared zero row in LDS: 128 VGPRs + 16 B of scratch, 36 KiB) would make 4096 blocks exactly
 // four rounds instead of 5.33 on 768 slots, but measured 117 us: the extra LDS reads per MFMA and the fourth block's traffic cost more
 // than the idle third of the last round.
-template <int REP, bool PREFETCH>
+// KS_ = keys per chunk.  128 (default): the measurements above.  64: 19.4 KiB of LDS and ~100 VGPRs per block instead of 38 KiB / 138 —
+// small enough to sit on a CU BESIDE a 256 x 256 GEMM block of another stream (130 of the 160 KiB of LDS, half the register file):
+// the HBM-bound attention of one in-flight batch can then run under the matrix-core-bound encode / prefill of the other
+// (SL_ATTN_DECODE_KS=64; DESIGN §8.10 has what it measured).
+template <int REP, bool PREFETCH, int KS_ = 128>
 __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __restrict__ q, int64_t q_stride, const bf16_t* __restrict__ kc,
                                                                const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
                                                                const int32_t* __restrict__ ctx_len, int ctx_add, int nh, int nkv, int max_ctx,
                                                                float scale, int shared_prefix) {
   using T = bf16_t;
-  constexpr int D = 128, KS = 128, NPS = KS / 16;
+  constexpr int D = 128, KS = KS_, NPS = KS / 16;
+  static_assert(KS == 64 || KS == 128, "chunks of 64 or 128 keys");
   constexpr int PROW = KS * 2 + 16;
   __shared__ float sc[REP][KS];
   __shared__ float alpha[4], linv[4];
@@ -1013,14 +1018,14 @@ __global__ __launch_bounds__(256) void attn_decode_full_kernel(const bf16_t* __r
       __syncthreads();
       // online softmax: wave h owns head h (two keys per lane); P rounded to bf16 as HF eager does
       if (wave < REP) {
-        const float s0 = sc[wave][lane], s1 = sc[wave][lane + 64];
+        const float s0 = sc[wave][lane], s1 = KS == 128 ? sc[wave][(lane + 64) & (KS - 1)] : -INFINITY;
         const float m_new = fmaxf(m_run, wave_max(fmaxf(s0, s1)));   // finite: key k0 is inside the context
-        const float p0 = __expf(s0 - m_new), p1 = __expf(s1 - m_new);
+        const float p0 = __expf(s0 - m_new), p1 = KS == 128 ? __expf(s1 - m_new) : 0.f;
         const float a = __expf(m_run - m_new);                        // first chunk: exp(-inf) = 0
         l_run = l_run * a + wave_sum(p0 + p1);
         m_run = m_new;
         *(T*)(pt + wave * PROW + lane * 2) = from_f32<T>(p0);
-        *(T*)(pt + wave * PROW + (lane + 64) * 2) = from_f32<T>(p1);
+        if constexpr (KS == 128) *(T*)(pt + wave * PROW + (lane + 64) * 2) = from_f32<T>(p1);
         if (lane == 0) alpha[wave] = a;
       }
       // V tile over the (dead) K tile
@@ -1107,8 +1112,12 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
     // per step at 16 sequences, 709 vs 743 ms for the Whisper leg's 32 sequences)
     const bool long_thin = max_ctx >= 1024 && (int64_t)B * nkv < 768;
     if ((int64_t)B * nkv >= full_min && !long_thin && !sl_env().attn_force_split) {
-      hipLaunchKernelGGL((attn_decode_full_kernel<REP, false>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
-                         (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale, shared_prefix);
+      if (sl_env().attn_decode_ks == 64)
+        hipLaunchKernelGGL((attn_decode_full_kernel<REP, false, 64>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
+                           (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale, shared_prefix);
+      else
+        hipLaunchKernelGGL((attn_decode_full_kernel<REP, false>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
+                           (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale, shared_prefix);
       SL_CHECK_LAUNCH("attn_decode_full");
       return 0;
     }

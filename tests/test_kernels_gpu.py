@@ -660,6 +660,29 @@ def test_attn_decode_split_in_launch_merge_equals_combine_launch(dt, tuning):
         assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("nh,nkv", [(24, 8), (6, 2), (2, 2), (4, 1)])
+def test_attn_decode_single_pass_64_key_chunks_equal_128_key_chunks(nh, nkv, tuning):
+    """SL_ATTN_DECODE_KS=64: the single-pass bf16 decode attention with 64-key chunks (a block of 19 KiB of LDS / ~116 VGPRs that can share
+    a CU with a 256-tile GEMM block of another stream) against the default 128-key form and the reference, contexts from 1 key to the
+    whole cache, with and without a shared prompt prefix."""
+    dt = torch.bfloat16
+    D, max_ctx, B = 128, 448, 64
+    lens = [1 + (53 * i) % max_ctx for i in range(B)]
+    lens[:8] = [1, 63, 64, 65, 127, 128, 129, 448]
+    kc = rnd(B, nkv, max_ctx, D, seed=60).to(dev(), dt)
+    vc = rnd(B, nkv, max_ctx, D, seed=61).to(dev(), dt)
+    qd = rnd(B, nh * D, seed=62).to(dev(), dt)
+    ctx = torch.tensor(lens, dtype=torch.int32, device=dev())
+    ref128 = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    tuning("SL_ATTN_DECODE_KS", "64")
+    out64 = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+    assert rel_err(out64, ref128) < 4e-3          # same products, online-softmax rescale points differ
+    for s in list(range(8)) + [31, 63]:
+        n = lens[s]
+        ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
+        assert rel_err(out64[s], ref[0]) < TOL[dt], s
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_attn_decode_long_cache_mid_batch(dt):
     """16 sequences against a 2 048-position cache (the long-form leg of bench.py): the dispatcher leaves the single-pass kernel for the
