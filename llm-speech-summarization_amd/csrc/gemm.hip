@@ -1596,9 +1596,66 @@ static int sk_grid(const GemmP& p, int batch, int bk, size_t ws_bytes) {
   return (nt * 8 <= cus && nkt >= 128) ? G : 0;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Plain split-K for products of FEW tiles (round 5): the per-rank KD window (634 LLM rows) has N = 3 072 products of 36 big / 120
+// small tiles under K = 3 072 ... 16 384 — a third of the chip busy (634 x 3 072 x 8 192: 425 TF/s against the vendor library's 729,
+// x 16 384: 294 against 672; profiles/r05_b_gemm_vs_vendor_pad_rule.txt).  The reduction is cut into S equal runs of whole slabs and
+// the S partial products run as ONE BATCHED launch of the ordinary tiled kernels (batch index = K run: A and W advance by K / S
+// columns, fp32 partial tiles go to the caller's workspace), so blocks of a run still share their slabs in L2 — which the stream-K form
+// above gives up — and a second launch adds the runs in run order and applies bias / residual / rounding: deterministic, no atomics.
+// Costs S x M x N x 4 bytes written and read back, which is why it is for few tiles only.
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t slab, GemmP p) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (int64_t)p.M * p.N) return;
+  const int64_t row = i / p.N;
+  const int col = (int)(i - row * p.N);          // N % 4 == 0 (admission): the four values are one row's
+  f32x4 acc = *(const f32x4*)(part + i);
+  for (int z = 1; z < S; ++z) {
+    const f32x4 v = *(const f32x4*)(part + (int64_t)z * slab + i);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = acc[e];
+    if (p.bias) v += to_f32(((const T*)p.bias)[col + e]);
+    store_out<T>(p, p.C, p.res, row, col + e, v);
+  }
+}
+
+static int splitk_runs(const GemmP& p, int batch, int bk, size_t ws_bytes) {
+  if (!sl_env().split_k || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.N < 128 || (p.N & 3)) return 0;
+  const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+  const int nkt = p.K / bk;
+  if (t128 > 200 || nkt < 32) return 0;          // from ~200 small tiles the chip is busy enough (two blocks per CU: 512 slots); short reductions
+  int S = (int)(512 / t128);
+  if (S > 8) S = 8;
+  if (S > nkt / 12) S = nkt / 12;                // every run keeps >= 12 slabs (768 k) behind its prologue
+  while (S > 1 && (nkt % S || (size_t)S * p.M * p.N * sizeof(float) > ws_bytes)) --S;
+  return S >= 2 ? S : 0;
+}
+
 template <typename T, int ACT>
 static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
   constexpr int BK_ = TROWB / (int)sizeof(T);
+  if constexpr (ACT == SL_ACT_NONE) {
+    if (sk_ws) {
+      const int S = splitk_runs(p, batch, BK_, sk_ws_bytes > SK_FLAG_BYTES ? sk_ws_bytes - SK_FLAG_BYTES : 0);
+      if (S) {
+        float* part = (float*)((unsigned char*)sk_ws + SK_FLAG_BYTES);      // behind the stream-K flags (which stay zero)
+        GemmP q = p;
+        q.K = p.K / S; q.sA = q.K; q.sW = q.K;                                // run z reads columns [z K/S, (z+1) K/S) of A and W
+        q.C = part; q.ldc = p.N; q.sC = (int64_t)p.M * p.N; q.out_f32 = 1;
+        q.bias = nullptr; q.sBias = 0; q.res = nullptr; q.ldr = 0; q.sR = 0; q.res_f32 = 0;
+        SL_TRY((launch_tiled<T, SL_ACT_NONE>(q, S, st)));
+        const int64_t vecs = ((int64_t)p.M * p.N + 3) / 4;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, part, S, (int64_t)p.M * p.N, p);
+        SL_CHECK_LAUNCH("splitk_reduce");
+        return 0;
+      }
+    }
+  }
   if (sk_ws) {
     const int G = sk_grid(p, batch, BK_, sk_ws_bytes);
     if (G) {

@@ -369,6 +369,7 @@ extern "C" int sl_llama_stack_train_fwd(const sl_llama_train_layer* layers, cons
   const int qkv_w = (nh + 2 * nkv) * D, att_w = nh * D;
   const int64_t n = c->n_tok;
   const float scale = 1.0f / sqrtf((float)D);
+  SL_HIP(hipMemsetAsync(w.sk, 0, 1024, st));        // the stream-K flags (gemm.hip): zero whenever no launch is in flight
   for (int l = 0; l < c->n_layers; ++l) {
     const sl_llama_train_layer& L = layers[l];
     const void* x = hidden[l];
@@ -382,14 +383,15 @@ extern "C" int sl_llama_stack_train_fwd(const sl_llama_train_layer* layers, cons
     float* lse = saved ? saved[l].lse : nullptr;
     SL_CHECK_ARG(qkv && x2 && gu && att && (!saved || lse), "sl_llama_stack_train_fwd: layer %d lacks a saved buffer", l);
     SL_TRY(sl_rmsnorm(x, w.h, L.norm1, n, H, c->rms_eps, dt, stream));
-    SL_TRY(gemm(dt, w.h, H, L.wqkv, H, qkv, qkv_w, nullptr, nullptr, 0, n, qkv_w, H, SL_ACT_NONE, nullptr, st));
+    // w.sk: products of few tiles (the per-rank window of a data-parallel run: a few hundred rows) are cut along K (gemm.hip splitk_runs)
+    SL_TRY(gemm(dt, w.h, H, L.wqkv, H, qkv, qkv_w, nullptr, nullptr, 0, n, qkv_w, H, SL_ACT_NONE, nullptr, st, w.sk));
     SL_TRY(sl_rope_inplace(qkv, c->pos, c->rope_cos, c->rope_sin, n, nh + 2 * nkv, nh + nkv, D, 0, dt, stream));
     SL_TRY(attn_fwd(dt, qkv, qkv_w, att, lse, c->cu, c->klen, c->nseq, c->max_len, nh, nkv, D, 1, scale, 0.f, 0, st));
-    SL_TRY(gemm(dt, att, att_w, L.wo, att_w, x2, H, nullptr, x, H, n, H, att_w, SL_ACT_NONE, nullptr, st));
+    SL_TRY(gemm(dt, att, att_w, L.wo, att_w, x2, H, nullptr, x, H, n, H, att_w, SL_ACT_NONE, nullptr, st, w.sk));
     SL_TRY(sl_rmsnorm(x2, w.h, L.norm2, n, H, c->rms_eps, dt, stream));
     SL_TRY(gemm(dt, w.h, H, L.wgu, H, gu, 2 * F, nullptr, nullptr, 0, n, 2 * F, H, SL_ACT_NONE, nullptr, st));   // interleaved gate/up pre-activations
     SL_TRY(sl_silu_mul(gu, w.mid, n, F, dt, stream));
-    SL_TRY(gemm(dt, w.mid, F, L.wdown, F, x_next, H, nullptr, x2, H, n, H, F, SL_ACT_NONE, nullptr, st));
+    SL_TRY(gemm(dt, w.mid, F, L.wdown, F, x_next, H, nullptr, x2, H, n, H, F, SL_ACT_NONE, nullptr, st, w.sk));
   }
   return 0;
 }
@@ -419,11 +421,11 @@ extern "C" int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, cons
     SL_TRY(sl_rmsnorm_bwd(sv.x2, L.norm2, w.d_h, w.dx2, n, H, c->rms_eps, dt, stream));
     SL_TRY(sl_axpby(dx, w.dx2, 1.f, 1.f, n * H, dt, stream));                       // residual join
     // x2 = x + wo . attn(rope(wqkv . rmsnorm(x)))
-    SL_TRY(dgrad(dt, w.dx2, H, L.wo, H, att_w, L.wo_t, w.d_att, att_w, n, w.s, st));
+    SL_TRY(dgrad(dt, w.dx2, H, L.wo, H, att_w, L.wo_t, w.d_att, att_w, n, w.s, st, w.sk));
     SL_TRY(attn_bwd(dt, sv.qkv, qkv_w, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nkv, D, 1, scale, 0.f, 0,
                     st));
     SL_TRY(sl_rope_inplace(w.d_qkv, c->pos, c->rope_cos, c->rope_sin, n, nh + 2 * nkv, nh + nkv, D, 1, dt, stream));
-    SL_TRY(dgrad(dt, w.d_qkv, qkv_w, L.wqkv, qkv_w, H, L.wqkv_t, w.d_h, H, n, w.s, st));
+    SL_TRY(dgrad(dt, w.d_qkv, qkv_w, L.wqkv, qkv_w, H, L.wqkv_t, w.d_h, H, n, w.s, st, w.sk));
     SL_TRY(sl_rmsnorm_bwd(hidden[l], L.norm1, w.d_h, dx, n, H, c->rms_eps, dt, stream));
     SL_TRY(sl_axpby(w.dx2, dx, 1.f, 1.f, n * H, dt, stream));
     if (d_tap && d_tap[l]) SL_TRY(sl_axpby(d_tap[l], dx, 1.f, 1.f, n * H, dt, stream));     // feature-distillation gradient of hidden_states[l]

@@ -926,14 +926,19 @@ def test_gemm_swapped_operand_epilogue_equals_lds_turned_rows_epilogue(M, N, K, 
     assert torch.equal(swapped[5], swapped[1]) and torch.equal(swapped[6], swapped[0])        # GELU output / pre-activation = the bias-only product
 
 
+@pytest.mark.parametrize("form", ["streamk", "splitk"])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("M,N,K", [(400, 3072, 16384), (634, 1000, 2048), (1300, 520, 4096), (257, 256, 8192), (3200, 3072, 1024)])
-def test_gemm_stream_k_equals_the_tile_kernel_product(M, N, K, dt, tuning):
+@pytest.mark.parametrize("M,N,K", [(400, 3072, 16384), (634, 1000, 2048), (1300, 520, 4096), (257, 256, 8192), (3200, 3072, 1024), (634, 3072, 8192),
+                                   (634, 3072, 3072), (1024, 1024, 8000), (634, 5120, 3072)])
+def test_gemm_stream_k_equals_the_tile_kernel_product(M, N, K, dt, form, tuning):
     """Stream-K form of the 256-tile GEMM (sl_gemm_ex_args.sk_ws): every CU takes an equal run of (tile, K slab) units, tiles cut
     between blocks are summed through the workspace inside the launch.  Forced on (SL_STREAM_K=2) over ragged M / N edges, tiles
     split two to five ways, whole tiles inside a block's run, bf16 (register epilogue and, with an odd N, the LDS-turned one) and
     fp32, plain / + residual / fp32 accumulation; repeated launches on one workspace (flags are cleared by their consumers).
-    Against the fp32 product, and against the one-block-per-tile result within a few fp32 ulps of re-association."""
+    Against the fp32 product, and against the one-block-per-tile result within a few fp32 ulps of re-association.
+    form = splitk (round 5, the default where a workspace is given and the product has few tiles): S equal K runs as one batched launch
+    of the ordinary tile kernels + a reduce launch that adds the runs in run order (634 x 3 072 x 8 192: 4 runs; x 3 072: 4; 1 024 x 1 024
+    x 8 000: 5; 634 x 5 120 x 3 072: 2) — same checks, and bitwise the same result launch after launch."""
     if dt == torch.float32 and M * N * K > 3e10:
         pytest.skip("fp32 MFMA at this size adds nothing")
     A, W, R = rnd(M, K, seed=191), rnd(N, K, seed=192, std=K ** -0.5), rnd(M, N, seed=193)
@@ -950,9 +955,14 @@ def test_gemm_stream_k_equals_the_tile_kernel_product(M, N, K, dt, tuning):
         return o1, o2, o3
 
     tile = run(False)
-    tuning("SL_STREAM_K", "2")
+    tuning("SL_STREAM_K", "2" if form == "streamk" else "0")
+    tuning("SL_SPLIT_K", "0" if form == "streamk" else "1")
+    first = None
     for rep in range(3):
         sk = run(True)
+        if first is None:
+            first = [t_.clone() for t_ in sk]
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(sk, first))          # fixed summation order: reproducible bit for bit
         ref = q(A, dt) @ q(W, dt).T
         assert rel_err(sk[0].float().cpu(), ref) < TOL[dt]
         assert rel_err(sk[1].float().cpu(), ref + q(R, dt)) < TOL[dt]

@@ -36,9 +36,24 @@ shapes = big + shapes
 variants = args.variants.split(",")
 
 
+SK = None
+
+
+def our_gemm(A, W, out, v):
+    """ops.gemm, or (variant sk) the same product with the split-K / stream-K workspace a KD tape passes (sl_gemm_ex_args.sk_ws)"""
+    global SK
+    if v != "sk":
+        return ops.gemm(A, W, out=out)
+    if SK is None:
+        SK = ops.streamk_workspace(A.device)
+    return ops.gemm_ex(A, W, M=A.shape[0], N=W.shape[0], K=A.shape[1], lda=A.stride(0), ldw=W.stride(0), out=out, sk_ws=SK)
+
+
 def set_variant(v):
     if v == "vendor":
         return
+    if v == "sk":
+        v = "p"
     os.environ["SL_T256_PHASED"] = {"r3": "0", "p": "1", "pad0": "1"}[v]
     os.environ["SL_T256_BY_ROUNDS_PAD"] = "0" if v == "pad0" else "1"      # pad0 = round 4's row-padding bound on the whole-rounds choice
     L.lib().sl_tuning_reload()
@@ -58,7 +73,7 @@ for M, N, K in shapes:
             continue
         set_variant(v)
         out.zero_()
-        ops.gemm(A, Ws[0], out=out)
+        our_gemm(A, Ws[0], out, v)
         err = float((out[idx].float() - ref).norm() / ref.norm())
         assert err < 6e-3, (M, N, K, v, err)
     n = 6 if M * N * K > 3e11 else 16
@@ -66,7 +81,7 @@ for M, N, K in shapes:
     for rnd in range(args.rounds + 1):
         for v in variants:
             set_variant(v)
-            fn = (lambda i: torch.nn.functional.linear(A, Ws[i % 3])) if v == "vendor" else (lambda i: ops.gemm(A, Ws[i % 3], out=out))
+            fn = (lambda i: torch.nn.functional.linear(A, Ws[i % 3])) if v == "vendor" else (lambda i, v=v: our_gemm(A, Ws[i % 3], out, v))
             fn(0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
