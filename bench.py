@@ -301,6 +301,10 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
                  "predicted_samples_per_s_at_world": [round(ranks * k_ / ((win_ms + e * f) * 1e-3), 1) for e, f in ((ex_ms[0], 0.0), (ex_ms[1], 1.0))],
                  "note": f"one GPU running the per-rank share of a {ranks}-rank step: window of {k_} samples + AdamW + weight refresh; exchange "
                          "estimated, not measured (bus bandwidth 350 / 250 GB/s); prediction = fully overlapped / not overlapped at all"}
+    try:
+        tr.close()          # collective tear-down of the exchange's communicator (every rank reaches this point or the leg has failed)
+    except Exception:       # noqa: BLE001 — the figures above stand
+        pass
     return {"samples_per_s": round(n_micro * world / dt_, 3), "ms_per_micro_step": round(dt_ / n_micro * 1e3, 2),
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                          "algorithmic_flops_per_sample": round(flops), "seq_audio": S_a, "seq_text": S_t,

@@ -183,6 +183,7 @@ struct EncWs {
   float* delta;
   void* ln_ws;         // per-block dgamma / dbeta records of the LayerNorm backward (sl_layernorm_bwd_ws)
   size_t ln_ws_bytes;
+  void* sk;            // split-K workspace of the few-tile products of a short window (main-stream products only)
   BwdScratch s;
 };
 
@@ -205,6 +206,9 @@ static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs
   w.s.yt = cv.take(big * Mp * sz);
   w.s.xt = cv.take(big * Mp * sz);
   w.s.wt = cv.take(big * (big + 8) * sz);
+  // a short window only (the per-rank share of a data-parallel step: ~1 000 frames): there FFN2 and the data gradients under K = 3 072 / 4 096
+  // are 64 tiles on 256 CUs, and everything runs on one stream (SideStream::init), so one workspace serves the whole call
+  w.sk = n < 2048 ? cv.take(sl_gemm_streamk_workspace_bytes()) : nullptr;
   return cv.off + 256;
 }
 
@@ -223,6 +227,7 @@ extern "C" int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const s
   const int dt = c->dtype, H = c->hidden, F = c->ffn, nh = c->n_heads;
   const int64_t n = c->n_tok;
   const void* x = x_in;
+  if (w.sk) SL_HIP(hipMemsetAsync(w.sk, 0, 1024, st));      // stream-K flags: zero whenever no launch is in flight
   for (int l = 0; l < c->n_layers; ++l) {
     sl_enc_layer_saved& sv = saved[l];
     sv.x = x;
@@ -243,10 +248,10 @@ extern "C" int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const s
     SL_TRY(gemm(dt, sv.ln2, H, L.w1, H, sv.mid, F, L.b1, nullptr, 0, n, F, H, SL_ACT_GELU, sv.pre1, st));
     if (c->p_act > 0.f) SL_TRY(sl_dropout(sv.mid, nullptr, sv.mid, n * F, c->p_act, sd[2], dt, stream));
     if (c->p_hidden > 0.f) {               // h = h + output_dropout(output_dense(...))
-      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, w.tmp_h, H, L.b2, nullptr, 0, n, H, F, SL_ACT_NONE, nullptr, st));
+      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, w.tmp_h, H, L.b2, nullptr, 0, n, H, F, SL_ACT_NONE, nullptr, st, w.sk));
       SL_TRY(sl_dropout(w.tmp_h, sv.x_mid, sv.x_out, n * H, c->p_hidden, sd[3], dt, stream));
     } else {
-      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, sv.x_out, H, L.b2, sv.x_mid, H, n, H, F, SL_ACT_NONE, nullptr, st));
+      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, sv.x_out, H, L.b2, sv.x_mid, H, n, H, F, SL_ACT_NONE, nullptr, st, w.sk));
     }
     x = sv.x_out;
   }
@@ -268,6 +273,8 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   SideStream ss;
   SL_TRY(ss.init(st, n));
   hipStream_t sw = st;           // where the current parameter-gradient group runs
+  void* sk = ss.on ? nullptr : w.sk;                           // split-K workspace: only when every product of the call is on `st`
+  if (sk) SL_HIP(hipMemsetAsync(sk, 0, 1024, st));
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     if (c->skip[l]) continue;
     const sl_hubert_layer& L = layers[l];
@@ -290,7 +297,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw));
     SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, (sl_stream)sw));
     SL_TRY(ss.end(1));
-    SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st));
+    SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
     SL_TRY(sl_layernorm_bwd_ws(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));   // d_h2 = d x_mid (LN path)
     SL_TRY(sl_axpby(dx, w.d_h2, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
@@ -309,7 +316,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw));
     SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, (sl_stream)sw));
     SL_TRY(ss.end(3));
-    SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st));
+    SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));
     SL_TRY(sl_layernorm_bwd_ws(sv.x, L.ln1_g, L.ln1_b, w.d_h1, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));            // dx = d x (LN path)
     SL_TRY(sl_axpby(w.d_h2, dx, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
     (void)sz;
