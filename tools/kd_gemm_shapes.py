@@ -21,7 +21,8 @@ if os.environ.get("KD_SHAPES_CHILD") == "1":
     g = torch.Generator().manual_seed(99)
     text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g); resp_ids = torch.randint(1, larch.vocab_size, (64,), generator=g)
     wave = ri.synthetic_waveform(160000, seed=4321).to(dev)
-    B = tr.local_accum
+    B = int(os.environ.get("KD_WINDOW", tr.local_accum))      # KD_WINDOW=2: the per-rank share of an 8-rank step
+    tr.local_accum = B
     args = ([wave] * B, [text_ids] * B, [resp_ids] * B)
     for _ in range(2):
         tr.micro_batch(*args)
