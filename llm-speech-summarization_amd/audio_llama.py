@@ -127,7 +127,8 @@ class AudioLlamaForCausalLM:
     # -- buffers --------------------------------------------------------------------------------
     def _kv_cache(self, slots: int, shared_prefix: int = 0):
         a = self.arch
-        if self._kv is None or self._kv[0].shape[1] < slots:
+        if self._kv is None or self._kv[0].shape[1] < slots or self._kv[0].shape[3] != self.max_ctx:
+            self._kv = None        # release the smaller cache BEFORE the larger one is allocated (2 048 slots x 448 positions of Llama-3.2-3B: 105 GB)
             shape = (a.num_hidden_layers, slots, a.num_key_value_heads, self.max_ctx, a.head_dim)
             k = torch.zeros(shape, device=self.device, dtype=self.dtype)
             v = torch.zeros(shape, device=self.device, dtype=self.dtype)

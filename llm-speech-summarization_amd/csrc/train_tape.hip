@@ -62,8 +62,9 @@ int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_i
 }
 
 // dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in)       (ops.wgrad_acc, plain Linear)
+// sk_ws: split-K workspace OF THE STREAM `st` (few output tiles under thousands of token rows: the 1 024 x 1 024 out_proj gradient)
 int wgrad_acc(int dt, const void* dY, int64_t ldy, int n_out, const void* X, int64_t ldx, int k_in, float* dW, int64_t M, const BwdScratch& s,
-              hipStream_t st) {
+              hipStream_t st, void* sk_ws = nullptr) {
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
   sl_gemm_ex_args ex;
@@ -76,6 +77,7 @@ int wgrad_acc(int dt, const void* dY, int64_t ldy, int n_out, const void* X, int
     SL_TRY(sl_transpose_pad(dY, ldy, s.yt, Mp, (int)M, n_out, (int)Mp, dt, (sl_stream)st));
     SL_TRY(sl_transpose_pad(X, ldx, s.xt, Mp, (int)M, k_in, (int)Mp, dt, (sl_stream)st));
     a.A = s.yt; a.lda = Mp; a.W = s.xt; a.ldw = Mp; a.K = (int)Mp;
+    if (sk_ws) { ex.sk_ws = sk_ws; ex.sk_ws_bytes = sl_gemm_streamk_workspace_bytes(); }
     return sl_gemm_ex(&a, &ex, (sl_stream)st);
   }
   ex.trans_a = 1; ex.trans_w = 1;
@@ -184,6 +186,7 @@ struct EncWs {
   void* ln_ws;         // per-block dgamma / dbeta records of the LayerNorm backward (sl_layernorm_bwd_ws)
   size_t ln_ws_bytes;
   void* sk;            // split-K workspace of the few-tile products of a short window (main-stream products only)
+  void* sk_w;          // ... of the parameter-gradient group's stream (the side stream of a long window, else the caller's)
   BwdScratch s;
 };
 
@@ -209,6 +212,7 @@ static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs
   // a short window only (the per-rank share of a data-parallel step: ~1 000 frames): there FFN2 and the data gradients under K = 3 072 / 4 096
   // are 64 tiles on 256 CUs, and everything runs on one stream (SideStream::init), so one workspace serves the whole call
   w.sk = n < 2048 ? cv.take(sl_gemm_streamk_workspace_bytes()) : nullptr;
+  w.sk_w = n < 2048 ? w.sk : cv.take(sl_gemm_streamk_workspace_bytes());    // long window: the weight gradients run on their own stream, with their own workspace
   return cv.off + 256;
 }
 
@@ -275,6 +279,8 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   hipStream_t sw = st;           // where the current parameter-gradient group runs
   void* sk = ss.on ? nullptr : w.sk;                           // split-K workspace: only when every product of the call is on `st`
   if (sk) SL_HIP(hipMemsetAsync(sk, 0, 1024, st));
+  void* sk_w = (ss.on || !w.sk) ? w.sk_w : sk;                 // the parameter-gradient group's own (side stream), or the shared one when all is on `st`
+  if (sk_w && sk_w != sk) SL_HIP(hipMemsetAsync(sk_w, 0, 1024, st));      // ordered before the first fork of the side stream
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     if (c->skip[l]) continue;
     const sl_hubert_layer& L = layers[l];
@@ -305,7 +311,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(ss.join(0));                                   // d_o2 (tmp_h or dx) is overwritten below
     if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(w.d_h2, nullptr, w.tmp_h, n * H, c->p_hidden, sd[1], dt, stream)); d_o1 = w.tmp_h; }
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw));
+    SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw, sk_w));
     SL_TRY(sl_colsum(d_o1, H, g.bo, n, H, dt, (sl_stream)sw));
     SL_TRY(ss.end(2));
     SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, nullptr, w.d_att, H, n, w.s, st));

@@ -222,7 +222,9 @@ class LlamaTape:
         H = w.lm_head.shape[1]
         vec = 4 if d_logits.dtype == torch.float32 else 8
         S = next((s_ for s_ in self.LM_HEAD_DGRAD_SPLITS if V % (s_ * 8 * vec) == 0), 1)
-        if S <= 1 or n < 256 or not d_logits.is_contiguous():
+        # from one 128-row tile up (the per-rank window of an 8-rank run has 128 loss rows: as a transposed-operand product it took 3.6 ms
+        # of a 39.8 ms window, profiles/r05_e_kd_window2_ops.txt)
+        if S <= 1 or n < 96 or not d_logits.is_contiguous():
             return ops.dgrad(d_logits, w.lm_head)
         if getattr(self, "_lm_head_t", None) is None:
             self._lm_head_t = w.lm_head.t().contiguous()        # frozen (ref:trainer.py:63-64): built once
