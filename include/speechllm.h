@@ -610,7 +610,7 @@ int sl_greedy_generate(const sl_llama_model* m, const sl_kv_cache* kv, void* x, 
  *   row_limits_host : NULL, or one token budget per sequence in [1, max_new_tokens] (a per-request max_new_tokens): a row that
  *                     has produced its budget is finished exactly like a row that emitted EOS.  Implies use_eos semantics.
  *   compact         : 1 = at a `check_every` synchronisation, once the live rows fit the next lower rung of a fixed ladder of
- *                     row counts (... 1024, 896, 768, 640, 512, 384, 256, 192, 128, ... 1), the batch is COMPACTED: finished
+ *                     row counts (multiples of 64 from 128 up; 96, 64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1 below), the batch is COMPACTED: finished
  *                     sequences are written out, the live rows above the rung take the places of finished rows below it — their
  *                     state, output ids and K / V cache slot move with them — and decoding continues with that many rows (one
  *                     cached graph per rung).  Per sequence the result is what compact = 0 gives: identical ids in SL_F32 (every

@@ -229,7 +229,7 @@ class AudioLlamaForCausalLM:
         return ids[:, :n_cols].to(torch.int64)
 
     def generate_packed(self, x: torch.Tensor, lens: Sequence[int], max_new_tokens: int, use_eos: bool = True, sample: Optional[dict] = None,
-                        shared_prefix: int = 0, row_limits: Optional[Sequence[int]] = None, compact: bool = True, check_every: int = 8):
+                        shared_prefix: int = 0, row_limits: Optional[Sequence[int]] = None, compact: bool = True, check_every: int = 4):
         """x: packed prompt embeddings (sum S_i, h) on the GPU (overwritten).  Returns (int32 (B, max_new) host tensor, n_cols).
         shared_prefix = P: the caller's promise that the first P rows of every sequence are the same rows (one prompt template in
         front of the audio, ref:inference.py:95-113) — the batched decode attention then reads those P cache positions from slot 0
