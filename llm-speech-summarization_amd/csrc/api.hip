@@ -68,7 +68,7 @@ static const SlEnv* env_load() {
   e.gemm_gm = env_int("SL_GEMM_GM", 8);
   e.attn_full_min = env_int("SL_ATTN_FULL_MIN", 32);
   e.attn_force_split = getenv("SL_ATTN_FORCE_SPLIT") != nullptr;
-  e.attn_decode_ks = env_int("SL_ATTN_DECODE_KS", 128) == 64 ? 64 : 128;
+  { const int ks = env_int("SL_ATTN_DECODE_KS", 128); e.attn_decode_ks = (ks == 64 || ks == 65) ? ks : 128; }      // 65 = 64-key chunks + register prefetch of the next chunk
   e.attn_split_merge = env_int("SL_ATTN_SPLIT_MERGE", -1);
   e.attn_generic = env_int("SL_ATTN_GENERIC", 0);
   e.attn_qt = env_int("SL_ATTN_QT", 0);

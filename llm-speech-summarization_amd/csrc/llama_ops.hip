@@ -1112,7 +1112,10 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
     // per step at 16 sequences, 709 vs 743 ms for the Whisper leg's 32 sequences)
     const bool long_thin = max_ctx >= 1024 && (int64_t)B * nkv < 768;
     if ((int64_t)B * nkv >= full_min && !long_thin && !sl_env().attn_force_split) {
-      if (sl_env().attn_decode_ks == 64)
+      if (sl_env().attn_decode_ks == 65)        // 64-key chunks with the NEXT chunk's K / V rows held in a second register set (twice the bytes in flight per block)
+        hipLaunchKernelGGL((attn_decode_full_kernel<REP, true, 64>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
+                           (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale, shared_prefix);
+      else if (sl_env().attn_decode_ks == 64)
         hipLaunchKernelGGL((attn_decode_full_kernel<REP, false, 64>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
                            (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale, shared_prefix);
       else

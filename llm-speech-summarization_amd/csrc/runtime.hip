@@ -974,7 +974,7 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
     key.model = m; key.layers = m->layers; key.w0 = m->n_layers > 0 ? m->layers[0].wqkv_dec : nullptr; key.lm = m->lm_head_dec ? m->lm_head_dec : m->lm_head;
     key.embed = m->embed; key.kc = kv->k_cache; key.vc = kv->v_cache; key.ws = workspace; key.ws_bytes = workspace_bytes;
     key.B = B; key.B0 = B0; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
-    key.slots = kv->slots; key.shared_prefix = kv->shared_prefix; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8) | ((sl_env().attn_decode_ks == 64) << 9);   // + the switch that shapes the captured launches
+    key.slots = kv->slots; key.shared_prefix = kv->shared_prefix; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8) | ((sl_env().attn_decode_ks & 127) << 9);   // + the switch that shapes the captured launches
     key.limits = row_limit_arg ? 1 : 0;
     key.content = model_content_hash(m);
     SL_HIP(hipGetDevice(&key.device));

@@ -674,13 +674,17 @@ def test_attn_decode_single_pass_64_key_chunks_equal_128_key_chunks(nh, nkv, tun
     qd = rnd(B, nh * D, seed=62).to(dev(), dt)
     ctx = torch.tensor(lens, dtype=torch.int32, device=dev())
     ref128 = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
-    tuning("SL_ATTN_DECODE_KS", "64")
-    out64 = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
-    assert rel_err(out64, ref128) < 4e-3          # same products, online-softmax rescale points differ
-    for s in list(range(8)) + [31, 63]:
-        n = lens[s]
-        ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
-        assert rel_err(out64[s], ref[0]) < TOL[dt], s
+    outs = {}
+    for form in ("64", "65"):                     # 65 = 64-key chunks with the next chunk's rows prefetched into a second register set
+        tuning("SL_ATTN_DECODE_KS", form)
+        out64 = ops.attn_decode_split(qd, qd.stride(0), kc, vc, ctx, nh, nkv, D, max_ctx, D ** -0.5).float().cpu()
+        outs[form] = out64
+        assert rel_err(out64, ref128) < 4e-3          # same products, online-softmax rescale points differ
+        for s in list(range(8)) + [31, 63]:
+            n = lens[s]
+            ref = ref_attention(qd[s].float().cpu().view(nh, 1, D), kc[s, :, :n].float().cpu(), vc[s, :, :n].float().cpu(), False, D ** -0.5, dt)
+            assert rel_err(out64[s], ref[0]) < TOL[dt], s
+    assert torch.equal(outs["64"], outs["65"])     # the prefetch changes when rows are requested, not what is computed
 
 
 @pytest.mark.parametrize("dt", DT)
