@@ -566,6 +566,7 @@ def test_llama_compacted_batch_mixed_stop_lengths_equals_single(B, check_every):
     new = 48
     refs = [lo.greedy_generate(sd, cfg, p[None], new, use_eos=True)[0] for p in base]
     limits = [3 + (11 * b) % 44 for b in range(B)]
+    limits[0], limits[1] = 1, new                    # a budget spent by the prefill's own token; a budget of the whole max_new_tokens
     prompts = [base[b % 5] for b in range(B)]
     lens = [int(p.shape[0]) for p in prompts]
     x = torch.cat(prompts).to(DEV, torch.float32)
@@ -601,6 +602,29 @@ def test_llama_compacted_batch_mixed_stop_lengths_equals_single(B, check_every):
         assert bool((ids_n[b, limits[b]:n_n] == (cfg.pad_token_id if cfg.pad_token_id is not None else 0)).all()), b
     with pytest.raises(pkg("_lib").SpeechLLMError):
         llm.generate_packed(x.clone(), lens, new, row_limits=[new + 1] * B)
+
+
+def test_llama_compaction_keeps_the_shared_prompt_prefix_promise():
+    """Compaction moves K / V slots; the single-pass decode attention reads the shared prompt-prefix positions from slot 0.  Every slot holds
+    bit-identical prefix rows (prefill's promise), so whichever sequence ends up in slot 0 the ids must equal those of shared_prefix = 0 and of
+    the uncompacted batch — fp32, 40 sequences with a common 11-row prefix, budgets that empty slot 0 early."""
+    cfg = TINY_LLAMA
+    llm, _ = make_llama(cfg, 35, torch.float32)
+    gen = torch.Generator().manual_seed(12)
+    P, B, new = 11, 40, 40
+    pre = torch.randn(P, cfg.hidden_size, generator=gen) * 0.05
+    tails = [torch.randn(n, cfg.hidden_size, generator=gen) * 0.05 for n in (9, 40, 14, 5, 27, 30, 21, 1)]
+    prompts = [torch.cat([pre, tails[b % len(tails)] * (1.0 + 0.01 * (b // len(tails)))]) for b in range(B)]
+    lens = [int(p.shape[0]) for p in prompts]
+    x = torch.cat(prompts).to(DEV, torch.float32)
+    limits = [2 + (7 * b) % 37 for b in range(B)]
+    limits[0] = 2                                     # slot 0's own sequence leaves first: a mover takes the slot
+    llm.generation_config.eos_token_id = None
+    ref, n_ref = llm.generate_packed(x.clone(), lens, new, use_eos=False, row_limits=limits, compact=False, shared_prefix=0)
+    for sp in (0, P):
+        ids, n = llm.generate_packed(x.clone(), lens, new, use_eos=False, row_limits=limits, compact=True, check_every=2, shared_prefix=sp)
+        assert llm.last_generate_stats["compactions"] >= 3
+        assert n == n_ref and torch.equal(ids[:, :n], ref[:, :n_ref]), sp
 
 
 def test_sampled_generation_is_reproducible_and_greedy_stays_default():
