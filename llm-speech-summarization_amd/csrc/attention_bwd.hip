@@ -158,37 +158,60 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   if (CAUSAL) { const int i0 = key0 - shift; qt_first = i0 > 0 ? i0 / TQ : 0; }   // first query that sees a key of this block
   const int n_qt = (qlen + TQ - 1) / TQ;
 
-  for (int h = 0; h < rep; ++h) {
-    const int head = kvh * rep + h;
+  // One thread stages one 16-byte column chunk of two consecutive rows of Q and of dO per tile ((TQ / 2) x CPR = 256 pairs in every
+  // instantiation).  The NEXT tile's rows are requested before the current tile's products start (round 5: the loop used to load, store
+  // and compute in sequence, with only other blocks to cover the global-load latency).
+  static_assert((TQ / 2) * CPR == 256, "one (row pair, chunk) per thread");
+  const int n_tiles = n_qt > qt_first ? rep * (n_qt - qt_first) : 0;
+  const int prow = 2 * (tid / CPR), pch = tid % CPR;
+  uint4 uq0, uq1, ud0, ud1;
+  float lse_r = 0.f, dl_r = 0.f;
+  auto gload = [&](int it) {
+    const int h = it / (n_qt - qt_first), qt = qt_first + it % (n_qt - qt_first);
+    const int head = kvh * rep + h, qt0 = qt * TQ;
     const T* qb = (const T*)p.q + (int64_t)head * p.q_hs;
     const T* dob = (const T*)p.dout + (int64_t)head * p.do_hs;
-    for (int qt = qt_first; qt < n_qt; ++qt) {
+    int qi0 = qt0 + prow, qi1 = qi0 + 1;
+    qi0 = qi0 < qlen ? qi0 : qlen - 1; qi1 = qi1 < qlen ? qi1 : qlen - 1;
+    uq0 = *(const uint4*)(qb + (int64_t)(q0 + qi0) * p.q_rs + pch * VEC); uq1 = *(const uint4*)(qb + (int64_t)(q0 + qi1) * p.q_rs + pch * VEC);
+    ud0 = *(const uint4*)(dob + (int64_t)(q0 + qi0) * p.do_rs + pch * VEC); ud1 = *(const uint4*)(dob + (int64_t)(q0 + qi1) * p.do_rs + pch * VEC);
+    if (tid < TQ) {
+      const int qi = qt0 + tid;
+      const int64_t idx = ((int64_t)q0 + (qi < qlen ? qi : qlen - 1)) * p.n_heads + head;
+      lse_r = p.lse[idx];
+      dl_r = p.delta[idx];
+    }
+  };
+  if (n_tiles > 0) gload(0);
+  for (int it = 0; it < n_tiles; ++it) {
+    const int h = it / (n_qt - qt_first), qt = qt_first + it % (n_qt - qt_first);
+    const int head = kvh * rep + h;
+    {
       const int qt0 = qt * TQ;
       __syncthreads();   // the previous tile's LDS reads are done
-      // stage Q and dO: row-major (A operands of S / dP) and transposed with permuted columns (B operands of dK / dV)
-      for (int c = tid; c < TQ * CPR; c += 256) {
-        const int row = c / CPR, ch = c % CPR;
-        int qi = qt0 + row; qi = qi < qlen ? qi : qlen - 1;
-        const uint4 uq = *(const uint4*)(qb + (int64_t)(q0 + qi) * p.q_rs + ch * VEC);
-        const uint4 ud = *(const uint4*)(dob + (int64_t)(q0 + qi) * p.do_rs + ch * VEC);
-        *(uint4*)(Qs + swz<CPR>(row, ch)) = uq;
-        *(uint4*)(dOs + swz<CPR>(row, ch)) = ud;
-        const int pos = tpos<T>(row);
+      // row-major images (A operands of S / dP) and transposed images with permuted columns (B operands of dK / dV).  The two rows a thread
+      // holds are neighbours in the transposed images (tpos keeps a row's low two bits), so an element pair is one 4-byte (bf16) / 8-byte
+      // (fp32) LDS store instead of two scalar ones
+      {
+        const int row = prow, ch = pch;
+        *(uint4*)(Qs + swz<CPR>(row, ch)) = uq0; *(uint4*)(Qs + swz<CPR>(row + 1, ch)) = uq1;
+        *(uint4*)(dOs + swz<CPR>(row, ch)) = ud0; *(uint4*)(dOs + swz<CPR>(row + 1, ch)) = ud1;
+        const int pos = tpos<T>(row);        // even, and tpos(row + 1) = pos + 1
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const int d = ch * VEC + j;
           const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
-          *(T*)(QT + off) = chunk_elem<T>(uq, j);
-          *(T*)(dOT + off) = chunk_elem<T>(ud, j);
+          if constexpr (sizeof(T) == 2) {
+            *(uint32_t*)(QT + off) = (uint32_t)chunk_elem<T>(uq0, j).bits | ((uint32_t)chunk_elem<T>(uq1, j).bits << 16);
+            *(uint32_t*)(dOT + off) = (uint32_t)chunk_elem<T>(ud0, j).bits | ((uint32_t)chunk_elem<T>(ud1, j).bits << 16);
+          } else {
+            *(float2*)(QT + off) = make_float2(chunk_elem<T>(uq0, j), chunk_elem<T>(uq1, j));
+            *(float2*)(dOT + off) = make_float2(chunk_elem<T>(ud0, j), chunk_elem<T>(ud1, j));
+          }
         }
       }
-      if (tid < TQ) {
-        const int qi = qt0 + tid;
-        const bool ok = qi < qlen;
-        const int64_t idx = ((int64_t)q0 + (ok ? qi : qlen - 1)) * p.n_heads + head;
-        lse_s[tid] = p.lse[idx];
-        dl_s[tid] = p.delta[idx];
-      }
+      if (tid < TQ) { lse_s[tid] = lse_r; dl_s[tid] = dl_r; }
+      if (it + 1 < n_tiles) gload(it + 1);      // in flight under this tile's products
       __syncthreads();
 
       // S = Q K^T and dP = dO V^T for TQ queries x this wave's 16 keys: lane (key r, a = qd) holds queries n*16 + 4a + i
@@ -205,7 +228,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
           MMA<T>::step(dp[n], ad, vf[ks]);
         }
       }
-      // probabilities (recomputed from the forward's lse), dropout mask, dS
+      // probabilities (recomputed from the forward's lse), dropout mask, dS.  The mask's index is ((query row * heads + head) << 16) | key: over a
+      // tile's queries its upper half takes at most two values, so the inner hash is taken twice per tile instead of once per score
+      const int64_t a_first = ((int64_t)q0 + qt0) * p.n_heads + head;
+      const uint32_t hi_base = (uint32_t)(a_first >> 16);
+      uint32_t inner0 = 0, inner1 = 0;
+      if (p.drop_thr) { inner0 = drop_inner(hi_base, p.drop_seed); inner1 = drop_inner(hi_base + 1, p.drop_seed); }
 #pragma unroll
       for (int n = 0; n < NQF; ++n) {
         const f32x4 ls = *(const f32x4*)(lse_s + n * 16 + 4 * qd);
@@ -219,7 +247,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
           float dpv = dp[n][i];
           float pd = pv;
           if (p.drop_thr) {
-            const bool keep = dropout_keep(((((int64_t)q0 + qi) * p.n_heads + head) << 16) | (int64_t)kj, p.drop_seed, p.drop_thr);
+            const int64_t a_q = ((int64_t)q0 + qi) * p.n_heads + head;            // (rows past qlen: masked by `ok`, any mask bit will do)
+            const uint32_t lo = ((uint32_t)a_q << 16) | (uint32_t)kj;
+            const bool keep = dropout_keep_lo(lo, (uint32_t)(a_q >> 16) == hi_base ? inner0 : inner1, p.drop_thr);
             pd = keep ? pv * p.drop_scale : 0.f;
             dpv = keep ? dpv * p.drop_scale : 0.f;
           }
@@ -310,23 +340,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
     const int lim = last < 0 ? 0 : last / TK + 1;
     n_kt = lim < n_kt ? lim : n_kt;
   }
+  // staging as in the dK / dV kernel: a thread holds NP (row pair, chunk) items of K and V, the next key tile's rows are requested before the
+  // current tile's products start, and the transposed K image is written two rows (one 4- / 8-byte store) at a time
+  constexpr int NP = (TK / 2) * CPR / 256;
+  static_assert(NP * 256 == (TK / 2) * CPR && NP >= 1, "whole (row pair, chunk) items per thread");
+  uint4 uk0[NP], uk1[NP], uv0[NP], uv1[NP];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = tid + 256 * i, row = 2 * (c / CPR), ch = c % CPR;
+      int k0r = kt * TK + row, k1r = k0r + 1;
+      k0r = k0r < klen ? k0r : klen - 1; k1r = k1r < klen ? k1r : klen - 1;
+      uk0[i] = *(const uint4*)(kb + (int64_t)k0r * p.k_rs + ch * VEC); uk1[i] = *(const uint4*)(kb + (int64_t)k1r * p.k_rs + ch * VEC);
+      uv0[i] = *(const uint4*)(vb + (int64_t)k0r * p.v_rs + ch * VEC); uv1[i] = *(const uint4*)(vb + (int64_t)k1r * p.v_rs + ch * VEC);
+    }
+  };
+  // dropout mask index = ((query row * heads + head) << 16) | key: its upper half is a constant of this lane's query
+  const int64_t a_q = ((int64_t)q0 + qc) * p.n_heads + head;
+  const uint32_t drop_in = p.drop_thr ? drop_inner((uint32_t)(a_q >> 16), p.drop_seed) : 0u;
+  if (n_kt > 0) gload(0);
   for (int kt = 0; kt < n_kt; ++kt) {
     const int key0 = kt * TK;
     __syncthreads();
-    for (int c = tid; c < TK * CPR; c += 256) {
-      const int row = c / CPR, ch = c % CPR;
-      int kr = key0 + row; kr = kr < klen ? kr : klen - 1;
-      const uint4 uk = *(const uint4*)(kb + (int64_t)kr * p.k_rs + ch * VEC);
-      const uint4 uv = *(const uint4*)(vb + (int64_t)kr * p.v_rs + ch * VEC);
-      *(uint4*)(Ks + swz<CPR>(row, ch)) = uk;
-      *(uint4*)(Vs + swz<CPR>(row, ch)) = uv;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = tid + 256 * i, row = 2 * (c / CPR), ch = c % CPR;
+      *(uint4*)(Ks + swz<CPR>(row, ch)) = uk0[i]; *(uint4*)(Ks + swz<CPR>(row + 1, ch)) = uk1[i];
+      *(uint4*)(Vs + swz<CPR>(row, ch)) = uv0[i]; *(uint4*)(Vs + swz<CPR>(row + 1, ch)) = uv1[i];
       const int pos = tpos<T>(row);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const int d = ch * VEC + j;
-        *(T*)(KT + swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ) = chunk_elem<T>(uk, j);
+        const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
+        if constexpr (sizeof(T) == 2) *(uint32_t*)(KT + off) = (uint32_t)chunk_elem<T>(uk0[i], j).bits | ((uint32_t)chunk_elem<T>(uk1[i], j).bits << 16);
+        else *(float2*)(KT + off) = make_float2(chunk_elem<T>(uk0[i], j), chunk_elem<T>(uk1[i], j));
       }
     }
+    if (kt + 1 < n_kt) gload(kt + 1);      // in flight under this tile's products
     __syncthreads();
 
     // S^T = K Q^T, dP^T = V dO^T: lane (query r, a = qd) holds keys n*16 + 4a + i
@@ -353,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
         const float pv = ok ? exp_scaled<T>(s[n][i] * p.scale - lse_q) : 0.f;
         float dpv = dp[n][i];
         if (p.drop_thr) {
-          const bool keep = dropout_keep(((((int64_t)q0 + qc) * p.n_heads + head) << 16) | (int64_t)kj, p.drop_seed, p.drop_thr);
+          const bool keep = dropout_keep_lo(((uint32_t)a_q << 16) | (uint32_t)kj, drop_in, p.drop_thr);
           dpv = keep ? dpv * p.drop_scale : 0.f;
         }
         dp[n][i] = pv * (dpv - dl_q) * p.scale;

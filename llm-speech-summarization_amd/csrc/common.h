@@ -163,6 +163,10 @@ __device__ __forceinline__ bool dropout_keep(int64_t i, uint64_t seed, uint32_t 
   const uint32_t h = lowbias32((uint32_t)i ^ lowbias32((uint32_t)((uint64_t)i >> 32) ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
   return (h >> 8) >= thr24;
 }
+// the same mask in two steps, for loops in which the upper half of the index takes one or two values: inner = drop_inner(hi, seed) once,
+// then dropout_keep_lo(lo, inner, thr) per element (a 32-bit integer multiply is a quarter-rate instruction: lowbias32 costs ~56 cycles)
+__device__ __forceinline__ uint32_t drop_inner(uint32_t hi, uint64_t seed) { return lowbias32(hi ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32); }
+__device__ __forceinline__ bool dropout_keep_lo(uint32_t lo, uint32_t inner, uint32_t thr24) { return (lowbias32(lo ^ inner) >> 8) >= thr24; }
 template <typename T> __device__ __forceinline__ float gelu_act(float x) {
   if constexpr (sizeof(T) == 2) return gelu_fast(x);
   else return gelu_erf(x);
