@@ -83,6 +83,25 @@ __device__ __forceinline__ uint4 pack_step(const f32x4 (&x)[NFR], int ks) {
   }
 }
 
+// bf16: the B (or A) operand of a product that contracts over the ROWS of a row-major LDS tile — 8 contraction slots of lane (r, a): rows
+// base + 4a + {0..3} (slots 8a .. 8a+3) and base + 16 + 4a + {0..3} (slots 8a+4 .. 8a+7) at column 16 n + r — gathered straight from the
+// row-major image by two ds_read_b64_tr_b16 (within a 16-lane group lane 4 qq + pp addresses row qq's 8-byte piece pp of the 32 bytes that
+// hold the 16 columns; the instruction hands lane r the four rows' values of column r).  The slot order is the one pack_step gives the
+// other operand.  Round 5: replaces a second, transposed LDS image of every tile, which cost 16 two-byte stores per staged chunk with up to
+// 16-way bank conflicts (its rows are 64-128 bytes: lanes that differ in the source chunk land on one bank).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_b_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_b_t;
+template <int CPR>
+__device__ __forceinline__ uint4 tr_frag(uint32_t img, int row_base, int n, int lane) {
+  const int r = lane & 15, a = lane >> 4, qq = r >> 2, pp = r & 3;
+  const int r0 = row_base + 4 * a + qq, r1 = r0 + 16;
+  u32x2_b_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(img + (uint32_t)(swz<CPR>(r0, 2 * n + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(img + (uint32_t)(swz<CPR>(r1, 2 * n + (pp >> 1)) + 8 * (pp & 1))) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
 // delta[t][h] = sum_d dO[t][h][d] * O[t][h][d]
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(AttnBwdP p) {
@@ -121,12 +140,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   constexpr int CPT = TQ * SZ / 16;     // chunks per row of the transposed images
   constexpr int TILE_B = TQ * D * SZ;
   static_assert(TQ % KSTEP == 0 && CPT == 4 * KS_Q, "tile shape");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B + 2 * TQ * 4];
+  constexpr bool TR = sizeof(T) == 2;   // bf16: transposed operands are read out of the row-major images (tr_frag); fp32 keeps transposed images
+  constexpr int NIMG = TR ? 2 : 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NIMG * TILE_B + 2 * TQ * 4];
   unsigned char* Qs = smem;
   unsigned char* dOs = smem + TILE_B;
-  unsigned char* QT = smem + 2 * TILE_B;
-  unsigned char* dOT = smem + 3 * TILE_B;
-  float* lse_s = (float*)(smem + 4 * TILE_B);
+  unsigned char* QT = smem + (TR ? 0 : 2) * TILE_B;      // (unused when TR)
+  unsigned char* dOT = smem + (TR ? 0 : 3) * TILE_B;
+  float* lse_s = (float*)(smem + NIMG * TILE_B);
   float* dl_s = lse_s + TQ;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,24 +210,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
     {
       const int qt0 = qt * TQ;
       __syncthreads();   // the previous tile's LDS reads are done
-      // row-major images (A operands of S / dP) and transposed images with permuted columns (B operands of dK / dV).  The two rows a thread
-      // holds are neighbours in the transposed images (tpos keeps a row's low two bits), so an element pair is one 4-byte (bf16) / 8-byte
-      // (fp32) LDS store instead of two scalar ones
+      // row-major images (A operands of S / dP; bf16: also the source of the transposed B operands of dK / dV, tr_frag).  fp32: transposed
+      // images beside them — the two rows a thread holds are neighbours there, so an element pair goes out as one 8-byte store
       {
         const int row = prow, ch = pch;
         *(uint4*)(Qs + swz<CPR>(row, ch)) = uq0; *(uint4*)(Qs + swz<CPR>(row + 1, ch)) = uq1;
         *(uint4*)(dOs + swz<CPR>(row, ch)) = ud0; *(uint4*)(dOs + swz<CPR>(row + 1, ch)) = ud1;
-        const int pos = tpos<T>(row);        // even, and tpos(row + 1) = pos + 1
+        if constexpr (!TR) {
+          const int pos = tpos<T>(row);        // even, and tpos(row + 1) = pos + 1
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const int d = ch * VEC + j;
-          const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
-          if constexpr (sizeof(T) == 2) {
-            *(uint32_t*)(QT + off) = (uint32_t)chunk_elem<T>(uq0, j).bits | ((uint32_t)chunk_elem<T>(uq1, j).bits << 16);
-            *(uint32_t*)(dOT + off) = (uint32_t)chunk_elem<T>(ud0, j).bits | ((uint32_t)chunk_elem<T>(ud1, j).bits << 16);
-          } else {
-            *(float2*)(QT + off) = make_float2(chunk_elem<T>(uq0, j), chunk_elem<T>(uq1, j));
-            *(float2*)(dOT + off) = make_float2(chunk_elem<T>(ud0, j), chunk_elem<T>(ud1, j));
+          for (int j = 0; j < VEC; ++j) {
+            const int d = ch * VEC + j;
+            const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
+            *(float2*)(QT + off) = make_float2(chunk_elem<float>(uq0, j), chunk_elem<float>(uq1, j));
+            *(float2*)(dOT + off) = make_float2(chunk_elem<float>(ud0, j), chunk_elem<float>(ud1, j));
           }
         }
       }
@@ -263,8 +280,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
         const uint4 ads = pack_step<T, NQF>(dp, ks);
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
-          const uint4 bd = *(const uint4*)(dOT + swz<CPT>(n * 16 + r, ks * 4 + qd));
-          const uint4 bq = *(const uint4*)(QT + swz<CPT>(n * 16 + r, ks * 4 + qd));
+          uint4 bd, bq;
+          if constexpr (TR) {
+            bd = tr_frag<CPR>((uint32_t)(uintptr_t)(lds_ptr_b_t)dOs, 32 * ks, n, lane);
+            bq = tr_frag<CPR>((uint32_t)(uintptr_t)(lds_ptr_b_t)Qs, 32 * ks, n, lane);
+          } else {
+            bd = *(const uint4*)(dOT + swz<CPT>(n * 16 + r, ks * 4 + qd));
+            bq = *(const uint4*)(QT + swz<CPT>(n * 16 + r, ks * 4 + qd));
+          }
           MMA<T>::step(dv[n], apd, bd);
           MMA<T>::step(dk[n], ads, bq);
         }
@@ -300,10 +323,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
   constexpr int CPR = D * SZ / 16;
   constexpr int CPT = TK * SZ / 16;
   constexpr int TILE_B = TK * D * SZ;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * TILE_B];
+  constexpr bool TR = sizeof(T) == 2;   // bf16: K^T fragments are read out of the row-major K image (tr_frag)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(TR ? 2 : 3) * TILE_B];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + TILE_B;
-  unsigned char* KT = smem + 2 * TILE_B;
+  unsigned char* KT = smem + (TR ? 0 : 2) * TILE_B;     // (unused when TR)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, qd = lane >> 4;
@@ -367,13 +391,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
       const int c = tid + 256 * i, row = 2 * (c / CPR), ch = c % CPR;
       *(uint4*)(Ks + swz<CPR>(row, ch)) = uk0[i]; *(uint4*)(Ks + swz<CPR>(row + 1, ch)) = uk1[i];
       *(uint4*)(Vs + swz<CPR>(row, ch)) = uv0[i]; *(uint4*)(Vs + swz<CPR>(row + 1, ch)) = uv1[i];
-      const int pos = tpos<T>(row);
+      if constexpr (!TR) {
+        const int pos = tpos<T>(row);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const int d = ch * VEC + j;
-        const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
-        if constexpr (sizeof(T) == 2) *(uint32_t*)(KT + off) = (uint32_t)chunk_elem<T>(uk0[i], j).bits | ((uint32_t)chunk_elem<T>(uk1[i], j).bits << 16);
-        else *(float2*)(KT + off) = make_float2(chunk_elem<T>(uk0[i], j), chunk_elem<T>(uk1[i], j));
+        for (int j = 0; j < VEC; ++j) {
+          const int d = ch * VEC + j;
+          const int off = swz<CPT>(d, pos / VEC) + (pos % VEC) * SZ;
+          *(float2*)(KT + off) = make_float2(chunk_elem<float>(uk0[i], j), chunk_elem<float>(uk1[i], j));
+        }
       }
     }
     if (kt + 1 < n_kt) gload(kt + 1);      // in flight under this tile's products
@@ -414,7 +439,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
       const uint4 bds = pack_step<T, NKF>(dp, ks);
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
-        const uint4 ak = *(const uint4*)(KT + swz<CPT>(n * 16 + r, ks * 4 + qd));
+        uint4 ak;
+        if constexpr (TR) ak = tr_frag<CPR>((uint32_t)(uintptr_t)(lds_ptr_b_t)Ks, 32 * ks, n, lane);
+        else ak = *(const uint4*)(KT + swz<CPT>(n * 16 + r, ks * 4 + qd));
         MMA<T>::step(dq[n], ak, bds);
       }
     }
