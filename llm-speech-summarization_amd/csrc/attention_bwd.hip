@@ -99,7 +99,7 @@ __device__ __forceinline__ void tr_issue(uint32_t img, int row_base, int n, int 
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(img + (uint32_t)(swz<CPR>(r1, 2 * n + (pp >> 1)) + 8 * (pp & 1))) : "memory");
 }
 // one wait for a group of fragments in flight (every register tied to it, so that no product moves above the wait): a wait per fragment
-// exposed the LDS latency sixteen times per tile (llama shape: 149 -> 134 us per layer with the reads batched four fragments at a time)
+// exposed the LDS latency sixteen times per tile (llama shape 134 -> 130 us per layer, hubert shape 212 -> 207, tools/time_attn_bwd.py)
 template <int NG>
 __device__ __forceinline__ void tr_wait(u32x2_b_t (&lo)[NG], u32x2_b_t (&hi)[NG]) {
   static_assert(NG == 4 || NG == 8, "groups of 4 or 8 fragments");
