@@ -56,9 +56,11 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, c
     float xv[VEC], rv[VEC];
     Vec16<T>::unpack(*(const uint4*)(x + i), xv);
     if (res) Vec16<T>::unpack(*(const uint4*)(res + i), rv);
+    // the chunk's VEC indices share their upper half (i is a multiple of VEC): one inner hash round per chunk, one outer round per element
+    const uint32_t inner = drop_inner((uint32_t)((uint64_t)i >> 32), seed);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float d = dropout_keep(i + e, seed, thr24) ? xv[e] * scale : 0.f;
+      const float d = dropout_keep_lo((uint32_t)(i + e), inner, thr24) ? xv[e] * scale : 0.f;
       xv[e] = res ? rv[e] + d : d;
     }
     *(uint4*)(y + i) = Vec16<T>::pack(xv);
