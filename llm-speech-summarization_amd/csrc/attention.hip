@@ -283,6 +283,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
     nkt = lim < nkt ? lim : nkt;
   }
   const float c = p.scale * 1.4426950408889634f;   // scores in the log2 domain: exp(x) = exp2(x log2 e)
+  // training-mode dropout of the probabilities: per query tile of this lane the upper half of the mask index (one inner hash round, taken here
+  // once instead of per score: a 32-bit integer multiply is a quarter-rate instruction) and the query's share of the lower half
+  uint32_t drop_in[QT], drop_lo[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    drop_in[t] = 0; drop_lo[t] = 0;
+    if constexpr (DROP) {
+      const int qi = qw0 + t * 16 + r;
+      const int64_t a_q = ((int64_t)q0 + (qi < qlen ? qi : qlen - 1)) * p.n_heads + head;
+      drop_in[t] = drop_inner((uint32_t)(a_q >> 16), p.drop_seed);
+      drop_lo[t] = (uint32_t)a_q << 16;
+    }
+  }
 
   u32x4_t kreg[NLD], vreg[NLD];
   auto gload = [&](int kt) {
@@ -365,9 +378,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
           for (int i = 0; i < 4; ++i) {
             float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][n][i], c, -m_use));
             ls += pv;                                   // undropped normaliser
-            if constexpr (DROP) {
-              const int64_t qg = (int64_t)q0 + (qi < qlen ? qi : qlen - 1);
-              pv = dropout_keep((((qg * p.n_heads + head) << 16) | (int64_t)(key0 + n * 16 + 4 * q + i)), p.drop_seed, p.drop_thr) ? pv * p.drop_scale : 0.f;
+            if constexpr (DROP) {      // mask index ((query row * heads + head) << 16) | key: the inner hash round belongs to the query (drop_in[t])
+              pv = dropout_keep_lo(drop_lo[t] | (uint32_t)(key0 + n * 16 + 4 * q + i), drop_in[t], p.drop_thr) ? pv * p.drop_scale : 0.f;
             }
             s[t][n][i] = pv;
           }
