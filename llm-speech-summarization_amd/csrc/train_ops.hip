@@ -255,7 +255,9 @@ template <typename T, bool RMS, int MAXF, int NW>
 __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int64_t rows, int cols, float eps, int gelu, int rows_per_block,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, const T* __restrict__ add = nullptr) {
+  // add (optional, same shape as dx, not aliasing it): dx = backward(dy) + add — the residual branch's gradient joins here instead of in a
+  // separate axpby launch (one read + one write of the whole activation less per LayerNorm / RMSNorm in the training tapes)
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int MAXCH = MAXF / VEC;
   __shared__ float red[NW][64 * VEC + 4];  // per-wave column partials of one 64-chunk group, folded in two passes (gamma, beta)
@@ -330,6 +332,12 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
         float o[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = RMS ? rstd * (dv[i][e] - xv[i][e] * s2) : rstd * (dv[i][e] - s1 - xv[i][e] * s2);
+        if (add) {      // rounded to the storage type first, then added: the bits of dx = round(backward) followed by axpby(add, dx)
+          float av[VEC];
+          Vec16<T>::unpack(*(const uint4*)(add + row * cols + ch * VEC), av);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = to_f32(from_f32<T>(o[e])) + av[e];
+        }
         *(uint4*)(dx + row * cols + ch * VEC) = Vec16<T>::pack(o);
       }
     }
@@ -1014,7 +1022,8 @@ extern "C" size_t sl_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
 }
 
 static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta, int64_t rows,
-                              int32_t cols, float eps, int32_t gelu, int32_t dtype, void* ws, size_t ws_bytes, sl_stream stream) {
+                              int32_t cols, float eps, int32_t gelu, int32_t dtype, void* ws, size_t ws_bytes, sl_stream stream, const void* add = nullptr) {
+  SL_CHECK_ARG(!add || add != dx, "sl_layernorm_bwd: the residual gradient must not alias dx");
   SL_CHECK_ARG(x && gamma && beta && dy && dx && rows >= 0 && cols > 0, "sl_layernorm_bwd: bad arguments");
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_layernorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
@@ -1025,7 +1034,7 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
       const int nb = ln_bwd_ws_blocks(rows, &rpb);
       SL_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                           (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws);
+                           (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws, (const T*)add);
       });
       SL_CHECK_LAUNCH("layernorm_bwd");
       hipLaunchKernelGGL(norm_colreduce_kernel, dim3((unsigned)((2 * cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nb, cols, dgamma,
@@ -1041,7 +1050,7 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
     rpb16 = rpb16 < 16 ? 16 : rpb16;
     SL_DISPATCH_DTYPE(dtype, T, {
       hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)ceil_div64(rows, rpb16)), dim3(1024), 0, (hipStream_t)stream, (const T*)x,
-                         (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb16, (float*)nullptr);
+                         (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb16, (float*)nullptr, (const T*)add);
     });
     SL_CHECK_LAUNCH("layernorm_bwd");
     return 0;
@@ -1052,10 +1061,16 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
   rpb = rpb < 4 ? 4 : (rpb > 64 ? 64 : rpb);
   SL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((norm_bwd_kernel<T, false, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                       (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)nullptr);
+                       (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)nullptr, (const T*)add);
   });
   SL_CHECK_LAUNCH("layernorm_bwd");
   return 0;
+}
+
+// the training tapes' forms (train_tape.hip): dx = backward(dy) + add
+int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
+                                 int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream) {
+  return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, 0, dtype, workspace, workspace_bytes, stream, add);
 }
 
 extern "C" int sl_layernorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta,
@@ -1069,19 +1084,24 @@ extern "C" int sl_layernorm_bwd_ws(const void* x, const void* gamma, const void*
   return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, gelu, dtype, workspace, workspace_bytes, stream);
 }
 
-extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
-                              sl_stream stream) {
-  SL_CHECK_ARG(x && w && dy && dx && rows >= 0 && cols > 0, "sl_rmsnorm_bwd: bad arguments");
+int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const void* add, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
+                            sl_stream stream) {
+  SL_CHECK_ARG(x && w && dy && dx && rows >= 0 && cols > 0 && (!add || add != dx), "sl_rmsnorm_bwd: bad arguments");
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_rmsnorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
   if (rows == 0) return 0;
   const int rpb = 16;
   SL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((norm_bwd_kernel<T, true, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr);
+                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add);
   });
   SL_CHECK_LAUNCH("rmsnorm_bwd");
   return 0;
+}
+
+extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
+                              sl_stream stream) {
+  return sl_rmsnorm_bwd_add_impl(x, w, dy, nullptr, dx, rows, cols, eps, dtype, stream);
 }
 
 extern "C" int sl_colsum(const void* x, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t dtype, sl_stream stream) {

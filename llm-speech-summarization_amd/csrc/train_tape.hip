@@ -8,6 +8,12 @@
 
 #include "common.h"
 
+// train_ops.hip: norm backward with the residual branch's gradient added in the same pass (dx = backward(dy) + add)
+int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
+                                 int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream);
+int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const void* add, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
+                            sl_stream stream);
+
 namespace {
 
 struct Carver {
@@ -304,8 +310,8 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, (sl_stream)sw));
     SL_TRY(ss.end(1));
     SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
-    SL_TRY(sl_layernorm_bwd_ws(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));   // d_h2 = d x_mid (LN path)
-    SL_TRY(sl_axpby(dx, w.d_h2, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
+    // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass
+    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream));
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
     const void* d_o1 = w.d_h2;
     SL_TRY(ss.join(0));                                   // d_o2 (tmp_h or dx) is overwritten below
@@ -323,8 +329,8 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, (sl_stream)sw));
     SL_TRY(ss.end(3));
     SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));
-    SL_TRY(sl_layernorm_bwd_ws(sv.x, L.ln1_g, L.ln1_b, w.d_h1, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, 0, dt, w.ln_ws, w.ln_ws_bytes, stream));            // dx = d x (LN path)
-    SL_TRY(sl_axpby(w.d_h2, dx, 1.f, 1.f, n * H, dt, stream));                                                                  // + residual path
+    // dx = d x: the LayerNorm path + the residual path (d_h2), one pass
+    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x, L.ln1_g, L.ln1_b, w.d_h1, w.d_h2, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream));
     (void)sz;
   }
   for (int k = 0; k < 4; ++k) SL_TRY(ss.join(k));          // the caller's stream owns the gradients again
@@ -431,16 +437,14 @@ extern "C" int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, cons
     SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_mid, F, n, w.s, st, w.sk));
     SL_TRY(sl_silu_mul_bwd(sv.gu, w.d_mid, w.d_gu, n, F, dt, stream));
     SL_TRY(dgrad(dt, w.d_gu, 2 * F, L.wgu, 2 * F, H, L.wgu_t, w.d_h, H, n, w.s, st, w.sk));
-    SL_TRY(sl_rmsnorm_bwd(sv.x2, L.norm2, w.d_h, w.dx2, n, H, c->rms_eps, dt, stream));
-    SL_TRY(sl_axpby(dx, w.dx2, 1.f, 1.f, n * H, dt, stream));                       // residual join
+    SL_TRY(sl_rmsnorm_bwd_add_impl(sv.x2, L.norm2, w.d_h, dx, w.dx2, n, H, c->rms_eps, dt, stream));      // + the residual path (dx), same pass
     // x2 = x + wo . attn(rope(wqkv . rmsnorm(x)))
     SL_TRY(dgrad(dt, w.dx2, H, L.wo, H, att_w, L.wo_t, w.d_att, att_w, n, w.s, st, w.sk));
     SL_TRY(attn_bwd(dt, sv.qkv, qkv_w, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nkv, D, 1, scale, 0.f, 0,
                     st));
     SL_TRY(sl_rope_inplace(w.d_qkv, c->pos, c->rope_cos, c->rope_sin, n, nh + 2 * nkv, nh + nkv, D, 1, dt, stream));
     SL_TRY(dgrad(dt, w.d_qkv, qkv_w, L.wqkv, qkv_w, H, L.wqkv_t, w.d_h, H, n, w.s, st, w.sk));
-    SL_TRY(sl_rmsnorm_bwd(hidden[l], L.norm1, w.d_h, dx, n, H, c->rms_eps, dt, stream));
-    SL_TRY(sl_axpby(w.dx2, dx, 1.f, 1.f, n * H, dt, stream));
+    SL_TRY(sl_rmsnorm_bwd_add_impl(hidden[l], L.norm1, w.d_h, w.dx2, dx, n, H, c->rms_eps, dt, stream));  // + the residual path (dx2), same pass
     if (d_tap && d_tap[l]) SL_TRY(sl_axpby(d_tap[l], dx, 1.f, 1.f, n * H, dt, stream));     // feature-distillation gradient of hidden_states[l]
   }
   return 0;
