@@ -1628,7 +1628,7 @@ static int splitk_runs(const GemmP& p, int batch, int bk, size_t ws_bytes) {
   if (!sl_env().split_k || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.N < 128 || (p.N & 3)) return 0;
   const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
   const int nkt = p.K / bk;
-  if (t128 > 200 || nkt < 32) return 0;          // from ~200 small tiles the chip is busy enough (two blocks per CU: 512 slots); short reductions
+  if (t128 > 256 || nkt < 32) return 0;          // above half the 512 slots (two blocks per CU) the chip is busy enough; short reductions
   int S = (int)(512 / t128);
   if (S > 8) S = 8;
   if (S > nkt / 12) S = nkt / 12;                // every run keeps >= 12 slabs (768 k) behind its prologue

@@ -79,7 +79,7 @@ int wgrad_acc(int dt, const void* dY, int64_t ldy, int n_out, const void* X, int
   a.C = dW; a.ldc = k_in; a.residual = dW; a.ldr = k_in; a.M = n_out; a.N = k_in; a.batch = 1; a.dtype = dt; a.out_f32 = 1;
   if (M >= 256) {
     // contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to whole K slabs): LDS-DMA tiled kernels
-    const int64_t Mp = rup(M, 64);
+    const int64_t Mp = rup(M, sk_ws ? 128 : 64);      // an even number of K slabs, so that the reduction can be cut in two runs (gemm.hip splitk_runs)
     SL_TRY(sl_transpose_pad(dY, ldy, s.yt, Mp, (int)M, n_out, (int)Mp, dt, (sl_stream)st));
     SL_TRY(sl_transpose_pad(X, ldx, s.xt, Mp, (int)M, k_in, (int)Mp, dt, (sl_stream)st));
     a.A = s.yt; a.lda = Mp; a.W = s.xt; a.ldw = Mp; a.K = (int)Mp;
@@ -199,7 +199,7 @@ struct EncWs {
 static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs& w) {
   const size_t sz = sl_dtype_size(c->dtype);
   const int64_t n = c->n_tok, H = c->hidden, F = c->ffn;
-  const int64_t Mp = rup(n, 64);
+  const int64_t Mp = rup(n, 128);
   const int64_t big = F > 3 * H ? F : 3 * H;
   Carver cv(base, cap);
   w.tmp_h = cv.take(n * H * sz);
@@ -298,7 +298,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(ss.join(2));                                   // tmp_h / d_h2 were the previous layer's d_o1 (read by its wo group)
     if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(dx, nullptr, w.tmp_h, n * H, c->p_hidden, sd[3], dt, stream)); d_o2 = w.tmp_h; }
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw));
+    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw, sk_w));
     SL_TRY(sl_colsum(d_o2, H, g.b2, n, H, dt, (sl_stream)sw));
     SL_TRY(ss.end(0));
     SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_mid, F, n, w.s, st));
@@ -306,7 +306,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(ss.join(1));                                   // d_pre1 was read by the previous layer's w1 group
     SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, w.d_pre1, n * F, dt, stream));
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw));
+    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w));
     SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, (sl_stream)sw));
     SL_TRY(ss.end(1));
     SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
@@ -325,7 +325,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(attn_bwd(dt, sv.qkv, 3 * H, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nh, 64, 0, 0.125f,
                     c->p_attn, sd[0], st));
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw));
+    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw, sk_w));
     SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, (sl_stream)sw));
     SL_TRY(ss.end(3));
     SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));

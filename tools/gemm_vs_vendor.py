@@ -26,6 +26,7 @@ for M in (7984, 3200, 5072, 1872):
 shapes += [(3200, 3072, 1024), (3200, 4096, 1024), (3200, 1024, 4096)]
 # the per-rank KD window (2 samples: 634 LLM rows, 998 encoder frames) and the decode rows
 shapes += [(634, 5120, 3072), (634, 3072, 3072), (634, 16384, 3072), (634, 3072, 8192), (634, 8192, 3072), (634, 3072, 16384),
+           (4096, 1024, 8064), (1024, 4096, 8064), (3072, 1024, 8064), (1024, 1024, 8064),      # the encoder's weight gradients of a 16-sample window (token rows padded to whole slab pairs)
            (998, 3072, 1024), (998, 4096, 1024), (998, 1024, 4096), (2048, 5120, 3072), (2048, 3072, 3072), (2048, 16384, 3072), (2048, 3072, 8192)]
 big = [(127744, 3072, 1024), (127744, 1024, 1024), (127744, 4096, 1024), (127744, 1024, 4096), (140288, 5120, 3072), (140288, 3072, 8192),
        (70144, 16384, 3072)]
