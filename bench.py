@@ -620,6 +620,7 @@ def main():
     ap.add_argument("--cpu-decode-steps", type=int, default=32, help="decode steps of the bounded CPU-oracle sample (SURVEY.md §8d: 32; ≈0.3-0.6 s per step)")
     ap.add_argument("--kd-optimizer-steps", type=int, default=3, help="optimizer steps of the KD training leg (0 = skip)")
     ap.add_argument("--kd-eval-mode", action="store_true", help="KD leg with the encoder's training-mode regularisers off")
+    ap.add_argument("--kd-order", choices=("auto", "first", "last"), default="auto", help="KD leg before or after the inference legs; auto = first on one GPU, last with N>1")
     ap.add_argument("--kd-timeout", type=float, default=600.0, help="N>1: seconds the KD leg may take before it is reported as failed")
     ap.add_argument("--no-eos-leg", action="store_true", help="skip the answers-of-different-lengths leg (per-sequence stop lengths, batch compaction)")
     ap.add_argument("--no-length-mix", action="store_true", help="skip the ragged dev-clean length-mix leg (rank 0, reported beside the headline)")
@@ -694,6 +695,47 @@ def main():
     del llm_sd
     wts = llm._dev()          # rope tables / split-attention workspace sized for the longest leg
     llm.max_ctx = max_ctx     # the headline's KV cache (and split-attention grid) is sized for its own context
+
+    # ---- KD training leg (BASELINE configs[2]): one optimizer step = grad_accum_interval micro-steps shared by the ranks,
+    # fp32 gradient buckets all-reduced with RCCL on a side stream while backward still runs.
+    # Order: on one GPU the leg runs BEFORE the inference legs (`--kd-order first`): behind 90 s of sustained inference the same
+    # kernels ran 4-6 % slower (clocks) than in a fresh process, and the leg is quoted as a step of training, not as the tail of a
+    # serving run.  With N > 1 it stays last: it is the only leg with collectives on its path, and a rank that fails alone must
+    # not be able to hang the headline line.  The three optimizer steps change the encoder's weights in place; throughput does not
+    # depend on their values.
+    import threading
+    kd_state = {"kd": None, "hung": False}
+
+    def run_kd_leg():
+        if args.kd_optimizer_steps <= 0:
+            return
+        box = {}
+
+        def run_kd():
+            torch.cuda.set_device(dev)
+            try:
+                box["kd"] = kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist)
+            except Exception as e:  # the inference line must survive a training-leg failure
+                box["kd"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        if dist is None:
+            run_kd()
+        else:
+            # bounded, so a rank that failed alone cannot hang the headline line
+            th = threading.Thread(target=run_kd, daemon=True)
+            th.start()
+            th.join(args.kd_timeout)
+            kd_state["hung"] = th.is_alive()
+        kd_state["kd"] = box.get("kd", {"error": f"no result after {args.kd_timeout} s (a collective did not complete)"})
+        if isinstance(kd_state["kd"], dict):
+            kd_state["kd"]["position"] = "before the inference legs" if kd_first else "after the inference legs"
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    kd_first = args.kd_order == "first" or (args.kd_order == "auto" and dist is None)
+    if kd_first:
+        run_kd_leg()
 
     # ---- synthetic inputs, resident in HBM -------------------------------------------------------------
     waves = [ri.synthetic_waveform(n_samples, seed=1234 + rank * 1000 + i).to(dev) for i in range(B)]
@@ -886,28 +928,9 @@ def main():
         attn_bytes = B * nkv * ctx_mid * D * 2 * 2 + 2 * B * nh * D * 2  # K and V rows once + q in / o out
         probes = {"gemm": (gemm_bytes, gemm_ms), "attn": (attn_bytes, attn_ms), "tiled_gu": tiled_gu}
 
-    # ---- KD training leg (BASELINE configs[2]): one optimizer step = grad_accum_interval micro-steps shared by the ranks,
-    # fp32 gradient buckets all-reduced with RCCL on a side stream while backward still runs
-    kd, kd_hung = None, False
-    if args.kd_optimizer_steps > 0:
-        box = {}
-
-        def run_kd():
-            torch.cuda.set_device(dev)
-            try:
-                box["kd"] = kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist)
-            except Exception as e:  # the inference line must survive a training-leg failure
-                box["kd"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-
-        if dist is None:
-            run_kd()
-        else:
-            # the only leg with collectives on its path: bounded, so a rank that failed alone cannot hang the headline line
-            th = threading.Thread(target=run_kd, daemon=True)
-            th.start()
-            th.join(args.kd_timeout)
-            kd_hung = th.is_alive()
-        kd = box.get("kd", {"error": f"no result after {args.kd_timeout} s (a collective did not complete)"})
+    if not kd_first:
+        run_kd_leg()
+    kd, kd_hung = kd_state["kd"], kd_state["hung"]
 
     def leave():
         sys.stdout.flush()
