@@ -251,7 +251,12 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(T* __restrict__ x, co
 // traffic (latency-bound: ~1 wave per SIMD, 8 rows one after the other).  Rows of <= 1 024 elements (every HuBERT / Whisper
 // LayerNorm: 512 conv channels, hidden 1 024) take MAXF = 16 and 16 waves per block: the same ~250 blocks, hence the same
 // number of atomics, but 16 rows in flight per CU instead of 4.
-template <typename T, bool RMS, int MAXF, int NW>
+// keeps the compiler from carrying the converted copy of a loaded vector from one pass to the next (it would: common subexpressions)
+__device__ __forceinline__ void reconvert_here(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// LEAN (rows without the fused GELU): a lane keeps its share of x and dy as LOADED (16-byte vectors) and converts them again in every
+// pass instead of holding xhat and dy * gamma as floats, and beta is not needed at all: the 16-wave form has 128 registers per lane
+// and the float copies made it spill 34 of them to scratch inside the row loop.  Same operations in the same order: same bits.
+template <typename T, bool RMS, int MAXF, int NW, bool LEAN = false>
 __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int64_t rows, int cols, float eps, int gelu, int rows_per_block,
@@ -271,11 +276,93 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
     for (int e = 0; e < VEC; ++e) { gg[i][e] = 0.f; bb[i][e] = 0.f; ag[i][e] = 0.f; ab[i][e] = 0.f; }
     if (ch < nch) {
       Vec16<T>::unpack(*(const uint4*)(g + ch * VEC), gg[i]);
-      if (!RMS) Vec16<T>::unpack(*(const uint4*)(b + ch * VEC), bb[i]);
+      if (!RMS && !LEAN) Vec16<T>::unpack(*(const uint4*)(b + ch * VEC), bb[i]);
     }
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block) < rows ? (r0 + rows_per_block) : rows;
+  if constexpr (LEAN) {
+    for (int64_t row = r0 + wave; row < r1; row += NW) {
+      uint4 xr[MAXCH], dr[MAXCH];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+          xr[i] = *(const uint4*)(x + row * cols + ch * VEC);
+          dr[i] = *(const uint4*)(dy + row * cols + ch * VEC);
+          float xv[VEC];
+          Vec16<T>::unpack(xr[i], xv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s += RMS ? xv[e] * xv[e] : xv[e];
+        }
+      }
+      s = wave_sum(s);
+      float mean = 0.f, rstd;
+      if constexpr (RMS) {
+        rstd = rsqrtf(s / (float)cols + eps);
+      } else {
+        mean = s / (float)cols;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+          if (lane + 64 * i < nch) {
+            float xv[VEC];
+            reconvert_here(xr[i]);
+            Vec16<T>::unpack(xr[i], xv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = xv[e] - mean; s2 += d * d; }
+          }
+        rstd = rsqrtf(wave_sum(s2) / (float)cols + eps);
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i)
+        if (lane + 64 * i < nch) {
+          float xv[VEC], dv[VEC];
+          reconvert_here(xr[i]);
+          reconvert_here(dr[i]);
+          Vec16<T>::unpack(xr[i], xv);
+          Vec16<T>::unpack(dr[i], dv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float xh = (xv[e] - mean) * rstd;
+            const float d = dv[e];
+            ag[i][e] += d * xh;
+            ab[i][e] += d;
+            const float dg = d * gg[i][e];
+            s1 += dg;
+            s2 += dg * xh;
+          }
+        }
+      s1 = wave_sum(s1) / (float)cols;
+      s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+          float xv[VEC], dv[VEC], o[VEC];
+          reconvert_here(xr[i]);
+          reconvert_here(dr[i]);
+          Vec16<T>::unpack(xr[i], xv);
+          Vec16<T>::unpack(dr[i], dv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float xh = (xv[e] - mean) * rstd;
+            const float dg = dv[e] * gg[i][e];
+            o[e] = RMS ? rstd * (dg - xh * s2) : rstd * (dg - s1 - xh * s2);
+          }
+          if (add) {
+            float av[VEC];
+            Vec16<T>::unpack(*(const uint4*)(add + row * cols + ch * VEC), av);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = to_f32(from_f32<T>(o[e])) + av[e];
+          }
+          *(uint4*)(dx + row * cols + ch * VEC) = Vec16<T>::pack(o);
+        }
+      }
+    }
+  } else
   for (int64_t row = r0 + wave; row < r1; row += NW) {
     float xv[MAXCH][VEC], dv[MAXCH][VEC];
     float s = 0.f;
@@ -1033,8 +1120,12 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
       int rpb = 16;
       const int nb = ln_bwd_ws_blocks(rows, &rpb);
       SL_DISPATCH_DTYPE(dtype, T, {
-        hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                           (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws, (const T*)add);
+        if (gelu)
+          hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws, (const T*)add);
+        else
+          hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16, true>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add);
       });
       SL_CHECK_LAUNCH("layernorm_bwd");
       hipLaunchKernelGGL(norm_colreduce_kernel, dim3((unsigned)((2 * cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nb, cols, dgamma,
@@ -1049,8 +1140,12 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
     int rpb16 = (int)ceil_div64(ceil_div64(rows, lnb), 16) * 16;
     rpb16 = rpb16 < 16 ? 16 : rpb16;
     SL_DISPATCH_DTYPE(dtype, T, {
-      hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)ceil_div64(rows, rpb16)), dim3(1024), 0, (hipStream_t)stream, (const T*)x,
-                         (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb16, (float*)nullptr, (const T*)add);
+      if (gelu)
+        hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)ceil_div64(rows, rpb16)), dim3(1024), 0, (hipStream_t)stream, (const T*)x,
+                           (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb16, (float*)nullptr, (const T*)add);
+      else
+        hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16, true>), dim3((unsigned)ceil_div64(rows, rpb16)), dim3(1024), 0, (hipStream_t)stream, (const T*)x,
+                           (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb16, (float*)nullptr, (const T*)add);
     });
     SL_CHECK_LAUNCH("layernorm_bwd");
     return 0;
