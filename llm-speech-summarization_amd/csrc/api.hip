@@ -58,6 +58,7 @@ static const SlEnv* env_load() {
   e.decode_tiled = env_int("SL_DECODE_TILED", 1);
   e.stream_k = env_int("SL_STREAM_K", 1);
   e.split_k = env_int("SL_SPLIT_K", 1);
+  e.wgrad_tr = env_int("SL_WGRAD_TR", 1);
   e.skinny_alt = env_int("SL_SKINNY_ALT", 0);
   e.prefill_share_prefix = env_int("SL_PREFILL_SHARE_PREFIX", 1);
   e.gemm_ko = env_int("SL_GEMM_KO", 0);

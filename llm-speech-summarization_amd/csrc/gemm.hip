@@ -805,6 +805,140 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// Both operands K-MAJOR (the weight-gradient product dW (No, Ni) += dY^T X with dY (tokens, No) and X (tokens, Ni) row-major, reduction
+// over the token rows): 128 x 128 tile, LDS-DMA staging of [64 token rows][128 columns] slabs (256-byte rows), fragments by
+// ds_read_b64_tr_b16 — a 16-lane group gathers 4 token rows x 16 columns and lane i receives column i's four values, i.e. four
+// consecutive k of output row i; two reads make the 16-byte MFMA operand.  No transposed copies of dY / X are made (sl_transpose_pad
+// read + wrote each of them once per product: 4 % of a KD window).  bf16 only.
+//   LDS image: row = token row of the slab (256 B = eight 32-byte slots of 16 columns); slot s of row r sits at physical slot
+//   s ^ f(r), f = (r & 3) | (((r >> 3) & 1) << 2): the 16 row segments one wave-wide read touches (rows 8g + {0..3} (+4), g = 0..3) fall on
+//   every 32-byte bank group exactly twice — the rate of a 512-byte read.  As in the kernels above the swizzle is applied to the
+//   per-lane SOURCE address of the DMA.
+//   K (token) tail: rows past K are fetched from a 16-byte zero constant.  blockIdx.y = K run (split-K: fp32 partial tiles to
+//   C + run * sC, summed by splitk_reduce_kernel), every run a whole number of slabs.
+// ----------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+#define SL_LDS_RD_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_tt_t;
+template <int N>
+__device__ __forceinline__ void lds_wait_tr16(u32x2_tt_t (&a)[8], u32x2_tt_t (&b)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%16)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]),
+                 "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+               : "n"(N));
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_tiled_tt_kernel(GemmP p, int slabs_per_run) {
+  using T = bf16_t;
+  constexpr int BK = 64;                       // token rows per slab
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BK * 256];   // [buf][A|W]: 64 rows x 256 B = 16 KiB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, q = lane >> 4;
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int qn = nt >> 3, rn = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int bm = bid % p.tiles_m, bn = bid / p.tiles_m;
+  const int z = blockIdx.y;
+  const int nkt_all = (p.K + BK - 1) / BK;
+  const int kt0 = z * slabs_per_run;
+  int kt1 = kt0 + slabs_per_run;
+  kt1 = kt1 < nkt_all ? kt1 : nkt_all;
+  const T* A = (const T*)p.A;
+  const T* W = (const T*)p.W;
+
+  // LDS chunk c = tid + 256 i sits at (row c >> 4, physical chunk c & 15) and must hold logical chunk ((pc >> 1) ^ f(row)) << 1 | (pc & 1)
+  const T* ga[4];
+  const T* gw[4];
+  int grow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    const int lc = (((pc >> 1) ^ f) << 1) | (pc & 1);
+    grow[i] = row;
+    ga[i] = A + (int64_t)row * p.lda + bm * TBM + lc * 8;
+    gw[i] = W + (int64_t)row * p.ldw + bn * TBN + lc * 8;
+  }
+  const int wave_lds = __builtin_amdgcn_readfirstlane(wave) * 1024;
+  const T* zero = (const T*)g_zero16;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool in = k0 + grow[i] < p.K;
+      const T* sa = in ? ga[i] + (int64_t)k0 * p.lda : zero;
+      const T* sw = in ? gw[i] + (int64_t)k0 * p.ldw : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)sa, (lds_ptr_t)(&smem[buf][0][i * 4096 + wave_lds]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)sw, (lds_ptr_t)(&smem[buf][1][i * 4096 + wave_lds]), 16, 0, 0);
+    }
+  };
+
+  // fragment addresses: lane (li = r, g = q) asks for token row 8 g + (li >> 2) (+ 4 for the upper half, + 32 for the second k-step: immediates),
+  // piece li & 3 of the 32-byte slot of its 16 columns; slot (4 wm + m) ^ f, f = (li >> 2) | ((g & 1) << 2)
+  const int qq = r >> 2, pp = r & 3;
+  const int f = qq | ((q & 1) << 2);
+  uint32_t aa[4], ab[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    aa[m] = (uint32_t)((8 * q + qq) * 256 + (((4 * wm + m) ^ f) << 5) + pp * 8);
+    ab[m] = (uint32_t)((8 * q + qq) * 256 + (((4 * wn + m) ^ f) << 5) + pp * 8);
+  }
+  const uint32_t sb0 = (uint32_t)(uintptr_t)(lds_ptr_t)(&smem[0][0][0]);
+
+  if (kt0 < kt1) {
+    issue(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) issue(kt + 1, buf ^ 1);
+    const uint32_t sa = sb0 + (uint32_t)buf * (2 * BK * 256), sw = sa + BK * 256;
+    u32x2_tt_t a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { SL_LDS_RD_TR(a0[2 * m], sa + aa[m], 0); SL_LDS_RD_TR(a0[2 * m + 1], sa + aa[m], 1024); }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { SL_LDS_RD_TR(b0[2 * m], sw + ab[m], 0); SL_LDS_RD_TR(b0[2 * m + 1], sw + ab[m], 1024); }
+    lds_wait_tr16<0>(a0, b0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { SL_LDS_RD_TR(a1[2 * m], sa + aa[m], 8192); SL_LDS_RD_TR(a1[2 * m + 1], sa + aa[m], 9216); }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { SL_LDS_RD_TR(b1[2 * m], sw + ab[m], 8192); SL_LDS_RD_TR(b1[2 * m + 1], sw + ab[m], 9216); }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        MMA<T>::step(acc[m][n], make_uint4(a0[2 * m].x, a0[2 * m].y, a0[2 * m + 1].x, a0[2 * m + 1].y), make_uint4(b0[2 * n].x, b0[2 * n].y, b0[2 * n + 1].x, b0[2 * n + 1].y));
+    __builtin_amdgcn_sched_barrier(0);
+    lds_wait_tr16<0>(a1, b1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        MMA<T>::step(acc[m][n], make_uint4(a1[2 * m].x, a1[2 * m].y, a1[2 * m + 1].x, a1[2 * m + 1].y), make_uint4(b1[2 * n].x, b1[2 * n].y, b1[2 * n + 1].x, b1[2 * n + 1].y));
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!p.direct_epi && tile_epilogue_rows<T, ACT, 4>(p, acc, bm * TBM + wm * 64, bn * TBN + wn * 64, lane, z, 0, (float*)&smem[0][0][0] + wave * 4096)) return;
+  tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, 0);
+}
+
+// ----------------------------------------------------------------------------------------------
 // 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each), same K slabs / swizzled LDS image / LDS-DMA staging as above.
 // Why: measured, a CU sustains only ~40 GB/s of operand fetches (L2 hits + HBM through one miss queue) — the 128^2 tile
 // needs 32 KiB per 2*128*128*64 FLOP and tops out at 600-980 TF/s on that, not on the MFMA pipe.  The 256^2 tile halves
@@ -1636,9 +1770,53 @@ static int splitk_runs(const GemmP& p, int batch, int bk, size_t ws_bytes) {
   return S >= 2 ? S : 0;
 }
 
+// both operands K-major (weight gradients): gemm_tiled_tt_kernel, with the reduction cut into S runs of whole slabs when the tiles alone
+// leave CUs idle (two blocks per CU: 512 slots) and the caller supplied a workspace
+template <typename T>
+static bool tt_ok(const GemmP& p, int batch) {
+  if (sizeof(T) != 2 || !sl_env().wgrad_tr || !p.ta || !p.tw || batch != 1 || p.grp || p.aux || p.ln_mr || p.stats_out || p.amax_val) return false;
+  return p.M % TBM == 0 && p.N % TBN == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.K >= 128 && p.wx == 0 && p.cx == 0 && p.rx == 0;
+}
+
+template <typename T>
+static int launch_tt(GemmP& p, hipStream_t st, void* sk_ws, size_t sk_ws_bytes) {
+  p.tiles_m = p.M / TBM;
+  p.tiles_n = p.N / TBN;
+  const int nt = p.tiles_m * p.tiles_n, nkt = (p.K + 63) / 64;
+  int S = 1;
+  const size_t ws = sk_ws && sk_ws_bytes > SK_FLAG_BYTES ? sk_ws_bytes - SK_FLAG_BYTES : 0;
+  if (ws && nt < 512 && !(p.N & 3)) {
+    S = 512 / nt;
+    if (S > 8) S = 8;
+    if (S > nkt / 12) S = nkt / 12;
+    while (S > 1 && (size_t)S * p.M * p.N * sizeof(float) > ws) --S;
+    if (S < 1) S = 1;
+  }
+  const int spr = (nkt + S - 1) / S;
+  S = (nkt + spr - 1) / spr;
+  if (S == 1) {
+    hipLaunchKernelGGL((gemm_tiled_tt_kernel<SL_ACT_NONE>), dim3(nt, 1), dim3(256), 0, st, p, spr);
+    SL_CHECK_LAUNCH("gemm_tiled_tt");
+    return 0;
+  }
+  float* part = (float*)((unsigned char*)sk_ws + SK_FLAG_BYTES);
+  GemmP q = p;
+  q.C = part; q.ldc = p.N; q.sC = (int64_t)p.M * p.N; q.out_f32 = 1;
+  q.bias = nullptr; q.sBias = 0; q.res = nullptr; q.ldr = 0; q.sR = 0; q.res_f32 = 0;
+  hipLaunchKernelGGL((gemm_tiled_tt_kernel<SL_ACT_NONE>), dim3(nt, S), dim3(256), 0, st, q, spr);
+  SL_CHECK_LAUNCH("gemm_tiled_tt (K runs)");
+  const int64_t vecs = ((int64_t)p.M * p.N + 3) / 4;
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, part, S, (int64_t)p.M * p.N, p);
+  SL_CHECK_LAUNCH("splitk_reduce");
+  return 0;
+}
+
 template <typename T, int ACT>
 static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
   constexpr int BK_ = TROWB / (int)sizeof(T);
+  if constexpr (ACT == SL_ACT_NONE && sizeof(T) == 2) {
+    if (tt_ok<T>(p, batch)) return launch_tt<T>(p, st, sk_ws, sk_ws_bytes);
+  }
   if constexpr (ACT == SL_ACT_NONE) {
     if (sk_ws) {
       const int S = splitk_runs(p, batch, BK_, sk_ws_bytes > SK_FLAG_BYTES ? sk_ws_bytes - SK_FLAG_BYTES : 0);

@@ -77,6 +77,13 @@ int wgrad_acc(int dt, const void* dY, int64_t ldy, int n_out, const void* X, int
   memset(&ex, 0, sizeof(ex));
   ex.w_mod = 1; ex.residual_f32 = 1;
   a.C = dW; a.ldc = k_in; a.residual = dW; a.ldr = k_in; a.M = n_out; a.N = k_in; a.batch = 1; a.dtype = dt; a.out_f32 = 1;
+  if (M >= 256 && sl_env().wgrad_tr && dt == SL_BF16 && n_out % 128 == 0 && k_in % 128 == 0 && ldy % 8 == 0 && ldx % 8 == 0) {
+    // both operands as stored (token-major): gemm_tiled_tt_kernel gathers its fragments with transposing LDS reads
+    ex.trans_a = 1; ex.trans_w = 1;
+    a.A = dY; a.lda = ldy; a.W = X; a.ldw = ldx; a.K = (int)M;
+    if (sk_ws) { ex.sk_ws = sk_ws; ex.sk_ws_bytes = sl_gemm_streamk_workspace_bytes(); }
+    return sl_gemm_ex(&a, &ex, (sl_stream)st);
+  }
   if (M >= 256) {
     // contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to whole K slabs): LDS-DMA tiled kernels
     const int64_t Mp = rup(M, sk_ws ? 128 : 64);      // an even number of K slabs, so that the reduction can be cut in two runs (gemm.hip splitk_runs)

@@ -4,6 +4,7 @@ on the current torch stream; nothing here computes on the CPU.
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -431,6 +432,11 @@ def wgrad_acc(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, ldx: Optio
     M = dY.shape[0] if M is None else M
     Nout = dY.shape[1]
     Kin = X.shape[1] if Kin is None else Kin
+    if (ldx is None and M >= 256 and dY.dtype == torch.bfloat16 and Nout % 128 == 0 and Kin % 128 == 0 and dY.stride(0) % 8 == 0 and X.stride(0) % 8 == 0
+            and os.environ.get("SL_WGRAD_TR", "1") != "0"):
+        # token-major operands as stored: the library's gemm_tiled_tt_kernel gathers its fragments with transposing LDS reads (no copies)
+        return gemm_ex(dY, X, M=Nout, N=Kin, K=M, lda=dY.stride(0), ldw=X.stride(0), out=dW, ldc=dW.stride(0), residual=dW, ldr=dW.stride(0),
+                       out_f32=True, residual_f32=True, trans_a=True, trans_w=True, dtype=dY.dtype)
     if ldx is None and M >= 256:
         # plain Linear: contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to a whole number of K slabs) so
         # the product runs the LDS-DMA tiled kernels; the doubly-transposed register loader measured ~100 TF/s on these shapes

@@ -2,6 +2,7 @@
 
 Tolerances: fp32 2e-5 relative L2 (3e-4 where fp32 atomics reorder a long reduction), bf16 2e-2.
 """
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -87,6 +88,45 @@ def test_gelu_silu_rope_backward(dt):
     assert torch.equal(xd[:, 384:], x.to(DEV, dt)[:, 384:])  # 4th head untouched
     ops.rope_inplace(xd, pos.to(DEV), cos.to(DEV), sin.to(DEV), 4, 3, 128, inverse=True)
     assert rel_err(xd.float().cpu(), q(x, dt)) < (1e-6 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("ws", [False, True])
+@pytest.mark.parametrize("M,Nout,Kin,ldy,ldx", [(7984, 1024, 1024, 1024, 1024), (7984, 1024, 1024, 3072, 1024), (1000, 1024, 4096, 1024, 4096),
+                                                   (256, 128, 128, 128, 136), (3999, 512, 512, 512, 512), (7984, 3072, 1024, 3072, 1024),
+                                                   (130, 128, 256, 128, 256)])
+def test_wgrad_token_major_operands(M, Nout, Kin, ldy, ldx, ws):
+    """SL_WGRAD_TR=1 (the default): dW += dY^T X straight from the token-major operands (gemm_tiled_tt_kernel: LDS-DMA of [64 tokens][128 columns]
+    slabs, fragments by transposing LDS reads, token tail from a zero constant, the reduction optionally cut into runs) against the
+    fp32 product of the same bf16 values and against the default path through K-contiguous transposed copies."""
+    dt = torch.bfloat16
+    dYb = rnd(M, ldy, seed=41).to(DEV, dt)
+    Xb = rnd(M, ldx, seed=42).to(DEV, dt)
+    dW0 = rnd(Nout, Kin, seed=43).to(DEV)
+    ref = dW0.double() + dYb[:, :Nout].double().t() @ Xb[:, :Kin].double()
+    sk = ops.streamk_workspace(DEV) if ws else None
+
+    def run():
+        dW = dW0.clone()
+        ops.gemm_ex(dYb, Xb, M=Nout, N=Kin, K=M, lda=ldy, ldw=ldx, out=dW, ldc=Kin, residual=dW, ldr=Kin, out_f32=True, residual_f32=True,
+                    trans_a=True, trans_w=True, dtype=dt, sk_ws=sk)
+        return dW
+
+    os.environ["SL_WGRAD_TR"] = "0"
+    try:
+        L.lib().sl_tuning_reload()
+        base = run()                  # the register-staged transposed loader these flags selected before
+        os.environ["SL_WGRAD_TR"] = "1"
+        L.lib().sl_tuning_reload()
+        tt = run()
+        tt2 = run()
+    finally:
+        del os.environ["SL_WGRAD_TR"]
+        L.lib().sl_tuning_reload()
+    assert torch.equal(tt, tt2)       # fixed summation order: reproducible
+    assert rel_err(tt.double().cpu(), ref.cpu()) < 1e-5, rel_err(tt.double().cpu(), ref.cpu())
+    assert rel_err(tt.cpu(), base.cpu()) < 1e-5
+    if sk is not None:
+        assert int(sk[:1024].to(torch.int32).sum().item()) == 0      # the flag area in front of the partial tiles stays zero
 
 
 @pytest.mark.parametrize("dt", DT)
