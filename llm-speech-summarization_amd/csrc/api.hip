@@ -59,6 +59,8 @@ static const SlEnv* env_load() {
   e.stream_k = env_int("SL_STREAM_K", 1);
   e.split_k = env_int("SL_SPLIT_K", 1);
   e.wgrad_tr = env_int("SL_WGRAD_TR", 1);
+  e.tt_max_splits = env_int("SL_TT_MAX_SPLITS", 8);
+  e.lnbwd_nw = env_int("SL_LNBWD_NW", 16);
   e.skinny_alt = env_int("SL_SKINNY_ALT", 0);
   e.prefill_share_prefix = env_int("SL_PREFILL_SHARE_PREFIX", 1);
   e.gemm_ko = env_int("SL_GEMM_KO", 0);

@@ -233,6 +233,8 @@ struct SlEnv {
   int decode_tiled;        // SL_DECODE_TILED      1 (default) = decode steps above ~900 rows run o and gate/up on the row-major 256-tile kernels, 0 = streaming forms
   int prefill_share_prefix; // SL_PREFILL_SHARE_PREFIX 1 (default) = prefill computes a shared prompt prefix (sl_kv_cache.shared_prefix) once per batch, 0 = per sequence (A/B)
   int skinny_alt;          // SL_SKINNY_ALT        1 = o / down at M <= 8 keep the two-steps-in-flight structure of the larger row counts (A/B)
+  int tt_max_splits;       // SL_TT_MAX_SPLITS     8 (default): most K runs of a token-major weight-gradient product (tuning)
+  int lnbwd_nw;            // SL_LNBWD_NW          16 (default) | 8 | 4: waves per block of the LayerNorm backward for rows <= 1 024 elements (tuning)
   int wgrad_tr;            // SL_WGRAD_TR          1 (default) = weight gradients read dY and X as stored (gemm_tiled_tt_kernel), 0 = through K-contiguous transposed copies (A/B)
   int split_k;             // SL_SPLIT_K           1 (default) = products of few tiles whose caller supplies a workspace (sk_ws) run as S batched K runs + a fixed-order reduce launch, 0 = off (A/B)
   int stream_k;            // SL_STREAM_K          stream-K form of the 256-tile GEMM when a workspace is supplied: 0 = never, 1 = by rule (default), 2 = whenever the form allows

@@ -1787,7 +1787,8 @@ static int launch_tt(GemmP& p, hipStream_t st, void* sk_ws, size_t sk_ws_bytes) 
   const size_t ws = sk_ws && sk_ws_bytes > SK_FLAG_BYTES ? sk_ws_bytes - SK_FLAG_BYTES : 0;
   if (ws && nt < 512 && !(p.N & 3)) {
     S = 512 / nt;
-    if (S > 8) S = 8;
+    const int smax = sl_env().tt_max_splits > 0 ? sl_env().tt_max_splits : 8;
+    if (S > smax) S = smax;
     if (S > nkt / 12) S = nkt / 12;
     while (S > 1 && (size_t)S * p.M * p.N * sizeof(float) > ws) --S;
     if (S < 1) S = 1;

@@ -1096,16 +1096,22 @@ extern "C" int sl_rope_inplace(void* x, const int32_t* tok_pos, const float* cos
 
 // blocks of the scratch-buffer form: 16 rows in flight per block (16 waves), ~one block per CU (a block pays for its gain / bias
 // loads and the LDS fold of its partials whatever its share of the rows: 500 blocks of 16 rows took 47 us on 7 984 x 1 024)
+static int ln_bwd_nw() { const int n = sl_env().lnbwd_nw; return n == 4 || n == 8 ? n : 16; }
 static int ln_bwd_ws_blocks(int64_t rows, int* rpb_out) {
-  int rpb = (int)ceil_div64(ceil_div64(rows, 256), 16) * 16;
-  rpb = rpb < 16 ? 16 : rpb;
+  const int nw = ln_bwd_nw();
+  int rpb = (int)ceil_div64(ceil_div64(rows, 256 * (16 / nw)), nw) * nw;      // the same rows in flight per CU whatever the block size
+  rpb = rpb < nw ? nw : rpb;
   if (rpb_out) *rpb_out = rpb;
   return (int)ceil_div64(rows, rpb);
 }
 
 extern "C" size_t sl_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
   if (rows <= 0 || cols <= 0 || cols > 64 * 16) return 0;     // wider rows take the general (atomics) form
-  return (size_t)ln_bwd_ws_blocks(rows, nullptr) * 2 * (size_t)cols * sizeof(float);
+  // sized for the smallest block form (SL_LNBWD_NW=4: four times the blocks), so that the tuning switch can change under a live workspace
+  const int64_t rpb4 = ceil_div64(ceil_div64(rows, 1024), 4) * 4;
+  const size_t nb_max = (size_t)ceil_div64(rows, rpb4 < 4 ? 4 : rpb4);
+  const size_t nb = (size_t)ln_bwd_ws_blocks(rows, nullptr);
+  return (nb_max > nb ? nb_max : nb) * 2 * (size_t)cols * sizeof(float);
 }
 
 static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta, int64_t rows,
@@ -1116,13 +1122,19 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_layernorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
   if (rows == 0) return 0;
   if (cols <= 64 * 16) {      // <= 1 024 elements per row: 16 floats per lane, 16 waves per block
-    if (ws && dgamma && dbeta && ws_bytes >= sl_layernorm_bwd_ws_bytes(rows, cols)) {
-      int rpb = 16;
-      const int nb = ln_bwd_ws_blocks(rows, &rpb);
+    int rpb = 16;
+    const int nb = ln_bwd_ws_blocks(rows, &rpb);
+    if (ws && dgamma && dbeta && ws_bytes >= (size_t)nb * 2 * (size_t)cols * sizeof(float)) {
       SL_DISPATCH_DTYPE(dtype, T, {
         if (gelu)
           hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
                              (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws, (const T*)add);
+        else if (ln_bwd_nw() == 8)
+          hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 8, true>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add);
+        else if (ln_bwd_nw() == 4)
+          hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 4, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add);
         else
           hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16, true>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
                              (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add);
