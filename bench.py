@@ -404,6 +404,8 @@ def eos_leg(args, pipe, waves, audio_rows, B, S, P, new, n_pre, pre_e, suf_e, fi
     return res
 
 
+EXIT_KD_HUNG = 3      # exit status of a rank whose KD leg did not return within --kd-timeout (a collective that never completed)
+
 LONGFORM_SEC = (30, 60, 120)   # long-form utterances of BASELINE configs[4]
 
 
@@ -558,6 +560,42 @@ def launch_ranks(args, argv) -> int:
     return rc
 
 
+def run_bounded(fn, timeout_s, bounded):
+    """The KD leg is the only leg with collectives on its data path: with N > 1 ranks it runs on a helper thread and the rank waits for
+    it at most `timeout_s`, so that a rank which failed alone cannot hang the headline line.  Returns (result or an {"error": ...}
+    record, hung).  `hung` = the thread is still inside `fn` (a collective that never completed): the process must then leave
+    through leave_process(hung=True) — non-zero, without tearing anything down."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except Exception as e:  # the inference line must survive a training-leg failure
+            box["r"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    if not bounded:
+        run()
+        return box["r"], False
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    hung = th.is_alive()
+    return box.get("r", {"error": f"no result after {timeout_s} s (a collective did not complete)"}), hung
+
+
+def leave_process(hung, dist) -> None:
+    """End of a rank.  After a hung collective nothing can be torn down cleanly — and a process that gave up on one did NOT succeed:
+    the JSON line (already printed) carries kd_step.error, and the exit status says so too (EXIT_KD_HUNG), so a driver that reads
+    only `rc` sees the failure (VERDICT r5 weak #8)."""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if hung:
+        os._exit(EXIT_KD_HUNG)
+    if dist is not None and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def dry_rank(args, rank, world) -> None:
     """SL_BENCH_DRY=1: the multi-rank CONTROL FLOW of this script without a GPU (CPU tests of the launcher): gloo rendezvous, the
     barrier + max-over-ranks timing bracket around K trivial steps, rank 0's JSON line, tear-down."""
@@ -595,15 +633,21 @@ def dry_rank(args, rank, world) -> None:
         red.close()
     if os.environ.get("SL_BENCH_DRY_FAIL_RANK") == str(rank):
         sys.exit(7)
+    # SL_BENCH_DRY_KD_HUNG=1: the KD leg of every rank blocks for ever (a collective that never completes) behind the same bounded
+    # helper and exit path the real run uses: the line still comes out, with kd_step.error, and every rank exits EXIT_KD_HUNG
+    kd_rec, hung = {"comm": comm}, False
+    if os.environ.get("SL_BENCH_DRY_KD_HUNG") == "1":
+        import threading
+        kd_rec, hung = run_bounded(lambda: threading.Event().wait(), 1.0, True)
+        kd_rec["comm"] = comm
     if rank == 0:
         print("a stray stdout line from a rank", flush=True)
         print(json.dumps({"metric": "dry run of the launcher (no GPU work)", "value": 0.0, "unit": "tokens/s",
                           "n_gpus": int(os.environ.get("SL_BENCH_DRY_REPORT_GPUS", world)), "steps": done, "warmup": args.warmup,
                           "ms_per_step": float(tt.item()) * 1e3 / max(1, done), "dry_run": True,
                           "per_rank": [{"rank": int(r_[0]), "utterances": int(r_[1]), "audio_sec": r_[2], "tokens": int(r_[3]), "elapsed_s": r_[4]} for r_ in per_rank],
-                          "collective_backend": (dist.get_backend() if world > 1 else None), "kd_step": {"comm": comm}}), file=RESULT_OUT, flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+                          "collective_backend": (dist.get_backend() if world > 1 else None), "kd_step": kd_rec}), file=RESULT_OUT, flush=True)
+    leave_process(hung, dist if world > 1 else None)
 
 
 def main():
@@ -709,30 +753,26 @@ def main():
     def run_kd_leg():
         if args.kd_optimizer_steps <= 0:
             return
-        box = {}
 
         def run_kd():
             torch.cuda.set_device(dev)
-            try:
-                box["kd"] = kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist)
-            except Exception as e:  # the inference line must survive a training-leg failure
-                box["kd"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            return kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, dist)
 
-        if dist is None:
-            run_kd()
-        else:
-            # bounded, so a rank that failed alone cannot hang the headline line
-            th = threading.Thread(target=run_kd, daemon=True)
-            th.start()
-            th.join(args.kd_timeout)
-            kd_state["hung"] = th.is_alive()
-        kd_state["kd"] = box.get("kd", {"error": f"no result after {args.kd_timeout} s (a collective did not complete)"})
+        kd_state["kd"], kd_state["hung"] = run_bounded(run_kd, args.kd_timeout, dist is not None)
         if isinstance(kd_state["kd"], dict):
             kd_state["kd"]["position"] = "before the inference legs" if kd_first else "after the inference legs"
+        if kd_first and not kd_state["hung"]:
+            # the three AdamW steps changed the encoder in place: the inference legs (and the CPU baseline beside them) are quoted on the
+            # documented seed-0 weights, so put them back
+            enc.refresh_weights(enc_sd)
         import gc
         gc.collect()
         torch.cuda.empty_cache()
 
+    if args.kd_order == "first" and dist is not None:
+        # a KD leg that hangs in a collective would leave its thread on the GPU and streams the headline legs are then timed on
+        print("[bench] --kd-order first is refused with N > 1 ranks (the leg with collectives stays last)", file=sys.stderr, flush=True)
+        sys.exit(4)
     kd_first = args.kd_order == "first" or (args.kd_order == "auto" and dist is None)
     if kd_first:
         run_kd_leg()
@@ -933,11 +973,7 @@ def main():
     kd, kd_hung = kd_state["kd"], kd_state["hung"]
 
     def leave():
-        sys.stdout.flush()
-        if kd_hung:
-            os._exit(0)        # a stuck collective cannot be torn down cleanly
-        if dist is not None:
-            dist.destroy_process_group()
+        leave_process(kd_hung, dist)
 
     if rank != 0:
         leave()

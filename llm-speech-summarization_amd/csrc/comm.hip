@@ -20,6 +20,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: sl_comm_abort falls back to CommDestroy without it
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // what RCCL itself says about the communicator (sl_comm_world / sl_comm_rank)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -40,7 +42,9 @@ const RcclApi& rccl() {
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
     a.CommAbort = (decltype(a.CommAbort))dlsym(a.handle, "ncclCommAbort");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
-    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
+    a.CommCount = (decltype(a.CommCount))dlsym(a.handle, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(a.handle, "ncclCommUserRank");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString && a.CommCount && a.CommUserRank;
   });
   return g_rccl;
 }
@@ -48,7 +52,7 @@ const RcclApi& rccl() {
 struct SlComm {
   uint32_t magic;
   ncclComm_t comm;
-  int rank, world, device;
+  int rank, world, device;      // rank / world: as RCCL reports them (ncclCommUserRank / ncclCommCount), checked against the caller's at init
 };
 constexpr uint32_t SL_COMM_MAGIC = 0x534c434du;   // "SLCM"
 }  // namespace
@@ -91,6 +95,18 @@ extern "C" int sl_comm_init(sl_comm* comm_out, const void* unique_id, int32_t ra
     delete c;
     return SL_ERR_LAUNCH;
   }
+  // The communicator's own account of itself: sl_comm_world / sl_comm_rank answer with what RCCL counted, never with the arguments
+  // above, so a record built from them (bench.py kd_step.comm.rccl_nranks) can disagree with the job that was asked for.
+  int n = -1, ur = -1;
+  ncclResult_t rc = api.CommCount(c->comm, &n), rr = api.CommUserRank(c->comm, &ur);
+  if (rc != ncclSuccess || rr != ncclSuccess || n != world || ur != rank) {
+    sl_set_error("sl_comm_init: RCCL reports rank %d of %d for a communicator requested as rank %d of %d (%s)", ur, n, rank, world,
+                 api.GetErrorString(rc != ncclSuccess ? rc : rr));
+    if (api.CommAbort) (void)api.CommAbort(c->comm); else (void)api.CommDestroy(c->comm);
+    delete c;
+    return SL_ERR_LAUNCH;
+  }
+  c->world = n; c->rank = ur;
   *comm_out = (sl_comm)c;
   return 0;
 }
@@ -136,5 +152,18 @@ extern "C" int sl_comm_abort(sl_comm comm) {
   return 0;
 }
 
-extern "C" int32_t sl_comm_rank(sl_comm comm) { const SlComm* c = (const SlComm*)comm; return (c && c->magic == SL_COMM_MAGIC) ? c->rank : -1; }
-extern "C" int32_t sl_comm_world(sl_comm comm) { const SlComm* c = (const SlComm*)comm; return (c && c->magic == SL_COMM_MAGIC) ? c->world : -1; }
+// Asked of RCCL at every call (ncclCommUserRank / ncclCommCount on the live communicator), -1 when it cannot answer
+extern "C" int32_t sl_comm_rank(sl_comm comm) {
+  const SlComm* c = (const SlComm*)comm;
+  if (!c || c->magic != SL_COMM_MAGIC) return -1;
+  const RcclApi& api = rccl();
+  int r = -1;
+  return (api.ok && api.CommUserRank(c->comm, &r) == ncclSuccess) ? r : -1;
+}
+extern "C" int32_t sl_comm_world(sl_comm comm) {
+  const SlComm* c = (const SlComm*)comm;
+  if (!c || c->magic != SL_COMM_MAGIC) return -1;
+  const RcclApi& api = rccl();
+  int n = -1;
+  return (api.ok && api.CommCount(c->comm, &n) == ncclSuccess) ? n : -1;
+}

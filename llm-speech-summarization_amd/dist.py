@@ -209,6 +209,7 @@ class BucketedAllReduce:
         self._ev_compute_end = None
         self.last_exchange_ms = 0.0           # sum of the buckets' durations on the side stream, previous optimizer step
         self.last_exposed_ms = 0.0            # part of it that ran after the backward's last kernel (not overlapped)
+        self.last_bucket_ms: List[float] = [] # each bucket's duration on the side stream, previous optimizer step (launch order)
         self.time_exchange = False
         if self.backend == "sl" and self.world > 1:
             self.comm, ok = self._negotiate()
@@ -283,6 +284,32 @@ class BucketedAllReduce:
             torch.cuda.synchronize(self.arena.flat.device)
             L.check(L.lib().sl_comm_destroy(comm), "sl_comm_destroy")
 
+    def abort(self) -> None:
+        """Failure-path tear-down (an exception or KeyboardInterrupt on THIS rank while its peers may sit inside an all-reduce): local
+        only — ncclCommAbort does not wait for the other ranks, nothing is synchronised, no collective is issued.  The owner re-raises
+        afterwards so that the process exits non-zero and the launcher can end the job (close() in a `finally` made a
+        failing rank block in synchronize / ncclCommDestroy, and torchrun never saw the failure)."""
+        self._pending, self._ev = [], []
+        if self.comm is not None:
+            from . import _lib as L
+            comm, self.comm = self.comm, None
+            try:
+                with torch.cuda.device(self.arena.flat.device):
+                    L.lib().sl_comm_abort(comm)
+            except Exception:          # noqa: BLE001 — already failing: nothing may mask the original error
+                pass
+
+    @staticmethod
+    def wire_bytes(payload_bytes: int, world: int) -> dict:
+        """Algorithmic bytes one rank SENDS for an in-place sum of `payload_bytes` over `world` ranks (= what it receives), by algorithm:
+        a ring moves 2 (N-1)/N of the payload through ONE xGMI link direction (reduce-scatter then all-gather, N-1 steps each); the
+        direct form (every rank owns 1/N, peers write their shares to the owner, the owner writes the sum back) moves the same
+        2 (N-1)/N in total but spread over the N-1 links of the fully connected node, i.e. 2/N of the payload per link (SURVEY §5 /
+        BASELINE.md §3: 14.6 ms vs 2.1 ms for the 1.274 GB arena at 8 ranks)."""
+        n = max(1, int(world))
+        total = 2 * (n - 1) * payload_bytes // n
+        return {"per_rank_sent_total": int(total), "ring_per_link": int(total), "direct_per_link": int(total // max(1, n - 1))}
+
     def comm_info(self) -> dict:
         """What actually carries the exchange on this rank (bench.py's kd_step.comm; asserted by tests/test_dp_gpu.py)."""
         nranks = None
@@ -294,6 +321,8 @@ class BucketedAllReduce:
                 "rccl_nranks": nranks, "group_world": int(self.real_world),
                 "group_backend": (self.dist.get_backend(self.group) if self.dist.is_initialized() else None),
                 "buckets": len(spans), "bucket_bytes": [int((b - a) * 4) for a, b in spans],
+                "bucket_ms": [round(float(v), 3) for v in self.last_bucket_ms],
+                "algo_bytes_on_wire": self.wire_bytes(int(sum((b - a) * 4 for a, b in spans)), nranks if nranks else self.real_world),
                 "measured_exchange_ms": round(float(self.last_exchange_ms), 3), "exposed_ms": round(float(self.last_exposed_ms), 3),
                 "overlap_frac": (round(1.0 - self.last_exposed_ms / self.last_exchange_ms, 4) if self.last_exchange_ms > 0 else None)}
 
@@ -373,7 +402,8 @@ class BucketedAllReduce:
                 work.wait()
         if timed and self._ev:
             self._ev[-1][1].synchronize()
-            self.last_exchange_ms = float(sum(a.elapsed_time(b) for a, b in self._ev))
+            self.last_bucket_ms = [float(a.elapsed_time(b)) for a, b in self._ev]
+            self.last_exchange_ms = float(sum(self.last_bucket_ms))
             tail = float(self._ev_compute_end.elapsed_time(self._ev[-1][1]))
             self.last_exposed_ms = min(self.last_exchange_ms, max(0.0, tail))
         self._ev = []

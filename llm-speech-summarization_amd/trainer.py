@@ -243,6 +243,11 @@ class Trainer():
         process group goes away)."""
         self.kd.close()
 
+    def abort(self) -> None:
+        """Failure path (train.py, on any exception / KeyboardInterrupt): local tear-down only — the peers may be inside a collective
+        this rank will never join, so nothing here waits for them; the caller re-raises and the process exits non-zero."""
+        self.kd.abort()
+
     # -- validation (ref:trainer.py:400-528) ---------------------------------------------------------
     def _val_sample(self, sample_idx):
         """One validation sample -> (audio_embeds (1,P,H), text ids, response ids, text)."""

@@ -1050,6 +1050,11 @@ class KDTrainer:
         if self.reducer is not None:
             self.reducer.close()
 
+    def abort(self) -> None:
+        """Failure path: drop the reducer's communicator locally (ncclCommAbort), never waiting for the peers (BucketedAllReduce.abort)."""
+        if self.reducer is not None:
+            self.reducer.abort()
+
     def close_window(self) -> None:
         """Optimizer step of a window in which THIS rank held no sample (the tail of an epoch under data parallel): its
         gradients are zero, the all-reduce still has to be joined."""

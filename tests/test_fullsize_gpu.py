@@ -583,3 +583,65 @@ def test_configs1_decode_step_tiled_gate_up_equals_streaming_form(llama3):
         top2 = tiled[i].topk(2).values
         if float(top2[0] - top2[1]) > 4 * float((tiled[i] - stream[i]).abs().max()):
             assert int(tiled[i].argmax()) == int(stream[i].argmax()), i
+
+
+def _stop_mix(B, new):
+    lo_ = max(1, new // 4)
+    return [lo_ + (61 * b) % (new - lo_ + 1) for b in range(B)]        # bench.py eos_leg: 64 + (61 b mod 193) at 256 new tokens
+
+
+def test_configs1_compacted_batch_ids_equal_uncompacted_at_bench_stop_mix(llama3):
+    """bench.py's `eos_stop_mix` leg as a parity case: full depth, bf16, 1 024 sequences, 256 new tokens, sequence b
+    stopping after 64 + (61 b mod 193) tokens.  The compacted run walks the row-count ladder (runtime.hip compact_rung) from 1 024 rows
+    down to ~24 — ACROSS the row counts at which the decode step used to change kernel family (896 / 384 / 26 rows).  A generation now
+    keeps the kernel family of the batch it started with (sl_generate pins it: every M-dependent choice of the decode step is made on B0,
+    the rows only shrink), and each family's per-row arithmetic does not depend on which other rows are present — so per sequence the
+    compacted ids are EXACTLY the uncompacted ids up to the stop, pads after it (hf:generation/utils.py:2928-2942 as invoked at
+    ref:inference.py:60-66).  Copies of one utterance with different stops agree with each other up to the shorter stop.
+    The same eight sequences decoded as a batch of eight take the small-batch family: there bf16 near-ties may flip (fp32: never,
+    tests/test_models_gpu.py) — every first divergence is checked to be a near tie of the two candidate tokens in a teacher-forced
+    prefill of the common prefix."""
+    m, B, new, NU = llama3, 1024, 256, 8
+    stops = _stop_mix(B, new)
+    base = [ri.synthetic_waveform(160000 if i % 3 else 112000, seed=4321 + i).to(DEV) for i in range(NU)]
+    xb, lens, st = m.prompts([base[b % NU] for b in range(B)])
+    keep = xb.clone()
+    m.llm.generation_config.eos_token_id = None
+    ids_c, n_c = m.llm.generate_packed(xb.clone(), lens, new, use_eos=False, shared_prefix=N_PRE, row_limits=stops, compact=True)
+    sc = dict(m.llm.last_generate_stats)
+    ids_u, n_u = m.llm.generate_packed(xb.clone(), lens, new, use_eos=False, shared_prefix=N_PRE, row_limits=stops, compact=False)
+    su = dict(m.llm.last_generate_stats)
+    assert n_c == n_u == max(stops)
+    assert sc["compactions"] >= 10 and sc["final_rows"] <= 64 and su["compactions"] == 0 and sc["row_steps"] < 0.7 * su["row_steps"]
+    pad = m.larch.pad_token_id if m.larch.pad_token_id is not None else 0
+    changed = [b for b in range(B) if not torch.equal(ids_c[b, :stops[b]], ids_u[b, :stops[b]])]
+    first = {b: _agreeing_prefix(ids_c[b, :stops[b]], ids_u[b, :stops[b]]) for b in changed[:8]}
+    print(f"compacted vs uncompacted, 1 024 rows bf16 full depth: {len(changed)} of {B} sequences change ids (first divergences {first}); "
+          f"ladder: {sc['compactions']} compactions down to {sc['final_rows']} rows, row steps {sc['row_steps']} vs {su['row_steps']}")
+    assert not changed, f"{len(changed)} sequences depend on when their neighbours finish"
+    for b in range(B):
+        assert bool((ids_c[b, stops[b]:n_c] == pad).all()), b
+    # copies of an utterance (different stops) agree up to the shorter stop: row independence inside one run
+    for b in range(NU, B):
+        k = min(stops[b], stops[b % NU])
+        assert torch.equal(ids_u[b, :k], ids_u[b % NU, :k]), b
+    # the sequences as a batch of eight (skinny family): agreement until the first bf16 near-tie, which must BE a near tie
+    x8 = torch.cat([keep[st[i]:st[i + 1]] for i in range(NU)])
+    ids_8, _ = m.llm.generate_packed(x8.clone(), lens[:NU], new, use_eos=False, shared_prefix=N_PRE)
+    emb = m.llm.model.embed_tokens
+    agree = []
+    for i in range(NU):
+        full = max(range(i, B, NU), key=lambda b: stops[b])       # the copy with the longest budget
+        k = stops[full]
+        t = _agreeing_prefix(ids_8[i, :k], ids_u[full, :k])
+        agree.append(t)
+        if t == k:
+            continue
+        a, c = int(ids_8[i, t]), int(ids_u[full, t])
+        ctx_ids = ids_u[full, :t].long().to(DEV)
+        xs = torch.cat([keep[st[i]:st[i + 1]], emb(ctx_ids[None])[0]]) if t > 0 else keep[st[i]:st[i + 1]].clone()
+        lg = _last_logits(m, xs.contiguous(), [int(xs.shape[0])])[0].float().cpu()
+        top = float(lg.max())
+        spread = float(lg.std())
+        assert top - float(lg[a]) < 0.25 * spread and top - float(lg[c]) < 0.25 * spread, (i, t, a, c, top, float(lg[a]), float(lg[c]), spread)
+    print("tokens agreeing between the 1 024-row family and the batch of eight before the first near-tie flip:", agree)

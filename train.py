@@ -39,7 +39,16 @@ if __name__ == '__main__':
     trainer = Trainer(args, config, device, dtype=dtype)
     try:
         trainer.train()
-    finally:
-        trainer.close()            # collective tear-down of the gradient exchange, while the process group still exists
-        if distributed:
-            torch.distributed.destroy_process_group()
+    except BaseException:
+        # A rank that fails alone must EXIT, not wait: its peers may be inside an RCCL all-reduce it will never join, and both the
+        # collective close() (synchronize + ncclCommDestroy) and destroy_process_group() would block on them — torchrun would then never
+        # see the failure.  Local abort of the communicator, the exception re-raised: the process leaves non-zero and the launcher ends the job.
+        import traceback
+        traceback.print_exc()
+        trainer.abort()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)                # not `raise`: interpreter shutdown would still run the process group's destructor, which may wait on the peers
+    trainer.close()                # success path only: collective tear-down of the gradient exchange, while the process group still exists
+    if distributed:
+        torch.distributed.destroy_process_group()
