@@ -392,14 +392,20 @@ def eos_leg(args, pipe, waves, audio_rows, B, S, P, new, n_pre, pre_e, suf_e, fi
                 dec.append(pipe.llm.last_timings_ms[1])
         st = dict(pipe.llm.last_generate_stats)
         assert n_cols == max(stops) and tuple(ids.shape) == (B, new)
-        res[mode] = {"ms_per_step": round(times[-1] * 1e3, 2), "decode_ms": round(dec[-1], 2), "useful_tokens_per_s": round(useful / times[-1], 1),
+        import zlib
+        crc = 0
+        for b in range(B):             # the useful ids of every sequence, in the caller's order: compacted and uncompacted runs must print the same value
+            crc = zlib.crc32(ids[b, :stops[b]].contiguous().numpy().tobytes(), crc)
+        res[mode] = {"useful_ids_crc32": f"{crc:08x}", "ms_per_step": round(times[-1] * 1e3, 2), "decode_ms": round(dec[-1], 2), "useful_tokens_per_s": round(useful / times[-1], 1),
                      "useful_decode_tokens_per_s": round((useful - B) / (dec[-1] * 1e-3), 1), "compactions": st["compactions"], "final_rows": st["final_rows"],
                      "row_steps": st["row_steps"], "decode_launches": st["decode_launches"], "first_pass_ms_incl_graph_captures": round(times[0] * 1e3, 2)}
     res["fixed_length_tokens_per_s_one_batch_alone"] = round(fixed_tok_s, 1)
     res["fixed_length_decode_tokens_per_s"] = round(fixed_decode_tok_s, 1)
     res["compacted_over_fixed_length_decode"] = round(res["compacted"]["useful_decode_tokens_per_s"] / fixed_decode_tok_s, 4)
+    res["ids_identical_compacted_vs_uncompacted"] = res["compacted"]["useful_ids_crc32"] == res["uncompacted"]["useful_ids_crc32"]
     res["compacted_over_uncompacted"] = round(res["compacted"]["useful_tokens_per_s"] / res["uncompacted"]["useful_tokens_per_s"], 4)
-    res["note"] = ("one batch alone on the GPU; useful_decode = useful tokens after each sequence's first (prefill) token / decode time; the fixed-length figures are "
+    res["note"] = ("one batch alone on the GPU; a compacting generation keeps the kernel family of its first batch (sl_generate pins it), so the useful ids are those of the "
+                   "uncompacted run bit for bit (useful_ids_crc32; tests/test_fullsize_gpu.py asserts it per sequence); useful_decode = useful tokens after each sequence's first (prefill) token / decode time; the fixed-length figures are "
                    "the same batch decoding max_new_tokens for every row (stage_ms_one_batch_alone)")
     return res
 

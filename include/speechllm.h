@@ -47,7 +47,7 @@ enum sl_act { SL_ACT_NONE = 0, SL_ACT_GELU = 1, SL_ACT_SILU_MUL = 2, SL_ACT_ROPE
 enum sl_w_layout { SL_W_ROWMAJOR = 0, SL_W_PACKED = 1 };
 
 const char* sl_last_error(void);       /* thread-local, never NULL */
-#define SL_ABI_VERSION 6
+#define SL_ABI_VERSION 7
 int sl_version(void);                  /* == SL_ABI_VERSION of the header the library was built from; bumps on any signature change */
 int sl_device_arch(char* buf, int n);  /* gcnArchName of the current device, e.g. "gfx950:sramecc+:xnack-" */
 /* Tuning switches (SL_* environment variables, documented in csrc/common.h) are read once, at first use; tools that change
@@ -174,7 +174,27 @@ typedef struct {
    * use and not shared by launches that may run concurrently (one per stream).  NULL, a shape the rule does not take, transposed /
    * grouped operands or the ln_* / stats_out / amax_* / aux_out forms: the product runs one block per tile as without it. */
   void* sk_ws; size_t sk_ws_bytes;
+  /* Training-tape epilogue fusions (ABI 7; ref:trainer.py:270-384 runs these as separate torch ops around every Linear).  Plain
+   * un-grouped row-major products on the tiled kernels only (no trans_*, groups, ln_*, stats_out, amax_*); all in the epilogue, with
+   * the roundings of the unfused launch sequence reproduced (bf16: the value is rounded to the storage type where the unfused
+   * sequence stored it), so fused and unfused tapes give the same bits.
+   *   post_op = SL_POST_DROPOUT:  C = residual + dropout(act(A.W^T + bias))      (hf HubertEncoderLayerStableLayerNorm: h = h + dropout(sublayer))
+   *             keep(i) as sl_dropout with seed drop_seed at element index i = row * drop_ld + col, kept values scaled by 1 / (1 - drop_p);
+   *             aux_out (the pre-activation) is stored before act as usual.
+   *   post_op = SL_POST_GELU_BWD: C = gelu'(post_in) * dropout(A.W^T)            (d pre = gelu'(pre) . d mid: sl_dropout + sl_gelu_bwd behind the
+   *             data-gradient product; post_in = the saved pre-activation, (M, N) with row stride post_ld; drop_p = 0: no mask)
+   *   post_op = SL_POST_SILU_MUL_BWD: C (M, 2 N) in the interleaved [16 gate | 16 up] layout = sl_silu_mul_bwd(post_in = gu (M, 2 N) with row
+   *             stride post_ld, d mid = A.W^T); ldc is the row stride of the 2 N-wide output.
+   *   colsum_out (any post_op incl. NONE): fp32 (N) += column sums of the values AS STORED in C (bias gradients: db = colsum(dY)),
+   *             float atomics, a few dozen adders per column. */
+  int32_t post_op, post_reserved;
+  float drop_p; float post_reserved_f;
+  uint64_t drop_seed;
+  int64_t drop_ld;
+  const void* post_in; int64_t post_ld;
+  float* colsum_out;
 } sl_gemm_ex_args;
+enum { SL_POST_NONE = 0, SL_POST_DROPOUT = 1, SL_POST_GELU_BWD = 2, SL_POST_SILU_MUL_BWD = 3 };
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);
 size_t sl_gemm_streamk_workspace_bytes(void);
 /* 1 when sl_gemm_ex takes ln_* / stats_out for a plain (M, N, K) product of this dtype, else 0 */

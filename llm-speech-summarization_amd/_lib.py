@@ -18,6 +18,7 @@ LIB_PATH = (os.environ.get("SL_LIB_PATH") if os.environ.get("SL_DEV") == "1" els
 
 SL_F32, SL_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU_MUL, ACT_ROPE_KV = 0, 1, 2, 3
+POST_NONE, POST_DROPOUT, POST_GELU_BWD, POST_SILU_MUL_BWD = 0, 1, 2, 3      # sl_gemm_ex_args.post_op
 W_ROWMAJOR, W_PACKED = 0, 1
 COMM_ID_BYTES = 128          # SL_COMM_ID_BYTES = sizeof(ncclUniqueId)
 MAX_DECODE_BATCH = 2048      # SL_MAX_DECODE_BATCH: sequences per generate call / rows per decode step
@@ -48,7 +49,10 @@ class GemmFused(C.Structure):
 class GemmEx(C.Structure):
     _fields_ = [("trans_a", c_i32), ("trans_w", c_i32), ("residual_f32", c_i32), ("w_mod", c_i32), ("aux_out", c_vp), ("groups", c_vp),
                 ("groups_ext", c_i32), ("reserved", c_i32), ("amax_val", c_vp), ("amax_idx", c_vp),
-                ("ln_mr", c_vp), ("ln_u", c_vp), ("ln_c", c_vp), ("stats_out", c_vp), ("sk_ws", c_vp), ("sk_ws_bytes", C.c_size_t)]
+                ("ln_mr", c_vp), ("ln_u", c_vp), ("ln_c", c_vp), ("stats_out", c_vp), ("sk_ws", c_vp), ("sk_ws_bytes", C.c_size_t),
+                # training-tape epilogue fusions (ABI 7)
+                ("post_op", c_i32), ("post_reserved", c_i32), ("drop_p", C.c_float), ("post_reserved_f", C.c_float), ("drop_seed", C.c_uint64),
+                ("drop_ld", C.c_int64), ("post_in", c_vp), ("post_ld", C.c_int64), ("colsum_out", c_vp)]
 
 
 class AttnArgs(C.Structure):

@@ -18,7 +18,7 @@ void sl_set_error(const char* fmt, ...) {
 
 extern "C" const char* sl_last_error(void) { return g_err; }
 
-extern "C" int sl_version(void) { return SL_ABI_VERSION; }   // 6: sl_comm_abort, SL_MAX_DECODE_BATCH 2048, sl_gemm_fused.norm_out / norm_gain (grew that struct in round 4), sl_generate_opts (compaction); 5: sl_kv_cache.shared_prefix; 4: sl_gemm_ex_args.sk_ws / sk_ws_bytes, sl_gemm_streamk_workspace_bytes; 3: sl_gemm_ex_args.amax_*, sl_greedy_select_partial, sl_adamw_step, sl_layernorm_bwd_ws, sl_decode_graph_cache_clear
+extern "C" int sl_version(void) { return SL_ABI_VERSION; }   // 7: sl_gemm_ex_args.post_op / drop_* / post_in / colsum_out (training-tape epilogue fusions), sl_comm_world asks RCCL; 6: sl_comm_abort, SL_MAX_DECODE_BATCH 2048, sl_gemm_fused.norm_out / norm_gain (grew that struct in round 4), sl_generate_opts (compaction); 5: sl_kv_cache.shared_prefix; 4: sl_gemm_ex_args.sk_ws / sk_ws_bytes, sl_gemm_streamk_workspace_bytes; 3: sl_gemm_ex_args.amax_*, sl_greedy_select_partial, sl_adamw_step, sl_layernorm_bwd_ws, sl_decode_graph_cache_clear
 
 extern "C" int sl_device_arch(char* buf, int n) {
   SL_CHECK_ARG(buf != nullptr && n > 0, "sl_device_arch: bad buffer");
@@ -48,6 +48,8 @@ static const SlEnv* env_load() {
   SlEnv& e = *new SlEnv();
   // 26: the decode step at 17..32 sequences on either family (tools/time_decode_step.py, profiles/r04_zb_stream_min_m.txt): the skinny kernels win
   // up to 26 rows (2.34 vs 2.36 ms), the 32-row streaming blocks from 27 (2.42 vs 2.38) to 32 (2.57 vs 2.40)
+  e.compact_pin = env_int("SL_COMPACT_PIN", 1);
+  e.tape_fuse = env_int("SL_TAPE_FUSE", 1);
   e.stream_min_m = env_int("SL_STREAM_MIN_M", 26);
   if (e.stream_min_m < 16) e.stream_min_m = 26;
   e.disable_t256 = getenv("SL_DISABLE_T256") != nullptr;
@@ -109,6 +111,14 @@ const SlEnv& sl_env() {
     }
   }
   return *e;
+}
+
+static thread_local int g_family_rows = 0;
+int sl_family_rows(int rows) { return g_family_rows > rows ? g_family_rows : rows; }
+int sl_family_pin(int rows) {
+  const int prev = g_family_rows;
+  g_family_rows = rows > 0 ? rows : 0;
+  return prev;
 }
 
 extern "C" int sl_tuning_reload(void) {

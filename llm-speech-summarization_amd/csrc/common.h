@@ -172,6 +172,12 @@ template <typename T> __device__ __forceinline__ float gelu_act(float x) {
   else return gelu_erf(x);
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// d gelu(u) / du (exact erf form, hf:activations.py GELUActivation): sl_gelu_bwd and the GEMM epilogue's SL_POST_GELU_BWD
+__device__ __forceinline__ float gelu_grad(float u) {
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -210,6 +216,8 @@ static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; 
 // sl_tuning_reload() (api.hip, exported for tools/tune_*.py) re-reads them for in-process A/B runs
 // ----------------------------------------------------------------------------------------------
 struct SlEnv {
+  int tape_fuse;           // SL_TAPE_FUSE         (default 1) training tapes: dropout / GELU' / SwiGLU' / bias-gradient passes inside the GEMM and norm-backward kernels (0: the unfused launch sequence, A/B + parity tests)
+  int compact_pin;         // SL_COMPACT_PIN       (default 1) a compacting generation keeps the kernel family of its first batch (0: each rung picks its own — A/B only)
   int stream_min_m;        // SL_STREAM_MIN_M      (default 26) packed-weight products with more rows than this take the LDS-staged streaming kernels
   int disable_t256;        // SL_DISABLE_T256
   int t256_min_tiles;      // SL_T256_MIN_TILES    (default 512)
@@ -248,3 +256,17 @@ struct SlEnv {
   int stream_nl;           // SL_STREAM_NL         loader waves of the 128-row streaming GEMM blocks (0 = default)
 };
 const SlEnv& sl_env();
+
+// Kernel-family pin (api.hip).  Every choice of the decode step that depends on the row count — skinny / streaming / tiled GEMM form,
+// K-split counts, the RMSNorm-scale chain, single-pass or split attention, fused lm_head top-1 — is made on sl_family_rows(M) =
+// max(M, pinned rows of the calling thread).  A compacting generation pins the rows of the batch it STARTED with (sl_generate): the
+// live rows shrink, the arithmetic each row goes through does not change, so a sequence's bf16 ids cannot depend on when its
+// neighbours finish (tests/test_fullsize_gpu.py::test_configs1_compacted_batch_ids_equal_uncompacted_at_bench_stop_mix).
+bool sl_gemm_post_ok(int64_t M, int N, int K, int dtype);      // gemm.hip: a product of this shape may carry sl_gemm_ex_args.post_op / colsum_out
+int sl_family_rows(int rows);
+int sl_family_pin(int rows);      // returns the previous pin (0 = none)
+struct SlFamilyPin {
+  int prev;
+  explicit SlFamilyPin(int rows) : prev(sl_family_pin(rows)) {}
+  ~SlFamilyPin() { sl_family_pin(prev); }
+};

@@ -103,6 +103,7 @@ __device__ __forceinline__ void tile_epilogue_g(const GemmP& p, f32x4 (&acc)[MT]
       const int col = col0 + n * 16;
       if (col >= p.N) continue;
       const float b = bias ? to_f32(bias[col]) : 0.f;
+      float csum = 0.f;
       // residual column first, all rows at once on clamped addresses: loads under the per-row bounds test are issued
       // and waited for one by one (MT*4 memory latencies in a chain per column, measured 2x on K = 1024 products)
       constexpr int MG = ACT == SL_ACT_GELU ? 1 : (MT < 4 ? MT : 4);   // 16 residual loads in flight per column (4 beside erf: more spills the 256-row tile)
@@ -128,10 +129,25 @@ __device__ __forceinline__ void tile_epilogue_g(const GemmP& p, f32x4 (&acc)[MT]
               float v = acc[mg + m][n][i] + b;
               if (p.aux) ((T*)p.aux + co)[(int64_t)row * p.ldc + col] = from_f32<T>(v);
               if constexpr (ACT == SL_ACT_GELU) v = gelu_act<T>(v);
+              if (p.post == SL_POST_SILU_MUL_BWD) {       // (M, 2 N) output in the interleaved [16 gate | 16 up] layout
+                const int64_t o = (int64_t)row * p.post_ld + 32 * (col >> 4) + (col & 15);
+                float dg, du;
+                post_silu_bwd<T>(v, to_f32(((const T*)p.post_in)[o]), to_f32(((const T*)p.post_in)[o + 16]), dg, du);
+                T* op = (T*)Cb + (int64_t)row * p.ldc + 32 * (col >> 4) + (col & 15);
+                op[0] = from_f32<T>(dg); op[16] = from_f32<T>(du);
+                continue;
+              }
+              if (p.post) { float v1[1] = {v}; post_apply<T, 1>(p, row, col, v1); v = v1[0]; }
               if (Rb) v += rv[m][i];
               store_out<T>(p, Cb, nullptr, row, col, v);
+              if (p.colsum) csum += p.out_f32 ? v : round_as<T>(v);
             }
           }
+      }
+      if (p.colsum) {          // the lane's rows of this column, then the four row groups of the wave: one atomic per column and wave
+        csum += __shfl_xor(csum, 16, 64);
+        csum += __shfl_xor(csum, 32, 64);
+        if (q == 0) atomicAdd(p.colsum + col, csum);
       }
     }
   }
@@ -175,7 +191,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 // The features of a launch are uniform, but tested per row pass they leave ~10 scalar branches in each pass and the compiler
 // cannot move the LDS read of pass t+1 over them (one block per CU: the epilogue is an exposed tail of every tile).  F fixes
 // them at compile time for the forms the encoder / prefill / KD launches use; EPI_GENERIC keeps every test at run time.
-enum : int { EPI_GENERIC = 1, EPI_RES = 2, EPI_LN = 4, EPI_STATS = 8, EPI_AUX = 16 };
+// EPI_POST (with EPI_GENERIC): the training tapes' post-ops (sl_gemm_ex_args.post_op / colsum_out) — their own instantiation, so that the plain
+// generic form keeps its registers; EPI_SBWD on top of it: SL_POST_SILU_MUL_BWD (two prefetched operand rows per pass).  Swapped-operand
+// epilogue: EPI_DROP / EPI_GBWD / EPI_SBWD select the post-op at compile time.
+enum : int { EPI_GENERIC = 1, EPI_RES = 2, EPI_LN = 4, EPI_STATS = 8, EPI_AUX = 16, EPI_POST = 32, EPI_SBWD = 64, EPI_DROP = 128, EPI_GBWD = 256 };
 
 template <typename T, int ACT, int MT, int F>
 __device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int wz, float* wsm,
@@ -185,6 +204,11 @@ __device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&
   const bool f_rest = G ? (p.res && !p.res_f32) : (F & EPI_RES) != 0;
   const bool f_ln = BF && (G ? p.ln_mr != nullptr : (F & EPI_LN) != 0);
   const bool f_stats = BF && (G ? p.stats_out != nullptr : (F & EPI_STATS) != 0);
+  constexpr bool PO = (F & EPI_POST) != 0, SB = (F & EPI_SBWD) != 0;
+  const int f_post = PO ? p.post : 0;                 // training-tape post-ops (their own instantiations: tile_epilogue_rows)
+  const bool f_cs = PO && p.colsum != nullptr;
+  const bool f_pin = PO && !SB && p.post == SL_POST_GELU_BWD;      // the saved pre-activation rows are requested up front, like a residual
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   const int q = lane >> 4, r = lane & 15;
   const int c4 = r * 4;                       // read phase: lane = (row within a 4-row pass, 4-column group)
   const int col = col_base + c4;
@@ -210,12 +234,30 @@ __device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&
     // before the tile is turned through LDS, on clamped addresses, so one memory latency is exposed per group (issued
     // pass by pass under the bounds test they cost ~45 % on the K = 1024 products)
     RawT raw[16];
+    RawT raw2[SB ? 16 : 1];
     if (f_rest) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         int64_t row = row_base + mg * 16 + t * 4 + q;
         row = row < p.M ? row : p.M - 1;
         raw[t] = *(const RawT*)((const T*)p.res + ro + row * p.ldr + colc);
+      }
+    } else if (f_pin) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        int64_t row = row_base + mg * 16 + t * 4 + q;
+        row = row < p.M ? row : p.M - 1;
+        raw[t] = *(const RawT*)((const T*)p.post_in + row * p.post_ld + colc);
+      }
+    }
+    if constexpr (SB) {       // gate and up pre-activations of the lane's four columns: [16 gate | 16 up] blocks
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        int64_t row = row_base + mg * 16 + t * 4 + q;
+        row = row < p.M ? row : p.M - 1;
+        const T* gp = (const T*)p.post_in + row * p.post_ld + 32 * (colc >> 4) + (colc & 15);
+        raw[t] = *(const RawT*)gp;
+        raw2[t] = *(const RawT*)(gp + 16);
       }
     }
     // LayerNorm fold, consumer side: {mean, rstd} of the group's 16 row passes, requested up front for the same reason (a load
@@ -276,6 +318,26 @@ __device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = gelu_act<T>(v[j]);
           }
+          if constexpr (SB) {     // (M, 2 N) output, interleaved [16 gate | 16 up]: the lane's four columns sit in one 16-group
+            float g4[4], up4[4], dg[4], du[4];
+            unpack4(raw[t], g4);
+            unpack4(raw2[t], up4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) post_silu_bwd<T>(v[j], g4[j], up4[j], dg[j], du[j]);
+            T* op = (T*)p.C + co + row * p.ldc + 32 * (col >> 4) + (col & 15);
+            st4(op, dg);
+            st4(op + 16, du);
+            continue;
+          }
+          if (f_post == SL_POST_DROPOUT) {
+            post_drop<T, 4>(p, row, col, v);
+          } else if (f_pin) {
+            post_drop<T, 4>(p, row, col, v);
+            float pre4[4];
+            unpack4(raw[t], pre4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = round_as<T>(v[j]) * gelu_grad(pre4[j]);
+          }
           if (f_rest) {
             float rr[4];
             unpack4(raw[t], rr);
@@ -287,6 +349,10 @@ __device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&
           }
           if (f_out32) st4((float*)p.C + co + row * p.ldc + col, v);
           else st4((T*)p.C + co + row * p.ldc + col, v);
+          if (f_cs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] += f_out32 ? v[j] : round_as<T>(v[j]);
+          }
           if (f_stats) {
             f32x2_t f01 = {v[0], v[1]}, f23 = {v[2], v[3]};
             if (!f_out32) {               // the values as stored: the same v_cvt_pk_bf16_f32 st4 issued, its halves shifted back up
@@ -311,9 +377,22 @@ __device__ __forceinline__ void tile_epilogue_rows_impl(const GemmP& p, f32x4 (&
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (f_cs) {      // the wave's rows of its 64 columns: the four row lanes of a column group meet, one atomic per column and wave
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cs[j] += __shfl_xor(cs[j], 16, 64);
+      cs[j] += __shfl_xor(cs[j], 32, 64);
+    }
+    if (q == 0 && col_ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(p.colsum + col + j, cs[j]);
+    }
+  }
 }
 
-template <typename T, int ACT, int MT>
+// POSTS: this kernel may be handed products with training-tape post-ops (launch_tiled routes them to the LDS-DMA 128-tile kernel and the
+// phased 256-tile kernel only — the other kernels do not carry those instantiations: compile time)
+template <typename T, int ACT, int MT, bool POSTS = false>
 __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[MT][4], int row_base, int col_base, int lane, int z, int wz, float* wsm,
                                                    const float2* mr_lds = nullptr) {
   static_assert(MT % 4 == 0 && ACT != SL_ACT_SILU_MUL, "64-row passes; the gate/up pairing keeps the direct epilogue");
@@ -321,10 +400,10 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
   const int64_t co = (int64_t)z * p.sC + p.cx, ro = (int64_t)z * p.sR + p.rx;
   const uintptr_t ca = p.out_f32 ? 15 : (4 * sizeof(T) - 1), ra = p.res_f32 ? 15 : (4 * sizeof(T) - 1);
   if ((p.N & 3) || (p.ldc & 3) || (co & 3) || ((uintptr_t)p.C & ca) || (p.aux && ((uintptr_t)p.aux & (4 * sizeof(T) - 1))) ||
-      (p.res && ((p.ldr & 3) || (ro & 3) || ((uintptr_t)p.res & ra))))
+      (p.res && ((p.ldr & 3) || (ro & 3) || ((uintptr_t)p.res & ra))) || (p.post_in && ((p.post_ld & 3) || ((uintptr_t)p.post_in & (4 * sizeof(T) - 1)))))
     return false;
   if constexpr (sizeof(T) == 2) {
-    if (!p.aux && !p.out_f32 && !(p.res && p.res_f32)) {
+    if (!p.aux && !p.out_f32 && !(p.res && p.res_f32) && !p.post && !p.colsum) {
       const bool res = p.res != nullptr, ln = p.ln_mr != nullptr, st = p.stats_out != nullptr;
       if (!ln && !st) {
         if (res) tile_epilogue_rows_impl<T, ACT, MT, EPI_RES>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro);
@@ -334,6 +413,15 @@ __device__ __forceinline__ bool tile_epilogue_rows(const GemmP& p, f32x4 (&acc)[
       if (ln && !res && !st) { tile_epilogue_rows_impl<T, ACT, MT, EPI_LN>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro); return true; }
       if (st && res && !ln) { tile_epilogue_rows_impl<T, ACT, MT, EPI_RES | EPI_STATS>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro); return true; }
     }
+  }
+  if constexpr (POSTS) {
+    if (p.post == SL_POST_SILU_MUL_BWD) {
+      if constexpr (ACT == SL_ACT_NONE) { tile_epilogue_rows_impl<T, ACT, MT, EPI_GENERIC | EPI_POST | EPI_SBWD>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro); return true; }
+      else return false;
+    }
+    if (p.post || p.colsum) { tile_epilogue_rows_impl<T, ACT, MT, EPI_GENERIC | EPI_POST>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro); return true; }
+  } else {
+    if (p.post || p.colsum) return false;       // (never routed here: the direct epilogue still applies them)
   }
   tile_epilogue_rows_impl<T, ACT, MT, EPI_GENERIC>(p, acc, row_base, col_base, lane, wz, wsm, mr_lds, co, ro);
   return true;
@@ -353,6 +441,15 @@ template <int ACT, int F>
 __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8][4], int row_base, int col_base, int lane, int z, int wz, const float2* mr_lds) {
   using T = bf16_t;
   constexpr bool RES = (F & EPI_RES) != 0, LN = (F & EPI_LN) != 0, ST = (F & EPI_STATS) != 0, AUX = (F & EPI_AUX) != 0;
+  // training-tape post-ops (sl_gemm_ex_args.post_op): dropout of the value before the residual add; GELU' x dropout behind a data-gradient product
+  // (+ the bias gradient's column sums); SwiGLU' writing the (M, 2 N) interleaved gate / up gradient
+  constexpr bool DROP = (F & EPI_DROP) != 0, GBWD = (F & EPI_GBWD) != 0, SBWD = (F & EPI_SBWD) != 0;
+  static_assert(!(GBWD || SBWD) || !(RES || LN || ST || AUX || DROP), "the backward post-ops take the plain product");
+  float csum[2][8];            // GBWD + colsum_out: this lane's rows of its sixteen columns
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csum[h][j] = 0.f;
   const int64_t co = (int64_t)z * p.sC, ro = (int64_t)z * p.sR;
   const int q = lane >> 4, r = lane & 15;
   int colh[2];
@@ -378,6 +475,7 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
 #pragma unroll
   for (int mb = 0; mb < 8; mb += 4) {
     uint4 raw[4][2];
+    uint4 raw2[SBWD ? 4 : 1][2];
     if constexpr (RES) {
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4) {
@@ -385,6 +483,28 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
         row = row < p.M ? row : p.M - 1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) raw[m4][h] = *(const uint4*)((const T*)p.res + ro + row * p.ldr + colh[h]);
+      }
+    }
+    if constexpr (GBWD) {        // the saved pre-activation, four rows at a time like a residual
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        int64_t row = row_base + (mb + m4) * 16 + r;
+        row = row < p.M ? row : p.M - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) raw[m4][h] = *(const uint4*)((const T*)p.post_in + row * p.post_ld + colh[h]);
+      }
+    }
+    if constexpr (SBWD) {        // gate / up pre-activations of the lane's eight columns (one half of a [16 gate | 16 up] block)
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        int64_t row = row_base + (mb + m4) * 16 + r;
+        row = row < p.M ? row : p.M - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const T* gp = (const T*)p.post_in + row * p.post_ld + 32 * (colh[h] >> 4) + (colh[h] & 15);
+          raw[m4][h] = *(const uint4*)gp;
+          raw2[m4][h] = *(const uint4*)(gp + 16);
+        }
       }
     }
 #pragma unroll
@@ -417,6 +537,27 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = gelu_act<T>(v[j]);
         }
+        if constexpr (SBWD) {
+          float g8[8], u8[8], dg[8], du[8];
+          Vec16<T>::unpack(raw[m4][h], g8);
+          Vec16<T>::unpack(raw2[m4][h], u8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) post_silu_bwd<T>(v[j], g8[j], u8[j], dg[j], du[j]);
+          if (row < p.M && okh[h]) {
+            T* op = (T*)p.C + co + row * p.ldc + 32 * (colh[h] >> 4) + (colh[h] & 15);
+            *(uint4*)op = Vec16<T>::pack(dg);
+            *(uint4*)(op + 16) = Vec16<T>::pack(du);
+          }
+          continue;
+        }
+        if constexpr (DROP) post_drop<T, 8>(p, row, colh[h], v);
+        if constexpr (GBWD) {
+          post_drop<T, 8>(p, row, colh[h], v);
+          float pre8[8];
+          Vec16<T>::unpack(raw[m4][h], pre8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = round_as<T>(v[j]) * gelu_grad(pre8[j]);
+        }
         if constexpr (RES) {
           float rr[8];
           Vec16<T>::unpack(raw[m4][h], rr);
@@ -425,6 +566,14 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
         }
         const uint4 pk = Vec16<T>::pack(v);
         pkh[h] = pk;
+        if constexpr (GBWD) {
+          if (p.colsum && row < p.M && okh[h]) {
+            float sv[8];
+            Vec16<T>::unpack(pk, sv);       // the values as stored
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csum[h][j] += sv[j];
+          }
+        }
         if (row < p.M && okh[h]) {
           if constexpr (ST) {             // statistics of the values as stored (the packed halves shifted back up), per 4-column leaf
             const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};   // exactly as the rows epilogue forms them: the tree below is its tree
@@ -439,7 +588,7 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
           }
         }
       }
-      {
+      if constexpr (!SBWD) {
         // Stores.  As computed, an instruction would put 64 bytes into each of 16 rows — 16 half-written 128-byte lines; a CU's store
         // path takes ~4 clocks per line touched whatever it carries (tools/probe_store_rate.hip, one CU storing alone: a 128 KiB tile in
         // 3.47 us that way, 1.23 us as 8 full lines per instruction, 1.84 us as the LDS-turned epilogue's 4 lines of 8-byte pieces).
@@ -466,6 +615,17 @@ __device__ __forceinline__ void tile_epilogue_sw(const GemmP& p, f32x4 (&acc)[8]
         s1[m][0] = la[0][0] + la[1][0]; s1[m][1] = la[0][1] + la[1][1];
         s2[m][0] = lq[0][0] + lq[1][0]; s2[m][1] = lq[0][1] + lq[1][1];
       }
+    }
+  }
+  if constexpr (GBWD) {
+    if (p.colsum) {        // the sixteen row lanes of a column group (one DPP row) meet; lane r = 0 adds the wave's sums: one atomic per column and wave
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = row16_sum(csum[h][j]);
+          if (r == 0 && okh[h]) atomicAdd(p.colsum + colh[h] + j, t);
+        }
     }
   }
   if constexpr (ST) {
@@ -799,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
     }
   }
   if constexpr (ACT != SL_ACT_SILU_MUL) {
-    if (!p.direct_epi && tile_epilogue_rows<T, ACT, 4>(p, acc, bm * TBM + wm * 64, bn * TBN + wn * 64, lane, z, wz, (float*)&smem[0][0][0] + wave * 4096)) return;
+    if (!p.direct_epi && tile_epilogue_rows<T, ACT, 4, ASMLDS>(p, acc, bm * TBM + wm * 64, bn * TBN + wn * 64, lane, z, wz, (float*)&smem[0][0][0] + wave * 4096)) return;
   }
   tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, wz);
 }
@@ -1299,7 +1459,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {      // bijective: th
   return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
 }
 
-template <typename T, int ACT, bool SW>
+template <typename T, int ACT, bool SW, bool POSTS = false>
 __device__ __forceinline__ void t256_epilogue(const GemmP& p, f32x4 (&acc)[8][4], int bm, int bn, int wave, int lane, int z, int wz, unsigned char* smem,
                                               float2* mr_s) {
   const int wm = wave >> 2, wn = wave & 3;
@@ -1307,6 +1467,20 @@ __device__ __forceinline__ void t256_epilogue(const GemmP& p, f32x4 (&acc)[8][4]
     const int rb0_ = bm * XBM + wm * 128, cb0 = bn * XBN + wn * 64;
     const float2* mrl = mr_s + wm * 128;
     const bool res = p.res != nullptr, ln = p.ln_mr != nullptr, st = p.stats_out != nullptr;    // launch_tiled admits these five forms only
+    bool done = false;
+    if constexpr (POSTS) {
+     if (p.post) {         // launch_tiled admits exactly these post-op forms on the swapped-operand kernels (the phased kernel only)
+      done = true;
+      if constexpr (ACT == SL_ACT_GELU) {
+        tile_epilogue_sw<ACT, EPI_AUX | EPI_DROP>(p, acc, rb0_, cb0, lane, z, wz, mrl);        // FFN1 forward: mid = dropout(gelu(pre)), pre kept
+      } else {
+        if (p.post == SL_POST_DROPOUT) tile_epilogue_sw<ACT, EPI_RES | EPI_DROP>(p, acc, rb0_, cb0, lane, z, wz, mrl);   // h = residual + dropout(sublayer)
+        else if (p.post == SL_POST_GELU_BWD) tile_epilogue_sw<ACT, EPI_GBWD>(p, acc, rb0_, cb0, lane, z, wz, mrl);
+        else tile_epilogue_sw<ACT, EPI_SBWD>(p, acc, rb0_, cb0, lane, z, wz, mrl);
+      }
+     }
+    }
+    if (done) return;
     if (p.aux) tile_epilogue_sw<ACT, EPI_AUX>(p, acc, rb0_, cb0, lane, z, wz, mrl);
     else if (ln) tile_epilogue_sw<ACT, EPI_LN>(p, acc, rb0_, cb0, lane, z, wz, mrl);
     else if (st) tile_epilogue_sw<ACT, EPI_RES | EPI_STATS>(p, acc, rb0_, cb0, lane, z, wz, mrl);
@@ -1315,7 +1489,7 @@ __device__ __forceinline__ void t256_epilogue(const GemmP& p, f32x4 (&acc)[8][4]
   } else {
     if constexpr (ACT != SL_ACT_SILU_MUL) {
       // the LDS-turned rows epilogue uses 16 KiB per wave of the piece slots (every DMA has landed: the last phases wait vmcnt(0))
-      if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)smem + wave * 4096,
+      if (!p.direct_epi && tile_epilogue_rows<T, ACT, 8, POSTS>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane, z, wz, (float*)smem + wave * 4096,
                                                         sizeof(T) == 2 && p.ln_mr ? mr_s + wm * 128 : nullptr)) return;
     }
     tile_epilogue_g<T, ACT, 8, 4>(p, acc, bm * XBM + wm * 128, bn * XBN + wn * 64, lane >> 4, lane & 15, z, wz);
@@ -1366,7 +1540,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
       p.stamp[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave >> 2)) * 32 + lane] = ((const uint32_t*)mr_s)[(wave >> 2) * 32 + lane];
     }
   }
-  t256_epilogue<T, ACT, SW>(p, acc, bm, bn, wave, lane, z, wz, smem, mr_s);
+  t256_epilogue<T, ACT, SW, DBG == 0>(p, acc, bm, bn, wave, lane, z, wz, smem, mr_s);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1714,7 +1888,7 @@ extern "C" size_t sl_gemm_streamk_workspace_bytes(void) { return SK_FLAG_BYTES +
 
 static int sk_grid(const GemmP& p, int batch, int bk, size_t ws_bytes) {
   const int mode = sl_env().stream_k;          // SL_STREAM_K: 0 = never, 1 = rule (default), 2 = whenever the form allows
-  if (!mode || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.N < 192) return 0;
+  if (!mode || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.N < 192 || p.post || p.colsum) return 0;
   const int cus = sk_cu_count() < 256 ? sk_cu_count() : 256;
   const int64_t tm = (p.M + XBM - 1) / XBM, tn = (p.N + XBN - 1) / XBN, nt = tm * tn, nkt = p.K / bk;
   if (nkt < 8 || tm * XBM * 4 > (int64_t)p.M * 5 + 4 * XBM) return 0;      // short reductions; rows padded by more than a quarter (+ one tile)
@@ -1750,15 +1924,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const f32x4 v = *(const f32x4*)(part + (int64_t)z * slab + i);
     acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
   }
+  float v4[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float v = acc[e];
-    if (p.bias) v += to_f32(((const T*)p.bias)[col + e]);
-    store_out<T>(p, p.C, p.res, row, col + e, v);
+  for (int e = 0; e < 4; ++e) v4[e] = acc[e] + (p.bias ? to_f32(((const T*)p.bias)[col + e]) : 0.f);
+  if (p.post == SL_POST_SILU_MUL_BWD) {
+    const int64_t o = row * p.post_ld + 32 * (col >> 4) + (col & 15);
+    T* op = (T*)p.C + row * p.ldc + 32 * (col >> 4) + (col & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float dg, du;
+      post_silu_bwd<T>(v4[e], to_f32(((const T*)p.post_in)[o + e]), to_f32(((const T*)p.post_in)[o + 16 + e]), dg, du);
+      op[e] = from_f32<T>(dg); op[16 + e] = from_f32<T>(du);
+    }
+    return;
   }
+  if (p.post) post_apply<T, 4>(p, row, col, v4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) store_out<T>(p, p.C, p.res, row, col + e, v4[e]);
 }
 
 static int splitk_runs(const GemmP& p, int batch, int bk, size_t ws_bytes) {
+  if (p.colsum) return 0;        // column sums are taken in the tile epilogues (one adder per wave and column), not in the reduce pass
   if (!sl_env().split_k || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.N < 128 || (p.N & 3)) return 0;
   const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
   const int nkt = p.K / bk;
@@ -1827,6 +2013,7 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
         q.K = p.K / S; q.sA = q.K; q.sW = q.K;                                // run z reads columns [z K/S, (z+1) K/S) of A and W
         q.C = part; q.ldc = p.N; q.sC = (int64_t)p.M * p.N; q.out_f32 = 1;
         q.bias = nullptr; q.sBias = 0; q.res = nullptr; q.ldr = 0; q.sR = 0; q.res_f32 = 0;
+        q.post = 0; q.drop_thr24 = 0; q.post_in = nullptr; q.colsum = nullptr;      // the reduce pass applies them
         SL_TRY((launch_tiled<T, SL_ACT_NONE>(q, S, st)));
         const int64_t vecs = ((int64_t)p.M * p.N + 3) / 4;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, part, S, (int64_t)p.M * p.N, p);
@@ -1854,19 +2041,20 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
     }
   }
   // large products: 256^2 tiles once they alone give every CU >= 2 tiles (ragged batches: sized by the largest group)
-  if (!p.ta && !p.tw && p.K % BK_ == 0 && !p.grp_ext && g_disable_glds == 0 && !sl_env().disable_t256) {
-    const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
+  if (!p.ta && !p.tw && p.K % BK_ == 0 && !p.grp_ext && g_disable_glds == 0 && !sl_env().disable_t256 && !((p.post || p.colsum) && !sl_env().t256_phased)) {
+    const int famM = (p.grp || batch != 1) ? p.M : sl_family_rows(p.M);      // the tile family follows the pinned rows (common.h sl_family_rows)
+    const int64_t t256 = (int64_t)((famM + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN) * batch;
     const int64_t min_tiles = sl_env().t256_min_tiles;   // tuning switches
     const int min_k = sl_env().t256_min_k;
     // rows padded to 256 vs to 128: short (grouped) products such as the 123-row projector would half-fill the big tile
-    const int64_t m128 = (int64_t)((p.M + TBM - 1) / TBM) * TBM, m256 = (int64_t)((p.M + XBM - 1) / XBM) * XBM;
+    const int64_t m128 = (int64_t)((famM + TBM - 1) / TBM) * TBM, m256 = (int64_t)((famM + XBM - 1) / XBM) * XBM;
     // Mid-size products (KD windows: M = 2-8 k rows): neither tile count fills the chip evenly, so the choice is made on whole
     // rounds of tiles — 256 slots of one 256^2 tile per CU against 512 slots of 128^2 tiles (two blocks per CU, each at ~0.85 of
     // the big tile's rate per flop): 5072 x 3072 is 240 big tiles = one round (1.09 PF/s; 960 small ones = two rounds, 0.99),
     // 3200 x 5120 is 260 big tiles = two rounds, the second almost empty (0.63 PF/s; small tiles 0.98).  tools/sweep_t256.py.
     bool by_rounds = false;
     if (t256 < min_tiles && !p.grp && batch == 1) {
-      const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+      const int64_t t128 = (int64_t)((famM + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
       const int64_t r256 = (t256 + 255) / 256, r128 = (t128 + 511) / 512;
       by_rounds = (double)r256 * (XBM * XBN) * 0.85 < (double)r128 * 2.0 * (TBM * TBN);
     }
@@ -1885,7 +2073,13 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
                         (!p.res || (!(p.ldr & 7) && !(p.sR & 7) && !((uintptr_t)p.res & 15)));
         const bool form = p.aux ? (!p.ln_mr && !p.stats_out && !p.res && !((uintptr_t)p.aux & 15))        // {bias, pre-activation copy}: the training forward's FFN1
                                 : !p.ln_mr ? (!p.stats_out || p.res) : (!p.res && !p.stats_out);
-        if (al && form && !p.grp && !p.out_f32 && !p.res_f32 && !p.amax_val && !p.direct_epi && !sl_env().no_swap_epilogue) {
+        // post-ops on the swapped-operand kernels: dropout in {bias, pre-activation copy, GELU} or {bias, residual}; GELU' (+ colsum_out) and SwiGLU' on
+        // the plain product; operand rows 16-byte aligned.  Everything else with a post-op takes the LDS-turned rows epilogue.
+        bool post_ok = !p.post && !p.colsum;      // (the phased kernel only: the one-barrier-per-slab A/B form keeps the plain epilogues)
+        if (p.post == SL_POST_DROPOUT) post_ok = !p.colsum && !p.ln_mr && !p.stats_out && (ACT == SL_ACT_GELU ? (p.aux && !p.res) : (p.res && !p.aux));
+        if (p.post == SL_POST_GELU_BWD || p.post == SL_POST_SILU_MUL_BWD)
+          post_ok = ACT == SL_ACT_NONE && !(p.post_ld & 7) && !((uintptr_t)p.post_in & 15) && (p.post == SL_POST_GELU_BWD || !p.colsum);
+        if (al && form && !p.grp && !p.out_f32 && !p.res_f32 && !p.amax_val && !p.direct_epi && !sl_env().no_swap_epilogue && post_ok && (phased || (!p.post && !p.colsum))) {
 #ifdef SL_GEMM_DEBUG
           if constexpr (ACT == SL_ACT_NONE) {       // instrumented / knocked-out builds (tools/gemm_stamps.py, tools/gemm_knockout.py), never in the product .so
             const int ko = sl_env().gemm_ko;
@@ -1919,6 +2113,10 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
   p.tiles_n = (p.N + TBN - 1) / TBN;
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   constexpr int BK = TROWB / (int)sizeof(T);
+  if ((p.post || p.colsum) && !(!p.ta && !p.tw && p.K % BK == 0 && (!p.grp_ext || p.grp_kslab) && !g_disable_glds)) {
+    sl_set_error("sl_gemm_ex: post_op / colsum_out need whole 128-byte K slabs (K %% %d == 0) and the LDS-DMA kernels (SL_DISABLE_GLDS unset)", BK);
+    return SL_ERR_UNSUPPORTED;
+  }
   if (!p.ta && !p.tw && p.K % BK == 0 && !p.grp_ext && g_disable_glds == 2)
     hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, false>), grid, dim3(256), 0, st, p);
   else if (!p.ta && !p.tw && p.K % BK == 0 && (!p.grp_ext || p.grp_kslab) && !g_disable_glds)   // per-group K: only the register path handles K tails (groups_ext = 2: the caller vouches for whole slabs)
@@ -1954,7 +2152,7 @@ static int launch_skinny_mt(GemmP& p, const SkinnyX& sx, int batch, hipStream_t 
       // of K divides evenly (o: 6 steps = 2 x 3, down: 16 = 4 x 4): 1.575 -> 1.49 ms per decode step at M = 1, +3 % at M = 16
       // where the x fragments crowd the loads.  The same sweep over the qkv and gate/up structures (2x16x3, 2x8x6, 2x8x3;
       // 4x4x6, 4x4x3, 2x8x3, 2x8x6, 4x8x3) moved nothing (profiles/r04_r_skinny_small_m.txt).  SL_SKINNY_ALT=1: old structure.
-      if (nfrag < 256 && p.M <= 8 && !(sl_env().skinny_alt & 1)) {
+      if (nfrag < 256 && sl_family_rows(p.M) <= 8 && !(sl_env().skinny_alt & 1)) {
         const int per_wave = p.K / 32 / 16;
         if (per_wave % 3 == 0) return launch_skinny_cfg<T, MT, ACT, 1, 16, 3, PACKED>(p, sx, batch, st);
         return launch_skinny_cfg<T, MT, ACT, 1, 16, 4, PACKED>(p, sx, batch, st);
@@ -1982,8 +2180,8 @@ static int launch_skinny(GemmP& p, const SkinnyX& sx, int batch, bool packed, hi
       sl_set_error("sl_gemm: packed weights are not built with the GELU epilogue");
       return SL_ERR_UNSUPPORTED;
     } else {
-      if (p.M <= 16) return launch_skinny_mt<T, 1, ACT, true>(p, sx, batch, st);
-      if (p.M <= 32) return launch_skinny_mt<T, 2, ACT, true>(p, sx, batch, st);
+      if (sl_family_rows(p.M) <= 16) return launch_skinny_mt<T, 1, ACT, true>(p, sx, batch, st);
+      if (sl_family_rows(p.M) <= 32) return launch_skinny_mt<T, 2, ACT, true>(p, sx, batch, st);
       return launch_skinny_mt<T, 4, ACT, true>(p, sx, batch, st);
     }
   }
@@ -1991,15 +2189,15 @@ static int launch_skinny(GemmP& p, const SkinnyX& sx, int batch, bool packed, hi
     sl_set_error("sl_gemm: the ROPE_KV epilogue needs packed weights");
     return SL_ERR_UNSUPPORTED;
   } else {
-    if (p.M <= 16) return launch_skinny_mt<T, 1, ACT, false>(p, sx, batch, st);
-    if (p.M <= 32) return launch_skinny_mt<T, 2, ACT, false>(p, sx, batch, st);
+    if (sl_family_rows(p.M) <= 16) return launch_skinny_mt<T, 1, ACT, false>(p, sx, batch, st);
+    if (sl_family_rows(p.M) <= 32) return launch_skinny_mt<T, 2, ACT, false>(p, sx, batch, st);
     return launch_skinny_mt<T, 4, ACT, false>(p, sx, batch, st);
   }
 }
 
 template <typename T>
 static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStream_t st, void* sk_ws, size_t sk_ws_bytes) {
-  const bool skinny = a->M <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32 && !p.grp && !p.ln_mr && !p.stats_out;  // backward features and the LayerNorm fold live in the tiled kernel
+  const bool skinny = sl_family_rows(a->M) <= 64 && !p.ta && !p.tw && !p.aux && !p.res_f32 && !p.grp && !p.ln_mr && !p.stats_out && !p.post && !p.colsum;  // backward features and the LayerNorm fold live in the tiled kernel
   const bool packed = a->w_layout == SL_W_PACKED;
   if (!skinny && (packed || a->act == SL_ACT_ROPE_KV || sx.fuse_rms)) {
     sl_set_error("sl_gemm: packed weights / ROPE_KV / fused RMSNorm need plain operands (no transposes / groups), M=%d", a->M);
@@ -2017,6 +2215,11 @@ static int gemm_typed(const sl_gemm_args* a, GemmP& p, const SkinnyX& sx, hipStr
 
 // true when a plain (M, N, K) product of this dtype is served by one of the LDS-DMA tiled kernels, whose rows epilogue carries the
 // LayerNorm fold (ln_* / stats_out)
+// shapes for which the training tapes may hand a product its post-ops (train_tape.hip fuse_ok): the tiled kernels' row range, whole K slabs
+bool sl_gemm_post_ok(int64_t M, int N, int K, int dtype) {
+  return sl_family_rows((int)(M > 0x7fffffff ? 0x7fffffff : M)) > 64 && M > 64 && N % 16 == 0 && K % (dtype == SL_F32 ? 32 : 64) == 0 && sl_env().disable_glds == 0;
+}
+
 bool sl_gemm_rows_epilogue_ok(int M, int N, int K, int dtype) {
   // any row count: a product that carries ln_* / stats_out is kept on the tiled kernels even below 65 rows (gemm_typed), so that the fold is a
   // property of the MODEL — a short utterance encoded alone takes the same epilogues, hence the same bits, as inside a batch
@@ -2051,6 +2254,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
+  p.post = 0; p.drop_thr24 = 0; p.drop_scale = 1.f; p.drop_seed = 0; p.drop_ld = 0; p.post_in = nullptr; p.post_ld = 0; p.colsum = nullptr;
   p.stamp = nullptr; p.amax_val = nullptr; p.amax_idx = nullptr; p.ln_mr = nullptr; p.ln_u = nullptr; p.ln_c = nullptr; p.stats_out = nullptr;
   const int direct_epi = sl_env().direct_epilogue;
   p.direct_epi = direct_epi;
@@ -2074,9 +2278,30 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
                    "sl_gemm_ex: the LayerNorm fold needs ln_mr, ln_u and ln_c together (the bias is inside ln_c)");
       p.ln_mr = ex->ln_mr; p.ln_u = ex->ln_u; p.ln_c = ex->ln_c; p.stats_out = ex->stats_out;
     }
+    if (ex->post_op || ex->colsum_out) {
+      SL_CHECK_ARG(ex->post_op >= SL_POST_NONE && ex->post_op <= SL_POST_SILU_MUL_BWD, "sl_gemm_ex: unknown post_op %d", ex->post_op);
+      SL_CHECK_ARG(!ex->trans_a && !ex->trans_w && !ex->groups && !ex->ln_mr && !ex->ln_u && !ex->ln_c && !ex->stats_out && !ex->amax_val && !ex->amax_idx &&
+                       a->batch == 1 && a->w_layout == SL_W_ROWMAJOR && a->act != SL_ACT_SILU_MUL && a->act != SL_ACT_ROPE_KV && a->M > 64,
+                   "sl_gemm_ex: post_op / colsum_out need one plain row-major product on the tiled kernels (M > 64, no transposes / groups / ln_* / stats_out / amax_*)");
+      SL_CHECK_ARG(ex->drop_p >= 0.f && ex->drop_p < 1.f, "sl_gemm_ex: drop_p %f outside [0, 1)", (double)ex->drop_p);
+      if (ex->post_op == SL_POST_DROPOUT) SL_CHECK_ARG(ex->drop_p > 0.f && ex->drop_ld >= a->N, "sl_gemm_ex: SL_POST_DROPOUT needs drop_p > 0 and drop_ld >= N");
+      if (ex->post_op == SL_POST_GELU_BWD)
+        SL_CHECK_ARG(ex->post_in && ex->post_ld >= a->N && !a->residual && !a->bias && a->act == SL_ACT_NONE && !ex->aux_out && !a->out_f32 && (ex->drop_p == 0.f || ex->drop_ld >= a->N),
+                     "sl_gemm_ex: SL_POST_GELU_BWD needs post_in (M, N), the plain epilogue (no bias / residual / act / aux_out) and an output in the storage type");
+      if (ex->post_op == SL_POST_SILU_MUL_BWD)
+        SL_CHECK_ARG(ex->post_in && ex->post_ld >= 2 * (int64_t)a->N && a->ldc >= 2 * (int64_t)a->N && a->N % 16 == 0 && !a->residual && !a->bias && a->act == SL_ACT_NONE &&
+                         !ex->aux_out && !a->out_f32 && !ex->colsum_out && ex->drop_p == 0.f,
+                     "sl_gemm_ex: SL_POST_SILU_MUL_BWD needs post_in = gu (M, 2 N), ldc >= 2 N, N %% 16 == 0 and the plain epilogue");
+      p.post = ex->post_op; p.post_in = ex->post_in; p.post_ld = ex->post_ld; p.colsum = ex->colsum_out;
+      if (ex->drop_p > 0.f && ex->post_op != SL_POST_NONE) {
+        p.drop_thr24 = (uint32_t)((double)ex->drop_p * 16777216.0);
+        p.drop_scale = 1.0f / (1.0f - ex->drop_p);
+        p.drop_seed = ex->drop_seed; p.drop_ld = ex->drop_ld;
+      }
+    }
     if (ex->amax_val || ex->amax_idx) {
       SL_CHECK_ARG(ex->amax_val && ex->amax_idx && a->act == SL_ACT_NONE && a->batch == 1 && !ex->groups && !ex->trans_a && !ex->trans_w && !ex->aux_out &&
-                       !a->residual && a->M > 64 && a->w_layout == SL_W_ROWMAJOR,
+                       !a->residual && sl_family_rows(a->M) > 64 && a->w_layout == SL_W_ROWMAJOR,
                    "sl_gemm_ex: amax_val / amax_idx (fused row-wise top-1) need both pointers, the plain epilogue without residual, one "
                    "un-grouped row-major product and M > 64 (M=%d act=%d batch=%d)", a->M, a->act, a->batch);
       p.amax_val = ex->amax_val; p.amax_idx = ex->amax_idx;
@@ -2101,10 +2326,10 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
     SL_CHECK_ARG(a->N == (fx->n_heads + 2 * fx->n_kv_heads) * 128 && a->batch == 1, "sl_gemm: ROPE_KV expects N = (n_heads + 2 n_kv) * 128");
   }
   // packed weights with more than g_stream_min_m rows: LDS-staged streaming kernel (gemm_stream.hip)
-  if (a->w_layout == SL_W_PACKED && a->M > stream_min_m() && a->batch == 1 && !ex && a->act != SL_ACT_GELU &&
+  if (a->w_layout == SL_W_PACKED && sl_family_rows(a->M) > stream_min_m() && a->batch == 1 && !ex && a->act != SL_ACT_GELU &&
       a->K % (a->dtype == SL_F32 ? 32 : 64) == 0)
     return sl_gemm_stream_launch(p, sx, a->dtype, a->act, fx ? fx->split_ws : nullptr, fx ? fx->split_ws_bytes : 0, st);
-  SL_CHECK_ARG(a->w_layout != SL_W_PACKED || a->M <= 64, "sl_gemm: packed weights with M=%d > 64 need batch 1 and K %% 64 == 0", a->M);
+  SL_CHECK_ARG(a->w_layout != SL_W_PACKED || sl_family_rows(a->M) <= 64, "sl_gemm: packed weights with M=%d > 64 need batch 1 and K %% 64 == 0", a->M);
   SL_CHECK_ARG(!sx.rstd_in && !sx.rstd_out && !sx.norm_out, "sl_gemm: rstd_in / rstd_out / norm_out are features of the streaming path (M > %d rows, packed weights)", stream_min_m());
   void* sk_ws = ex ? ex->sk_ws : nullptr;
   const size_t sk_ws_bytes = ex ? ex->sk_ws_bytes : 0;
@@ -2114,12 +2339,13 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
 }
 
 extern "C" int32_t sl_gemm_split_count(int32_t M, int32_t N, int32_t K, int32_t dtype) {
+  M = sl_family_rows(M);
   if (M <= stream_min_m() || M <= 0 || N <= 0 || K <= 0 || K % (dtype == SL_F32 ? 32 : 64) != 0) return 1;
   return sl_gemm_stream_splits(M, N, K, dtype);
 }
 
 extern "C" size_t sl_gemm_split_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t dtype) {
-  if (M <= stream_min_m() || M <= 0 || N <= 0 || K <= 0) return 0;
+  if (sl_family_rows(M) <= stream_min_m() || M <= 0 || N <= 0 || K <= 0) return 0;
   return sl_gemm_stream_ws_bytes(M, N, K, dtype);
 }
 

@@ -27,6 +27,14 @@ struct GemmP {
   float* stats_out;    // producer: per row and 64-column segment {sum, sum of squares} of the STORED (rounded) values, [row][N / 64][2]
   float* amax_val;     // fused row-wise top-1 (sl_gemm_ex_args.amax_*): per 64-column group g and row m the largest value of
   int* amax_idx;       // columns [64 g, 64 g + 64) at [g][m] and its column index; C is then not written at all
+  // training-tape epilogue fusions (sl_gemm_ex_args.post_op ...): rows epilogue (generic form) / direct epilogue / split-K reduce pass
+  int post;            // SL_POST_*
+  uint32_t drop_thr24; // keep iff u24(hash) >= thr (0: no mask)
+  float drop_scale;    // 1 / (1 - p)
+  uint64_t drop_seed;
+  int64_t drop_ld;     // element index of (row, col) in the mask = row * drop_ld + col
+  const void* post_in; int64_t post_ld;
+  float* colsum;       // fp32 column sums of the stored values (+=, atomics)
   uint32_t* stamp;     // instrumented build of the phased 256-tile kernel only: [block][half][32] cycle stamps (SL_GEMM_STAMP_PTR)
 };
 
@@ -58,6 +66,51 @@ __device__ __forceinline__ void store_out(const GemmP& p, void* Cb, const void* 
     ((float*)Cb)[row * p.ldc + col] = v;
   else
     ((T*)Cb)[row * p.ldc + col] = from_f32<T>(v);
+}
+
+// ----------------------------------------------------------------------------------------------
+// training-tape post-ops on NV consecutive columns of one output row (v = A.W^T + bias, after act; before the residual add).
+// Roundings follow the unfused launch sequence: GEMM store -> sl_dropout (in place) -> sl_gelu_bwd, each storing in T.
+// ----------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float round_as(float v) { return to_f32(from_f32<T>(v)); }
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+
+template <typename T, int NV>
+__device__ __forceinline__ void post_drop(const GemmP& p, int64_t row, int col, float (&v)[NV]) {
+  if (!p.drop_thr24) return;
+  const int64_t i0 = row * p.drop_ld + col;
+  const uint32_t inner = drop_inner((uint32_t)((uint64_t)i0 >> 32), p.drop_seed);
+  const uint32_t inner2 = drop_inner((uint32_t)((uint64_t)(i0 + NV - 1) >> 32), p.drop_seed);     // the NV indices straddle a 2^32 boundary at most once
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int64_t i = i0 + j;
+    const uint32_t in_ = ((uint64_t)i >> 32) == ((uint64_t)i0 >> 32) ? inner : inner2;
+    v[j] = dropout_keep_lo((uint32_t)i, in_, p.drop_thr24) ? round_as<T>(v[j]) * p.drop_scale : 0.f;
+  }
+}
+
+// SL_POST_DROPOUT / SL_POST_GELU_BWD on NV columns starting at `col` (NV = 4 rows epilogue, 1 direct epilogue)
+template <typename T, int NV>
+__device__ __forceinline__ void post_apply(const GemmP& p, int64_t row, int col, float (&v)[NV]) {
+  if (p.post == SL_POST_DROPOUT) {
+    post_drop<T, NV>(p, row, col, v);
+  } else if (p.post == SL_POST_GELU_BWD) {
+    if (p.drop_thr24) {
+      post_drop<T, NV>(p, row, col, v);
+    }
+    const T* pre = (const T*)p.post_in + row * p.post_ld + col;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = round_as<T>(v[j]) * gelu_grad(to_f32(pre[j]));
+  }
+}
+
+// SL_POST_SILU_MUL_BWD: d = (A.W^T)[row][col], gate / up pre-activations from gu (interleaved [16 gate | 16 up]) -> d gate, d up
+template <typename T>
+__device__ __forceinline__ void post_silu_bwd(float d, float g, float u, float& dg, float& du) {
+  d = round_as<T>(d);
+  const float sg = 1.0f / (1.0f + __expf(-g));
+  dg = d * u * sg * (1.0f + g * (1.0f - sg));
+  du = d * g * sg;
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -755,13 +755,13 @@ static StreamCfg stream_cfg(int M, int N, int K, int kstep, bool have_ws, int dt
 static size_t stream_ws_header(int M) { return 8192 + (((size_t)32 * M * sizeof(float) + 255) & ~(size_t)255); }
 
 int sl_gemm_stream_splits(int M, int N, int K, int dtype) {
-  const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
+  const StreamCfg c = stream_cfg(sl_family_rows(M), N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
   return c.wide ? c.wsplits : c.splits;
 }
 
 size_t sl_gemm_stream_ws_bytes(int M, int N, int K, int dtype) {
   const size_t np = (size_t)((N + 15) / 16) * 16;
-  const StreamCfg c = stream_cfg(M, N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
+  const StreamCfg c = stream_cfg(sl_family_rows(M), N, K, dtype == SL_F32 ? 16 : 32, true, dtype);
   const int most = c.wide && c.wsplits > c.splits ? c.wsplits : c.splits;   // either form may run (the wide one not when the kernel takes the RMSNorm statistics itself)
   size_t splits = most > 1 ? (size_t)most : 0;
   return stream_ws_header(M) + splits * ((size_t)M * np + (size_t)M) * sizeof(float) + 256;
@@ -877,7 +877,7 @@ static int launch_stream_wide(GemmP& p, const SkinnyX& sx, int act, const Stream
 int sl_gemm_stream_launch(GemmP& p, const SkinnyX& sx, int dtype, int act, void* split_ws, size_t split_ws_bytes, hipStream_t st) {
   const int kstep = dtype == SL_F32 ? 16 : 32;
   SL_CHECK_ARG(p.K % (2 * kstep) == 0, "sl_gemm: streaming path needs K %% %d == 0 (K=%d)", 2 * kstep, p.K);
-  StreamCfg c = stream_cfg(p.M, p.N, p.K, kstep, split_ws != nullptr, dtype);
+  StreamCfg c = stream_cfg(sl_family_rows(p.M), p.N, p.K, kstep, split_ws != nullptr, dtype);      // the block shape and K-split of the pinned family (common.h)
   StreamX s;
   const bool wide = stream_wide_ok(sx, act, c, split_ws != nullptr);
   if (wide) c.splits = c.wsplits;

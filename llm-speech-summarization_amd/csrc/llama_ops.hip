@@ -1110,8 +1110,9 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
     // form spreads the same keys over (sequence, kv head, 64 keys) blocks: long-form leg of bench.py (16 utterances of 30-120 s,
     // contexts up to 1 782) decode 680 -> 627 ms; at contexts of a few hundred keys the single pass stays ahead (1.88 vs 1.94 ms
     // per step at 16 sequences, 709 vs 743 ms for the Whisper leg's 32 sequences)
-    const bool long_thin = max_ctx >= 1024 && (int64_t)B * nkv < 768;
-    if ((int64_t)B * nkv >= full_min && !long_thin && !sl_env().attn_force_split) {
+    const int64_t Bf = sl_family_rows(B);              // the form follows the pinned family's rows (common.h sl_family_rows)
+    const bool long_thin = max_ctx >= 1024 && Bf * nkv < 768;
+    if (Bf * nkv >= full_min && !long_thin && !sl_env().attn_force_split) {
       if (sl_env().attn_decode_ks == 65)        // 64-key chunks with the NEXT chunk's K / V rows held in a second register set (twice the bytes in flight per block)
         hipLaunchKernelGGL((attn_decode_full_kernel<REP, true, 64>), dim3(nkv, B), dim3(256), 0, st, (const bf16_t*)q, q_stride, (const bf16_t*)kc,
                            (const bf16_t*)vc, (bf16_t*)out, ctx_len, ctx_add, nh, nkv, max_ctx, scale, shared_prefix);
@@ -1126,7 +1127,7 @@ static int launch_attn_decode_split(const void* q, int64_t q_stride, const void*
     }
   }
   int nsplit;
-  if ((int64_t)B * nkv >= 512) {
+  if ((int64_t)sl_family_rows(B) * nkv >= 512) {
     nsplit = (max_ctx + 127) / 128;
     hipLaunchKernelGGL((attn_decode_split_kernel<T, REP, 128>), dim3(nkv, B, nsplit), dim3(256), 0, st, (const T*)q, q_stride, (const T*)kc,
                        (const T*)vc, part, ctx_len, ctx_add, nkv, max_ctx, scale, cnt, (T*)out);
@@ -1160,7 +1161,7 @@ int sl_attn_decode_split_impl(const void* q, int64_t q_stride, const void* k_cac
   // path serves small batches (B * n_kv <= 32); large fp32 batches keep the combine launch (one counter per (sequence, kv head)).
   // SL_ATTN_SPLIT_MERGE = 0 / 1 forces it off / on.
   const int mode = sl_env().attn_split_merge;
-  if (mode == 0 || (mode < 0 && (int64_t)B * n_kv > 32)) counters = 0;
+  if (mode == 0 || (mode < 0 && (int64_t)sl_family_rows(B) * n_kv > 32)) counters = 0;
   int32_t* cnt = counters ? (int32_t*)((unsigned char*)workspace + attn_split_records_bytes(B, n_heads, n_kv, max_ctx)) : nullptr;
   if (counters == 2) SL_TRY(sl_attn_decode_split_zero_counters(workspace, B, n_heads, n_kv, max_ctx, st));
   SL_DISPATCH_DTYPE(dtype, T, {

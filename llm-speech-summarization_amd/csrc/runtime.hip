@@ -566,7 +566,7 @@ static int llama_layer(const sl_llama_model* m, const sl_kv_cache* kv, int l, vo
         fn.fuse_rms = 1; fn.rms_eps = m->rms_eps;
         SL_TRY(dec_gemm(m, w, x, H, L.wgu_dec, w.mid, m->ffn, nullptr, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, &fn, st, w.rstd_a));
       }
-    } else if (n > 896 && dt == SL_BF16 && L.wgu && rstd_chain && sl_env().decode_tiled) {
+    } else if (sl_family_rows((int)n) > 896 && dt == SL_BF16 && L.wgu && rstd_chain && sl_env().decode_tiled) {
       SL_TRY(dec_gemm(m, w, w.att, (int64_t)nh * D, L.wo_dec, x, H, x, (int)n, H, nh * D, SL_ACT_NONE, 0, nullptr, st, nullptr, w.rstd_a, w.h, L.norm2));
       SL_TRY(gemm(dt, w.h, H, L.wgu, H, w.mid, m->ffn, nullptr, nullptr, 0, (int)n, 2 * m->ffn, H, SL_ACT_SILU_MUL, 0, st));
     } else {
@@ -710,7 +710,7 @@ extern "C" int sl_llama_prefill(const sl_llama_model* m, const sl_kv_cache* kv, 
 constexpr int SL_FUSED_ARGMAX_MIN_B = 256;
 
 // = the steps whose lm_head runs on the tiled kernels (below: packed weights stream through dec_gemm up to 255 rows)
-static bool decode_fuses_argmax(const sl_llama_model* m, int B) { return B > 64 && !(m->lm_head_dec && B < SL_FUSED_ARGMAX_MIN_B); }
+static bool decode_fuses_argmax(const sl_llama_model* m, int B) { B = sl_family_rows(B); return B > 64 && !(m->lm_head_dec && B < SL_FUSED_ARGMAX_MIN_B); }
 
 // fused_top1: the caller will run sl_greedy_select_partial_impl over `logits` reinterpreted as [n_groups][B] floats followed by
 // [n_groups][B] int32 (n_groups = ceil(vocab / 64)) — only honoured where decode_fuses_argmax() says so
@@ -727,7 +727,7 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
   }
   // rows whose o / down projections run UNSPLIT on the 256 x 128 blocks (from ~1 500 rows at Llama-3.2-3B's widths: 8 x 24 = 192 blocks
   // at 2 048): no reduce pass exists to take the RMSNorm scales in, a one-read pass in front of qkv and gate/up leaves them instead
-  bool rstd_pass = !chain && dt == SL_BF16 && m->dec_fused_norm && B > 384 && sl_gemm_split_count(B, H, m->n_heads * m->head_dim, dt) == 1 &&
+  bool rstd_pass = !chain && dt == SL_BF16 && m->dec_fused_norm && sl_family_rows(B) > 384 && sl_gemm_split_count(B, H, m->n_heads * m->head_dim, dt) == 1 &&
                    sl_gemm_split_count(B, H, m->ffn, dt) == 1;
   for (int l = 0; l < m->n_layers && rstd_pass; ++l) {
     const sl_llama_layer& L = m->layers[l];
@@ -737,7 +737,7 @@ static int decode_step(const sl_llama_model* m, const sl_kv_cache* kv, const int
     SL_TRY(llama_layer(m, kv, l, x, B, w, true, B, 1, ctx_len, st, chain, (chain && l > 0) ? w.rstd_b : nullptr, 0, 0, rstd_pass));
   // lm_head: above ~256 rows the 128-tile MFMA kernel on the row-major matrix beats the streaming kernel on the packed one
   // (M=512: 439 vs 632 us; the 263 MB of fp32 logits dominate either way)
-  if (m->lm_head_dec && B < SL_FUSED_ARGMAX_MIN_B) {
+  if (m->lm_head_dec && sl_family_rows(B) < SL_FUSED_ARGMAX_MIN_B) {
     sl_gemm_fused fx;
     memset(&fx, 0, sizeof(fx));
     fx.fuse_rms = m->dec_fused_norm; fx.rms_eps = m->rms_eps;
@@ -962,7 +962,12 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
   // without re-capturing.  Every pointer the captured launches were recorded with is part of the key (the state arrays and the
   // scratch layout follow from the workspace pointer, the ORIGINAL batch B0 and the row count B), so a changed buffer can never
   // replay a stale graph.  Also resets the per-graph scratch (K-split counters, split-attention counters, the slot index list).
+  // A compacting generation keeps the kernel family of the batch it started with (common.h sl_family_rows): measured at full depth in bf16,
+  // 819 of 1 024 random-init sequences changed ids when each rung picked its own family (near-ties flip between the families' rounding
+  // orders) — pinned, a sequence's ids are those of the uncompacted batch, bit for bit.  SL_COMPACT_PIN=0: the old behaviour (A/B only).
+  const int pin_rows = (o->compact && use_eos && sl_env().compact_pin) ? B0 : 0;
   auto graph_for = [&](int B, hipGraphExec_t* exec_out) -> int {
+    SlFamilyPin pin(pin_rows);
     LlamaWs w;
     llama_carve(m, B, B, scratch, scratch_bytes, w);
     if (w.split && w.split_bytes >= 8192) SL_HIP(hipMemsetAsync(w.split, 0, 8192, st));   // the K-split fix-up's counters start at zero (sl_gemm_fused.split_ws)
@@ -974,7 +979,7 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
     key.model = m; key.layers = m->layers; key.w0 = m->n_layers > 0 ? m->layers[0].wqkv_dec : nullptr; key.lm = m->lm_head_dec ? m->lm_head_dec : m->lm_head;
     key.embed = m->embed; key.kc = kv->k_cache; key.vc = kv->v_cache; key.ws = workspace; key.ws_bytes = workspace_bytes;
     key.B = B; key.B0 = B0; key.max_new = max_new_tokens; key.use_eos = use_eos; key.n_eos = n_eos; key.pad = pad_id; key.max_ctx = kv->max_ctx;
-    key.slots = kv->slots; key.shared_prefix = kv->shared_prefix; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8) | ((sl_env().attn_decode_ks & 127) << 9);   // + the switch that shapes the captured launches
+    key.slots = kv->slots; key.shared_prefix = kv->shared_prefix; key.dtype = m->dtype; key.n_layers = m->n_layers; key.vocab = m->vocab; key.fused = m->dec_fused_norm | (sl_env().decode_tiled << 8) | ((sl_env().attn_decode_ks & 127) << 9) | ((pin_rows ? 1 : 0) << 16);   // + the switch that shapes the captured launches
     key.limits = row_limit_arg ? 1 : 0;
     key.content = model_content_hash(m);
     SL_HIP(hipGetDevice(&key.device));

@@ -9,12 +9,6 @@
 
 constexpr int TR_MAXF = 64;  // floats per lane for row kernels (rows up to 4096 elements)
 
-__device__ __forceinline__ float gelu_grad(float u) {
-  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
-  return cdf + u * pdf;
-}
-
 // ----------------------------------------------------------------------------------------------
 // elementwise: GELU backward, axpby, SwiGLU on the 16-row interleaved gate/up layout
 // ----------------------------------------------------------------------------------------------
@@ -256,11 +250,48 @@ __device__ __forceinline__ void reconvert_here(uint4& v) { asm volatile("" : "+v
 // LEAN (rows without the fused GELU): a lane keeps its share of x and dy as LOADED (16-byte vectors) and converts them again in every
 // pass instead of holding xhat and dy * gamma as floats, and beta is not needed at all: the 16-wave form has 128 registers per lane
 // and the float copies made it spill 34 of them to scratch inside the row loop.  Same operations in the same order: same bits.
+// optional extras of the training tapes (train_tape.hip): a second residual-branch gradient, and a second OUTPUT — the dropout of the stored dx
+// under the mask of the Linear the gradient flows into next (h = h + dropout(sublayer(h)): the sublayer's output gradient is dropout(dx)),
+// which saves that layer's sl_dropout launch and its read of dx
+struct NormBwdX {
+  const void* add2;      // dx = round(dx + add2) after the first add (the bits of a following sl_axpby(add2, dx))
+  void* dx_drop;         // dropout(dx as stored) at element index row * cols + col
+  uint32_t thr24; float scale; uint64_t seed;
+};
+
+template <typename T>
+__device__ __forceinline__ void norm_bwd_store(T* __restrict__ dx, const T* __restrict__ add, const NormBwdX& ex, int64_t row, int cols, int c0, float (&o)[Vec16<T>::VEC]) {
+  constexpr int VEC = Vec16<T>::VEC;
+  if (add) {      // rounded to the storage type first, then added: the bits of dx = round(backward) followed by axpby(add, dx)
+    float av[VEC];
+    Vec16<T>::unpack(*(const uint4*)(add + row * cols + c0), av);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = to_f32(from_f32<T>(o[e])) + av[e];
+  }
+  if (ex.add2) {
+    float av[VEC];
+    Vec16<T>::unpack(*(const uint4*)((const T*)ex.add2 + row * cols + c0), av);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = to_f32(from_f32<T>(o[e])) + av[e];
+  }
+  const uint4 pk = Vec16<T>::pack(o);
+  *(uint4*)(dx + row * cols + c0) = pk;
+  if (ex.dx_drop) {
+    float sv[VEC];
+    Vec16<T>::unpack(pk, sv);          // the values as stored
+    const int64_t i0 = row * cols + c0;         // a multiple of VEC: the chunk's indices share their upper half
+    const uint32_t inner = drop_inner((uint32_t)((uint64_t)i0 >> 32), ex.seed);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sv[e] = dropout_keep_lo((uint32_t)(i0 + e), inner, ex.thr24) ? sv[e] * ex.scale : 0.f;
+    *(uint4*)((T*)ex.dx_drop + row * cols + c0) = Vec16<T>::pack(sv);
+  }
+}
+
 template <typename T, bool RMS, int MAXF, int NW, bool LEAN = false>
 __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int64_t rows, int cols, float eps, int gelu, int rows_per_block,
-                                                           float* __restrict__ part, const T* __restrict__ add = nullptr) {
+                                                           float* __restrict__ part, const T* __restrict__ add = nullptr, NormBwdX ex = NormBwdX{}) {
   // add (optional, same shape as dx, not aliasing it): dx = backward(dy) + add — the residual branch's gradient joins here instead of in a
   // separate axpby launch (one read + one write of the whole activation less per LayerNorm / RMSNorm in the training tapes)
   constexpr int VEC = Vec16<T>::VEC;
@@ -352,13 +383,7 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
             const float dg = dv[e] * gg[i][e];
             o[e] = RMS ? rstd * (dg - xh * s2) : rstd * (dg - s1 - xh * s2);
           }
-          if (add) {
-            float av[VEC];
-            Vec16<T>::unpack(*(const uint4*)(add + row * cols + ch * VEC), av);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = to_f32(from_f32<T>(o[e])) + av[e];
-          }
-          *(uint4*)(dx + row * cols + ch * VEC) = Vec16<T>::pack(o);
+          norm_bwd_store<T>(dx, add, ex, row, cols, ch * VEC, o);
         }
       }
     }
@@ -419,13 +444,7 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
         float o[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = RMS ? rstd * (dv[i][e] - xv[i][e] * s2) : rstd * (dv[i][e] - s1 - xv[i][e] * s2);
-        if (add) {      // rounded to the storage type first, then added: the bits of dx = round(backward) followed by axpby(add, dx)
-          float av[VEC];
-          Vec16<T>::unpack(*(const uint4*)(add + row * cols + ch * VEC), av);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) o[e] = to_f32(from_f32<T>(o[e])) + av[e];
-        }
-        *(uint4*)(dx + row * cols + ch * VEC) = Vec16<T>::pack(o);
+        norm_bwd_store<T>(dx, add, ex, row, cols, ch * VEC, o);
       }
     }
   }
@@ -1115,8 +1134,10 @@ extern "C" size_t sl_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
 }
 
 static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta, int64_t rows,
-                              int32_t cols, float eps, int32_t gelu, int32_t dtype, void* ws, size_t ws_bytes, sl_stream stream, const void* add = nullptr) {
+                              int32_t cols, float eps, int32_t gelu, int32_t dtype, void* ws, size_t ws_bytes, sl_stream stream, const void* add = nullptr,
+                              NormBwdX ex = NormBwdX{}) {
   SL_CHECK_ARG(!add || add != dx, "sl_layernorm_bwd: the residual gradient must not alias dx");
+  SL_CHECK_ARG(!ex.dx_drop || (ex.dx_drop != dx && ex.dx_drop != dy && ex.dx_drop != add), "sl_layernorm_bwd: the dropped copy must not alias dx / dy / add");
   SL_CHECK_ARG(x && gamma && beta && dy && dx && rows >= 0 && cols > 0, "sl_layernorm_bwd: bad arguments");
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_layernorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
@@ -1128,16 +1149,16 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
       SL_DISPATCH_DTYPE(dtype, T, {
         if (gelu)
           hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws, (const T*)add);
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)ws, (const T*)add, ex);
         else if (ln_bwd_nw() == 8)
           hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 8, true>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add);
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add, ex);
         else if (ln_bwd_nw() == 4)
           hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 4, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add);
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add, ex);
         else
           hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16, true>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add);
+                             (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add, ex);
       });
       SL_CHECK_LAUNCH("layernorm_bwd");
       hipLaunchKernelGGL(norm_colreduce_kernel, dim3((unsigned)((2 * cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nb, cols, dgamma,
@@ -1154,10 +1175,10 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
     SL_DISPATCH_DTYPE(dtype, T, {
       if (gelu)
         hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)ceil_div64(rows, rpb16)), dim3(1024), 0, (hipStream_t)stream, (const T*)x,
-                           (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb16, (float*)nullptr, (const T*)add);
+                           (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb16, (float*)nullptr, (const T*)add, ex);
       else
         hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16, true>), dim3((unsigned)ceil_div64(rows, rpb16)), dim3(1024), 0, (hipStream_t)stream, (const T*)x,
-                           (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb16, (float*)nullptr, (const T*)add);
+                           (const T*)gamma, (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb16, (float*)nullptr, (const T*)add, ex);
     });
     SL_CHECK_LAUNCH("layernorm_bwd");
     return 0;
@@ -1168,16 +1189,22 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
   rpb = rpb < 4 ? 4 : (rpb > 64 ? 64 : rpb);
   SL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((norm_bwd_kernel<T, false, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
-                       (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)nullptr, (const T*)add);
+                       (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, gelu, rpb, (float*)nullptr, (const T*)add, ex);
   });
   SL_CHECK_LAUNCH("layernorm_bwd");
   return 0;
 }
 
 // the training tapes' forms (train_tape.hip): dx = backward(dy) + add
+// dx_drop (optional): also dropout(dx) with (p, seed) — the incoming gradient of the Linear below (h = h + dropout(sublayer(h)))
 int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
-                                 int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream) {
-  return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, 0, dtype, workspace, workspace_bytes, stream, add);
+                                 int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream,
+                                 void* dx_drop, float drop_p, uint64_t drop_seed) {
+  NormBwdX ex{};
+  if (dx_drop && drop_p > 0.f) {
+    ex.dx_drop = dx_drop; ex.thr24 = (uint32_t)((double)drop_p * 16777216.0); ex.scale = 1.0f / (1.0f - drop_p); ex.seed = drop_seed;
+  }
+  return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, 0, dtype, workspace, workspace_bytes, stream, add, ex);
 }
 
 extern "C" int sl_layernorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta,
@@ -1191,16 +1218,20 @@ extern "C" int sl_layernorm_bwd_ws(const void* x, const void* gamma, const void*
   return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, gelu, dtype, workspace, workspace_bytes, stream);
 }
 
+// add2 (optional): a second gradient joining at this hidden state (the feature-distillation term), added after `add` with the roundings of a
+// following sl_axpby(add2, dx)
 int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const void* add, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
-                            sl_stream stream) {
-  SL_CHECK_ARG(x && w && dy && dx && rows >= 0 && cols > 0 && (!add || add != dx), "sl_rmsnorm_bwd: bad arguments");
+                            sl_stream stream, const void* add2) {
+  SL_CHECK_ARG(x && w && dy && dx && rows >= 0 && cols > 0 && (!add || add != dx) && (!add2 || add2 != dx), "sl_rmsnorm_bwd: bad arguments");
+  NormBwdX ex{};
+  ex.add2 = add2;
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_rmsnorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
   if (rows == 0) return 0;
   const int rpb = 16;
   SL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((norm_bwd_kernel<T, true, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add);
+                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add, ex);
   });
   SL_CHECK_LAUNCH("rmsnorm_bwd");
   return 0;
@@ -1208,7 +1239,7 @@ int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const 
 
 extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
                               sl_stream stream) {
-  return sl_rmsnorm_bwd_add_impl(x, w, dy, nullptr, dx, rows, cols, eps, dtype, stream);
+  return sl_rmsnorm_bwd_add_impl(x, w, dy, nullptr, dx, rows, cols, eps, dtype, stream, nullptr);
 }
 
 extern "C" int sl_colsum(const void* x, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t dtype, sl_stream stream) {

@@ -9,10 +9,12 @@
 #include "common.h"
 
 // train_ops.hip: norm backward with the residual branch's gradient added in the same pass (dx = backward(dy) + add)
+// ... and, optionally, dropout(dx) as a second output (dx_drop: the incoming gradient of the sublayer below) / a second joining gradient (add2)
 int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
-                                 int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream);
+                                 int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream,
+                                 void* dx_drop, float drop_p, uint64_t drop_seed);
 int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const void* add, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
-                            sl_stream stream);
+                            sl_stream stream, const void* add2);
 
 namespace {
 
@@ -30,21 +32,37 @@ struct Carver {
 
 inline int64_t rup(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
+// epilogue fusion of a product (sl_gemm_ex_args.post_op ...): the element-wise launch that used to follow it
+struct Post {
+  int op = SL_POST_NONE;
+  float p = 0.f; uint64_t seed = 0; int64_t ld = 0;     // dropout mask (p = 0: none)
+  const void* in = nullptr; int64_t in_ld = 0;          // GELU_BWD: pre-activation; SILU_MUL_BWD: gu
+  float* colsum = nullptr;                              // bias gradient of the stored values
+};
+
 // C = act(A W^T + bias) + residual   (ops.gemm)
 // sk_ws: optional stream-K workspace (sl_gemm_ex_args.sk_ws) for products of a few tiles under a long reduction
 int gemm(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* res, int64_t ldr,
-         int64_t M, int N, int K, int act, void* aux_out, hipStream_t st, void* sk_ws = nullptr) {
+         int64_t M, int N, int K, int act, void* aux_out, hipStream_t st, void* sk_ws = nullptr, const Post* post = nullptr) {
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.residual = res; a.ldr = ldr;
   a.M = (int)M; a.N = N; a.K = K; a.batch = 1; a.dtype = dt; a.act = act;
-  if (!aux_out && !sk_ws) return sl_gemm(&a, (sl_stream)st);
+  if (!aux_out && !sk_ws && !post) return sl_gemm(&a, (sl_stream)st);
   sl_gemm_ex_args ex;
   memset(&ex, 0, sizeof(ex));
   ex.aux_out = aux_out; ex.w_mod = 1;
   if (sk_ws) { ex.sk_ws = sk_ws; ex.sk_ws_bytes = sl_gemm_streamk_workspace_bytes(); }
+  if (post) {
+    ex.post_op = post->op; ex.drop_p = post->p; ex.drop_seed = post->seed; ex.drop_ld = post->ld;
+    ex.post_in = post->in; ex.post_ld = post->in_ld; ex.colsum_out = post->colsum;
+  }
   return sl_gemm_ex(&a, &ex, (sl_stream)st);
 }
+
+// the fused forms need the tiled kernels' row range and whole K slabs in every product of the layer (sl_gemm_post_ok) and SL_TAPE_FUSE != 0
+// (A/B switch; default on)
+inline bool fuse_ok(int64_t M, int dt, int H, int F) { return sl_env().tape_fuse != 0 && sl_gemm_post_ok(M, H, F, dt) && sl_gemm_post_ok(M, F, H, dt); }
 
 // scratch for the K-contiguous operand copies of the backward products
 struct BwdScratch {
@@ -56,7 +74,7 @@ struct BwdScratch {
 // dX (M, K_in) = dY (M, N_out) . W (N_out, K_in), through a transposed copy of W so that the product is K-contiguous
 // (ops.dgrad with wt = ops.transpose_pad(W)); wt_cached != NULL: the copy already exists (frozen weights)
 int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_in, const void* wt_cached, void* dX, int64_t ldx, int64_t M,
-          const BwdScratch& s, hipStream_t st, void* sk_ws = nullptr) {
+          const BwdScratch& s, hipStream_t st, void* sk_ws = nullptr, const Post* post = nullptr) {
   const int vec = dt == SL_F32 ? 4 : 8;
   const int64_t ldw = rup(n_out, vec);
   const void* wt = wt_cached;
@@ -64,7 +82,7 @@ int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_i
     SL_TRY(sl_transpose_pad(W, k_in, s.wt, ldw, n_out, k_in, n_out, dt, (sl_stream)st));
     wt = s.wt;
   }
-  return gemm(dt, dY, ldy, wt, wt_cached ? n_out : ldw, dX, ldx, nullptr, nullptr, 0, M, k_in, n_out, SL_ACT_NONE, nullptr, st, sk_ws);
+  return gemm(dt, dY, ldy, wt, wt_cached ? n_out : ldw, dX, ldx, nullptr, nullptr, 0, M, k_in, n_out, SL_ACT_NONE, nullptr, st, sk_ws, post);
 }
 
 // dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in)       (ops.wgrad_acc, plain Linear)
@@ -194,7 +212,7 @@ struct SideStream {
 // encoder stack (hf:models/hubert/modeling_hubert.py:504-547 stable-LN layer; hf:models/whisper/modeling_whisper.py:360-414)
 // ================================================================================================
 struct EncWs {
-  void *tmp_h, *d_mid, *d_pre1, *d_h1, *d_h2, *d_att, *d_qkv;
+  void *tmp_h, *tmp_h2, *d_mid, *d_pre1, *d_h1, *d_h2, *d_att, *d_qkv;      // tmp_h: dropout(dx) (FFN2's incoming gradient), tmp_h2: dropout(d_h2) (the out-projection's)
   float* delta;
   void* ln_ws;         // per-block dgamma / dbeta records of the LayerNorm backward (sl_layernorm_bwd_ws)
   size_t ln_ws_bytes;
@@ -210,6 +228,7 @@ static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs
   const int64_t big = F > 3 * H ? F : 3 * H;
   Carver cv(base, cap);
   w.tmp_h = cv.take(n * H * sz);
+  w.tmp_h2 = cv.take(n * H * sz);
   w.d_mid = cv.take(n * F * sz);
   w.d_pre1 = cv.take(n * F * sz);
   w.d_h1 = cv.take(n * H * sz);
@@ -255,16 +274,31 @@ extern "C" int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const s
     SL_TRY(sl_layernorm(x, sv.ln1, L.ln1_g, L.ln1_b, n, H, c->ln_eps, 0, dt, stream));
     SL_TRY(gemm(dt, sv.ln1, H, L.wqkv, H, sv.qkv, 3 * H, L.bqkv, nullptr, 0, n, 3 * H, H, SL_ACT_NONE, nullptr, st));
     SL_TRY(attn_fwd(dt, sv.qkv, 3 * H, sv.att, sv.lse, c->cu, c->klen, c->nseq, c->max_len, nh, nh, 64, 0, 0.125f, c->p_attn, sd[0], st));
-    if (c->p_hidden > 0.f) {               // h = residual + dropout(attention(layer_norm(h)))
+    const bool fuse = fuse_ok(n, dt, H, F);
+    Post pd;                                // h = residual + dropout(sublayer(h)): the mask in the producing GEMM's epilogue
+    pd.op = SL_POST_DROPOUT; pd.p = c->p_hidden; pd.ld = H;
+    if (c->p_hidden > 0.f && fuse) {       // h = residual + dropout(attention(layer_norm(h)))
+      pd.seed = sd[1];
+      SL_TRY(gemm(dt, sv.att, H, L.wo, H, sv.x_mid, H, L.bo, x, H, n, H, H, SL_ACT_NONE, nullptr, st, nullptr, &pd));
+    } else if (c->p_hidden > 0.f) {
       SL_TRY(gemm(dt, sv.att, H, L.wo, H, w.tmp_h, H, L.bo, nullptr, 0, n, H, H, SL_ACT_NONE, nullptr, st));
       SL_TRY(sl_dropout(w.tmp_h, x, sv.x_mid, n * H, c->p_hidden, sd[1], dt, stream));
     } else {
       SL_TRY(gemm(dt, sv.att, H, L.wo, H, sv.x_mid, H, L.bo, x, H, n, H, H, SL_ACT_NONE, nullptr, st));
     }
     SL_TRY(sl_layernorm(sv.x_mid, sv.ln2, L.ln2_g, L.ln2_b, n, H, c->ln_eps, 0, dt, stream));
-    SL_TRY(gemm(dt, sv.ln2, H, L.w1, H, sv.mid, F, L.b1, nullptr, 0, n, F, H, SL_ACT_GELU, sv.pre1, st));
-    if (c->p_act > 0.f) SL_TRY(sl_dropout(sv.mid, nullptr, sv.mid, n * F, c->p_act, sd[2], dt, stream));
-    if (c->p_hidden > 0.f) {               // h = h + output_dropout(output_dense(...))
+    if (c->p_act > 0.f && fuse) {          // mid = dropout(gelu(pre1)), pre1 kept
+      Post pa;
+      pa.op = SL_POST_DROPOUT; pa.p = c->p_act; pa.seed = sd[2]; pa.ld = F;
+      SL_TRY(gemm(dt, sv.ln2, H, L.w1, H, sv.mid, F, L.b1, nullptr, 0, n, F, H, SL_ACT_GELU, sv.pre1, st, nullptr, &pa));
+    } else {
+      SL_TRY(gemm(dt, sv.ln2, H, L.w1, H, sv.mid, F, L.b1, nullptr, 0, n, F, H, SL_ACT_GELU, sv.pre1, st));
+      if (c->p_act > 0.f) SL_TRY(sl_dropout(sv.mid, nullptr, sv.mid, n * F, c->p_act, sd[2], dt, stream));
+    }
+    if (c->p_hidden > 0.f && fuse) {       // h = h + output_dropout(output_dense(...))
+      pd.seed = sd[3];
+      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, sv.x_out, H, L.b2, sv.x_mid, H, n, H, F, SL_ACT_NONE, nullptr, st, w.sk, &pd));
+    } else if (c->p_hidden > 0.f) {
       SL_TRY(gemm(dt, sv.mid, F, L.w2, F, w.tmp_h, H, L.b2, nullptr, 0, n, H, F, SL_ACT_NONE, nullptr, st, w.sk));
       SL_TRY(sl_dropout(w.tmp_h, sv.x_mid, sv.x_out, n * H, c->p_hidden, sd[3], dt, stream));
     } else {
@@ -294,6 +328,10 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   if (sk) SL_HIP(hipMemsetAsync(sk, 0, 1024, st));
   void* sk_w = (ss.on || !w.sk) ? w.sk_w : sk;                 // the parameter-gradient group's own (side stream), or the shared one when all is on `st`
   if (sk_w && sk_w != sk) SL_HIP(hipMemsetAsync(sk_w, 0, 1024, st));      // ordered before the first fork of the side stream
+  // w.tmp_h already holds dropout(dx) under the CURRENT layer's output-dropout mask: the LayerNorm backward that produced dx (the layer
+  // above's) wrote it as its second output, so this layer starts without an sl_dropout launch and without re-reading dx
+  bool have_drop = false;
+  const bool fuse = fuse_ok(n, dt, H, F);
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     if (c->skip[l]) continue;
     const sl_hubert_layer& L = layers[l];
@@ -302,27 +340,42 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     const uint64_t* sd = c->seeds + 4 * (size_t)l;
     // ---- feed-forward half: x_out = x_mid + drop(w2 . drop_act(gelu(w1 . ln2(x_mid) + b1)) + b2)
     const void* d_o2 = dx;
-    SL_TRY(ss.join(2));                                   // tmp_h / d_h2 were the previous layer's d_o1 (read by its wo group)
-    if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(dx, nullptr, w.tmp_h, n * H, c->p_hidden, sd[3], dt, stream)); d_o2 = w.tmp_h; }
+    if (c->p_hidden > 0.f) {
+      if (!have_drop) SL_TRY(sl_dropout(dx, nullptr, w.tmp_h, n * H, c->p_hidden, sd[3], dt, stream));      // (the layer above joined group 0 before it let go of tmp_h)
+      d_o2 = w.tmp_h;
+    }
+    have_drop = false;
     SL_TRY(ss.begin(sw));
     SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw, sk_w));
     SL_TRY(sl_colsum(d_o2, H, g.b2, n, H, dt, (sl_stream)sw));
     SL_TRY(ss.end(0));
-    SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_mid, F, n, w.s, st));
-    if (c->p_act > 0.f) SL_TRY(sl_dropout(w.d_mid, nullptr, w.d_mid, n * F, c->p_act, sd[2], dt, stream));
     SL_TRY(ss.join(1));                                   // d_pre1 was read by the previous layer's w1 group
-    SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, w.d_pre1, n * F, dt, stream));
+    if (fuse) {
+      // d_pre1 = gelu'(pre1) * drop_act(d_o2 . w2) and b1 += colsum(d_pre1), all in the data-gradient product's epilogue
+      Post pg;
+      pg.op = SL_POST_GELU_BWD; pg.p = c->p_act; pg.seed = sd[2]; pg.ld = F; pg.in = sv.pre1; pg.in_ld = F; pg.colsum = g.b1;
+      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_pre1, F, n, w.s, st, nullptr, &pg));
+    } else {
+      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_mid, F, n, w.s, st));
+      if (c->p_act > 0.f) SL_TRY(sl_dropout(w.d_mid, nullptr, w.d_mid, n * F, c->p_act, sd[2], dt, stream));
+      SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, w.d_pre1, n * F, dt, stream));
+    }
     SL_TRY(ss.begin(sw));
     SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w));
-    SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, (sl_stream)sw));
+    if (!fuse) SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, (sl_stream)sw));
     SL_TRY(ss.end(1));
     SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
-    // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass
-    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream));
+    // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass — and dropout(d_h2), the out-projection's incoming gradient
+    SL_TRY(ss.join(2));                                   // d_h2 / tmp_h2 were the previous layer's d_o1 (read by its wo group)
+    const bool drop1 = c->p_hidden > 0.f && fuse;
+    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
+                                        drop1 ? w.tmp_h2 : nullptr, c->p_hidden, sd[1]));
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
     const void* d_o1 = w.d_h2;
-    SL_TRY(ss.join(0));                                   // d_o2 (tmp_h or dx) is overwritten below
-    if (c->p_hidden > 0.f) { SL_TRY(sl_dropout(w.d_h2, nullptr, w.tmp_h, n * H, c->p_hidden, sd[1], dt, stream)); d_o1 = w.tmp_h; }
+    if (c->p_hidden > 0.f) {
+      if (!drop1) SL_TRY(sl_dropout(w.d_h2, nullptr, w.tmp_h2, n * H, c->p_hidden, sd[1], dt, stream));
+      d_o1 = w.tmp_h2;
+    }
     SL_TRY(ss.begin(sw));
     SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw, sk_w));
     SL_TRY(sl_colsum(d_o1, H, g.bo, n, H, dt, (sl_stream)sw));
@@ -336,8 +389,14 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, (sl_stream)sw));
     SL_TRY(ss.end(3));
     SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));
-    // dx = d x: the LayerNorm path + the residual path (d_h2), one pass
-    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x, L.ln1_g, L.ln1_b, w.d_h1, w.d_h2, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream));
+    // dx = d x: the LayerNorm path + the residual path (d_h2), one pass — and dropout(dx) under the mask of the next layer down this call visits
+    SL_TRY(ss.join(0));                                   // this layer's w2 group read dx / tmp_h, both rewritten here
+    int below = -1;
+    for (int k = l - 1; k >= layer_begin && below < 0; --k)
+      if (!c->skip[k]) below = k;
+    have_drop = below >= 0 && c->p_hidden > 0.f && fuse;
+    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x, L.ln1_g, L.ln1_b, w.d_h1, w.d_h2, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
+                                        have_drop ? w.tmp_h : nullptr, c->p_hidden, have_drop ? c->seeds[4 * (size_t)below + 3] : 0));
     (void)sz;
   }
   for (int k = 0; k < 4; ++k) SL_TRY(ss.join(k));          // the caller's stream owns the gradients again
@@ -436,23 +495,31 @@ extern "C" int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, cons
   const int64_t n = c->n_tok;
   const float scale = 1.0f / sqrtf((float)D);
   SL_HIP(hipMemsetAsync(w.sk, 0, 1024, st));        // the stream-K flags (a run of an earlier call cut short must not poison this one)
+  const bool fuse = fuse_ok(n, dt, H, F);
   for (int l = c->n_layers - 1; l >= 0; --l) {
     const sl_llama_train_layer& L = layers[l];
     const sl_llama_layer_saved& sv = saved[l];
     SL_CHECK_ARG(L.wqkv_t && L.wo_t && L.wgu_t && L.wdown_t, "sl_llama_stack_train_bwd: layer %d lacks the transposed weights", l);
     // x3 = x2 + wdown . (silu(gate) * up),   [gate | up] = wgu . rmsnorm(x2)
-    SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_mid, F, n, w.s, st, w.sk));
-    SL_TRY(sl_silu_mul_bwd(sv.gu, w.d_mid, w.d_gu, n, F, dt, stream));
+    if (fuse) {      // d [gate | up] written by the down projection's data-gradient product itself (SL_POST_SILU_MUL_BWD)
+      Post ps;
+      ps.op = SL_POST_SILU_MUL_BWD; ps.in = sv.gu; ps.in_ld = 2 * F;
+      SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_gu, 2 * F, n, w.s, st, w.sk, &ps));
+    } else {
+      SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_mid, F, n, w.s, st, w.sk));
+      SL_TRY(sl_silu_mul_bwd(sv.gu, w.d_mid, w.d_gu, n, F, dt, stream));
+    }
     SL_TRY(dgrad(dt, w.d_gu, 2 * F, L.wgu, 2 * F, H, L.wgu_t, w.d_h, H, n, w.s, st, w.sk));
-    SL_TRY(sl_rmsnorm_bwd_add_impl(sv.x2, L.norm2, w.d_h, dx, w.dx2, n, H, c->rms_eps, dt, stream));      // + the residual path (dx), same pass
+    SL_TRY(sl_rmsnorm_bwd_add_impl(sv.x2, L.norm2, w.d_h, dx, w.dx2, n, H, c->rms_eps, dt, stream, nullptr));      // + the residual path (dx), same pass
     // x2 = x + wo . attn(rope(wqkv . rmsnorm(x)))
     SL_TRY(dgrad(dt, w.dx2, H, L.wo, H, att_w, L.wo_t, w.d_att, att_w, n, w.s, st, w.sk));
     SL_TRY(attn_bwd(dt, sv.qkv, qkv_w, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nkv, D, 1, scale, 0.f, 0,
                     st));
     SL_TRY(sl_rope_inplace(w.d_qkv, c->pos, c->rope_cos, c->rope_sin, n, nh + 2 * nkv, nh + nkv, D, 1, dt, stream));
     SL_TRY(dgrad(dt, w.d_qkv, qkv_w, L.wqkv, qkv_w, H, L.wqkv_t, w.d_h, H, n, w.s, st, w.sk));
-    SL_TRY(sl_rmsnorm_bwd_add_impl(hidden[l], L.norm1, w.d_h, w.dx2, dx, n, H, c->rms_eps, dt, stream));  // + the residual path (dx2), same pass
-    if (d_tap && d_tap[l]) SL_TRY(sl_axpby(d_tap[l], dx, 1.f, 1.f, n * H, dt, stream));     // feature-distillation gradient of hidden_states[l]
+    // + the residual path (dx2) and the feature-distillation gradient of hidden_states[l], same pass
+    SL_TRY(sl_rmsnorm_bwd_add_impl(hidden[l], L.norm1, w.d_h, w.dx2, dx, n, H, c->rms_eps, dt, stream, (d_tap && fuse) ? d_tap[l] : nullptr));
+    if (d_tap && d_tap[l] && !fuse) SL_TRY(sl_axpby(d_tap[l], dx, 1.f, 1.f, n * H, dt, stream));
   }
   return 0;
 }

@@ -359,9 +359,11 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
             residual_f32: bool = False, aux_out=None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0,
             strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, r_off: int = 0,
             dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1, groups_ext: bool = False,
-            ln_mr=None, ln_u=None, ln_c=None, stats_out=None, sk_ws: Optional[torch.Tensor] = None):
+            ln_mr=None, ln_u=None, ln_c=None, stats_out=None, sk_ws: Optional[torch.Tensor] = None,
+            post_op: int = 0, drop_p: float = 0.0, drop_seed: int = 0, drop_ld: int = 0, post_in=None, post_ld: int = 0, colsum_out=None):
     """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors.  ln_mr/ln_u/ln_c: the
-    LayerNorm-folded consumer epilogue; stats_out: per-64-column {sum, sum of squares} of the stored rows (speechllm.h)."""
+    LayerNorm-folded consumer epilogue; stats_out: per-64-column {sum, sum of squares} of the stored rows (speechllm.h).
+    post_op / drop_* / post_in / colsum_out: the training tape's epilogue fusions (sl_gemm_ex_args, ABI 7)."""
     dt = dtype or A.dtype
     esz = 4 if dt == torch.float32 else 2
     a = L.GemmArgs()
@@ -379,6 +381,8 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
     e.ln_mr, e.ln_u, e.ln_c, e.stats_out = L.ptr(ln_mr), L.ptr(ln_u), L.ptr(ln_c), L.ptr(stats_out)
     if sk_ws is not None:       # stream-K workspace (streamk_workspace): zeroed once, one per stream
         e.sk_ws, e.sk_ws_bytes = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size()
+    e.post_op, e.drop_p, e.drop_seed, e.drop_ld = int(post_op), float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, int(drop_ld)
+    e.post_in, e.post_ld, e.colsum_out = L.ptr(post_in), int(post_ld), L.ptr(colsum_out)
     L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(e), L.stream_ptr()), "sl_gemm_ex")
     return out
 

@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_declared_in_header():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/speechllm.h but not exported"
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
-    assert L.lib().sl_version() == 6
+    assert L.lib().sl_version() == 7
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -473,3 +473,83 @@ def test_weight_norm_backward_of_the_positional_conv_vs_autograd():
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert float((outs[0][0].double() - g.grad).norm() / g.grad.norm()) < 2e-6
         assert float((outs[0][1].double() - v.grad).norm() / v.grad.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K,sk", [(3200, 1024, 1024, False), (998, 1024, 4096, True), (400, 1024, 4096, False), (5072, 4096, 1024, False), (300, 192, 256, False)])
+def test_gemm_epilogue_dropout_equals_the_unfused_launches(dt, M, N, K, sk):
+    """sl_gemm_ex_args.post_op = SL_POST_DROPOUT (ABI 7): C = residual + dropout(act(A W^T + bias)) in the GEMM epilogue is bit for bit
+    sl_gemm -> sl_dropout(residual) — the HuBERT layer's `h = h + dropout(sublayer)` (hf:models/hubert/modeling_hubert.py:529-540 under
+    ref:trainer.py:258 train()) on the 128-tile, 256-tile and split-K (reduce pass) forms; and with GELU + the saved pre-activation
+    (FFN1: mid = dropout(gelu(pre)), pre kept for the backward)."""
+    A, W, b, R = (rnd(M, K, seed=1).to(DEV, dt), (rnd(N, K, seed=2) * K ** -0.5).to(DEV, dt), rnd(N, seed=3).to(DEV, dt), rnd(M, N, seed=4).to(DEV, dt))
+    p_, seed = 0.1, 0x1234567890ABCDEF
+    ws = ops.streamk_workspace(DEV) if sk else None
+    ref = ops.dropout(ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), bias=b, sk_ws=ws), p_, seed, residual=R)
+    out = ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), bias=b, residual=R, ldr=N, sk_ws=ws,
+                      post_op=L.POST_DROPOUT, drop_p=p_, drop_seed=seed, drop_ld=N)
+    assert torch.equal(out, ref)
+    keep = ops.dropout_keep_mask(M * N, p_, seed).view(M, N)
+    assert abs(float((out - R == 0).float().mean()) - p_) < 0.02 and bool(((out.cpu() - R.cpu() == 0) | keep).all())
+    if not sk:
+        pre_ref = torch.empty((M, N), device=DEV, dtype=dt)
+        mid_ref = ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), bias=b, act=L.ACT_GELU, aux_out=pre_ref)
+        mid_ref = ops.dropout(mid_ref, p_, seed + 1)
+        pre = torch.empty((M, N), device=DEV, dtype=dt)
+        mid = ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), bias=b, act=L.ACT_GELU, aux_out=pre,
+                          post_op=L.POST_DROPOUT, drop_p=p_, drop_seed=seed + 1, drop_ld=N)
+        assert torch.equal(mid, mid_ref) and torch.equal(pre, pre_ref)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K,p_", [(3200, 4096, 1024, 0.1), (998, 4096, 1024, 0.0), (400, 1024, 1024, 0.1), (5072, 4096, 1024, 0.1), (200, 192, 256, 0.1)])
+def test_gemm_epilogue_gelu_backward_and_bias_gradient_equal_the_unfused_launches(dt, M, N, K, p_):
+    """post_op = SL_POST_GELU_BWD + colsum_out: d pre = gelu'(pre) * dropout(dY W) and db += colsum(d pre) behind the data-gradient
+    product are sl_gemm -> sl_dropout (in place) -> sl_gelu_bwd -> sl_colsum: the values bit for bit, the column sums to fp32 atomics'
+    ordering (hf:models/hubert/modeling_hubert.py:467-474 HubertFeedForward backward under ref:trainer.py:373)."""
+    dY, Wt, pre = (rnd(M, K, seed=5).to(DEV, dt), (rnd(N, K, seed=6) * K ** -0.5).to(DEV, dt), rnd(M, N, seed=7).to(DEV, dt))
+    seed = 0xFEDCBA0987654321
+    d_mid = ops.gemm_ex(dY, Wt, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt))
+    if p_ > 0:
+        ops.dropout(d_mid, p_, seed, out=d_mid)
+    ref = ops.gelu_bwd(d_mid, pre)
+    db_ref = ops.colsum_acc(ref, torch.full((N,), 0.5, device=DEV, dtype=torch.float32))
+    db = torch.full((N,), 0.5, device=DEV, dtype=torch.float32)
+    out = ops.gemm_ex(dY, Wt, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), post_op=L.POST_GELU_BWD, drop_p=p_,
+                      drop_seed=seed, drop_ld=N, post_in=pre, post_ld=N, colsum_out=db)
+    assert torch.equal(out, ref)
+    assert rel_err(db.cpu(), db_ref.cpu()) < 3e-4
+    assert rel_err(db.cpu() - 0.5, out.float().sum(0).cpu()) < (3e-4 if dt == torch.float32 else 2e-3)
+    # colsum_out without a post-op: the bias gradient of a plain product's stored values
+    db2 = torch.zeros((N,), device=DEV, dtype=torch.float32)
+    plain = ops.gemm_ex(dY, Wt, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), colsum_out=db2)
+    assert torch.equal(plain, ops.gemm_ex(dY, Wt, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt)))
+    assert rel_err(db2.cpu(), plain.float().sum(0).cpu()) < (3e-4 if dt == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,F_,K,sk", [(634, 8192, 3072, False), (634, 1024, 8192, True), (3200, 2048, 1024, False), (130, 64, 256, False)])
+def test_gemm_epilogue_swiglu_backward_equals_the_unfused_launches(dt, M, F_, K, sk):
+    """post_op = SL_POST_SILU_MUL_BWD: d [gate | up] (M, 2 F, interleaved in 16-column blocks) = silu_mul_bwd(gu, dX Wdown^T-stored) written by
+    the down projection's data-gradient product itself (hf:models/llama/modeling_llama.py:187-189 LlamaMLP backward, frozen weights:
+    ref:trainer.py:63-64) — bit for bit sl_gemm -> sl_silu_mul_bwd, on the tile epilogues and the split-K reduce pass."""
+    dX, Wt, gu = (rnd(M, K, seed=8).to(DEV, dt), (rnd(F_, K, seed=9) * K ** -0.5).to(DEV, dt), rnd(M, 2 * F_, seed=10).to(DEV, dt))
+    ws = ops.streamk_workspace(DEV) if sk else None
+    d_mid = ops.gemm_ex(dX, Wt, M=M, N=F_, K=K, lda=K, ldw=K, out=torch.empty((M, F_), device=DEV, dtype=dt), sk_ws=ws)
+    ref = ops.silu_mul_bwd(gu, d_mid)
+    out = ops.gemm_ex(dX, Wt, M=M, N=F_, K=K, lda=K, ldw=K, out=torch.full((M, 2 * F_), 7.0, device=DEV, dtype=dt), ldc=2 * F_, sk_ws=ws,
+                      post_op=L.POST_SILU_MUL_BWD, post_in=gu, post_ld=2 * F_)
+    assert torch.equal(out, ref)
+
+
+def test_gemm_epilogue_fusions_refuse_the_forms_they_do_not_cover():
+    A, W = rnd(128, 64).to(DEV, torch.bfloat16), rnd(128, 64).to(DEV, torch.bfloat16)
+    out = torch.empty((128, 128), device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(L.SpeechLLMError):      # a mask needs its index stride
+        ops.gemm_ex(A, W, M=128, N=128, K=64, lda=64, ldw=64, out=out, post_op=L.POST_DROPOUT, drop_p=0.1, drop_seed=1, drop_ld=0)
+    with pytest.raises(L.SpeechLLMError):      # transposed operands keep the plain epilogue
+        ops.gemm_ex(A, W, M=128, N=128, K=64, lda=64, ldw=64, out=out, trans_w=True, post_op=L.POST_DROPOUT, drop_p=0.1, drop_seed=1, drop_ld=128)
+    with pytest.raises(L.SpeechLLMError):      # GELU backward without the saved pre-activation
+        ops.gemm_ex(A, W, M=128, N=128, K=64, lda=64, ldw=64, out=out, post_op=L.POST_GELU_BWD)
+    with pytest.raises(L.SpeechLLMError):
+        ops.gemm_ex(A, W, M=128, N=128, K=64, lda=64, ldw=64, out=out, post_op=9)

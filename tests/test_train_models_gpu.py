@@ -568,3 +568,57 @@ def test_parameter_gradient_side_stream_equals_single_stream(monkeypatch):
             for f in forked:
                 assert float((f[o:o + n] - a).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, name
     assert fixed >= 4 * HC.num_hidden_layers
+
+
+@pytest.mark.parametrize("B", [16, 2])      # a 16-sample window (>= 2 048 frames: parameter gradients on the side stream) and the per-rank share of an 8-rank step
+def test_fused_tape_epilogues_give_the_bits_of_the_unfused_launch_sequence(monkeypatch, B):
+    """Round 6: the KD tapes run dropout (forward and backward), GELU', SwiGLU', the b1 bias gradient and the feature-distillation adds inside
+    the GEMM epilogues / norm-backward kernels (sl_gemm_ex_args.post_op, train_tape.hip) instead of as launches of their own.  Every fused
+    form reproduces the roundings of the sequence it replaces, so with the training-mode regularisers ON (dropouts, LayerDrop,
+    SpecAugment — ref:trainer.py:258) the losses and every weight gradient equal those of SL_TAPE_FUSE=0 bit for bit; bias gradients
+    (float atomics either way) to their usual last-bit movement."""
+    from oracle.golden_cfgs import WIDE_HUBERT, WIDE_LLAMA
+    L_ = pkg("_lib")
+    HC, LC = WIDE_HUBERT, WIDE_LLAMA
+    enc, _ = make_encoder(HC, LC.hidden_size, 93, torch.bfloat16)
+    llm, _ = make_llama(LC, 94, torch.bfloat16, max_ctx=512)
+    prefix, suffix = ri.synthetic_ids(9, LC.vocab_size, seed=7, bos=128000), ri.synthetic_ids(6, LC.vocab_size, seed=8, bos=128000)
+    gen = torch.Generator().manual_seed(272)
+    waves = [ri.synthetic_waveform(90000 + 4000 * u, seed=810 + u).to(DEV) for u in range(B)]
+    texts = [torch.randint(1, LC.vocab_size, (30 + u % 7,), generator=gen) for u in range(B)]
+    resps = [torch.randint(1, LC.vocab_size, (40 + (3 * u) % 13,), generator=gen) for u in range(B)]
+
+    def window():
+        import numpy as np
+        np.random.seed(13)                 # SpecAugment spans come from numpy's global generator (hf's _compute_mask_indices)
+        torch.manual_seed(13)
+        reg = training.TrainRegularizers(feat_proj_dropout=0.1, hidden_dropout=0.1, activation_dropout=0.1, attention_dropout=0.1, layerdrop=0.25,
+                                         apply_spec_augment=True, seed=77)        # a fresh counter state: the same masks in every run
+        tr = training.KDTrainer(kd_config(taps=(0, 1, 2), accum=B), enc, llm, prefix, suffix, regularizers=reg)
+        tr.optimizer_step = lambda: None
+        tr.enc_tape.arena.zero_()
+        losses = tr.micro_batch(waves, texts, resps)
+        torch.cuda.synchronize()
+        return tr, tr.enc_tape.arena.flat.clone(), losses
+
+    tr, fused, l_f = window()
+    monkeypatch.setenv("SL_TAPE_FUSE", "0")
+    L_.lib().sl_tuning_reload()
+    try:
+        _, plain, l_p = window()
+    finally:
+        monkeypatch.undo()
+        L_.lib().sl_tuning_reload()
+    assert float(plain.abs().max()) > 0 and len(l_f) == len(l_p)
+    for a_, b_ in zip(l_f, l_p):           # (the loss sums are float atomics: their last bits move from run to run)
+        for k in a_:
+            assert abs(a_[k] - b_[k]) <= 2e-5 * abs(b_[k]) + 1e-7, (k, a_[k], b_[k])
+    same = 0
+    for name, (o, n, _shape) in tr.enc_tape.arena.span.items():
+        a, b = fused[o:o + n], plain[o:o + n]
+        if any(name.endswith(w) for w in (".wqkv", ".wo", ".w1", ".w2", ".ln1_g", ".ln1_b", ".ln2_g", ".ln2_b")):
+            assert torch.equal(a, b), name
+            same += 1
+        else:
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, name
+    assert same >= 6 * HC.num_hidden_layers * 0.5      # LayerDrop leaves some layers out
