@@ -50,6 +50,7 @@ static const SlEnv* env_load() {
   // up to 26 rows (2.34 vs 2.36 ms), the 32-row streaming blocks from 27 (2.42 vs 2.38) to 32 (2.57 vs 2.40)
   e.compact_pin = env_int("SL_COMPACT_PIN", 1);
   e.tape_fuse = env_int("SL_TAPE_FUSE", 1);
+  e.attn_bwd_kf = env_int("SL_ATTN_BWD_KF", 0);
   e.stream_min_m = env_int("SL_STREAM_MIN_M", 26);
   if (e.stream_min_m < 16) e.stream_min_m = 26;
   e.disable_t256 = getenv("SL_DISABLE_T256") != nullptr;

@@ -33,7 +33,7 @@ static void fill_hubert(sl_hubert_model* m, sl_hubert_layer* layers, int n_layer
 }
 
 int main() {
-  EXPECT(sl_version() == SL_ABI_VERSION && SL_ABI_VERSION == 6, "ABI version");
+  EXPECT(sl_version() == SL_ABI_VERSION && SL_ABI_VERSION == 7, "ABI version");
   EXPECT(sl_last_error() != nullptr, "error string never NULL");
 
   // ---- tuning switches: parser under the sanitizers, garbage included
@@ -210,6 +210,25 @@ int main() {
     gx.w_mod = 1; gx.amax_val = (float*)ws;                         // amax_idx missing
     EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
     gx.amax_idx = (int32_t*)ws;                                     // M <= 64: the fused top-1 lives in the tiled kernels
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    // training-tape epilogue fusions (ABI 7): every refused combination comes back as an argument error, before any launch
+    memset(&gx, 0, sizeof(gx));
+    gx.w_mod = 1; ga.M = 256; ga.out_f32 = 0; ga.C = ws; ga.ldc = 128;
+    gx.post_op = 9;                                                 // unknown post-op
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.post_op = SL_POST_DROPOUT; gx.drop_p = 0.1f; gx.drop_ld = 0; // a mask needs its index stride
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.drop_ld = 128; gx.drop_p = 1.5f;                             // p outside [0, 1)
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.drop_p = 0.1f; gx.trans_w = 1;                               // transposed operands keep the plain epilogue
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.trans_w = 0; gx.post_op = SL_POST_GELU_BWD; gx.post_in = nullptr;   // GELU' without the saved pre-activation
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.post_op = SL_POST_SILU_MUL_BWD; gx.post_in = ws; gx.post_ld = 256; gx.drop_p = 0.f;     // ldc must span the 2 N-wide output
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.post_op = SL_POST_NONE; gx.colsum_out = (float*)ws; ga.M = 32;      // M <= 64: post-ops / colsum_out live in the tiled kernels
+    EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
+    gx.trans_a = gx.trans_w = 1; ga.M = 192; ga.N = 128; ga.K = 512;        // the bias-gradient rider needs the token-major kernel's shapes (M % 128)
     EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
   }
   EXPECT(sl_decode_graph_cache_clear() == 0, "nothing cached on this thread");

@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(AttnBwdP p) {
   if (pair < n_pairs && sub == 0) p.delta[pair] = acc;
 }
 
-template <typename T, int D, bool CAUSAL, int TQ>
+// KF = 16-key fragments per wave (round 6: 2, a block owns 128 keys): every Q / dO fragment read from LDS — row-major for S and dP, transposed for
+// dV and dK — now feeds KF products instead of one.  With one fragment per wave the kernel was LDS-bound (per tile and wave 16 ds_read_b128 +
+// 32 ds_read_b64_tr for 32 MFMAs: ~256 LDS cycles per wave, four waves on one LDS port, against 512 matrix-core cycles per SIMD).
+template <typename T, int D, bool CAUSAL, int TQ, int KF>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int SZ = (int)sizeof(T);
@@ -164,24 +167,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   const int rep = p.n_heads / p.n_kv;
   const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
   const int klen = p.klen[seq];
-  const int key0 = blockIdx.x * 64;
+  constexpr int BKEYS = 64 * KF;        // keys per block
+  const int key0 = blockIdx.x * BKEYS;
   if (key0 >= klen) return;
   const int shift = klen - qlen;        // causal: key j visible to query i iff j <= i + shift
   const int64_t krow0 = p.cu_k[seq];
 
-  // this wave's 16 keys: K and V fragments (B operands of S = Q K^T and dP = dO V^T)
-  const int kj = key0 + wave * 16 + r;
-  uint4 kf[KS_D], vf[KS_D];
-  {
-    const int kc = kj < klen ? kj : klen - 1;
+  // this wave's KF x 16 keys: K and V fragments (B operands of S = Q K^T and dP = dO V^T)
+  int kj[KF];
+  uint4 kf[KF][KS_D], vf[KF][KS_D];
+#pragma unroll
+  for (int f = 0; f < KF; ++f) {
+    kj[f] = key0 + (wave * KF + f) * 16 + r;
+    const int kc = kj[f] < klen ? kj[f] : klen - 1;
     const T* kp = (const T*)p.k + (krow0 + kc) * p.k_rs + (int64_t)kvh * p.k_hs + qd * VEC;
     const T* vp = (const T*)p.v + (krow0 + kc) * p.v_rs + (int64_t)kvh * p.v_hs + qd * VEC;
 #pragma unroll
-    for (int s = 0; s < KS_D; ++s) { kf[s] = *(const uint4*)(kp + s * KSTEP); vf[s] = *(const uint4*)(vp + s * KSTEP); }
+    for (int s = 0; s < KS_D; ++s) { kf[f][s] = *(const uint4*)(kp + s * KSTEP); vf[f][s] = *(const uint4*)(vp + s * KSTEP); }
   }
-  f32x4 dk[NF], dv[NF];
+  f32x4 dk[KF][NF], dv[KF][NF];
 #pragma unroll
-  for (int n = 0; n < NF; ++n) { dk[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int f = 0; f < KF; ++f)
+#pragma unroll
+    for (int n = 0; n < NF; ++n) { dk[f][n] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[f][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   int qt_first = 0;
   if (CAUSAL) { const int i0 = key0 - shift; qt_first = i0 > 0 ? i0 / TQ : 0; }   // first query that sees a key of this block
@@ -240,17 +248,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
       __syncthreads();
 
       // S = Q K^T and dP = dO V^T for TQ queries x this wave's 16 keys: lane (key r, a = qd) holds queries n*16 + 4a + i
-      f32x4 s[NQF], dp[NQF];
+      f32x4 s[KF][NQF], dp[KF][NQF];
 #pragma unroll
       for (int n = 0; n < NQF; ++n) {
-        s[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < KF; ++f) { s[f][n] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[f][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < KS_D; ++ks) {
           const uint4 aq = *(const uint4*)(Qs + swz<CPR>(n * 16 + r, ks * 4 + qd));
           const uint4 ad = *(const uint4*)(dOs + swz<CPR>(n * 16 + r, ks * 4 + qd));
-          MMA<T>::step(s[n], aq, kf[ks]);
-          MMA<T>::step(dp[n], ad, vf[ks]);
+#pragma unroll
+          for (int f = 0; f < KF; ++f) {
+            MMA<T>::step(s[f][n], aq, kf[f][ks]);
+            MMA<T>::step(dp[f][n], ad, vf[f][ks]);
+          }
         }
       }
       // probabilities (recomputed from the forward's lse), dropout mask, dS.  The mask's index is ((query row * heads + head) << 16) | key: over a
@@ -266,26 +277,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int qi = qt0 + n * 16 + 4 * qd + i;
-          bool ok = kj < klen && qi < qlen;
-          if (CAUSAL) ok = ok && (kj <= qi + shift);
-          float pv = ok ? exp_scaled<T>(s[n][i] * p.scale - ls[i]) : 0.f;
-          float dpv = dp[n][i];
-          float pd = pv;
-          if (p.drop_thr) {
-            const int64_t a_q = ((int64_t)q0 + qi) * p.n_heads + head;            // (rows past qlen: masked by `ok`, any mask bit will do)
-            const uint32_t lo = ((uint32_t)a_q << 16) | (uint32_t)kj;
-            const bool keep = dropout_keep_lo(lo, (uint32_t)(a_q >> 16) == hi_base ? inner0 : inner1, p.drop_thr);
-            pd = keep ? pv * p.drop_scale : 0.f;
-            dpv = keep ? dpv * p.drop_scale : 0.f;
+          const int64_t a_q = ((int64_t)q0 + qi) * p.n_heads + head;            // (rows past qlen: masked by `ok`, any mask bit will do)
+          const uint32_t inner = (uint32_t)(a_q >> 16) == hi_base ? inner0 : inner1;
+#pragma unroll
+          for (int f = 0; f < KF; ++f) {
+            bool ok = kj[f] < klen && qi < qlen;
+            if (CAUSAL) ok = ok && (kj[f] <= qi + shift);
+            float pv = ok ? exp_scaled<T>(s[f][n][i] * p.scale - ls[i]) : 0.f;
+            float dpv = dp[f][n][i];
+            float pd = pv;
+            if (p.drop_thr) {
+              const uint32_t lo = ((uint32_t)a_q << 16) | (uint32_t)kj[f];
+              const bool keep = dropout_keep_lo(lo, inner, p.drop_thr);
+              pd = keep ? pv * p.drop_scale : 0.f;
+              dpv = keep ? dpv * p.drop_scale : 0.f;
+            }
+            s[f][n][i] = pd;                                    // Pd  -> dV += Pd^T dO
+            dp[f][n][i] = pv * (dpv - dl[i]) * p.scale;         // dS (scale folded) -> dK += dS^T Q
           }
-          s[n][i] = pd;                                    // Pd  -> dV += Pd^T dO
-          dp[n][i] = pv * (dpv - dl[i]) * p.scale;         // dS (scale folded) -> dK += dS^T Q
         }
       }
 #pragma unroll
       for (int ks = 0; ks < KS_Q; ++ks) {
-        const uint4 apd = pack_step<T, NQF>(s, ks);
-        const uint4 ads = pack_step<T, NQF>(dp, ks);
+        uint4 apd[KF], ads[KF];
+#pragma unroll
+        for (int f = 0; f < KF; ++f) { apd[f] = pack_step<T, NQF>(s[f], ks); ads[f] = pack_step<T, NQF>(dp[f], ks); }
         if constexpr (TR) {
           const uint32_t img_d = (uint32_t)(uintptr_t)(lds_ptr_b_t)dOs, img_q = (uint32_t)(uintptr_t)(lds_ptr_b_t)Qs;
 #pragma unroll
@@ -298,18 +314,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
             }
             tr_wait<8>(lo, hi);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              MMA<T>::step(dv[n0 + g], apd, make_uint4(lo[g].x, lo[g].y, hi[g].x, hi[g].y));
-              MMA<T>::step(dk[n0 + g], ads, make_uint4(lo[4 + g].x, lo[4 + g].y, hi[4 + g].x, hi[4 + g].y));
-            }
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int f = 0; f < KF; ++f) {
+                MMA<T>::step(dv[f][n0 + g], apd[f], make_uint4(lo[g].x, lo[g].y, hi[g].x, hi[g].y));
+                MMA<T>::step(dk[f][n0 + g], ads[f], make_uint4(lo[4 + g].x, lo[4 + g].y, hi[4 + g].x, hi[4 + g].y));
+              }
           }
         } else {
 #pragma unroll
           for (int n = 0; n < NF; ++n) {
             const uint4 bd = *(const uint4*)(dOT + swz<CPT>(n * 16 + r, ks * 4 + qd));
             const uint4 bq = *(const uint4*)(QT + swz<CPT>(n * 16 + r, ks * 4 + qd));
-            MMA<T>::step(dv[n], apd, bd);
-            MMA<T>::step(dk[n], ads, bq);
+#pragma unroll
+            for (int f = 0; f < KF; ++f) {
+              MMA<T>::step(dv[f][n], apd[f], bd);
+              MMA<T>::step(dk[f][n], ads[f], bq);
+            }
           }
         }
       }
@@ -319,20 +340,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   T* dkb = (T*)p.dk + (int64_t)kvh * p.dk_hs;
   T* dvb = (T*)p.dv + (int64_t)kvh * p.dv_hs;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int kk = key0 + wave * 16 + 4 * qd + i;
-    if (kk >= klen) continue;
-    T* dkr = dkb + (krow0 + kk) * p.dk_rs;
-    T* dvr = dvb + (krow0 + kk) * p.dv_rs;
+  for (int f = 0; f < KF; ++f)
 #pragma unroll
-    for (int n = 0; n < NF; ++n) {
-      dkr[n * 16 + r] = from_f32<T>(dk[n][i]);
-      dvr[n * 16 + r] = from_f32<T>(dv[n][i]);
+    for (int i = 0; i < 4; ++i) {
+      const int kk = key0 + (wave * KF + f) * 16 + 4 * qd + i;
+      if (kk >= klen) continue;
+      T* dkr = dkb + (krow0 + kk) * p.dk_rs;
+      T* dvr = dvb + (krow0 + kk) * p.dv_rs;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        dkr[n * 16 + r] = from_f32<T>(dk[f][n][i]);
+        dvr[n * 16 + r] = from_f32<T>(dv[f][n][i]);
+      }
     }
-  }
 }
 
-template <typename T, int D, bool CAUSAL, int TK>
+// QF = 16-query fragments per wave (round 6: 2, a block owns 128 queries): every K / V fragment read from LDS feeds QF products
+template <typename T, int D, bool CAUSAL, int TK, int QF>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int SZ = (int)sizeof(T);
@@ -356,7 +380,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
   const int kvh = head / (p.n_heads / p.n_kv);
   const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
   const int klen = p.klen[seq];
-  const int qt0 = blockIdx.x * 64;
+  constexpr int BQ = 64 * QF;           // queries per block
+  const int qt0 = blockIdx.x * BQ;
   if (qt0 >= qlen) return;
   const int shift = klen - qlen;
   const int64_t krow0 = p.cu_k[seq];
@@ -364,24 +389,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
   const T* vb = (const T*)p.v + krow0 * p.v_rs + (int64_t)kvh * p.v_hs;
 
   // this wave's 16 queries: q and dO fragments (B operands of S^T = K Q^T and dP^T = V dO^T), lse and delta of query r
-  const int qi = qt0 + wave * 16 + r;
-  const int qc = qi < qlen ? qi : qlen - 1;
-  uint4 qf[KS_D], dof[KS_D];
-  {
+  int qi[QF];
+  uint4 qf[QF][KS_D], dof[QF][KS_D];
+  float lse_q[QF], dl_q[QF];
+  int64_t a_q[QF];
+  uint32_t drop_in[QF];
+  f32x4 dq[QF][NF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    qi[f] = qt0 + (wave * QF + f) * 16 + r;
+    const int qc = qi[f] < qlen ? qi[f] : qlen - 1;
     const T* qp = (const T*)p.q + (int64_t)(q0 + qc) * p.q_rs + (int64_t)head * p.q_hs + qd * VEC;
     const T* dp_ = (const T*)p.dout + (int64_t)(q0 + qc) * p.do_rs + (int64_t)head * p.do_hs + qd * VEC;
 #pragma unroll
-    for (int s = 0; s < KS_D; ++s) { qf[s] = *(const uint4*)(qp + s * KSTEP); dof[s] = *(const uint4*)(dp_ + s * KSTEP); }
-  }
-  const int64_t lidx = ((int64_t)q0 + qc) * p.n_heads + head;
-  const float lse_q = p.lse[lidx], dl_q = p.delta[lidx];
-  f32x4 dq[NF];
+    for (int s = 0; s < KS_D; ++s) { qf[f][s] = *(const uint4*)(qp + s * KSTEP); dof[f][s] = *(const uint4*)(dp_ + s * KSTEP); }
+    const int64_t lidx = ((int64_t)q0 + qc) * p.n_heads + head;
+    lse_q[f] = p.lse[lidx]; dl_q[f] = p.delta[lidx];
+    // dropout mask index = ((query row * heads + head) << 16) | key: its upper half is a constant of this lane's query
+    a_q[f] = lidx;
+    drop_in[f] = p.drop_thr ? drop_inner((uint32_t)(a_q[f] >> 16), p.drop_seed) : 0u;
 #pragma unroll
-  for (int n = 0; n < NF; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NF; ++n) dq[f][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   int n_kt = (klen + TK - 1) / TK;
   if (CAUSAL) {
-    const int last = qt0 + 63 + shift;   // largest key index any query of this block sees
+    const int last = qt0 + BQ - 1 + shift;   // largest key index any query of this block sees
     const int lim = last < 0 ? 0 : last / TK + 1;
     n_kt = lim < n_kt ? lim : n_kt;
   }
@@ -400,9 +433,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
       uv0[i] = *(const uint4*)(vb + (int64_t)k0r * p.v_rs + ch * VEC); uv1[i] = *(const uint4*)(vb + (int64_t)k1r * p.v_rs + ch * VEC);
     }
   };
-  // dropout mask index = ((query row * heads + head) << 16) | key: its upper half is a constant of this lane's query
-  const int64_t a_q = ((int64_t)q0 + qc) * p.n_heads + head;
-  const uint32_t drop_in = p.drop_thr ? drop_inner((uint32_t)(a_q >> 16), p.drop_seed) : 0u;
   if (n_kt > 0) gload(0);
   for (int kt = 0; kt < n_kt; ++kt) {
     const int key0 = kt * TK;
@@ -426,38 +456,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
     __syncthreads();
 
     // S^T = K Q^T, dP^T = V dO^T: lane (query r, a = qd) holds keys n*16 + 4a + i
-    f32x4 s[NKF], dp[NKF];
+    f32x4 s[QF][NKF], dp[QF][NKF];
 #pragma unroll
     for (int n = 0; n < NKF; ++n) {
-      s[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < QF; ++f) { s[f][n] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[f][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < KS_D; ++ks) {
         const uint4 ak = *(const uint4*)(Ks + swz<CPR>(n * 16 + r, ks * 4 + qd));
         const uint4 av = *(const uint4*)(Vs + swz<CPR>(n * 16 + r, ks * 4 + qd));
-        MMA<T>::step(s[n], ak, qf[ks]);
-        MMA<T>::step(dp[n], av, dof[ks]);
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+          MMA<T>::step(s[f][n], ak, qf[f][ks]);
+          MMA<T>::step(dp[f][n], av, dof[f][ks]);
+        }
       }
     }
 #pragma unroll
-    for (int n = 0; n < NKF; ++n)
+    for (int f = 0; f < QF; ++f)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kj = key0 + n * 16 + 4 * qd + i;
-        bool ok = kj < klen && qi < qlen;
-        if (CAUSAL) ok = ok && (kj <= qi + shift);
-        const float pv = ok ? exp_scaled<T>(s[n][i] * p.scale - lse_q) : 0.f;
-        float dpv = dp[n][i];
-        if (p.drop_thr) {
-          const bool keep = dropout_keep_lo(((uint32_t)a_q << 16) | (uint32_t)kj, drop_in, p.drop_thr);
-          dpv = keep ? dpv * p.drop_scale : 0.f;
+      for (int n = 0; n < NKF; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kj = key0 + n * 16 + 4 * qd + i;
+          bool ok = kj < klen && qi[f] < qlen;
+          if (CAUSAL) ok = ok && (kj <= qi[f] + shift);
+          const float pv = ok ? exp_scaled<T>(s[f][n][i] * p.scale - lse_q[f]) : 0.f;
+          float dpv = dp[f][n][i];
+          if (p.drop_thr) {
+            const bool keep = dropout_keep_lo(((uint32_t)a_q[f] << 16) | (uint32_t)kj, drop_in[f], p.drop_thr);
+            dpv = keep ? dpv * p.drop_scale : 0.f;
+          }
+          dp[f][n][i] = pv * (dpv - dl_q[f]) * p.scale;
         }
-        dp[n][i] = pv * (dpv - dl_q) * p.scale;
-      }
     // dQ^T += K^T dS^T
 #pragma unroll
     for (int ks = 0; ks < KS_K; ++ks) {
-      const uint4 bds = pack_step<T, NKF>(dp, ks);
+      uint4 bds[QF];
+#pragma unroll
+      for (int f = 0; f < QF; ++f) bds[f] = pack_step<T, NKF>(dp[f], ks);
       if constexpr (TR) {
         const uint32_t img_k = (uint32_t)(uintptr_t)(lds_ptr_b_t)Ks;
 #pragma unroll
@@ -467,26 +504,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
           for (int g = 0; g < 4; ++g) tr_issue<CPR>(img_k, 32 * ks, n0 + g, lane, lo[g], hi[g]);
           tr_wait<4>(lo, hi);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) MMA<T>::step(dq[n0 + g], make_uint4(lo[g].x, lo[g].y, hi[g].x, hi[g].y), bds);
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) MMA<T>::step(dq[f][n0 + g], make_uint4(lo[g].x, lo[g].y, hi[g].x, hi[g].y), bds[f]);
         }
       } else {
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
           const uint4 ak = *(const uint4*)(KT + swz<CPT>(n * 16 + r, ks * 4 + qd));
-          MMA<T>::step(dq[n], ak, bds);
+#pragma unroll
+          for (int f = 0; f < QF; ++f) MMA<T>::step(dq[f][n], ak, bds[f]);
         }
       }
     }
   }
   // epilogue: lane (query r, a = qd) holds dims n*16 + 4a + i
-  if (qi < qlen) {
-    T* dqr = (T*)p.dq + (int64_t)(q0 + qi) * p.dq_rs + (int64_t)head * p.dq_hs + 4 * qd;
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    if (qi[f] >= qlen) continue;
+    T* dqr = (T*)p.dq + (int64_t)(q0 + qi[f]) * p.dq_rs + (int64_t)head * p.dq_hs + 4 * qd;
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
       if constexpr (sizeof(T) == 2) {
-        *(uint2*)(dqr + n * 16) = make_uint2(pack2_bf16(dq[n][0], dq[n][1]), pack2_bf16(dq[n][2], dq[n][3]));
+        *(uint2*)(dqr + n * 16) = make_uint2(pack2_bf16(dq[f][n][0], dq[f][n][1]), pack2_bf16(dq[f][n][2], dq[f][n][3]));
       } else {
-        *(f32x4*)(dqr + n * 16) = dq[n];
+        *(f32x4*)(dqr + n * 16) = dq[f][n];
       }
     }
   }
@@ -502,9 +544,26 @@ int launch_attn_bwd(const sl_attn_bwd_args* a, const AttnBwdP& p, hipStream_t st
   // tile sizes keep every kernel inside 64 KiB of static LDS
   constexpr int TQ = sizeof(T) == 2 ? (D == 64 ? 64 : 32) : (D == 64 ? 32 : 16);
   constexpr int TK = sizeof(T) == 2 ? 64 : 32;
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, CAUSAL, TQ>), dim3((a->max_klen + 63) / 64, a->n_kv_heads, a->nseq), dim3(256), 0, st, p);
+  // keys (queries) per block: 128 in bf16 — two 16-row fragments per wave share every LDS operand read; fp32 (parity mode) keeps one.
+  // SL_ATTN_BWD_KF=1: the one-fragment kernels (A/B; same bits)
+  // Measured (profiles/r06_e_attn_bwd_ab.txt): the two-fragment form needs 320-360 registers, one wave per SIMD.  Llama's shape (head_dim 128, causal)
+  // gains where its 128-key blocks still fill the chip (16 x 200: 140 -> 113 us per layer); HuBERT's (head_dim 64: 201 -> 238 us) and the per-rank
+  // window's few blocks (2 x 317: 83 -> 99 us) lose the second wave that hid their latencies.  SL_ATTN_BWD_KF = 1 / 2 forces a form.
+  if constexpr (sizeof(T) == 2) {
+    const int64_t blocks2 = (int64_t)((a->max_klen + 127) / 128) * a->n_kv_heads * a->nseq;
+    const int kf = sl_env().attn_bwd_kf;
+    if (kf == 2 || (kf != 1 && D == 128 && blocks2 >= 192)) {
+      constexpr int TK2 = D == 64 ? 64 : 32;      // (head_dim 128 with two query fragments per wave: 64-key tiles spill)
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, CAUSAL, TQ, 2>), dim3((a->max_klen + 127) / 128, a->n_kv_heads, a->nseq), dim3(256), 0, st, p);
+      SL_CHECK_LAUNCH("attn_bwd_dkdv");
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, CAUSAL, TK2, 2>), dim3((a->max_qlen + 127) / 128, a->n_heads, a->nseq), dim3(256), 0, st, p);
+      SL_CHECK_LAUNCH("attn_bwd_dq");
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, CAUSAL, TQ, 1>), dim3((a->max_klen + 63) / 64, a->n_kv_heads, a->nseq), dim3(256), 0, st, p);
   SL_CHECK_LAUNCH("attn_bwd_dkdv");
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, CAUSAL, TK>), dim3((a->max_qlen + 63) / 64, a->n_heads, a->nseq), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, CAUSAL, TK, 1>), dim3((a->max_qlen + 63) / 64, a->n_heads, a->nseq), dim3(256), 0, st, p);
   SL_CHECK_LAUNCH("attn_bwd_dq");
   return 0;
 }

@@ -216,6 +216,7 @@ static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; 
 // sl_tuning_reload() (api.hip, exported for tools/tune_*.py) re-reads them for in-process A/B runs
 // ----------------------------------------------------------------------------------------------
 struct SlEnv {
+  int attn_bwd_kf;         // SL_ATTN_BWD_KF       (default 0 = by shape) 16-row fragments per wave in the attention-backward kernels: 1 / 2 force a form
   int tape_fuse;           // SL_TAPE_FUSE         (default 1) training tapes: dropout / GELU' / SwiGLU' / bias-gradient passes inside the GEMM and norm-backward kernels (0: the unfused launch sequence, A/B + parity tests)
   int compact_pin;         // SL_COMPACT_PIN       (default 1) a compacting generation keeps the kernel family of its first batch (0: each rung picks its own — A/B only)
   int stream_min_m;        // SL_STREAM_MIN_M      (default 26) packed-weight products with more rows than this take the LDS-staged streaming kernels

@@ -124,6 +124,17 @@ __device__ __forceinline__ int lds_off(int row, int ch) { return row * TROWB + (
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// 256 x 256 tile geometry and the stream-K workspace layout (kernels: gemm256.hip; launch decisions: gemm.hip)
+constexpr int XBM = 256, XBN = 256;
+constexpr size_t SK_FLAG_BYTES = 1024, SK_SLOT_BYTES = (size_t)XBM * XBN * 4;
+
+// gemm256.hip: launch one of the 256-tile kernels (explicitly instantiated for bf16 / fp32 x NONE / GELU / SILU_MUL)
+enum : int { SL_T256_PHASED = 0, SL_T256_PHASED_SW = 1, SL_T256_PLAIN = 2, SL_T256_PLAIN_SW = 3, SL_T256_SK = 4, SL_T256_SK_SW = 5, SL_T256_DBG = 16 };
+template <typename T, int ACT>
+int sl_gemm256_launch(const GemmP& p, int kind, dim3 grid, void* sk_ws, hipStream_t st);
+// gemm_tt.hip: the weight-gradient kernel on token-major operands, grid (tiles, K runs)
+int sl_gemm_tt_kernel_launch(const GemmP& p, int nt, int S, int slabs_per_run, hipStream_t st);
+
 // decode-side fused inputs of the weight-streaming kernels (sl_gemm_fused on the device side)
 struct SkinnyX {
   const float* cos; const float* sin;      // (rope_len, 64) tables

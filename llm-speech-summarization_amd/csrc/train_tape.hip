@@ -87,8 +87,10 @@ int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_i
 
 // dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in)       (ops.wgrad_acc, plain Linear)
 // sk_ws: split-K workspace OF THE STREAM `st` (few output tiles under thousands of token rows: the 1 024 x 1 024 out_proj gradient)
+// db (optional): the bias gradient db += colsum(dY) — inside the token-major product where that kernel runs (sl_gemm_ex_args.colsum_out with
+// both operands transposed), else as a sl_colsum launch behind it
 int wgrad_acc(int dt, const void* dY, int64_t ldy, int n_out, const void* X, int64_t ldx, int k_in, float* dW, int64_t M, const BwdScratch& s,
-              hipStream_t st, void* sk_ws = nullptr) {
+              hipStream_t st, void* sk_ws = nullptr, float* db = nullptr) {
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
   sl_gemm_ex_args ex;
@@ -100,8 +102,12 @@ int wgrad_acc(int dt, const void* dY, int64_t ldy, int n_out, const void* X, int
     ex.trans_a = 1; ex.trans_w = 1;
     a.A = dY; a.lda = ldy; a.W = X; a.ldw = ldx; a.K = (int)M;
     if (sk_ws) { ex.sk_ws = sk_ws; ex.sk_ws_bytes = sl_gemm_streamk_workspace_bytes(); }
-    return sl_gemm_ex(&a, &ex, (sl_stream)st);
+    if (sl_env().tape_fuse) ex.colsum_out = db;
+    SL_TRY(sl_gemm_ex(&a, &ex, (sl_stream)st));
+    if (db && !ex.colsum_out) SL_TRY(sl_colsum(dY, ldy, db, M, n_out, dt, (sl_stream)st));
+    return 0;
   }
+  if (db) SL_TRY(sl_colsum(dY, ldy, db, M, n_out, dt, (sl_stream)st));
   if (M >= 256) {
     // contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to whole K slabs): LDS-DMA tiled kernels
     const int64_t Mp = rup(M, sk_ws ? 128 : 64);      // an even number of K slabs, so that the reduction can be cut in two runs (gemm.hip splitk_runs)
@@ -346,8 +352,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     }
     have_drop = false;
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw, sk_w));
-    SL_TRY(sl_colsum(d_o2, H, g.b2, n, H, dt, (sl_stream)sw));
+    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw, sk_w, g.b2));
     SL_TRY(ss.end(0));
     SL_TRY(ss.join(1));                                   // d_pre1 was read by the previous layer's w1 group
     if (fuse) {
@@ -361,8 +366,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
       SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, w.d_pre1, n * F, dt, stream));
     }
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w));
-    if (!fuse) SL_TRY(sl_colsum(w.d_pre1, F, g.b1, n, F, dt, (sl_stream)sw));
+    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w, fuse ? nullptr : g.b1));      // (fused: b1 came out of the data-gradient epilogue above)
     SL_TRY(ss.end(1));
     SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
     // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass — and dropout(d_h2), the out-projection's incoming gradient
@@ -377,16 +381,14 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
       d_o1 = w.tmp_h2;
     }
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw, sk_w));
-    SL_TRY(sl_colsum(d_o1, H, g.bo, n, H, dt, (sl_stream)sw));
+    SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw, sk_w, g.bo));
     SL_TRY(ss.end(2));
     SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, nullptr, w.d_att, H, n, w.s, st));
     SL_TRY(ss.join(3));                                   // d_qkv was read by the previous layer's wqkv group
     SL_TRY(attn_bwd(dt, sv.qkv, 3 * H, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nh, 64, 0, 0.125f,
                     c->p_attn, sd[0], st));
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw, sk_w));
-    SL_TRY(sl_colsum(w.d_qkv, 3 * H, g.bqkv, n, 3 * H, dt, (sl_stream)sw));
+    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw, sk_w, g.bqkv));
     SL_TRY(ss.end(3));
     SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));
     // dx = d x: the LayerNorm path + the residual path (d_h2), one pass — and dropout(dx) under the mask of the next layer down this call visits

@@ -92,7 +92,7 @@ def hubert_conv0_batch(flat_waves: torch.Tensor, sample_offsets: Sequence[int], 
     """conv0 + LayerNorm + GELU of every utterance of a ragged batch in one launch -> packed (sum L_u, C) rows."""
     dev = flat_waves.device
     n_utt = len(sample_offsets) - 1
-    desc = torch.tensor([list(sample_offsets), list(row_offsets)], dtype=torch.int64, device=dev)
+    desc = L.h2d([list(sample_offsets), list(row_offsets)], torch.int64, dev)
     out = torch.empty((row_offsets[-1], w.shape[0]), device=dev, dtype=dtype)
     max_L = max(row_offsets[u + 1] - row_offsets[u] for u in range(n_utt))
     L.check(L.lib().sl_hubert_conv0_batch(L.ptr(flat_waves), desc[0].data_ptr(), desc[1].data_ptr(), n_utt, max_L, L.ptr(w), L.ptr(bias), L.ptr(gamma),
@@ -120,7 +120,7 @@ def avgpool_batch(x: torch.Tensor, seqlens: Sequence[int], kernel: int, stride: 
     for p_ in P:
         rec.append([p_, row * H, 0, 0])
         row += p_
-    rec_t = torch.tensor(rec, dtype=torch.int64, device=x.device)
+    rec_t = L.h2d(rec, torch.int64, x.device)
     y = torch.empty((row, H), device=x.device, dtype=x.dtype)
     L.check(L.lib().sl_avgpool_batch(L.ptr(x), L.ptr(y), cu.data_ptr(), klen.data_ptr(), rec_t.data_ptr(), len(seqlens), max(P), H, kernel, stride,
                                      L.dtype_code(x.dtype), L.stream_ptr()), "sl_avgpool_batch")
@@ -163,7 +163,7 @@ def seq_descriptors(seqlens: Sequence[int], device):
         cu = [0]
         for n in key[0]:
             cu.append(cu[-1] + n)
-        d = (torch.tensor(cu, dtype=torch.int32, device=device), torch.tensor(list(key[0]), dtype=torch.int32, device=device))
+        d = (L.h2d(cu, torch.int32, device), L.h2d(list(key[0]), torch.int32, device))
         _SEQ_DESC[key] = d
     return d
 
@@ -431,16 +431,20 @@ def dgrad(dY: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None,
 
 
 def wgrad_acc(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, ldx: Optional[int] = None, Kin: Optional[int] = None,
-              M: Optional[int] = None) -> torch.Tensor:
-    """dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in); X rows may overlap (ldx < K_in: implicit-GEMM conv windows)."""
+              M: Optional[int] = None, db: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in); X rows may overlap (ldx < K_in: implicit-GEMM conv windows).
+    db (fp32, N_out): the bias gradient db += colsum(dY) — inside the token-major product where that kernel runs, else a sl_colsum launch."""
     M = dY.shape[0] if M is None else M
     Nout = dY.shape[1]
     Kin = X.shape[1] if Kin is None else Kin
-    if (ldx is None and M >= 256 and dY.dtype == torch.bfloat16 and Nout % 128 == 0 and Kin % 128 == 0 and dY.stride(0) % 8 == 0 and X.stride(0) % 8 == 0
-            and os.environ.get("SL_WGRAD_TR", "1") != "0"):
-        # token-major operands as stored: the library's gemm_tiled_tt_kernel gathers its fragments with transposing LDS reads (no copies)
+    tt = (ldx is None and M >= 256 and dY.dtype == torch.bfloat16 and Nout % 128 == 0 and Kin % 128 == 0 and dY.stride(0) % 8 == 0 and X.stride(0) % 8 == 0
+          and dY.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0 and os.environ.get("SL_WGRAD_TR", "1") != "0")
+    if db is not None and not (tt and os.environ.get("SL_TAPE_FUSE", "1") != "0"):
+        colsum_acc(dY[:M], db)
+        db = None
+    if tt:
         return gemm_ex(dY, X, M=Nout, N=Kin, K=M, lda=dY.stride(0), ldw=X.stride(0), out=dW, ldc=dW.stride(0), residual=dW, ldr=dW.stride(0),
-                       out_f32=True, residual_f32=True, trans_a=True, trans_w=True, dtype=dY.dtype)
+                       out_f32=True, residual_f32=True, trans_a=True, trans_w=True, dtype=dY.dtype, colsum_out=db)
     if ldx is None and M >= 256:
         # plain Linear: contract over token rows on K-contiguous copies (dY^T, X^T zero-padded to a whole number of K slabs) so
         # the product runs the LDS-DMA tiled kernels; the doubly-transposed register loader measured ~100 TF/s on these shapes
@@ -608,7 +612,7 @@ def hubert_conv0_bwd_batch(waves: Sequence[torch.Tensor], w, bias, gamma, beta, 
     for u, wv in enumerate(waves):
         soff.append(soff[-1] + wv.numel())
         spref.append(spref[-1] + (row_offsets[u + 1] - row_offsets[u] + 23) // 24)        # strips of 24 time steps (k=10, s=5)
-    desc = torch.tensor([soff, list(row_offsets), spref], dtype=torch.int64, device=dev)
+    desc = L.h2d([soff, list(row_offsets), spref], torch.int64, dev)
     L.check(L.lib().sl_hubert_conv0_bwd_batch(L.ptr(flat), desc[0].data_ptr(), desc[1].data_ptr(), desc[2].data_ptr(), len(waves), spref[-1], L.ptr(w),
                                               L.ptr(bias), L.ptr(gamma), L.ptr(beta), L.ptr(dy), w.shape[0], k, stride, eps, L.ptr(dw), L.ptr(dbias),
                                               L.ptr(dgamma), L.ptr(dbeta), L.dtype_code(dy.dtype), L.stream_ptr()), "sl_hubert_conv0_bwd_batch")

@@ -184,7 +184,7 @@ class LlamaTape:
         dt, dev, n = x.dtype, x.device, x.shape[0]
         nh, nkv, D, H, F_ = a.num_attention_heads, a.num_key_value_heads, a.head_dim, a.hidden_size, a.intermediate_size
         nl = a.num_hidden_layers
-        pos = torch.cat([torch.arange(s_, dtype=torch.int32) for s_ in seqlens]).to(dev)
+        pos = L.h2d(torch.cat([torch.arange(s_, dtype=torch.int32) for s_ in seqlens]), torch.int32, dev)
         cfg, keep = self._cfg(n, seqlens, pos, dt)
         states = torch.empty((nl, n, H), device=dev, dtype=dt)                 # outputs of the layers = hidden[1..L]
         hidden = [x] + [states[l] for l in range(nl)]
@@ -350,7 +350,7 @@ class EncoderTape:
         acts, pres = [x], [None]
         for i in range(1, nc):
             Cin, Cout, k, s = a.conv_dim[i - 1], a.conv_dim[i], a.conv_kernel[i], a.conv_stride[i]
-            grp = torch.tensor([[Ls[i][u], offs[i - 1][u] * Cin, offs[i][u] * Cout, 0] for u in range(B)], dtype=torch.int64, device=dev)
+            grp = L.h2d([[Ls[i][u], offs[i - 1][u] * Cin, offs[i][u] * Cout, 0] for u in range(B)], torch.int64, dev)
             c = torch.empty((offs[i][B], Cout), device=dev, dtype=dt)
             ops.gemm_ex(x, t[f"conv{i}_w"], M=max(Ls[i]), N=Cout, K=k * Cin, lda=s * Cin, ldw=k * Cin, out=c, bias=t[f"conv{i}_b"], batch=B,
                         groups=grp, dtype=dt)
@@ -372,7 +372,7 @@ class EncoderTape:
                 for u in range(B):
                     m = compute_mask_indices((1, T[u]), reg.mask_time_prob, reg.mask_time_length, reg.mask_time_min_masks)[0]
                     rows.append(torch.from_numpy(np.nonzero(m)[0]) + toff[u])
-                spec_rows = torch.cat(rows).to(dev)
+                spec_rows = L.h2d(torch.cat(rows), torch.int64, dev)
                 if spec_rows.numel():
                     if masked_spec_embed is None:
                         raise L.SpeechLLMError("SpecAugment needs the encoder's masked_spec_embed")
@@ -381,8 +381,8 @@ class EncoderTape:
         Hg = H // G
         xg_off = _offsets([(T[u] + k) * H for u in range(B)])
         xg = ops.posconv_stage_batch(x0, T, G, k)                                   # one launch; utterance u at xg_off[u]
-        pos_grp = torch.tensor([[T[u], xg_off[u] + g * (T[u] + k) * Hg, toff[u] * H + g * Hg, toff[u] * H + g * Hg] for u in range(B) for g in range(G)],
-                               dtype=torch.int64, device=dev)
+        pos_grp = L.h2d([[T[u], xg_off[u] + g * (T[u] + k) * Hg, toff[u] * H + g * Hg, toff[u] * H + g * Hg] for u in range(B) for g in range(G)],
+                        torch.int64, dev)
         pre_pos = torch.empty_like(x0)
         x1 = torch.empty_like(x0)
         ops.gemm_ex(xg, t["pos_w"], M=max(T), N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=x1, ldc=H, bias=t["pos_b"], residual=x0, ldr=H, act=L.ACT_GELU,
@@ -501,7 +501,7 @@ class EncoderTape:
         if reg is not None and reg.feat_proj_dropout > 0:
             ops.dropout(dx0, reg.feat_proj_dropout, _site_seed(base, "fp"), out=dx0)
         # feature projection
-        ops.wgrad_acc(dx0, tape["fp_ln"], g["fp_w"]); ops.colsum_acc(dx0, g["fp_b"])
+        ops.wgrad_acc(dx0, tape["fp_ln"], g["fp_w"], db=g["fp_b"])
         d_fpln = ops.dgrad(dx0, t["fp_w"])
         acts, pres, offs, Ls = tape["acts"], tape["pres"], tape["offs"], tape["Ls"]
         d_act = ops.layernorm_bwd(acts[-1], t["fp_ln_g"], t["fp_ln_b"], d_fpln, a.layer_norm_eps, g["fp_ln_g"], g["fp_ln_b"])
@@ -518,7 +518,7 @@ class EncoderTape:
             Kin = kk * Cin
             part = torch.empty((B, Cout, Kin), device=d_c.device, dtype=torch.float32)
             recs = [[Cout, offs[i][u] * Cout, u * Cout * Kin, 0, offs[i - 1][u] * Cin, Kin, offs[i][u + 1] - offs[i][u], 0] for u in range(B)]
-            grp = torch.tensor(recs, dtype=torch.int64, device=d_c.device)
+            grp = L.h2d(recs, torch.int64, d_c.device)
             ops.gemm_ex(d_c, acts[i - 1], M=Cout, N=Kin, K=max(r_[6] for r_ in recs), lda=Cout, ldw=s * Cin, out=part, ldc=Kin, out_f32=True,
                         trans_a=True, trans_w=True, batch=B, dtype=dt, groups=grp, groups_ext=True)
             g[f"conv{i}_w"] += part.sum(0)
@@ -537,7 +537,7 @@ class EncoderTape:
         t, dt = W.t, enc.dtype
         H, T, toff, poff = self.hidden, tape["T"], tape["toff"], tape["poff"]
         B, NT = len(T), tape["toff"][len(T)]
-        ops.wgrad_acc(d_out, tape["pooled"], g["proj_w"]); ops.colsum_acc(d_out, g["proj_b"])
+        ops.wgrad_acc(d_out, tape["pooled"], g["proj_w"], db=g["proj_b"])
         d_pooled = ops.dgrad(d_out, t["proj_w"])
         d_lnf = torch.empty((NT, H), device=d_out.device, dtype=dt)
         for u in range(B):
@@ -686,7 +686,7 @@ class WhisperEncoderTape(EncoderTape):
         full, head = self._head_forward(x, T, toff)
         Pfull = head["P"][0]
         keep = [min(Pfull, max(0, compute_num_audio_embeds(n, sr=a.sampling_rate))) for n in lens]       # ref:trainer.py:283-289
-        rows = torch.cat([torch.arange(u * Pfull, u * Pfull + keep[u]) for u in range(B)]).to(dev)
+        rows = L.h2d(torch.cat([torch.arange(u * Pfull, u * Pfull + keep[u]) for u in range(B)]), torch.int64, dev)
         out = full.index_select(0, rows)
         tape.update(layers=layers, x_last=x, pooled=head["pooled"], P=keep, poff=_offsets(keep), P_full=head["P"], poff_full=head["poff"], rows=rows)
         return out, tape
@@ -951,7 +951,8 @@ class KDTrainer:
         # so the early per-bucket launches, whose sequence must be identical on all ranks, are skipped)
         last = (self.micro + B) == self.local_accum if close_window is None else bool(close_window)
         early_buckets = last and close_window is None and self.reducer is not None
-        response_ids = [r.to(dev) for r in response_ids]
+        response_ids = [r if r.is_cuda else L.h2d(r, r.dtype, dev) for r in response_ids]      # (asynchronous uploads: nothing in a window may stall the stream)
+        text_ids = [t_ if t_.is_cuda else L.h2d(t_, t_.dtype, dev) for t_ in text_ids]
         ns = [int(r.shape[0]) for r in response_ids]
         audio, etape = self.enc_tape.forward(waves, self.reg, step=self.micro_batches,
                                              masked_spec_embed=self.master.get("encoder.masked_spec_embed"))   # (sum P, H) packed
@@ -975,7 +976,7 @@ class KDTrainer:
         if need_teacher:
             t_parts, t_lens = [], []
             for u in range(B):
-                te = emb(text_ids[u].to(dev)[None])[0]
+                te = emb(text_ids[u][None])[0]
                 t_parts += [pre, te, suf, resp[u]]
                 t_lens.append(n_pre + te.shape[0] + suf.shape[0] + resp[u].shape[0])
             t_seq = torch.cat(t_parts, 0).contiguous()
@@ -988,7 +989,7 @@ class KDTrainer:
             hidden_a, ltape = self.llm_tape.forward(a_seq, a_lens)
             hidden_t = self.llm_tape.forward(t_seq, t_lens, save=False)[0] if need_teacher else None   # teacher pass: same kernels, nothing kept
         # rows whose logits / hidden states the losses read: the last n_u rows of every sequence
-        tail = torch.cat([torch.arange(aoff[u + 1] - ns[u], aoff[u + 1]) for u in range(B)]).to(dev)
+        tail = L.h2d(torch.cat([torch.arange(aoff[u + 1] - ns[u], aoff[u + 1]) for u in range(B)]), torch.int64, dev)
         toffs = _offsets(ns)
         logits_a = self.llm_tape.logits(hidden_a[-1].index_select(0, tail))           # (sum n, V) fp32
         V = logits_a.shape[1]
@@ -1011,17 +1012,17 @@ class KDTrainer:
             slot_rows += [u] * n
             mse_rows += [[1.0 / (n * H_llm), 2.0 * self.fd_w * inv_acc / (n * H_llm)]] * n
         labels = torch.cat(lab_rows).contiguous()
-        row_coef = torch.tensor(coef_rows, dtype=torch.float32, device=dev)
-        row_slot = torch.tensor(slot_rows, dtype=torch.int32, device=dev)
+        row_coef = L.h2d(coef_rows, torch.float32, dev)
+        row_slot = L.h2d(slot_rows, torch.int32, dev)
         d_hidden: Dict[int, torch.Tensor] = {}
         logits_t = None
         if need_teacher:
             tto = _offsets(t_lens)
-            ttail = torch.cat([torch.arange(tto[u + 1] - ns[u], tto[u + 1]) for u in range(B)]).to(dev)
+            ttail = L.h2d(torch.cat([torch.arange(tto[u + 1] - ns[u], tto[u + 1]) for u in range(B)]), torch.int64, dev)
             if self.use_ld:
                 logits_t = self.llm_tape.logits(hidden_t[-1].index_select(0, ttail))
             if self.use_fd:
-                mse_coef = torch.tensor(mse_rows, dtype=torch.float32, device=dev)
+                mse_coef = L.h2d(mse_rows, torch.float32, dev)
                 for l in self.taps:                                                   # one launch per tap for the whole window
                     ha, ht = hidden_a[l].index_select(0, tail), hidden_t[l].index_select(0, ttail)
                     dtail = torch.empty_like(ha)

@@ -553,3 +553,32 @@ def test_gemm_epilogue_fusions_refuse_the_forms_they_do_not_cover():
         ops.gemm_ex(A, W, M=128, N=128, K=64, lda=64, ldw=64, out=out, post_op=L.POST_GELU_BWD)
     with pytest.raises(L.SpeechLLMError):
         ops.gemm_ex(A, W, M=128, N=128, K=64, lda=64, ldw=64, out=out, post_op=9)
+
+
+@pytest.mark.parametrize("ws", [False, True])
+@pytest.mark.parametrize("M,Nout,Kin,ldy", [(3200, 1024, 1024, 1024), (7984, 3072, 1024, 3072), (998, 1024, 4096, 1024), (400, 4096, 1024, 4096), (3200, 1024, 4096, 3072)])
+def test_wgrad_token_major_product_carries_the_bias_gradient(M, Nout, Kin, ldy, ws):
+    """colsum_out with both operands transposed (ABI 7): db += colsum(dY) comes out of the weight-gradient product itself (the first column
+    tile's left-half waves multiply their dY fragments with a fragment of ones) — against sl_colsum on the same dY, with and without K runs,
+    on a column slice of a wider buffer (d_qkv -> bqkv); dW keeps the bits it has without the rider."""
+    dY_full = rnd(M, ldy, seed=21).to(DEV, torch.bfloat16)
+    dY = dY_full[:, :Nout]
+    X = rnd(M, Kin, seed=22).to(DEV, torch.bfloat16)
+    sk = ops.streamk_workspace(DEV) if ws else None
+
+    def run(db):
+        dW = torch.full((Nout, Kin), 0.25, device=DEV, dtype=torch.float32)
+        ops.gemm_ex(dY, X, M=Nout, N=Kin, K=M, lda=ldy, ldw=Kin, out=dW, ldc=Kin, residual=dW, ldr=Kin, out_f32=True, residual_f32=True, trans_a=True, trans_w=True,
+                    dtype=torch.bfloat16, sk_ws=sk, colsum_out=db)
+        return dW
+
+    db = torch.full((Nout,), 0.5, device=DEV, dtype=torch.float32)
+    with_rider, plain = run(db), run(None)
+    assert torch.equal(with_rider, plain)
+    ref = ops.colsum_acc(dY, torch.full((Nout,), 0.5, device=DEV, dtype=torch.float32))
+    assert rel_err(db.cpu(), ref.cpu()) < 3e-4
+    assert rel_err(db.cpu() - 0.5, dY.float().sum(0).cpu()) < 1e-3
+    # ops.wgrad_acc(db=...) takes this path for such shapes and the sl_colsum launch otherwise (a row count below the kernel's range)
+    small = torch.zeros((Nout,), device=DEV, dtype=torch.float32)
+    ops.wgrad_acc(dY[:100], X[:100], torch.zeros((Nout, Kin), device=DEV, dtype=torch.float32), db=small)
+    assert rel_err(small.cpu(), dY[:100].float().sum(0).cpu()) < 1e-3
