@@ -320,8 +320,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
 
   const int qq = r >> 2, pp = r & 3;   // transposed read: lane 4 qq + pp of a 16-lane group addresses row qq, 8-byte piece pp
   for (int kt = 0; kt < nkt; ++kt) {
+#if !defined(SL_ATTN_KO) || SL_ATTN_KO != 4
     const int buf = kt & 1, key0 = kt * 64;
     if (kt + 1 < nkt) gload(kt + 1);
+#else
+    const int buf = 0, key0 = kt * 64;      // knock-out: one staged tile, no global loads / LDS stores / barriers in the loop
+#endif
     bool active = wave_on;
     if (CAUSAL) active = active && (key0 <= qw0 + QT * 16 - 1 + shift);
     if (active) {
@@ -337,7 +341,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
         for (int ks = 0; ks < KS_D; ++ks) {
           const uint4 kf = *(const uint4*)(Kt + swz_off<CPR>(n * 16 + r, ks * 4 + q));
 #pragma unroll
+#if !defined(SL_ATTN_KO) || SL_ATTN_KO != 3
           for (int t = 0; t < QT; ++t) MMA<T>::step(s[t][n], kf, qf[t][ks]);
+#else
+          for (int t = 0; t < QT; ++t) s[t][n][0] += __builtin_bit_cast(float, kf.x & 0x3f800000u) + __builtin_bit_cast(float, qf[t][ks].x & 0x3f800000u);      // knock-out: no S products
+#endif
         }
       }
       bool need_mask = key0 + 64 > klen;
@@ -365,8 +373,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) mloc = fmaxf(mloc, s[t][n][i]);
         }
+#if !defined(SL_ATTN_KO) || SL_ATTN_KO != 5
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+#endif
         const float m_new = fmaxf(m_run[t], mloc * c);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);
@@ -376,7 +386,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
         for (int n = 0; n < 4; ++n)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+#if !defined(SL_ATTN_KO) || SL_ATTN_KO != 1
             float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][n][i], c, -m_use));
+#else
+            float pv = __builtin_fmaf(s[t][n][i], c, -m_use);      // knock-out: no exp
+#endif
             ls += pv;                                   // undropped normaliser
             if constexpr (DROP) {      // mask index ((query row * heads + head) << 16) | key: the inner hash round belongs to the query (drop_in[t])
               pv = dropout_keep_lo(drop_lo[t] | (uint32_t)(key0 + n * 16 + 4 * q + i), drop_in[t], p.drop_thr) ? pv * p.drop_scale : 0.f;
@@ -418,12 +432,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
           else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo[n]), "+v"(hi[n]) : "n"(2 * (NF_O - 1 - n)));
           const uint4 vf = make_uint4(lo[n].x, lo[n].y, hi[n].x, hi[n].y);
 #pragma unroll
+#if !defined(SL_ATTN_KO) || SL_ATTN_KO != 2
           for (int t = 0; t < QT; ++t) MMA<T>::step(o[n][t], vf, pb[t][kk]);
+#else
+          for (int t = 0; t < QT; ++t) o[n][t][0] += __builtin_bit_cast(float, vf.x & 0x3f800000u) + __builtin_bit_cast(float, pb[t][kk].x & 0x3f800000u);   // knock-out: no PV products
+#endif
         }
       }
     }
+#if !defined(SL_ATTN_KO) || SL_ATTN_KO != 4
     if (kt + 1 < nkt) sstore(buf ^ 1);
     __syncthreads();
+#endif
   }
 
   if (!wave_on) return;

@@ -58,8 +58,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // 16-byte streaming load with the non-temporal hint (weights read once per token: guide nt-weights)
 __device__ __forceinline__ uint4 ld_nt16(const void* p) {
+#ifdef SL_W_PLAIN      // A/B builds only (tools/ab): default-policy weight loads
+  return *(const uint4*)p;
+#else
   u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
   return make_uint4(v.x, v.y, v.z, v.w);
+#endif
 }
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
@@ -216,6 +220,7 @@ static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; 
 // sl_tuning_reload() (api.hip, exported for tools/tune_*.py) re-reads them for in-process A/B runs
 // ----------------------------------------------------------------------------------------------
 struct SlEnv {
+  int decode_prefetch;     // SL_DECODE_PREFETCH   (default 0: measured 2.2 x SLOWER, profiles/r06_j_decode_prefetch_ab.txt) small-batch decode graphs with a weight-prefetch branch two matrices ahead of the chain (runtime.hip DecodePrefetch)
   int attn_bwd_kf;         // SL_ATTN_BWD_KF       (default 0 = by shape) 16-row fragments per wave in the attention-backward kernels: 1 / 2 force a form
   int tape_fuse;           // SL_TAPE_FUSE         (default 1) training tapes: dropout / GELU' / SwiGLU' / bias-gradient passes inside the GEMM and norm-backward kernels (0: the unfused launch sequence, A/B + parity tests)
   int compact_pin;         // SL_COMPACT_PIN       (default 1) a compacting generation keeps the kernel family of its first batch (0: each rung picks its own — A/B only)
