@@ -259,7 +259,8 @@ class AudioLlamaForCausalLM:
         eos_c = (C.c_int32 * max(1, len(eos)))(*eos)
         out = (C.c_int32 * (B * max_new_tokens))()
         o = L.GenerateOpts()
-        o.eos_ids_host, o.n_eos, o.pad_id, o.use_eos = eos_c, (len(eos) if use_eos else 0), int(pad), int(use_eos)
+        # the ids are handed over as configured; with use_eos = 0 the library ignores them (rows then finish on their budgets only)
+        o.eos_ids_host, o.n_eos, o.pad_id, o.use_eos = eos_c, len(eos), int(pad), int(use_eos)
         o.max_new_tokens, o.check_every, o.compact = int(max_new_tokens), int(check_every), int(bool(compact))
         lim_c = None
         if row_limits is not None:

@@ -230,16 +230,20 @@ __device__ __forceinline__ int v_img_off(int row, int ch) {
   }
 }
 
-template <int D, bool CAUSAL, int QT, bool DROP = false>
+// ST = 64-key tiles per staged block of keys.  Round 6 built ST = 2 for head_dim 64 (one barrier and one global -> LDS hand-over per 128 keys instead of
+// per 64: the knock-outs of profiles/r06_i_attn_fwd_knockouts.txt put staging + barriers at 22 % of the kernel) and measured it EQUAL to ST = 1
+// (1 132-1 154 against 1 133-1 146 us at 512 x 499, encoder pass 107.9 against 107.8 ms, profiles/r06_l_attn_fwd_st_ab.txt): the barrier count is not what
+// the staging costs.  Default ST = 1; SL_ATTN_FWD_ST=2 selects the other form.
+template <int D, bool CAUSAL, int QT, bool DROP = false, int ST = 1>
 __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
   using T = bf16_t;
   constexpr int KS_D = D / 32;             // 32-wide steps across the head dim (S^T)
   constexpr int NF_O = D / 16;             // 16-wide output fragments
   constexpr int CPR = D / 8;               // 16-byte chunks per K / V row
   constexpr int TILE_B = 64 * D * 2;       // bytes of one 64-key tile
-  constexpr int NLD = (64 * CPR) / 256;    // chunks per thread per tile
+  constexpr int NLD = ST * (64 * CPR) / 256;   // chunks per thread per staged block of ST tiles
   constexpr int QB = QT * 64;              // queries per block
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_B];   // [buffer][K | V]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ST * TILE_B];   // [buffer][K | V][tile of the block]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -298,11 +302,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
   }
 
   u32x4_t kreg[NLD], vreg[NLD];
-  auto gload = [&](int kt) {
+  auto gload = [&](int sb) {      // staged block sb = tiles [sb ST, sb ST + ST)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int cidx = tid + 256 * i, row = cidx / CPR, ch = cidx % CPR;
-      int kr = kt * 64 + row; kr = kr < klen ? kr : klen - 1;
+      int kr = sb * (64 * ST) + row; kr = kr < klen ? kr : klen - 1;
       kreg[i] = *(const u32x4_t*)(kb + (int64_t)kr * p.k_rs + ch * 8);
       vreg[i] = *(const u32x4_t*)(vb + (int64_t)kr * p.v_rs + ch * 8);
     }
@@ -311,26 +315,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int cidx = tid + 256 * i, row = cidx / CPR, ch = cidx % CPR;
-      *(u32x4_t*)(&smem[buf][0][0] + swz_off<CPR>(row, ch)) = kreg[i];
-      *(u32x4_t*)(&smem[buf][1][0] + v_img_off<D>(row, ch)) = vreg[i];
+      *(u32x4_t*)(&smem[buf][0][0] + (row >> 6) * TILE_B + swz_off<CPR>(row & 63, ch)) = kreg[i];
+      *(u32x4_t*)(&smem[buf][1][0] + (row >> 6) * TILE_B + v_img_off<D>(row & 63, ch)) = vreg[i];
     }
   };
   if (nkt > 0) { gload(0); sstore(0); }
   __syncthreads();
 
   const int qq = r >> 2, pp = r & 3;   // transposed read: lane 4 qq + pp of a 16-lane group addresses row qq, 8-byte piece pp
-  for (int kt = 0; kt < nkt; ++kt) {
+  const int nsb = (nkt + ST - 1) / ST;
+  for (int sb = 0; sb < nsb; ++sb) {
 #if !defined(SL_ATTN_KO) || SL_ATTN_KO != 4
-    const int buf = kt & 1, key0 = kt * 64;
-    if (kt + 1 < nkt) gload(kt + 1);
+    const int buf = sb & 1;
+    if (sb + 1 < nsb) gload(sb + 1);
 #else
-    const int buf = 0, key0 = kt * 64;      // knock-out: one staged tile, no global loads / LDS stores / barriers in the loop
+    const int buf = 0;                      // knock-out: one staged block, no global loads / LDS stores / barriers in the loop
 #endif
+   for (int sub = 0; sub < ST; ++sub) {
+    const int kt = sb * ST + sub, key0 = kt * 64;
+    if (kt >= nkt) break;
     bool active = wave_on;
     if (CAUSAL) active = active && (key0 <= qw0 + QT * 16 - 1 + shift);
     if (active) {
-      const unsigned char* Kt = &smem[buf][0][0];
-      const uint32_t vbase = (uint32_t)(uintptr_t)(lds_ptr_a_t)&smem[buf][1][0];
+      const unsigned char* Kt = &smem[buf][0][0] + sub * TILE_B;
+      const uint32_t vbase = (uint32_t)(uintptr_t)(lds_ptr_a_t)(&smem[buf][1][0] + sub * TILE_B);
       // S^T = K.Q^T: lane (r, q) <- keys n*16 + 4q + i of query r
       f32x4 s[QT][4];
 #pragma unroll
@@ -440,8 +448,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_tr_kernel(AttnP p) {
         }
       }
     }
+   }
 #if !defined(SL_ATTN_KO) || SL_ATTN_KO != 4
-    if (kt + 1 < nkt) sstore(buf ^ 1);
+    if (sb + 1 < nsb) sstore(buf ^ 1);
     __syncthreads();
 #endif
   }
@@ -488,7 +497,8 @@ static int launch_attn(const sl_attn_args* a, hipStream_t st) {
                           // the packed probabilities; other shapes take the generic kernel, which applies the same mask
         if constexpr (D == 64 && !CAUSAL) {
           dim3 grid((a->max_qlen + 127) / 128, a->n_heads, a->nseq);
-          hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 2, true>), grid, dim3(256), 0, st, p);
+          if (sl_env().attn_fwd_st == 2) hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 2, true, 2>), grid, dim3(256), 0, st, p);
+          else hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 2, true>), grid, dim3(256), 0, st, p);
           SL_CHECK_LAUNCH("attn_fwd_tr");
           return 0;
         }
@@ -498,7 +508,8 @@ static int launch_attn(const sl_attn_args* a, hipStream_t st) {
           // 64 queries per wave where the sequences are long enough to fill such blocks: K / V fragments read once per 4 query tiles
           if (qt_env ? qt_env == 4 : a->max_qlen > 192) {
             dim3 grid((a->max_qlen + 255) / 256, a->n_heads, a->nseq);
-            hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 4>), grid, dim3(256), 0, st, p);
+            if (sl_env().attn_fwd_st == 2) hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 4, false, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_fwd_tr_kernel<D, CAUSAL, 4>), grid, dim3(256), 0, st, p);
             SL_CHECK_LAUNCH("attn_fwd_tr");
             return 0;
           }

@@ -220,6 +220,7 @@ static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; 
 // sl_tuning_reload() (api.hip, exported for tools/tune_*.py) re-reads them for in-process A/B runs
 // ----------------------------------------------------------------------------------------------
 struct SlEnv {
+  int attn_fwd_st;         // SL_ATTN_FWD_ST       (default 1; 2 measured equal, profiles/r06_l_attn_fwd_st_ab.txt) head_dim-64 attention forward: 64-key tiles per staged block
   int decode_prefetch;     // SL_DECODE_PREFETCH   (default 0: measured 2.2 x SLOWER, profiles/r06_j_decode_prefetch_ab.txt) small-batch decode graphs with a weight-prefetch branch two matrices ahead of the chain (runtime.hip DecodePrefetch)
   int attn_bwd_kf;         // SL_ATTN_BWD_KF       (default 0 = by shape) 16-row fragments per wave in the attention-backward kernels: 1 / 2 force a form
   int tape_fuse;           // SL_TAPE_FUSE         (default 1) training tapes: dropout / GELU' / SwiGLU' / bias-gradient passes inside the GEMM and norm-backward kernels (0: the unfused launch sequence, A/B + parity tests)

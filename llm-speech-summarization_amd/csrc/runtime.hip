@@ -954,7 +954,8 @@ static int generate_impl(const sl_llama_model* m, const sl_kv_cache* kv, void* x
                          sl_stream stream) {
   SL_TRY(llama_check(m, kv));
   SL_CHECK_ARG(o != nullptr, "sl_generate: null options");
-  const int max_new_tokens = o->max_new_tokens, n_eos = o->n_eos, pad_id = o->pad_id;
+  // use_eos = 0: the EOS ids are ignored even when the caller left them in the struct — rows then finish on their budgets only
+  const int max_new_tokens = o->max_new_tokens, n_eos = o->use_eos ? o->n_eos : 0, pad_id = o->pad_id;
   const int32_t* eos_ids_host = o->eos_ids_host;
   const int use_eos = (o->use_eos || o->row_limits_host) ? 1 : 0;       // per-row budgets finish rows the way EOS does
   SL_CHECK_ARG(x && cu_seqlens_host && out_ids_host && workspace && nseq > 0 && nseq <= SL_MAX_DECODE_BATCH && max_new_tokens > 0,

@@ -13,7 +13,7 @@ vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            name = re.sub(r"\(.*$", "", row.get("Kernel_Name", "")).replace("void ", "").strip()
+            name = re.sub(r"\(.*$", "", row.get("Kernel_Name", "").replace("(anonymous namespace)::", "")).replace("void ", "").strip()
             vals[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for name, cs in vals.items():
