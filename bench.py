@@ -993,7 +993,7 @@ def main():
     # `traffic` cannot be measured inside this process (PMC counters need rocprofv3 around it): it is READ from the committed
     # counter summary of the same two launches (tools/probe_decode_kernels.py under separate --pmc passes), and says so
     pmc, pmc_src = {}, None
-    for name in ("r05_pmc_decode_kernels.json", "r04_pmc_decode_kernels.json", "r03_pmc_decode_kernels.json", "r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):   # newest committed PMC passes first
+    for name in ("r06_pmc_decode_kernels.json", "r05_pmc_decode_kernels.json", "r04_pmc_decode_kernels.json", "r03_pmc_decode_kernels.json", "r02_pmc_decode_kernels.json", "r01_pmc_decode_kernels.json"):   # newest committed PMC passes first
         pmc_path = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
