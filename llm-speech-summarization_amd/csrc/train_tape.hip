@@ -218,7 +218,12 @@ struct SideStream {
 // encoder stack (hf:models/hubert/modeling_hubert.py:504-547 stable-LN layer; hf:models/whisper/modeling_whisper.py:360-414)
 // ================================================================================================
 struct EncWs {
-  void *tmp_h, *tmp_h2, *d_mid, *d_pre1, *d_h1, *d_h2, *d_att, *d_qkv;      // tmp_h: dropout(dx) (FFN2's incoming gradient), tmp_h2: dropout(d_h2) (the out-projection's)
+  // Buffers the parameter-gradient groups read come in two copies, used by alternate (visited) layers: the side stream may still be working on a
+  // layer's groups while the next layer's main chain runs, and the main stream then waits for it once per layer instead of once per group
+  // (every event operation on the main stream cost a 5-20 us bubble: 253 of them = 2.6 ms of a 91 ms window, profiles/r06_p_kd_timeline.txt).
+  // tmp_h: dropout(dx) (FFN2's incoming gradient), tmp_h2: dropout(d_h2) (the out-projection's)
+  void *tmp_h[2], *tmp_h2[2], *d_pre1[2], *d_h2[2], *d_qkv[2];
+  void *d_mid, *d_h1, *d_att;
   float* delta;
   void* ln_ws;         // per-block dgamma / dbeta records of the LayerNorm backward (sl_layernorm_bwd_ws)
   size_t ln_ws_bytes;
@@ -233,14 +238,16 @@ static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs
   const int64_t Mp = rup(n, 128);
   const int64_t big = F > 3 * H ? F : 3 * H;
   Carver cv(base, cap);
-  w.tmp_h = cv.take(n * H * sz);
-  w.tmp_h2 = cv.take(n * H * sz);
+  for (int k = 0; k < 2; ++k) {
+    w.tmp_h[k] = cv.take(n * H * sz);
+    w.tmp_h2[k] = cv.take(n * H * sz);
+    w.d_pre1[k] = cv.take(n * F * sz);
+    w.d_h2[k] = cv.take(n * H * sz);
+    w.d_qkv[k] = cv.take(n * 3 * H * sz);
+  }
   w.d_mid = cv.take(n * F * sz);
-  w.d_pre1 = cv.take(n * F * sz);
   w.d_h1 = cv.take(n * H * sz);
-  w.d_h2 = cv.take(n * H * sz);
   w.d_att = cv.take(n * H * sz);
-  w.d_qkv = cv.take(n * 3 * H * sz);
   w.delta = (float*)cv.take(n * c->n_heads * sizeof(float));
   w.ln_ws_bytes = sl_layernorm_bwd_ws_bytes(n, (int32_t)H);
   w.ln_ws = cv.take(w.ln_ws_bytes);
@@ -287,8 +294,8 @@ extern "C" int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const s
       pd.seed = sd[1];
       SL_TRY(gemm(dt, sv.att, H, L.wo, H, sv.x_mid, H, L.bo, x, H, n, H, H, SL_ACT_NONE, nullptr, st, nullptr, &pd));
     } else if (c->p_hidden > 0.f) {
-      SL_TRY(gemm(dt, sv.att, H, L.wo, H, w.tmp_h, H, L.bo, nullptr, 0, n, H, H, SL_ACT_NONE, nullptr, st));
-      SL_TRY(sl_dropout(w.tmp_h, x, sv.x_mid, n * H, c->p_hidden, sd[1], dt, stream));
+      SL_TRY(gemm(dt, sv.att, H, L.wo, H, w.tmp_h[0], H, L.bo, nullptr, 0, n, H, H, SL_ACT_NONE, nullptr, st));
+      SL_TRY(sl_dropout(w.tmp_h[0], x, sv.x_mid, n * H, c->p_hidden, sd[1], dt, stream));
     } else {
       SL_TRY(gemm(dt, sv.att, H, L.wo, H, sv.x_mid, H, L.bo, x, H, n, H, H, SL_ACT_NONE, nullptr, st));
     }
@@ -305,8 +312,8 @@ extern "C" int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const s
       pd.seed = sd[3];
       SL_TRY(gemm(dt, sv.mid, F, L.w2, F, sv.x_out, H, L.b2, sv.x_mid, H, n, H, F, SL_ACT_NONE, nullptr, st, w.sk, &pd));
     } else if (c->p_hidden > 0.f) {
-      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, w.tmp_h, H, L.b2, nullptr, 0, n, H, F, SL_ACT_NONE, nullptr, st, w.sk));
-      SL_TRY(sl_dropout(w.tmp_h, sv.x_mid, sv.x_out, n * H, c->p_hidden, sd[3], dt, stream));
+      SL_TRY(gemm(dt, sv.mid, F, L.w2, F, w.tmp_h[0], H, L.b2, nullptr, 0, n, H, F, SL_ACT_NONE, nullptr, st, w.sk));
+      SL_TRY(sl_dropout(w.tmp_h[0], sv.x_mid, sv.x_out, n * H, c->p_hidden, sd[3], dt, stream));
     } else {
       SL_TRY(gemm(dt, sv.mid, F, L.w2, F, sv.x_out, H, L.b2, sv.x_mid, H, n, H, F, SL_ACT_NONE, nullptr, st, w.sk));
     }
@@ -334,71 +341,77 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   if (sk) SL_HIP(hipMemsetAsync(sk, 0, 1024, st));
   void* sk_w = (ss.on || !w.sk) ? w.sk_w : sk;                 // the parameter-gradient group's own (side stream), or the shared one when all is on `st`
   if (sk_w && sk_w != sk) SL_HIP(hipMemsetAsync(sk_w, 0, 1024, st));      // ordered before the first fork of the side stream
-  // w.tmp_h already holds dropout(dx) under the CURRENT layer's output-dropout mask: the LayerNorm backward that produced dx (the layer
+  // tmp_h[par] already holds dropout(dx) under the CURRENT layer's output-dropout mask: the LayerNorm backward that produced dx (the layer
   // above's) wrote it as its second output, so this layer starts without an sl_dropout launch and without re-reading dx
   bool have_drop = false;
   const bool fuse = fuse_ok(n, dt, H, F);
+  int par = 0;                   // which copy of the group-read buffers this layer uses (alternates over the layers visited)
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     if (c->skip[l]) continue;
     const sl_hubert_layer& L = layers[l];
     const sl_enc_layer_saved& sv = saved[l];
     const sl_enc_layer_grads& g = grads[l];
     const uint64_t* sd = c->seeds + 4 * (size_t)l;
+    void* const tmp_h = w.tmp_h[par];
+    void* const tmp_h2 = w.tmp_h2[par];
+    void* const d_pre1 = w.d_pre1[par];
+    void* const d_h2 = w.d_h2[par];
+    void* const d_qkv = w.d_qkv[par];
     // ---- feed-forward half: x_out = x_mid + drop(w2 . drop_act(gelu(w1 . ln2(x_mid) + b1)) + b2)
     const void* d_o2 = dx;
     if (c->p_hidden > 0.f) {
-      if (!have_drop) SL_TRY(sl_dropout(dx, nullptr, w.tmp_h, n * H, c->p_hidden, sd[3], dt, stream));      // (the layer above joined group 0 before it let go of tmp_h)
-      d_o2 = w.tmp_h;
+      if (!have_drop) SL_TRY(sl_dropout(dx, nullptr, tmp_h, n * H, c->p_hidden, sd[3], dt, stream));      // (first layer of the call: nothing reads tmp_h[0] yet)
+      d_o2 = tmp_h;
     }
     have_drop = false;
-    SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw, sk_w, g.b2));
-    SL_TRY(ss.end(0));
-    SL_TRY(ss.join(1));                                   // d_pre1 was read by the previous layer's w1 group
     if (fuse) {
       // d_pre1 = gelu'(pre1) * drop_act(d_o2 . w2) and b1 += colsum(d_pre1), all in the data-gradient product's epilogue
       Post pg;
       pg.op = SL_POST_GELU_BWD; pg.p = c->p_act; pg.seed = sd[2]; pg.ld = F; pg.in = sv.pre1; pg.in_ld = F; pg.colsum = g.b1;
-      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_pre1, F, n, w.s, st, nullptr, &pg));
+      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, d_pre1, F, n, w.s, st, nullptr, &pg));
     } else {
       SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_mid, F, n, w.s, st));
       if (c->p_act > 0.f) SL_TRY(sl_dropout(w.d_mid, nullptr, w.d_mid, n * F, c->p_act, sd[2], dt, stream));
-      SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, w.d_pre1, n * F, dt, stream));
+      SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, d_pre1, n * F, dt, stream));
     }
+    // group A (one fork): the two feed-forward parameter gradients
     SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, w.d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w, fuse ? nullptr : g.b1));      // (fused: b1 came out of the data-gradient epilogue above)
-    SL_TRY(ss.end(1));
-    SL_TRY(dgrad(dt, w.d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
+    SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw, sk_w, g.b2));
+    SL_TRY(wgrad_acc(dt, d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w, fuse ? nullptr : g.b1));      // (fused: b1 came out of the data-gradient epilogue above)
+    if (c->p_hidden <= 0.f) SL_TRY(ss.end(2));             // (group A reads dx itself then: it must be through before dx is rewritten below)
+    SL_TRY(dgrad(dt, d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
     // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass — and dropout(d_h2), the out-projection's incoming gradient
-    SL_TRY(ss.join(2));                                   // d_h2 / tmp_h2 were the previous layer's d_o1 (read by its wo group)
     const bool drop1 = c->p_hidden > 0.f && fuse;
-    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, w.d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
-                                        drop1 ? w.tmp_h2 : nullptr, c->p_hidden, sd[1]));
+    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
+                                        drop1 ? tmp_h2 : nullptr, c->p_hidden, sd[1]));
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
-    const void* d_o1 = w.d_h2;
+    const void* d_o1 = d_h2;
     if (c->p_hidden > 0.f) {
-      if (!drop1) SL_TRY(sl_dropout(w.d_h2, nullptr, w.tmp_h2, n * H, c->p_hidden, sd[1], dt, stream));
-      d_o1 = w.tmp_h2;
+      if (!drop1) SL_TRY(sl_dropout(d_h2, nullptr, tmp_h2, n * H, c->p_hidden, sd[1], dt, stream));
+      d_o1 = tmp_h2;
     }
+    SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, nullptr, w.d_att, H, n, w.s, st));
+    SL_TRY(attn_bwd(dt, sv.qkv, 3 * H, sv.att, w.d_att, sv.lse, w.delta, d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nh, 64, 0, 0.125f,
+                    c->p_attn, sd[0], st));
+    // group B (one fork): the two attention parameter gradients; its completion event covers group A too (the side stream is in order)
     SL_TRY(ss.begin(sw));
     SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw, sk_w, g.bo));
-    SL_TRY(ss.end(2));
-    SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, nullptr, w.d_att, H, n, w.s, st));
-    SL_TRY(ss.join(3));                                   // d_qkv was read by the previous layer's wqkv group
-    SL_TRY(attn_bwd(dt, sv.qkv, 3 * H, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nh, 64, 0, 0.125f,
-                    c->p_attn, sd[0], st));
-    SL_TRY(ss.begin(sw));
-    SL_TRY(wgrad_acc(dt, w.d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw, sk_w, g.bqkv));
-    SL_TRY(ss.end(3));
-    SL_TRY(dgrad(dt, w.d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));
-    // dx = d x: the LayerNorm path + the residual path (d_h2), one pass — and dropout(dx) under the mask of the next layer down this call visits
-    SL_TRY(ss.join(0));                                   // this layer's w2 group read dx / tmp_h, both rewritten here
+    SL_TRY(wgrad_acc(dt, d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw, sk_w, g.bqkv));
+    SL_TRY(ss.end(par));
+    SL_TRY(dgrad(dt, d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));
+    // The one wait of the layer: the PREVIOUS visited layer's groups (the other copy of the buffers) must be through before this layer's last
+    // kernel writes that copy's tmp_h (the dropped gradient of the next layer down) — and with them everything older, so the next layer may
+    // overwrite its own copy freely.  p_hidden = 0: group A read dx, which is rewritten here.
+    SL_TRY(ss.join(1 - par));
+    SL_TRY(ss.join(2));
     int below = -1;
     for (int k = l - 1; k >= layer_begin && below < 0; --k)
       if (!c->skip[k]) below = k;
     have_drop = below >= 0 && c->p_hidden > 0.f && fuse;
-    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x, L.ln1_g, L.ln1_b, w.d_h1, w.d_h2, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
-                                        have_drop ? w.tmp_h : nullptr, c->p_hidden, have_drop ? c->seeds[4 * (size_t)below + 3] : 0));
+    // dx = d x: the LayerNorm path + the residual path (d_h2), one pass — and dropout(dx) under the mask of the next layer down this call visits
+    SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x, L.ln1_g, L.ln1_b, w.d_h1, d_h2, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
+                                        have_drop ? w.tmp_h[1 - par] : nullptr, c->p_hidden, have_drop ? c->seeds[4 * (size_t)below + 3] : 0));
+    par ^= 1;
     (void)sz;
   }
   for (int k = 0; k < 4; ++k) SL_TRY(ss.join(k));          // the caller's stream owns the gradients again

@@ -1038,11 +1038,24 @@ class KDTrainer:
         self.micro += B
         self.micro_total += B
         self.last_d_audio = d_audio
-        out = []
-        for ntp, ld, fd in losses.tolist():
-            out.append(dict(ntp_loss=ntp, ld_loss=ld, fd_loss=fd, total=self.ntp_w * ntp + self.ld_w * ld + self.fd_w * fd))
+        # The losses go to the host through a pinned asynchronous copy queued BEFORE the optimizer step's launches, and are waited for only after
+        # those launches are queued: reading them first (losses.tolist()) left the GPU idle for the 1.4 ms the host needs to prepare the step
+        # (profiles/r06_n_kd_timeline.txt: the largest gap of a window), and a read behind the step would wait for AdamW as well.
+        ev = None
+        if losses.is_cuda:
+            host = torch.empty(losses.shape, dtype=losses.dtype, pin_memory=True)
+            host.copy_(losses, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host = losses
         if last:
             self.optimizer_step()
+        if ev is not None:
+            ev.synchronize()
+        out = []
+        for ntp, ld, fd in host.tolist():
+            out.append(dict(ntp_loss=ntp, ld_loss=ld, fd_loss=fd, total=self.ntp_w * ntp + self.ld_w * ld + self.fd_w * fd))
         return out
 
     def close(self) -> None:
