@@ -193,6 +193,12 @@ typedef struct {
   int64_t drop_ld;
   const void* post_in; int64_t post_ld;
   float* colsum_out;
+  /* deferred_splits (host pointer, optional; plain un-grouped product with sk_ws, no bias / residual / post_op, output in the storage type): if the
+   * product is cut into K runs (the few-tile rule of sk_ws), the reduce pass is NOT launched: *deferred_splits = S >= 2 and the S fp32 partial
+   * products stay in sk_ws at byte offset 1024, S slabs of M x N floats (row stride N) — for a consumer that sums them itself while loading
+   * (the norm-backward kernels of the training tapes: C = round(sum over runs, in run order) is what the reduce pass would have stored, and C is
+   * NOT written).  Otherwise *deferred_splits = 0 and C is written as usual.  The partials live until the next product that uses sk_ws. */
+  int32_t* deferred_splits;
 } sl_gemm_ex_args;
 enum { SL_POST_NONE = 0, SL_POST_DROPOUT = 1, SL_POST_GELU_BWD = 2, SL_POST_SILU_MUL_BWD = 3 };
 int sl_gemm_ex(const sl_gemm_args* a, const sl_gemm_ex_args* ex, sl_stream stream);

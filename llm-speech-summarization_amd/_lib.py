@@ -52,7 +52,7 @@ class GemmEx(C.Structure):
                 ("ln_mr", c_vp), ("ln_u", c_vp), ("ln_c", c_vp), ("stats_out", c_vp), ("sk_ws", c_vp), ("sk_ws_bytes", C.c_size_t),
                 # training-tape epilogue fusions (ABI 7)
                 ("post_op", c_i32), ("post_reserved", c_i32), ("drop_p", C.c_float), ("post_reserved_f", C.c_float), ("drop_seed", C.c_uint64),
-                ("drop_ld", C.c_int64), ("post_in", c_vp), ("post_ld", C.c_int64), ("colsum_out", c_vp)]
+                ("drop_ld", C.c_int64), ("post_in", c_vp), ("post_ld", C.c_int64), ("colsum_out", c_vp), ("deferred_splits", c_vp)]
 
 
 class AttnArgs(C.Structure):

@@ -679,7 +679,9 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
         q.C = part; q.ldc = p.N; q.sC = (int64_t)p.M * p.N; q.out_f32 = 1;
         q.bias = nullptr; q.sBias = 0; q.res = nullptr; q.ldr = 0; q.sR = 0; q.res_f32 = 0;
         q.post = 0; q.drop_thr24 = 0; q.post_in = nullptr; q.colsum = nullptr;      // the reduce pass applies them
+        q.defer = nullptr;
         SL_TRY((launch_tiled<T, SL_ACT_NONE>(q, S, st)));
+        if (p.defer && !p.bias && !p.res && !p.post && !p.colsum && !p.out_f32) { *p.defer = S; return 0; }      // the consumer sums the runs (speechllm.h deferred_splits)
         const int64_t vecs = ((int64_t)p.M * p.N + 3) / 4;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, part, S, (int64_t)p.M * p.N, p);
         SL_CHECK_LAUNCH("splitk_reduce");
@@ -902,7 +904,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.M = a->M; p.N = a->N; p.K = a->K; p.out_f32 = a->out_f32;
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
-  p.post = 0; p.drop_thr24 = 0; p.drop_scale = 1.f; p.drop_seed = 0; p.drop_ld = 0; p.post_in = nullptr; p.post_ld = 0; p.colsum = nullptr;
+  p.post = 0; p.drop_thr24 = 0; p.drop_scale = 1.f; p.drop_seed = 0; p.drop_ld = 0; p.post_in = nullptr; p.post_ld = 0; p.colsum = nullptr; p.defer = nullptr;
   p.stamp = nullptr; p.amax_val = nullptr; p.amax_idx = nullptr; p.ln_mr = nullptr; p.ln_u = nullptr; p.ln_c = nullptr; p.stats_out = nullptr;
   const int direct_epi = sl_env().direct_epilogue;
   p.direct_epi = direct_epi;
@@ -911,6 +913,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   if (ex) {
     p.ta = ex->trans_a; p.tw = ex->trans_w; p.aux = ex->aux_out; p.res_f32 = ex->residual_f32;
     p.grp = ex->groups; p.w_mod = ex->w_mod > 0 ? ex->w_mod : 1;
+    if (ex->deferred_splits) { *ex->deferred_splits = 0; p.defer = ex->deferred_splits; }
     p.grp_ext = ex->groups && ex->groups_ext;
     p.grp_kslab = ex->groups && ex->groups_ext == 2;
     SL_CHECK_ARG(!(p.ta || p.tw || p.aux) || a->act != SL_ACT_SILU_MUL, "sl_gemm_ex: transposed operands / aux_out are not combined with SILU_MUL");

@@ -35,6 +35,7 @@ struct GemmP {
   int64_t drop_ld;     // element index of (row, col) in the mask = row * drop_ld + col
   const void* post_in; int64_t post_ld;
   float* colsum;       // fp32 column sums of the stored values (+=, atomics)
+  int32_t* defer;      // host: split-K reduce pass left to the consumer (sl_gemm_ex_args.deferred_splits)
   uint32_t* stamp;     // instrumented build of the phased 256-tile kernel only: [block][half][32] cycle stamps (SL_GEMM_STAMP_PTR)
 };
 

@@ -257,7 +257,32 @@ struct NormBwdX {
   const void* add2;      // dx = round(dx + add2) after the first add (the bits of a following sl_axpby(add2, dx))
   void* dx_drop;         // dropout(dx as stored) at element index row * cols + col
   uint32_t thr24; float scale; uint64_t seed;
+  // dy left as the S fp32 partial products of a K-split GEMM (sl_gemm_ex_args.deferred_splits): dy = round(sum of the runs, in run order) is formed
+  // while loading — the reduce launch between the product and this kernel, and its round trip of dy through memory, are gone
+  const float* dy_parts; int dy_S; int64_t dy_slab;
 };
+
+template <typename T>
+__device__ __forceinline__ uint4 norm_bwd_load_dy(const T* __restrict__ dy, const NormBwdX& ex, int64_t row, int cols, int c0) {
+  if (!ex.dy_parts) return *(const uint4*)(dy + row * cols + c0);
+  constexpr int VEC = Vec16<T>::VEC;
+  float acc[VEC];
+  const float* p0 = ex.dy_parts + row * cols + c0;
+#pragma unroll
+  for (int e = 0; e < VEC; e += 4) {
+    const f32x4 v = *(const f32x4*)(p0 + e);
+    acc[e] = v[0]; acc[e + 1] = v[1]; acc[e + 2] = v[2]; acc[e + 3] = v[3];
+  }
+  for (int z = 1; z < ex.dy_S; ++z) {
+    const float* pz = p0 + (int64_t)z * ex.dy_slab;
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4) {
+      const f32x4 v = *(const f32x4*)(pz + e);
+      acc[e] += v[0]; acc[e + 1] += v[1]; acc[e + 2] += v[2]; acc[e + 3] += v[3];
+    }
+  }
+  return Vec16<T>::pack(acc);      // rounded to the storage type, as the reduce pass would have stored it
+}
 
 template <typename T>
 __device__ __forceinline__ void norm_bwd_store(T* __restrict__ dx, const T* __restrict__ add, const NormBwdX& ex, int64_t row, int cols, int c0, float (&o)[Vec16<T>::VEC]) {
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
         const int ch = lane + 64 * i;
         if (ch < nch) {
           xr[i] = *(const uint4*)(x + row * cols + ch * VEC);
-          dr[i] = *(const uint4*)(dy + row * cols + ch * VEC);
+          dr[i] = norm_bwd_load_dy<T>(dy, ex, row, cols, ch * VEC);
           float xv[VEC];
           Vec16<T>::unpack(xr[i], xv);
 #pragma unroll
@@ -396,7 +421,7 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
       const int ch = lane + 64 * i;
       if (ch < nch) {
         Vec16<T>::unpack(*(const uint4*)(x + row * cols + ch * VEC), xv[i]);
-        Vec16<T>::unpack(*(const uint4*)(dy + row * cols + ch * VEC), dv[i]);
+        Vec16<T>::unpack(norm_bwd_load_dy<T>(dy, ex, row, cols, ch * VEC), dv[i]);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s += RMS ? xv[i][e] * xv[i][e] : xv[i][e];
       }
@@ -1199,8 +1224,9 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
 // dx_drop (optional): also dropout(dx) with (p, seed) — the incoming gradient of the Linear below (h = h + dropout(sublayer(h)))
 int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
                                  int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream,
-                                 void* dx_drop, float drop_p, uint64_t drop_seed) {
+                                 void* dx_drop, float drop_p, uint64_t drop_seed, const float* dy_parts, int dy_splits) {
   NormBwdX ex{};
+  if (dy_parts && dy_splits >= 2) { ex.dy_parts = dy_parts; ex.dy_S = dy_splits; ex.dy_slab = rows * (int64_t)cols; }
   if (dx_drop && drop_p > 0.f) {
     ex.dx_drop = dx_drop; ex.thr24 = (uint32_t)((double)drop_p * 16777216.0); ex.scale = 1.0f / (1.0f - drop_p); ex.seed = drop_seed;
   }
@@ -1221,14 +1247,17 @@ extern "C" int sl_layernorm_bwd_ws(const void* x, const void* gamma, const void*
 // add2 (optional): a second gradient joining at this hidden state (the feature-distillation term), added after `add` with the roundings of a
 // following sl_axpby(add2, dx)
 int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const void* add, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
-                            sl_stream stream, const void* add2) {
+                            sl_stream stream, const void* add2, const float* dy_parts, int dy_splits) {
   SL_CHECK_ARG(x && w && dy && dx && rows >= 0 && cols > 0 && (!add || add != dx) && (!add2 || add2 != dx), "sl_rmsnorm_bwd: bad arguments");
   NormBwdX ex{};
   ex.add2 = add2;
+  if (dy_parts && dy_splits >= 2) { ex.dy_parts = dy_parts; ex.dy_S = dy_splits; ex.dy_slab = rows * (int64_t)cols; }
   const int vec = dtype == SL_F32 ? 4 : 8;
   SL_CHECK_ARG(cols % vec == 0 && cols <= 64 * TR_MAXF, "sl_rmsnorm_bwd: cols=%d must be a multiple of %d and <= %d", cols, vec, 64 * TR_MAXF);
   if (rows == 0) return 0;
-  const int rpb = 16;
+  // rows per block (4 waves, a wave per row at a time): 16 keeps ~300 blocks at the 5 072 rows of a 16-sample window; the per-rank window's 634 rows
+  // would make 40 blocks of four sequential rows per wave (31 us for 4 MB) — one row per wave there: 159 blocks
+  const int rpb = rows <= 2048 ? 4 : 16;
   SL_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((norm_bwd_kernel<T, true, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
                        (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add, ex);
@@ -1239,7 +1268,7 @@ int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const 
 
 extern "C" int sl_rmsnorm_bwd(const void* x, const void* w, const void* dy, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
                               sl_stream stream) {
-  return sl_rmsnorm_bwd_add_impl(x, w, dy, nullptr, dx, rows, cols, eps, dtype, stream, nullptr);
+  return sl_rmsnorm_bwd_add_impl(x, w, dy, nullptr, dx, rows, cols, eps, dtype, stream, nullptr, nullptr, 0);
 }
 
 extern "C" int sl_colsum(const void* x, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t dtype, sl_stream stream) {

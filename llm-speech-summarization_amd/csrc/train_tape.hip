@@ -12,9 +12,9 @@
 // ... and, optionally, dropout(dx) as a second output (dx_drop: the incoming gradient of the sublayer below) / a second joining gradient (add2)
 int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
                                  int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream,
-                                 void* dx_drop, float drop_p, uint64_t drop_seed);
+                                 void* dx_drop, float drop_p, uint64_t drop_seed, const float* dy_parts, int dy_splits);
 int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const void* add, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
-                            sl_stream stream, const void* add2);
+                            sl_stream stream, const void* add2, const float* dy_parts, int dy_splits);
 
 namespace {
 
@@ -43,11 +43,12 @@ struct Post {
 // C = act(A W^T + bias) + residual   (ops.gemm)
 // sk_ws: optional stream-K workspace (sl_gemm_ex_args.sk_ws) for products of a few tiles under a long reduction
 int gemm(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* res, int64_t ldr,
-         int64_t M, int N, int K, int act, void* aux_out, hipStream_t st, void* sk_ws = nullptr, const Post* post = nullptr) {
+         int64_t M, int N, int K, int act, void* aux_out, hipStream_t st, void* sk_ws = nullptr, const Post* post = nullptr, int32_t* defer = nullptr) {
   sl_gemm_args a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias; a.residual = res; a.ldr = ldr;
   a.M = (int)M; a.N = N; a.K = K; a.batch = 1; a.dtype = dt; a.act = act;
+  if (defer) *defer = 0;
   if (!aux_out && !sk_ws && !post) return sl_gemm(&a, (sl_stream)st);
   sl_gemm_ex_args ex;
   memset(&ex, 0, sizeof(ex));
@@ -57,6 +58,7 @@ int gemm(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, void* C
     ex.post_op = post->op; ex.drop_p = post->p; ex.drop_seed = post->seed; ex.drop_ld = post->ld;
     ex.post_in = post->in; ex.post_ld = post->in_ld; ex.colsum_out = post->colsum;
   }
+  if (sk_ws && sl_env().tape_fuse) ex.deferred_splits = defer;      // the K runs of a few-tile product stay in sk_ws for a norm backward that sums them while loading
   return sl_gemm_ex(&a, &ex, (sl_stream)st);
 }
 
@@ -74,7 +76,7 @@ struct BwdScratch {
 // dX (M, K_in) = dY (M, N_out) . W (N_out, K_in), through a transposed copy of W so that the product is K-contiguous
 // (ops.dgrad with wt = ops.transpose_pad(W)); wt_cached != NULL: the copy already exists (frozen weights)
 int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_in, const void* wt_cached, void* dX, int64_t ldx, int64_t M,
-          const BwdScratch& s, hipStream_t st, void* sk_ws = nullptr, const Post* post = nullptr) {
+          const BwdScratch& s, hipStream_t st, void* sk_ws = nullptr, const Post* post = nullptr, int32_t* defer = nullptr) {
   const int vec = dt == SL_F32 ? 4 : 8;
   const int64_t ldw = rup(n_out, vec);
   const void* wt = wt_cached;
@@ -82,7 +84,7 @@ int dgrad(int dt, const void* dY, int64_t ldy, const void* W, int n_out, int k_i
     SL_TRY(sl_transpose_pad(W, k_in, s.wt, ldw, n_out, k_in, n_out, dt, (sl_stream)st));
     wt = s.wt;
   }
-  return gemm(dt, dY, ldy, wt, wt_cached ? n_out : ldw, dX, ldx, nullptr, nullptr, 0, M, k_in, n_out, SL_ACT_NONE, nullptr, st, sk_ws, post);
+  return gemm(dt, dY, ldy, wt, wt_cached ? n_out : ldw, dX, ldx, nullptr, nullptr, 0, M, k_in, n_out, SL_ACT_NONE, nullptr, st, sk_ws, post, defer);
 }
 
 // dW (N_out, K_in) fp32 += dY^T (N_out, M) . X (M, K_in)       (ops.wgrad_acc, plain Linear)
@@ -379,11 +381,12 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, d_o2, H, H, sv.mid, F, F, g.w2, n, w.s, sw, sk_w, g.b2));
     SL_TRY(wgrad_acc(dt, d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w, fuse ? nullptr : g.b1));      // (fused: b1 came out of the data-gradient epilogue above)
     if (c->p_hidden <= 0.f) SL_TRY(ss.end(2));             // (group A reads dx itself then: it must be through before dx is rewritten below)
-    SL_TRY(dgrad(dt, d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk));
+    int32_t S1 = 0, S2 = 0;      // K runs left in `sk` for the LayerNorm backward behind the product (0: d_h1 was written as usual)
+    SL_TRY(dgrad(dt, d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk, nullptr, &S1));
     // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass — and dropout(d_h2), the out-projection's incoming gradient
     const bool drop1 = c->p_hidden > 0.f && fuse;
     SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
-                                        drop1 ? tmp_h2 : nullptr, c->p_hidden, sd[1]));
+                                        drop1 ? tmp_h2 : nullptr, c->p_hidden, sd[1], S1 ? (const float*)((const unsigned char*)sk + 1024) : nullptr, S1));
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
     const void* d_o1 = d_h2;
     if (c->p_hidden > 0.f) {
@@ -398,7 +401,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw, sk_w, g.bo));
     SL_TRY(wgrad_acc(dt, d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw, sk_w, g.bqkv));
     SL_TRY(ss.end(par));
-    SL_TRY(dgrad(dt, d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk));
+    SL_TRY(dgrad(dt, d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk, nullptr, &S2));
     // The one wait of the layer: the PREVIOUS visited layer's groups (the other copy of the buffers) must be through before this layer's last
     // kernel writes that copy's tmp_h (the dropped gradient of the next layer down) — and with them everything older, so the next layer may
     // overwrite its own copy freely.  p_hidden = 0: group A read dx, which is rewritten here.
@@ -410,7 +413,8 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     have_drop = below >= 0 && c->p_hidden > 0.f && fuse;
     // dx = d x: the LayerNorm path + the residual path (d_h2), one pass — and dropout(dx) under the mask of the next layer down this call visits
     SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x, L.ln1_g, L.ln1_b, w.d_h1, d_h2, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
-                                        have_drop ? w.tmp_h[1 - par] : nullptr, c->p_hidden, have_drop ? c->seeds[4 * (size_t)below + 3] : 0));
+                                        have_drop ? w.tmp_h[1 - par] : nullptr, c->p_hidden, have_drop ? c->seeds[4 * (size_t)below + 3] : 0,
+                                        S2 ? (const float*)((const unsigned char*)sk + 1024) : nullptr, S2));
     par ^= 1;
     (void)sz;
   }
@@ -524,16 +528,18 @@ extern "C" int sl_llama_stack_train_bwd(const sl_llama_train_layer* layers, cons
       SL_TRY(dgrad(dt, dx, H, L.wdown, H, F, L.wdown_t, w.d_mid, F, n, w.s, st, w.sk));
       SL_TRY(sl_silu_mul_bwd(sv.gu, w.d_mid, w.d_gu, n, F, dt, stream));
     }
-    SL_TRY(dgrad(dt, w.d_gu, 2 * F, L.wgu, 2 * F, H, L.wgu_t, w.d_h, H, n, w.s, st, w.sk));
-    SL_TRY(sl_rmsnorm_bwd_add_impl(sv.x2, L.norm2, w.d_h, dx, w.dx2, n, H, c->rms_eps, dt, stream, nullptr));      // + the residual path (dx), same pass
+    int32_t S1 = 0, S2 = 0;      // K runs of the product in front of each RMSNorm backward, summed there while loading (0: written as usual)
+    const float* parts = (const float*)((const unsigned char*)w.sk + 1024);
+    SL_TRY(dgrad(dt, w.d_gu, 2 * F, L.wgu, 2 * F, H, L.wgu_t, w.d_h, H, n, w.s, st, w.sk, nullptr, &S1));
+    SL_TRY(sl_rmsnorm_bwd_add_impl(sv.x2, L.norm2, w.d_h, dx, w.dx2, n, H, c->rms_eps, dt, stream, nullptr, S1 ? parts : nullptr, S1));      // + the residual path (dx), same pass
     // x2 = x + wo . attn(rope(wqkv . rmsnorm(x)))
     SL_TRY(dgrad(dt, w.dx2, H, L.wo, H, att_w, L.wo_t, w.d_att, att_w, n, w.s, st, w.sk));
     SL_TRY(attn_bwd(dt, sv.qkv, qkv_w, sv.att, w.d_att, sv.lse, w.delta, w.d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nkv, D, 1, scale, 0.f, 0,
                     st));
     SL_TRY(sl_rope_inplace(w.d_qkv, c->pos, c->rope_cos, c->rope_sin, n, nh + 2 * nkv, nh + nkv, D, 1, dt, stream));
-    SL_TRY(dgrad(dt, w.d_qkv, qkv_w, L.wqkv, qkv_w, H, L.wqkv_t, w.d_h, H, n, w.s, st, w.sk));
+    SL_TRY(dgrad(dt, w.d_qkv, qkv_w, L.wqkv, qkv_w, H, L.wqkv_t, w.d_h, H, n, w.s, st, w.sk, nullptr, &S2));
     // + the residual path (dx2) and the feature-distillation gradient of hidden_states[l], same pass
-    SL_TRY(sl_rmsnorm_bwd_add_impl(hidden[l], L.norm1, w.d_h, w.dx2, dx, n, H, c->rms_eps, dt, stream, (d_tap && fuse) ? d_tap[l] : nullptr));
+    SL_TRY(sl_rmsnorm_bwd_add_impl(hidden[l], L.norm1, w.d_h, w.dx2, dx, n, H, c->rms_eps, dt, stream, (d_tap && fuse) ? d_tap[l] : nullptr, S2 ? parts : nullptr, S2));
     if (d_tap && d_tap[l] && !fuse) SL_TRY(sl_axpby(d_tap[l], dx, 1.f, 1.f, n * H, dt, stream));
   }
   return 0;
