@@ -155,6 +155,8 @@ def cpu_baseline(enc_sd, llm_sd_gpu, harch, larch, wave, prefix, suffix, new_tok
             "decode_ms_per_token_by_threads": tried,
             "audio_sec_per_s": round(wave.numel() / 16000.0 / enc_s, 2), "prefill_tokens_per_s": round(prompt.shape[1] / pre_s, 1),
             "decode_tokens_per_s": round(1.0 / tok_s, 3),
+            # the thread-count choice moves between runs on one host (32 / 16 threads, 429-547 ms per token across rounds): the baseline is a range
+            "decode_tokens_per_s_range_over_thread_settings": ([round(1e3 / max(tried.values()), 3), round(1e3 / min(tried.values()), 3)] if tried else None),
             "sample": (f"1 utterance of {wave.numel() / 16000:.0f} s on {cores} threads (fastest of {[k for k in tried if isinstance(k, int)]} on a host with {phys} physical cores), "
                        f"after 1 warm-up pass: encoder {enc_s:.2f} s and prefill S={prompt.shape[1]} {pre_s:.2f} s (medians of 3), "
                        f"{new_tokens} decode steps at {tok_s * 1e3:.0f} ms/token (median), fp32 oracle; value "

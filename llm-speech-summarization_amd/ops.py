@@ -360,10 +360,12 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
             strideBias: int = 0, strideR: int = 0, a_off: int = 0, w_off: int = 0, c_off: int = 0, r_off: int = 0,
             dtype: Optional[torch.dtype] = None, groups: Optional[torch.Tensor] = None, w_mod: int = 1, groups_ext: bool = False,
             ln_mr=None, ln_u=None, ln_c=None, stats_out=None, sk_ws: Optional[torch.Tensor] = None,
-            post_op: int = 0, drop_p: float = 0.0, drop_seed: int = 0, drop_ld: int = 0, post_in=None, post_ld: int = 0, colsum_out=None):
+            post_op: int = 0, drop_p: float = 0.0, drop_seed: int = 0, drop_ld: int = 0, post_in=None, post_ld: int = 0, colsum_out=None,
+            deferred_splits=None):
     """Raw-pointer GEMM with every backward feature; *_off are element offsets into the tensors.  ln_mr/ln_u/ln_c: the
     LayerNorm-folded consumer epilogue; stats_out: per-64-column {sum, sum of squares} of the stored rows (speechllm.h).
-    post_op / drop_* / post_in / colsum_out: the training tape's epilogue fusions (sl_gemm_ex_args, ABI 7)."""
+    post_op / drop_* / post_in / colsum_out: the training tape's epilogue fusions (sl_gemm_ex_args, ABI 7).
+    deferred_splits: a ctypes c_int32 the library sets to the number of K runs it left un-reduced in sk_ws (0: `out` was written)."""
     dt = dtype or A.dtype
     esz = 4 if dt == torch.float32 else 2
     a = L.GemmArgs()
@@ -383,6 +385,8 @@ def gemm_ex(A, W, *, M: int, N: int, K: int, lda: int, ldw: int, out: torch.Tens
         e.sk_ws, e.sk_ws_bytes = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size()
     e.post_op, e.drop_p, e.drop_seed, e.drop_ld = int(post_op), float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, int(drop_ld)
     e.post_in, e.post_ld, e.colsum_out = L.ptr(post_in), int(post_ld), L.ptr(colsum_out)
+    if deferred_splits is not None:
+        e.deferred_splits = C.cast(C.byref(deferred_splits), C.c_void_p)
     L.check(L.lib().sl_gemm_ex(C.byref(a), C.byref(e), L.stream_ptr()), "sl_gemm_ex")
     return out
 
@@ -590,15 +594,19 @@ def mse_loss(a, b, coef, loss, da=None, accumulate=False):
                                 L.stream_ptr()), "sl_mse_loss")
 
 
-def avgpool_bwd(dy, T, kernel, stride):
+def avgpool_bwd(dy, T, kernel, stride, out=None):
+    """out (optional): the (T, H) rows of a packed buffer the gradient is written into (no temporary + copy per utterance)."""
     P, H = dy.shape
-    dx = torch.empty((T, H), device=dy.device, dtype=dy.dtype)
+    dx = torch.empty((T, H), device=dy.device, dtype=dy.dtype) if out is None else out
+    assert dx.is_contiguous() and tuple(dx.shape) == (T, H)
     L.check(L.lib().sl_avgpool_bwd(L.ptr(dy), L.ptr(dx), T, H, kernel, stride, P, L.dtype_code(dy.dtype), L.stream_ptr()), "sl_avgpool_bwd")
     return dx
 
 
-def col2im(dcol, Lin, Cc, k, s):
-    dx = torch.empty((Lin, Cc), device=dcol.device, dtype=dcol.dtype)
+def col2im(dcol, Lin, Cc, k, s, out=None):
+    """out (optional): the (Lin, Cc) rows of a packed buffer the gradient is written into (no temporary + copy per utterance)."""
+    dx = torch.empty((Lin, Cc), device=dcol.device, dtype=dcol.dtype) if out is None else out
+    assert dx.is_contiguous() and tuple(dx.shape) == (Lin, Cc)
     L.check(L.lib().sl_col2im(L.ptr(dcol), L.ptr(dx), Lin, dcol.shape[0], Cc, k, s, L.dtype_code(dcol.dtype), L.stream_ptr()), "sl_col2im")
     return dx
 

@@ -524,7 +524,7 @@ class EncoderTape:
             g[f"conv{i}_w"] += part.sum(0)
             for u in range(B):
                 o0, o1, i0, i1 = offs[i][u], offs[i][u + 1], offs[i - 1][u], offs[i - 1][u + 1]
-                d_prev[i0:i1] = ops.col2im(dcol[o0:o1], i1 - i0, Cin, kk, s)
+                ops.col2im(dcol[o0:o1], i1 - i0, Cin, kk, s, out=d_prev[i0:i1])      # straight into the packed rows
             d_act = d_prev
             done([f"conv{i}_w", f"conv{i}_b", f"conv{i}_g", f"conv{i}_beta"])
         ops.hubert_conv0_bwd_batch(tape["waves"], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], d_act, offs[0], g["conv0_w"], g["conv0_b"],
@@ -541,7 +541,7 @@ class EncoderTape:
         d_pooled = ops.dgrad(d_out, t["proj_w"])
         d_lnf = torch.empty((NT, H), device=d_out.device, dtype=dt)
         for u in range(B):
-            d_lnf[toff[u]:toff[u + 1]] = ops.avgpool_bwd(d_pooled[poff[u]:poff[u + 1]], T[u], enc.pool_kernel, enc.pool_stride)
+            ops.avgpool_bwd(d_pooled[poff[u]:poff[u + 1]], T[u], enc.pool_kernel, enc.pool_stride, out=d_lnf[toff[u]:toff[u + 1]])
         dx = ops.layernorm_bwd(tape["x_last"], t["final_ln_g"], t["final_ln_b"], d_lnf, self.ln_eps, g["final_ln_g"], g["final_ln_b"])
         done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
         return dx

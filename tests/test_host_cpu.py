@@ -569,3 +569,15 @@ def test_integration_md_binding_stub_structs_match_the_library():
         assert C.sizeof(a) == C.sizeof(b), name
         assert [(f[0], getattr(a, f[0]).offset) for f in a._fields_] == [(f[0], getattr(b, f[0]).offset) for f in b._fields_], name
     assert "speechllm_structs" not in src
+
+
+def test_h2d_upload_helper_on_cpu_devices_and_dtypes():
+    """_lib.h2d (the training path's asynchronous upload helper): on a CPU device it is a plain conversion — values, dtype and shape kept for
+    lists and for tensors of another dtype (the CUDA branch, pinned block + non-blocking copy, runs under the GPU suites)."""
+    L = pkg("_lib")
+    t = L.h2d([[1, 2, 3], [4, 5, 6]], torch.int64, "cpu")
+    assert t.dtype == torch.int64 and t.tolist() == [[1, 2, 3], [4, 5, 6]]
+    u = L.h2d(torch.arange(5, dtype=torch.int32), torch.int64, torch.device("cpu"))
+    assert u.dtype == torch.int64 and u.tolist() == [0, 1, 2, 3, 4]
+    f = L.h2d([0.5, 1.5], torch.float32, "cpu")
+    assert f.dtype == torch.float32 and f.tolist() == [0.5, 1.5]

@@ -582,3 +582,31 @@ def test_wgrad_token_major_product_carries_the_bias_gradient(M, Nout, Kin, ldy, 
     small = torch.zeros((Nout,), device=DEV, dtype=torch.float32)
     ops.wgrad_acc(dY[:100], X[:100], torch.zeros((Nout, Kin), device=DEV, dtype=torch.float32), db=small)
     assert rel_err(small.cpu(), dY[:100].float().sum(0).cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(998, 1024, 4096), (634, 3072, 16384), (400, 1024, 4096)])
+def test_gemm_deferred_split_k_partials_sum_to_the_reduced_product(dt, M, N, K):
+    """sl_gemm_ex_args.deferred_splits: for a few-tile product under a long reduction the library leaves the S fp32 partial products in sk_ws
+    (byte offset 1 024, S slabs of M x N) and skips its reduce pass; summed in run order and rounded to the storage type they are bit for bit
+    the product with the reduce pass (what the norm-backward kernels of the KD tapes do while loading dY).  A product the split rule does not
+    take reports 0 and writes C as usual."""
+    import ctypes as C
+    A, W = rnd(M, K, seed=31).to(DEV, dt), (rnd(N, K, seed=32) * K ** -0.5).to(DEV, dt)
+    ws = ops.streamk_workspace(DEV)
+    ref = ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), sk_ws=ws)
+    S = C.c_int32(-1)
+    out = torch.full((M, N), 3.0, device=DEV, dtype=dt)
+    ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=out, sk_ws=ws, deferred_splits=S)
+    assert S.value >= 2, S.value
+    parts = ws[1024:1024 + S.value * M * N * 4].view(torch.float32).view(S.value, M, N)
+    acc = parts[0].clone()
+    for z in range(1, S.value):
+        acc += parts[z]
+    assert torch.equal(acc.to(dt), ref)
+    assert bool((out == 3.0).all())                       # C untouched: the consumer owns the sum
+    S2 = C.c_int32(-1)                                    # a short reduction: no K runs, the ordinary product
+    small = ops.gemm_ex(A[:, :512].contiguous(), W[:, :512].contiguous(), M=M, N=N, K=512, lda=512, ldw=512, out=torch.empty((M, N), device=DEV, dtype=dt),
+                        sk_ws=ws, deferred_splits=S2)
+    assert S2.value == 0 and torch.equal(small, ops.gemm_ex(A[:, :512].contiguous(), W[:, :512].contiguous(), M=M, N=N, K=512, lda=512, ldw=512,
+                                                             out=torch.empty((M, N), device=DEV, dtype=dt)))
