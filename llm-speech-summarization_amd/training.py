@@ -489,10 +489,12 @@ class EncoderTape:
             ops.gemm_ex(d_pre, xg, M=Hg, N=k * Hg, K=Tu, lda=H, ldw=Hg, out=g["pos_w"], ldc=k * Hg, residual=g["pos_w"], ldr=k * Hg,
                         out_f32=True, residual_f32=True, trans_a=True, trans_w=True, batch=G, strideA=Hg, strideW=(Tu + k) * Hg, strideC=Hg * k * Hg,
                         strideR=Hg * k * Hg, a_off=r0 * H, w_off=xg_off[u], dtype=dt)
-            # dgrad: correlation with the flipped, transposed weight over the staged d_pre (windows start one row later)
-            dpg = ops.posconv_stage(d_pre[r0:r0 + Tu], G, k)
-            ops.gemm_ex(dpg, wd, M=Tu, N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=dx0, ldc=H, residual=dx, ldr=H, batch=G, strideA=(Tu + k) * Hg,
-                        strideW=Hg * k * Hg, strideC=Hg, strideR=Hg, a_off=Hg, c_off=r0 * H, r_off=r0 * H, dtype=dt)
+        # dgrad: correlation with the flipped, transposed weight over the staged d_pre (windows start one row later) — every utterance and group in ONE
+        # staging launch + ONE grouped product (the forward's records shifted by a row; was a staging launch + a 16-group product per utterance)
+        dpg = ops.posconv_stage_batch(d_pre, T, G, k)
+        grp = L.h2d([[T[u], xg_off[u] + g * (T[u] + k) * Hg + Hg, toff[u] * H + g * Hg, toff[u] * H + g * Hg] for u in range(B) for g in range(G)], torch.int64, dx.device)
+        ops.gemm_ex(dpg, wd, M=max(T), N=Hg, K=k * Hg, lda=Hg, ldw=k * Hg, out=dx0, ldc=H, residual=dx, ldr=H, batch=B * G, strideW=Hg * k * Hg, groups=grp,
+                    w_mod=G, dtype=dt)
         # SpecAugment rows took the learned mask embedding; feature-projection dropout
         spec_rows = tape.get("spec_rows")
         if spec_rows is not None and spec_rows.numel():
