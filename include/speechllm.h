@@ -486,6 +486,13 @@ int sl_avgpool_bwd(const void* dy, void* dx, int64_t T, int32_t H, int32_t kerne
                    sl_stream stream);
 int sl_col2im(const void* dcol, void* dx, int64_t Lin, int64_t Lout, int32_t C, int32_t k, int32_t s, int32_t dtype,
               sl_stream stream);
+/* The same two for every utterance of a packed (ragged) batch in ONE launch (ABI 7; ref:trainer.py:270-384 loops over utterances):
+ * desc_dev = n_utt device records of four int64 {source rows (Lout / P), destination rows (Lin / T), first source row, first destination row}
+ * into the packed source / destination buffers; max_Lin / max_T = the largest destination row count (sizes the grid). */
+int sl_col2im_batch(const void* dcol, void* dx, const int64_t* desc_dev, int32_t n_utt, int64_t max_Lin, int32_t C, int32_t k, int32_t s,
+                    int32_t dtype, sl_stream stream);
+int sl_avgpool_bwd_batch(const void* dy, void* dx, const int64_t* desc_dev, int32_t n_utt, int64_t max_T, int32_t H, int32_t kernel,
+                         int32_t stride, int32_t dtype, sl_stream stream);
 int sl_hubert_conv0_bwd(const float* wave, int64_t n_samples, const float* w, const float* bias, const float* gamma,
                         const float* beta, const void* dy, int32_t C, int32_t k, int32_t stride, float eps, float* dw,
                         float* dbias, float* dgamma, float* dbeta, int32_t dtype, sl_stream stream);

@@ -221,6 +221,8 @@ _PROTOS = {
     "sl_kd_mse_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "sl_avgpool_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp]),
     "sl_col2im": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sl_col2im_batch": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "sl_avgpool_bwd_batch": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "sl_hubert_conv0_bwd_batch": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp,
                                           c_vp, c_i32, c_vp]),
     "sl_hubert_conv0_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp,

@@ -231,6 +231,10 @@ int main() {
     gx.trans_a = gx.trans_w = 1; ga.M = 192; ga.N = 128; ga.K = 512;        // the bias-gradient rider needs the token-major kernel's shapes (M % 128)
     EXPECT_ARG_ERROR(sl_gemm_ex(&ga, &gx, nullptr));
   }
+  EXPECT_ARG_ERROR(sl_col2im_batch(nullptr, nullptr, nullptr, 4, 100, 64, 3, 2, SL_BF16, nullptr));
+  EXPECT_ARG_ERROR(sl_col2im_batch(ws, ws, (const int64_t*)ws, 4, 100, 60, 3, 2, SL_BF16, nullptr));            // C not a multiple of 8
+  EXPECT_ARG_ERROR(sl_avgpool_bwd_batch(ws, ws, (const int64_t*)ws, 0, 100, 128, 8, 4, SL_BF16, nullptr));      // no utterances
+  EXPECT_ARG_ERROR(sl_avgpool_bwd_batch(ws, ws, (const int64_t*)ws, 2, 100, 130, 8, 4, SL_BF16, nullptr));      // H not a multiple of 8
   EXPECT(sl_decode_graph_cache_clear() == 0, "nothing cached on this thread");
 
   {   // collective group: argument checks only (no device here)

@@ -1414,6 +1414,94 @@ extern "C" int sl_avgpool_bwd(const void* dy, void* dx, int64_t T_, int32_t H, i
   return 0;
 }
 
+// whole ragged batch in one launch: utterance u = blockIdx.y; desc[u] = {rows in, rows out, first input row, first output row} (int64)
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_batch_kernel(const T* __restrict__ dcol, T* __restrict__ dx, const int64_t* __restrict__ desc, int Cc, int k, int s) {
+  const int64_t* d = desc + 4 * (int64_t)blockIdx.y;
+  const int64_t Lout = d[0], Lin = d[1];
+  dcol += d[2] * (int64_t)k * Cc;
+  dx += d[3] * Cc;
+  constexpr int VEC = Vec16<T>::VEC;
+  const int cpr = Cc / VEC;
+  const int64_t total = Lin * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % cpr);
+    const int64_t t = i / cpr;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int64_t dd = t - j;
+      if (dd < 0 || dd % s) continue;
+      const int64_t to = dd / s;
+      if (to >= Lout) continue;
+      float f[VEC];
+      Vec16<T>::unpack(*(const uint4*)(dcol + to * (int64_t)k * Cc + (int64_t)j * Cc + ch * VEC), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+    }
+    *(uint4*)(dx + t * Cc + ch * VEC) = Vec16<T>::pack(acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_batch_kernel(const T* __restrict__ dy, T* __restrict__ dx, const int64_t* __restrict__ desc, int H, int kernel,
+                                                                int stride) {
+  const int64_t* d = desc + 4 * (int64_t)blockIdx.y;
+  const int64_t P = d[0], T_ = d[1];
+  dy += d[2] * H;
+  dx += d[3] * H;
+  constexpr int VEC = Vec16<T>::VEC;
+  const int cpr = H / VEC;
+  const int64_t total = T_ * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % cpr);
+    const int64_t t = i / cpr;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    const int64_t first = t - kernel + 1;
+    const int64_t p_lo = first <= 0 ? 0 : (first + stride - 1) / stride;
+    for (int64_t pp = p_lo; pp < P && pp * stride <= t; ++pp) {
+      float f[VEC];
+      Vec16<T>::unpack(*(const uint4*)(dy + pp * H + ch * VEC), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+    }
+    const float inv = 1.0f / (float)kernel;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] *= inv;
+    *(uint4*)(dx + t * H + ch * VEC) = Vec16<T>::pack(acc);
+  }
+}
+
+// desc_dev: n_utt records {rows of the source (Lout / P), rows of the destination (Lin / T), first source row, first destination row}
+extern "C" int sl_col2im_batch(const void* dcol, void* dx, const int64_t* desc_dev, int32_t n_utt, int64_t max_Lin, int32_t Cc, int32_t k, int32_t s, int32_t dtype,
+                               sl_stream stream) {
+  SL_CHECK_ARG(dcol && dx && desc_dev && n_utt > 0 && max_Lin > 0 && Cc > 0 && k > 0 && s > 0, "sl_col2im_batch: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(Cc % vec == 0, "sl_col2im_batch: C must be a multiple of %d", vec);
+  const unsigned gx = grid_for(max_Lin * (Cc / vec), 1024);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((col2im_batch_kernel<T>), dim3(gx, (unsigned)n_utt), dim3(256), 0, (hipStream_t)stream, (const T*)dcol, (T*)dx, desc_dev, Cc, k, s);
+  });
+  SL_CHECK_LAUNCH("col2im_batch");
+  return 0;
+}
+
+extern "C" int sl_avgpool_bwd_batch(const void* dy, void* dx, const int64_t* desc_dev, int32_t n_utt, int64_t max_T, int32_t H, int32_t kernel, int32_t stride,
+                                    int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(dy && dx && desc_dev && n_utt > 0 && max_T > 0 && H > 0 && kernel > 0 && stride > 0, "sl_avgpool_bwd_batch: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  SL_CHECK_ARG(H % vec == 0, "sl_avgpool_bwd_batch: H must be a multiple of %d", vec);
+  const unsigned gx = grid_for(max_T * (H / vec), 1024);
+  SL_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((avgpool_bwd_batch_kernel<T>), dim3(gx, (unsigned)n_utt), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, desc_dev, H, kernel, stride);
+  });
+  SL_CHECK_LAUNCH("avgpool_bwd_batch");
+  return 0;
+}
+
 extern "C" int sl_col2im(const void* dcol, void* dx, int64_t Lin, int64_t Lout, int32_t Cc, int32_t k, int32_t s, int32_t dtype, sl_stream stream) {
   SL_CHECK_ARG(dcol && dx && Lin > 0 && Lout > 0 && Cc > 0 && k > 0 && s > 0, "sl_col2im: bad arguments");
   const int vec = dtype == SL_F32 ? 4 : 8;

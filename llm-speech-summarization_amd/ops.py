@@ -611,6 +611,23 @@ def col2im(dcol, Lin, Cc, k, s, out=None):
     return dx
 
 
+def col2im_batch(dcol, out, src_rows: Sequence[int], dst_rows: Sequence[int], src_off: Sequence[int], dst_off: Sequence[int], Cc: int, k: int, s: int):
+    """sl_col2im for every utterance of a packed batch in one launch: utterance u's windows are rows src_off[u] .. + src_rows[u] of dcol (k * Cc wide), its
+    gradient rows dst_off[u] .. + dst_rows[u] of `out` (Cc wide)."""
+    desc = L.h2d([[src_rows[u], dst_rows[u], src_off[u], dst_off[u]] for u in range(len(src_rows))], torch.int64, dcol.device)
+    L.check(L.lib().sl_col2im_batch(L.ptr(dcol), L.ptr(out), desc.data_ptr(), len(src_rows), max(int(n) for n in dst_rows), Cc, k, s, L.dtype_code(dcol.dtype),
+                                    L.stream_ptr()), "sl_col2im_batch")
+    return out
+
+
+def avgpool_bwd_batch(dy, out, P: Sequence[int], T: Sequence[int], src_off: Sequence[int], dst_off: Sequence[int], kernel: int, stride: int):
+    """sl_avgpool_bwd for every utterance of a packed batch in one launch (rows src_off[u] .. + P[u] of dy -> rows dst_off[u] .. + T[u] of out)."""
+    desc = L.h2d([[P[u], T[u], src_off[u], dst_off[u]] for u in range(len(P))], torch.int64, dy.device)
+    L.check(L.lib().sl_avgpool_bwd_batch(L.ptr(dy), L.ptr(out), desc.data_ptr(), len(P), max(int(n) for n in T), dy.shape[1], kernel, stride,
+                                         L.dtype_code(dy.dtype), L.stream_ptr()), "sl_avgpool_bwd_batch")
+    return out
+
+
 def hubert_conv0_bwd_batch(waves: Sequence[torch.Tensor], w, bias, gamma, beta, dy, row_offsets: Sequence[int], dw, dbias, dgamma, dbeta, k=10, stride=5,
                            eps=1e-5):
     """conv0 + LayerNorm + GELU backward of every utterance of a packed batch in ONE launch (dy rows row_offsets[u]..)."""

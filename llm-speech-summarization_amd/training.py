@@ -524,9 +524,9 @@ class EncoderTape:
             ops.gemm_ex(d_c, acts[i - 1], M=Cout, N=Kin, K=max(r_[6] for r_ in recs), lda=Cout, ldw=s * Cin, out=part, ldc=Kin, out_f32=True,
                         trans_a=True, trans_w=True, batch=B, dtype=dt, groups=grp, groups_ext=True)
             g[f"conv{i}_w"] += part.sum(0)
-            for u in range(B):
-                o0, o1, i0, i1 = offs[i][u], offs[i][u + 1], offs[i - 1][u], offs[i - 1][u + 1]
-                ops.col2im(dcol[o0:o1], i1 - i0, Cin, kk, s, out=d_prev[i0:i1])      # straight into the packed rows
+            # every utterance's windows folded back in ONE launch, straight into the packed rows (was a launch + a copy per utterance)
+            ops.col2im_batch(dcol, d_prev, [offs[i][u + 1] - offs[i][u] for u in range(B)], [offs[i - 1][u + 1] - offs[i - 1][u] for u in range(B)],
+                             [offs[i][u] for u in range(B)], [offs[i - 1][u] for u in range(B)], Cin, kk, s)
             d_act = d_prev
             done([f"conv{i}_w", f"conv{i}_b", f"conv{i}_g", f"conv{i}_beta"])
         ops.hubert_conv0_bwd_batch(tape["waves"], t["conv0_w"], t["conv0_b"], t["conv0_g"], t["conv0_beta"], d_act, offs[0], g["conv0_w"], g["conv0_b"],
@@ -542,8 +542,8 @@ class EncoderTape:
         ops.wgrad_acc(d_out, tape["pooled"], g["proj_w"], db=g["proj_b"])
         d_pooled = ops.dgrad(d_out, t["proj_w"])
         d_lnf = torch.empty((NT, H), device=d_out.device, dtype=dt)
-        for u in range(B):
-            ops.avgpool_bwd(d_pooled[poff[u]:poff[u + 1]], T[u], enc.pool_kernel, enc.pool_stride, out=d_lnf[toff[u]:toff[u + 1]])
+        ops.avgpool_bwd_batch(d_pooled, d_lnf, [poff[u + 1] - poff[u] for u in range(B)], T, [poff[u] for u in range(B)], [toff[u] for u in range(B)],
+                              enc.pool_kernel, enc.pool_stride)
         dx = ops.layernorm_bwd(tape["x_last"], t["final_ln_g"], t["final_ln_b"], d_lnf, self.ln_eps, g["final_ln_g"], g["final_ln_b"])
         done(["proj_w", "proj_b", "final_ln_g", "final_ln_b"])
         return dx

@@ -610,3 +610,32 @@ def test_gemm_deferred_split_k_partials_sum_to_the_reduced_product(dt, M, N, K):
                         sk_ws=ws, deferred_splits=S2)
     assert S2.value == 0 and torch.equal(small, ops.gemm_ex(A[:, :512].contiguous(), W[:, :512].contiguous(), M=M, N=N, K=512, lda=512, ldw=512,
                                                              out=torch.empty((M, N), device=DEV, dtype=dt)))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_batched_col2im_and_avgpool_backward_equal_the_per_utterance_launches(dt):
+    """sl_col2im_batch / sl_avgpool_bwd_batch (ABI 7): the strided-conv data gradient's fold-back and the AvgPool1d backward for every utterance of a packed
+    ragged batch in one launch each, written straight into the packed rows — bit for bit the per-utterance launches (hf:models/hubert/modeling_hubert.py:141
+    conv layers, ref:model/audio_encoder.py:37-41 pooling, walked backwards by ref:trainer.py:373)."""
+    Cc, k, s = 64, 3, 2
+    Lin = [401, 37, 999, 5]
+    Lout = [(n - k) // s + 1 for n in Lin]
+    so, do = [0], [0]
+    for a, b in zip(Lout, Lin):
+        so.append(so[-1] + a); do.append(do[-1] + b)
+    dcol = rnd(so[-1], k * Cc, seed=41).to(DEV, dt)
+    out = torch.full((do[-1], Cc), 9.0, device=DEV, dtype=dt)
+    ops.col2im_batch(dcol, out, Lout, Lin, so[:-1], do[:-1], Cc, k, s)
+    for u in range(len(Lin)):
+        assert torch.equal(out[do[u]:do[u + 1]], ops.col2im(dcol[so[u]:so[u + 1]], Lin[u], Cc, k, s)), u
+    H, kernel, stride = 128, 8, 4
+    T = [499, 12, 123, 8]
+    P = [(t_ - kernel) // stride + 1 for t_ in T]
+    po, to = [0], [0]
+    for a, b in zip(P, T):
+        po.append(po[-1] + a); to.append(to[-1] + b)
+    dy = rnd(po[-1], H, seed=42).to(DEV, dt)
+    dx = torch.full((to[-1], H), 9.0, device=DEV, dtype=dt)
+    ops.avgpool_bwd_batch(dy, dx, P, T, po[:-1], to[:-1], kernel, stride)
+    for u in range(len(T)):
+        assert torch.equal(dx[to[u]:to[u + 1]], ops.avgpool_bwd(dy[po[u]:po[u + 1]], T[u], kernel, stride)), u
