@@ -1,4 +1,5 @@
-"""Statistics of the two per-element mixers of the dropout mask on sequential indices (csrc/common.h lowbias32 / dropmix24), CPU only:
+"""Statistics of two per-element mixers for the dropout mask on sequential indices, CPU only: lowbias32 (csrc/common.h, the product's) and dropmix24 (the same
+shape on 24-bit multiplies: built and measured in round 6, no gain, not adopted — profiles/r06_w_dropout_hash_ab.txt):
 drop rate at p = 0.1 / 0.5, largest serial correlation of the mask over lags 1 ... 4096, chi-square (255 d.o.f.) of the top and bottom byte
 of the 24-bit value, four (inner, start) draws of 4 M elements each.
     python tools/dropout_hash_stats.py"""
