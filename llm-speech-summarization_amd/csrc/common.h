@@ -221,6 +221,8 @@ static inline size_t sl_dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; 
 // ----------------------------------------------------------------------------------------------
 struct SlEnv {
   int attn_fwd_st;         // SL_ATTN_FWD_ST       (default 1; 2 measured equal, profiles/r06_l_attn_fwd_st_ab.txt) head_dim-64 attention forward: 64-key tiles per staged block
+  int conv0_fold;          // SL_CONV0_FOLD        (default 1) conv0 backward of a batch: the block's four waves fold their sums through LDS and flush once, >= 4 strips per wave; 0 = a flush per wave of a 512-block grid (A/B)
+  int enc_wt_ahead;        // SL_ENC_WT_AHEAD      (default 1) encoder tape: the layers' transposed weights for the data-gradient products are made in one batched launch on a side stream beside the forward; 0 = a transpose in front of each product
   int decode_prefetch;     // SL_DECODE_PREFETCH   (default 0: measured 2.2 x SLOWER, profiles/r06_j_decode_prefetch_ab.txt) small-batch decode graphs with a weight-prefetch branch two matrices ahead of the chain (runtime.hip DecodePrefetch)
   int attn_bwd_kf;         // SL_ATTN_BWD_KF       (default 0 = by shape) 16-row fragments per wave in the attention-backward kernels: 1 / 2 force a form
   int tape_fuse;           // SL_TAPE_FUSE         (default 1) training tapes: dropout / GELU' / SwiGLU' / bias-gradient passes inside the GEMM and norm-backward kernels (0: the unfused launch sequence, A/B + parity tests)
@@ -269,6 +271,20 @@ const SlEnv& sl_env();
 // max(M, pinned rows of the calling thread).  A compacting generation pins the rows of the batch it STARTED with (sl_generate): the
 // live rows shrink, the arithmetic each row goes through does not change, so a sequence's bf16 ids cannot depend on when its
 // neighbours finish (tests/test_fullsize_gpu.py::test_configs1_compacted_batch_ids_equal_uncompacted_at_bench_stop_mix).
+// train_ops.hip: y (cols, ld_out) = x (rows, cols)^T for a list of matrices in one launch per SL_TRANSPOSE_BATCH records (sl_transpose_pad's
+// argument rules per record; tiles_r is filled by the launcher)
+#define SL_TRANSPOSE_BATCH 64
+struct SlTransposeRec {
+  const void* x; void* y;
+  int64_t ldx, ldy;
+  int32_t rows, cols, ld_out, tiles_r;
+};
+struct SlTransposeBatch {
+  SlTransposeRec rec[SL_TRANSPOSE_BATCH];
+  int32_t first_block[SL_TRANSPOSE_BATCH];
+  int32_t n, pad;
+};
+int sl_transpose_pad_batch_impl(const SlTransposeRec* recs, int n, int32_t dtype, sl_stream stream);
 bool sl_gemm_post_ok(int64_t M, int N, int K, int dtype);      // gemm.hip: a product of this shape may carry sl_gemm_ex_args.post_op / colsum_out
 int sl_family_rows(int rows);
 int sl_family_pin(int rows);      // returns the previous pin (0 = none)

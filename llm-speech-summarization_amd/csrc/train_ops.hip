@@ -83,10 +83,10 @@ __global__ __launch_bounds__(256) void attn_dropout_bwd_kernel(const T* __restri
 // gradient products (dY^T, X^T padded to whole K slabs) and of the data-gradient products (W^T).  64 x 64 tiles through LDS,
 // 16-byte global accesses on both sides.
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int cols,
-                                                            int ld_out) {
+__device__ __forceinline__ void transpose_pad_tile(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int cols, int ld_out,
+                                                   int tile_r, int tile_c) {
   constexpr int VEC = Vec16<T>::VEC, TS = 64;
-  const int r0 = blockIdx.x * TS, c0 = blockIdx.y * TS;
+  const int r0 = tile_r * TS, c0 = tile_c * TS;
   const int tid = threadIdx.x;
   constexpr int CPR = TS / VEC;                       // 16-byte chunks per 64-element row
   if constexpr (sizeof(T) == 2) {
@@ -171,6 +171,27 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict_
       }
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int cols,
+                                                            int ld_out) {
+  transpose_pad_tile<T>(x, ldx, y, ldy, rows, cols, ld_out, blockIdx.x, blockIdx.y);
+}
+
+// up to SL_TRANSPOSE_BATCH matrices in one launch (the records travel as a kernel argument): block b belongs to the record r with
+// first_block[r] <= b < first_block[r + 1].  The encoder tape turns every layer's four weight matrices for the data-gradient products this
+// way, once per window, beside the forward (train_tape.hip WtCache) — 96 launches of 5-8 us on the backward's critical path before.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_batch_kernel(SlTransposeBatch b) {
+  int r = 0;
+  const int blk = blockIdx.x;
+#pragma unroll 1
+  for (int step = SL_TRANSPOSE_BATCH / 2; step > 0; step >>= 1)
+    if (r + step < b.n && b.first_block[r + step] <= blk) r += step;
+  const SlTransposeRec& q = b.rec[r];
+  const int local = blk - b.first_block[r];
+  transpose_pad_tile<T>((const T*)q.x, q.ldx, (T*)q.y, q.ldy, q.rows, q.cols, q.ld_out, local % q.tiles_r, local / q.tiles_r);
 }
 
 // gu: (M, 2F) with blocks [16 gate | 16 up];  out/dy: (M, F)
@@ -919,6 +940,29 @@ struct Conv0Acc {
       abias[c] = 0.f; ag[c] = 0.f; ab[c] = 0.f;
     }
   }
+  static constexpr int NV = CPL * (K + 3);          // gradient sums per lane
+  template <typename F>
+  __device__ __forceinline__ void each(F&& f) {     // every sum with its (compile-time) index
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) f(aw[c][j], c * (K + 3) + j);
+      f(abias[c], c * (K + 3) + K);
+      f(ag[c], c * (K + 3) + K + 1);
+      f(ab[c], c * (K + 3) + K + 2);
+    }
+  }
+  // the four waves of a block folded into wave 0 through LDS (red: 2 x NV x 64 floats) in two rounds — (1 -> 0, 3 -> 2), then 2 -> 0 — so that a
+  // block ends in ONE set of atomics instead of four; every wave of the block must call it
+  __device__ __forceinline__ void fold_block(float* red, int wave, int lane) {
+    if (wave & 1) each([&](float& v, int i) { red[((wave >> 1) * NV + i) * 64 + lane] = v; });
+    __syncthreads();
+    if (!(wave & 1)) each([&](float& v, int i) { v += red[((wave >> 1) * NV + i) * 64 + lane]; });
+    __syncthreads();
+    if (wave == 2) each([&](float& v, int i) { red[i * 64 + lane] = v; });
+    __syncthreads();
+    if (wave == 0) each([&](float& v, int i) { v += red[i * 64 + lane]; });
+  }
   __device__ __forceinline__ void flush(float* dw, float* dbias, float* dgamma, float* dbeta, int lane) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -1005,19 +1049,22 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
 }
 
 // The whole ragged batch with a fixed number of waves: a wave walks (utterance, strip) pairs spref[u] + strip with a
-// stride of the grid and flushes its sums ONCE.  One launch per utterance had every wave end in 104 atomic instructions
-// on the same 6.6 k addresses after only 24 time steps (0.9 ms per 10 s clip, almost all of it atomic traffic).
+// stride of the grid; the four waves of a block fold their sums through LDS and the block flushes ONCE.  One launch per
+// utterance had every wave end in 104 atomic instructions on the same 6.6 k addresses after only 24 time steps (0.9 ms per
+// 10 s clip, almost all of it atomic traffic); a flush per WAVE of a 512-block grid was still 13.6 M atomics = ~1 ms whatever
+// the batch (1.08 ms for 2 utterances, 1.85 ms for 16: profiles/r06_kd_window{2,16}_ops_after.txt) — the launcher now also
+// gives every wave >= 4 strips before it widens the grid.
 template <typename T, int CPL, int K, int STRIDE>
 __global__ __launch_bounds__(256) void conv0_bwd_batch_kernel(const float* __restrict__ waves, const int64_t* __restrict__ soff,
                                                               const int64_t* __restrict__ row0, const int64_t* __restrict__ spref, int n_utt,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ dy,
                                                               float eps, float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+                                                              float* __restrict__ dbeta, int fold) {
+  __shared__ float red[2 * Conv0Acc<CPL, K>::NV * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave, n_waves = (int64_t)gridDim.x * 4;
   const int64_t total = spref[n_utt];
-  if (wave_id >= total) return;
   Conv0Acc<CPL, K> A;
   A.load(w, bias, gamma, beta, lane);
   for (int64_t gs = wave_id; gs < total; gs += n_waves) {
@@ -1029,7 +1076,8 @@ __global__ __launch_bounds__(256) void conv0_bwd_batch_kernel(const float* __res
     const int64_t s0 = soff[lo], r0 = row0[lo];
     conv0_bwd_strip<T, CPL, K, STRIDE>(A, waves + s0, soff[lo + 1] - s0, dy + r0 * (64 * CPL), row0[lo + 1] - r0, eps, gs - spref[lo], lane);
   }
-  A.flush(dw, dbias, dgamma, dbeta, lane);
+  if (fold) A.fold_block(red, wave, lane);                   // (uniform over the grid)
+  if (wave == 0 || (!fold && wave_id < total)) A.flush(dw, dbias, dgamma, dbeta, lane);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1090,6 +1138,31 @@ extern "C" int sl_attn_dropout_bwd(const void* p, void* p_dropped, float* d_p, i
                        dims, ld, cu_q, n_heads, n_kv_heads, r, scale, thr24, (uint64_t)seed);
   });
   SL_CHECK_LAUNCH("attn_dropout_bwd");
+  return 0;
+}
+
+// internal (train_tape.hip): every record checked like sl_transpose_pad's arguments; n may exceed SL_TRANSPOSE_BATCH (several launches)
+int sl_transpose_pad_batch_impl(const SlTransposeRec* recs, int n, int32_t dtype, sl_stream stream) {
+  SL_CHECK_ARG(recs && n > 0, "sl_transpose_pad_batch: bad arguments");
+  const int vec = dtype == SL_F32 ? 4 : 8;
+  for (int i0 = 0; i0 < n; i0 += SL_TRANSPOSE_BATCH) {
+    SlTransposeBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = n - i0 < SL_TRANSPOSE_BATCH ? n - i0 : SL_TRANSPOSE_BATCH;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      SlTransposeRec q = recs[i0 + i];
+      SL_CHECK_ARG(q.x && q.y && q.rows > 0 && q.cols > 0 && q.ld_out >= q.rows && q.ldy >= q.ld_out && q.ldx >= q.cols, "sl_transpose_pad_batch: bad shape (record %d)", i0 + i);
+      SL_CHECK_ARG(q.ldx % vec == 0 && q.ldy % vec == 0 && ((uintptr_t)q.x & 15) == 0 && ((uintptr_t)q.y & 15) == 0, "sl_transpose_pad_batch: rows must stay 16-byte aligned");
+      q.tiles_r = (int)ceil_div64(q.ld_out, 64);
+      b.rec[i] = q;
+      b.first_block[i] = blocks;
+      blocks += q.tiles_r * (int)ceil_div64(q.cols, 64);
+    }
+    for (int i = b.n; i < SL_TRANSPOSE_BATCH; ++i) b.first_block[i] = blocks;
+    SL_DISPATCH_DTYPE(dtype, T, { hipLaunchKernelGGL((transpose_pad_batch_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b); });
+    SL_CHECK_LAUNCH("transpose_pad_batch");
+  }
   return 0;
 }
 
@@ -1528,9 +1601,13 @@ template <typename T, int CPL>
 static int launch_conv0_bwd_batch(const float* waves, const int64_t* soff, const int64_t* row0, const int64_t* spref, int n_utt, int64_t total_strips,
                                   const float* w, const float* b, const float* g, const float* be, const void* dy, float eps, float* dw, float* db,
                                   float* dg, float* dbe, hipStream_t st) {
-  const int64_t blocks = ceil_div64(total_strips, 4);
-  hipLaunchKernelGGL((conv0_bwd_batch_kernel<T, CPL, 10, 5>), dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, st, waves, soff, row0, spref, n_utt,
-                     w, b, g, be, (const T*)dy, eps, dw, db, dg, dbe);
+  const int fold = sl_env().conv0_fold != 0;
+  // folded: >= 4 strips per wave (4 waves per block) before the grid widens, and at 512 channels (256 registers per lane: one block per CU is
+  // resident) no second round of blocks — each would only add a flush
+  const int64_t blocks = ceil_div64(total_strips, fold ? 16 : 4);
+  const int64_t cap = fold && CPL >= 8 ? 256 : 512;
+  hipLaunchKernelGGL((conv0_bwd_batch_kernel<T, CPL, 10, 5>), dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, st, waves, soff, row0, spref, n_utt,
+                     w, b, g, be, (const T*)dy, eps, dw, db, dg, dbe, fold);
   SL_CHECK_LAUNCH("conv0_bwd_batch");
   return 0;
 }

@@ -232,7 +232,40 @@ struct EncWs {
   void* sk;            // split-K workspace of the few-tile products of a short window (main-stream products only)
   void* sk_w;          // ... of the parameter-gradient group's stream (the side stream of a long window, else the caller's)
   BwdScratch s;
+  // every layer's transposed weights for the data-gradient products, [layer][w2^T (F, H) | w1^T (H, F) | wo^T (H, H) | wqkv^T (H, 3 H)]: written by
+  // the FORWARD call (one batched launch on a side stream), read by the backward calls on the same workspace (WtCache below)
+  unsigned char* wt_all;
+  size_t wt_layer_bytes;
+  const void* wt(int l, int which, int64_t H, int64_t F, size_t sz) const {
+    const size_t off[4] = {0, (size_t)(F * H) * sz, (size_t)(2 * F * H) * sz, (size_t)(2 * F * H + H * H) * sz};
+    return wt_all + (size_t)l * wt_layer_bytes + off[which];
+  }
 };
+
+// Which workspace holds current transposed weights, per thread and device: set by sl_encoder_stack_train_fwd, honoured by
+// sl_encoder_stack_train_bwd only for the same (workspace, layer table, shape) — any other backward makes its own transposes as before.
+struct WtCache {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr;
+  const void* ws = nullptr;
+  const void* layers = nullptr;
+  int n_layers = 0, H = 0, F = 0, dt = -1;
+  bool valid = false, waited = false;
+};
+static int wt_cache(WtCache*& out) {
+  int dev = 0;
+  SL_HIP(hipGetDevice(&dev));
+  SL_CHECK_ARG(dev >= 0 && dev < SL_MAX_DEVICES, "device %d out of range", dev);
+  static thread_local WtCache per[SL_MAX_DEVICES];
+  WtCache& c = per[dev];
+  if (!c.s) {
+    SL_HIP(hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking));
+    SL_HIP(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+    SL_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  }
+  out = &c;
+  return 0;
+}
 
 static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs& w) {
   const size_t sz = sl_dtype_size(c->dtype);
@@ -260,6 +293,9 @@ static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs
   // are 64 tiles on 256 CUs, and everything runs on one stream (SideStream::init), so one workspace serves the whole call
   w.sk = n < 2048 ? cv.take(sl_gemm_streamk_workspace_bytes()) : nullptr;
   w.sk_w = n < 2048 ? w.sk : cv.take(sl_gemm_streamk_workspace_bytes());    // long window: the weight gradients run on their own stream, with their own workspace
+  const int vec = c->dtype == SL_F32 ? 4 : 8;
+  w.wt_layer_bytes = (H % vec == 0 && F % vec == 0) ? (size_t)(2 * F * H + 4 * H * H) * sz : 0;
+  w.wt_all = w.wt_layer_bytes ? (unsigned char*)cv.take(w.wt_layer_bytes * (size_t)c->n_layers) : nullptr;
   return cv.off + 256;
 }
 
@@ -279,6 +315,36 @@ extern "C" int sl_encoder_stack_train_fwd(const sl_hubert_layer* layers, const s
   const int64_t n = c->n_tok;
   const void* x = x_in;
   if (w.sk) SL_HIP(hipMemsetAsync(w.sk, 0, 1024, st));      // stream-K flags: zero whenever no launch is in flight
+  {
+    // the backward's W^T copies, off its critical path: one batched launch beside this forward (the weights are final — the optimizer step
+    // that wrote them is earlier on `stream`)
+    WtCache* wc = nullptr;
+    SL_TRY(wt_cache(wc));
+    wc->valid = false;
+    if (w.wt_all && sl_env().enc_wt_ahead) {
+      std::vector<SlTransposeRec> recs;
+      const size_t sz = sl_dtype_size(dt);
+      for (int l = 0; l < c->n_layers; ++l) {
+        if (c->skip[l]) continue;
+        const sl_hubert_layer& L = layers[l];
+        const void* src[4] = {L.w2, L.w1, L.wo, L.wqkv};
+        const int n_out[4] = {H, F, H, 3 * H}, k_in[4] = {F, H, H, H};
+        for (int k = 0; k < 4; ++k) {
+          SlTransposeRec q;
+          q.x = src[k]; q.y = (void*)w.wt(l, k, H, F, sz); q.ldx = k_in[k]; q.ldy = n_out[k]; q.rows = n_out[k]; q.cols = k_in[k]; q.ld_out = n_out[k]; q.tiles_r = 0;
+          recs.push_back(q);
+        }
+      }
+      if (!recs.empty()) {
+        SL_HIP(hipEventRecord(wc->fork, st));
+        SL_HIP(hipStreamWaitEvent(wc->s, wc->fork, 0));
+        SL_TRY(sl_transpose_pad_batch_impl(recs.data(), (int)recs.size(), dt, (sl_stream)wc->s));
+        SL_HIP(hipEventRecord(wc->done, wc->s));
+        wc->ws = workspace; wc->layers = layers; wc->n_layers = c->n_layers; wc->H = H; wc->F = F; wc->dt = dt;
+        wc->valid = true; wc->waited = false;
+      }
+    }
+  }
   for (int l = 0; l < c->n_layers; ++l) {
     sl_enc_layer_saved& sv = saved[l];
     sv.x = x;
@@ -347,6 +413,16 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   // above's) wrote it as its second output, so this layer starts without an sl_dropout launch and without re-reading dx
   bool have_drop = false;
   const bool fuse = fuse_ok(n, dt, H, F);
+  // transposed weights made beside the forward on this workspace (WtCache): wait for that launch once, then no transposes in this call
+  WtCache* wc = nullptr;
+  SL_TRY(wt_cache(wc));
+  const bool wt_ahead = w.wt_all && wc->valid && wc->ws == workspace && wc->layers == (const void*)layers && wc->n_layers == c->n_layers && wc->H == H &&
+                        wc->F == F && wc->dt == dt;
+  if (wt_ahead && !wc->waited) {
+    SL_HIP(hipStreamWaitEvent(st, wc->done, 0));
+    wc->waited = true;
+  }
+  auto WT = [&](int l, int which) -> const void* { return wt_ahead ? w.wt(l, which, H, F, sz) : nullptr; };
   int par = 0;                   // which copy of the group-read buffers this layer uses (alternates over the layers visited)
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     if (c->skip[l]) continue;
@@ -370,9 +446,9 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
       // d_pre1 = gelu'(pre1) * drop_act(d_o2 . w2) and b1 += colsum(d_pre1), all in the data-gradient product's epilogue
       Post pg;
       pg.op = SL_POST_GELU_BWD; pg.p = c->p_act; pg.seed = sd[2]; pg.ld = F; pg.in = sv.pre1; pg.in_ld = F; pg.colsum = g.b1;
-      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, d_pre1, F, n, w.s, st, nullptr, &pg));
+      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, WT(l, 0), d_pre1, F, n, w.s, st, nullptr, &pg));
     } else {
-      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, nullptr, w.d_mid, F, n, w.s, st));
+      SL_TRY(dgrad(dt, d_o2, H, L.w2, H, F, WT(l, 0), w.d_mid, F, n, w.s, st));
       if (c->p_act > 0.f) SL_TRY(sl_dropout(w.d_mid, nullptr, w.d_mid, n * F, c->p_act, sd[2], dt, stream));
       SL_TRY(sl_gelu_bwd(w.d_mid, sv.pre1, d_pre1, n * F, dt, stream));
     }
@@ -382,7 +458,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, d_pre1, F, F, sv.ln2, H, H, g.w1, n, w.s, sw, sk_w, fuse ? nullptr : g.b1));      // (fused: b1 came out of the data-gradient epilogue above)
     if (c->p_hidden <= 0.f) SL_TRY(ss.end(2));             // (group A reads dx itself then: it must be through before dx is rewritten below)
     int32_t S1 = 0, S2 = 0;      // K runs left in `sk` for the LayerNorm backward behind the product (0: d_h1 was written as usual)
-    SL_TRY(dgrad(dt, d_pre1, F, L.w1, F, H, nullptr, w.d_h1, H, n, w.s, st, sk, nullptr, &S1));
+    SL_TRY(dgrad(dt, d_pre1, F, L.w1, F, H, WT(l, 1), w.d_h1, H, n, w.s, st, sk, nullptr, &S1));
     // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass — and dropout(d_h2), the out-projection's incoming gradient
     const bool drop1 = c->p_hidden > 0.f && fuse;
     SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
@@ -393,7 +469,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
       if (!drop1) SL_TRY(sl_dropout(d_h2, nullptr, tmp_h2, n * H, c->p_hidden, sd[1], dt, stream));
       d_o1 = tmp_h2;
     }
-    SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, nullptr, w.d_att, H, n, w.s, st));
+    SL_TRY(dgrad(dt, d_o1, H, L.wo, H, H, WT(l, 2), w.d_att, H, n, w.s, st));
     SL_TRY(attn_bwd(dt, sv.qkv, 3 * H, sv.att, w.d_att, sv.lse, w.delta, d_qkv, c->cu, c->klen, c->nseq, c->max_len, n, nh, nh, 64, 0, 0.125f,
                     c->p_attn, sd[0], st));
     // group B (one fork): the two attention parameter gradients; its completion event covers group A too (the side stream is in order)
@@ -401,7 +477,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     SL_TRY(wgrad_acc(dt, d_o1, H, H, sv.att, H, H, g.wo, n, w.s, sw, sk_w, g.bo));
     SL_TRY(wgrad_acc(dt, d_qkv, 3 * H, 3 * H, sv.ln1, H, H, g.wqkv, n, w.s, sw, sk_w, g.bqkv));
     SL_TRY(ss.end(par));
-    SL_TRY(dgrad(dt, d_qkv, 3 * H, L.wqkv, 3 * H, H, nullptr, w.d_h1, H, n, w.s, st, sk, nullptr, &S2));
+    SL_TRY(dgrad(dt, d_qkv, 3 * H, L.wqkv, 3 * H, H, WT(l, 3), w.d_h1, H, n, w.s, st, sk, nullptr, &S2));
     // The one wait of the layer: the PREVIOUS visited layer's groups (the other copy of the buffers) must be through before this layer's last
     // kernel writes that copy's tmp_h (the dropped gradient of the next layer down) — and with them everything older, so the next layer may
     // overwrite its own copy freely.  p_hidden = 0: group A read dx, which is rewritten here.
@@ -416,7 +492,6 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
                                         have_drop ? w.tmp_h[1 - par] : nullptr, c->p_hidden, have_drop ? c->seeds[4 * (size_t)below + 3] : 0,
                                         S2 ? (const float*)((const unsigned char*)sk + 1024) : nullptr, S2));
     par ^= 1;
-    (void)sz;
   }
   for (int k = 0; k < 4; ++k) SL_TRY(ss.join(k));          // the caller's stream owns the gradients again
   return 0;
