@@ -571,12 +571,25 @@ def test_parameter_gradient_side_stream_equals_single_stream(monkeypatch):
 
 
 @pytest.mark.parametrize("B", [16, 2])      # a 16-sample window (>= 2 048 frames: parameter gradients on the side stream) and the per-rank share of an 8-rank step
+def test_weights_transposed_beside_the_forward_give_the_bits_of_a_transpose_per_product(monkeypatch, B):
+    """The encoder tape's forward call turns every layer's four weight matrices for the data-gradient products in ONE batched launch on a side
+    stream (train_tape.hip WtCache, sl_transpose_pad_batch_impl) and the backward calls on the same workspace read those copies; with
+    SL_ENC_WT_AHEAD=0 each product makes its own transpose first, as before.  The copies are exact, so every gradient keeps its bits."""
+    _window_bits_equal_under_switch(monkeypatch, B, "SL_ENC_WT_AHEAD")
+
+
+@pytest.mark.parametrize("B", [16, 2])      # a 16-sample window (>= 2 048 frames: parameter gradients on the side stream) and the per-rank share of an 8-rank step
 def test_fused_tape_epilogues_give_the_bits_of_the_unfused_launch_sequence(monkeypatch, B):
     """Round 6: the KD tapes run dropout (forward and backward), GELU', SwiGLU', the b1 bias gradient and the feature-distillation adds inside
     the GEMM epilogues / norm-backward kernels (sl_gemm_ex_args.post_op, train_tape.hip) instead of as launches of their own.  Every fused
     form reproduces the roundings of the sequence it replaces, so with the training-mode regularisers ON (dropouts, LayerDrop,
     SpecAugment — ref:trainer.py:258) the losses and every weight gradient equal those of SL_TAPE_FUSE=0 bit for bit; bias gradients
     (float atomics either way) to their usual last-bit movement."""
+    _window_bits_equal_under_switch(monkeypatch, B, "SL_TAPE_FUSE")
+
+
+def _window_bits_equal_under_switch(monkeypatch, B, switch):
+    """One KD window with the regularisers on, default build against `switch`=0 (re-read through sl_tuning_reload)."""
     from oracle.golden_cfgs import WIDE_HUBERT, WIDE_LLAMA
     L_ = pkg("_lib")
     HC, LC = WIDE_HUBERT, WIDE_LLAMA
@@ -602,7 +615,7 @@ def test_fused_tape_epilogues_give_the_bits_of_the_unfused_launch_sequence(monke
         return tr, tr.enc_tape.arena.flat.clone(), losses
 
     tr, fused, l_f = window()
-    monkeypatch.setenv("SL_TAPE_FUSE", "0")
+    monkeypatch.setenv(switch, "0")
     L_.lib().sl_tuning_reload()
     try:
         _, plain, l_p = window()
