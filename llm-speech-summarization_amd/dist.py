@@ -202,6 +202,9 @@ class BucketedAllReduce:
         self._pending = []
         self.cuda = arena.flat.is_cuda
         self.stream = torch.cuda.Stream(device=arena.flat.device) if (self.cuda and self.world > 1) else None
+        # called as after_bucket(upto) behind every bucket launched on `stream` (GPU runs only): KDTrainer chains the AdamW of the summed
+        # prefix there while the backward produces the next bucket
+        self.after_bucket = None
         self.bucket_log: List[tuple] = []     # (start, end) element ranges of the buckets launched so far in this step
         self.last_buckets: List[tuple] = []   # ... of the previous optimizer step
         # exchange timing (events on the side stream around every bucket, read back in finish()): what bench.py's kd_step.comm reports
@@ -369,6 +372,12 @@ class BucketedAllReduce:
             if timed:
                 t1.record(self.stream)
                 self._ev.append((t0, t1))
+            if self.after_bucket is not None:
+                if work is not None:
+                    with torch.cuda.stream(self.stream):
+                        work.wait()                            # stream-ordered: the hook may chain work on self.stream's tail
+                    work = None
+                self.after_bucket(upto)                        # the arena below `upto` is summed once self.stream reaches this point
         else:
             work = self.dist.all_reduce(chunk, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append(work)

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -789,46 +790,63 @@ class FusedAdamW:
             raise L.SpeechLLMError("FusedAdamW covers plain AdamW (one param group, amsgrad / maximize off)")
         lib = L.lib()
         self._blocks = [int(lib.sl_adamw_blocks(p.numel())) for _, p in self.named]
+        self._cache = {}                        # record tables of the `only` sets of step(), by name tuple
 
-    def step(self) -> None:
+    def step(self, only=None) -> None:
+        """only: a set of parameter names — the step of just those (KDTrainer._early_step); launched on the CURRENT stream.  The record
+        table of an `only` set is built and uploaded once and reused (masters, moments, arena gradients and the kernels' weight copies
+        keep their addresses; `invalidate()` after anything that replaces them, e.g. loading an optimizer checkpoint)."""
         g = self.opt.param_groups[0]
         lib = L.lib()
-        live = [(k, p, nb) for (k, p), nb in zip(self.named, self._blocks) if p.grad is not None]
-        if not live:
-            return
-        dev = live[0][1].device
-        table = (L.AdamWTensor * len(live))()
-        first = np.zeros(len(live), dtype=np.int64)
-        steps, total, t_now = [], 0, None
-        for i, (k, p, nb) in enumerate(live):
-            st = self.opt.state[p]
-            if len(st) == 0:                     # torch creates the state on a parameter's first step
-                st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            t_i = int(st["step"]) + 1
-            if t_now is None:
-                t_now = t_i
-            elif t_i != t_now:
-                raise L.SpeechLLMError("FusedAdamW: parameters disagree on the step count")
-            grad = p.grad
-            if not (grad.is_contiguous() and grad.dtype == torch.float32 and p.dtype == torch.float32 and p.is_contiguous()):
-                raise L.SpeechLLMError(f"FusedAdamW: parameter {k} / its gradient must be contiguous fp32")
-            rec = table[i]
-            rec.p, rec.g, rec.m, rec.v, rec.n = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-            d = self.dst_of.get(k)
-            if d is not None:
-                rec.dst, rec.dst_dtype = d[0].data_ptr() + d[1] * d[0].element_size(), L.dtype_code(d[0].dtype)
-            first[i] = total
-            total += nb
-            steps.append(st["step"])
-        t_dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
-        f_dev = torch.from_numpy(first).to(dev)
-        L.check(lib.sl_adamw_step(t_dev.data_ptr(), f_dev.data_ptr(), len(live), total, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+        ckey = None if only is None else (only if isinstance(only, tuple) else tuple(sorted(only)))
+        hit = self._cache.get(ckey) if ckey is not None else None
+        if hit is not None:
+            t_dev, f_dev, n_live, total, steps = hit
+            t_now = int(steps[0]) + 1
+        else:
+            live = [(k, p, nb) for (k, p), nb in zip(self.named, self._blocks) if p.grad is not None and (only is None or k in only)]
+            if not live:
+                return
+            dev = live[0][1].device
+            table = (L.AdamWTensor * len(live))()
+            first = np.zeros(len(live), dtype=np.int64)
+            steps, total, t_now = [], 0, None
+            for i, (k, p, nb) in enumerate(live):
+                st = self.opt.state[p]
+                if len(st) == 0:                     # torch creates the state on a parameter's first step
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                t_i = int(st["step"]) + 1
+                if t_now is None:
+                    t_now = t_i
+                elif t_i != t_now:
+                    raise L.SpeechLLMError("FusedAdamW: parameters disagree on the step count")
+                grad = p.grad
+                if not (grad.is_contiguous() and grad.dtype == torch.float32 and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise L.SpeechLLMError(f"FusedAdamW: parameter {k} / its gradient must be contiguous fp32")
+                rec = table[i]
+                rec.p, rec.g, rec.m, rec.v, rec.n = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                d = self.dst_of.get(k)
+                if d is not None:
+                    rec.dst, rec.dst_dtype = d[0].data_ptr() + d[1] * d[0].element_size(), L.dtype_code(d[0].dtype)
+                first[i] = total
+                total += nb
+                steps.append(st["step"])
+            # (pinned, asynchronous: a pageable upload here made the host wait for the whole backward before it could queue the step)
+            t_dev = L.h2d(torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8), torch.uint8, dev)
+            f_dev = L.h2d(torch.from_numpy(first), torch.int64, dev)
+            n_live = len(live)
+            if ckey is not None:
+                self._cache[ckey] = (t_dev, f_dev, n_live, total, steps)
+        L.check(lib.sl_adamw_step(t_dev.data_ptr(), f_dev.data_ptr(), n_live, total, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                   float(g["eps"]), float(g["weight_decay"]), t_now, L.stream_ptr()), "sl_adamw_step")
         torch._foreach_add_(steps, 1.0)
-        self._keep = (t_dev, f_dev)             # alive until the launch has consumed them
+        self._keep = getattr(self, "_keep", [])[-15:] + [(t_dev, f_dev)]      # alive until the launches have consumed them
         self.opt._opt_called = True             # what lr_scheduler's order check looks at (it wraps optimizer.step to set it)
+
+    def invalidate(self) -> None:
+        self._cache.clear()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -858,7 +876,8 @@ class KDTrainer:
     summed with an all-reduce of the fp32 buckets on a side stream while the rest of the backward still runs."""
 
     def __init__(self, config, encoder: AudioEncoder, llm: AudioLlamaForCausalLM, prefix_ids: torch.Tensor, suffix_ids: torch.Tensor,
-                 total_optimizer_steps: int = 1000, process_group=None, regularizers: Optional[TrainRegularizers] = None):
+                 total_optimizer_steps: int = 1000, process_group=None, regularizers: Optional[TrainRegularizers] = None,
+                 overlap_optimizer: Optional[bool] = None):
         tr = config.train
         self.enc, self.llm = encoder, llm
         self.ntp_w, self.ld_w, self.fd_w = tr.ntp_loss_weight, tr.ld_loss_weight, tr.fd_loss_weight
@@ -907,6 +926,113 @@ class KDTrainer:
         self.use_fused_adamw = True
         self._fused: Optional[FusedAdamW] = None
         self._fused_indirect = None
+        # AdamW of the gradient buckets that are already final (and, under data parallel, summed) while the rest of the backward still runs
+        # (_early_step).  OFF by default — measured: per-rank window 32.0 vs 31.4 ms, 16-sample window 89.1 vs 89.1 ms
+        # (profiles/r06_ac_overlap_optimizer_ab.txt): the step's 1.6 ms of HBM-bound blocks take the CUs from the backward's small kernels for
+        # as long as they save at the end.  `train.overlap_optimizer: true` / overlap_optimizer=True turn it on (SL_KD_OVERLAP_OPT=0 overrides).
+        self.overlap_optimizer = bool(getattr(tr, "overlap_optimizer", False)) if overlap_optimizer is None else bool(overlap_optimizer)
+        self._opt_stream = None
+        self._early_plan_ = None
+        self._early_names = {}
+        self.early_min_bytes = 64 << 20            # a prefix of the arena steps early once this much of it has become final since the last early step
+        self.early_launches = 0                    # early AdamW launches so far (tests, bench)
+        self._early_reset()
+        if self.reducer is not None:
+            self.reducer.after_bucket = self._early_after_bucket
+
+    # -- the optimizer step of finished gradient buckets, beside the rest of the backward -----------------------------------
+    # (Opt-in, see __init__.)  AdamW is element-wise: a parameter's update needs its own (final) gradient only.  The arena is laid out in the order the backward
+    # finishes its buffers (projector, layer N-1 .. 0, ...), so once a prefix of it is final its parameters can step — 1.6 ms of HBM-bound
+    # work per window (30 B per parameter) that otherwise sits between the last backward kernel and the next forward.  Bit-identical to the
+    # step behind the backward (same kernel, same hyper-parameters; the scheduler moves after the whole step).  Only parameters whose
+    # state-dict gradient IS a slice of the arena take part (the transformer layers, the projector: 95 % of HuBERT-large); the re-laid-out
+    # ones (conv taps, weight-norm) step at the end as before.
+    def _early_reset(self) -> None:
+        self._early_armed = False
+        self._early_next = 0
+        self._early_done = set()
+        self._early_final = None
+        self._early_n_final = 0
+        self._early_upto = 0
+
+    def _early_plan(self):
+        """[(name, arena offset, elements)] by offset, of the parameters whose gradient is a contiguous slice of the arena."""
+        if self._early_plan_ is None:
+            flat = self.enc_tape.arena.flat
+            sd = self.to_state_dict(self.enc, self.grads, self.master)
+            base, store = flat.data_ptr(), flat.untyped_storage().data_ptr()
+            plan = []
+            for k in self.trainable:
+                g = sd[k]
+                if g.is_contiguous() and g.dtype == torch.float32 and g.untyped_storage().data_ptr() == store and g.numel() == self._param[k].numel():
+                    plan.append((k, (g.data_ptr() - base) // 4, g.numel()))
+            self._early_plan_ = sorted(plan, key=lambda r: r[1])
+        return self._early_plan_
+
+    def _early_step(self, upto: int, after_stream=None) -> None:
+        """AdamW, on the optimizer's own stream, of every planned parameter not yet stepped whose gradient ends at or below arena offset `upto`;
+        ordered behind `after_stream` (default: the current stream) at the time of the call."""
+        fused = self._fused_optimizer() if self.use_fused_adamw else None
+        if fused is None:
+            return
+        plan, i0 = self._early_plan(), self._early_next
+        while self._early_next < len(plan) and plan[self._early_next][1] + plan[self._early_next][2] <= upto:
+            self._early_next += 1
+        i1 = self._early_next
+        if i1 == i0:
+            return
+        names = self._early_names.get((i0, i1))          # the same chunks every window: their record tables are built once (FusedAdamW.step)
+        if names is None:
+            names = self._early_names[(i0, i1)] = tuple(sorted(k for k, _, _ in plan[i0:i1]))
+        flat = self.enc_tape.arena.flat
+        if names not in fused._cache:
+            for k, off, n in plan[i0:i1]:
+                p = self._param[k]
+                p.grad = flat[off:off + n].view(p.shape)
+        if self._opt_stream is None:
+            self._opt_stream = self._make_opt_stream(flat.device)
+        ev = torch.cuda.Event()
+        ev.record(after_stream if after_stream is not None else torch.cuda.current_stream())
+        self._opt_stream.wait_event(ev)
+        with torch.cuda.stream(self._opt_stream):
+            fused.step(only=names)
+        self._early_done.update(names)
+        self.early_launches += 1
+
+    @staticmethod
+    def _make_opt_stream(device):
+        """The early steps' stream.  SL_KD_OPT_CUS=n (default 0: no mask) confines it to n CUs of every XCD (hipExtStreamCreateWithCUMask): the
+        step's HBM-bound blocks then trickle beside the backward instead of taking every CU from its small kernels."""
+        n = int(os.environ.get("SL_KD_OPT_CUS", "0") or 0)
+        if n <= 0 or n >= 32:
+            return torch.cuda.Stream(device=device)
+        hip = C.CDLL("libamdhip64.so")
+        words = (C.c_uint32 * 8)(*([(1 << n) - 1] * 8))           # bit 32 x + c = CU c of XCD x
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, words)
+        if rc != 0:
+            raise L.SpeechLLMError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        return torch.cuda.ExternalStream(h.value, device=device)
+
+    def _early_ready(self, names) -> None:
+        """on_bucket callback of the backward without a reducer: the same final-prefix bookkeeping as BucketedAllReduce.ready."""
+        arena = self.enc_tape.arena
+        if self._early_final is None:
+            self._early_final = [False] * len(arena.order)
+        for n in names:
+            self._early_final[arena.index[n]] = True
+        while self._early_n_final < len(self._early_final) and self._early_final[self._early_n_final]:
+            self._early_n_final += 1
+        upto = arena.end_offset(self._early_n_final - 1) if self._early_n_final > 0 else 0
+        if (upto - self._early_upto) * 4 >= self.early_min_bytes:
+            self._early_upto = upto
+            self._early_step(upto)
+
+    def _early_after_bucket(self, upto: int) -> None:
+        """BucketedAllReduce.after_bucket: the arena below `upto` has been summed over the ranks on the reducer's stream."""
+        if self._early_armed and self.reducer is not None and self.reducer.stream is not None:
+            self._early_step(upto, after_stream=self.reducer.stream)
 
     def _fused_optimizer(self) -> Optional["FusedAdamW"]:
         if self._fused is None:
@@ -1036,7 +1162,12 @@ class KDTrainer:
         ops.kd_logit_losses(logits_a, logits_t, labels, row_coef, row_slot, losses, d_logits, dt)
         d_seq = self.llm_tape.backward(ltape, tail, d_logits, d_hidden, n_seq=B if merged else None)
         d_audio = torch.cat([d_seq[aoff[u] + n_pre: aoff[u] + n_pre + (poff[u + 1] - poff[u])] for u in range(B)], 0).contiguous()
-        self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=self.reducer.ready if early_buckets else None)
+        # (an instance whose optimizer_step was replaced — gradient inspection in the tests — never steps early)
+        sw = os.environ.get("SL_KD_OVERLAP_OPT", "")                  # "1" / "0" override the trainer's setting (A/B runs)
+        self._early_armed = ((sw == "1" or (self.overlap_optimizer and sw != "0")) and last and close_window is None and self.use_fused_adamw and
+                             d_audio.is_cuda and "optimizer_step" not in self.__dict__)
+        on_bucket = self.reducer.ready if early_buckets else (self._early_ready if self._early_armed and self.reducer is None else None)
+        self.enc_tape.backward(etape, d_audio, self.grads, on_bucket=on_bucket)
         self.micro += B
         self.micro_total += B
         self.last_d_audio = d_audio
@@ -1080,11 +1211,14 @@ class KDTrainer:
     def optimizer_step(self) -> None:
         if self.reducer is not None:
             self.reducer.finish()                  # in place on the arena: nothing to scatter back
+        early = self._early_done
+        if early:                                  # their AdamW ran beside the backward (_early_step): this stream owns weights and gradients again
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
         sd_grads = self.to_state_dict(self.enc, self.grads, self.master)
-        for k, p in zip(self.trainable, self.params):
-            p.grad = sd_grads[k].reshape(p.shape)  # views of the arena wherever kernel and state-dict layouts coincide
         if self.keep_last_grads:                   # tests / debugging only: a 1.27 GB clone per step otherwise
-            self.last_grads = {k: p.grad.clone() for k, p in zip(self.trainable, self.params)}
+            self.last_grads = {k: sd_grads[k].reshape(p.shape).clone() for k, p in zip(self.trainable, self.params)}
+        for k, p in zip(self.trainable, self.params):
+            p.grad = None if k in early else sd_grads[k].reshape(p.shape)  # views of the arena wherever kernel and state-dict layouts coincide
         fused = self._fused_optimizer() if self.use_fused_adamw else None
         if fused is not None:
             fused.step()                           # p, m, v and the kernels' copy of p: one pass over 30 B per parameter
@@ -1099,6 +1233,7 @@ class KDTrainer:
             self.enc.refresh_weights(self.master)  # compute-dtype kernel weights follow the fp32 master, in place
         self.optimizer_steps += 1
         self.micro = 0
+        self._early_reset()
 
     # -- optimizer state in the reference's checkpoint layout ------------------------------------------
     def _n_llm_params(self) -> int:
@@ -1127,6 +1262,8 @@ class KDTrainer:
         g0["params"] = list(range(n_enc))
         state = {int(i): v for i, v in sd["state"].items() if int(i) < n_enc}
         self.optimizer.load_state_dict({"state": state, "param_groups": [g0]})
+        if self._fused is not None:
+            self._fused.invalidate()              # the moments were replaced: cached record tables point at the old ones
         dev = self.enc.device
         for st in self.optimizer.state.values():          # ref:trainer.py:124-130 moves the state to the GPU by hand
             for k, v in st.items():

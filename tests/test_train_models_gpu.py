@@ -570,6 +570,61 @@ def test_parameter_gradient_side_stream_equals_single_stream(monkeypatch):
     assert fixed >= 4 * HC.num_hidden_layers
 
 
+def test_optimizer_step_overlapped_with_the_backward_equals_the_step_behind_it():
+    """KDTrainer steps the parameters of every gradient bucket that is already final (arena prefix: projector, layer N-1, ...) on its own
+    stream while the backward still runs (_early_step, opt-in); the rest steps at the end.  AdamW is element-wise, so after ONE window the
+    masters, moments and step counts of the layers' weights equal those of `overlap_optimizer=False` bit for bit (bias / conv gradients are
+    float-atomic sums whose last bits move from run to run — after a second window everything has seen them, so that one is compared
+    to a tolerance)."""
+    from oracle.golden_cfgs import WIDE_HUBERT, WIDE_LLAMA
+    HC, LC = WIDE_HUBERT, WIDE_LLAMA
+    llm, _ = make_llama(LC, 94, torch.bfloat16, max_ctx=512)
+    prefix, suffix = ri.synthetic_ids(9, LC.vocab_size, seed=7, bos=128000), ri.synthetic_ids(6, LC.vocab_size, seed=8, bos=128000)
+    gen = torch.Generator().manual_seed(55)
+    B = 4
+    waves = [ri.synthetic_waveform(70000 + 6000 * u, seed=910 + u).to(DEV) for u in range(B)]
+    texts = [torch.randint(1, LC.vocab_size, (30 + u,), generator=gen) for u in range(B)]
+    resps = [torch.randint(1, LC.vocab_size, (40 + 2 * u,), generator=gen) for u in range(B)]
+
+    def run(overlap):
+        enc, _ = make_encoder(HC, LC.hidden_size, 93, torch.bfloat16)
+        tr = training.KDTrainer(kd_config(taps=(0, 1, 2), accum=B), enc, llm, prefix, suffix, overlap_optimizer=overlap)
+        tr.early_min_bytes = 0                      # every on_bucket call may step (the default waits for 64 MB of final gradients)
+        tr.micro_batch(waves, texts, resps)
+        torch.cuda.synchronize()
+        state = {k: {n: v.clone() for n, v in tr.optimizer.state[tr._param[k]].items()} for k in tr.trainable}
+        masters = {k: v.clone() for k, v in tr.master.items()}
+        tr.micro_batch(waves, texts, resps)            # a second window: cached record tables, the reset of the early bookkeeping
+        torch.cuda.synchronize()
+        out = tr.enc(waves[0][None]).clone()
+        return tr, masters, state, out, {k: v.clone() for k, v in tr.master.items()}
+
+    tr_o, m_o, s_o, out_o, m2_o = run(True)
+    tr_p, m_p, s_p, out_p, m2_p = run(False)
+    assert tr_o.early_launches >= 4 and tr_p.early_launches == 0 and tr_o.optimizer_steps == tr_p.optimizer_steps == 2
+    for k in m2_o:
+        assert float((m2_o[k] - m2_p[k]).abs().max()) <= 2.5e-4, k
+    plan = tr_o._early_plan()
+    assert sum(n for _, _, n in plan) > 0.9 * sum(tr_o._param[k].numel() for k in tr_o.trainable if ".layers." in k)      # the layers step early
+    exact = lambda k: ".layers." in k and k.endswith(".weight")      # (bias / conv gradients are float-atomic sums: their last bits move from run to run)
+    n_exact = 0
+    for k in m_o:
+        if exact(k):
+            assert torch.equal(m_o[k], m_p[k]), k
+            n_exact += 1
+        else:
+            assert float((m_o[k] - m_p[k]).abs().max()) <= 2.5e-4, k      # (AdamW's g / (|g| + eps): an element whose gradient is ~0 may move by up to lr per step either way)
+    assert n_exact >= 8 * HC.num_hidden_layers
+    for k in s_o:
+        for n in s_o[k]:
+            a, b = s_o[k][n].float().cpu(), s_p[k][n].float().cpu()
+            if exact(k):
+                assert torch.equal(a, b), (k, n)
+            else:
+                assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, (k, n)
+    assert float((out_o.float() - out_p.float()).abs().max()) <= 2e-2 * float(out_p.float().abs().max())
+
+
 @pytest.mark.parametrize("B", [16, 2])      # a 16-sample window (>= 2 048 frames: parameter gradients on the side stream) and the per-rank share of an 8-rank step
 def test_weights_transposed_beside_the_forward_give_the_bits_of_a_transpose_per_product(monkeypatch, B):
     """The encoder tape's forward call turns every layer's four weight matrices for the data-gradient products in ONE batched launch on a side
