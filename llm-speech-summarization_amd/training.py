@@ -937,7 +937,7 @@ class KDTrainer:
         self.early_min_bytes = 64 << 20            # a prefix of the arena steps early once this much of it has become final since the last early step
         self.early_launches = 0                    # early AdamW launches so far (tests, bench)
         self._early_reset()
-        if self.reducer is not None:
+        if self.reducer is not None and self.overlap_optimizer:      # (the default exchange path stays exactly as it was: no hook, no extra stream waits)
             self.reducer.after_bucket = self._early_after_bucket
 
     # -- the optimizer step of finished gradient buckets, beside the rest of the backward -----------------------------------
