@@ -55,6 +55,7 @@ static const SlEnv* env_load() {
   e.attn_fwd_st = env_int("SL_ATTN_FWD_ST", 1);
   e.conv0_fold = env_int("SL_CONV0_FOLD", 1);
   e.enc_wt_ahead = env_int("SL_ENC_WT_AHEAD", 1);
+  e.rms_bwd_lean = env_int("SL_RMSBWD_LEAN", 2);
   e.stream_min_m = env_int("SL_STREAM_MIN_M", 26);
   if (e.stream_min_m < 16) e.stream_min_m = 26;
   e.disable_t256 = getenv("SL_DISABLE_T256") != nullptr;

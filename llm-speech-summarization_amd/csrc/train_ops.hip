@@ -359,6 +359,19 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block) < rows ? (r0 + rows_per_block) : rows;
   if constexpr (LEAN) {
+    // (the gain, too, stays as loaded where no column partials are kept — RMSNorm: 24 registers instead of 48 at 3 072 columns)
+    uint4 gl[RMS ? MAXCH : 1];
+    if constexpr (RMS) {
+#pragma unroll
+      for (int i = 0; i < MAXCH; ++i) gl[i] = lane + 64 * i < nch ? *(const uint4*)(g + (lane + 64 * i) * VEC) : make_uint4(0, 0, 0, 0);
+    }
+    auto gain = [&](int i, float (&out)[VEC]) {
+      if constexpr (RMS) { reconvert_here(gl[i]); Vec16<T>::unpack(gl[i], out); }
+      else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[e] = gg[i][e];
+      }
+    };
     for (int64_t row = r0 + wave; row < r1; row += NW) {
       uint4 xr[MAXCH], dr[MAXCH];
       float s = 0.f;
@@ -396,18 +409,19 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
 #pragma unroll
       for (int i = 0; i < MAXCH; ++i)
         if (lane + 64 * i < nch) {
-          float xv[VEC], dv[VEC];
+          float xv[VEC], dv[VEC], gv[VEC];
           reconvert_here(xr[i]);
           reconvert_here(dr[i]);
           Vec16<T>::unpack(xr[i], xv);
           Vec16<T>::unpack(dr[i], dv);
+          gain(i, gv);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const float xh = (xv[e] - mean) * rstd;
             const float d = dv[e];
             ag[i][e] += d * xh;
             ab[i][e] += d;
-            const float dg = d * gg[i][e];
+            const float dg = d * gv[e];
             s1 += dg;
             s2 += dg * xh;
           }
@@ -418,15 +432,16 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
       for (int i = 0; i < MAXCH; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
-          float xv[VEC], dv[VEC], o[VEC];
+          float xv[VEC], dv[VEC], gv[VEC], o[VEC];
           reconvert_here(xr[i]);
           reconvert_here(dr[i]);
           Vec16<T>::unpack(xr[i], xv);
           Vec16<T>::unpack(dr[i], dv);
+          gain(i, gv);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const float xh = (xv[e] - mean) * rstd;
-            const float dg = dv[e] * gg[i][e];
+            const float dg = dv[e] * gv[e];
             o[e] = RMS ? rstd * (dg - xh * s2) : rstd * (dg - s1 - xh * s2);
           }
           norm_bwd_store<T>(dx, add, ex, row, cols, ch * VEC, o);
@@ -1330,10 +1345,21 @@ int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const 
   if (rows == 0) return 0;
   // rows per block (4 waves, a wave per row at a time): 16 keeps ~300 blocks at the 5 072 rows of a 16-sample window; the per-rank window's 634 rows
   // would make 40 blocks of four sequential rows per wave (31 us for 4 MB) — one row per wave there: 159 blocks
-  const int rpb = rows <= 2048 ? 4 : 16;
+  // The lean form (x / dy kept as loaded, converted again in every pass — the same operations in the same order, the same bits) needs ~130 registers
+  // where the float copies need 256: three waves per SIMD instead of one, so the passes of different rows overlap.  With that many resident
+  // waves the rows are spread thin (rpb 4) at every row count.
+  const int lean = sl_env().rms_bwd_lean;
+  const int rpb = rows <= 2048 || lean == 2 ? 4 : (lean == 3 ? 8 : 16);
   SL_DISPATCH_DTYPE(dtype, T, {
-    hipLaunchKernelGGL((norm_bwd_kernel<T, true, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                       (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add, ex);
+    if (lean && cols <= 64 * 48)           // (Llama-3.2-3B: 3 072 = 48 floats per lane — arrays sized for it, not for the 4 096 the general form admits)
+      hipLaunchKernelGGL((norm_bwd_kernel<T, true, 48, 4, true>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                         (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add, ex);
+    else if (lean)
+      hipLaunchKernelGGL((norm_bwd_kernel<T, true, TR_MAXF, 4, true>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                         (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add, ex);
+    else
+      hipLaunchKernelGGL((norm_bwd_kernel<T, true, TR_MAXF, 4>), dim3((unsigned)ceil_div64(rows, rpb)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                         (const T*)nullptr, (const T*)dy, (T*)dx, (float*)nullptr, (float*)nullptr, rows, cols, eps, 0, rpb, (float*)nullptr, (const T*)add, ex);
   });
   SL_CHECK_LAUNCH("rmsnorm_bwd");
   return 0;
