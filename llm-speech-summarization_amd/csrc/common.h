@@ -223,6 +223,9 @@ struct SlEnv {
   int attn_fwd_st;         // SL_ATTN_FWD_ST       (default 1; 2 measured equal, profiles/r06_l_attn_fwd_st_ab.txt) head_dim-64 attention forward: 64-key tiles per staged block
   int conv0_fold;          // SL_CONV0_FOLD        (default 1) conv0 backward of a batch: the block's four waves fold their sums through LDS and flush once, >= 4 strips per wave; 0 = a flush per wave of a 512-block grid (A/B)
   int enc_wt_ahead;        // SL_ENC_WT_AHEAD      (default 1) encoder tape: the layers' transposed weights for the data-gradient products are made in one batched launch on a side stream beside the forward; 0 = a transpose in front of each product
+  int glds_ring;           // SL_GLDS_RING         (default 4) bf16 products of <= 256 tiles of 128 x 128 (one block per CU) run the ring form of the 128-tile kernel (gemm128.hip): 4 / 3 = stages of 32 KiB, 104 = four stages without the software-pipelined fragment reads, 0 = the two-stage kernel (A/B)
+  int glds_dmab;           // SL_GLDS_DMAB         (default 0: measured equal to -6 % at two blocks per CU, profiles/r06_ah_*) 1 = the two-stage 128-tile kernel issues the next slab's DMA requests between the MFMAs of the current one (0: in a burst at the top of the iteration)
+  int splitk_slots;        // SL_SPLITK_SLOTS      (default 0 = rule) block slots the plain split-K rule fills with K runs: 256 = one block per CU (ring form), 512 = two (two-stage kernel)
   int rms_bwd_lean;        // SL_RMSBWD_LEAN       (default 2) RMSNorm backward: x / dy kept as loaded 16-byte vectors (no float copies: ~130 registers instead of 256, 3 waves per SIMD instead of 1); 2 = and four rows per block at every row count, 3 = eight; 0 = the float-copy form
   int decode_prefetch;     // SL_DECODE_PREFETCH   (default 0: measured 2.2 x SLOWER, profiles/r06_j_decode_prefetch_ab.txt) small-batch decode graphs with a weight-prefetch branch two matrices ahead of the chain (runtime.hip DecodePrefetch)
   int attn_bwd_kf;         // SL_ATTN_BWD_KF       (default 0 = by shape) 16-row fragments per wave in the attention-backward kernels: 1 / 2 force a form

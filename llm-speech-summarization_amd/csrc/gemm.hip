@@ -202,8 +202,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmP p) {
 // ----------------------------------------------------------------------------------------------
 
 
-template <typename T, int ACT, bool ASMLDS = false>
+// DMAB (round 6, with ASMLDS, bf16): the eight DMA requests of slab kt + 1 are issued BETWEEN the MFMAs of slab kt's first k-step (one per two,
+// MFMAs as asm statements so that the order holds) instead of in a burst at the top of the iteration: a request costs the issuing wave
+// ~60-185 cycles (guide: LDS-DMA piece issue cost) during which its SIMD's matrix pipe has only the other block's wave to draw from.  Same
+// MFMA order, same bits.  SL_GLDS_DMAB=1 selects it; default off — with two blocks per CU the other block covers the burst (7 984 x 3 072 x 1 024: 795 against 845 TF/s, the rest within 1 %, profiles/r06_ah_gemm_vs_vendor_mid.txt); at ONE block per CU the same placement is worth +20 % (gemm128.hip).
+template <typename T>
+__device__ __forceinline__ void mfma_fence_step(f32x4& acc, const u32x4_t& a, const u32x4_t& b) {
+  if constexpr (sizeof(T) == 2) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "memory");
+}
+
+template <typename T, int ACT, bool ASMLDS = false, bool DMAB = false>
 __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
+  static_assert(!DMAB || (ASMLDS && sizeof(T) == 2), "the interleaved form is the bf16 asm-read loop");
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int BK = TROWB / (int)sizeof(T);
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TBM * TROWB];
@@ -265,6 +275,52 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_glds_kernel(GemmP p) {
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (DMAB) {
+    const uint32_t x0 = (uint32_t)((q ^ (r & 7)) << 4), x1 = (uint32_t)(((4 + q) ^ (r & 7)) << 4);
+    const uint32_t sb0 = (uint32_t)(uintptr_t)(lds_ptr_t)(&smem[0][0][0]);
+    const uint32_t ra0 = sb0 + (uint32_t)((wm * 64 + r) * TROWB), rb0 = sb0 + (uint32_t)(TBM * TROWB + (wn * 64 + r) * TROWB);
+    u32x4_t a0[4], b0[4], a1[4], b1[4];
+    auto reads = [&](int buf) {
+      const uint32_t ra = ra0 + (uint32_t)(buf * 2 * TBM * TROWB), rb = rb0 + (uint32_t)(buf * 2 * TBM * TROWB);
+      SL_LDS_RD(a0[0], ra + x0, 0); SL_LDS_RD(a0[1], ra + x0, 2048); SL_LDS_RD(a0[2], ra + x0, 4096); SL_LDS_RD(a0[3], ra + x0, 6144);
+      SL_LDS_RD(b0[0], rb + x0, 0); SL_LDS_RD(b0[1], rb + x0, 2048); SL_LDS_RD(b0[2], rb + x0, 4096); SL_LDS_RD(b0[3], rb + x0, 6144);
+      SL_LDS_RD(a1[0], ra + x1, 0); SL_LDS_RD(a1[1], ra + x1, 2048); SL_LDS_RD(a1[2], ra + x1, 4096); SL_LDS_RD(a1[3], ra + x1, 6144);
+      SL_LDS_RD(b1[0], rb + x1, 0); SL_LDS_RD(b1[1], rb + x1, 2048); SL_LDS_RD(b1[2], rb + x1, 4096); SL_LDS_RD(b1[3], rb + x1, 6144);
+      lds_wait8<8>(a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3]);
+    };
+    auto step1 = [&]() {
+      lds_wait8<0>(a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) mfma_fence_step<T>(acc[m][n], a1[m], b1[n]);
+    };
+    for (int kt = 0; kt + 1 < nkt; ++kt) {
+      const int buf = kt & 1;
+      reads(buf);
+      const int k0 = (kt + 1) * BK;
+      unsigned char* dst = &smem[buf ^ 1][0][0] + wave_lds;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          mfma_fence_step<T>(acc[m][n], a0[m], b0[n]);
+          if (n == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[m] + k0), (lds_ptr_t)(dst + m * 4096), 16, 0, 0);
+          if (n == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t)(gw[m] + k0), (lds_ptr_t)(dst + TBM * TROWB + m * 4096), 16, 0, 0);
+        }
+      step1();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    reads((nkt - 1) & 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) mfma_fence_step<T>(acc[m][n], a0[m], b0[n]);
+    step1();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // XDL write -> VALU read wait states the compiler cannot see behind asm MFMAs
+    __builtin_amdgcn_s_barrier();
+  } else
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
@@ -613,16 +669,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   for (int e = 0; e < 4; ++e) store_out<T>(p, p.C, p.res, row, col + e, v4[e]);
 }
 
+// the ring form of the 128-tile kernel (gemm128.hip): whole-slab untransposed ungrouped products whose 128 x 128 tiles (x batch) give every CU
+// at most one block, with enough slabs behind the ring's prologue
+static bool ring_ok(const GemmP& p, int batch, int bk) {
+  if (!sl_env().glds_ring || g_disable_glds || p.ta || p.tw || p.grp || p.K % bk || p.amax_val) return false;
+  const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * batch;
+  return t128 <= sk_cu_count() && p.K / bk >= 8;
+}
+
 static int splitk_runs(const GemmP& p, int batch, int bk, size_t ws_bytes) {
   if (p.colsum) return 0;        // column sums are taken in the tile epilogues (one adder per wave and column), not in the reduce pass
   if (!sl_env().split_k || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.N < 128 || (p.N & 3)) return 0;
   const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
   const int nkt = p.K / bk;
   if (t128 > 256 || nkt < 32) return 0;          // above half the 512 slots (two blocks per CU) the chip is busy enough; short reductions
-  int S = (int)(512 / t128);
+  // slots: two blocks per CU of the two-stage kernel, ONE of the ring form (whose runs then also need no second round)
+  // Measured with the ring form (profiles/r06_ag_gemm_vs_vendor_small.txt): one block per CU wins up to K = 8 192 (634 x 3 072 x 8 192: 725 against
+  // 707 TF/s on two blocks per CU of the two-stage kernel), two blocks per CU from 192 slabs (x 16 384: 786 against 724)
+  const bool ring = sl_env().glds_ring && !g_disable_glds && !p.amax_val;
+  const int slots = sl_env().splitk_slots > 0 ? sl_env().splitk_slots : ((ring && nkt < 192) ? 256 : 512);
+  int S = (int)(slots / t128);
   if (S > 8) S = 8;
   if (S > nkt / 12) S = nkt / 12;                // every run keeps >= 12 slabs (768 k) behind its prologue
   while (S > 1 && (nkt % S || (size_t)S * p.M * p.N * sizeof(float) > ws_bytes)) --S;
+  // the reduce launch costs what ~25-30 slabs of the ring loop cost (634 x 3 072 x 3 072: 494 TF/s unsplit, 447 in two runs): cut only where the
+  // runs save more slabs than that per block — or where the consumer sums the runs itself (deferred_splits: no reduce launch)
+  if (ring && slots == 256 && !p.defer && S >= 2 && (int64_t)nkt * (S - 1) < 32 * (int64_t)S) return 0;
   return S >= 2 ? S : 0;
 }
 
@@ -767,10 +839,22 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
     sl_set_error("sl_gemm_ex: post_op / colsum_out need whole 128-byte K slabs (K %% %d == 0) and the LDS-DMA kernels (SL_DISABLE_GLDS unset)", BK);
     return SL_ERR_UNSUPPORTED;
   }
+  // at most one block per CU: the ring form keeps NS - 1 slabs of DMA in flight per block (gemm128.hip; same bits as the two-stage kernel)
+  if constexpr (sizeof(T) == 2) {
+    if (ring_ok(p, batch, BK)) return sl_gemm128_ring_launch<T, ACT>(p, sl_env().glds_ring, grid, st);
+  }
   if (!p.ta && !p.tw && p.K % BK == 0 && !p.grp_ext && g_disable_glds == 2)
     hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, false>), grid, dim3(256), 0, st, p);
-  else if (!p.ta && !p.tw && p.K % BK == 0 && (!p.grp_ext || p.grp_kslab) && !g_disable_glds)   // per-group K: only the register path handles K tails (groups_ext = 2: the caller vouches for whole slabs)
+  else if (!p.ta && !p.tw && p.K % BK == 0 && (!p.grp_ext || p.grp_kslab) && !g_disable_glds) {   // per-group K: only the register path handles K tails (groups_ext = 2: the caller vouches for whole slabs)
+    if constexpr (sizeof(T) == 2) {
+      if (sl_env().glds_dmab && !p.grp_ext) {
+        hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, true, true>), grid, dim3(256), 0, st, p);
+        SL_CHECK_LAUNCH("gemm_tiled");
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((gemm_tiled_glds_kernel<T, ACT, true>), grid, dim3(256), 0, st, p);
+  }
   else
     hipLaunchKernelGGL((gemm_tiled_kernel<T, ACT>), grid, dim3(256), 0, st, p);
   SL_CHECK_LAUNCH("gemm_tiled");

@@ -133,6 +133,9 @@ constexpr size_t SK_FLAG_BYTES = 1024, SK_SLOT_BYTES = (size_t)XBM * XBN * 4;
 enum : int { SL_T256_PHASED = 0, SL_T256_PHASED_SW = 1, SL_T256_PLAIN = 2, SL_T256_PLAIN_SW = 3, SL_T256_SK = 4, SL_T256_SK_SW = 5, SL_T256_DBG = 16 };
 template <typename T, int ACT>
 int sl_gemm256_launch(const GemmP& p, int kind, dim3 grid, void* sk_ws, hipStream_t st);
+// gemm128.hip: the 128-tile kernel with a ring of `stages` K slabs (3 or 4), one block per CU; whole-slab untransposed ungrouped 2-byte products
+template <typename T, int ACT>
+int sl_gemm128_ring_launch(const GemmP& p, int stages, dim3 grid, hipStream_t st);
 // gemm_tt.hip: the weight-gradient kernel on token-major operands, grid (tiles, K runs)
 int sl_gemm_tt_kernel_launch(const GemmP& p, int nt, int S, int slabs_per_run, hipStream_t st);
 

@@ -56,6 +56,51 @@ def test_library_loads_and_reports_gfx950():
     assert buf.value.decode().startswith("gfx950"), buf.value
 
 
+@pytest.mark.parametrize("M,N,K", [(634, 3072, 3072), (634, 5120, 3072), (998, 1024, 4096), (998, 3072, 1024), (137, 5120, 3072), (130, 96, 512),
+                                   (1, 3072, 1024), (255, 16384, 512), (2048, 2048, 1024)])
+def test_gemm_ring_form_of_the_128_tile_kernel_gives_the_two_stage_kernels_bits(M, N, K, tuning):
+    """gemm128.hip: products of at most one 128 x 128 tile per CU keep a ring of 3 or 4 K slabs in flight (counted vmcnt) instead of the
+    two stages of gemm_tiled_glds_kernel.  Same tile, fragment order and epilogues: every form — plain, bias + GELU + pre-activation copy,
+    bias + residual, fp32 accumulation into C, batched K runs (split-K with a workspace, where the ring changes the NUMBER of runs and so
+    only the fp32 reference applies) — must give the two-stage kernel's bits, and agree with the fp32 product.  Ragged M / N edges, K from
+    8 slabs (the admission bound) to 48; 2 048 x 2 048 has exactly 256 tiles (the last product the ring takes)."""
+    dt = torch.bfloat16
+    A, W, R, b = rnd(M, K, seed=291), rnd(N, K, seed=292, std=K ** -0.5), rnd(M, N, seed=293), rnd(N, seed=294)
+    Ad, Wd, Rd, bd = A.to(dev(), dt), W.to(dev(), dt), R.to(dev(), dt), b.to(dev(), dt)
+    acc0 = rnd(M, N, seed=295).to(dev())
+
+    def run():
+        kw = dict(M=M, N=N, K=K, lda=K, ldw=K)
+        o1 = ops.gemm_ex(Ad, Wd, out=torch.empty((M, N), device=dev(), dtype=dt), **kw)
+        aux = torch.empty((M, N), device=dev(), dtype=dt)
+        o2 = ops.gemm_ex(Ad, Wd, out=torch.empty((M, N), device=dev(), dtype=dt), bias=bd, act=L.ACT_GELU, aux_out=aux, **kw)
+        o3 = ops.gemm_ex(Ad, Wd, out=torch.empty((M, N), device=dev(), dtype=dt), bias=bd, residual=Rd, ldr=N, **kw)
+        o4 = acc0.clone()
+        ops.gemm_ex(Ad, Wd, out=o4, residual=o4, ldr=N, out_f32=True, residual_f32=True, **kw)
+        return o1, o2, aux, o3, o4
+
+    tuning("SL_GLDS_RING", "0")
+    tuning("SL_GLDS_DMAB", "0")
+    two_stage = run()
+    ref = q(A, dt) @ q(W, dt).T
+    assert rel_err(two_stage[0].float().cpu(), ref) < TOL[dt]
+    tuning("SL_GLDS_DMAB", "1")       # the two-stage kernel with the next slab's DMA requests between its MFMAs (A/B form, off by default): same bits
+    for a_, b_ in zip(run(), two_stage):
+        assert torch.equal(a_, b_)
+    for stages in ("4", "3", "104"):
+        tuning("SL_GLDS_RING", stages)
+        for rep in range(2):
+            ring = run()
+            for a_, b_ in zip(ring, two_stage):
+                assert torch.equal(a_, b_), (stages, rep)
+    if K >= 2048 and N % 4 == 0:      # split-K admission: the ring form cuts into 256 / tiles runs instead of 512 / tiles
+        ws = ops.streamk_workspace(dev())
+        for stages in ("0", "4"):
+            tuning("SL_GLDS_RING", stages)
+            o = ops.gemm_ex(Ad, Wd, out=torch.empty((M, N), device=dev(), dtype=dt), bias=bd, residual=Rd, ldr=N, M=M, N=N, K=K, lda=K, ldw=K, sk_ws=ws)
+            assert rel_err(o.float().cpu(), ref + q(b, dt) + q(R, dt)) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", [(499, 1024, 1024), (130, 96, 192), (128, 128, 64), (257, 3072, 1024), (1000, 512, 1536)])
 def test_gemm_tiled_bias_gelu_residual(dt, M, N, K):

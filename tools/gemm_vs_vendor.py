@@ -15,6 +15,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--variants", default="r3,p,vendor")
+ap.add_argument("--mid", action="store_true", help="the KD-window rows (M = 1 872 ... 7 984) and the per-rank rows")
+ap.add_argument("--small", action="store_true", help="only the per-rank KD window rows (M <= 1 000) and the 2 048-row products")
 args = ap.parse_args()
 dev = "cuda:0"
 
@@ -34,6 +36,10 @@ if args.quick:
     shapes = [(7984, 3072, 1024), (5072, 5120, 3072), (3200, 3072, 3072)]
     big = [(127744, 3072, 1024), (127744, 1024, 4096), (140288, 5120, 3072)]
 shapes = big + shapes
+if args.mid:
+    shapes = [sh for sh in shapes if sh[0] <= 7984 and sh[2] != 8064]
+if args.small:
+    shapes = [sh for sh in shapes if sh[0] <= 2048 and sh[2] != 8064] + [(634, 3072, 5120), (998, 1024, 1024), (998, 1024, 3072), (137, 5120, 3072), (137, 16384, 3072)]
 variants = args.variants.split(",")
 
 
@@ -43,7 +49,7 @@ SK = None
 def our_gemm(A, W, out, v):
     """ops.gemm, or (variant sk) the same product with the split-K / stream-K workspace a KD tape passes (sl_gemm_ex_args.sk_ws)"""
     global SK
-    if v != "sk":
+    if not v.startswith("sk"):
         return ops.gemm(A, W, out=out)
     if SK is None:
         SK = ops.streamk_workspace(A.device)
@@ -53,7 +59,10 @@ def our_gemm(A, W, out, v):
 def set_variant(v):
     if v == "vendor":
         return
-    if v == "sk":
+    # p2 / sk2: the two-stage 128-tile kernel (SL_GLDS_RING=0, round 5's rule), p3 / sk3: three ring stages; p / sk: the default (four)
+    os.environ["SL_GLDS_RING"] = "0" if v.endswith("2") else ("3" if v.endswith("3") and v != "r3" else ("104" if v.endswith("u") else "4"))
+    os.environ["SL_GLDS_DMAB"] = "1" if v.endswith("d") else "0"      # pd: the two-stage kernel with its DMA requests between the MFMAs (default: a burst)
+    if v.startswith("sk") or v in ("p2", "p3", "pu", "pd"):      # pu / sku: the ring without the software-pipelined fragment reads
         v = "p"
     os.environ["SL_T256_PHASED"] = {"r3": "0", "p": "1", "pad0": "1"}[v]
     os.environ["SL_T256_BY_ROUNDS_PAD"] = "0" if v == "pad0" else "1"      # pad0 = round 4's row-padding bound on the whole-rounds choice
@@ -99,4 +108,6 @@ for M, N, K in shapes:
 print(f"worst p/vendor ratio: {worst:.3f}")
 os.environ.pop("SL_T256_PHASED", None)
 os.environ.pop("SL_T256_BY_ROUNDS_PAD", None)
+os.environ.pop("SL_GLDS_RING", None)
+os.environ.pop("SL_GLDS_DMAB", None)
 L.lib().sl_tuning_reload()
