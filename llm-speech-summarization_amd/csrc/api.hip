@@ -57,7 +57,7 @@ static const SlEnv* env_load() {
   e.enc_wt_ahead = env_int("SL_ENC_WT_AHEAD", 1);
   e.rms_bwd_lean = env_int("SL_RMSBWD_LEAN", 2);
   e.glds_ring = env_int("SL_GLDS_RING", 4);
-  if (e.glds_ring != 3 && e.glds_ring != 4 && e.glds_ring != 104) e.glds_ring = 0;
+  if (e.glds_ring != 3 && e.glds_ring != 4 && e.glds_ring != 104 && e.glds_ring != 204) e.glds_ring = 0;
   e.splitk_slots = env_int("SL_SPLITK_SLOTS", 0);
   e.glds_dmab = env_int("SL_GLDS_DMAB", 0);
   e.stream_min_m = env_int("SL_STREAM_MIN_M", 26);

@@ -36,9 +36,10 @@ __device__ __forceinline__ void mfma_asm_drain() { asm volatile("s_nop 15\n\ts_n
 
 template <int N> __device__ __forceinline__ void vm_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int ACT, int NS, bool PIPE, bool DMA_BETWEEN = true>
+template <typename T, int ACT, int NS, bool PIPE, bool SPLIT = false, bool DMA_BETWEEN = true>
 __global__ __launch_bounds__(256, 1) void gemm_tiled_ring_kernel(GemmP p) {
   static_assert(NS >= 3 && NS <= 4, "8 (NS - 2) DMA instructions stay in flight; NS x 32 KiB of LDS");
+  static_assert(!SPLIT || (PIPE && NS == 4), "the split request schedule is written for the pipelined four-stage ring");
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int BK = TROWB / (int)sizeof(T);
   constexpr int HALF = TBM * TROWB;            // 16 KiB: one operand's slab
@@ -100,9 +101,15 @@ __global__ __launch_bounds__(256, 1) void gemm_tiled_ring_kernel(GemmP p) {
   };
 
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (SPLIT) {      // slabs 0, 1 and the A half of slab 2 (nkt >= 4: launch_tiled admits the ring from 8 slabs)
+    issue(0); issue(1);
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nkt) issue(s);
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[i] + 2 * BK), (lds_ptr_t)(smem + 2 * STAGE + wave_lds + i * 4096), 16, 0, 0);
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nkt) issue(s);
+  }
 
   const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   const uint32_t x0 = (uint32_t)((q ^ (r & 7)) << 4), x1 = (uint32_t)(((4 + q) ^ (r & 7)) << 4);
@@ -153,8 +160,67 @@ __global__ __launch_bounds__(256, 1) void gemm_tiled_ring_kernel(GemmP p) {
           if (n == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t)(gw[m] + k0), (lds_ptr_t)(dst + HALF + m * 4096), 16, 0, 0);
         }
     };
+    // SPLIT: a slab's eight requests spread over TWO 16-MFMA phases, one per four MFMAs — its A half between the MFMAs of k-step 1 of iteration
+    // nk - 3 (behind that iteration's barrier every wave has retired its reads of slab nk - 4, the slot's last tenant), its W half between the
+    // MFMAs of k-step 0 of iteration nk - 2.  Behind W(kt + 1) the requests A(kt + 2), W(kt + 2) are younger: vmcnt(8) admits slab kt + 1.
+    auto mma0_dmaW = [&](int nk) {
+      lds_wait8<8>(a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3]);
+      const int k0 = nk * BK;
+      unsigned char* dst = smem + (nk % NS) * STAGE + HALF + wave_lds;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          mfma_asm_fence<T>(acc[m][n], a0[m], b0[n]);
+          if (n == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(gw[m] + k0), (lds_ptr_t)(dst + m * 4096), 16, 0, 0);
+        }
+    };
+    auto mma1_dmaA = [&](int nk) {
+      lds_wait8<8>(a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3]);
+      const int k0 = nk * BK;
+      unsigned char* dst = smem + (nk % NS) * STAGE + wave_lds;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          mfma_asm_fence<T>(acc[m][n], a1[m], b1[n]);
+          if (n == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[m] + k0), (lds_ptr_t)(dst + m * 4096), 16, 0, 0);
+        }
+    };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
+    if constexpr (SPLIT) {
+      vm_wait_n<12>();                 // slab 0 has landed: slab 1 and A(2) are younger
+      __builtin_amdgcn_s_barrier();
+      rd0(0);
+      int kt = 0;
+      for (; kt + 3 < nkt; ++kt) {
+        rd1(kt);
+        mma0_dmaW(kt + 2);
+        vm_wait_n<8>();
+        __builtin_amdgcn_s_barrier();      // behind it: slab kt + 1 is visible, and every wave has retired its reads of slab kt - 1
+        rd0(kt + 1);
+        mma1_dmaA(kt + 3);
+      }
+      rd1(kt);                             // kt = nkt - 3: the last W half; A(nkt - 1) and it stay younger than slab nkt - 2
+      mma0_dmaW(kt + 2);
+      vm_wait_n<8>();
+      __builtin_amdgcn_s_barrier();
+      rd0(kt + 1);
+      mma1(no{});
+      ++kt;
+      rd1(kt);                             // kt = nkt - 2
+      mma0();
+      vm_wait_n<0>();
+      __builtin_amdgcn_s_barrier();
+      rd0(kt + 1);
+      mma1(no{});
+      ++kt;
+      rd1(kt);
+      mma0();
+      mma1(yes{});
+      mfma_asm_drain();
+    } else {
     {   // slab 0 has landed once at most min(NS - 2, nkt - 1) younger slabs are outstanding
       if (nkt - 1 >= NS - 2) vm_wait_n<8 * (NS - 2)>();
       else if (NS > 3 && nkt == 2) vm_wait_n<8>();
@@ -187,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tiled_ring_kernel(GemmP p) {
     mma0();
     mma1(yes{});
     mfma_asm_drain();
+    }
   } else {
     for (int kt = 0; kt < nkt; ++kt) {
       {   // slab kt has landed once at most min(NS - 2, nkt - 1 - kt) younger slabs are outstanding (uniform)
@@ -225,17 +292,17 @@ __global__ __launch_bounds__(256, 1) void gemm_tiled_ring_kernel(GemmP p) {
   tile_epilogue<T, ACT>(p, acc, bm, bn, wm, wn, q, r, z, wz);
 }
 
-template <typename T, int ACT, int NS, bool PIPE>
+template <typename T, int ACT, int NS, bool PIPE, bool SPLIT = false>
 static int launch_ring(const GemmP& p, dim3 grid, hipStream_t st) {
   constexpr int LDS_BYTES = NS * 2 * TBM * TROWB;
   static std::atomic<uint64_t> attr_set{0};   // one bit per device: the opt-in to > 64 KiB of dynamic LDS is per device
   int devid = 0;
   SL_HIP(hipGetDevice(&devid));
   if (devid < 0 || devid >= 64 || !((attr_set.load(std::memory_order_relaxed) >> devid) & 1)) {
-    SL_HIP(hipFuncSetAttribute((const void*)gemm_tiled_ring_kernel<T, ACT, NS, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    SL_HIP(hipFuncSetAttribute((const void*)gemm_tiled_ring_kernel<T, ACT, NS, PIPE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     if (devid >= 0 && devid < 64) attr_set.fetch_or(1ull << devid, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL((gemm_tiled_ring_kernel<T, ACT, NS, PIPE>), grid, dim3(256), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_tiled_ring_kernel<T, ACT, NS, PIPE, SPLIT>), grid, dim3(256), LDS_BYTES, st, p);
   SL_CHECK_LAUNCH("gemm_tiled_ring");
   return 0;
 }
@@ -245,7 +312,8 @@ int sl_gemm128_ring_launch(const GemmP& p, int stages, dim3 grid, hipStream_t st
   if constexpr (sizeof(T) == 2) {
     if (stages == 3) return launch_ring<T, ACT, 3, true>(p, grid, st);
     if (stages == 104) return launch_ring<T, ACT, 4, false>(p, grid, st);      // the un-pipelined loop (A/B)
-    return launch_ring<T, ACT, 4, true>(p, grid, st);
+    if (stages == 204) return launch_ring<T, ACT, 4, true>(p, grid, st);       // all eight requests of a slab inside one 16-MFMA phase (A/B)
+    return launch_ring<T, ACT, 4, true, true>(p, grid, st);
   } else {
     sl_set_error("sl_gemm: the ring form of the 128-tile kernel is built for 2-byte types only");
     return SL_ERR_UNSUPPORTED;

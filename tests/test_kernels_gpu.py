@@ -87,7 +87,7 @@ def test_gemm_ring_form_of_the_128_tile_kernel_gives_the_two_stage_kernels_bits(
     tuning("SL_GLDS_DMAB", "1")       # the two-stage kernel with the next slab's DMA requests between its MFMAs (A/B form, off by default): same bits
     for a_, b_ in zip(run(), two_stage):
         assert torch.equal(a_, b_)
-    for stages in ("4", "3", "104"):
+    for stages in ("4", "3", "104", "204"):
         tuning("SL_GLDS_RING", stages)
         for rep in range(2):
             ring = run()

@@ -60,9 +60,9 @@ def set_variant(v):
     if v == "vendor":
         return
     # p2 / sk2: the two-stage 128-tile kernel (SL_GLDS_RING=0, round 5's rule), p3 / sk3: three ring stages; p / sk: the default (four)
-    os.environ["SL_GLDS_RING"] = "0" if v.endswith("2") else ("3" if v.endswith("3") and v != "r3" else ("104" if v.endswith("u") else "4"))
+    os.environ["SL_GLDS_RING"] = "0" if v.endswith("2") else ("3" if v.endswith("3") and v != "r3" else ("104" if v.endswith("u") else ("204" if v.endswith("o") else "4")))      # po / sko: the ring with a slab's eight requests inside one 16-MFMA phase
     os.environ["SL_GLDS_DMAB"] = "1" if v.endswith("d") else "0"      # pd: the two-stage kernel with its DMA requests between the MFMAs (default: a burst)
-    if v.startswith("sk") or v in ("p2", "p3", "pu", "pd"):      # pu / sku: the ring without the software-pipelined fragment reads
+    if v.startswith("sk") or v in ("p2", "p3", "pu", "pd", "po"):      # pu / sku: the ring without the software-pipelined fragment reads
         v = "p"
     os.environ["SL_T256_PHASED"] = {"r3": "0", "p": "1", "pad0": "1"}[v]
     os.environ["SL_T256_BY_ROUNDS_PAD"] = "0" if v == "pad0" else "1"      # pad0 = round 4's row-padding bound on the whole-rounds choice
