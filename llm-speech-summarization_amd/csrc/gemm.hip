@@ -713,8 +713,12 @@ static int launch_tt(GemmP& p, hipStream_t st, void* sk_ws, size_t sk_ws_bytes) 
   const int nt = p.tiles_m * p.tiles_n, nkt = (p.K + 63) / 64;
   int S = 1;
   const size_t ws = sk_ws && sk_ws_bytes > SK_FLAG_BYTES ? sk_ws_bytes - SK_FLAG_BYTES : 0;
-  if (ws && nt < 512 && !(p.N & 3)) {
-    S = 512 / nt;
+  // K runs fill 512 block slots (two blocks per CU of the two-stage kernel); launches that end at <= 256 blocks take the ring form (gemm_tt.hip).
+  // Filling only 256 slots so that every product rides the ring was measured mixed at 7 984 tokens (4 096 x 1 024: 746 against 675 TF/s,
+  // 3 072 x 1 024: 571 against 622, 1 024 x 4 096: 749 against 824; profiles/r06_ak_wgrad_ring.txt) — SL_SPLITK_SLOTS=256 selects it.
+  const int slots = sl_env().splitk_slots > 0 ? sl_env().splitk_slots : 512;
+  if (ws && nt < slots && !(p.N & 3)) {
+    S = slots / nt;
     const int smax = sl_env().tt_max_splits > 0 ? sl_env().tt_max_splits : 8;
     if (S > smax) S = smax;
     if (S > nkt / 12) S = nkt / 12;

@@ -584,6 +584,45 @@ def test_wgrad_token_major_product_carries_the_bias_gradient(M, Nout, Kin, ldy, 
     assert rel_err(small.cpu(), dY[:100].float().sum(0).cpu()) < 1e-3
 
 
+@pytest.mark.parametrize("M,Nout,Kin,ldy", [(998, 1024, 1024, 1024), (998, 3072, 1024, 3072), (7984, 1024, 1024, 1024), (7984, 4096, 1024, 4096), (1000, 1024, 512, 3072),
+                                            (8001, 1024, 1024, 1024), (640, 2048, 2048, 2048), (130, 1024, 1024, 1024)])
+def test_wgrad_token_major_ring_form_gives_the_two_stage_kernels_bits(M, Nout, Kin, ldy):
+    """gemm_tiled_tt_ring_kernel (launches of at most one block per CU: four stages of DMA, fragment reads pipelined across the barrier, asm
+    MFMAs with the DMA requests between them) against gemm_tiled_tt_kernel on the same K runs (SL_SPLITK_SLOTS pins the split rule to 256 block
+    slots for both): dW and the bias-gradient rider bit for bit, with and without the workspace; token tails inside a slab (998, 1 000, 8 001
+    rows), a last run shorter than the others (8 001 rows: 32 / 32 / 32 / 30 slabs), 130 rows (three slabs: below the ring's admission of eight slabs per run, both switches
+    run the two-stage kernel), and the fp64 product."""
+    dY_full = rnd(M, ldy, seed=51).to(DEV, torch.bfloat16)
+    dY = dY_full[:, :Nout]
+    X = rnd(M, Kin, seed=52).to(DEV, torch.bfloat16)
+    sk = ops.streamk_workspace(DEV)
+    ref = dY.double().t() @ X.double()
+
+    def run(ws):
+        dW = torch.zeros((Nout, Kin), device=DEV, dtype=torch.float32)
+        db = torch.zeros((Nout,), device=DEV, dtype=torch.float32)
+        ops.gemm_ex(dY, X, M=Nout, N=Kin, K=M, lda=ldy, ldw=Kin, out=dW, ldc=Kin, residual=dW, ldr=Kin, out_f32=True, residual_f32=True, trans_a=True, trans_w=True,
+                    dtype=torch.bfloat16, sk_ws=ws, colsum_out=db)
+        return dW, db
+
+    res = {}
+    os.environ["SL_SPLITK_SLOTS"] = "256"
+    try:
+        for ring in ("0", "4"):
+            os.environ["SL_GLDS_RING"] = ring
+            L.lib().sl_tuning_reload()
+            res[ring] = [run(sk), run(None), run(sk)]
+    finally:
+        del os.environ["SL_SPLITK_SLOTS"], os.environ["SL_GLDS_RING"]
+        L.lib().sl_tuning_reload()
+    for (w0, b0), (w1, b1) in zip(res["0"], res["4"]):
+        assert torch.equal(w0, w1)
+        assert rel_err(b1.cpu(), b0.cpu()) < 1e-6          # atomics across K runs: the order of the adds is not fixed
+    assert torch.equal(res["4"][0][0], res["4"][2][0])
+    assert rel_err(res["4"][0][0].double().cpu(), ref.cpu()) < 1e-5
+    assert rel_err(res["4"][0][1].cpu(), dY.float().sum(0).cpu()) < 1e-3
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", [(998, 1024, 4096), (634, 3072, 16384), (400, 1024, 4096)])
 def test_gemm_deferred_split_k_partials_sum_to_the_reduced_product(dt, M, N, K):
