@@ -281,6 +281,10 @@ struct NormBwdX {
   // dy left as the S fp32 partial products of a K-split GEMM (sl_gemm_ex_args.deferred_splits): dy = round(sum of the runs, in run order) is formed
   // while loading — the reduce launch between the product and this kernel, and its round trip of dy through memory, are gone
   const float* dy_parts; int dy_S; int64_t dy_slab;
+  // LayerNorm, scratch-record form, 16-wave blocks: the block that arrives LAST at this counter (zero between launches; it leaves it zero) sums the
+  // blocks' records into dgamma / dbeta itself, in norm_colreduce_kernel's order (same bits) — no second launch.  Records and counter cross the XCDs'
+  // L2s as agent-scope (sc1) stores / loads drained with s_waitcnt around the arrival (the hand-off form of gemm_stream.hip).
+  int32_t* colred_cnt;
 };
 
 template <typename T>
@@ -533,7 +537,54 @@ __global__ __launch_bounds__(64 * NW) void norm_bwd_kernel(const T* __restrict__
           float t = red[0][k];
 #pragma unroll
           for (int w = 1; w < NW; ++w) t += red[w][k];
-          if (part) dst[ch * VEC + e] = t; else atomicAdd(dst + ch * VEC + e, t);
+          if (part) {
+            if (ex.colred_cnt) __hip_atomic_store(dst + ch * VEC + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dst[ch * VEC + e] = t;
+          } else atomicAdd(dst + ch * VEC + e, t);
+        }
+      }
+    }
+  }
+  if constexpr (NW == 16) {
+    if (part && ex.colred_cnt) {
+      __shared__ int last_s;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's record stores have reached the memory side
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int old = atomicAdd(ex.colred_cnt, 1);
+        const int last = old == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(ex.colred_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every block has arrived: leave the counter as found
+        last_s = last;
+      }
+      __syncthreads();
+      if (!last_s) return;
+      // norm_colreduce_kernel's sum, chunk of 64 record entries after chunk: 16 stripes of blocks, eight records in flight per thread, the stripes
+      // folded in stripe order
+      const int nblocks = (int)gridDim.x, stripe = wave;
+      float (*rr)[64 * VEC + 4] = red;
+      for (int c0 = 0; c0 < 2 * cols; c0 += 64) {
+        const int i = c0 + lane;
+        const int ic = i < 2 * cols ? i : 2 * cols - 1;
+        float t = 0.f;
+        for (int b0 = stripe; b0 < nblocks; b0 += 16 * 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int bq = b0 + 16 * u;
+            v[u] = bq < nblocks ? __hip_atomic_load(part + (int64_t)bq * 2 * cols + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        __syncthreads();
+        rr[stripe][lane] = t;
+        __syncthreads();
+        if (stripe == 0 && i < 2 * cols) {
+          float sum = rr[0][lane];
+#pragma unroll
+          for (int w2 = 1; w2 < 16; ++w2) sum += rr[w2][lane];
+          float* dstp = i < cols ? dgamma + i : dbeta + (i - cols);
+          *dstp += sum;
         }
       }
     }
@@ -1243,12 +1294,12 @@ extern "C" size_t sl_layernorm_bwd_ws_bytes(int64_t rows, int32_t cols) {
   const int64_t rpb4 = ceil_div64(ceil_div64(rows, 1024), 4) * 4;
   const size_t nb_max = (size_t)ceil_div64(rows, rpb4 < 4 ? 4 : rpb4);
   const size_t nb = (size_t)ln_bwd_ws_blocks(rows, nullptr);
-  return (nb_max > nb ? nb_max : nb) * 2 * (size_t)cols * sizeof(float);
+  return (nb_max > nb ? nb_max : nb) * 2 * (size_t)cols * sizeof(float) + 256;      // + the arrival counter of the in-kernel column reduce (its last 256 bytes)
 }
 
 static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta, int64_t rows,
                               int32_t cols, float eps, int32_t gelu, int32_t dtype, void* ws, size_t ws_bytes, sl_stream stream, const void* add = nullptr,
-                              NormBwdX ex = NormBwdX{}) {
+                              NormBwdX ex = NormBwdX{}, int32_t* colred_cnt = nullptr) {
   SL_CHECK_ARG(!add || add != dx, "sl_layernorm_bwd: the residual gradient must not alias dx");
   SL_CHECK_ARG(!ex.dx_drop || (ex.dx_drop != dx && ex.dx_drop != dy && ex.dx_drop != add), "sl_layernorm_bwd: the dropped copy must not alias dx / dy / add");
   SL_CHECK_ARG(x && gamma && beta && dy && dx && rows >= 0 && cols > 0, "sl_layernorm_bwd: bad arguments");
@@ -1259,6 +1310,8 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
     int rpb = 16;
     const int nb = ln_bwd_ws_blocks(rows, &rpb);
     if (ws && dgamma && dbeta && ws_bytes >= (size_t)nb * 2 * (size_t)cols * sizeof(float)) {
+      const bool in_kernel = colred_cnt && !gelu && ln_bwd_nw() == 16 && sl_env().ln_colred_inkernel;      // the 16-wave LEAN form carries the last-block reduce
+      ex.colred_cnt = in_kernel ? colred_cnt : nullptr;
       SL_DISPATCH_DTYPE(dtype, T, {
         if (gelu)
           hipLaunchKernelGGL((norm_bwd_kernel<T, false, 16, 16>), dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, (const T*)x, (const T*)gamma,
@@ -1274,6 +1327,7 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
                              (const T*)beta, (const T*)dy, (T*)dx, dgamma, dbeta, rows, cols, eps, 0, rpb, (float*)ws, (const T*)add, ex);
       });
       SL_CHECK_LAUNCH("layernorm_bwd");
+      if (in_kernel) return 0;
       hipLaunchKernelGGL(norm_colreduce_kernel, dim3((unsigned)((2 * cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nb, cols, dgamma,
                          dbeta);
       SL_CHECK_LAUNCH("layernorm_bwd(colreduce)");
@@ -1312,13 +1366,13 @@ static int layernorm_bwd_impl(const void* x, const void* gamma, const void* beta
 // dx_drop (optional): also dropout(dx) with (p, seed) — the incoming gradient of the Linear below (h = h + dropout(sublayer(h)))
 int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
                                  int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream,
-                                 void* dx_drop, float drop_p, uint64_t drop_seed, const float* dy_parts, int dy_splits) {
+                                 void* dx_drop, float drop_p, uint64_t drop_seed, const float* dy_parts, int dy_splits, int32_t* colred_cnt) {
   NormBwdX ex{};
   if (dy_parts && dy_splits >= 2) { ex.dy_parts = dy_parts; ex.dy_S = dy_splits; ex.dy_slab = rows * (int64_t)cols; }
   if (dx_drop && drop_p > 0.f) {
     ex.dx_drop = dx_drop; ex.thr24 = (uint32_t)((double)drop_p * 16777216.0); ex.scale = 1.0f / (1.0f - drop_p); ex.seed = drop_seed;
   }
-  return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, 0, dtype, workspace, workspace_bytes, stream, add, ex);
+  return layernorm_bwd_impl(x, gamma, beta, dy, dx, dgamma, dbeta, rows, cols, eps, 0, dtype, workspace, workspace_bytes, stream, add, ex, colred_cnt);
 }
 
 extern "C" int sl_layernorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* dgamma, float* dbeta,

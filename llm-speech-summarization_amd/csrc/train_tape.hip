@@ -12,7 +12,7 @@
 // ... and, optionally, dropout(dx) as a second output (dx_drop: the incoming gradient of the sublayer below) / a second joining gradient (add2)
 int sl_layernorm_bwd_ws_add_impl(const void* x, const void* gamma, const void* beta, const void* dy, const void* add, void* dx, float* dgamma, float* dbeta,
                                  int64_t rows, int32_t cols, float eps, int32_t dtype, void* workspace, size_t workspace_bytes, sl_stream stream,
-                                 void* dx_drop, float drop_p, uint64_t drop_seed, const float* dy_parts, int dy_splits);
+                                 void* dx_drop, float drop_p, uint64_t drop_seed, const float* dy_parts, int dy_splits, int32_t* colred_cnt);
 int sl_rmsnorm_bwd_add_impl(const void* x, const void* w, const void* dy, const void* add, void* dx, int64_t rows, int32_t cols, float eps, int32_t dtype,
                             sl_stream stream, const void* add2, const float* dy_parts, int dy_splits);
 
@@ -407,6 +407,10 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   hipStream_t sw = st;           // where the current parameter-gradient group runs
   void* sk = ss.on ? nullptr : w.sk;                           // split-K workspace: only when every product of the call is on `st`
   if (sk) SL_HIP(hipMemsetAsync(sk, 0, 1024, st));
+  // arrival counter of the LayerNorm backward's in-kernel column reduce: the last 256 bytes of its record workspace (sl_layernorm_bwd_ws_bytes), zero
+  // whenever no launch is in flight (a call cut short must not poison this one)
+  int32_t* const ln_cnt = w.ln_ws_bytes >= 256 ? (int32_t*)((unsigned char*)w.ln_ws + w.ln_ws_bytes - 256) : nullptr;
+  if (ln_cnt) SL_HIP(hipMemsetAsync(ln_cnt, 0, 256, st));
   void* sk_w = (ss.on || !w.sk) ? w.sk_w : sk;                 // the parameter-gradient group's own (side stream), or the shared one when all is on `st`
   if (sk_w && sk_w != sk) SL_HIP(hipMemsetAsync(sk_w, 0, 1024, st));      // ordered before the first fork of the side stream
   // tmp_h[par] already holds dropout(dx) under the CURRENT layer's output-dropout mask: the LayerNorm backward that produced dx (the layer
@@ -462,7 +466,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     // d_h2 = d x_mid: the LayerNorm path + the residual path (dx), one pass — and dropout(d_h2), the out-projection's incoming gradient
     const bool drop1 = c->p_hidden > 0.f && fuse;
     SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x_mid, L.ln2_g, L.ln2_b, w.d_h1, dx, d_h2, g.ln2_g, g.ln2_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
-                                        drop1 ? tmp_h2 : nullptr, c->p_hidden, sd[1], S1 ? (const float*)((const unsigned char*)sk + 1024) : nullptr, S1));
+                                        drop1 ? tmp_h2 : nullptr, c->p_hidden, sd[1], S1 ? (const float*)((const unsigned char*)sk + 1024) : nullptr, S1, ln_cnt));
     // ---- attention half: x_mid = x + drop(wo . attn(qkv(ln1(x))) + bo)
     const void* d_o1 = d_h2;
     if (c->p_hidden > 0.f) {
@@ -490,7 +494,7 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
     // dx = d x: the LayerNorm path + the residual path (d_h2), one pass — and dropout(dx) under the mask of the next layer down this call visits
     SL_TRY(sl_layernorm_bwd_ws_add_impl(sv.x, L.ln1_g, L.ln1_b, w.d_h1, d_h2, dx, g.ln1_g, g.ln1_b, n, H, c->ln_eps, dt, w.ln_ws, w.ln_ws_bytes, stream,
                                         have_drop ? w.tmp_h[1 - par] : nullptr, c->p_hidden, have_drop ? c->seeds[4 * (size_t)below + 3] : 0,
-                                        S2 ? (const float*)((const unsigned char*)sk + 1024) : nullptr, S2));
+                                        S2 ? (const float*)((const unsigned char*)sk + 1024) : nullptr, S2, ln_cnt));
     par ^= 1;
   }
   for (int k = 0; k < 4; ++k) SL_TRY(ss.join(k));          // the caller's stream owns the gradients again

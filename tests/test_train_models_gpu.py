@@ -643,6 +643,16 @@ def test_fused_tape_epilogues_give_the_bits_of_the_unfused_launch_sequence(monke
     _window_bits_equal_under_switch(monkeypatch, B, "SL_TAPE_FUSE")
 
 
+@pytest.mark.parametrize("B", [16, 2])
+def test_layernorm_backward_in_kernel_column_reduce_gives_the_bits_of_the_reduce_launch(monkeypatch, B):
+    """Round 6: in the encoder tape the LayerNorm backward's last-arriving block sums the per-block dgamma / dbeta records itself (arrival counter
+    behind the records, agent-scope stores / loads) instead of a norm_colreduce_kernel launch per LayerNorm — same summation order, so every
+    LayerNorm gain / bias gradient (and everything else) equals SL_LN_COLRED_INKERNEL=0 bit for bit, window after window on one counter."""
+    monkeypatch.setenv("SL_LN_COLRED_INKERNEL", "1")      # (off by default: 52 launches fewer per window but +1.1 ms on the per-rank window, profiles/r06_am_kd_windows.txt)
+    pkg("_lib").lib().sl_tuning_reload()
+    _window_bits_equal_under_switch(monkeypatch, B, "SL_LN_COLRED_INKERNEL")
+
+
 def _window_bits_equal_under_switch(monkeypatch, B, switch):
     """One KD window with the regularisers on, default build against `switch`=0 (re-read through sl_tuning_reload)."""
     from oracle.golden_cfgs import WIDE_HUBERT, WIDE_LLAMA
