@@ -610,7 +610,7 @@ static int sk_cu_count() {
   }
   return cus[dev];
 }
-extern "C" size_t sl_gemm_streamk_workspace_bytes(void) { return SK_FLAG_BYTES + 256 * SK_SLOT_BYTES; }
+extern "C" size_t sl_gemm_streamk_workspace_bytes(void) { return SK_FLAG_BYTES + (size_t)SK_WS_SLOTS * SK_SLOT_BYTES; }
 
 static int sk_grid(const GemmP& p, int batch, int bk, size_t ws_bytes) {
   const int mode = sl_env().stream_k;          // SL_STREAM_K: 0 = never, 1 = rule (default), 2 = whenever the form allows
@@ -698,6 +698,30 @@ static int splitk_runs(const GemmP& p, int batch, int bk, size_t ws_bytes) {
   return S >= 2 ? S : 0;
 }
 
+// K runs of 256-tile products that fill 50-66 % of ONE round (round 6).  The LLM data gradients of a 16-sample KD window are 3 200 x 3 072 under
+// K = 3 072 / 5 120 / 16 384: 13 x 12 = 156 tiles on 256 CUs, 280 us at K = 16 384 whatever the kernel does inside a tile.  Cut into S = 3 runs of
+// whole slabs (86 / 86 / 84 of the 256 — uneven: GemmP.krun) the 468 blocks make two rounds of a third of the length each: 2/3 of the time, and the
+// three fp32 partial products stay in the workspace for the RMSNorm backward behind the product, which sums them while loading (deferred_splits);
+// a caller without deferred_splits gets the reduce launch (the same bits: the unfused tape of the A/B tests), which gives most of the gain back.
+// From 48 slabs per run up.  Measured: 16-sample KD window 88.7 -> 88.4 ms (profiles/r06_an_kd_windows.txt) — a third of what the round count
+// promises: 118 MB of partial tiles are written and read back per product.
+static int splitk256_runs(const GemmP& p, int batch, int bk, size_t ws_bytes, int* krun) {
+  if (!sl_env().split_k256 || p.colsum || p.ta || p.tw || p.grp || batch != 1 || p.K % bk || p.ln_mr || p.stats_out || p.amax_val || p.aux || p.post ||
+      p.bias || p.res || p.out_f32 || (p.N & 3) || g_disable_glds || sl_env().disable_t256 || !sl_env().t256_phased)
+    return 0;
+  const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN);
+  const int nkt = p.K / bk;
+  int best = 0;
+  double best_cost = 0.7;                       // rounds(S) / S must fall below it
+  for (int S = 2; S <= 4; ++S) {
+    if (nkt / S < 48 || (size_t)S * p.M * p.N * sizeof(float) > ws_bytes) continue;
+    const double cost = (double)((t256 * S + 255) / 256) / S;
+    if (cost < best_cost) { best_cost = cost; best = S; }
+  }
+  if (best) *krun = (nkt + best - 1) / best;
+  return best;
+}
+
 // both operands K-major (weight gradients): gemm_tiled_tt_kernel, with the reduction cut into S runs of whole slabs when the tiles alone
 // leave CUs idle (two blocks per CU: 512 slots) and the caller supplied a workspace
 template <typename T>
@@ -744,6 +768,26 @@ static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullp
   constexpr int BK_ = TROWB / (int)sizeof(T);
   if constexpr (ACT == SL_ACT_NONE && sizeof(T) == 2) {
     if (tt_ok<T>(p, batch)) return launch_tt<T>(p, st, sk_ws, sk_ws_bytes);
+  }
+  if constexpr (ACT == SL_ACT_NONE && sizeof(T) == 2) {
+    if (sk_ws) {
+      int krun = 0;
+      const int S = splitk256_runs(p, batch, BK_, sk_ws_bytes > SK_FLAG_BYTES ? sk_ws_bytes - SK_FLAG_BYTES : 0, &krun);
+      if (S) {
+        GemmP q = p;
+        q.krun = krun; q.sA = 0; q.sW = 0;
+        q.C = (unsigned char*)sk_ws + SK_FLAG_BYTES; q.ldc = p.N; q.sC = (int64_t)p.M * p.N; q.out_f32 = 1;
+        q.defer = nullptr;
+        q.tiles_m = (p.M + XBM - 1) / XBM;
+        q.tiles_n = (p.N + XBN - 1) / XBN;
+        SL_TRY((sl_gemm256_launch<T, SL_ACT_NONE>(q, SL_T256_PHASED, dim3(q.tiles_m * q.tiles_n, S), nullptr, st)));
+        if (p.defer) { *p.defer = S; return 0; }      // the consumer sums the runs (speechllm.h deferred_splits)
+        const int64_t vecs = ((int64_t)p.M * p.N + 3) / 4;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, (const float*)q.C, S, (int64_t)p.M * p.N, p);
+        SL_CHECK_LAUNCH("splitk_reduce");
+        return 0;
+      }
+    }
   }
   if constexpr (ACT == SL_ACT_NONE) {
     if (sk_ws) {
@@ -993,7 +1037,7 @@ int sl_gemm_impl(const sl_gemm_args* a, const sl_gemm_fused* fx, const sl_gemm_e
   p.tiles_m = p.tiles_n = 0;
   p.ta = p.tw = 0; p.aux = nullptr; p.res_f32 = 0; p.grp = nullptr; p.w_mod = 1; p.cx = p.rx = p.wx = 0; p.grp_ext = 0; p.grp_kslab = 0;
   p.post = 0; p.drop_thr24 = 0; p.drop_scale = 1.f; p.drop_seed = 0; p.drop_ld = 0; p.post_in = nullptr; p.post_ld = 0; p.colsum = nullptr; p.defer = nullptr;
-  p.stamp = nullptr; p.amax_val = nullptr; p.amax_idx = nullptr; p.ln_mr = nullptr; p.ln_u = nullptr; p.ln_c = nullptr; p.stats_out = nullptr;
+  p.krun = 0; p.stamp = nullptr; p.amax_val = nullptr; p.amax_idx = nullptr; p.ln_mr = nullptr; p.ln_u = nullptr; p.ln_c = nullptr; p.stats_out = nullptr;
   const int direct_epi = sl_env().direct_epilogue;
   p.direct_epi = direct_epi;
   const int gm_env = sl_env().gemm_gm;

@@ -438,7 +438,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tiled256p_kernel(GemmP p) {
     row = row < p.M ? row : p.M - 1;
     mr_s[tid] = ((const float2*)p.ln_mr)[row];
   }
-  t256_mainloop<T, SW, DBG>(smem, gp, 0, p.K / BK, wave, lane, acc, (uint32_t*)mr_s);
+  int64_t k_first = 0;
+  int nkt = p.K / BK;
+  if (p.krun > 0) {      // K runs of uneven length (gemm.hip splitk256_runs): this block's run of whole slabs
+    k_first = (int64_t)z * p.krun * BK;
+    const int left = nkt - z * p.krun;
+    nkt = left < p.krun ? left : p.krun;
+  }
+  t256_mainloop<T, SW, DBG>(smem, gp, k_first, nkt, wave, lane, acc, (uint32_t*)mr_s);
   if constexpr (STAMP) {
     if ((wave & 3) == 0 && lane < 32 && p.stamp) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

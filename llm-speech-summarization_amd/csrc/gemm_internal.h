@@ -36,6 +36,8 @@ struct GemmP {
   const void* post_in; int64_t post_ld;
   float* colsum;       // fp32 column sums of the stored values (+=, atomics)
   int32_t* defer;      // host: split-K reduce pass left to the consumer (sl_gemm_ex_args.deferred_splits)
+  int krun;            // phased 256-tile kernel, K runs of UNEVEN length on blockIdx.y: run z takes slabs [z krun, min((z + 1) krun, K / BK)) of the same A / W (sA = sW = 0) and
+                       // writes its fp32 partial tile to C + z sC (gemm.hip splitk256_runs); 0 = blockIdx.y is a batch index
   uint32_t* stamp;     // instrumented build of the phased 256-tile kernel only: [block][half][32] cycle stamps (SL_GEMM_STAMP_PTR)
 };
 
@@ -128,6 +130,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // 256 x 256 tile geometry and the stream-K workspace layout (kernels: gemm256.hip; launch decisions: gemm.hip)
 constexpr int XBM = 256, XBN = 256;
 constexpr size_t SK_FLAG_BYTES = 1024, SK_SLOT_BYTES = (size_t)XBM * XBN * 4;
+constexpr int SK_WS_SLOTS = 512;      // workspace = flags + 512 slots (128 MiB): the stream-K form uses <= 256 of them, three fp32 partial products of 3 200 x 3 072 need 450
 
 // gemm256.hip: launch one of the 256-tile kernels (explicitly instantiated for bf16 / fp32 x NONE / GELU / SILU_MUL)
 enum : int { SL_T256_PHASED = 0, SL_T256_PHASED_SW = 1, SL_T256_PLAIN = 2, SL_T256_PLAIN_SW = 3, SL_T256_SK = 4, SL_T256_SK_SW = 5, SL_T256_DBG = 16 };

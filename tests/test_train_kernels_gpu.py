@@ -651,6 +651,49 @@ def test_gemm_deferred_split_k_partials_sum_to_the_reduced_product(dt, M, N, K):
                                                              out=torch.empty((M, N), device=DEV, dtype=dt)))
 
 
+@pytest.mark.parametrize("M,N,K,S_want", [(3200, 3072, 16384, 3), (3200, 3072, 9216, 3), (3100, 3072, 12352, 3), (3200, 3072, 5120, 0), (5072, 3072, 16384, 0)])
+def test_gemm_256_tile_k_runs_of_uneven_length_left_to_the_consumer(M, N, K, S_want):
+    """gemm.hip splitk256_runs (round 6): a 256-tile product that fills 50-66 % of one round of the chip (3 200 x 3 072: 156 tiles) under a long
+    reduction, whose caller sums the K runs itself (deferred_splits: the RMSNorm backward of the LLM tape), runs as S = 3 runs of whole slabs
+    of UNEVEN length (K = 16 384: 86 / 86 / 84 slabs; 12 352: 65 / 65 / 63) on the phased 256-tile kernel: the fp32 partial products in
+    run order sum to the product (fp64 reference on a row sample; against the unsplit bf16 result to a rounding), C is untouched.  A caller
+    without deferred_splits gets the reduce launch: the same bits.  Not taken: runs shorter than 48 slabs (K = 5 120), tile counts that fill the chip
+    (5 072 rows: 240 tiles), SL_SPLIT_K256=0."""
+    import ctypes as C
+    dt = torch.bfloat16
+    A, W = rnd(M, K, seed=61).to(DEV, dt), (rnd(N, K, seed=62) * K ** -0.5).to(DEV, dt)
+    ws = ops.streamk_workspace(DEV)
+    plain = ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), sk_ws=ws)      # no deferred_splits: the same runs + the reduce launch
+    S = C.c_int32(-1)
+    out = torch.full((M, N), 3.0, device=DEV, dtype=dt)
+    ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=out, sk_ws=ws, deferred_splits=S)
+    if S_want == 0:
+        assert S.value == 0 and torch.equal(out, plain)
+        return
+    assert S.value == S_want, S.value
+    parts = ws[1024:1024 + S.value * M * N * 4].view(torch.float32).view(S.value, M, N)
+    acc = parts[0].clone()
+    for z in range(1, S.value):
+        acc += parts[z]
+    idx = torch.randint(0, M, (256,), generator=torch.Generator().manual_seed(5)).to(DEV)
+    ref = A[idx].double() @ W.double().t()
+    assert rel_err(acc[idx].double().cpu(), ref.cpu()) < 2e-6
+    assert torch.equal(acc.to(dt), plain) and bool((out == 3.0).all())      # the reduce launch adds the runs in the same order
+    nows = ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt))                  # no workspace: one run per tile
+    assert rel_err(plain.float().cpu(), nows.float().cpu()) < 4e-3
+    ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=out, sk_ws=ws, deferred_splits=S)          # again on the same workspace: the same bits
+    assert torch.equal(parts[0] + parts[1] + parts[2], acc)
+    os.environ["SL_SPLIT_K256"] = "0"
+    try:
+        L.lib().sl_tuning_reload()
+        S0 = C.c_int32(-1)
+        off = ops.gemm_ex(A, W, M=M, N=N, K=K, lda=K, ldw=K, out=torch.empty((M, N), device=DEV, dtype=dt), sk_ws=ws, deferred_splits=S0)
+        assert S0.value == 0 and torch.equal(off, nows)
+    finally:
+        del os.environ["SL_SPLIT_K256"]
+        L.lib().sl_tuning_reload()
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_batched_col2im_and_avgpool_backward_equal_the_per_utterance_launches(dt):
     """sl_col2im_batch / sl_avgpool_bwd_batch (ABI 7): the strided-conv data gradient's fold-back and the AvgPool1d backward for every utterance of a packed
