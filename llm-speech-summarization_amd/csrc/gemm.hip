@@ -674,7 +674,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static bool ring_ok(const GemmP& p, int batch, int bk) {
   if (!sl_env().glds_ring || g_disable_glds || p.ta || p.tw || p.grp || p.K % bk || p.amax_val) return false;
   const int64_t t128 = (int64_t)((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * batch;
-  return t128 <= sk_cu_count() && p.K / bk >= 8;
+  // up to `ring_max_tiles` (default 256 = one block per CU; above it the blocks beyond the first round wait for a CU: SL_GLDS_RING_MAX_TILES)
+  const int64_t cap = sl_env().ring_max_tiles > 0 ? sl_env().ring_max_tiles : sk_cu_count();
+  return t128 <= cap && p.K / bk >= 8;
 }
 
 static int splitk_runs(const GemmP& p, int batch, int bk, size_t ws_bytes) {

@@ -59,6 +59,9 @@ def our_gemm(A, W, out, v):
 def set_variant(v):
     if v == "vendor":
         return
+    os.environ["SL_GLDS_RING_MAX_TILES"] = v[1:] if v[0] == "m" and v[1:].isdigit() else "0"      # m384: the ring takes up to 384 tiles (two rounds)
+    if v[0] == "m" and v[1:].isdigit():
+        v = "p"
     # p2 / sk2: the two-stage 128-tile kernel (SL_GLDS_RING=0, round 5's rule), p3 / sk3: three ring stages; p / sk: the default (four)
     os.environ["SL_GLDS_RING"] = "0" if v.endswith("2") else ("3" if v.endswith("3") and v != "r3" else ("104" if v.endswith("u") else ("204" if v.endswith("o") else "4")))      # po / sko: the ring with a slab's eight requests inside one 16-MFMA phase
     os.environ["SL_GLDS_DMAB"] = "1" if v.endswith("d") else "0"      # pd: the two-stage kernel with its DMA requests between the MFMAs (default: a burst)
@@ -110,4 +113,5 @@ os.environ.pop("SL_T256_PHASED", None)
 os.environ.pop("SL_T256_BY_ROUNDS_PAD", None)
 os.environ.pop("SL_GLDS_RING", None)
 os.environ.pop("SL_GLDS_DMAB", None)
+os.environ.pop("SL_GLDS_RING_MAX_TILES", None)
 L.lib().sl_tuning_reload()
