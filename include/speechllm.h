@@ -170,7 +170,10 @@ typedef struct {
    * thousand rows (ref:trainer.py:270-384 at grad_accum_interval 16), its per-rank share under data parallelism, weight gradients of a
    * few dozen tiles under a long reduction — are cut along K as well: every CU takes an equal run of (tile, K slab) units, tiles
    * shared by two or three CUs are summed through this workspace inside the launch (fp32, fixed order: reproducible, not bit-equal
-   * to the unsplit product).  Caller-owned, sl_gemm_streamk_workspace_bytes() bytes, 16-byte aligned, ZEROED ONCE before its first
+   * to the unsplit product).  The same workspace carries the PLAIN K runs of products of few tiles (S batched runs of whole slabs + a
+   * fixed-order reduce launch; round 6: at most one 128 x 128 tile per CU runs on the ring form of the tile kernel, and a 256-tile
+   * product that fills 50-66 % of one round is cut into three runs of uneven length).  Caller-owned, sl_gemm_streamk_workspace_bytes()
+   * bytes (1 KiB of flags + 128 MiB of fp32 partial tiles), 16-byte aligned, ZEROED ONCE before its first
    * use and not shared by launches that may run concurrently (one per stream).  NULL, a shape the rule does not take, transposed /
    * grouped operands or the ln_* / stats_out / amax_* / aux_out forms: the product runs one block per tile as without it. */
   void* sk_ws; size_t sk_ws_bytes;
