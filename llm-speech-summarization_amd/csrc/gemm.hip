@@ -712,6 +712,9 @@ static int splitk256_runs(const GemmP& p, int batch, int bk, size_t ws_bytes, in
       p.bias || p.res || p.out_f32 || (p.N & 3) || g_disable_glds || sl_env().disable_t256 || !sl_env().t256_phased)
     return 0;
   const int64_t t256 = (int64_t)((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN);
+  // 129 ... 200 tiles only: fewer tiles belong to the 128-tile rule below (more blocks, the ring form), and the admission must not depend on
+  // whether the product carries a post-op (the fused and the unfused tape cut the same products the same way)
+  if (t256 <= 128 || t256 > 200) return 0;
   const int nkt = p.K / bk;
   int best = 0;
   double best_cost = 0.7;                       // rounds(S) / S must fall below it

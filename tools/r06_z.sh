@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out; T=${1:-r06_z}
 T0=$(date +%s)
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/${T}_pytest_gpu.txt
+timeout 2400 python -m pytest tests -m gpu -q -rf 2>&1 | grep -E "passed|failed|error|^FAILED" | tail -6 > $O/${T}_pytest_gpu.txt
 T1=$(date +%s)
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -i "smoke" > $O/${T}_smoke.txt
 python bench.py > $O/${T}_bench_default_line.json 2> $O/${T}_bench_default.err
