@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(AttnBwdP p) {
 // dV and dK — now feeds KF products instead of one.  With one fragment per wave the kernel was LDS-bound (per tile and wave 16 ds_read_b128 +
 // 32 ds_read_b64_tr for 32 MFMAs: ~256 LDS cycles per wave, four waves on one LDS port, against 512 matrix-core cycles per SIMD).
 template <typename T, int D, bool CAUSAL, int TQ, int KF>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+__device__ __forceinline__ void attn_bwd_dkdv_body(const AttnBwdP& p, const int bx, const int by, const int bz) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int SZ = (int)sizeof(T);
   constexpr int KSTEP = MMA<T>::KSTEP;
@@ -163,12 +163,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, qd = lane >> 4;
-  const int seq = blockIdx.z, kvh = blockIdx.y;
+  const int seq = bz, kvh = by;
   const int rep = p.n_heads / p.n_kv;
   const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
   const int klen = p.klen[seq];
   constexpr int BKEYS = 64 * KF;        // keys per block
-  const int key0 = blockIdx.x * BKEYS;
+  const int key0 = bx * BKEYS;
   if (key0 >= klen) return;
   const int shift = klen - qlen;        // causal: key j visible to query i iff j <= i + shift
   const int64_t krow0 = p.cu_k[seq];
@@ -356,8 +356,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
 }
 
 // QF = 16-query fragments per wave (round 6: 2, a block owns 128 queries): every K / V fragment read from LDS feeds QF products
+template <typename T, int D, bool CAUSAL, int TQ, int KF>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+  attn_bwd_dkdv_body<T, D, CAUSAL, TQ, KF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 template <typename T, int D, bool CAUSAL, int TK, int QF>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnBwdP& p, const int bx, const int by, const int bz) {
   constexpr int VEC = Vec16<T>::VEC;
   constexpr int SZ = (int)sizeof(T);
   constexpr int KSTEP = MMA<T>::KSTEP;
@@ -376,12 +381,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, qd = lane >> 4;
-  const int seq = blockIdx.z, head = blockIdx.y;
+  const int seq = bz, head = by;
   const int kvh = head / (p.n_heads / p.n_kv);
   const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
   const int klen = p.klen[seq];
   constexpr int BQ = 64 * QF;           // queries per block
-  const int qt0 = blockIdx.x * BQ;
+  const int qt0 = bx * BQ;
   if (qt0 >= qlen) return;
   const int shift = klen - qlen;
   const int64_t krow0 = p.cu_k[seq];
@@ -534,6 +539,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
   }
 }
 
+template <typename T, int D, bool CAUSAL, int TK, int QF>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdP p) {
+  attn_bwd_dq_body<T, D, CAUSAL, TK, QF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Both passes in ONE launch (round 6): the first n_dkdv blocks are the dK / dV blocks, the rest the dQ blocks.  The two passes are independent (they
+// read the same q / k / v / dO / lse / delta and write disjoint outputs); in the per-rank KD window (2 sequences) each alone fills a third of the
+// chip — 80 dK / dV blocks for Llama's 8 kv heads — and they ran back to back.  Same block bodies, same bits.  The LDS of the two bodies adds up
+// (static arrays: 33-49 KiB), which is why the large launches of a 16-sample window, where each pass fills the chip by itself, keep their own kernels.
+template <typename T, int D, bool CAUSAL, int TQ, int TK>
+__global__ __launch_bounds__(256) void attn_bwd_both_kernel(AttnBwdP p, int kx, int ky, int n_dkdv, int qx, int qy) {
+  int b = blockIdx.x;
+  if (b < n_dkdv) {
+    const int bx = b % kx; b /= kx;
+    attn_bwd_dkdv_body<T, D, CAUSAL, TQ, 1>(p, bx, b % ky, b / ky);
+  } else {
+    b -= n_dkdv;
+    const int bx = b % qx; b /= qx;
+    attn_bwd_dq_body<T, D, CAUSAL, TK, 1>(p, bx, b % qy, b / qy);
+  }
+}
+
 template <typename T, int D, bool CAUSAL>
 int launch_attn_bwd(const sl_attn_bwd_args* a, const AttnBwdP& p, hipStream_t st) {
   constexpr int VEC = Vec16<T>::VEC;
@@ -558,6 +585,16 @@ int launch_attn_bwd(const sl_attn_bwd_args* a, const AttnBwdP& p, hipStream_t st
       SL_CHECK_LAUNCH("attn_bwd_dkdv");
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, CAUSAL, TK2, 2>), dim3((a->max_qlen + 127) / 128, a->n_heads, a->nseq), dim3(256), 0, st, p);
       SL_CHECK_LAUNCH("attn_bwd_dq");
+      return 0;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    const int kx = (a->max_klen + 63) / 64, qx = (a->max_qlen + 63) / 64;
+    const int64_t n_dkdv = (int64_t)kx * a->n_kv_heads * a->nseq, n_dq = (int64_t)qx * a->n_heads * a->nseq;
+    if (sl_env().attn_bwd_both == 2 || (sl_env().attn_bwd_both && n_dkdv + n_dq <= 1024)) {      // neither pass fills the chip (256 CUs x 2-4 blocks) by itself; 2 = always (A/B)
+      hipLaunchKernelGGL((attn_bwd_both_kernel<T, D, CAUSAL, TQ, TK>), dim3((unsigned)(n_dkdv + n_dq)), dim3(256), 0, st, p, kx, a->n_kv_heads, (int)n_dkdv, qx,
+                         a->n_heads);
+      SL_CHECK_LAUNCH("attn_bwd_both");
       return 0;
     }
   }
