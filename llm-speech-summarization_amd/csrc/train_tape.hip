@@ -173,7 +173,10 @@ struct SideStream {
   bool on = false;
   int init(hipStream_t main, int64_t n_tok) {
     main_ = main;
-    on = !sl_env().no_wgrad_stream && n_tok >= 2048;      // below ~2 k rows the products are too short for the fork / join events to pay (1 k rows: -1 %)
+    // from 512 token rows (SL_WGRAD_STREAM_MIN_TOK): at 998 rows — the per-rank window of an 8-rank step — the fork / join events cost more than the
+    // overlap bought in round 5 (-1 %: the bound was 2 048 rows); with the ring kernels (one block per CU, a few dozen to 256 blocks per product) the
+    // products of the two streams fill the chip together: 28.50 -> 28.08 ms (profiles/r06_au_kd_windows.txt).  Each stream has its own split-K workspace.
+    on = !sl_env().no_wgrad_stream && n_tok >= (sl_env().wgrad_stream_min_tok > 0 ? sl_env().wgrad_stream_min_tok : 512);
     if (!on) return 0;
     int dev = 0;
     SL_HIP(hipGetDevice(&dev));
@@ -292,7 +295,7 @@ static size_t enc_carve(const sl_enc_stack_cfg* c, void* base, size_t cap, EncWs
   // a short window only (the per-rank share of a data-parallel step: ~1 000 frames): there FFN2 and the data gradients under K = 3 072 / 4 096
   // are 64 tiles on 256 CUs, and everything runs on one stream (SideStream::init), so one workspace serves the whole call
   w.sk = n < 2048 ? cv.take(sl_gemm_streamk_workspace_bytes()) : nullptr;
-  w.sk_w = n < 2048 ? w.sk : cv.take(sl_gemm_streamk_workspace_bytes());    // long window: the weight gradients run on their own stream, with their own workspace
+  w.sk_w = cv.take(sl_gemm_streamk_workspace_bytes());      // the weight gradients' own workspace (they may run on their own stream)
   const int vec = c->dtype == SL_F32 ? 4 : 8;
   w.wt_layer_bytes = (H % vec == 0 && F % vec == 0) ? (size_t)(2 * F * H + 4 * H * H) * sz : 0;
   w.wt_all = w.wt_layer_bytes ? (unsigned char*)cv.take(w.wt_layer_bytes * (size_t)c->n_layers) : nullptr;
@@ -405,13 +408,13 @@ extern "C" int sl_encoder_stack_train_bwd(const sl_hubert_layer* layers, const s
   SideStream ss;
   SL_TRY(ss.init(st, n));
   hipStream_t sw = st;           // where the current parameter-gradient group runs
-  void* sk = ss.on ? nullptr : w.sk;                           // split-K workspace: only when every product of the call is on `st`
+  void* sk = w.sk;                                             // split-K workspace of the caller's stream (short windows only: NULL from 2 048 rows)
   if (sk) SL_HIP(hipMemsetAsync(sk, 0, 1024, st));
   // arrival counter of the LayerNorm backward's in-kernel column reduce: the last 256 bytes of its record workspace (sl_layernorm_bwd_ws_bytes), zero
   // whenever no launch is in flight (a call cut short must not poison this one)
   int32_t* const ln_cnt = w.ln_ws_bytes >= 256 ? (int32_t*)((unsigned char*)w.ln_ws + w.ln_ws_bytes - 256) : nullptr;
   if (ln_cnt) SL_HIP(hipMemsetAsync(ln_cnt, 0, 256, st));
-  void* sk_w = (ss.on || !w.sk) ? w.sk_w : sk;                 // the parameter-gradient group's own (side stream), or the shared one when all is on `st`
+  void* sk_w = w.sk_w;                                         // the parameter-gradient group's own
   if (sk_w && sk_w != sk) SL_HIP(hipMemsetAsync(sk_w, 0, 1024, st));      // ordered before the first fork of the side stream
   // tmp_h[par] already holds dropout(dx) under the CURRENT layer's output-dropout mask: the LayerNorm backward that produced dx (the layer
   // above's) wrote it as its second output, so this layer starts without an sl_dropout launch and without re-reading dx
