@@ -276,6 +276,7 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
         k_ = args.kd_local_accum
         full = tr.local_accum
         tr.local_accum = k_
+        tr.enc_tape.stack_chunk = 4           # a rank of a data-parallel run hands finished gradient buckets to its reducer every four layers: keep those call boundaries
         for _ in range(2):
             tr.micro_batch(waves[:k_], texts[:k_], resps[:k_])
         torch.cuda.synchronize()
@@ -286,6 +287,7 @@ def kd_leg(args, mod, conf, enc, llm, larch, prefix, suffix, dev, rank, world, d
         torch.cuda.synchronize()
         win_ms = (time.perf_counter() - tp) / n_win * 1e3
         tr.local_accum = full
+        tr.enc_tape.stack_chunk = None
         ar_bytes = sum(p.numel() for p in tr.params) * 4
         ranks = tr.accum // k_
         # ring all-reduce over xGMI: 2 (N-1)/N x bytes cross each GPU's links; RCCL's measured bus bandwidth on 8 x MI300-class

@@ -471,7 +471,12 @@ class EncoderTape:
         nh = a.num_attention_heads
         done = on_bucket or (lambda names: None)
         dx = self._head_backward(tape, d_out, g, done)
-        dx = self._stack_backward(tape, dx, g, done)
+        # `on_bucket` is what the chunks are for (finished gradient buffers go to the data-parallel reducer while the rest still runs); with nobody listening
+        # the whole stack is ONE call: every call boundary joins the side stream of the parameter-gradient products (main stream idle until the lagging
+        # products of the chunk have finished) and costs the first layer of the next call its fused dropout.  stack_chunk forces a size (bench.py's
+        # per-rank probe keeps the reducer's hand-over points).
+        chunk = getattr(self, "stack_chunk", None) or (4 if on_bucket is not None else len(W.layer_t))
+        dx = self._stack_backward(tape, dx, g, done, chunk=chunk)
         reg, base = tape.get("reg"), tape.get("base")
         p_h = reg.hidden_dropout if reg is not None else 0.0
         # positional conv: x1 = x0 + gelu(conv(x0) + b)
@@ -703,7 +708,7 @@ class WhisperEncoderTape(EncoderTape):
         d_full.index_copy_(0, tape["rows"], d_out)
         full = dict(tape, P=tape["P_full"], poff=tape["poff_full"])
         dx = self._head_backward(full, d_full, g, done)
-        dx = self._stack_backward(tape, dx, g, done)
+        dx = self._stack_backward(tape, dx, g, done, chunk=getattr(self, "stack_chunk", None) or (4 if on_bucket is not None else len(W.layer_t)))
         # x0 = gelu(conv2(b1) + bias) + pos  (the positional table is frozen, hf:...whisper.py:606)
         d_pre2 = ops.gelu_bwd(dx, tape["pre2"])
         ops.colsum_acc(d_pre2, g["conv2_b"])

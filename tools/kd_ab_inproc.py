@@ -25,6 +25,8 @@ conf.train["per_rank_accum"] = 0
 tr = training.KDTrainer(conf, enc, llm, prefix, suffix, total_optimizer_steps=1000, regularizers=training.TrainRegularizers(seed=1234))
 if window:
     tr.local_accum = window
+if os.environ.get("KD_STACK_CHUNK"):      # 4 = the call boundaries a data-parallel rank keeps for its reducer (default: one call when nobody listens)
+    tr.enc_tape.stack_chunk = int(os.environ["KD_STACK_CHUNK"])
 B = tr.local_accum
 g = torch.Generator().manual_seed(99)
 text_ids = torch.randint(1, larch.vocab_size, (40,), generator=g)
@@ -48,7 +50,9 @@ windows(3)
 res = {"default": [], sys.argv[1]: []}
 for _ in range(pairs):
     for name in res:
-        if name == "default":
+        if var == "PY_STACK_CHUNK":      # a host-side setting, not a library switch: layers per sl_encoder_stack_train_bwd call (default: the whole stack when nobody listens)
+            tr.enc_tape.stack_chunk = None if name == "default" else int(val)
+        elif name == "default":
             os.environ.pop(var, None)
         else:
             os.environ[var] = val
