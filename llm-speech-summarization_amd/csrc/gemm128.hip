@@ -11,7 +11,14 @@
 // vmcnt: iteration kt waits only for slab kt (8 DMA instructions per slab and thread: vmcnt(8 (NS - 2)) in the steady loop), passes
 // ONE barrier — behind it every wave has retired its fragment reads of slab kt - 1, whose slot the DMA of slab kt + NS - 1 may now
 // overwrite — requests that slab and multiplies slab kt.  The DMA queue never drains inside the loop.
-// launch_tiled (gemm.hip) takes it for whole-slab, untransposed, ungrouped bf16 products of <= 256 tiles (SL_GLDS_RING=0: off, 104: the un-pipelined loop, 3: three stages — A/B).
+// That loop is the PIPE = false form (SL_GLDS_RING=104), +6-7 % on the two-stage kernel.  The default (PIPE, SPLIT) adds, measured step by step on
+// 634 x 5 120 x 3 072 (598 TF/s on the two-stage kernel, vendor 756-778; profiles/r06_af / ag / aj):
+//   * fragment reads software-pipelined across the barrier, MFMAs as asm statements (below)                          -> 692
+//   * the slab's eight DMA requests BETWEEN the MFMAs instead of in a burst behind the barrier (SL_GLDS_RING=204)      -> 757-778
+//   * those requests spread over two 16-MFMA phases, one per four MFMAs (A half / W half in different iterations)      -> 802-857
+// which is the L2 -> CU fetch bound of a 128^2 tile (32 KiB per slab at ~31 B/clk).  Three stages (SL_GLDS_RING=3): 623.
+// launch_tiled (gemm.hip) takes it for whole-slab, untransposed, ungrouped bf16 products of <= 256 tiles (SL_GLDS_RING=0: off; more tiles run in two
+// rounds and lose to the two-stage kernel, profiles/r06_ap).
 #include <atomic>
 #include <type_traits>
 #include "common.h"
