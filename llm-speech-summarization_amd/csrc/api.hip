@@ -65,6 +65,7 @@ static const SlEnv* env_load() {
   e.ring_max_tiles = env_int("SL_GLDS_RING_MAX_TILES", 0);
   e.attn_bwd_both = env_int("SL_ATTN_BWD_BOTH", 1);
   e.wgrad_stream_min_tok = env_int("SL_WGRAD_STREAM_MIN_TOK", 0);
+  e.tt_batched = env_int("SL_TT_BATCHED", 1);
   e.ln_colred_inkernel = env_int("SL_LN_COLRED_INKERNEL", 0);
   e.stream_min_m = env_int("SL_STREAM_MIN_M", 26);
   if (e.stream_min_m < 16) e.stream_min_m = 26;

@@ -224,6 +224,7 @@ struct SlEnv {
   int conv0_fold;          // SL_CONV0_FOLD        (default 1) conv0 backward of a batch: the block's four waves fold their sums through LDS and flush once, >= 4 strips per wave; 0 = a flush per wave of a 512-block grid (A/B)
   int enc_wt_ahead;        // SL_ENC_WT_AHEAD      (default 1) encoder tape: the layers' transposed weights for the data-gradient products are made in one batched launch on a side stream beside the forward; 0 = a transpose in front of each product
   int glds_ring;           // SL_GLDS_RING         (default 4) bf16 products of <= 256 tiles of 128 x 128 (one block per CU) run the ring form of the 128-tile kernel (gemm128.hip): 4 / 3 = stages of 32 KiB, 104 = four stages without the software-pipelined fragment reads, 0 = the two-stage kernel (A/B)
+  int tt_batched;          // SL_TT_BATCHED        (default 1) batched both-transposed products of 64 or 128 k output rows (the positional conv's weight gradient) run on the token-major kernel, batch index on blockIdx.z (0: the register-staged loader — A/B)
   int wgrad_stream_min_tok; // SL_WGRAD_STREAM_MIN_TOK (default 0 = 512; 2 048 until round 6) encoder tape: from this many token rows the parameter-gradient products run on the library's side stream (tuning)
   int attn_bwd_both;       // SL_ATTN_BWD_BOTH     (default 1) attention backward: dK / dV and dQ blocks in ONE launch where neither pass fills the chip (<= 1 024 blocks together: the per-rank KD window); 0 = two launches (A/B, same bits)
   int ring_max_tiles;      // SL_GLDS_RING_MAX_TILES (default 0 = the CU count) most 128 x 128 tiles (x batch) of a product the ring form of the 128-tile kernel takes; above the CU count its blocks run in two rounds (tuning)

@@ -731,15 +731,24 @@ static int splitk256_runs(const GemmP& p, int batch, int bk, size_t ws_bytes, in
 // leave CUs idle (two blocks per CU: 512 slots) and the caller supplied a workspace
 template <typename T>
 static bool tt_ok(const GemmP& p, int batch) {
-  if (sizeof(T) != 2 || !sl_env().wgrad_tr || !p.ta || !p.tw || batch != 1 || p.grp || p.aux || p.ln_mr || p.stats_out || p.amax_val) return false;
+  if (sizeof(T) != 2 || !sl_env().wgrad_tr || !p.ta || !p.tw || p.grp || p.aux || p.ln_mr || p.stats_out || p.amax_val) return false;
+  // batched (round 6: the positional conv's weight gradient, 16 groups x 64 output rows per utterance, was 16 launches of the register-staged
+  // loader at 84 TF/s): one K run, 64 output rows allowed (the tile's upper half reads zeros), no rider, 8-element aligned batch strides
+  if (batch != 1) {
+    if (!sl_env().tt_batched || p.colsum || p.bias || (p.M != 64 && p.M % TBM) || p.N % TBN || p.lda % 8 || p.ldw % 8 || p.K < 128 || (p.sA & 7) || (p.sW & 7) ||
+        p.wx || p.cx || p.rx)
+      return false;
+    return true;
+  }
   return p.M % TBM == 0 && p.N % TBN == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.K >= 128 && p.wx == 0 && p.cx == 0 && p.rx == 0;
 }
 
 template <typename T>
-static int launch_tt(GemmP& p, hipStream_t st, void* sk_ws, size_t sk_ws_bytes) {
-  p.tiles_m = p.M / TBM;
+static int launch_tt(GemmP& p, hipStream_t st, void* sk_ws, size_t sk_ws_bytes, int batch = 1) {
+  p.tiles_m = (p.M + TBM - 1) / TBM;
   p.tiles_n = p.N / TBN;
   const int nt = p.tiles_m * p.tiles_n, nkt = (p.K + 63) / 64;
+  if (batch > 1) return sl_gemm_tt_kernel_launch(p, nt, 1, nkt, st, batch);
   int S = 1;
   const size_t ws = sk_ws && sk_ws_bytes > SK_FLAG_BYTES ? sk_ws_bytes - SK_FLAG_BYTES : 0;
   // K runs fill 512 block slots (two blocks per CU of the two-stage kernel); launches that end at <= 256 blocks take the ring form (gemm_tt.hip).
@@ -772,7 +781,7 @@ template <typename T, int ACT>
 static int launch_tiled(GemmP& p, int batch, hipStream_t st, void* sk_ws = nullptr, size_t sk_ws_bytes = 0) {
   constexpr int BK_ = TROWB / (int)sizeof(T);
   if constexpr (ACT == SL_ACT_NONE && sizeof(T) == 2) {
-    if (tt_ok<T>(p, batch)) return launch_tt<T>(p, st, sk_ws, sk_ws_bytes);
+    if (tt_ok<T>(p, batch)) return launch_tt<T>(p, st, sk_ws, sk_ws_bytes, batch);
   }
   if constexpr (ACT == SL_ACT_NONE && sizeof(T) == 2) {
     if (sk_ws) {

@@ -140,7 +140,7 @@ int sl_gemm256_launch(const GemmP& p, int kind, dim3 grid, void* sk_ws, hipStrea
 template <typename T, int ACT>
 int sl_gemm128_ring_launch(const GemmP& p, int stages, dim3 grid, hipStream_t st);
 // gemm_tt.hip: the weight-gradient kernel on token-major operands, grid (tiles, K runs)
-int sl_gemm_tt_kernel_launch(const GemmP& p, int nt, int S, int slabs_per_run, hipStream_t st);
+int sl_gemm_tt_kernel_launch(const GemmP& p, int nt, int S, int slabs_per_run, hipStream_t st, int batch = 1);
 
 // decode-side fused inputs of the weight-streaming kernels (sl_gemm_fused on the device side)
 struct SkinnyX {

@@ -47,24 +47,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_tt_kernel(GemmP p, int slab
     bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   }
   const int bm = bid % p.tiles_m, bn = bid / p.tiles_m;
-  const int z = blockIdx.y;
+  // blockIdx.y = K run (split-K); blockIdx.z = batch index (round 6: the positional conv's weight gradient is 16 groups of 64 output rows per
+  // utterance — batched launches have one K run, and `z` below indexes C / residual by the batch strides)
+  const int zb = blockIdx.z;
+  const int z = gridDim.z > 1 ? zb : (int)blockIdx.y;
   const int nkt_all = (p.K + BK - 1) / BK;
-  const int kt0 = z * slabs_per_run;
+  const int kt0 = (gridDim.z > 1 ? 0 : (int)blockIdx.y) * slabs_per_run;
   int kt1 = kt0 + slabs_per_run;
   kt1 = kt1 < nkt_all ? kt1 : nkt_all;
-  const T* A = (const T*)p.A;
-  const T* W = (const T*)p.W;
+  const T* A = (const T*)p.A + (int64_t)zb * p.sA;
+  const T* W = (const T*)p.W + (int64_t)zb * p.sW;
 
   // LDS chunk c = tid + 256 i sits at (row c >> 4, physical chunk c & 15) and must hold logical chunk ((pc >> 1) ^ f(row)) << 1 | (pc & 1)
   const T* ga[4];
   const T* gw[4];
   int grow[4];
+  bool a_in[4];       // this chunk's 8 output rows (columns of dY) lie inside M (M = 64: the upper half of the tile reads the zero constant)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
     const int f = (row & 3) | (((row >> 3) & 1) << 2);
     const int lc = (((pc >> 1) ^ f) << 1) | (pc & 1);
     grow[i] = row;
+    a_in[i] = bm * TBM + lc * 8 < p.M;
     ga[i] = A + (int64_t)row * p.lda + bm * TBM + lc * 8;
     gw[i] = W + (int64_t)row * p.ldw + bn * TBN + lc * 8;
   }
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_tt_kernel(GemmP p, int slab
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool in = k0 + grow[i] < p.K;
-      const T* sa = in ? ga[i] + (int64_t)k0 * p.lda : zero;
+      const T* sa = (in && a_in[i]) ? ga[i] + (int64_t)k0 * p.lda : zero;
       const T* sw = in ? gw[i] + (int64_t)k0 * p.ldw : zero;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)sa, (lds_ptr_t)(&smem[buf][0][i * 4096 + wave_lds]), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((glb_ptr_t)sw, (lds_ptr_t)(&smem[buf][1][i * 4096 + wave_lds]), 16, 0, 0);
@@ -367,7 +372,12 @@ __global__ __launch_bounds__(256, 1) void gemm_tiled_tt_ring_kernel(GemmP p, int
 }
 
 // launch of the kernel above (gemm.hip launch_tt decides the K runs and issues the reduce pass): grid (tiles, runs)
-int sl_gemm_tt_kernel_launch(const GemmP& p, int nt, int S, int slabs_per_run, hipStream_t st) {
+int sl_gemm_tt_kernel_launch(const GemmP& p, int nt, int S, int slabs_per_run, hipStream_t st, int batch) {
+  if (batch > 1) {        // batched (one K run): the two-stage kernel, batch index on blockIdx.z
+    hipLaunchKernelGGL((gemm_tiled_tt_kernel<SL_ACT_NONE>), dim3(nt, 1, batch), dim3(256), 0, st, p, slabs_per_run);
+    SL_CHECK_LAUNCH("gemm_tiled_tt(batch)");
+    return 0;
+  }
   if (sl_env().glds_ring && sl_env().tt_ring && (int64_t)nt * S <= 256 && slabs_per_run >= 8) {       // at most one block per CU: the ring form
     constexpr int LDS_BYTES = 4 * 2 * 64 * 256;
     static std::atomic<uint64_t> attr_set{0};   // one bit per device: the opt-in to > 64 KiB of dynamic LDS is per device
