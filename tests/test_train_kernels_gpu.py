@@ -623,6 +623,42 @@ def test_wgrad_token_major_ring_form_gives_the_two_stage_kernels_bits(M, Nout, K
     assert rel_err(res["4"][0][1].cpu(), dY.float().sum(0).cpu()) < 1e-3
 
 
+@pytest.mark.parametrize("T_,G,Hg,k", [(499, 16, 64, 128), (130, 4, 64, 128), (1000, 2, 128, 64)])
+def test_batched_token_major_weight_gradient_of_the_positional_conv(T_, G, Hg, k):
+    """The positional conv's weight gradient (hf:models/hubert/modeling_hubert.py:113-135 walked backwards): per group g of Hg channels
+    dW[g][n][j Hg + c] += sum_t d_pre[t][g Hg + n] * xg[g][t + j][c] — G products of (Hg x T) . (T x k Hg) whose second operand is a set of OVERLAPPING
+    windows (row stride Hg, row length k Hg).  Round 6 runs them as ONE batched launch of the token-major kernel (batch index on blockIdx.z; with
+    Hg = 64 the tile's upper 64 rows read a zero constant); SL_TT_BATCHED=0 is the register-staged loader it replaced.  Against each other and
+    against the fp64 sum, accumulating on top of a non-zero dW."""
+    H = G * Hg
+    dt = torch.bfloat16
+    d_pre = rnd(T_, H, seed=71).to(DEV, dt)
+    xg = rnd(G, T_ + k, Hg, seed=72).to(DEV, dt)
+    dW0 = rnd(G, Hg, k * Hg, seed=73).to(DEV)
+    ref = dW0.double().clone()
+    for g in range(G):
+        win = torch.stack([xg[g, j:j + T_].double() for j in range(k)], 1).reshape(T_, k * Hg)      # [t][j Hg + c]
+        ref[g] += d_pre[:, g * Hg:(g + 1) * Hg].double().t() @ win
+
+    def run():
+        dW = dW0.clone()
+        ops.gemm_ex(d_pre, xg, M=Hg, N=k * Hg, K=T_, lda=H, ldw=Hg, out=dW, ldc=k * Hg, residual=dW, ldr=k * Hg, out_f32=True, residual_f32=True,
+                    trans_a=True, trans_w=True, batch=G, strideA=Hg, strideW=(T_ + k) * Hg, strideC=Hg * k * Hg, strideR=Hg * k * Hg, dtype=dt)
+        return dW
+
+    os.environ["SL_TT_BATCHED"] = "0"
+    try:
+        L.lib().sl_tuning_reload()
+        base = run()
+    finally:
+        del os.environ["SL_TT_BATCHED"]
+        L.lib().sl_tuning_reload()
+    tt, tt2 = run(), run()
+    assert torch.equal(tt, tt2)
+    assert rel_err(tt.double().cpu(), ref.cpu()) < 1e-5 and rel_err(base.double().cpu(), ref.cpu()) < 1e-5
+    assert rel_err(tt.cpu(), base.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", [(998, 1024, 4096), (634, 3072, 16384), (400, 1024, 4096)])
 def test_gemm_deferred_split_k_partials_sum_to_the_reduced_product(dt, M, N, K):
